@@ -1,0 +1,113 @@
+"""Synthetic inputs for the pdgstrf3d / pdgstrs3d hot path.
+
+* ``poisson3d(N)``      7-point Poisson on an N^3 grid, natural index ((i*N+j)*N+k), diagonal 6,
+                        off-diagonals -1, Dirichlet truncation.
+* ``nd_perm_grid3d``    geometric nested-dissection column permutation for that grid; stands in for
+                        METIS (absent in this image) and is passed to both the reference
+                        (``ColPerm = MY_PERMC``, SRC/double/pdgssvx3d.c:749-791) and to our driver so both
+                        factor the same permuted matrix.
+* ``xtrue_rhs``         xtrue_i = +-1 alternating (reference: SRC/double/dutil_dist.c:598 dGenXtrue_dist),
+                        b = A xtrue (dFillRHS_dist :619).
+* ``random_unsym``      small diagonally dominant matrix with an UNSYMMETRIC pattern (ragged U skyline).
+"""
+import numpy as np
+
+
+def poisson3d(N, nx=None, ny=None, nz=None):
+    nx = nx or N; ny = ny or N; nz = nz or N
+    n = nx * ny * nz
+    idx = np.arange(n, dtype=np.int64)
+    i = idx // (ny * nz); j = (idx // nz) % ny; k = idx % nz
+    rows = [idx]; cols = [idx]; vals = [np.full(n, 6.0)]
+    for cond, off in ((i > 0, -ny * nz), (i < nx - 1, ny * nz), (j > 0, -nz), (j < ny - 1, nz),
+                      (k > 0, -1), (k < nz - 1, 1)):
+        r = idx[cond]
+        rows.append(r); cols.append(r + off); vals.append(np.full(r.size, -1.0))
+    rows = np.concatenate(rows); cols = np.concatenate(cols); vals = np.concatenate(vals)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return n, rowptr.astype(np.int32), cols.astype(np.int32), vals
+
+
+def nd_perm_grid3d(nx, ny, nz, leaf=64):
+    """Return perm_c with perm_c[old] = new (SuperLU convention) for the natural grid index."""
+    out = []
+    ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    gid = (ii * ny + jj) * nz + kk
+
+    def rec(x0, x1, y0, y1, z0, z1):
+        dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
+        if dx <= 0 or dy <= 0 or dz <= 0:
+            return
+        if dx * dy * dz <= leaf or max(dx, dy, dz) < 3:
+            out.append(gid[x0:x1, y0:y1, z0:z1].ravel())
+            return
+        if dx >= dy and dx >= dz:
+            m = x0 + dx // 2
+            rec(x0, m, y0, y1, z0, z1); rec(m + 1, x1, y0, y1, z0, z1)
+            out.append(gid[m:m + 1, y0:y1, z0:z1].ravel())
+        elif dy >= dz:
+            m = y0 + dy // 2
+            rec(x0, x1, y0, m, z0, z1); rec(x0, x1, m + 1, y1, z0, z1)
+            out.append(gid[x0:x1, m:m + 1, z0:z1].ravel())
+        else:
+            m = z0 + dz // 2
+            rec(x0, x1, y0, y1, z0, m); rec(x0, x1, y0, y1, m + 1, z1)
+            out.append(gid[x0:x1, y0:y1, m:m + 1].ravel())
+
+    rec(0, nx, 0, ny, 0, nz)
+    order = np.concatenate(out)           # order[new] = old
+    perm = np.empty(nx * ny * nz, dtype=np.int32)
+    perm[order] = np.arange(order.size, dtype=np.int32)
+    return perm
+
+
+def xtrue_rhs(n, rowptr, colind, vals, nrhs=1):
+    """xtrue = +1/-1 alternating per row (reference dGenXtrue_dist); b = A*xtrue."""
+    x = np.where((np.arange(n) % 2) == 1, 1.0, -1.0)   # i odd ? 1 : -1  (dutil_dist.c:598)
+    xt = np.tile(x[:, None], (1, nrhs)).copy(order="F")
+    b = csr_matvec(n, rowptr, colind, vals, xt)
+    return xt, b
+
+
+def csr_matvec(n, rowptr, colind, vals, x):
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+    prod = vals[:, None] * x[colind, :]
+    out = np.zeros((n, x.shape[1]))
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    np.add.at(out, rows, prod)
+    return np.asfortranarray(out)
+
+
+def random_unsym(n, density=0.02, seed=0):
+    rng = np.random.default_rng(seed)
+    nnz_off = int(density * n * n)
+    r = rng.integers(0, n, nnz_off); c = rng.integers(0, n, nnz_off)
+    keep = r != c
+    r, c = r[keep], c[keep]
+    key = np.unique(r.astype(np.int64) * n + c)
+    r = (key // n).astype(np.int64); c = (key % n).astype(np.int64)
+    v = rng.uniform(-1.0, 1.0, r.size)
+    rowsum = np.zeros(n); np.add.at(rowsum, r, np.abs(v))
+    colsum = np.zeros(n); np.add.at(colsum, c, np.abs(v))
+    d = np.maximum(rowsum, colsum) + 1.0
+    rows = np.concatenate([r, np.arange(n)]); cols = np.concatenate([c, np.arange(n)])
+    vals = np.concatenate([v, d])
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64); np.add.at(rowptr, rows + 1, 1)
+    return n, np.cumsum(rowptr).astype(np.int32), cols.astype(np.int32), vals
+
+
+def write_triplet_dat(path, n, rowptr, colind, vals):
+    """'.dat' triplet file the reference reads (SRC/double/dreadtriple.c:43-92): header 'm n nnz', 1-based."""
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    with open(path, "w") as f:
+        f.write(f"{n} {n} {len(vals)}\n")
+        for r, c, v in zip(rows, colind, vals):
+            f.write(f"{r + 1} {c + 1} {float(v)!r}\n")

@@ -1,0 +1,86 @@
+"""ctypes access to oracle/libslu_oracle.so (CPU restatement; TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes, os, subprocess
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libslu_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")])
+        _lib = ctypes.CDLL(_SO)
+        _lib.slu_oracle_dfactor.restype = ctypes.c_int
+        _lib.slu_oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+class LUStore:
+    """Flat copy of a 1x1x1 reference-format L/U store (see oracle/slu_oracle.c header)."""
+
+    def __init__(self, n, xsup, Lrowind_off, Lrowind, Lnzval_off, Lnzval, Ufstnz_off, Ufstnz, Unzval_off, Unzval):
+        self.n = int(n)
+        self.xsup = np.ascontiguousarray(xsup, dtype=np.int32)
+        self.nsupers = len(self.xsup) - 1
+        self.Lrowind_off = np.ascontiguousarray(Lrowind_off, dtype=np.int64)
+        self.Lrowind = np.ascontiguousarray(Lrowind, dtype=np.int32)
+        self.Lnzval_off = np.ascontiguousarray(Lnzval_off, dtype=np.int64)
+        self.Lnzval = np.array(Lnzval, dtype=np.float64)
+        self.Ufstnz_off = np.ascontiguousarray(Ufstnz_off, dtype=np.int64)
+        self.Ufstnz = np.ascontiguousarray(Ufstnz, dtype=np.int32)
+        self.Unzval_off = np.ascontiguousarray(Unzval_off, dtype=np.int64)
+        self.Unzval = np.array(Unzval, dtype=np.float64)
+
+    @classmethod
+    def from_golden(cls, g, rank=0, which="pre"):
+        r = f"r{rank}__"
+        return cls(int(g[r + "n"][0]), g[r + "xsup"], g[r + "Lrowind_off"], g[r + "Lrowind"], g[r + "Lnzval_off"],
+                   g[r + f"Lnzval_{which}"], g[r + "Ufstnz_off"], g[r + "Ufstnz"], g[r + "Unzval_off"],
+                   g[r + f"Unzval_{which}"])
+
+    def copy(self):
+        return LUStore(self.n, self.xsup, self.Lrowind_off, self.Lrowind, self.Lnzval_off, self.Lnzval.copy(),
+                       self.Ufstnz_off, self.Ufstnz, self.Unzval_off, self.Unzval.copy())
+
+    def _args(self):
+        return (ctypes.c_int(self.n), ctypes.c_int(self.nsupers), _p(self.xsup, ctypes.c_int),
+                _p(self.Lrowind_off, ctypes.c_int64), _p(self.Lrowind, ctypes.c_int),
+                _p(self.Lnzval_off, ctypes.c_int64), _p(self.Lnzval, ctypes.c_double),
+                _p(self.Ufstnz_off, ctypes.c_int64), _p(self.Ufstnz, ctypes.c_int),
+                _p(self.Unzval_off, ctypes.c_int64), _p(self.Unzval, ctypes.c_double))
+
+
+def dfactor(store, order=None, replace_tiny=False, thresh=0.0):
+    """In-place factorisation of `store`; returns (info, tiny, flops[schur_padded, panel])."""
+    if order is None:
+        order = np.arange(store.nsupers, dtype=np.int32)
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    info = ctypes.c_int(0)
+    flops = np.zeros(2)
+    tiny = lib().slu_oracle_dfactor(*store._args(), _p(order, ctypes.c_int), ctypes.c_int(len(order)),
+                                    ctypes.c_int(int(replace_tiny)), ctypes.c_double(thresh), ctypes.byref(info),
+                                    _p(flops, ctypes.c_double))
+    return info.value, tiny, flops
+
+
+def dsolve(store, x):
+    """Solve L U x = b on the permuted system; x (n x nrhs, Fortran order) overwritten and returned."""
+    x = np.asfortranarray(np.array(x, dtype=np.float64))
+    if x.ndim == 1:
+        x = np.asfortranarray(x[:, None])
+    lib().slu_oracle_dsolve(*store._args(), _p(x, ctypes.c_double), ctypes.c_int(x.shape[0]), ctypes.c_int(x.shape[1]))
+    return x
+
+
+def num_threads():
+    return lib().slu_oracle_num_threads()
