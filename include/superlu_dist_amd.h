@@ -1,0 +1,163 @@
+/*
+ * superlu_dist_amd.h -- C ABI of the MI355X (gfx950) implementation of SuperLU_DIST's 3D supernodal
+ * LU hot path: numeric factorisation (pdgstrf3d) and block triangular solve (pdgstrs3d).
+ *
+ * Drop-in boundary.  The reference is plain C; its GPU factorisation is
+ * reached through an opaque-handle hook set called from pdgssvx3d
+ * (/root/reference/SRC/double/pdgssvx3d.c:1013-1021):
+ *
+ *     dCreateLUgpuHandle / pdgstrf3d_LUv1 / dCopyLUGPU2Host / dDestroyLUgpuHandle
+ *     (/root/reference/SRC/include/superlu_upacked.h:16-29,
+ *      /root/reference/SRC/CplusplusFactor/LUgpuCHandle_interface_impl.cu:11-73)
+ *
+ * The entry points below replace exactly that set (plus the solve hooks), with the reference's
+ * struct arguments flattened to plain pointers and sizes so that the library has no dependency on the
+ * reference headers.  INTEGRATION.md shows the ~40-line stub a maintainer adds to pdgssvx3d.c to bind
+ * dLUstruct_t / gridinfo3d_t / dtrf3Dpartition_t to these calls.
+ *
+ * All functions return 0 on success, a negative SLUAMD_E* code on failure; none of them falls back to
+ * a CPU path: without a HIP device they fail with SLUAMD_ENODEVICE.
+ */
+#ifndef SUPERLU_DIST_AMD_H
+#define SUPERLU_DIST_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference int_t (superlu_defs.h:121-129): 32-bit in the default build, 64-bit with _LONGINT.
+ * This library is built for the default 32-bit int_t; value offsets are 64-bit internally. */
+typedef int32_t sluamd_int_t;
+
+#define SLUAMD_OK 0
+#define SLUAMD_EINVAL (-1)
+#define SLUAMD_ENODEVICE (-2)
+#define SLUAMD_EHIP (-3)
+#define SLUAMD_ENOMEM (-4)
+#define SLUAMD_ESTRUCT (-5) /* malformed L/U index structure */
+
+/* One rank's view of dLUstruct_t->Llu + Glu_persist + gridinfo3d_t
+ * (superlu_ddefs.h:97-172, superlu_defs.h:454-457, :385-420).  Index formats are the reference's own
+ * (superlu_defs.h:156-198).  Pointer arrays have ceil(nsupers/npcol) and
+ * ceil(nsupers/nprow) entries; absent panels are NULL. */
+typedef struct sluamd_dLUview {
+    int64_t n;                      /* order of the matrix                                  */
+    int32_t nsupers;                /* Glu_persist->supno[n-1]+1                             */
+    const sluamd_int_t *xsup;       /* Glu_persist->xsup[nsupers+1]                          */
+    int32_t nprow, npcol, npdep;    /* gridinfo3d_t: grid2d.nprow, grid2d.npcol, npdep       */
+    int32_t myrow, mycol, myzlayer; /* MYROW(iam), MYCOL(iam), zscp.Iam                      */
+    sluamd_int_t **Lrowind_bc_ptr;  /* Llu->Lrowind_bc_ptr                                   */
+    double **Lnzval_bc_ptr;         /* Llu->Lnzval_bc_ptr                                    */
+    sluamd_int_t **Ufstnz_br_ptr;   /* Llu->Ufstnz_br_ptr                                    */
+    double **Unzval_br_ptr;         /* Llu->Unzval_br_ptr                                    */
+} sluamd_dLUview_t;
+
+/* dtrf3Dpartition_t (superlu_ddefs.h:317-337) flattened: elimination forests of this rank's Z layer.
+ * May be NULL for a 1x1x1 grid: the library then derives a level schedule from the block structure. */
+typedef struct sluamd_forest_view {
+    int32_t maxLvl;                   /* log2(npdep)+1                                        */
+    const sluamd_int_t *myTreeIdxs;   /* [maxLvl] forest id handled at each Z level           */
+    const sluamd_int_t *myZeroTrIdxs; /* [maxLvl] 1 = this layer does not factor that level   */
+    int32_t numForests;               /* 2^maxLvl - 1                                         */
+    const int32_t *nNodes;            /* [numForests] sForest_t.nNodes                        */
+    const sluamd_int_t *const *nodeList; /* [numForests] sForest_t.nodeList (elimination order) */
+} sluamd_forest_view_t;
+
+typedef struct sluamd_options {
+    int32_t device;             /* HIP device ordinal (-1 = current device)                      */
+    int32_t replace_tiny_pivot; /* options->ReplaceTinyPivot == YES (superlu_defs.h:697)         */
+    int32_t deterministic;      /* 1: one supernode per Schur launch, no fp64 atomics            */
+    int32_t verbose;
+    double  reserved[4];
+} sluamd_options_t;
+
+typedef struct sluamd_stats {
+    double flops_schur_padded; /* reference tally 2*nbrow*ldu*ncols (sec_structs.c:692-693), in double */
+    double flops_schur_exact;  /* 2*nbrow*segsize per U column                                        */
+    double flops_panel;        /* diag LU + the two panel TRSMs                                       */
+    double t_factor_ms;        /* last sluamd_pdgstrf3d: HIP-event time of the numeric phase          */
+    double t_schur_ms, t_panel_ms; /* split by kernel family (events on the compute stream)           */
+    double t_solve_ms;         /* last sluamd_pdgstrs3d                                               */
+    double t_h2d_ms, t_d2h_ms;
+    int64_t nnz_L, nnz_U;      /* stored entries (incl. explicit zeros of the supernodal format)      */
+    int64_t bytes_device;
+    int32_t num_levels, num_launches;
+    int32_t tiny_pivots;
+    int32_t reserved_i;
+    int64_t schur_launches, schur_tiles;
+    double  schur_bytes_alg;   /* algorithmic HBM bytes of all Schur launches             */
+} sluamd_stats_t;
+
+typedef struct sluamd_lu_handle_s *sluamd_handle_t;
+
+void sluamd_default_options(sluamd_options_t *opt);
+
+/* Replaces dCreateLUgpuHandle (LUgpuCHandle_interface_impl.cu:11): uploads this rank's L/U index and
+ * value arrays to HBM (kept resident for factor + solve), builds the device-side block directories and
+ * the level schedule.  `forests` may be NULL (see above). */
+int sluamd_dCreateLUHandle(sluamd_handle_t *h, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
+                           const sluamd_options_t *opt);
+
+/* Re-upload numeric values only (same structure): the SamePattern_SameRowPerm refactor path
+ * (superlu_defs.h:545-566). */
+int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu);
+
+/* Replaces pdgstrf3d_LUv1 (LUgpuCHandle_interface_impl.cu:66) == the numeric work of pdgstrf3d
+ * (pdgstrf3d.c:121-439): factors L\U in place in HBM.  thresh = smach("Epsilon")*anorm
+ * (pdgstrf3d.c:132-133).  *info: 0, or 1-based column of a zero pivot (pdgstrf2.c:568-571). */
+int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info);
+
+/* Replaces dCopyLUGPU2Host (LUgpuCHandle_interface_impl.cu:43): writes the factored values back into
+ * the caller's Lnzval_bc_ptr / Unzval_br_ptr arrays in the reference panel / skyline formats. */
+int sluamd_dCopyLU2Host(sluamd_handle_t h, const sluamd_dLUview_t *lu);
+
+/* Replaces the L- and U-solves of pdgstrs3d / pdgstrs3d_newsolve (pdgstrs3d.c:6604, :6935) between
+ * pdReDistribute3d_B_to_X and pdReDistribute3d_X_to_B: x is the right-hand side already permuted by
+ * Pc*Pr (row index = global row of the factored matrix), n x nrhs column-major with leading dimension
+ * ldx, overwritten by the solution of L U y = x.  Host-pointer and device-pointer variants. */
+int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs);
+int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nrhs);
+
+/* Replaces dDestroyLUgpuHandle (LUgpuCHandle_interface_impl.cu:30). */
+void sluamd_dDestroyLUHandle(sluamd_handle_t h);
+
+int sluamd_get_stats(sluamd_handle_t h, sluamd_stats_t *out);
+const char *sluamd_last_error(void);
+/* number of visible HIP devices (0 when none) -- lets callers fail loudly instead of falling back */
+int sluamd_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side producers of the L/U store (rows of SURVEY.md section 8(f) that the hot path needs when the
+ * reference's pre-processing is not linked): symmetric-pattern symbolic factorisation + distribution
+ * for a 1 x 1 x npdep grid.  Mirrors symbfact_dist / pddistribute3d (symbfact.c, pddistribute3d.c:1357)
+ * in effect (same store formats), not in algorithm.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct sluamd_symb_s *sluamd_symb_t;
+
+/* A: n x n CSR (rowptr/colind/nzval) of the ORIGINAL matrix; perm_c[old] = new is applied symmetrically
+ * (A1 = Pc A Pc^T, i.e. RowPerm = NOROWPERM, ColPerm = MY_PERMC; pdgssvx3d.c:749-791); the etree
+ * postorder is composed into perm_c_out like sp_colorder does (sp_colorder.c).  relax / maxsup play the
+ * roles of sp_ienv_dist(2) / sp_ienv_dist(3) (sp_ienv.c:95-110). */
+int sluamd_dsymbfact(sluamd_symb_t *s, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                     const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out);
+int sluamd_symb_info(sluamd_symb_t s, int32_t *nsupers, int64_t *nnzL, int64_t *nnzU, int64_t *lidx_len,
+                     int64_t *uidx_len, double *flops);
+/* borrow the store in the reference's formats (valid until sluamd_symb_free) */
+int sluamd_symb_view(sluamd_symb_t s, sluamd_dLUview_t *view);
+/* scatter A's values (original CSR + the same perm_c_out) into the zero-initialised store held by `s`
+ * (host) -- what pddistribute3d does for a 1x1x1 grid */
+int sluamd_ddistribute_host(sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                            const double *nzval, const sluamd_int_t *perm_c_final);
+/* device-resident variant: create the LU handle straight from the symbolic structure; values are
+ * zero-filled in HBM and A's entries scattered by a kernel (no host copy of the factors exists) */
+int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                   const sluamd_int_t *colind, const double *nzval,
+                                   const sluamd_int_t *perm_c_final, const sluamd_options_t *opt);
+void sluamd_symb_free(sluamd_symb_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUPERLU_DIST_AMD_H */

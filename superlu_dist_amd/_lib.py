@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI in include/superlu_dist_amd.h (libsluamd.so, built in-tree by
+superlu_dist_amd/csrc/Makefile).  No fallback: a missing library or a missing GPU raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsluamd.so")
+
+int_t = C.c_int32
+P_int = C.POINTER(C.c_int32)
+P_dbl = C.POINTER(C.c_double)
+
+
+class LUView(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nsupers", C.c_int32), ("xsup", P_int),
+                ("nprow", C.c_int32), ("npcol", C.c_int32), ("npdep", C.c_int32),
+                ("myrow", C.c_int32), ("mycol", C.c_int32), ("myzlayer", C.c_int32),
+                ("Lrowind_bc_ptr", C.POINTER(P_int)), ("Lnzval_bc_ptr", C.POINTER(P_dbl)),
+                ("Ufstnz_br_ptr", C.POINTER(P_int)), ("Unzval_br_ptr", C.POINTER(P_dbl))]
+
+
+class ForestView(C.Structure):
+    _fields_ = [("maxLvl", C.c_int32), ("myTreeIdxs", P_int), ("myZeroTrIdxs", P_int),
+                ("numForests", C.c_int32), ("nNodes", P_int), ("nodeList", C.POINTER(P_int))]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("replace_tiny_pivot", C.c_int32), ("deterministic", C.c_int32),
+                ("verbose", C.c_int32), ("reserved", C.c_double * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("flops_schur_padded", C.c_double), ("flops_schur_exact", C.c_double), ("flops_panel", C.c_double),
+                ("t_factor_ms", C.c_double), ("t_schur_ms", C.c_double), ("t_panel_ms", C.c_double),
+                ("t_solve_ms", C.c_double), ("t_h2d_ms", C.c_double), ("t_d2h_ms", C.c_double),
+                ("nnz_L", C.c_int64), ("nnz_U", C.c_int64), ("bytes_device", C.c_int64),
+                ("num_levels", C.c_int32), ("num_launches", C.c_int32), ("tiny_pivots", C.c_int32),
+                ("reserved_i", C.c_int32), ("schur_launches", C.c_int64), ("schur_tiles", C.c_int64),
+                ("schur_bytes_alg", C.c_double)]
+
+
+EXPORTS = [
+    "sluamd_default_options", "sluamd_dCreateLUHandle", "sluamd_dSetValues", "sluamd_pdgstrf3d",
+    "sluamd_dCopyLU2Host", "sluamd_pdgstrs3d", "sluamd_pdgstrs3d_dev", "sluamd_dDestroyLUHandle",
+    "sluamd_get_stats", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_symb_info",
+    "sluamd_symb_view", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RuntimeError(f"{_SO} not built: run `make -C superlu_dist_amd/csrc` (or __graft_entry__.build()); "
+                           "there is no CPU fallback for the hot path")
+    L = C.CDLL(_SO)
+    L.sluamd_last_error.restype = C.c_char_p
+    L.sluamd_dDestroyLUHandle.restype = None
+    L.sluamd_symb_free.restype = None
+    L.sluamd_default_options.restype = None
+    L.sluamd_dsymbfact.argtypes = [C.POINTER(C.c_void_p), C.c_int64, P_int, P_int, P_int, C.c_int32, C.c_int32, P_int]
+    L.sluamd_symb_info.argtypes = [C.c_void_p, P_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64), P_dbl]
+    L.sluamd_symb_view.argtypes = [C.c_void_p, C.POINTER(LUView)]
+    L.sluamd_ddistribute_host.argtypes = [C.c_void_p, P_int, P_int, P_dbl, P_int]
+    L.sluamd_symb_free.argtypes = [C.c_void_p]
+    L.sluamd_dCreateLUHandle.argtypes = [C.POINTER(C.c_void_p), C.POINTER(LUView), C.POINTER(ForestView), C.POINTER(Options)]
+    L.sluamd_dCreateLUHandleFromSymb.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int, C.POINTER(Options)]
+    L.sluamd_dSetValues.argtypes = [C.c_void_p, C.POINTER(LUView)]
+    L.sluamd_pdgstrf3d.argtypes = [C.c_void_p, C.c_double, P_int]
+    L.sluamd_pdgstrf3d_level.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.sluamd_factor_info.argtypes = [C.c_void_p, P_int, P_int]
+    L.sluamd_dCopyLU2Host.argtypes = [C.c_void_p, C.POINTER(LUView)]
+    L.sluamd_pdgstrs3d.argtypes = [C.c_void_p, P_dbl, C.c_int64, C.c_int32]
+    L.sluamd_pdgstrs3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    L.sluamd_dDestroyLUHandle.argtypes = [C.c_void_p]
+    L.sluamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.sluamd_arena.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.sluamd_mfma_selftest.argtypes = [P_dbl, P_dbl, P_dbl]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {load().sluamd_last_error().decode()}")

@@ -1,0 +1,1156 @@
+// sluamd_core.hip -- MI355X (gfx950) implementation of the 3D supernodal LU hot path.
+//
+// Host side: flattens the caller's reference-format L/U store (superlu_dist_amd.h), uploads it ONCE to
+// HBM (index arena + value arena stay resident for factor and solve), builds device-side block
+// directories, tile lists and an elimination-DAG level schedule.
+// Device side (hand-written HIP, wave64): per level of the schedule
+//     k_diag_lu      unpivoted LU of every diagonal block of the level   (Local_Dgstrf2, pdgstrf2.c:508)
+//     k_lpanel_trsm  L(:,k) <- L(:,k) U_kk^-1                            (dLPanelTrSolve, dtrfCommWrapper.c:120)
+//     k_upanel_trsm  U(k,:) <- L_kk^-1 U(k,:) directly on the skyline    (dTrs2_GatherTrsmScatter, pdgstrf2.c:804)
+//     k_schur        A(I,J) -= L(I,k) U(k,J): fused gather -> fp64 MFMA GEMM -> scatter, no bigU/bigV
+//                    round trip (dRgather_L/U dgather.c:133-398 + dblock_gemm_scatter dscatter3d.c:81-189
+//                    + dscatter_l dscatter.c:109 + scatter_u dscatter3d.c:555)
+// and for pdgstrs3d the level-set forward/backward block solves (dlsum_fmod_inv / dlsum_bmod_inv,
+// pdgstrs_lsum.c:414 / :1362).
+//
+// There is NO CPU fallback in this file: every entry point fails when no HIP device is present.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+#include "sluamd_internal.h"
+
+namespace sluamd {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_));             \
+            return SLUAMD_EHIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Device-side tables (all pointers into HBM).  SoA per supernode / per block.
+// ------------------------------------------------------------------------------------------------
+struct DevTables {
+    double *val;          // value arena: [L panels | U rows]
+    const int *lidx;      // Lrowind arena
+    const int *uidx;      // Ufstnz arena
+    const int *ucolptr;   // parallel to uidx: value offset (within the row) of each U column
+    const int *unzcol;    // parallel to uidx: compact list of non-empty column ids of each U block
+    const int *xsup;
+    // per supernode
+    const int64_t *sn_lval, *sn_uval;  // offsets into val
+    const int64_t *sn_lidx, *sn_uidx;  // offsets into lidx / uidx
+    const int *sn_nsupr;               // LDA of the L panel
+    const int *sn_ldu;                 // max U segment height of block row k
+    const int *sn_ncolu;               // total non-empty U columns of block row k
+    const int *sn_lb_off, *sn_nlb;     // L block table range
+    const int *sn_ub_off, *sn_nub;     // U block table range
+    const int *sn_rt_off, *sn_nrt;     // row-tile range
+    const int *sn_ct_off, *sn_nct;     // col-tile range
+    // per L block (stored order) + gid-sorted directory
+    const int *lb_gid, *lb_nbrow, *lb_rowoff, *lb_lptr;
+    const int *lbs_gid, *lbs_idx;
+    // per U block (sorted by gid)
+    const int *ub_gid, *ub_ncols, *ub_iukp, *ub_stcol;
+    // tiles
+    const int4 *rtile;  // (L block idx within panel, row start in block, nrows, panel row offset)
+    const int4 *ctile;  // (U block idx within row, first non-empty col rank, ncols, unused)
+};
+
+struct LevelSched {
+    int nlevels = 0;
+    std::vector<int> lvl_off;       // [nlevels+1] into nodes
+    std::vector<int> nodes;         // supernodes sorted by level
+    std::vector<int> tile_prefix;   // per node (aligned with nodes), exclusive prefix WITHIN its level (+1 total slot per level)
+    std::vector<int> ltr_prefix;    // L-TRSM strips
+    std::vector<int> utr_prefix;    // U-TRSM column chunks
+    std::vector<int> lvl_poff;      // [nlevels+1] offset of each level's prefix arrays (size nodes_in_level+1)
+    std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
+    std::vector<int> max_nsupc;     // per level
+    // device copies
+    int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
+    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr;
+};
+
+struct Handle {
+    int device = 0;
+    sluamd_options_t opt{};
+    HostStruct hs;
+    int Pz = 1, myz = 0;
+    // device arenas
+    double *d_val = nullptr;
+    int *d_lidx = nullptr, *d_uidx = nullptr, *d_ucolptr = nullptr, *d_unzcol = nullptr, *d_xsup = nullptr;
+    std::vector<void *> d_misc;  // everything else to free
+    DevTables T{};
+    std::vector<LevelSched> sched;  // one per Z level (forests) or a single one
+    hipStream_t stream = nullptr;
+    int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
+    double *d_x = nullptr; int64_t x_cap = 0;
+    sluamd_stats_t st{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // host tables kept for stats
+    std::vector<int> h_nsupr, h_ldu, h_ncolu;
+    int max_nsupc = 0;
+};
+
+// ================================================================================================
+//                                          KERNELS
+// ================================================================================================
+constexpr int TM = 64, TN = 64, KC = 16;
+constexpr int LDT = TM + 16;  // LDS row stride in doubles: == 16 mod 32 -> ds_read_b64 of a 16x4 fragment is conflict-free
+
+__device__ __forceinline__ int find_node(const int *__restrict__ prefix, int nn, int id)
+{   // largest i in [0,nn) with prefix[i] <= id   (prefix has nn+1 entries)
+    int lo = 0, hi = nn;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= id) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void atomic_sub_f64(double *p, double v)
+{
+    unsafeAtomicAdd(p, -v);  // global_atomic_add_f64 (hardware fp64 atomic on gfx950)
+}
+
+// ---- diagonal block LU -------------------------------------------------------------------------
+// One workgroup per supernode of the level.  Blocks with nsupc <= lds_max_ns are factored inside LDS,
+// larger ones in place in HBM/L2.  Arithmetic = right-looking rank-1 updates as Local_Dgstrf2.
+__global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restrict__ nodes, int lds_max_ns,
+                                                 int replace_tiny, double thresh, int *__restrict__ info)
+{
+    extern __shared__ double s_a[];
+    __shared__ double s_piv;
+    const int k = nodes[blockIdx.x];
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_nsupr[k];
+    double *A = T.val + T.sn_lval[k];
+    const int tid = threadIdx.x;
+    const bool in_lds = ns <= lds_max_ns;
+    const int ld = in_lds ? (ns | 1) : lda;  // odd stride in LDS
+    double *W = in_lds ? s_a : A;
+    if (in_lds) {
+        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; s_a[i + j * ld] = A[i + (size_t) j * lda]; }
+    }
+    __syncthreads();
+    for (int j = 0; j < ns; ++j) {
+        if (tid == 0) {
+            double p = W[j + (size_t) j * ld];
+            if (replace_tiny && fabs(p) < thresh) { p = (p < 0) ? -thresh : thresh; W[j + (size_t) j * ld] = p; atomicAdd(&info[1], 1); }
+            if (p == 0.0) atomicMin(&info[0], fst + j + 1);
+            s_piv = p;
+        }
+        __syncthreads();
+        const double p = s_piv;
+        const int m = ns - j - 1;
+        if (p != 0.0) {
+            const double r = 1.0 / p;
+            for (int i = tid; i < m; i += 256) W[j + 1 + i + (size_t) j * ld] *= r;
+        }
+        __syncthreads();
+        // trailing update: columns strided over waves, rows over lanes
+        for (int c = (tid >> 6); c < m; c += 4) {
+            const double u = W[j + (size_t) (j + 1 + c) * ld];
+            if (u != 0.0) {
+                double *col = W + (size_t) (j + 1 + c) * ld + j + 1;
+                const double *l = W + (size_t) j * ld + j + 1;
+                for (int i = (tid & 63); i < m; i += 64) col[i] -= l[i] * u;
+            }
+        }
+        __syncthreads();
+    }
+    if (in_lds) {
+        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; A[i + (size_t) j * lda] = s_a[i + j * ld]; }
+    }
+}
+
+// ---- L panel TRSM:  X U_kk = B  (R,U,N,N), one thread per panel row, 64-row strips ---------------
+__global__ __launch_bounds__(64) void k_lpanel_trsm(DevTables T, const int *__restrict__ nodes,
+                                                    const int *__restrict__ prefix, int nn)
+{
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int strip = blockIdx.x - prefix[ni];
+    const int ns = T.xsup[k + 1] - T.xsup[k];
+    const int lda = T.sn_nsupr[k];
+    const int row = ns + strip * 64 + threadIdx.x;
+    if (row >= lda) return;
+    double *A = T.val + T.sn_lval[k];
+    double *B = A + row;
+    for (int j = 0; j < ns; ++j) {
+        const double *u = A + (size_t) j * lda;  // column j of U_kk (rows 0..j)
+        double acc = B[(size_t) j * lda];
+        for (int kk = 0; kk < j; ++kk) acc -= B[(size_t) kk * lda] * u[kk];
+        B[(size_t) j * lda] = acc / u[j];
+    }
+}
+
+// ---- U panel TRSM:  L_kk X = U(k, cols)  (L,L,N,U) directly on the skyline, one thread per column ----
+__global__ __launch_bounds__(64) void k_upanel_trsm(DevTables T, const int *__restrict__ nodes,
+                                                    const int *__restrict__ prefix, int nn)
+{
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int chunk = blockIdx.x - prefix[ni];
+    const int c = chunk * 64 + threadIdx.x;  // rank among the non-empty columns of block row k
+    if (c >= T.sn_ncolu[k]) return;
+    const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+    // locate the U block holding column rank c
+    int lo = 0, hi = nub;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
+    const int b = ub0 + lo;
+    const int t = c - T.ub_stcol[b];
+    const int *uix = T.uidx + T.sn_uidx[k];
+    const int iukp = T.ub_iukp[b];
+    const int jj = T.unzcol[T.sn_uidx[k] + iukp + t];
+    const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
+    const int seg = klst - uix[iukp + jj];
+    double *u = T.val + T.sn_uval[k] + T.ucolptr[T.sn_uidx[k] + iukp + jj];
+    const int lda = T.sn_nsupr[k];
+    const double *Lkk = T.val + T.sn_lval[k] + (size_t) (ns - seg) * (lda + 1);  // unit lower, trailing seg x seg
+    for (int i = 1; i < seg; ++i) {
+        double acc = u[i];
+        for (int kk = 0; kk < i; ++kk) acc -= Lkk[i + (size_t) kk * lda] * u[kk];
+        u[i] = acc;
+    }
+}
+
+// ---- Schur complement update: fused gather -> MFMA fp64 GEMM -> scatter ---------------------------
+// One workgroup (4 waves) per 64x64 tile of one (L block, U block) pair of one supernode of the level.
+// MFMA v_mfma_f64_16x16x4_f64 computes D[i][j] = sum_k A[i][k] B[k][j] with lane l holding
+// A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[(l>>4)+4r][l&15].  We feed A := U^T (i = tile column) and
+// B := L^T (j = tile row) so that the 16 fast lanes of every accumulator register run along tile ROWS:
+// the scatter then writes 128-byte runs of a destination column (column-major L panel / U skyline).
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <bool USE_MFMA>
+__global__ __launch_bounds__(256) void k_schur(DevTables T, const int *__restrict__ nodes,
+                                               const int *__restrict__ prefix, int nn, int id_base,
+                                               int *__restrict__ info)
+{
+    __shared__ double Ls[KC * LDT];
+    __shared__ double Us[KC * LDT];
+    __shared__ int s_ind[512 + 8];
+    __shared__ int s_rowmap[TM];
+    __shared__ int s_colmap[TN];
+    __shared__ int s_cptr[TN];   // value offset of tile column j inside U(k,:)
+    __shared__ int s_lead[TN];   // ns - seg (leading zeros) of tile column j
+    __shared__ int s_jj[TN];     // column id inside supernode jb
+    __shared__ int64_t s_dbase;
+    __shared__ int s_dinfo[4];
+
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x + id_base;
+    const int ni = find_node(prefix, nn, bid);
+    const int k = nodes[ni];
+    const int local = bid - prefix[ni];
+    const int nct = T.sn_nct[k];
+    const int rt = local / nct, ct = local - rt * nct;
+    const int4 R = T.rtile[T.sn_rt_off[k] + rt];
+    const int4 C = T.ctile[T.sn_ct_off[k] + ct];
+    const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
+    const int nr = R.z, nc = C.z;
+    const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
+    const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
+    const int lda = T.sn_nsupr[k];
+    const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;  // global row ids of the tile rows
+    const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
+    const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
+    const double *Uv = T.val + T.sn_uval[k];
+
+    if (tid < TN) {
+        int cp = 0, lead = ns, jj = 0;
+        if (tid < nc) {
+            jj = T.unzcol[uix0 + C.y + tid];
+            lead = ns - (klst - T.uidx[uix0 + jj]);
+            cp = T.ucolptr[uix0 + jj];
+        }
+        s_cptr[tid] = cp; s_lead[tid] = lead; s_jj[tid] = jj;
+    }
+    // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
+    if (tid == 64) {
+        int found = 0;
+        if (ib >= jb) {
+            const int o = T.sn_lb_off[jb], nb = T.sn_nlb[jb];
+            int lo = 0, hi = nb;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.lbs_gid[o + mid] <= ib) lo = mid; else hi = mid; }
+            if (nb > 0 && T.lbs_gid[o + lo] == ib) {
+                const int d = o + T.lbs_idx[o + lo];
+                s_dinfo[0] = T.lb_rowoff[d]; s_dinfo[1] = T.lb_lptr[d]; s_dinfo[2] = T.lb_nbrow[d];
+                s_dbase = T.sn_lval[jb];
+                found = 1;
+            }
+        } else {
+            const int o = T.sn_ub_off[ib], nb = T.sn_nub[ib];
+            int lo = 0, hi = nb;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_gid[o + mid] <= jb) lo = mid; else hi = mid; }
+            if (nb > 0 && T.ub_gid[o + lo] == jb) {
+                s_dinfo[0] = T.ub_iukp[o + lo];
+                s_dbase = T.sn_uval[ib];
+                found = 1;
+            }
+        }
+        s_dinfo[3] = found;
+        if (!found) atomicAdd(&info[2], 1);
+    }
+    __syncthreads();
+
+    // ---- main loop -------------------------------------------------------------------------------
+    const int wave = tid >> 6, lane = tid & 63;
+    const int rm0 = (wave & 1) * 32, cn0 = (wave >> 1) * 32;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    double accs[16];  // VALU fallback accumulators (same element ownership as the MFMA layout)
+    if (!USE_MFMA) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[e] = 0.0;
+    }
+
+    const int kbeg = (ns - T.sn_ldu[k]) & ~3;  // U is zero above its tallest segment: skip those k
+    const int li = tid & 63, lk = tid >> 6;    // L loader: row li, k = lk + 4q
+    const int uk = tid & 15, uj = tid >> 4;    // U loader: k = uk, col = uj + 16q
+    for (int k0 = kbeg; k0 < ns; k0 += KC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = lk + 4 * q, kg = k0 + kk;
+            double v = 0.0;
+            if (li < nr && kg < ns) v = Lp[(size_t) kg * lda + li];
+            Ls[kk * LDT + li] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = uj + 16 * q, kg = k0 + uk;
+            double v = 0.0;
+            const int lead = s_lead[j];
+            if (kg >= lead && kg < ns) v = Uv[s_cptr[j] + (kg - lead)];
+            Us[uk * LDT + j] = v;
+        }
+        __syncthreads();
+        if (USE_MFMA) {
+#pragma unroll
+            for (int k4 = 0; k4 < KC; k4 += 4) {
+                const int kr = (k4 + (lane >> 4)) * LDT + (lane & 15);
+                const double a0 = Us[kr + cn0], a1 = Us[kr + cn0 + 16];
+                const double b0 = Ls[kr + rm0], b1 = Ls[kr + rm0 + 16];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        } else {
+            for (int kk = 0; kk < KC; ++kk) {
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = cn0 + 16 * ci + (lane >> 4) + 4 * r, row = rm0 + 16 * ri + (lane & 15);
+                            accs[(ci * 2 + ri) * 4 + r] += Us[kk * LDT + col] * Ls[kk * LDT + row];
+                        }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- scatter (epilogue) ----------------------------------------------------------------------
+    if (!s_dinfo[3]) return;
+    double *dst = T.val + s_dbase;
+    if (ib >= jb) {
+        // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
+        const int *drows = T.lidx + T.sn_lidx[jb] + s_dinfo[1];
+        const int fnz = T.xsup[ib], dn = s_dinfo[2];
+        for (int i = tid; i < dn; i += 256) s_ind[drows[i] - fnz] = i;
+        __syncthreads();
+        if (tid < TM) s_rowmap[tid] = (tid < nr) ? s_dinfo[0] + s_ind[lsub[tid] - fnz] : 0;
+        if (tid >= 64 && tid < 64 + TN) { const int j = tid - 64; s_colmap[j] = s_jj[j] * T.sn_nsupr[jb]; }
+    } else {
+        const int64_t d0 = T.sn_uidx[ib] + s_dinfo[0];
+        if (tid < TM) s_rowmap[tid] = (tid < nr) ? lsub[tid] : 0;
+        if (tid >= 64 && tid < 64 + TN) {
+            const int j = tid - 64;
+            int cm = 0;
+            if (j < nc) cm = T.ucolptr[d0 + s_jj[j]] - T.uidx[d0 + s_jj[j]];  // colptr - fstnz
+            s_colmap[j] = cm;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = cn0 + 16 * ci + (lane >> 4) + 4 * r, row = rm0 + 16 * ri + (lane & 15);
+                if (row < nr && col < nc) {
+                    const double v = USE_MFMA ? acc[ci][ri][r] : accs[(ci * 2 + ri) * 4 + r];
+                    atomic_sub_f64(dst + s_rowmap[row] + s_colmap[col], v);
+                }
+            }
+}
+
+// ---- triangular solves --------------------------------------------------------------------------
+// x_k <- inv(L_kk) x_k (unit lower) or inv(U_kk) x_k (upper): one workgroup per supernode of the level.
+template <bool LOWER>
+__global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
+                                                    int64_t ldx, int nrhs)
+{
+    extern __shared__ double xs[];  // ns x nrhs
+    const int k = nodes[blockIdx.x];
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_nsupr[k];
+    const double *A = T.val + T.sn_lval[k];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < ns * nrhs; idx += 256) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    __syncthreads();
+    if (LOWER) {
+        for (int j = 0; j < ns - 1; ++j) {
+            for (int idx = tid; idx < (ns - j - 1) * nrhs; idx += 256) {
+                const int i = j + 1 + idx % (ns - j - 1), r = idx / (ns - j - 1);
+                xs[i + r * ns] -= A[i + (size_t) j * lda] * xs[j + r * ns];
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int j = ns - 1; j >= 0; --j) {
+            if (tid < nrhs) xs[j + tid * ns] /= A[j + (size_t) j * lda];
+            __syncthreads();
+            for (int idx = tid; idx < j * nrhs; idx += 256) {
+                const int i = idx % j, r = idx / j;
+                xs[i + r * ns] -= A[i + (size_t) j * lda] * xs[j + r * ns];
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = tid; idx < ns * nrhs; idx += 256) x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = xs[idx];
+}
+
+// lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414):
+// one thread per panel row, 256-row strips; x_k staged in LDS.
+__global__ __launch_bounds__(256) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                    int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+{
+    extern __shared__ double xk[];  // ns x nrhs
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int strip = blockIdx.x - prefix[ni];
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_nsupr[k];
+    for (int idx = threadIdx.x; idx < ns * nrhs; idx += 256) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    __syncthreads();
+    const int row = ns + strip * 256 + threadIdx.x;
+    if (row >= lda) return;
+    const double *L = T.val + T.sn_lval[k] + row;
+    // global row id of panel row `row`: rows are listed block after block, 2 descriptor ints per block
+    // -> precomputed flat map is not stored; walk the (few) blocks
+    const int *lsub = T.lidx + T.sn_lidx[k];
+    int p = BC_HEADER, base = 0, grow = -1;
+    const int nb = lsub[0];
+    for (int b = 0; b < nb; ++b) {
+        const int nbrow = lsub[p + 1];
+        if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
+        base += nbrow; p += LB_DESCRIPTOR + nbrow;
+    }
+    for (int r = 0; r < nrhs; ++r) {
+        double acc = 0.0;
+        for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * xk[kk + r * ns];
+        atomic_sub_f64(x + grow + (int64_t) r * ldx, acc);
+    }
+}
+
+// x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362):
+// lanes run along the rows of supernode k (coalesced over the skyline segments), the 4 waves split the columns.
+__global__ __launch_bounds__(256) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                    int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+{
+    __shared__ int s_cp[64], s_ld[64], s_gc[64];
+    __shared__ double s_red[4][64];
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int chunk = blockIdx.x - prefix[ni];
+    const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
+    const int ncol = min(64, T.sn_ncolu[k] - chunk * 64);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 64) {
+        int cp = 0, ld = ns, gc = 0;
+        if (tid < ncol) {
+            const int c = chunk * 64 + tid;
+            const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+            int lo = 0, hi = nub;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
+            const int b = ub0 + lo;
+            const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+            const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
+            ld = ns - (klst - T.uidx[u0 + jj]);
+            cp = T.ucolptr[u0 + jj];
+            gc = T.xsup[T.ub_gid[b]] + jj;
+        }
+        s_cp[tid] = cp; s_ld[tid] = ld; s_gc[tid] = gc;
+    }
+    __syncthreads();
+    const double *Uv = T.val + T.sn_uval[k];
+    for (int r = 0; r < nrhs; ++r) {
+        for (int rb = 0; rb < ns; rb += 64) {
+            const int i = rb + lane;
+            double acc = 0.0;
+            for (int c = wave; c < ncol; c += 4) {
+                const int ld = s_ld[c];
+                if (i < ns && i >= ld) acc += Uv[s_cp[c] + (i - ld)] * x[s_gc[c] + (int64_t) r * ldx];
+            }
+            s_red[wave][lane] = acc;
+            __syncthreads();
+            if (wave == 0 && i < ns) {
+                const double s = s_red[0][lane] + s_red[1][lane] + s_red[2][lane] + s_red[3][lane];
+                if (s != 0.0) atomic_sub_f64(x + fst + i + (int64_t) r * ldx, s);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// A's entries -> value arena (device-side pddistribute): val[pos[e]] = a[e]
+__global__ void k_scatter_values(double *__restrict__ val, const int64_t *__restrict__ pos, const double *__restrict__ a, int64_t nnz)
+{
+    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) val[pos[e]] = a[e];
+}
+
+// MFMA layout self-test (used by tests): D = A(16x4) * B(4x16)
+__global__ void k_mfma_selftest(const double *A, const double *B, double *D)
+{
+    const int l = threadIdx.x;
+    d4 acc = (d4){0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+// ================================================================================================
+//                                       HOST: planning
+// ================================================================================================
+template <class Tv>
+static int upload(std::vector<void *> &keep, const std::vector<Tv> &h, Tv **d)
+{
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(Tv);
+    HIPCHK(hipMalloc((void **) d, bytes));
+    keep.push_back(*d);
+    if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(Tv), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int flatten_view(const sluamd_dLUview_t *lu, HostStruct &hs, bool want_sizes_only)
+{
+    (void) want_sizes_only;
+    if (!lu || !lu->xsup || lu->nsupers <= 0) { set_error("invalid LU view"); return SLUAMD_EINVAL; }
+    if (lu->nprow != 1 || lu->npcol != 1) {
+        set_error("round-1 library supports 1 x 1 x Pz process grids only (XY block-cyclic panels: later round)");
+        return SLUAMD_EINVAL;
+    }
+    const int ns = lu->nsupers;
+    hs.n = lu->n; hs.nsupers = ns;
+    hs.xsup.assign(lu->xsup, lu->xsup + ns + 1);
+    hs.lidx_off.assign(ns + 1, 0); hs.uidx_off.assign(ns + 1, 0);
+    hs.lval_off.assign(ns + 1, 0); hs.uval_off.assign(ns + 1, 0);
+    for (int k = 0; k < ns; ++k) {
+        const int *li = lu->Lrowind_bc_ptr[k];
+        if (!li) { set_error("L panel missing on a 1x1 grid"); return SLUAMD_ESTRUCT; }
+        const int nsupc = hs.xsup[k + 1] - hs.xsup[k];
+        hs.lidx_off[k + 1] = hs.lidx_off[k] + BC_HEADER + (int64_t) li[0] * LB_DESCRIPTOR + li[1];
+        hs.lval_off[k + 1] = hs.lval_off[k] + (int64_t) li[1] * nsupc;
+        const int *ui = lu->Ufstnz_br_ptr[k];
+        hs.uidx_off[k + 1] = hs.uidx_off[k] + (ui ? ui[2] : 0);
+        hs.uval_off[k + 1] = hs.uval_off[k] + (ui ? ui[1] : 0);
+    }
+    hs.nnzL = hs.lval_off[ns]; hs.nnzU = hs.uval_off[ns];
+    hs.lidx.resize(hs.lidx_off[ns]); hs.uidx.resize(hs.uidx_off[ns]);
+    for (int k = 0; k < ns; ++k) {
+        std::memcpy(hs.lidx.data() + hs.lidx_off[k], lu->Lrowind_bc_ptr[k], sizeof(int) * (hs.lidx_off[k + 1] - hs.lidx_off[k]));
+        if (hs.uidx_off[k + 1] > hs.uidx_off[k])
+            std::memcpy(hs.uidx.data() + hs.uidx_off[k], lu->Ufstnz_br_ptr[k], sizeof(int) * (hs.uidx_off[k + 1] - hs.uidx_off[k]));
+    }
+    return 0;
+}
+
+struct HostTables {
+    std::vector<int64_t> sn_lval, sn_uval, sn_lidx, sn_uidx;
+    std::vector<int> sn_nsupr, sn_ldu, sn_ncolu, sn_lb_off, sn_nlb, sn_ub_off, sn_nub, sn_rt_off, sn_nrt, sn_ct_off, sn_nct;
+    std::vector<int> lb_gid, lb_nbrow, lb_rowoff, lb_lptr, lbs_gid, lbs_idx;
+    std::vector<int> ub_gid, ub_ncols, ub_iukp, ub_stcol;
+    std::vector<int> ucolptr, unzcol;
+    std::vector<int4> rtile, ctile;
+};
+
+static int build_tables(Handle &H, HostTables &t)
+{
+    const HostStruct &hs = H.hs;
+    const int ns = hs.nsupers;
+    t.sn_lval.resize(ns); t.sn_uval.resize(ns); t.sn_lidx.resize(ns); t.sn_uidx.resize(ns);
+    t.sn_nsupr.resize(ns); t.sn_ldu.assign(ns, 0); t.sn_ncolu.assign(ns, 0);
+    t.sn_lb_off.resize(ns); t.sn_nlb.resize(ns); t.sn_ub_off.resize(ns); t.sn_nub.resize(ns);
+    t.sn_rt_off.resize(ns); t.sn_nrt.resize(ns); t.sn_ct_off.resize(ns); t.sn_nct.resize(ns);
+    t.ucolptr.assign(hs.uidx.size(), 0); t.unzcol.assign(hs.uidx.size(), 0);
+    H.max_nsupc = 0;
+    auto &st = H.st;
+    st.flops_schur_padded = st.flops_schur_exact = st.flops_panel = 0;
+    for (int k = 0; k < ns; ++k) {
+        const int nsupc = hs.xsup[k + 1] - hs.xsup[k], klst = hs.xsup[k + 1];
+        H.max_nsupc = std::max(H.max_nsupc, nsupc);
+        const int *li = hs.lidx.data() + hs.lidx_off[k];
+        const int nb = li[0], nsupr = li[1];
+        t.sn_lval[k] = hs.lval_off[k];
+        t.sn_uval[k] = hs.nnzL + hs.uval_off[k];
+        t.sn_lidx[k] = hs.lidx_off[k]; t.sn_uidx[k] = hs.uidx_off[k];
+        t.sn_nsupr[k] = nsupr;
+        t.sn_lb_off[k] = (int) t.lb_gid.size(); t.sn_nlb[k] = nb;
+        t.sn_rt_off[k] = (int) t.rtile.size();
+        int p = BC_HEADER, rowoff = 0;
+        std::vector<std::pair<int, int>> dir;
+        for (int b = 0; b < nb; ++b) {
+            const int gid = li[p], nbrow = li[p + 1];
+            if (gid < k || gid >= ns || nbrow <= 0 || rowoff + nbrow > nsupr) { set_error("malformed L block"); return SLUAMD_ESTRUCT; }
+            if (b == 0 && gid != k) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
+            t.lb_gid.push_back(gid); t.lb_nbrow.push_back(nbrow); t.lb_rowoff.push_back(rowoff); t.lb_lptr.push_back(p + LB_DESCRIPTOR);
+            dir.emplace_back(gid, b);
+            if (gid != k)
+                for (int r0 = 0; r0 < nbrow; r0 += TM) t.rtile.push_back(make_int4(b, r0, std::min(TM, nbrow - r0), rowoff + r0));
+            rowoff += nbrow; p += LB_DESCRIPTOR + nbrow;
+        }
+        if (rowoff != nsupr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
+        std::sort(dir.begin(), dir.end());
+        for (auto &d : dir) { t.lbs_gid.push_back(d.first); t.lbs_idx.push_back(d.second); }
+        t.sn_nrt[k] = (int) t.rtile.size() - t.sn_rt_off[k];
+        // U block row
+        t.sn_ub_off[k] = (int) t.ub_gid.size();
+        t.sn_ct_off[k] = (int) t.ctile.size();
+        int nub = 0, ldu = 0, ncol_tot = 0;
+        double exact = 0;
+        if (hs.uidx_off[k + 1] > hs.uidx_off[k]) {
+            const int *ui = hs.uidx.data() + hs.uidx_off[k];
+            int *cp = t.ucolptr.data() + hs.uidx_off[k];
+            int *nz = t.unzcol.data() + hs.uidx_off[k];
+            nub = ui[0];
+            int iukp = BR_HEADER; int64_t rukp = 0; int prev = k;
+            for (int b = 0; b < nub; ++b) {
+                const int jb = ui[iukp];
+                if (jb <= prev || jb >= ns) { set_error("U blocks must be sorted by block column"); return SLUAMD_ESTRUCT; }
+                prev = jb;
+                const int nsj = hs.xsup[jb + 1] - hs.xsup[jb];
+                int nc = 0;
+                for (int jj = 0; jj < nsj; ++jj) {
+                    const int seg = klst - ui[iukp + UB_DESCRIPTOR + jj];
+                    if (seg < 0 || seg > nsupc) { set_error("bad U segment"); return SLUAMD_ESTRUCT; }
+                    cp[iukp + UB_DESCRIPTOR + jj] = (int) rukp;
+                    if (seg) { nz[iukp + UB_DESCRIPTOR + nc] = jj; ++nc; rukp += seg; ldu = std::max(ldu, seg); exact += seg; }
+                }
+                t.ub_gid.push_back(jb); t.ub_ncols.push_back(nc); t.ub_iukp.push_back(iukp + UB_DESCRIPTOR); t.ub_stcol.push_back(ncol_tot);
+                for (int c0 = 0; c0 < nc; c0 += TN) t.ctile.push_back(make_int4(b, c0, std::min(TN, nc - c0), 0));
+                ncol_tot += nc;
+                iukp += UB_DESCRIPTOR + nsj;
+            }
+            if (rukp != hs.uval_off[k + 1] - hs.uval_off[k]) { set_error("U value count mismatch"); return SLUAMD_ESTRUCT; }
+        }
+        t.sn_nub[k] = nub; t.sn_ldu[k] = ldu; t.sn_ncolu[k] = ncol_tot;
+        t.sn_nct[k] = (int) t.ctile.size() - t.sn_ct_off[k];
+        const double rrows = nsupr - nsupc;
+        st.flops_schur_padded += 2.0 * rrows * ldu * ncol_tot;
+        st.flops_schur_exact += 2.0 * rrows * exact;
+        st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc + (double) nsupc * nsupc * rrows + (double) nsupc * exact;
+    }
+    H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu;
+    return 0;
+}
+
+// level schedule over `list` (a valid elimination order); node k's level = longest path of updates into it
+static void build_schedule(const Handle &H, const HostTables &t, const std::vector<int> &list, LevelSched &S)
+{
+    const HostStruct &hs = H.hs;
+    const int ns = hs.nsupers;
+    std::vector<int> lvl(ns, -1);
+    for (int k : list) lvl[k] = 0;
+    std::vector<int> sorted = list;
+    std::sort(sorted.begin(), sorted.end());
+    int maxl = 0;
+    for (int k : sorted) {
+        const int l1 = lvl[k] + 1;
+        for (int b = 1; b < t.sn_nlb[k]; ++b) { int g = t.lb_gid[t.sn_lb_off[k] + b]; if (lvl[g] >= 0 && lvl[g] < l1) lvl[g] = l1; }
+        for (int b = 0; b < t.sn_nub[k]; ++b) { int g = t.ub_gid[t.sn_ub_off[k] + b]; if (lvl[g] >= 0 && lvl[g] < l1) lvl[g] = l1; }
+        maxl = std::max(maxl, lvl[k]);
+    }
+    S.nlevels = list.empty() ? 0 : maxl + 1;
+    S.lvl_off.assign(S.nlevels + 1, 0);
+    for (int k : sorted) S.lvl_off[lvl[k] + 1]++;
+    for (int l = 0; l < S.nlevels; ++l) S.lvl_off[l + 1] += S.lvl_off[l];
+    S.nodes.resize(sorted.size());
+    std::vector<int> fill(S.lvl_off.begin(), S.lvl_off.end() - (S.nlevels ? 1 : 0));
+    for (int k : sorted) S.nodes[fill[lvl[k]]++] = k;
+    S.lvl_poff.assign(S.nlevels + 1, 0);
+    for (int l = 0; l < S.nlevels; ++l) S.lvl_poff[l + 1] = S.lvl_poff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 1;
+    const int psz = S.lvl_poff[S.nlevels];
+    S.tile_prefix.assign(psz, 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
+    S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0);
+    S.max_nsupc.assign(S.nlevels, 0);
+    for (int l = 0; l < S.nlevels; ++l) {
+        int po = S.lvl_poff[l];
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i, ++po) {
+            const int k = S.nodes[i];
+            const int nsupc = hs.xsup[k + 1] - hs.xsup[k];
+            const int rrows = t.sn_nsupr[k] - nsupc;
+            S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc);
+            S.tile_prefix[po + 1] = S.tile_prefix[po] + t.sn_nrt[k] * t.sn_nct[k];
+            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + 63) / 64;
+            S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
+            S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (rrows + 255) / 256;
+            S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
+        }
+    }
+}
+
+static int upload_schedule(Handle &H, LevelSched &S)
+{
+    if (upload(H.d_misc, S.nodes, &S.d_nodes)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.tile_prefix, &S.d_tile_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.ltr_prefix, &S.d_ltr_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.utr_prefix, &S.d_utr_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.fwd_prefix, &S.d_fwd_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.bwd_prefix, &S.d_bwd_prefix)) return SLUAMD_EHIP;
+    return 0;
+}
+
+static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
+{
+    HostTables t;
+    int rc = build_tables(*H, t);
+    if (rc) return rc;
+    // ---- device uploads ----
+    HIPCHK(hipStreamCreate(&H->stream));
+    HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
+    const HostStruct &hs = H->hs;
+    auto &K = H->d_misc;
+    DevTables &T = H->T;
+    T.val = H->d_val;
+    if (upload(K, hs.lidx, &H->d_lidx) || upload(K, hs.uidx, &H->d_uidx) || upload(K, t.ucolptr, &H->d_ucolptr) ||
+        upload(K, t.unzcol, &H->d_unzcol) || upload(K, hs.xsup, &H->d_xsup)) return SLUAMD_EHIP;
+    T.lidx = H->d_lidx; T.uidx = H->d_uidx; T.ucolptr = H->d_ucolptr; T.unzcol = H->d_unzcol; T.xsup = H->d_xsup;
+#define UP(field, vec, type) { type *p_; if (upload(K, vec, &p_)) return SLUAMD_EHIP; T.field = p_; }
+    UP(sn_lval, t.sn_lval, int64_t) UP(sn_uval, t.sn_uval, int64_t) UP(sn_lidx, t.sn_lidx, int64_t) UP(sn_uidx, t.sn_uidx, int64_t)
+    UP(sn_nsupr, t.sn_nsupr, int) UP(sn_ldu, t.sn_ldu, int) UP(sn_ncolu, t.sn_ncolu, int)
+    UP(sn_lb_off, t.sn_lb_off, int) UP(sn_nlb, t.sn_nlb, int) UP(sn_ub_off, t.sn_ub_off, int) UP(sn_nub, t.sn_nub, int)
+    UP(sn_rt_off, t.sn_rt_off, int) UP(sn_nrt, t.sn_nrt, int) UP(sn_ct_off, t.sn_ct_off, int) UP(sn_nct, t.sn_nct, int)
+    UP(lb_gid, t.lb_gid, int) UP(lb_nbrow, t.lb_nbrow, int) UP(lb_rowoff, t.lb_rowoff, int) UP(lb_lptr, t.lb_lptr, int)
+    UP(lbs_gid, t.lbs_gid, int) UP(lbs_idx, t.lbs_idx, int)
+    UP(ub_gid, t.ub_gid, int) UP(ub_ncols, t.ub_ncols, int) UP(ub_iukp, t.ub_iukp, int) UP(ub_stcol, t.ub_stcol, int)
+    UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4)
+#undef UP
+    // ---- schedules ----
+    std::vector<std::vector<int>> lists;
+    if (forests && forests->maxLvl > 0 && forests->nodeList) {
+        for (int l = 0; l < forests->maxLvl; ++l) {
+            std::vector<int> v;
+            if (!forests->myZeroTrIdxs[l]) {
+                const int f = forests->myTreeIdxs[l];
+                if (f >= 0 && f < forests->numForests && forests->nNodes[f] > 0)
+                    v.assign(forests->nodeList[f], forests->nodeList[f] + forests->nNodes[f]);
+            }
+            lists.push_back(std::move(v));
+        }
+    } else {
+        std::vector<int> v(hs.nsupers);
+        std::iota(v.begin(), v.end(), 0);
+        lists.push_back(std::move(v));
+    }
+    H->sched.resize(lists.size());
+    int nlev = 0;
+    for (size_t i = 0; i < lists.size(); ++i) {
+        build_schedule(*H, t, lists[i], H->sched[i]);
+        if (upload_schedule(*H, H->sched[i])) return SLUAMD_EHIP;
+        nlev += H->sched[i].nlevels;
+    }
+    H->st.num_levels = nlev;
+    HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
+    H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
+    size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
+    H->st.bytes_device = (int64_t) ((hs.nnzL + hs.nnzU) * sizeof(double) + idxb);
+    return 0;
+}
+
+static int check_device(int dev)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return SLUAMD_ENODEVICE; }
+    if (dev >= 0) { HIPCHK(hipSetDevice(dev)); }
+    return 0;
+}
+
+// ================================================================================================
+//                                   HOST: factorisation driver
+// ================================================================================================
+static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
+{
+    const bool use_mfma = getenv("SLUAMD_NO_MFMA") == nullptr;
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    auto schur = [&](int grid, const int *nodes, const int *prefix, int nn, int id_base) {
+        if (use_mfma) hipLaunchKernelGGL(k_schur<true>, dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, H->d_info);
+        else hipLaunchKernelGGL(k_schur<false>, dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, H->d_info);
+        H->st.num_launches++; H->st.schur_launches++;
+    };
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        const int *nodes = S.d_nodes + n0;
+        const int mx = S.max_nsupc[l];
+        const int lds_ns = (mx <= 128) ? mx : 128;
+        const size_t lds = (size_t) lds_ns * (lds_ns | 1) * sizeof(double);
+        hipLaunchKernelGGL(k_diag_lu, dim3(nn), dim3(256), lds, s, T, nodes, lds_ns, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
+        if (nl) hipLaunchKernelGGL(k_lpanel_trsm, dim3(nl), dim3(64), 0, s, T, nodes, S.d_ltr_prefix + po, nn);
+        if (nu) hipLaunchKernelGGL(k_upanel_trsm, dim3(nu), dim3(64), 0, s, T, nodes, S.d_utr_prefix + po, nn);
+        H->st.num_launches += 1 + (nl > 0) + (nu > 0);
+        const int nt = S.tile_prefix[po + nn];
+        if (!nt) continue;
+        if (!H->opt.deterministic) {
+            schur(nt, nodes, S.d_tile_prefix + po, nn, 0);
+        } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
+            for (int i = 0; i < nn; ++i) {
+                const int c = S.tile_prefix[po + i + 1] - S.tile_prefix[po + i];
+                if (c) schur(c, nodes, S.d_tile_prefix + po, nn, S.tile_prefix[po + i]);
+            }
+        }
+        H->st.schur_tiles += nt;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int run_solve(Handle *H, double *d_x, int64_t ldx, int nrhs)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    const size_t lds = (size_t) H->max_nsupc * nrhs * sizeof(double);
+    if (lds > 64 * 1024) { set_error("nrhs too large for the LDS-staged solve (max_nsupc*nrhs*8 must be <= 64 KiB)"); return SLUAMD_EINVAL; }
+    // forward: Z levels ascending, DAG levels ascending
+    for (size_t z = 0; z < H->sched.size(); ++z) {
+        LevelSched &S = H->sched[z];
+        for (int l = 0; l < S.nlevels; ++l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, d_x, ldx, nrhs);
+            const int nf = S.fwd_prefix[po + nn];
+            if (nf) hipLaunchKernelGGL(k_fwd_update, dim3(nf), dim3(256), lds, s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, d_x, ldx, nrhs);
+        }
+    }
+    for (int z = (int) H->sched.size() - 1; z >= 0; --z) {
+        LevelSched &S = H->sched[z];
+        for (int l = S.nlevels - 1; l >= 0; --l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            const int nb = S.bwd_prefix[po + nn];
+            if (nb) hipLaunchKernelGGL(k_bwd_update, dim3(nb), dim3(256), 0, s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, d_x, ldx, nrhs);
+            hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, d_x, ldx, nrhs);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sluamd
+
+// ================================================================================================
+//                                          C ABI
+// ================================================================================================
+using namespace sluamd;
+
+struct sluamd_lu_handle_s { Handle H; };
+
+extern "C" {
+
+const char *sluamd_last_error(void) { return g_err.c_str(); }
+
+int sluamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void sluamd_default_options(sluamd_options_t *opt)
+{
+    std::memset(opt, 0, sizeof(*opt));
+    opt->device = -1;
+}
+
+static int upload_values(Handle *H, const sluamd_dLUview_t *lu)
+{
+    const HostStruct &hs = H->hs;
+    // stage through one pinned buffer per half to keep the number of H2D copies small
+    const int ns = hs.nsupers;
+    std::vector<double> stage;
+    stage.resize((size_t) std::max(hs.nnzL, hs.nnzU));
+    for (int k = 0; k < ns; ++k) {
+        const int64_t len = hs.lval_off[k + 1] - hs.lval_off[k];
+        if (len) std::memcpy(stage.data() + hs.lval_off[k], lu->Lnzval_bc_ptr[k], sizeof(double) * len);
+    }
+    if (hs.nnzL) HIPCHK(hipMemcpy(H->d_val, stage.data(), sizeof(double) * hs.nnzL, hipMemcpyHostToDevice));
+    for (int k = 0; k < ns; ++k) {
+        const int64_t len = hs.uval_off[k + 1] - hs.uval_off[k];
+        if (len) std::memcpy(stage.data() + hs.uval_off[k], lu->Unzval_br_ptr[k], sizeof(double) * len);
+    }
+    if (hs.nnzU) HIPCHK(hipMemcpy(H->d_val + hs.nnzL, stage.data(), sizeof(double) * hs.nnzU, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int sluamd_dCreateLUHandle(sluamd_handle_t *out, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
+                           const sluamd_options_t *opt)
+{
+    if (!out) { set_error("null handle pointer"); return SLUAMD_EINVAL; }
+    *out = nullptr;
+    sluamd_options_t o;
+    if (opt) o = *opt; else sluamd_default_options(&o);
+    int rc = check_device(o.device);
+    if (rc) return rc;
+    auto *hh = new sluamd_lu_handle_s();
+    Handle *H = &hh->H;
+    H->opt = o;
+    HIPCHK(hipGetDevice(&H->device));
+    rc = flatten_view(lu, H->hs, false);
+    if (rc) { delete hh; return rc; }
+    H->Pz = lu->npdep; H->myz = lu->myzlayer;
+    const int64_t tot = H->hs.nnzL + H->hs.nnzU;
+    if (hipMalloc((void **) &H->d_val, sizeof(double) * std::max<int64_t>(tot, 1)) != hipSuccess) {
+        set_error("hipMalloc of the value arena failed"); delete hh; return SLUAMD_ENOMEM;
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    rc = upload_values(H, lu);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); H->st.t_h2d_ms = ms;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (!rc) rc = finish_create(H, forests);
+    if (rc) { sluamd_dDestroyLUHandle(hh); return rc; }
+    *out = hh;
+    return 0;
+}
+
+int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
+{
+    if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(h->H.device));
+    return upload_values(&h->H, lu);
+}
+
+int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info)
+{
+    if (!h) { set_error("null handle"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    int init[4] = {0x7fffffff, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
+    H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
+    HIPCHK(hipEventRecord(H->ev0, H->stream));
+    // Z levels in order (pdgstrf3d.c:333-385); the ancestor reduction between levels is the caller's
+    // collective (RCCL reduce on the arena slice) in a multi-rank run.
+    for (size_t z = 0; z < H->sched.size(); ++z) {
+        int rc = run_factor_sched(H, H->sched[z], thresh);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(H->ev1, H->stream));
+    int res[4];
+    HIPCHK(hipMemcpyAsync(res, H->d_info, sizeof(res), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_factor_ms = ms;
+    H->st.tiny_pivots = res[1];
+    if (info) *info = (res[0] == 0x7fffffff) ? 0 : res[0];
+    if (res[2]) { set_error("Schur update found no destination block for " + std::to_string(res[2]) + " tiles (structure not closed)"); return SLUAMD_ESTRUCT; }
+    return 0;
+}
+
+// factor one Z level only (multi-rank orchestration: level, reduce, level, ...)
+int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh)
+{
+    if (!h || zlevel < 0 || zlevel >= (int) h->H.sched.size()) { set_error("bad level"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    if (zlevel == 0) {
+        int init[4] = {0x7fffffff, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
+    }
+    int rc = run_factor_sched(H, H->sched[zlevel], thresh);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    return 0;
+}
+
+int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny)
+{
+    if (!h) return SLUAMD_EINVAL;
+    int res[4];
+    HIPCHK(hipMemcpy(res, h->H.d_info, sizeof(res), hipMemcpyDeviceToHost));
+    if (info) *info = (res[0] == 0x7fffffff) ? 0 : res[0];
+    if (tiny) *tiny = res[1];
+    return 0;
+}
+
+int sluamd_dCopyLU2Host(sluamd_handle_t h, const sluamd_dLUview_t *lu)
+{
+    if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    const HostStruct &hs = H->hs;
+    HIPCHK(hipSetDevice(H->device));
+    std::vector<double> stage((size_t) std::max(hs.nnzL, hs.nnzU));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0);
+    if (hs.nnzL) HIPCHK(hipMemcpy(stage.data(), H->d_val, sizeof(double) * hs.nnzL, hipMemcpyDeviceToHost));
+    for (int k = 0; k < hs.nsupers; ++k) {
+        const int64_t len = hs.lval_off[k + 1] - hs.lval_off[k];
+        if (len) std::memcpy(lu->Lnzval_bc_ptr[k], stage.data() + hs.lval_off[k], sizeof(double) * len);
+    }
+    if (hs.nnzU) HIPCHK(hipMemcpy(stage.data(), H->d_val + hs.nnzL, sizeof(double) * hs.nnzU, hipMemcpyDeviceToHost));
+    for (int k = 0; k < hs.nsupers; ++k) {
+        const int64_t len = hs.uval_off[k + 1] - hs.uval_off[k];
+        if (len) std::memcpy(lu->Unzval_br_ptr[k], stage.data() + hs.uval_off[k], sizeof(double) * len);
+    }
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); H->st.t_d2h_ms = ms;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
+
+int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nrhs)
+{
+    if (!h || !d_x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) return 0;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    HIPCHK(hipEventRecord(H->ev0, H->stream));
+    int rc = run_solve(H, d_x, ldx, nrhs);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(H->ev1, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_solve_ms = ms;
+    return 0;
+}
+
+int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs)
+{
+    if (!h || !x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) return 0;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t need = ldx * nrhs;
+    if (need > H->x_cap) {
+        if (H->d_x) hipFree(H->d_x);
+        HIPCHK(hipMalloc((void **) &H->d_x, sizeof(double) * need));
+        H->x_cap = need;
+    }
+    HIPCHK(hipMemcpy(H->d_x, x, sizeof(double) * need, hipMemcpyHostToDevice));
+    int rc = sluamd_pdgstrs3d_dev(h, H->d_x, ldx, nrhs);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(x, H->d_x, sizeof(double) * need, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+void sluamd_dDestroyLUHandle(sluamd_handle_t h)
+{
+    if (!h) return;
+    Handle *H = &h->H;
+    hipSetDevice(H->device);
+    if (H->stream) hipStreamSynchronize(H->stream);
+    for (void *p : H->d_misc) hipFree(p);
+    if (H->d_val) hipFree(H->d_val);
+    if (H->d_info) hipFree(H->d_info);
+    if (H->d_x) hipFree(H->d_x);
+    if (H->ev0) hipEventDestroy(H->ev0);
+    if (H->ev1) hipEventDestroy(H->ev1);
+    if (H->stream) hipStreamDestroy(H->stream);
+    delete h;
+}
+
+int sluamd_get_stats(sluamd_handle_t h, sluamd_stats_t *out)
+{
+    if (!h || !out) return SLUAMD_EINVAL;
+    *out = h->H.st;
+    return 0;
+}
+
+// raw access for the multi-rank orchestration (RCCL collectives operate on arena slices)
+int sluamd_arena(sluamd_handle_t h, double **d_val, int64_t *nnzL, int64_t *nnzU)
+{
+    if (!h) return SLUAMD_EINVAL;
+    if (d_val) *d_val = h->H.d_val;
+    if (nnzL) *nnzL = h->H.hs.nnzL;
+    if (nnzU) *nnzU = h->H.hs.nnzU;
+    return 0;
+}
+
+int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                   const sluamd_int_t *colind, const double *nzval,
+                                   const sluamd_int_t *perm_c_final, const sluamd_options_t *opt)
+{
+    if (!out || !s) { set_error("null argument"); return SLUAMD_EINVAL; }
+    *out = nullptr;
+    sluamd_options_t o;
+    if (opt) o = *opt; else sluamd_default_options(&o);
+    int rc = check_device(o.device);
+    if (rc) return rc;
+    Symb *sy = reinterpret_cast<Symb *>(s);
+    auto *hh = new sluamd_lu_handle_s();
+    Handle *H = &hh->H;
+    H->opt = o;
+    HIPCHK(hipGetDevice(&H->device));
+    H->hs = sy->hs;  // structure copy (index arrays only)
+    const HostStruct &hs = H->hs;
+    const int64_t tot = hs.nnzL + hs.nnzU;
+    if (hipMalloc((void **) &H->d_val, sizeof(double) * std::max<int64_t>(tot, 1)) != hipSuccess) {
+        set_error("hipMalloc of the value arena failed"); delete hh; return SLUAMD_ENOMEM;
+    }
+    HIPCHK(hipMemset(H->d_val, 0, sizeof(double) * tot));
+    {   // device-side distribution of A's values
+        std::vector<int64_t> pos; std::vector<uint8_t> isu;
+        compute_scatter_positions(*sy, hs.n, rowptr, colind, perm_c_final, pos, isu);
+        const int64_t nnz = (int64_t) pos.size();
+        for (int64_t e = 0; e < nnz; ++e) if (isu[e]) pos[e] += hs.nnzL;
+        int64_t *d_pos; double *d_a;
+        HIPCHK(hipMalloc((void **) &d_pos, sizeof(int64_t) * std::max<int64_t>(nnz, 1)));
+        HIPCHK(hipMalloc((void **) &d_a, sizeof(double) * std::max<int64_t>(nnz, 1)));
+        HIPCHK(hipMemcpy(d_pos, pos.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_a, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        if (nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, 0, H->d_val, d_pos, d_a, nnz);
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(d_pos); hipFree(d_a);
+    }
+    rc = finish_create(H, nullptr);
+    if (rc) { sluamd_dDestroyLUHandle(hh); return rc; }
+    *out = hh;
+    return 0;
+}
+
+// test hook: MFMA fp64 fragment layout check
+int sluamd_mfma_selftest(const double *A, const double *B, double *D)
+{
+    int rc = check_device(-1);
+    if (rc) return rc;
+    double *dA, *dB, *dD;
+    HIPCHK(hipMalloc((void **) &dA, 64 * 8)); HIPCHK(hipMalloc((void **) &dB, 64 * 8)); HIPCHK(hipMalloc((void **) &dD, 256 * 8));
+    HIPCHK(hipMemcpy(dA, A, 64 * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dB, B, 64 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    HIPCHK(hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dB); hipFree(dD);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+// sluamd_symb.cpp -- host-side producer of the L/U store for the hot path when the reference's
+// pre-processing is not linked (built only as far as the path needs):
+// symmetric-pattern supernodal symbolic factorisation + distribution for a 1x1 process layer.
+//
+// Effect mirrors symbfact_dist (SRC/prec-independent/symbfact.c) + pddistribute3d
+// (SRC/double/pddistribute3d.c:1357): same store formats (superlu_defs.h:156-198), relaxed supernodes
+// like relax_snode (SRC/prec-independent/symbfact.c, sp_ienv_dist(2)), supernode width capped like
+// sp_ienv_dist(3).  The algorithm is our own: elimination tree of A+A^T (Liu), postorder composed into
+// perm_c (as sp_colorder does), supernodal structure by child-structure union.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include "sluamd_internal.h"
+
+using namespace sluamd;
+
+namespace {
+
+struct Graph {           // permuted symmetric pattern, strictly-lower and strictly-upper adjacency
+    std::vector<int64_t> lo_off, up_off;
+    std::vector<int> lo, up;   // lo: rows > col ; up: rows < col
+};
+
+void build_graph(int64_t n, const int *rowptr, const int *colind, const int *perm, Graph &g)
+{
+    std::vector<int64_t> cl(n + 1, 0), cu(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i)
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            int a = perm[i], b = perm[colind[e]];
+            if (a == b) continue;
+            int lo = std::min(a, b), hi = std::max(a, b);
+            cl[lo + 1]++; cu[hi + 1]++;
+        }
+    for (int64_t i = 0; i < n; ++i) { cl[i + 1] += cl[i]; cu[i + 1] += cu[i]; }
+    g.lo_off = cl; g.up_off = cu;
+    g.lo.resize(cl[n]); g.up.resize(cu[n]);
+    std::vector<int64_t> pl(cl.begin(), cl.end() - 1), pu(cu.begin(), cu.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            int a = perm[i], b = perm[colind[e]];
+            if (a == b) continue;
+            int lo = std::min(a, b), hi = std::max(a, b);
+            g.lo[pl[lo]++] = hi; g.up[pu[hi]++] = lo;
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                     const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out)
+{
+    if (!out || n <= 0 || !rowptr || !colind) { set_error("bad symbfact arguments"); return SLUAMD_EINVAL; }
+    if (maxsup < 1) maxsup = 256;
+    if (maxsup > 512) maxsup = 512;  // MAX_SUPER_SIZE, superlu_defs.h:154
+    if (relax < 1) relax = 1;
+    if (relax > maxsup) relax = maxsup;
+    std::vector<int> perm(n);
+    if (perm_c) std::copy(perm_c, perm_c + n, perm.begin()); else std::iota(perm.begin(), perm.end(), 0);
+    {   // validate permutation
+        std::vector<char> seen(n, 0);
+        for (int64_t i = 0; i < n; ++i) { if (perm[i] < 0 || perm[i] >= n || seen[perm[i]]) { set_error("perm_c is not a permutation"); return SLUAMD_EINVAL; } seen[perm[i]] = 1; }
+    }
+    Graph g;
+    build_graph(n, rowptr, colind, perm.data(), g);
+    // ---- elimination tree (Liu, path compression) ----
+    std::vector<int> parent(n, -1), anc(n, -1);
+    for (int j = 0; j < n; ++j)
+        for (int64_t e = g.up_off[j]; e < g.up_off[j + 1]; ++e) {
+            int i = g.up[e];
+            while (i != -1 && i < j) {
+                int nx = anc[i];
+                anc[i] = j;
+                if (nx == -1) parent[i] = j;
+                i = nx;
+            }
+        }
+    // ---- postorder (children in increasing order, iterative DFS) ----
+    std::vector<int> head(n, -1), next(n, -1), post(n), newlab(n);
+    for (int j = (int) n - 1; j >= 0; --j) if (parent[j] != -1) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+    {
+        int k = 0;
+        std::vector<int> stack;
+        for (int r = 0; r < n; ++r) {
+            if (parent[r] != -1) continue;
+            stack.push_back(r);
+            while (!stack.empty()) {
+                int v = stack.back();
+                int c = head[v];
+                if (c == -1) { post[k] = v; newlab[v] = k++; stack.pop_back(); }
+                else { head[v] = next[c]; stack.push_back(c); }
+            }
+        }
+    }
+    // compose postorder into the permutation and relabel
+    for (int64_t i = 0; i < n; ++i) perm[i] = newlab[perm[i]];
+    if (perm_c_out) std::copy(perm.begin(), perm.end(), perm_c_out);
+    {
+        std::vector<int> p2(n, -1);
+        for (int j = 0; j < n; ++j) if (parent[j] != -1) p2[newlab[j]] = newlab[parent[j]];
+        parent.swap(p2);
+    }
+    build_graph(n, rowptr, colind, perm.data(), g);  // adjacency in final labels
+    // ---- subtree sizes, child counts, relaxed subtree roots ----
+    std::vector<int> sz(n, 1), nchild(n, 0);
+    for (int j = 0; j < n; ++j) if (parent[j] != -1) { sz[parent[j]] += sz[j]; nchild[parent[j]]++; }
+    std::vector<int> relax_end(n, -1);  // relax_end[a] = b if [a,b] is a relaxed subtree
+    for (int j = 0; j < n; ++j)
+        if (sz[j] <= relax && (parent[j] == -1 || sz[parent[j]] > relax)) relax_end[j - sz[j] + 1] = j;
+    // ---- supernodal structure ----
+    auto *sy = new Symb();
+    HostStruct &hs = sy->hs;
+    hs.n = n;
+    sy->supno.assign(n, -1);
+    std::vector<int> mark(n, -1);
+    std::vector<int> pend_head(n, -1), pend_next;  // child units pending on a column (linked by unit id)
+    std::vector<int> ufirst, ulast;
+    sy->srow_off.push_back(0);
+    std::vector<int> cur;
+    int j = 0;
+    while (j < n) {
+        const int u = (int) ufirst.size();
+        int a = j, b;
+        cur.clear();
+        auto add_adj = [&](int c) {
+            for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != u) { mark[r] = u; cur.push_back(r); } }
+        };
+        auto add_children_of = [&](int c) {
+            for (int cu = pend_head[c]; cu != -1; cu = pend_next[cu])
+                for (int64_t e = sy->srow_off[cu]; e < sy->srow_off[cu + 1]; ++e) { int r = sy->srows[e]; if (mark[r] != u) { mark[r] = u; cur.push_back(r); } }
+        };
+        if (relax_end[j] >= 0) {
+            b = relax_end[j];
+            for (int c = a; c <= b; ++c) add_adj(c);  // full subtree: no child unit lies outside [a,b]
+        } else {
+            b = a;
+            add_adj(a); add_children_of(a);
+            while (b + 1 < n && (b - a + 1) < maxsup && parent[b] == b + 1 && nchild[b + 1] == 1 && relax_end[b + 1] < 0) {
+                const int c = b + 1;
+                bool sub = true;
+                for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1] && sub; ++e) sub = (mark[g.lo[e]] == u);
+                if (!sub) break;
+                b = c;
+            }
+        }
+        // finalize: rows > b, sorted
+        size_t w = 0;
+        for (size_t i = 0; i < cur.size(); ++i) if (cur[i] > b) cur[w++] = cur[i];
+        cur.resize(w);
+        std::sort(cur.begin(), cur.end());
+        sy->srows.insert(sy->srows.end(), cur.begin(), cur.end());
+        sy->srow_off.push_back((int64_t) sy->srows.size());
+        ufirst.push_back(a); ulast.push_back(b);
+        for (int c = a; c <= b; ++c) sy->supno[c] = u;
+        pend_next.push_back(-1);
+        if (parent[b] != -1) { pend_next[u] = pend_head[parent[b]]; pend_head[parent[b]] = u; }
+        j = b + 1;
+    }
+    const int ns = (int) ufirst.size();
+    hs.nsupers = ns;
+    hs.xsup.resize(ns + 1);
+    for (int k = 0; k < ns; ++k) hs.xsup[k] = ufirst[k];
+    hs.xsup[ns] = (int) n;
+    // ---- index arrays in the reference formats ----
+    hs.lidx_off.assign(ns + 1, 0); hs.uidx_off.assign(ns + 1, 0); hs.lval_off.assign(ns + 1, 0); hs.uval_off.assign(ns + 1, 0);
+    double flops = 0;
+    for (int k = 0; k < ns; ++k) {
+        const int nsupc = hs.xsup[k + 1] - hs.xsup[k];
+        const int64_t s0 = sy->srow_off[k], s1 = sy->srow_off[k + 1];
+        int nblk = 0, ucols = 0; int64_t ulen = 0;
+        for (int64_t e = s0; e < s1;) {
+            const int gb = sy->supno[sy->srows[e]];
+            int64_t f = e;
+            while (f < s1 && sy->supno[sy->srows[f]] == gb) ++f;
+            ++nblk; ulen += UB_DESCRIPTOR + (hs.xsup[gb + 1] - hs.xsup[gb]); ucols += (int) (f - e);
+            e = f;
+        }
+        const int64_t r = s1 - s0;
+        hs.lidx_off[k + 1] = hs.lidx_off[k] + BC_HEADER + (int64_t) (nblk + 1) * LB_DESCRIPTOR + nsupc + r;
+        hs.lval_off[k + 1] = hs.lval_off[k] + (int64_t) (nsupc + r) * nsupc;
+        hs.uidx_off[k + 1] = hs.uidx_off[k] + (nblk ? BR_HEADER + ulen : 0);
+        hs.uval_off[k + 1] = hs.uval_off[k] + (int64_t) ucols * nsupc;
+        flops += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc + 2.0 * (double) nsupc * nsupc * r + 2.0 * (double) nsupc * r * r;
+    }
+    sy->flops = flops;
+    hs.nnzL = hs.lval_off[ns]; hs.nnzU = hs.uval_off[ns];
+    hs.lidx.resize(hs.lidx_off[ns]); hs.uidx.resize(hs.uidx_off[ns]);
+    for (int k = 0; k < ns; ++k) {
+        const int nsupc = hs.xsup[k + 1] - hs.xsup[k], klst = hs.xsup[k + 1];
+        const int64_t s0 = sy->srow_off[k], s1 = sy->srow_off[k + 1];
+        int *li = hs.lidx.data() + hs.lidx_off[k];
+        int p = BC_HEADER, nblk = 1;
+        li[1] = (int) (nsupc + (s1 - s0));
+        li[p] = k; li[p + 1] = nsupc;
+        for (int i = 0; i < nsupc; ++i) li[p + LB_DESCRIPTOR + i] = hs.xsup[k] + i;
+        p += LB_DESCRIPTOR + nsupc;
+        int *ui = (s1 > s0) ? hs.uidx.data() + hs.uidx_off[k] : nullptr;
+        int q = BR_HEADER, nub = 0;
+        for (int64_t e = s0; e < s1;) {
+            const int gb = sy->supno[sy->srows[e]];
+            int64_t f = e;
+            while (f < s1 && sy->supno[sy->srows[f]] == gb) ++f;
+            li[p] = gb; li[p + 1] = (int) (f - e);
+            for (int64_t t = e; t < f; ++t) li[p + LB_DESCRIPTOR + (t - e)] = sy->srows[t];
+            p += LB_DESCRIPTOR + (int) (f - e); ++nblk;
+            const int nsj = hs.xsup[gb + 1] - hs.xsup[gb];
+            ui[q] = gb; ui[q + 1] = (int) (f - e) * nsupc;
+            for (int c = 0; c < nsj; ++c) ui[q + UB_DESCRIPTOR + c] = klst;            // empty segment
+            for (int64_t t = e; t < f; ++t) ui[q + UB_DESCRIPTOR + (sy->srows[t] - hs.xsup[gb])] = hs.xsup[k];  // full segment
+            q += UB_DESCRIPTOR + nsj; ++nub;
+            e = f;
+        }
+        li[0] = nblk;
+        if (ui) { ui[0] = nub; ui[1] = (int) (hs.uval_off[k + 1] - hs.uval_off[k]); ui[2] = q; }
+    }
+    sy->perm_c_final = perm;
+    *out = reinterpret_cast<sluamd_symb_t>(sy);
+    return 0;
+}
+
+int sluamd_symb_info(sluamd_symb_t s, int32_t *nsupers, int64_t *nnzL, int64_t *nnzU, int64_t *lidx_len,
+                     int64_t *uidx_len, double *flops)
+{
+    if (!s) return SLUAMD_EINVAL;
+    Symb *sy = reinterpret_cast<Symb *>(s);
+    if (nsupers) *nsupers = sy->hs.nsupers;
+    if (nnzL) *nnzL = sy->hs.nnzL;
+    if (nnzU) *nnzU = sy->hs.nnzU;
+    if (lidx_len) *lidx_len = (int64_t) sy->hs.lidx.size();
+    if (uidx_len) *uidx_len = (int64_t) sy->hs.uidx.size();
+    if (flops) *flops = sy->flops;
+    return 0;
+}
+
+int sluamd_symb_view(sluamd_symb_t s, sluamd_dLUview_t *v)
+{
+    if (!s || !v) return SLUAMD_EINVAL;
+    Symb *sy = reinterpret_cast<Symb *>(s);
+    HostStruct &hs = sy->hs;
+    const int ns = hs.nsupers;
+    if (sy->lval.size() != (size_t) hs.nnzL) sy->lval.assign(hs.nnzL, 0.0);
+    if (sy->uval.size() != (size_t) hs.nnzU) sy->uval.assign(hs.nnzU, 0.0);
+    sy->lptr.resize(ns); sy->uptr.resize(ns); sy->lvptr.resize(ns); sy->uvptr.resize(ns);
+    for (int k = 0; k < ns; ++k) {
+        sy->lptr[k] = hs.lidx.data() + hs.lidx_off[k];
+        sy->lvptr[k] = sy->lval.data() + hs.lval_off[k];
+        const bool hasu = hs.uidx_off[k + 1] > hs.uidx_off[k];
+        sy->uptr[k] = hasu ? hs.uidx.data() + hs.uidx_off[k] : nullptr;
+        sy->uvptr[k] = hasu ? sy->uval.data() + hs.uval_off[k] : nullptr;
+    }
+    std::memset(v, 0, sizeof(*v));
+    v->n = hs.n; v->nsupers = ns; v->xsup = hs.xsup.data();
+    v->nprow = v->npcol = v->npdep = 1;
+    v->Lrowind_bc_ptr = sy->lptr.data(); v->Lnzval_bc_ptr = sy->lvptr.data();
+    v->Ufstnz_br_ptr = sy->uptr.data(); v->Unzval_br_ptr = sy->uvptr.data();
+    return 0;
+}
+
+int sluamd_ddistribute_host(sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                            const double *nzval, const sluamd_int_t *perm_c_final)
+{
+    if (!s) return SLUAMD_EINVAL;
+    Symb *sy = reinterpret_cast<Symb *>(s);
+    HostStruct &hs = sy->hs;
+    sy->lval.assign(hs.nnzL, 0.0); sy->uval.assign(hs.nnzU, 0.0);
+    std::vector<int64_t> pos; std::vector<uint8_t> isu;
+    compute_scatter_positions(*sy, hs.n, rowptr, colind, perm_c_final ? perm_c_final : sy->perm_c_final.data(), pos, isu);
+    for (size_t e = 0; e < pos.size(); ++e) (isu[e] ? sy->uval : sy->lval)[pos[e]] = nzval[e];
+    return 0;
+}
+
+void sluamd_symb_free(sluamd_symb_t s) { delete reinterpret_cast<Symb *>(s); }
+
+}  // extern "C"
+
+namespace sluamd {
+
+void compute_scatter_positions(const Symb &sy, int64_t n, const int *rowptr, const int *colind,
+                               const int *perm, std::vector<int64_t> &pos, std::vector<uint8_t> &is_u)
+{
+    const HostStruct &hs = sy.hs;
+    const int64_t nnz = rowptr[n];
+    pos.resize(nnz); is_u.resize(nnz);
+    auto rank_in = [&](int k, int row) -> int64_t {
+        const int *b = sy.srows.data() + sy.srow_off[k], *e = sy.srows.data() + sy.srow_off[k + 1];
+        return std::lower_bound(b, e, row) - b;
+    };
+    for (int64_t i = 0; i < n; ++i)
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const int pi = perm[i], pj = perm[colind[e]];
+            const int s = sy.supno[pj];
+            const int nsupc = hs.xsup[s + 1] - hs.xsup[s];
+            if (pi >= hs.xsup[s]) {
+                const int nsupr = nsupc + (int) (sy.srow_off[s + 1] - sy.srow_off[s]);
+                const int64_t lr = (pi < hs.xsup[s + 1]) ? (pi - hs.xsup[s]) : nsupc + rank_in(s, pi);
+                pos[e] = hs.lval_off[s] + lr + (int64_t) (pj - hs.xsup[s]) * nsupr;
+                is_u[e] = 0;
+            } else {
+                const int r = sy.supno[pi];
+                const int nr = hs.xsup[r + 1] - hs.xsup[r];
+                pos[e] = hs.uval_off[r] + rank_in(r, pj) * nr + (pi - hs.xsup[r]);
+                is_u[e] = 1;
+            }
+        }
+}
+
+}  // namespace sluamd

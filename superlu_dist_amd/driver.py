@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's expert-driver interface for the hot path.
+
+Names follow the reference (SRC/double/pdgssvx3d.c:519 `pdgssvx3d`, SRC/double/pdgstrf3d.c:121 `pdgstrf3d`,
+SRC/double/pdgstrs3d.c:6604 `pdgstrs3d`): Python here is only the test/bench harness above the C ABI
+(include/superlu_dist_amd.h) -- all numerics run in libsluamd.so on the GPU; nothing here computes on the CPU
+except permutation bookkeeping and the residual check.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import LUView, ForestView, Options, Stats, P_int, P_dbl
+
+
+def _pi(a):
+    return a.ctypes.data_as(P_int)
+
+
+def _pd(a):
+    return a.ctypes.data_as(P_dbl)
+
+
+class FlatStore:
+    """A 1 x 1 x Pz rank's L/U store as flat arrays + offsets (what tests/golden holds), exposed to the C ABI
+    through the reference's pointer-array view (Lrowind_bc_ptr[lk], Lnzval_bc_ptr[lk], ...)."""
+
+    def __init__(self, n, xsup, Lrowind_off, Lrowind, Lnzval_off, Lnzval, Ufstnz_off, Ufstnz, Unzval_off, Unzval,
+                 grid=(1, 1, 1), coords=(0, 0, 0)):
+        self.n = int(n)
+        self.xsup = np.ascontiguousarray(xsup, dtype=np.int32)
+        self.nsupers = len(self.xsup) - 1
+        self.Lrowind_off = np.asarray(Lrowind_off, dtype=np.int64)
+        self.Lrowind = np.ascontiguousarray(Lrowind, dtype=np.int32)
+        self.Lnzval_off = np.asarray(Lnzval_off, dtype=np.int64)
+        self.Lnzval = np.array(Lnzval, dtype=np.float64)
+        self.Ufstnz_off = np.asarray(Ufstnz_off, dtype=np.int64)
+        self.Ufstnz = np.ascontiguousarray(Ufstnz, dtype=np.int32)
+        self.Unzval_off = np.asarray(Unzval_off, dtype=np.int64)
+        self.Unzval = np.array(Unzval, dtype=np.float64)
+        self.grid, self.coords = grid, coords
+        self._build_view()
+
+    @classmethod
+    def from_golden(cls, g, rank=0, which="pre"):
+        r = f"r{rank}__"
+        grid = (int(g[r + "Pr"][0]), int(g[r + "Pc"][0]), int(g[r + "Pz"][0]))
+        coords = (int(g[r + "myrow"][0]), int(g[r + "mycol"][0]), int(g[r + "myz"][0]))
+        return cls(int(g[r + "n"][0]), g[r + "xsup"], g[r + "Lrowind_off"], g[r + "Lrowind"], g[r + "Lnzval_off"],
+                   g[r + f"Lnzval_{which}"], g[r + "Ufstnz_off"], g[r + "Ufstnz"], g[r + "Unzval_off"],
+                   g[r + f"Unzval_{which}"], grid, coords)
+
+    def _build_view(self):
+        ns = self.nsupers
+
+        def ptrs(base, off, ctype, elem):
+            arr = (C.POINTER(ctype) * ns)()
+            addr = base.ctypes.data
+            for k in range(ns):
+                if off[k + 1] > off[k]:
+                    arr[k] = C.cast(addr + int(off[k]) * elem, C.POINTER(ctype))
+            return arr
+        self._lp = ptrs(self.Lrowind, self.Lrowind_off, C.c_int32, 4)
+        self._lv = ptrs(self.Lnzval, self.Lnzval_off, C.c_double, 8)
+        self._up = ptrs(self.Ufstnz, self.Ufstnz_off, C.c_int32, 4)
+        self._uv = ptrs(self.Unzval, self.Unzval_off, C.c_double, 8)
+        v = LUView()
+        v.n, v.nsupers, v.xsup = self.n, ns, _pi(self.xsup)
+        v.nprow, v.npcol, v.npdep = self.grid
+        v.myrow, v.mycol, v.myzlayer = self.coords
+        v.Lrowind_bc_ptr = C.cast(self._lp, C.POINTER(P_int))
+        v.Lnzval_bc_ptr = C.cast(self._lv, C.POINTER(P_dbl))
+        v.Ufstnz_br_ptr = C.cast(self._up, C.POINTER(P_int))
+        v.Unzval_br_ptr = C.cast(self._uv, C.POINTER(P_dbl))
+        self.view = v
+
+
+class Symbolic:
+    """sluamd_dsymbfact result (our symbfact_dist + pddistribute3d stand-in for a 1x1 layer)."""
+
+    def __init__(self, n, rowptr, colind, perm_c=None, relax=32, maxsup=256):
+        L = _lib.load()
+        self.n = int(n)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        self.colind = np.ascontiguousarray(colind, dtype=np.int32)
+        self.perm_c = np.empty(self.n, dtype=np.int32)
+        pin = None if perm_c is None else np.ascontiguousarray(perm_c, dtype=np.int32)
+        self._h = C.c_void_p()
+        _lib.check(L.sluamd_dsymbfact(C.byref(self._h), self.n, _pi(self.rowptr), _pi(self.colind),
+                                      None if pin is None else _pi(pin), relax, maxsup, _pi(self.perm_c)), "sluamd_dsymbfact")
+        ns = C.c_int32(); nl = C.c_int64(); nu = C.c_int64(); li = C.c_int64(); ui = C.c_int64(); fl = C.c_double()
+        L.sluamd_symb_info(self._h, C.byref(ns), C.byref(nl), C.byref(nu), C.byref(li), C.byref(ui), C.byref(fl))
+        self.nsupers, self.nnzL, self.nnzU, self.flops = ns.value, nl.value, nu.value, fl.value
+        self.lidx_len, self.uidx_len = li.value, ui.value
+
+    def distribute_host(self, nzval):
+        L = _lib.load()
+        nz = np.ascontiguousarray(nzval, dtype=np.float64)
+        _lib.check(L.sluamd_ddistribute_host(self._h, _pi(self.rowptr), _pi(self.colind), _pd(nz), _pi(self.perm_c)),
+                   "sluamd_ddistribute_host")
+
+    def flat_store(self):
+        """Copy the host store out as a FlatStore (small problems / tests only)."""
+        L = _lib.load()
+        v = LUView()
+        _lib.check(L.sluamd_symb_view(self._h, C.byref(v)), "sluamd_symb_view")
+        ns = v.nsupers
+        xsup = np.ctypeslib.as_array(v.xsup, shape=(ns + 1,)).copy()
+        lo = [0]; lvo = [0]; uo = [0]; uvo = [0]; li = []; lv = []; ui = []; uv = []
+        for k in range(ns):
+            p = v.Lrowind_bc_ptr[k]
+            nb, nsupr = p[0], p[1]
+            ln = 2 + 2 * nb + nsupr
+            li.append(np.ctypeslib.as_array(p, shape=(ln,)).copy())
+            nv = nsupr * (xsup[k + 1] - xsup[k])
+            lv.append(np.ctypeslib.as_array(v.Lnzval_bc_ptr[k], shape=(nv,)).copy())
+            lo.append(lo[-1] + ln); lvo.append(lvo[-1] + nv)
+            q = v.Ufstnz_br_ptr[k]
+            if q:
+                ui.append(np.ctypeslib.as_array(q, shape=(q[2],)).copy())
+                uv.append(np.ctypeslib.as_array(v.Unzval_br_ptr[k], shape=(q[1],)).copy())
+                uo.append(uo[-1] + q[2]); uvo.append(uvo[-1] + q[1])
+            else:
+                uo.append(uo[-1]); uvo.append(uvo[-1])
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
+        return FlatStore(self.n, xsup, lo, cat(li, np.int32), lvo, cat(lv, np.float64), uo, cat(ui, np.int32), uvo,
+                         cat(uv, np.float64))
+
+    def free(self):
+        if self._h:
+            _lib.load().sluamd_symb_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class LUHandle:
+    """Device-resident L/U (sluamd_handle_t): dCreateLUgpuHandle / pdgstrf3d_LUv1 / dCopyLUGPU2Host /
+    dDestroyLUgpuHandle replacement (SRC/CplusplusFactor/LUgpuCHandle_interface_impl.cu:11-73)."""
+
+    def __init__(self, h, store=None):
+        self._h = h
+        self.store = store
+
+    @staticmethod
+    def _opts(replace_tiny=False, deterministic=False, device=-1):
+        o = Options()
+        _lib.load().sluamd_default_options(C.byref(o))
+        o.device = device; o.replace_tiny_pivot = int(replace_tiny); o.deterministic = int(deterministic)
+        return o
+
+    @classmethod
+    def from_store(cls, store, forests=None, **kw):
+        L = _lib.load()
+        h = C.c_void_p()
+        o = cls._opts(**kw)
+        fv = None
+        keep = None
+        if forests is not None:
+            fv, keep = _forest_view(forests)
+        _lib.check(L.sluamd_dCreateLUHandle(C.byref(h), C.byref(store.view), None if fv is None else C.byref(fv), C.byref(o)),
+                   "sluamd_dCreateLUHandle")
+        obj = cls(h, store)
+        obj._keep = keep
+        return obj
+
+    @classmethod
+    def from_symbolic(cls, symb, nzval, **kw):
+        L = _lib.load()
+        h = C.c_void_p()
+        o = cls._opts(**kw)
+        nz = np.ascontiguousarray(nzval, dtype=np.float64)
+        _lib.check(L.sluamd_dCreateLUHandleFromSymb(C.byref(h), symb._h, _pi(symb.rowptr), _pi(symb.colind), _pd(nz),
+                                                    _pi(symb.perm_c), C.byref(o)), "sluamd_dCreateLUHandleFromSymb")
+        return cls(h, None)
+
+    def set_values(self, store):
+        _lib.check(_lib.load().sluamd_dSetValues(self._h, C.byref(store.view)), "sluamd_dSetValues")
+
+    def pdgstrf3d(self, thresh=0.0):
+        info = C.c_int32(0)
+        _lib.check(_lib.load().sluamd_pdgstrf3d(self._h, float(thresh), C.byref(info)), "sluamd_pdgstrf3d")
+        return info.value
+
+    def copy_to_host(self, store=None):
+        store = store or self.store
+        _lib.check(_lib.load().sluamd_dCopyLU2Host(self._h, C.byref(store.view)), "sluamd_dCopyLU2Host")
+        return store
+
+    def pdgstrs3d(self, x):
+        x = np.asfortranarray(np.array(x, dtype=np.float64))
+        if x.ndim == 1:
+            x = np.asfortranarray(x[:, None])
+        _lib.check(_lib.load().sluamd_pdgstrs3d(self._h, _pd(x), x.shape[0], x.shape[1]), "sluamd_pdgstrs3d")
+        return x
+
+    def pdgstrs3d_dev(self, ptr, ldx, nrhs):
+        _lib.check(_lib.load().sluamd_pdgstrs3d_dev(self._h, C.c_void_p(ptr), ldx, nrhs), "sluamd_pdgstrs3d_dev")
+
+    def stats(self):
+        s = Stats()
+        _lib.load().sluamd_get_stats(self._h, C.byref(s))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def destroy(self):
+        if self._h:
+            _lib.load().sluamd_dDestroyLUHandle(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _forest_view(forests):
+    """forests = dict(maxLvl, myTreeIdxs, myZeroTrIdxs, nodeLists=[array or None per forest])"""
+    fv = ForestView()
+    mt = np.ascontiguousarray(forests["myTreeIdxs"], dtype=np.int32)
+    mz = np.ascontiguousarray(forests["myZeroTrIdxs"], dtype=np.int32)
+    lists = [np.ascontiguousarray(a if a is not None else [], dtype=np.int32) for a in forests["nodeLists"]]
+    nn = np.array([len(a) for a in lists], dtype=np.int32)
+    arr = (P_int * len(lists))()
+    for i, a in enumerate(lists):
+        arr[i] = _pi(a) if len(a) else None
+    fv.maxLvl = int(forests["maxLvl"]); fv.myTreeIdxs = _pi(mt); fv.myZeroTrIdxs = _pi(mz)
+    fv.numForests = len(lists); fv.nNodes = _pi(nn); fv.nodeList = C.cast(arr, C.POINTER(P_int))
+    return fv, (mt, mz, lists, nn, arr)
+
+
+def pdgssvx3d(n, rowptr, colind, nzval, b, perm_c=None, relax=32, maxsup=256, replace_tiny=False, anorm=None,
+              keep=False):
+    """Solve A x = b through the GPU hot path: symbolic (host) -> device-resident distribute -> pdgstrf3d ->
+    pdgstrs3d, with Equil = NO, RowPerm = NOROWPERM, ColPerm = MY_PERMC/NATURAL, IterRefine = NOREFINE
+    (the timing configuration of BASELINE.md section 4).  Returns (x, info, stats[, handle, symb])."""
+    symb = Symbolic(n, rowptr, colind, perm_c, relax, maxsup)
+    h = LUHandle.from_symbolic(symb, nzval, replace_tiny=replace_tiny)
+    if anorm is None:
+        rp = np.asarray(rowptr)
+        anorm = float(np.max(np.add.reduceat(np.abs(nzval), rp[:-1]))) if len(nzval) else 0.0
+    thresh = float(np.finfo(np.float32).eps) * anorm          # pdgstrf3d.c:132-133 (single-precision epsilon)
+    info = h.pdgstrf3d(thresh)
+    b = np.asfortranarray(np.array(b, dtype=np.float64))
+    if b.ndim == 1:
+        b = np.asfortranarray(b[:, None])
+    xp = np.zeros_like(b, order="F")
+    xp[symb.perm_c, :] = b                                     # Pc*b
+    y = h.pdgstrs3d(xp)
+    x = np.asfortranarray(y[symb.perm_c, :])                   # Pc^T y
+    st = h.stats()
+    if keep:
+        return x, info, st, h, symb
+    h.destroy(); symb.free()
+    return x, info, st

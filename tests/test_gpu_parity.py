@@ -1,0 +1,134 @@
+"""Parity of the HIP hot path (through the C ABI) against the golden fixtures recorded from the real reference
+and against the CPU oracle.  Tolerances: L/U values 1e-12*||A||_max (summation order differs from the CPU loop:
+MFMA k-blocking + fp64 atomics), solutions 1e-10 relative (BASELINE.json north_star)."""
+import os
+import numpy as np
+import pytest
+import oracle as orc
+from superlu_dist_amd import _lib, driver, matgen
+
+pytestmark = pytest.mark.gpu
+
+CASES_1RANK = ["g20_1x1x1", "g20_1x1x1_nrhs3", "poisson8_nd", "poisson10_nd", "unsym300", "unsym120_tiny"]
+
+
+def test_mfma_f64_fragment_layout():
+    import ctypes as C
+    L = _lib.load()
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((16, 4)); B = rng.standard_normal((4, 16))   # asymmetric on purpose
+    D = np.zeros((16, 16))
+    Ac, Bc = np.ascontiguousarray(A), np.ascontiguousarray(B)
+    rc = L.sluamd_mfma_selftest(Ac.ctypes.data_as(_lib.P_dbl), Bc.ctypes.data_as(_lib.P_dbl), D.ctypes.data_as(_lib.P_dbl))
+    assert rc == 0
+    assert np.abs(D - A @ B).max() < 1e-13
+
+
+def _factor(g, deterministic=False):
+    st = driver.FlatStore.from_golden(g, 0, "pre")
+    h = driver.LUHandle.from_store(st, replace_tiny=bool(g["r0__ReplaceTinyPivot"][0]), deterministic=deterministic)
+    info = h.pdgstrf3d(float(g["r0__thresh"][0]))
+    h.copy_to_host()
+    return st, h, info
+
+
+@pytest.mark.parametrize("case", CASES_1RANK)
+def test_factor_matches_reference(golden, case):
+    g = golden(case)
+    st, h, info = _factor(g)
+    assert info == int(g["r0__info"][0])
+    assert h.stats()["tiny_pivots"] == int(g["r0__TinyPivots"][0])
+    scale = max(np.abs(g["r0__Lnzval_pre"]).max(), np.abs(g["r0__Unzval_pre"]).max())
+    assert np.abs(st.Lnzval - g["r0__Lnzval_post"]).max() <= 1e-12 * scale
+    assert np.abs(st.Unzval - g["r0__Unzval_post"]).max() <= 1e-12 * scale
+    # and against the CPU oracle on the same input
+    o = orc.LUStore.from_golden(g, 0, "pre")
+    orc.dfactor(o, g["r0__forest0_nodeList"], bool(g["r0__ReplaceTinyPivot"][0]), float(g["r0__thresh"][0]))
+    assert np.abs(st.Lnzval - o.Lnzval).max() <= 1e-12 * scale
+    assert np.abs(st.Unzval - o.Unzval).max() <= 1e-12 * scale
+    h.destroy()
+
+
+@pytest.mark.parametrize("case", CASES_1RANK)
+def test_solve_matches_reference(golden, case):
+    g = golden(case)
+    st, h, info = _factor(g)
+    n = st.n
+    pr, pc = g["r0__perm_r"], g["r0__perm_c"]
+    s = 0
+    while f"r0__solve{s}_B_in" in g:
+        nrhs = int(g[f"r0__solve{s}_nrhs"][0])
+        B = g[f"r0__solve{s}_B_in"].reshape((n, nrhs), order="F")
+        X = g[f"r0__solve{s}_B_out"].reshape((n, nrhs), order="F")
+        xp = np.zeros((n, nrhs), order="F"); xp[pc[pr], :] = B
+        got = h.pdgstrs3d(xp)
+        assert np.abs(got - X).max() <= 1e-10 * max(1.0, np.abs(X).max())
+        s += 1
+    assert s >= 1
+    h.destroy()
+
+
+def test_deterministic_mode_is_bitwise_reproducible(golden):
+    g = golden("poisson10_nd")
+    a, h1, _ = _factor(g, deterministic=True)
+    b, h2, _ = _factor(g, deterministic=True)
+    assert np.array_equal(a.Lnzval, b.Lnzval) and np.array_equal(a.Unzval, b.Unzval)
+    h1.destroy(); h2.destroy()
+
+
+def test_refactor_same_pattern(golden):
+    g = golden("unsym300")
+    st, h, _ = _factor(g)
+    first = st.Lnzval.copy()
+    st2 = driver.FlatStore.from_golden(g, 0, "pre")
+    h.set_values(st2)
+    h.pdgstrf3d(float(g["r0__thresh"][0]))
+    h.copy_to_host(st2)
+    scale = np.abs(g["r0__Lnzval_pre"]).max()
+    assert np.abs(st2.Lnzval - first).max() <= 1e-12 * scale
+    h.destroy()
+
+
+def test_zero_pivot_reports_info():
+    # 2x2 block of zeros on the diagonal -> exact zero pivot at column 1 (1-based), pdgstrf2.c:568-571
+    n = 4
+    rp = np.array([0, 2, 4, 6, 8], dtype=np.int32)
+    ci = np.array([0, 1, 0, 1, 2, 3, 2, 3], dtype=np.int32)
+    v = np.array([0.0, 1.0, 1.0, 0.0, 2.0, 1.0, 1.0, 2.0])
+    symb = driver.Symbolic(n, rp, ci, None, relax=1, maxsup=4)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    info = h.pdgstrf3d(0.0)
+    assert info == 1
+    h.destroy()
+
+
+@pytest.mark.parametrize("N,leaf,relax,maxsup,nrhs", [(8, 16, 16, 64, 1), (12, 27, 32, 128, 3), (16, 64, 64, 256, 1)])
+def test_own_pipeline_poisson_residual(N, leaf, relax, maxsup, nrhs):
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, nrhs)
+    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=relax, maxsup=maxsup)
+    assert info == 0
+    res = np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b)
+    assert res < 1e-10
+    assert np.abs(x - xt).max() < 1e-9
+    # CPU oracle on the same store: solutions agree to 1e-10
+    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+    symb.distribute_host(v)
+    fs = symb.flat_store()
+    o = orc.LUStore(fs.n, fs.xsup, fs.Lrowind_off, fs.Lrowind, fs.Lnzval_off, fs.Lnzval, fs.Ufstnz_off, fs.Ufstnz,
+                    fs.Unzval_off, fs.Unzval)
+    orc.dfactor(o)
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    xo = orc.dsolve(o, xp)[symb.perm_c, :]
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+
+
+def test_valu_fallback_kernel_agrees(golden, monkeypatch):
+    g = golden("poisson8_nd")
+    a, h1, _ = _factor(g)
+    monkeypatch.setenv("SLUAMD_NO_MFMA", "1")
+    b, h2, _ = _factor(g)
+    scale = np.abs(g["r0__Lnzval_pre"]).max()
+    assert np.abs(a.Lnzval - b.Lnzval).max() <= 1e-12 * scale
+    h1.destroy(); h2.destroy()
