@@ -155,7 +155,20 @@ int sluamd_ddistribute_host(sluamd_symb_t s, const sluamd_int_t *rowptr, const s
 int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
                                    const sluamd_int_t *colind, const double *nzval,
                                    const sluamd_int_t *perm_c_final, const sluamd_options_t *opt);
+/* copy the store out as flat arrays + offsets (any pointer may be NULL) */
+int sluamd_symb_export(sluamd_symb_t s, sluamd_int_t *xsup, int64_t *lidx_off, sluamd_int_t *lidx, int64_t *lval_off,
+                       double *lval, int64_t *uidx_off, sluamd_int_t *uidx, int64_t *uval_off, double *uval);
 void sluamd_symb_free(sluamd_symb_t s);
+/* re-run the device-side distribution (zero-fill + scatter of A) on such a handle: refactor loops */
+int sluamd_dResetValues(sluamd_handle_t h);
+
+/* ---- auxiliary (timing / multi-rank orchestration / tests) ---- */
+int sluamd_device_synchronize(void);
+int sluamd_set_profile(sluamd_handle_t h, int on);         /* per-kernel-family HIP-event timing in stats */
+int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh); /* one Z level of pdgstrf3d.c:333-385 */
+int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny_pivots);
+int sluamd_arena(sluamd_handle_t h, double **d_val, int64_t *nnzL, int64_t *nnzU); /* value arena [L | U] in HBM */
+int sluamd_mfma_selftest(const double *A16x4, const double *B4x16, double *D16x16);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ static int g_solve_count = 0;
 
 static void put(const char *name, int dtype, long long count, const void *data)
 {
+    if (!g_out) return;            /* -o none: timing run, nothing recorded */
     int nl = (int) strlen(name);
     size_t esz = dtype == 0 ? 4 : 8;
     fwrite(&nl, 4, 1, g_out);
@@ -153,9 +154,9 @@ int_t __wrap_pdgstrf3d(superlu_dist_options_t *options, int m, int n, double ano
         snprintf(nm, sizeof nm, "forest%d_eTreeTopLims", f);
         put_intt(nm, sf->topoInfo.numLvl + 1, sf->topoInfo.eTreeTopLims);
     }
-    dump_lu("pre", LUstruct, grid, 0);
+    if (g_out) dump_lu("pre", LUstruct, grid, 0);
     int_t r = __real_pdgstrf3d(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
-    dump_lu("post", LUstruct, grid, 1);
+    if (g_out) dump_lu("post", LUstruct, grid, 1);
     put_i("info", *info);
     put_i("TinyPivots", stat->TinyPivots);
     put_d("ops_fact_float", (double) stat->ops[FACT]);
@@ -176,6 +177,7 @@ static void dump_solve(const char *which, int_t n, dScalePermstruct_t *SP, doubl
             put("perm_c", 0, n, SP->perm_c);
         }
     }
+    if (!g_out) return;
     double *buf = (double *) malloc(8 * (size_t) (m_loc * nrhs + 1));
     for (int j = 0; j < nrhs; ++j)
         for (int_t i = 0; i < m_loc; ++i) buf[i + j * m_loc] = B[i + j * ldb];
@@ -270,8 +272,10 @@ int main(int argc, char *argv[])
     {
         char fn[512];
         snprintf(fn, sizeof fn, "%s.r%d.slud", outp, grid.iam);
-        g_out = fopen(fn, "wb");
-        if (!g_out) { fprintf(stderr, "cannot open %s\n", fn); exit(2); }
+        if (strcmp(outp, "none") != 0) {
+            g_out = fopen(fn, "wb");
+            if (!g_out) { fprintf(stderr, "cannot open %s\n", fn); exit(2); }
+        }
     }
     dcreate_matrix_postfix3d(&A, nrhs, &b, &ldb, &xtrue, &ldx, fp, suffix, &grid);
     if (!(berr = doubleMalloc_dist(nrhs))) ABORT("Malloc fails for berr[].");
@@ -324,7 +328,7 @@ int main(int argc, char *argv[])
     else if (!quiet) pdinf_norm_error(grid.iam, ((NRformat_loc *) A.Store)->m_loc, nrhs, b, ldb, xtrue, ldx, grid.comm);
     if (grid.zscp.Iam == 0 && !quiet) PStatPrint(&options, &stat, &(grid.grid2d));
     if (!grid.iam) printf("REFTIMES n %ld FACT %.6f s SOLVE %.6f s ops_FACT %.6e\n", (long) n, stat.utime[FACT], stat.utime[SOLVE], (double) stat.ops[FACT]);
-    fclose(g_out);
+    if (g_out) fclose(g_out);
     fclose(fp);
 out:
     superlu_gridexit3d(&grid);

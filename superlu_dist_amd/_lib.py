@@ -67,6 +67,8 @@ def load():
     L.sluamd_symb_view.argtypes = [C.c_void_p, C.POINTER(LUView)]
     L.sluamd_ddistribute_host.argtypes = [C.c_void_p, P_int, P_int, P_dbl, P_int]
     L.sluamd_symb_free.argtypes = [C.c_void_p]
+    P64 = C.POINTER(C.c_int64)
+    L.sluamd_symb_export.argtypes = [C.c_void_p, P_int, P64, P_int, P64, P_dbl, P64, P_int, P64, P_dbl]
     L.sluamd_dCreateLUHandle.argtypes = [C.POINTER(C.c_void_p), C.POINTER(LUView), C.POINTER(ForestView), C.POINTER(Options)]
     L.sluamd_dCreateLUHandleFromSymb.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int, C.POINTER(Options)]
     L.sluamd_dSetValues.argtypes = [C.c_void_p, C.POINTER(LUView)]
@@ -80,6 +82,8 @@ def load():
     L.sluamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.sluamd_arena.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sluamd_mfma_selftest.argtypes = [P_dbl, P_dbl, P_dbl]
+    L.sluamd_dResetValues.argtypes = [C.c_void_p]
+    L.sluamd_set_profile.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 

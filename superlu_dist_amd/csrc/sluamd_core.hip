@@ -99,6 +99,10 @@ struct Handle {
     hipStream_t stream = nullptr;
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
     double *d_x = nullptr; int64_t x_cap = 0;
+    int64_t *d_apos = nullptr; double *d_aval = nullptr; int64_t a_nnz = 0;  // A's entries for device-side (re)distribution
+    bool profile = false;                                   // per-kernel-family HIP-event timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
+    size_t ev_schur_used = 0, ev_panel_used = 0;
     sluamd_stats_t st{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // host tables kept for stats
@@ -800,14 +804,35 @@ static int check_device(int dev)
 // ================================================================================================
 //                                   HOST: factorisation driver
 // ================================================================================================
+static void ev_begin(Handle *H, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t &used)
+{
+    if (!H->profile) return;
+    if (used == v.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); v.emplace_back(a, b); }
+    hipEventRecord(v[used].first, H->stream);
+}
+static void ev_end(Handle *H, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t &used)
+{
+    if (!H->profile) return;
+    hipEventRecord(v[used].second, H->stream);
+    ++used;
+}
+static double ev_sum(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t used)
+{
+    double tot = 0;
+    for (size_t i = 0; i < used; ++i) { float ms = 0; hipEventElapsedTime(&ms, v[i].first, v[i].second); tot += ms; }
+    return tot;
+}
+
 static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
 {
     const bool use_mfma = getenv("SLUAMD_NO_MFMA") == nullptr;
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
     auto schur = [&](int grid, const int *nodes, const int *prefix, int nn, int id_base) {
+        ev_begin(H, H->ev_schur, H->ev_schur_used);
         if (use_mfma) hipLaunchKernelGGL(k_schur<true>, dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, H->d_info);
         else hipLaunchKernelGGL(k_schur<false>, dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, H->d_info);
+        ev_end(H, H->ev_schur, H->ev_schur_used);
         H->st.num_launches++; H->st.schur_launches++;
     };
     for (int l = 0; l < S.nlevels; ++l) {
@@ -816,10 +841,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int mx = S.max_nsupc[l];
         const int lds_ns = (mx <= 128) ? mx : 128;
         const size_t lds = (size_t) lds_ns * (lds_ns | 1) * sizeof(double);
+        ev_begin(H, H->ev_panel, H->ev_panel_used);
         hipLaunchKernelGGL(k_diag_lu, dim3(nn), dim3(256), lds, s, T, nodes, lds_ns, H->opt.replace_tiny_pivot, thresh, H->d_info);
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
         if (nl) hipLaunchKernelGGL(k_lpanel_trsm, dim3(nl), dim3(64), 0, s, T, nodes, S.d_ltr_prefix + po, nn);
         if (nu) hipLaunchKernelGGL(k_upanel_trsm, dim3(nu), dim3(64), 0, s, T, nodes, S.d_utr_prefix + po, nn);
+        ev_end(H, H->ev_panel, H->ev_panel_used);
         H->st.num_launches += 1 + (nl > 0) + (nu > 0);
         const int nt = S.tile_prefix[po + nn];
         if (!nt) continue;
@@ -960,6 +987,8 @@ int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info)
     int init[4] = {0x7fffffff, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
     H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
+    H->profile = H->opt.verbose >= 2 || getenv("SLUAMD_PROFILE") != nullptr;
+    H->ev_schur_used = H->ev_panel_used = 0;
     HIPCHK(hipEventRecord(H->ev0, H->stream));
     // Z levels in order (pdgstrf3d.c:333-385); the ancestor reduction between levels is the caller's
     // collective (RCCL reduce on the arena slice) in a multi-rank run.
@@ -973,6 +1002,8 @@ int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info)
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
+    H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
+    H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
     H->st.tiny_pivots = res[1];
     if (info) *info = (res[0] == 0x7fffffff) ? 0 : res[0];
     if (res[2]) { set_error("Schur update found no destination block for " + std::to_string(res[2]) + " tiles (structure not closed)"); return SLUAMD_ESTRUCT; }
@@ -1074,6 +1105,10 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_val) hipFree(H->d_val);
     if (H->d_info) hipFree(H->d_info);
     if (H->d_x) hipFree(H->d_x);
+    if (H->d_apos) hipFree(H->d_apos);
+    if (H->d_aval) hipFree(H->d_aval);
+    for (auto &e : H->ev_schur) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : H->ev_panel) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (H->ev0) hipEventDestroy(H->ev0);
     if (H->ev1) hipEventDestroy(H->ev1);
     if (H->stream) hipStreamDestroy(H->stream);
@@ -1124,18 +1159,44 @@ int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const 
         compute_scatter_positions(*sy, hs.n, rowptr, colind, perm_c_final, pos, isu);
         const int64_t nnz = (int64_t) pos.size();
         for (int64_t e = 0; e < nnz; ++e) if (isu[e]) pos[e] += hs.nnzL;
-        int64_t *d_pos; double *d_a;
-        HIPCHK(hipMalloc((void **) &d_pos, sizeof(int64_t) * std::max<int64_t>(nnz, 1)));
-        HIPCHK(hipMalloc((void **) &d_a, sizeof(double) * std::max<int64_t>(nnz, 1)));
-        HIPCHK(hipMemcpy(d_pos, pos.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_a, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
-        if (nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, 0, H->d_val, d_pos, d_a, nnz);
+        HIPCHK(hipMalloc((void **) &H->d_apos, sizeof(int64_t) * std::max<int64_t>(nnz, 1)));
+        HIPCHK(hipMalloc((void **) &H->d_aval, sizeof(double) * std::max<int64_t>(nnz, 1)));
+        H->a_nnz = nnz;
+        HIPCHK(hipMemcpy(H->d_apos, pos.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(H->d_aval, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        if (nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, 0, H->d_val, H->d_apos, H->d_aval, nnz);
         HIPCHK(hipDeviceSynchronize());
-        hipFree(d_pos); hipFree(d_a);
     }
     rc = finish_create(H, nullptr);
     if (rc) { sluamd_dDestroyLUHandle(hh); return rc; }
     *out = hh;
+    return 0;
+}
+
+// Device-side re-distribution of A's values into the resident store (handles made by
+// sluamd_dCreateLUHandleFromSymb): zero-fill + scatter, asynchronous on the handle's stream.
+int sluamd_dResetValues(sluamd_handle_t h)
+{
+    if (!h || !h->H.d_apos) { set_error("handle has no device-side copy of A"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    HIPCHK(hipMemsetAsync(H->d_val, 0, sizeof(double) * (H->hs.nnzL + H->hs.nnzU), H->stream));
+    if (H->a_nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((H->a_nnz + 255) / 256)), dim3(256), 0, H->stream,
+                                     H->d_val, H->d_apos, H->d_aval, H->a_nnz);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int sluamd_device_synchronize(void)
+{
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+int sluamd_set_profile(sluamd_handle_t h, int on)
+{
+    if (!h) return SLUAMD_EINVAL;
+    h->H.opt.verbose = on ? 2 : 0;
     return 0;
 }
 

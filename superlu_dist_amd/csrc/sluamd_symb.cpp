@@ -8,6 +8,7 @@
 // sp_ienv_dist(3).  The algorithm is our own: elimination tree of A+A^T (Liu), postorder composed into
 // perm_c (as sp_colorder does), supernodal structure by child-structure union.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include "sluamd_internal.h"
@@ -56,6 +57,8 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     if (maxsup > 512) maxsup = 512;  // MAX_SUPER_SIZE, superlu_defs.h:154
     if (relax < 1) relax = 1;
     if (relax > maxsup) relax = maxsup;
+    double amalg_frac = 0.05;  // tolerated explicit-zero fraction when amalgamating along etree chains
+    if (const char *e = getenv("SLUAMD_AMALG_FRAC")) amalg_frac = atof(e);
     std::vector<int> perm(n);
     if (perm_c) std::copy(perm_c, perm_c + n, perm.begin()); else std::iota(perm.begin(), perm.end(), 0);
     {   // validate permutation
@@ -136,11 +139,29 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
         } else {
             b = a;
             add_adj(a); add_children_of(a);
-            while (b + 1 < n && (b - a + 1) < maxsup && parent[b] == b + 1 && nchild[b + 1] == 1 && relax_end[b + 1] < 0) {
+            // extend the supernode by column c = b+1 (its etree parent) while struct(c) ~= struct(b) \ {c}.
+            // Non-fundamental supernodes are allowed (other children of c may hang anywhere), and so is a small
+            // amount of explicit-zero padding (relaxed amalgamation): where two ND separators meet, every
+            // separator column brings ONE private row of the ancestor separator, which would otherwise shatter
+            // the separator into singleton supernodes.
+            double zacc = 0;
+            std::vector<int> extra;
+            while (b + 1 < n && (b - a + 1) < maxsup && parent[b] == b + 1 && relax_end[b + 1] < 0) {
                 const int c = b + 1;
-                bool sub = true;
-                for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1] && sub; ++e) sub = (mark[g.lo[e]] == u);
-                if (!sub) break;
+                extra.clear();
+                for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != u) { mark[r] = u; extra.push_back(r); } }
+                for (int cu = pend_head[c]; cu != -1; cu = pend_next[cu])
+                    for (int64_t e = sy->srow_off[cu]; e < sy->srow_off[cu + 1]; ++e) {
+                        const int r = sy->srows[e];
+                        if (r > c && mark[r] != u) { mark[r] = u; extra.push_back(r); }
+                    }
+                const double cols = c - a, rows = (double) cur.size();
+                const double znew = zacc + (double) extra.size() * cols;
+                const bool ok = extra.empty() ||
+                                ((double) extra.size() <= amalg_frac * rows + 2.0 && znew <= 2.0 * amalg_frac * rows * (cols + 1) + 16.0);
+                if (!ok) { for (int r : extra) mark[r] = -1; break; }
+                zacc = znew;
+                cur.insert(cur.end(), extra.begin(), extra.end());
                 b = c;
             }
         }
@@ -267,6 +288,26 @@ int sluamd_ddistribute_host(sluamd_symb_t s, const sluamd_int_t *rowptr, const s
     std::vector<int64_t> pos; std::vector<uint8_t> isu;
     compute_scatter_positions(*sy, hs.n, rowptr, colind, perm_c_final ? perm_c_final : sy->perm_c_final.data(), pos, isu);
     for (size_t e = 0; e < pos.size(); ++e) (isu[e] ? sy->uval : sy->lval)[pos[e]] = nzval[e];
+    return 0;
+}
+
+/* copy the store out as flat arrays (any pointer may be NULL) -- test / baseline harness helper */
+int sluamd_symb_export(sluamd_symb_t s, sluamd_int_t *xsup, int64_t *lidx_off, sluamd_int_t *lidx, int64_t *lval_off,
+                       double *lval, int64_t *uidx_off, sluamd_int_t *uidx, int64_t *uval_off, double *uval)
+{
+    if (!s) return SLUAMD_EINVAL;
+    Symb *sy = reinterpret_cast<Symb *>(s);
+    const HostStruct &hs = sy->hs;
+    const size_t ns1 = (size_t) hs.nsupers + 1;
+    if (xsup) std::memcpy(xsup, hs.xsup.data(), ns1 * sizeof(int));
+    if (lidx_off) std::memcpy(lidx_off, hs.lidx_off.data(), ns1 * sizeof(int64_t));
+    if (lval_off) std::memcpy(lval_off, hs.lval_off.data(), ns1 * sizeof(int64_t));
+    if (uidx_off) std::memcpy(uidx_off, hs.uidx_off.data(), ns1 * sizeof(int64_t));
+    if (uval_off) std::memcpy(uval_off, hs.uval_off.data(), ns1 * sizeof(int64_t));
+    if (lidx) std::memcpy(lidx, hs.lidx.data(), hs.lidx.size() * sizeof(int));
+    if (uidx) std::memcpy(uidx, hs.uidx.data(), hs.uidx.size() * sizeof(int));
+    if (lval) { if (sy->lval.size() != (size_t) hs.nnzL) { set_error("no host values: call sluamd_ddistribute_host first"); return SLUAMD_EINVAL; } std::memcpy(lval, sy->lval.data(), hs.nnzL * sizeof(double)); }
+    if (uval) { if (sy->uval.size() != (size_t) hs.nnzU) { set_error("no host values: call sluamd_ddistribute_host first"); return SLUAMD_EINVAL; } std::memcpy(uval, sy->uval.data(), hs.nnzU * sizeof(double)); }
     return 0;
 }
 

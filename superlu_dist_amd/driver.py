@@ -97,32 +97,22 @@ class Symbolic:
         _lib.check(L.sluamd_ddistribute_host(self._h, _pi(self.rowptr), _pi(self.colind), _pd(nz), _pi(self.perm_c)),
                    "sluamd_ddistribute_host")
 
-    def flat_store(self):
-        """Copy the host store out as a FlatStore (small problems / tests only)."""
+    def flat_store(self, values=True):
+        """Copy the host store out as a FlatStore (tests / CPU-baseline harness)."""
         L = _lib.load()
-        v = LUView()
-        _lib.check(L.sluamd_symb_view(self._h, C.byref(v)), "sluamd_symb_view")
-        ns = v.nsupers
-        xsup = np.ctypeslib.as_array(v.xsup, shape=(ns + 1,)).copy()
-        lo = [0]; lvo = [0]; uo = [0]; uvo = [0]; li = []; lv = []; ui = []; uv = []
-        for k in range(ns):
-            p = v.Lrowind_bc_ptr[k]
-            nb, nsupr = p[0], p[1]
-            ln = 2 + 2 * nb + nsupr
-            li.append(np.ctypeslib.as_array(p, shape=(ln,)).copy())
-            nv = nsupr * (xsup[k + 1] - xsup[k])
-            lv.append(np.ctypeslib.as_array(v.Lnzval_bc_ptr[k], shape=(nv,)).copy())
-            lo.append(lo[-1] + ln); lvo.append(lvo[-1] + nv)
-            q = v.Ufstnz_br_ptr[k]
-            if q:
-                ui.append(np.ctypeslib.as_array(q, shape=(q[2],)).copy())
-                uv.append(np.ctypeslib.as_array(v.Unzval_br_ptr[k], shape=(q[1],)).copy())
-                uo.append(uo[-1] + q[2]); uvo.append(uvo[-1] + q[1])
-            else:
-                uo.append(uo[-1]); uvo.append(uvo[-1])
-        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
-        return FlatStore(self.n, xsup, lo, cat(li, np.int32), lvo, cat(lv, np.float64), uo, cat(ui, np.int32), uvo,
-                         cat(uv, np.float64))
+        ns = self.nsupers
+        xsup = np.empty(ns + 1, dtype=np.int32)
+        lo = np.empty(ns + 1, dtype=np.int64); lvo = np.empty(ns + 1, dtype=np.int64)
+        uo = np.empty(ns + 1, dtype=np.int64); uvo = np.empty(ns + 1, dtype=np.int64)
+        li = np.empty(self.lidx_len, dtype=np.int32); ui = np.empty(self.uidx_len, dtype=np.int32)
+        lv = np.zeros(self.nnzL if values else 0); uv = np.zeros(self.nnzU if values else 0)
+        P64 = C.POINTER(C.c_int64)
+        p64 = lambda a: a.ctypes.data_as(P64)
+        _lib.check(L.sluamd_symb_export(self._h, _pi(xsup), p64(lo), _pi(li), p64(lvo), _pd(lv) if values else None,
+                                        p64(uo), _pi(ui), p64(uvo), _pd(uv) if values else None), "sluamd_symb_export")
+        if not values:
+            lv = np.zeros(self.nnzL); uv = np.zeros(self.nnzU)
+        return FlatStore(self.n, xsup, lo, li, lvo, lv, uo, ui, uvo, uv)
 
     def free(self):
         if self._h:
@@ -198,6 +188,12 @@ class LUHandle:
 
     def pdgstrs3d_dev(self, ptr, ldx, nrhs):
         _lib.check(_lib.load().sluamd_pdgstrs3d_dev(self._h, C.c_void_p(ptr), ldx, nrhs), "sluamd_pdgstrs3d_dev")
+
+    def reset_values(self):
+        _lib.check(_lib.load().sluamd_dResetValues(self._h), "sluamd_dResetValues")
+
+    def set_profile(self, on=True):
+        _lib.load().sluamd_set_profile(self._h, int(on))
 
     def stats(self):
         s = Stats()
