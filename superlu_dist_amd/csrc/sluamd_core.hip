@@ -5,8 +5,8 @@
 // directories, tile lists and an elimination-DAG level schedule.
 // Device side (hand-written HIP, wave64): per level of the schedule
 //     k_diag_lu      unpivoted LU of every diagonal block of the level   (Local_Dgstrf2, pdgstrf2.c:508)
-//     k_lpanel_trsm  L(:,k) <- L(:,k) U_kk^-1                            (dLPanelTrSolve, dtrfCommWrapper.c:120)
-//     k_upanel_trsm  U(k,:) <- L_kk^-1 U(k,:) directly on the skyline    (dTrs2_GatherTrsmScatter, pdgstrf2.c:804)
+//     k_panel_trsm<0> L(:,k) <- L(:,k) U_kk^-1                           (dLPanelTrSolve, dtrfCommWrapper.c:120)
+//     k_panel_trsm<1> U(k,:) <- L_kk^-1 U(k,:) directly on the skyline   (dTrs2_GatherTrsmScatter, pdgstrf2.c:804)
 //     k_schur        A(I,J) -= L(I,k) U(k,J): fused gather -> fp64 MFMA GEMM -> scatter, no bigU/bigV
 //                    round trip (dRgather_L/U dgather.c:133-398 + dblock_gemm_scatter dscatter3d.c:81-189
 //                    + dscatter_l dscatter.c:109 + scatter_u dscatter3d.c:555)
@@ -54,6 +54,8 @@ struct DevTables {
     const int64_t *sn_lval, *sn_uval;  // offsets into val
     const int64_t *sn_lidx, *sn_uidx;  // offsets into lidx / uidx
     const int *sn_nsupr;               // LDA of the L panel
+    double *dinv;                      // inverted 32x32 diagonal sub-blocks of U_kk and L_kk^T (workspace)
+    const int64_t *sn_dinv;            // offset of supernode k's blocks in dinv
     const int *sn_ldu;                 // max U segment height of block row k
     const int *sn_ncolu;               // total non-empty U columns of block row k
     const int *sn_lb_off, *sn_nlb;     // L block table range
@@ -77,12 +79,13 @@ struct LevelSched {
     std::vector<int> tile_prefix;   // per node (aligned with nodes), exclusive prefix WITHIN its level (+1 total slot per level)
     std::vector<int> ltr_prefix;    // L-TRSM strips
     std::vector<int> utr_prefix;    // U-TRSM column chunks
+    std::vector<int> inv_prefix;    // diagonal sub-block inversion tasks
     std::vector<int> lvl_poff;      // [nlevels+1] offset of each level's prefix arrays (size nodes_in_level+1)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
     std::vector<int> max_nsupc;     // per level
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
-    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr;
+    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr;
 };
 
 struct Handle {
@@ -113,6 +116,7 @@ struct Handle {
 // ================================================================================================
 //                                          KERNELS
 // ================================================================================================
+typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 64, TN = 64, KC = 16;
 constexpr int LDT = TM + 16;  // LDS row stride in doubles: == 16 mod 32 -> ds_read_b64 of a 16x4 fragment is conflict-free
 
@@ -131,10 +135,25 @@ __device__ __forceinline__ void atomic_sub_f64(double *p, double v)
     unsafeAtomicAdd(p, -v);  // global_atomic_add_f64 (hardware fp64 atomic on gfx950)
 }
 
-// ---- diagonal block LU -------------------------------------------------------------------------
-// One workgroup per supernode of the level.  Blocks with nsupc <= lds_max_ns are factored inside LDS,
-// larger ones in place in HBM/L2.  Arithmetic = right-looking rank-1 updates as Local_Dgstrf2.
-__global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restrict__ nodes, int lds_max_ns,
+// ---- diagonal block LU ----------------------------------------------------------------------------
+// One workgroup per supernode of the level.  Arithmetic = right-looking elimination without pivoting as
+// Local_Dgstrf2 (pdgstrf2.c:508-601; tiny-pivot replacement :544-560, zero-pivot info :568-571).
+//   ns <= 128 : whole block factored inside LDS (rank-1 updates).
+//   ns  > 128 : blocked by 32 columns: LDS-resident column panel, U12 = L11^-1 A12 per thread-column,
+//               rank-32 trailing update with the panel rows held in registers.
+// Afterwards the workgroup inverts the 32x32 diagonal sub-blocks of U_kk and of L_kk^T (unit) into
+// T.dinv; the panel TRSM kernels use them (block TRSM with inverted 32x32 diagonal blocks).
+constexpr int DB = 32;  // diagonal sub-block size
+
+__device__ __forceinline__ void pivot_fix(double *p, int col1based, int replace_tiny, double thresh, int *info, double *s_piv)
+{
+    double v = *p;
+    if (replace_tiny && fabs(v) < thresh) { v = (v < 0) ? -thresh : thresh; *p = v; atomicAdd(&info[1], 1); }
+    if (v == 0.0) atomicMin(&info[0], col1based);
+    *s_piv = v;
+}
+
+__global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restrict__ nodes,
                                                  int replace_tiny, double thresh, int *__restrict__ info)
 {
     extern __shared__ double s_a[];
@@ -144,92 +163,266 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
     const int lda = T.sn_nsupr[k];
     double *A = T.val + T.sn_lval[k];
     const int tid = threadIdx.x;
-    const bool in_lds = ns <= lds_max_ns;
-    const int ld = in_lds ? (ns | 1) : lda;  // odd stride in LDS
-    double *W = in_lds ? s_a : A;
-    if (in_lds) {
+    if (ns <= 128) {
+        const int ld = ns | 1;
         for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; s_a[i + j * ld] = A[i + (size_t) j * lda]; }
-    }
-    __syncthreads();
-    for (int j = 0; j < ns; ++j) {
-        if (tid == 0) {
-            double p = W[j + (size_t) j * ld];
-            if (replace_tiny && fabs(p) < thresh) { p = (p < 0) ? -thresh : thresh; W[j + (size_t) j * ld] = p; atomicAdd(&info[1], 1); }
-            if (p == 0.0) atomicMin(&info[0], fst + j + 1);
-            s_piv = p;
-        }
         __syncthreads();
-        const double p = s_piv;
-        const int m = ns - j - 1;
-        if (p != 0.0) {
-            const double r = 1.0 / p;
-            for (int i = tid; i < m; i += 256) W[j + 1 + i + (size_t) j * ld] *= r;
-        }
-        __syncthreads();
-        // trailing update: columns strided over waves, rows over lanes
-        for (int c = (tid >> 6); c < m; c += 4) {
-            const double u = W[j + (size_t) (j + 1 + c) * ld];
-            if (u != 0.0) {
-                double *col = W + (size_t) (j + 1 + c) * ld + j + 1;
-                const double *l = W + (size_t) j * ld + j + 1;
-                for (int i = (tid & 63); i < m; i += 64) col[i] -= l[i] * u;
+        for (int j = 0; j < ns; ++j) {
+            if (tid == 0) pivot_fix(&s_a[j + j * ld], fst + j + 1, replace_tiny, thresh, info, &s_piv);
+            __syncthreads();
+            const double p = s_piv;
+            const int m = ns - j - 1;
+            if (p != 0.0) {
+                const double r = 1.0 / p;
+                for (int i = tid; i < m; i += 256) s_a[j + 1 + i + j * ld] *= r;
             }
+            __syncthreads();
+            for (int c = (tid >> 6); c < m; c += 4) {
+                const double u = s_a[j + (j + 1 + c) * ld];
+                if (u != 0.0) {
+                    double *col = s_a + (j + 1 + c) * ld + j + 1;
+                    const double *l = s_a + j * ld + j + 1;
+                    for (int i = (tid & 63); i < m; i += 64) col[i] -= l[i] * u;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (in_lds) {
         for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; A[i + (size_t) j * lda] = s_a[i + j * ld]; }
+    } else {
+        // blocked path (128 < ns <= 256): Ps = column panel [c][r], Us = U12 block row [kk][c]
+        double *Ps = s_a;                       // DB x (ns|1)
+        const int ldp = ns | 1;
+        double *Us = s_a + DB * ldp;            // DB x ns
+        for (int jb = 0; jb < ns; jb += DB) {
+            const int nb = min(DB, ns - jb), m = ns - jb;
+            for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; Ps[c * ldp + r] = A[jb + r + (size_t) (jb + c) * lda]; }
+            __syncthreads();
+            for (int j = 0; j < nb; ++j) {
+                if (tid == 0) pivot_fix(&Ps[j * ldp + j], fst + jb + j + 1, replace_tiny, thresh, info, &s_piv);
+                __syncthreads();
+                const double p = s_piv;
+                if (p != 0.0) {
+                    const double r = 1.0 / p;
+                    for (int i = j + 1 + tid; i < m; i += 256) Ps[j * ldp + i] *= r;
+                }
+                __syncthreads();
+                for (int c = j + 1 + (tid >> 6); c < nb; c += 4) {
+                    const double u = Ps[c * ldp + j];
+                    if (u != 0.0)
+                        for (int i = j + 1 + (tid & 63); i < m; i += 64) Ps[c * ldp + i] -= Ps[j * ldp + i] * u;
+                }
+                __syncthreads();
+            }
+            for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
+            const int nc = ns - jb - nb;  // columns to the right
+            if (nc > 0) {
+                // U12 = L11^-1 A12 : stage A12 in LDS, one thread per column does the forward substitution there
+                for (int idx = tid; idx < nb * nc; idx += 256) { int i2 = idx % nb, c = idx / nb; Us[i2 * ns + c] = A[jb + i2 + (size_t) (jb + nb + c) * lda]; }
+                __syncthreads();
+                for (int c = tid; c < nc; c += 256) {
+#pragma unroll 1
+                    for (int i2 = 1; i2 < nb; ++i2) {
+                        double a = Us[i2 * ns + c];
+#pragma unroll 4
+                        for (int kk = 0; kk < i2; ++kk) a -= Ps[kk * ldp + i2] * Us[kk * ns + c];
+                        Us[i2 * ns + c] = a;
+                    }
+                }
+                __syncthreads();
+                for (int idx = tid; idx < nb * nc; idx += 256) { int i2 = idx % nb, c = idx / nb; A[jb + i2 + (size_t) (jb + nb + c) * lda] = Us[i2 * ns + c]; }
+                if (nb < DB) for (int idx = tid; idx < (DB - nb) * nc; idx += 256) Us[(nb + idx / nc) * ns + idx % nc] = 0.0;
+                __syncthreads();
+                // A22 -= L21 * U12 : thread = row, L21 row in registers, U12 broadcast from LDS
+                for (int r = tid; r < nc; r += 256) {
+                    double l[DB];
+#pragma unroll
+                    for (int kk = 0; kk < DB; ++kk) l[kk] = (kk < nb) ? Ps[kk * ldp + nb + r] : 0.0;
+                    double *row = A + jb + nb + r + (size_t) (jb + nb) * lda;
+                    for (int c = 0; c < nc; ++c) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int kk = 0; kk < DB; ++kk) a += l[kk] * Us[kk * ns + c];
+                        row[(size_t) c * lda] -= a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
-// ---- L panel TRSM:  X U_kk = B  (R,U,N,N), one thread per panel row, 64-row strips ---------------
-__global__ __launch_bounds__(64) void k_lpanel_trsm(DevTables T, const int *__restrict__ nodes,
+// Inverses of the 32x32 diagonal sub-blocks of U_kk (typ 0) and L_kk^T (typ 1, unit), identity-padded past
+// ns, written to T.dinv; 4 sub-blocks per 128-thread workgroup, one thread per column of an inverse
+// (back substitution with the block and the private solution column staged in LDS).
+__global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__restrict__ nodes,
+                                                  const int *__restrict__ prefix, int nn)
+{
+    __shared__ double Bs[4][DB * (DB + 1)];
+    __shared__ double Xi[4][DB * (DB + 1)];
+    const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int task = blockIdx.x * 4 + g;
+    const bool valid = task < prefix[nn];
+    int k = 0, typ = 0, b = 0, ns = 0, lda = 1, nblk = 1;
+    const double *A = nullptr;
+    if (valid) {
+        const int ni = find_node(prefix, nn, task);
+        k = nodes[ni];
+        ns = T.xsup[k + 1] - T.xsup[k];
+        nblk = (ns + DB - 1) / DB;
+        const int rem = task - prefix[ni];
+        typ = rem / nblk; b = rem - typ * nblk;
+        lda = T.sn_nsupr[k];
+        A = T.val + T.sn_lval[k];
+    }
+    const int o = b * DB;
+    if (valid) {
+        for (int i = 0; i < DB; ++i) {
+            double v = (i == c) ? 1.0 : 0.0;
+            if (o + i < ns && o + c < ns && i <= c) {
+                if (typ == 0) v = A[o + i + (size_t) (o + c) * lda];               // U(i,c)
+                else if (i < c) v = A[o + c + (size_t) (o + i) * lda];            // L(c,i) = (L^T)(i,c)
+            }
+            Bs[g][i * (DB + 1) + c] = v;
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        for (int i = c; i >= 0; --i) {
+            double a = (i == c) ? 1.0 : 0.0;
+            for (int jj = i + 1; jj <= c; ++jj) a -= Bs[g][i * (DB + 1) + jj] * Xi[g][jj * (DB + 1) + c];
+            Xi[g][i * (DB + 1) + c] = a / Bs[g][i * (DB + 1) + i];
+        }
+        double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB + c * DB;
+        for (int i = 0; i < DB; ++i) dst[i] = (i <= c) ? Xi[g][i * (DB + 1) + c] : 0.0;
+    }
+}
+
+// ---- panel TRSMs: blocked by 32 with inverted diagonal sub-blocks, GEMM parts on fp64 MFMA ---------------
+// MODE 0  L(:,k) <- L(:,k) U_kk^-1        (dLPanelTrSolve, dtrfCommWrapper.c:120-223: TRSM R,U,N,N)
+//         strip = 32 panel rows; T = U_kk.
+// MODE 1  U(k,:) <- L_kk^-1 U(k,:)        (dTrs2_GatherTrsmScatter, pdgstrf2.c:804-840: gather, TRSM L,L,N,U,
+//         scatter) solved as X^T L_kk^T = B^T on the skyline in place: strip = 32 non-empty U columns
+//         (implicit zero padding above each segment), T = L_kk^T (unit upper).
+// The 32 x ns strip lives in LDS for the whole solve: HBM traffic = one read + one write of the panel.
+constexpr int RS = 32, XS = 48;  // strip rows, LDS stride (== 16 mod 32 doubles -> conflict-free MFMA fragment reads)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__restrict__ nodes,
                                                     const int *__restrict__ prefix, int nn)
 {
+    extern __shared__ double sm[];
+    __shared__ int s_cp[RS], s_ld[RS];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int strip = blockIdx.x - prefix[ni];
-    const int ns = T.xsup[k + 1] - T.xsup[k];
-    const int lda = T.sn_nsupr[k];
-    const int row = ns + strip * 64 + threadIdx.x;
-    if (row >= lda) return;
-    double *A = T.val + T.sn_lval[k];
-    double *B = A + row;
-    for (int j = 0; j < ns; ++j) {
-        const double *u = A + (size_t) j * lda;  // column j of U_kk (rows 0..j)
-        double acc = B[(size_t) j * lda];
-        for (int kk = 0; kk < j; ++kk) acc -= B[(size_t) kk * lda] * u[kk];
-        B[(size_t) j * lda] = acc / u[j];
-    }
-}
-
-// ---- U panel TRSM:  L_kk X = U(k, cols)  (L,L,N,U) directly on the skyline, one thread per column ----
-__global__ __launch_bounds__(64) void k_upanel_trsm(DevTables T, const int *__restrict__ nodes,
-                                                    const int *__restrict__ prefix, int nn)
-{
-    const int ni = find_node(prefix, nn, blockIdx.x);
-    const int k = nodes[ni];
-    const int chunk = blockIdx.x - prefix[ni];
-    const int c = chunk * 64 + threadIdx.x;  // rank among the non-empty columns of block row k
-    if (c >= T.sn_ncolu[k]) return;
-    const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
-    // locate the U block holding column rank c
-    int lo = 0, hi = nub;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
-    const int b = ub0 + lo;
-    const int t = c - T.ub_stcol[b];
-    const int *uix = T.uidx + T.sn_uidx[k];
-    const int iukp = T.ub_iukp[b];
-    const int jj = T.unzcol[T.sn_uidx[k] + iukp + t];
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
-    const int seg = klst - uix[iukp + jj];
-    double *u = T.val + T.sn_uval[k] + T.ucolptr[T.sn_uidx[k] + iukp + jj];
+    const int nsp = (ns + DB - 1) & ~(DB - 1);
     const int lda = T.sn_nsupr[k];
-    const double *Lkk = T.val + T.sn_lval[k] + (size_t) (ns - seg) * (lda + 1);  // unit lower, trailing seg x seg
-    for (int i = 1; i < seg; ++i) {
-        double acc = u[i];
-        for (int kk = 0; kk < i; ++kk) acc -= Lkk[i + (size_t) kk * lda] * u[kk];
-        u[i] = acc;
+    const int nblk = nsp / DB;
+    double *A = T.val + T.sn_lval[k];
+    double *Uv = T.val + T.sn_uval[k];
+    const double *dinv = T.dinv + T.sn_dinv[k] + (MODE == 0 ? 0 : (size_t) nblk * DB * DB);
+    double *Xs = sm;                 // [nsp][XS]
+    double *Ts = sm + (size_t) nsp * XS;  // [32][XS]
+    double *Ds = Ts + DB * XS;       // [32][XS]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int rb = (wave & 1) * 16, cb = (wave >> 1) * 16;
+
+    if (MODE == 0) {
+        const int row0 = ns + strip * RS;
+        for (int idx = tid; idx < RS * nsp; idx += 256) {
+            const int r = idx & (RS - 1), c = idx >> 5;
+            double v = 0.0;
+            if (c < ns && row0 + r < lda) v = A[row0 + r + (size_t) c * lda];
+            Xs[c * XS + r] = v;
+        }
+    } else {
+        if (tid < RS) {
+            const int cr = strip * RS + tid;
+            int cp = 0, ld = nsp;
+            if (cr < T.sn_ncolu[k]) {
+                const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+                int lo = 0, hi = nub;
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= cr) lo = mid; else hi = mid; }
+                const int b = ub0 + lo;
+                const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+                const int jj = T.unzcol[u0 + (cr - T.ub_stcol[b])];
+                ld = ns - (klst - T.uidx[u0 + jj]);
+                cp = T.ucolptr[u0 + jj];
+            }
+            s_cp[tid] = cp; s_ld[tid] = ld;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < RS * nsp; idx += 256) {
+            const int c = idx % nsp, r = idx / nsp;
+            double v = 0.0;
+            const int ld = s_ld[r];
+            if (c >= ld && c < ns) v = Uv[s_cp[r] + (c - ld)];
+            Xs[c * XS + r] = v;
+        }
+    }
+    __syncthreads();
+
+    for (int jb = 0; jb < nsp; jb += DB) {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int kc = 0; kc < jb; kc += DB) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q;
+                int kk, cc;
+                if (MODE == 0) { kk = idx & 31; cc = idx >> 5; } else { cc = idx & 31; kk = idx >> 5; }
+                const int kg = kc + kk, cg = jb + cc;
+                double v = 0.0;
+                if (kg < ns && cg < ns) v = (MODE == 0) ? A[kg + (size_t) cg * lda] : A[cg + (size_t) kg * lda];
+                Ts[kk * XS + cc] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k4 = 0; k4 < DB; k4 += 4) {
+                const double a = Xs[(kc + k4 + (lane >> 4)) * XS + rb + (lane & 15)];
+                const double b = Ts[(k4 + (lane >> 4)) * XS + cb + (lane & 15)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // rhs = X_jb - acc (each wave owns a 16x16 block of the 32x32 strip block)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(jb + cb + (lane & 15)) * XS + rb + (lane >> 4) + 4 * r] -= acc[r];
+        {
+            const double *dblk = dinv + (size_t) (jb / DB) * DB * DB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q;
+                const int kk = idx & 31, cc = idx >> 5;
+                Ds[kk * XS + cc] = dblk[cc * DB + kk];
+            }
+        }
+        __syncthreads();
+        d4 acc2 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k4 = 0; k4 < DB; k4 += 4) {
+            const double a = Xs[(jb + k4 + (lane >> 4)) * XS + rb + (lane & 15)];
+            const double b = Ds[(k4 + (lane >> 4)) * XS + cb + (lane & 15)];
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(jb + cb + (lane & 15)) * XS + rb + (lane >> 4) + 4 * r] = acc2[r];
+        __syncthreads();
+    }
+
+    if (MODE == 0) {
+        const int row0 = ns + strip * RS;
+        for (int idx = tid; idx < RS * ns; idx += 256) {
+            const int r = idx & (RS - 1), c = idx >> 5;
+            if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[c * XS + r];
+        }
+    } else {
+        for (int idx = tid; idx < RS * nsp; idx += 256) {
+            const int c = idx % nsp, r = idx / nsp;
+            const int ld = s_ld[r];
+            if (c >= ld && c < ns) Uv[s_cp[r] + (c - ld)] = Xs[c * XS + r];
+        }
     }
 }
 
@@ -239,7 +432,6 @@ __global__ __launch_bounds__(64) void k_upanel_trsm(DevTables T, const int *__re
 // A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[(l>>4)+4r][l&15].  We feed A := U^T (i = tile column) and
 // B := L^T (j = tile row) so that the 16 fast lanes of every accumulator register run along tile ROWS:
 // the scatter then writes 128-byte runs of a destination column (column-major L panel / U skyline).
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <bool USE_MFMA>
 __global__ __launch_bounds__(256) void k_schur(DevTables T, const int *__restrict__ nodes,
@@ -592,7 +784,8 @@ static int flatten_view(const sluamd_dLUview_t *lu, HostStruct &hs, bool want_si
 }
 
 struct HostTables {
-    std::vector<int64_t> sn_lval, sn_uval, sn_lidx, sn_uidx;
+    std::vector<int64_t> sn_lval, sn_uval, sn_lidx, sn_uidx, sn_dinv;
+    int64_t dinv_total = 0;
     std::vector<int> sn_nsupr, sn_ldu, sn_ncolu, sn_lb_off, sn_nlb, sn_ub_off, sn_nub, sn_rt_off, sn_nrt, sn_ct_off, sn_nct;
     std::vector<int> lb_gid, lb_nbrow, lb_rowoff, lb_lptr, lbs_gid, lbs_idx;
     std::vector<int> ub_gid, ub_ncols, ub_iukp, ub_stcol;
@@ -604,7 +797,7 @@ static int build_tables(Handle &H, HostTables &t)
 {
     const HostStruct &hs = H.hs;
     const int ns = hs.nsupers;
-    t.sn_lval.resize(ns); t.sn_uval.resize(ns); t.sn_lidx.resize(ns); t.sn_uidx.resize(ns);
+    t.sn_lval.resize(ns); t.sn_uval.resize(ns); t.sn_lidx.resize(ns); t.sn_uidx.resize(ns); t.sn_dinv.resize(ns);
     t.sn_nsupr.resize(ns); t.sn_ldu.assign(ns, 0); t.sn_ncolu.assign(ns, 0);
     t.sn_lb_off.resize(ns); t.sn_nlb.resize(ns); t.sn_ub_off.resize(ns); t.sn_nub.resize(ns);
     t.sn_rt_off.resize(ns); t.sn_nrt.resize(ns); t.sn_ct_off.resize(ns); t.sn_nct.resize(ns);
@@ -615,6 +808,9 @@ static int build_tables(Handle &H, HostTables &t)
     for (int k = 0; k < ns; ++k) {
         const int nsupc = hs.xsup[k + 1] - hs.xsup[k], klst = hs.xsup[k + 1];
         H.max_nsupc = std::max(H.max_nsupc, nsupc);
+        if (nsupc > 256) { set_error("supernodes wider than 256 columns are not supported yet (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
+        t.sn_dinv[k] = t.dinv_total;
+        t.dinv_total += (int64_t) 2 * ((nsupc + 31) / 32) * 32 * 32;
         const int *li = hs.lidx.data() + hs.lidx_off[k];
         const int nb = li[0], nsupr = li[1];
         t.sn_lval[k] = hs.lval_off[k];
@@ -707,7 +903,7 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
     for (int l = 0; l < S.nlevels; ++l) S.lvl_poff[l + 1] = S.lvl_poff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 1;
     const int psz = S.lvl_poff[S.nlevels];
     S.tile_prefix.assign(psz, 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
-    S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0);
+    S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l) {
         int po = S.lvl_poff[l];
@@ -717,8 +913,9 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             const int rrows = t.sn_nsupr[k] - nsupc;
             S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc);
             S.tile_prefix[po + 1] = S.tile_prefix[po] + t.sn_nrt[k] * t.sn_nct[k];
-            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + 63) / 64;
-            S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
+            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + 31) / 32;
+            S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + 31) / 32;
+            S.inv_prefix[po + 1] = S.inv_prefix[po] + 2 * ((nsupc + 31) / 32);
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (rrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
         }
@@ -733,6 +930,7 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.utr_prefix, &S.d_utr_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.fwd_prefix, &S.d_fwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.bwd_prefix, &S.d_bwd_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.inv_prefix, &S.d_inv_prefix)) return SLUAMD_EHIP;
     return 0;
 }
 
@@ -753,6 +951,12 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
     T.lidx = H->d_lidx; T.uidx = H->d_uidx; T.ucolptr = H->d_ucolptr; T.unzcol = H->d_unzcol; T.xsup = H->d_xsup;
 #define UP(field, vec, type) { type *p_; if (upload(K, vec, &p_)) return SLUAMD_EHIP; T.field = p_; }
     UP(sn_lval, t.sn_lval, int64_t) UP(sn_uval, t.sn_uval, int64_t) UP(sn_lidx, t.sn_lidx, int64_t) UP(sn_uidx, t.sn_uidx, int64_t)
+    UP(sn_dinv, t.sn_dinv, int64_t)
+    {
+        double *dv;
+        if (hipMalloc((void **) &dv, sizeof(double) * std::max<int64_t>(t.dinv_total, 1)) != hipSuccess) { set_error("hipMalloc(dinv) failed"); return SLUAMD_ENOMEM; }
+        K.push_back(dv); T.dinv = dv;
+    }
     UP(sn_nsupr, t.sn_nsupr, int) UP(sn_ldu, t.sn_ldu, int) UP(sn_ncolu, t.sn_ncolu, int)
     UP(sn_lb_off, t.sn_lb_off, int) UP(sn_nlb, t.sn_nlb, int) UP(sn_ub_off, t.sn_ub_off, int) UP(sn_nub, t.sn_nub, int)
     UP(sn_rt_off, t.sn_rt_off, int) UP(sn_nrt, t.sn_nrt, int) UP(sn_ct_off, t.sn_ct_off, int) UP(sn_nct, t.sn_nct, int)
@@ -787,6 +991,10 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
     }
     H->st.num_levels = nlev;
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
+    // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
+    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
     H->st.bytes_device = (int64_t) ((hs.nnzL + hs.nnzU) * sizeof(double) + idxb);
@@ -839,15 +1047,18 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
-        const int lds_ns = (mx <= 128) ? mx : 128;
-        const size_t lds = (size_t) lds_ns * (lds_ns | 1) * sizeof(double);
+        const size_t lds = (mx <= 128) ? (size_t) mx * (mx | 1) * sizeof(double)
+                                       : (size_t) (32 * (mx | 1) + 32 * mx) * sizeof(double);
+        const int mxp = (mx + 31) & ~31;
+        const size_t lds_tr = (size_t) (mxp * XS + 2 * 32 * XS) * sizeof(double);
         ev_begin(H, H->ev_panel, H->ev_panel_used);
-        hipLaunchKernelGGL(k_diag_lu, dim3(nn), dim3(256), lds, s, T, nodes, lds_ns, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        hipLaunchKernelGGL(k_diag_lu, dim3(nn), dim3(256), lds, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, s, T, nodes, S.d_inv_prefix + po, nn);
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
-        if (nl) hipLaunchKernelGGL(k_lpanel_trsm, dim3(nl), dim3(64), 0, s, T, nodes, S.d_ltr_prefix + po, nn);
-        if (nu) hipLaunchKernelGGL(k_upanel_trsm, dim3(nu), dim3(64), 0, s, T, nodes, S.d_utr_prefix + po, nn);
+        if (nl) hipLaunchKernelGGL(k_panel_trsm<0>, dim3(nl), dim3(256), lds_tr, s, T, nodes, S.d_ltr_prefix + po, nn);
+        if (nu) hipLaunchKernelGGL(k_panel_trsm<1>, dim3(nu), dim3(256), lds_tr, s, T, nodes, S.d_utr_prefix + po, nn);
         ev_end(H, H->ev_panel, H->ev_panel_used);
-        H->st.num_launches += 1 + (nl > 0) + (nu > 0);
+        H->st.num_launches += 2 + (nl > 0) + (nu > 0);
         const int nt = S.tile_prefix[po + nn];
         if (!nt) continue;
         if (!H->opt.deterministic) {

@@ -132,3 +132,33 @@ def test_valu_fallback_kernel_agrees(golden, monkeypatch):
     scale = np.abs(g["r0__Lnzval_pre"]).max()
     assert np.abs(a.Lnzval - b.Lnzval).max() <= 1e-12 * scale
     h1.destroy(); h2.destroy()
+
+
+@pytest.mark.parametrize("N,leaf,relax,maxsup", [(24, 64, 64, 256), (20, 27, 20, 200), (22, 64, 48, 130)])
+def test_large_supernodes_match_oracle(N, leaf, relax, maxsup):
+    """Wide supernodes: blocked diagonal LU (ns > 128), multi-block MFMA TRSMs, 64x64 Schur tiles with several
+    row/column tiles per block pair; every L/U value against the CPU oracle."""
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(N)
+    v = v * (1.0 + 0.3 * rng.random(v.size))          # unsymmetric values on the symmetric pattern
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+    symb.distribute_host(v)
+    fs = symb.flat_store()
+    assert np.diff(fs.xsup).max() > 128 or maxsup <= 130
+    o = orc.LUStore(fs.n, fs.xsup, fs.Lrowind_off, fs.Lrowind, fs.Lnzval_off, fs.Lnzval, fs.Ufstnz_off, fs.Ufstnz,
+                    fs.Unzval_off, fs.Unzval)
+    h = driver.LUHandle.from_store(fs)
+    info = h.pdgstrf3d(0.0)
+    h.copy_to_host()
+    orc.dfactor(o)
+    scale = np.abs(v).max()
+    assert info == 0
+    assert np.abs(fs.Lnzval - o.Lnzval).max() <= 1e-12 * scale
+    assert np.abs(fs.Unzval - o.Unzval).max() <= 1e-12 * scale
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    x = h.pdgstrs3d(xp)[symb.perm_c, :]
+    assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
+    h.destroy()
