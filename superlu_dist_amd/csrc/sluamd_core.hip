@@ -83,6 +83,7 @@ struct LevelSched {
     std::vector<int> lvl_poff;      // [nlevels+1] offset of each level's prefix arrays (size nodes_in_level+1)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
     std::vector<int> max_nsupc;     // per level
+    std::vector<size_t> diag_lds;   // per level: dynamic LDS bytes k_diag_lu needs (max over the level's nodes)
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
     int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr;
@@ -905,6 +906,7 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
     S.tile_prefix.assign(psz, 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
+    S.diag_lds.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l) {
         int po = S.lvl_poff[l];
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i, ++po) {
@@ -912,6 +914,7 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             const int nsupc = hs.xsup[k + 1] - hs.xsup[k];
             const int rrows = t.sn_nsupr[k] - nsupc;
             S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc);
+            S.diag_lds[l] = std::max(S.diag_lds[l], sizeof(double) * (nsupc <= 128 ? (size_t) nsupc * (nsupc | 1) : (size_t) 32 * (nsupc | 1) + (size_t) 32 * nsupc));
             S.tile_prefix[po + 1] = S.tile_prefix[po] + t.sn_nrt[k] * t.sn_nct[k];
             S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + 31) / 32;
             S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + 31) / 32;
@@ -1047,8 +1050,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
-        const size_t lds = (mx <= 128) ? (size_t) mx * (mx | 1) * sizeof(double)
-                                       : (size_t) (32 * (mx | 1) + 32 * mx) * sizeof(double);
+        const size_t lds = S.diag_lds[l];
         const int mxp = (mx + 31) & ~31;
         const size_t lds_tr = (size_t) (mxp * XS + 2 * 32 * XS) * sizeof(double);
         ev_begin(H, H->ev_panel, H->ev_panel_used);
