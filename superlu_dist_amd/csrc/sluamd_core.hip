@@ -81,6 +81,8 @@ struct LevelSched {
     std::vector<int> utr_prefix;    // U-TRSM column chunks
     std::vector<int> inv_prefix;    // diagonal sub-block inversion tasks
     std::vector<int> lvl_poff;      // [nlevels+1] offset of each level's prefix arrays (size nodes_in_level+1)
+    std::vector<int> lvl_soff;      // [nlevels+1] offset of each level's Schur prefix arrays (big group | small group)
+    std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
     std::vector<int> max_nsupc;     // per level
     std::vector<size_t> diag_lds;   // per level: dynamic LDS bytes k_diag_lu needs (max over the level's nodes)
@@ -118,8 +120,7 @@ struct Handle {
 //                                          KERNELS
 // ================================================================================================
 typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int TM = 64, TN = 64, KC = 16;
-constexpr int LDT = TM + 16;  // LDS row stride in doubles: == 16 mod 32 -> ds_read_b64 of a 16x4 fragment is conflict-free
+constexpr int KC = 16;  // K chunk of the Schur GEMM pipeline
 
 __device__ __forceinline__ int find_node(const int *__restrict__ prefix, int nn, int id)
 {   // largest i in [0,nn) with prefix[i] <= id   (prefix has nn+1 entries)
@@ -434,24 +435,39 @@ __global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__re
 // B := L^T (j = tile row) so that the 16 fast lanes of every accumulator register run along tile ROWS:
 // the scatter then writes 128-byte runs of a destination column (column-major L panel / U skyline).
 
-template <bool USE_MFMA>
-__global__ __launch_bounds__(256) void k_schur(DevTables T, const int *__restrict__ nodes,
-                                               const int *__restrict__ prefix, int nn, int id_base,
-                                               int *__restrict__ info)
+// Two tile configurations: 128x128 (wide supernodes, big block pairs: 4x4 MFMA blocks per wave) and 64x64
+// (everything else).  Software pipeline: the next K chunk is fetched from HBM/L2 into registers while the
+// MFMAs of the current chunk run out of the other LDS buffer (one barrier per chunk).
+template <int TMv, int TNv>
+__global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T, const int *__restrict__ nodes,
+                                                                    const int *__restrict__ prefix, int nn, int id_base,
+                                                                    int ntiles, int *__restrict__ info)
 {
-    __shared__ double Ls[KC * LDT];
-    __shared__ double Us[KC * LDT];
-    __shared__ int s_ind[512 + 8];
-    __shared__ int s_rowmap[TM];
-    __shared__ int s_colmap[TN];
-    __shared__ int s_cptr[TN];   // value offset of tile column j inside U(k,:)
-    __shared__ int s_lead[TN];   // ns - seg (leading zeros) of tile column j
-    __shared__ int s_jj[TN];     // column id inside supernode jb
+    constexpr int LDL = TMv + 16, LDU = TNv + 16;      // == 16 mod 32 doubles: conflict-free fragment reads
+    constexpr int NBR = TMv / 32, NBC = TNv / 32;      // 16x16 MFMA blocks per wave (rows, cols)
+    constexpr int LQ = TMv * KC / 256, UQ = TNv * KC / 256;  // prefetch registers per thread
+    constexpr int LKS = 256 / TMv;                      // k stride of the L loader
+    __shared__ double Ls[2][KC * LDL];
+    __shared__ double Us[2][KC * LDU];
+    __shared__ int s_ind[256 + 8];
+    __shared__ int s_rowmap[TMv];
+    __shared__ int s_colmap[TNv];
+    __shared__ int s_cptr[TNv];   // value offset of tile column j inside U(k,:)
+    __shared__ int s_lead[TNv];   // ns - seg (leading zeros) of tile column j
+    __shared__ int s_jj[TNv];     // column id inside supernode jb
     __shared__ int64_t s_dbase;
     __shared__ int s_dinfo[4];
 
     const int tid = threadIdx.x;
-    const int bid = blockIdx.x + id_base;
+    // XCD-aware mapping: workgroup b runs on XCD b%8; give every XCD a contiguous range of tiles so that the
+    // row tile (L rows) shared by consecutive tiles stays in ONE XCD's L2
+    int bid;
+    {
+        const int chunk = (ntiles + 7) >> 3;
+        bid = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= chunk || bid >= ntiles) return;
+        bid += id_base;
+    }
     const int ni = find_node(prefix, nn, bid);
     const int k = nodes[ni];
     const int local = bid - prefix[ni];
@@ -469,17 +485,17 @@ __global__ __launch_bounds__(256) void k_schur(DevTables T, const int *__restric
     const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
     const double *Uv = T.val + T.sn_uval[k];
 
-    if (tid < TN) {
+    for (int t = tid; t < TNv; t += 256) {
         int cp = 0, lead = ns, jj = 0;
-        if (tid < nc) {
-            jj = T.unzcol[uix0 + C.y + tid];
+        if (t < nc) {
+            jj = T.unzcol[uix0 + C.y + t];
             lead = ns - (klst - T.uidx[uix0 + jj]);
             cp = T.ucolptr[uix0 + jj];
         }
-        s_cptr[tid] = cp; s_lead[tid] = lead; s_jj[tid] = jj;
+        s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
     }
     // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
-    if (tid == 64) {
+    if (tid == 255) {
         int found = 0;
         if (ib >= jb) {
             const int o = T.sn_lb_off[jb], nb = T.sn_nlb[jb];
@@ -506,65 +522,65 @@ __global__ __launch_bounds__(256) void k_schur(DevTables T, const int *__restric
     }
     __syncthreads();
 
-    // ---- main loop -------------------------------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
-    const int rm0 = (wave & 1) * 32, cn0 = (wave >> 1) * 32;
-    d4 acc[2][2];
+    const int rm0 = (wave & 1) * (TMv / 2), cn0 = (wave >> 1) * (TNv / 2);
+    d4 acc[NBC][NBR];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NBC; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-    double accs[16];  // VALU fallback accumulators (same element ownership as the MFMA layout)
-    if (!USE_MFMA) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accs[e] = 0.0;
-    }
+        for (int b = 0; b < NBR; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int kbeg = (ns - T.sn_ldu[k]) & ~3;  // U is zero above its tallest segment: skip those k
-    const int li = tid & 63, lk = tid >> 6;    // L loader: row li, k = lk + 4q
-    const int uk = tid & 15, uj = tid >> 4;    // U loader: k = uk, col = uj + 16q
+    const int kbeg = (ns - T.sn_ldu[k]) & ~3;          // U is zero above its tallest segment: skip those k
+    const int li = tid % TMv, lk = tid / TMv;           // L loader: row li, k = lk + LKS*q
+    const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + 16q
+    double pl[LQ], pu[UQ];
+    int ucp[UQ], uld[UQ];
+#pragma unroll
+    for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + 16 * q]; uld[q] = s_lead[uj + 16 * q]; }
+    const bool lrow_ok = li < nr;
+    const double *Lrow = Lp + li;
+
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) {
+            const int kg = k0 + lk + LKS * q;
+            pl[q] = (lrow_ok && kg < ns) ? Lrow[(size_t) kg * lda] : 0.0;
+        }
+        const int kg = k0 + uk;
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) pu[q] = (kg >= uld[q] && kg < ns) ? Uv[ucp[q] + (kg - uld[q])] : 0.0;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) Ls[buf][(lk + LKS * q) * LDL + li] = pl[q];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + 16 * q] = pu[q];
+    };
+
+    fetch(kbeg);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = kbeg; k0 < ns; k0 += KC) {
+        const bool more = k0 + KC < ns;
+        if (more) fetch(k0 + KC);
+        const double *Lb = Ls[buf], *Ub = Us[buf];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int kk = lk + 4 * q, kg = k0 + kk;
-            double v = 0.0;
-            if (li < nr && kg < ns) v = Lp[(size_t) kg * lda + li];
-            Ls[kk * LDT + li] = v;
-        }
+        for (int k4 = 0; k4 < KC; k4 += 4) {
+            const int kr = k4 + (lane >> 4);
+            double a[NBC], b[NBR];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = uj + 16 * q, kg = k0 + uk;
-            double v = 0.0;
-            const int lead = s_lead[j];
-            if (kg >= lead && kg < ns) v = Uv[s_cptr[j] + (kg - lead)];
-            Us[uk * LDT + j] = v;
+            for (int c = 0; c < NBC; ++c) a[c] = Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
+#pragma unroll
+            for (int r = 0; r < NBR; ++r) b[r] = Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
+#pragma unroll
+            for (int c = 0; c < NBC; ++c)
+#pragma unroll
+                for (int r = 0; r < NBR; ++r) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[r], acc[c][r], 0, 0, 0);
         }
+        if (more) stash(buf ^ 1);
         __syncthreads();
-        if (USE_MFMA) {
-#pragma unroll
-            for (int k4 = 0; k4 < KC; k4 += 4) {
-                const int kr = (k4 + (lane >> 4)) * LDT + (lane & 15);
-                const double a0 = Us[kr + cn0], a1 = Us[kr + cn0 + 16];
-                const double b0 = Ls[kr + rm0], b1 = Ls[kr + rm0 + 16];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-            }
-        } else {
-            for (int kk = 0; kk < KC; ++kk) {
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-                    for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int col = cn0 + 16 * ci + (lane >> 4) + 4 * r, row = rm0 + 16 * ri + (lane & 15);
-                            accs[(ci * 2 + ri) * 4 + r] += Us[kk * LDT + col] * Ls[kk * LDT + row];
-                        }
-            }
-        }
-        __syncthreads();
+        buf ^= 1;
     }
 
     // ---- scatter (epilogue) ----------------------------------------------------------------------
@@ -576,31 +592,33 @@ __global__ __launch_bounds__(256) void k_schur(DevTables T, const int *__restric
         const int fnz = T.xsup[ib], dn = s_dinfo[2];
         for (int i = tid; i < dn; i += 256) s_ind[drows[i] - fnz] = i;
         __syncthreads();
-        if (tid < TM) s_rowmap[tid] = (tid < nr) ? s_dinfo[0] + s_ind[lsub[tid] - fnz] : 0;
-        if (tid >= 64 && tid < 64 + TN) { const int j = tid - 64; s_colmap[j] = s_jj[j] * T.sn_nsupr[jb]; }
+        for (int t = tid; t < TMv; t += 256) s_rowmap[t] = (t < nr) ? s_dinfo[0] + s_ind[lsub[t] - fnz] : 0;
+        const int ldv = T.sn_nsupr[jb];
+        for (int t = tid; t < TNv; t += 256) s_colmap[t] = s_jj[t] * ldv;
     } else {
         const int64_t d0 = T.sn_uidx[ib] + s_dinfo[0];
-        if (tid < TM) s_rowmap[tid] = (tid < nr) ? lsub[tid] : 0;
-        if (tid >= 64 && tid < 64 + TN) {
-            const int j = tid - 64;
+        for (int t = tid; t < TMv; t += 256) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
+        for (int t = tid; t < TNv; t += 256) {
             int cm = 0;
-            if (j < nc) cm = T.ucolptr[d0 + s_jj[j]] - T.uidx[d0 + s_jj[j]];  // colptr - fstnz
-            s_colmap[j] = cm;
+            if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
+            s_colmap[t] = cm;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+    for (int ci = 0; ci < NBC; ++ci)
 #pragma unroll
-        for (int ri = 0; ri < 2; ++ri)
+        for (int r = 0; r < 4; ++r) {
+            const int col = cn0 + 16 * ci + (lane >> 4) + 4 * r;
+            if (col < nc) {
+                double *dcol = dst + s_colmap[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = cn0 + 16 * ci + (lane >> 4) + 4 * r, row = rm0 + 16 * ri + (lane & 15);
-                if (row < nr && col < nc) {
-                    const double v = USE_MFMA ? acc[ci][ri][r] : accs[(ci * 2 + ri) * 4 + r];
-                    atomic_sub_f64(dst + s_rowmap[row] + s_colmap[col], v);
+                for (int ri = 0; ri < NBR; ++ri) {
+                    const int row = rm0 + 16 * ri + (lane & 15);
+                    if (row < nr) atomic_sub_f64(dcol + s_rowmap[row], acc[ci][ri][r]);
                 }
             }
+        }
 }
 
 // ---- triangular solves --------------------------------------------------------------------------
@@ -792,6 +810,7 @@ struct HostTables {
     std::vector<int> ub_gid, ub_ncols, ub_iukp, ub_stcol;
     std::vector<int> ucolptr, unzcol;
     std::vector<int4> rtile, ctile;
+    std::vector<uint8_t> sn_big;   // 1: supernode uses the 128x128 Schur tile configuration
 };
 
 static int build_tables(Handle &H, HostTables &t)
@@ -828,14 +847,11 @@ static int build_tables(Handle &H, HostTables &t)
             if (b == 0 && gid != k) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
             t.lb_gid.push_back(gid); t.lb_nbrow.push_back(nbrow); t.lb_rowoff.push_back(rowoff); t.lb_lptr.push_back(p + LB_DESCRIPTOR);
             dir.emplace_back(gid, b);
-            if (gid != k)
-                for (int r0 = 0; r0 < nbrow; r0 += TM) t.rtile.push_back(make_int4(b, r0, std::min(TM, nbrow - r0), rowoff + r0));
             rowoff += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
         if (rowoff != nsupr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
         std::sort(dir.begin(), dir.end());
         for (auto &d : dir) { t.lbs_gid.push_back(d.first); t.lbs_idx.push_back(d.second); }
-        t.sn_nrt[k] = (int) t.rtile.size() - t.sn_rt_off[k];
         // U block row
         t.sn_ub_off[k] = (int) t.ub_gid.size();
         t.sn_ct_off[k] = (int) t.ctile.size();
@@ -860,13 +876,34 @@ static int build_tables(Handle &H, HostTables &t)
                     if (seg) { nz[iukp + UB_DESCRIPTOR + nc] = jj; ++nc; rukp += seg; ldu = std::max(ldu, seg); exact += seg; }
                 }
                 t.ub_gid.push_back(jb); t.ub_ncols.push_back(nc); t.ub_iukp.push_back(iukp + UB_DESCRIPTOR); t.ub_stcol.push_back(ncol_tot);
-                for (int c0 = 0; c0 < nc; c0 += TN) t.ctile.push_back(make_int4(b, c0, std::min(TN, nc - c0), 0));
                 ncol_tot += nc;
                 iukp += UB_DESCRIPTOR + nsj;
             }
             if (rukp != hs.uval_off[k + 1] - hs.uval_off[k]) { set_error("U value count mismatch"); return SLUAMD_ESTRUCT; }
         }
         t.sn_nub[k] = nub; t.sn_ldu[k] = ldu; t.sn_ncolu[k] = ncol_tot;
+        {   // tile configuration + tile lists of supernode k
+            const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k];
+            long t128r = 0, t128c = 0;
+            for (int b = 1; b < nb; ++b) t128r += (t.lb_nbrow[lb0 + b] + 127) / 128;
+            for (int b = 0; b < nub; ++b) t128c += (t.ub_ncols[ub0 + b] + 127) / 128;
+            const double cells = (double) (nsupr - nsupc) * ncol_tot;
+            const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * 128.0 * 128.0) : 0.0;
+            const bool big = nsupc >= 96 && util128 >= 0.5 && !getenv("SLUAMD_NO_BIG_TILES");
+            t.sn_big.push_back(big);
+            const int tm = big ? 128 : 64;
+            t.sn_rt_off[k] = (int) t.rtile.size();
+            for (int b = 1; b < nb; ++b) {
+                const int nbrow = t.lb_nbrow[lb0 + b], ro = t.lb_rowoff[lb0 + b];
+                for (int r0 = 0; r0 < nbrow; r0 += tm) t.rtile.push_back(make_int4(b, r0, std::min(tm, nbrow - r0), ro + r0));
+            }
+            t.sn_nrt[k] = (int) t.rtile.size() - t.sn_rt_off[k];
+            t.sn_ct_off[k] = (int) t.ctile.size();
+            for (int b = 0; b < nub; ++b) {
+                const int nc = t.ub_ncols[ub0 + b];
+                for (int c0 = 0; c0 < nc; c0 += tm) t.ctile.push_back(make_int4(b, c0, std::min(tm, nc - c0), 0));
+            }
+        }
         t.sn_nct[k] = (int) t.ctile.size() - t.sn_ct_off[k];
         const double rrows = nsupr - nsupc;
         st.flops_schur_padded += 2.0 * rrows * ldu * ncol_tot;
@@ -899,23 +936,30 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
     for (int l = 0; l < S.nlevels; ++l) S.lvl_off[l + 1] += S.lvl_off[l];
     S.nodes.resize(sorted.size());
     std::vector<int> fill(S.lvl_off.begin(), S.lvl_off.end() - (S.nlevels ? 1 : 0));
-    for (int k : sorted) S.nodes[fill[lvl[k]]++] = k;
+    for (int pass = 1; pass >= 0; --pass)   // big-tile supernodes first inside each level
+        for (int k : sorted) if ((int) t.sn_big[k] == pass) S.nodes[fill[lvl[k]]++] = k;
+    S.n_big.assign(S.nlevels, 0);
+    for (int k : sorted) if (t.sn_big[k]) S.n_big[lvl[k]]++;
+    S.lvl_soff.assign(S.nlevels + 1, 0);
+    for (int l = 0; l < S.nlevels; ++l) S.lvl_soff[l + 1] = S.lvl_soff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 2;
     S.lvl_poff.assign(S.nlevels + 1, 0);
     for (int l = 0; l < S.nlevels; ++l) S.lvl_poff[l + 1] = S.lvl_poff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 1;
     const int psz = S.lvl_poff[S.nlevels];
-    S.tile_prefix.assign(psz, 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
+    S.tile_prefix.assign(S.lvl_soff[S.nlevels], 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     S.diag_lds.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l) {
         int po = S.lvl_poff[l];
-        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i, ++po) {
+        int so = S.lvl_soff[l];
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i, ++po, ++so) {
             const int k = S.nodes[i];
+            if (i - S.lvl_off[l] == S.n_big[l]) ++so;      // start of the small group: its own prefix, from 0
+            S.tile_prefix[so + 1] = S.tile_prefix[so] + t.sn_nrt[k] * t.sn_nct[k];
             const int nsupc = hs.xsup[k + 1] - hs.xsup[k];
             const int rrows = t.sn_nsupr[k] - nsupc;
             S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc);
             S.diag_lds[l] = std::max(S.diag_lds[l], sizeof(double) * (nsupc <= 128 ? (size_t) nsupc * (nsupc | 1) : (size_t) 32 * (nsupc | 1) + (size_t) 32 * nsupc));
-            S.tile_prefix[po + 1] = S.tile_prefix[po] + t.sn_nrt[k] * t.sn_nct[k];
             S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + 31) / 32;
             S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + 31) / 32;
             S.inv_prefix[po + 1] = S.inv_prefix[po] + 2 * ((nsupc + 31) / 32);
@@ -1036,15 +1080,15 @@ static double ev_sum(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t u
 
 static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
 {
-    const bool use_mfma = getenv("SLUAMD_NO_MFMA") == nullptr;
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
-    auto schur = [&](int grid, const int *nodes, const int *prefix, int nn, int id_base) {
+    auto schur = [&](bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base) {
         ev_begin(H, H->ev_schur, H->ev_schur_used);
-        if (use_mfma) hipLaunchKernelGGL(k_schur<true>, dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, H->d_info);
-        else hipLaunchKernelGGL(k_schur<false>, dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, H->d_info);
+        const int grid = ((ntile + 7) / 8) * 8;
+        if (big) hipLaunchKernelGGL((k_schur<128, 128>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info);
+        else hipLaunchKernelGGL((k_schur<64, 64>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info);
         ev_end(H, H->ev_schur, H->ev_schur_used);
-        H->st.num_launches++; H->st.schur_launches++;
+        H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
@@ -1061,17 +1105,24 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         if (nu) hipLaunchKernelGGL(k_panel_trsm<1>, dim3(nu), dim3(256), lds_tr, s, T, nodes, S.d_utr_prefix + po, nn);
         ev_end(H, H->ev_panel, H->ev_panel_used);
         H->st.num_launches += 2 + (nl > 0) + (nu > 0);
-        const int nt = S.tile_prefix[po + nn];
-        if (!nt) continue;
-        if (!H->opt.deterministic) {
-            schur(nt, nodes, S.d_tile_prefix + po, nn, 0);
-        } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
-            for (int i = 0; i < nn; ++i) {
-                const int c = S.tile_prefix[po + i + 1] - S.tile_prefix[po + i];
-                if (c) schur(c, nodes, S.d_tile_prefix + po, nn, S.tile_prefix[po + i]);
+        // Schur update: group 0 = 128x128-tile supernodes, group 1 = 64x64-tile supernodes
+        const int nbig = S.n_big[l];
+        for (int g = 0; g < 2; ++g) {
+            const int cnt = g == 0 ? nbig : nn - nbig;
+            if (!cnt) continue;
+            const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
+            const int *gn = nodes + (g == 0 ? 0 : nbig);
+            const int nt = S.tile_prefix[so + cnt];
+            if (!nt) continue;
+            if (!H->opt.deterministic) {
+                schur(g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0);
+            } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
+                for (int i = 0; i < cnt; ++i) {
+                    const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
+                    if (c) schur(g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i]);
+                }
             }
         }
-        H->st.schur_tiles += nt;
     }
     HIPCHK(hipGetLastError());
     return 0;

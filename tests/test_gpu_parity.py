@@ -124,14 +124,24 @@ def test_own_pipeline_poisson_residual(N, leaf, relax, maxsup, nrhs):
     assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
 
 
-def test_valu_fallback_kernel_agrees(golden, monkeypatch):
-    g = golden("poisson8_nd")
-    a, h1, _ = _factor(g)
-    monkeypatch.setenv("SLUAMD_NO_MFMA", "1")
-    b, h2, _ = _factor(g)
-    scale = np.abs(g["r0__Lnzval_pre"]).max()
-    assert np.abs(a.Lnzval - b.Lnzval).max() <= 1e-12 * scale
-    h1.destroy(); h2.destroy()
+def test_small_tile_configuration_agrees(golden, monkeypatch):
+    """Forcing the 64x64 Schur tiles everywhere gives the same factors as the mixed 128/64 configuration."""
+    N = 20
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    outs = []
+    for force_small in (False, True):
+        if force_small:
+            monkeypatch.setenv("SLUAMD_NO_BIG_TILES", "1")
+        symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=256)
+        symb.distribute_host(v)
+        fs = symb.flat_store()
+        h = driver.LUHandle.from_store(fs)
+        assert h.pdgstrf3d(0.0) == 0
+        h.copy_to_host(); h.destroy()
+        outs.append(fs)
+    assert np.abs(outs[0].Lnzval - outs[1].Lnzval).max() <= 1e-12 * 6.0
+    assert np.abs(outs[0].Unzval - outs[1].Unzval).max() <= 1e-12 * 6.0
 
 
 @pytest.mark.parametrize("N,leaf,relax,maxsup", [(24, 64, 64, 256), (20, 27, 20, 200), (22, 64, 48, 130)])
