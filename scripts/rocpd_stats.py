@@ -6,6 +6,15 @@ db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
+if len(sys.argv) > 2 and sys.argv[2] == "--launches":   # per-launch listing of one kernel family
+    pat = sys.argv[3]
+    gcols = [c for c in cols if c in ("grid_size_x", "grid_x", "workgroup_size_x", "grid_size")]
+    q = cur.execute(f"select {name_col}, start, end" + "".join(", " + c for c in gcols) + " from kernels order by start").fetchall()
+    print("# launches of kernels matching", pat, "cols: idx dur_us", gcols)
+    for i, r in enumerate(q):
+        if pat in r[0]:
+            print(i, f"{(r[2]-r[1])/1e3:.1f}", *r[3:], re.sub(r"\(.*", "", r[0])[-40:])
+    sys.exit(0)
 agg = {}
 for nm, s, e in rows:
     nm = re.sub(r"\(.*", "", nm)

@@ -106,6 +106,7 @@ struct Handle {
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
     double *d_x = nullptr; int64_t x_cap = 0;
     int64_t *d_apos = nullptr; double *d_aval = nullptr; int64_t a_nnz = 0;  // A's entries for device-side (re)distribution
+    bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
     size_t ev_schur_used = 0, ev_panel_used = 0;
@@ -155,43 +156,87 @@ __device__ __forceinline__ void pivot_fix(double *p, int col1based, int replace_
     *s_piv = v;
 }
 
+// Unpivoted LU of an nb x nb (nb <= 32) block held in LDS, executed by ONE wave without barriers: lane c owns
+// column c; LDS operations of a wave complete in program order.
+__device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, int replace_tiny, double thresh, int *info)
+{
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < nb; ++j) {
+        double p = P[j * ld + j];
+        if (replace_tiny && fabs(p) < thresh) {
+            p = (p < 0) ? -thresh : thresh;
+            if (lane == 0) { P[j * ld + j] = p; atomicAdd(&info[1], 1); }
+        }
+        if (p == 0.0 && lane == 0) atomicMin(&info[0], col1 + j);
+        const double rinv = (p != 0.0) ? 1.0 / p : 1.0;   // zero pivot: column left unscaled (pdgstrf2.c:566-575)
+        const double u = (lane > j && lane < nb) ? P[lane * ld + j] : 0.0;
+        for (int i = j + 1; i < nb; ++i) {
+            const double l = P[j * ld + i] * rinv;
+            if (lane == j) P[j * ld + i] = l;
+            else if (lane > j && lane < nb) P[lane * ld + i] -= l * u;
+        }
+    }
+}
+
+// rows below an already factored nb x nb block: x U11 = a, one thread per row, in place.
+// element (row, j) at X[j * ld]; U11(kk, j) at U[j * ld + kk]
+__device__ __forceinline__ void row_solve_upper(double *X, const double *U, int ld, int nb)
+{
+    for (int j = 0; j < nb; ++j) {
+        double a = X[j * ld];
+        for (int kk = 0; kk < j; ++kk) a -= X[kk * ld] * U[j * ld + kk];
+        X[j * ld] = a / U[j * ld + j];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restrict__ nodes,
                                                  int replace_tiny, double thresh, int *__restrict__ info)
 {
     extern __shared__ double s_a[];
-    __shared__ double s_piv;
     const int k = nodes[blockIdx.x];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     double *A = T.val + T.sn_lval[k];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6;
     if (ns <= 128) {
+        // whole block in LDS, right-looking blocked by 32
         const int ld = ns | 1;
-        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; s_a[i + j * ld] = A[i + (size_t) j * lda]; }
+        double *W = s_a;
+        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; W[i + j * ld] = A[i + (size_t) j * lda]; }
         __syncthreads();
-        for (int j = 0; j < ns; ++j) {
-            if (tid == 0) pivot_fix(&s_a[j + j * ld], fst + j + 1, replace_tiny, thresh, info, &s_piv);
+        for (int jb = 0; jb < ns; jb += DB) {
+            const int m = ns - jb, nb = min(DB, m), nc = m - nb;
+            if (wave == 0) wave_lu32(W + jb * ld + jb, ld, nb, fst + jb + 1, replace_tiny, thresh, info);
             __syncthreads();
-            const double p = s_piv;
-            const int m = ns - j - 1;
-            if (p != 0.0) {
-                const double r = 1.0 / p;
-                for (int i = tid; i < m; i += 256) s_a[j + 1 + i + j * ld] *= r;
-            }
-            __syncthreads();
-            for (int c = (tid >> 6); c < m; c += 4) {
-                const double u = s_a[j + (j + 1 + c) * ld];
-                if (u != 0.0) {
-                    double *col = s_a + (j + 1 + c) * ld + j + 1;
-                    const double *l = s_a + j * ld + j + 1;
-                    for (int i = (tid & 63); i < m; i += 64) col[i] -= l[i] * u;
+            if (nc > 0) {
+                if (tid < nc) row_solve_upper(W + jb * ld + jb + nb + tid, W + jb * ld + jb, ld, nb);
+                else if (tid >= 128 && tid < 128 + nc) {  // U12 column: L11 x = a (unit lower)
+                    double *col = W + (jb + nb + (tid - 128)) * ld + jb;
+                    for (int i2 = 1; i2 < nb; ++i2) {
+                        double a = col[i2];
+                        for (int kk = 0; kk < i2; ++kk) a -= W[(jb + kk) * ld + jb + i2] * col[kk];
+                        col[i2] = a;
+                    }
                 }
+                __syncthreads();
+                for (int r = (tid & 63); r < nc; r += 64) {
+                    double l[DB];
+#pragma unroll
+                    for (int kk = 0; kk < DB; ++kk) l[kk] = (kk < nb) ? W[(jb + kk) * ld + jb + nb + r] : 0.0;
+                    for (int c = wave; c < nc; c += 4) {
+                        const double *uc = W + (jb + nb + c) * ld + jb;
+                        double a = 0.0;
+#pragma unroll
+                        for (int kk = 0; kk < DB; ++kk) a += l[kk] * ((kk < nb) ? uc[kk] : 0.0);
+                        W[(jb + nb + c) * ld + jb + nb + r] -= a;
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
-        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; A[i + (size_t) j * lda] = s_a[i + j * ld]; }
+        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; A[i + (size_t) j * lda] = W[i + j * ld]; }
     } else {
-        // blocked path (128 < ns <= 256): Ps = column panel [c][r], Us = U12 block row [kk][c]
+        // 128 < ns <= 256: matrix stays in HBM/L2; Ps = column panel [c][r], Us = U12 block row [kk][c]
         double *Ps = s_a;                       // DB x (ns|1)
         const int ldp = ns | 1;
         double *Us = s_a + DB * ldp;            // DB x ns
@@ -199,22 +244,10 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
             const int nb = min(DB, ns - jb), m = ns - jb;
             for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; Ps[c * ldp + r] = A[jb + r + (size_t) (jb + c) * lda]; }
             __syncthreads();
-            for (int j = 0; j < nb; ++j) {
-                if (tid == 0) pivot_fix(&Ps[j * ldp + j], fst + jb + j + 1, replace_tiny, thresh, info, &s_piv);
-                __syncthreads();
-                const double p = s_piv;
-                if (p != 0.0) {
-                    const double r = 1.0 / p;
-                    for (int i = j + 1 + tid; i < m; i += 256) Ps[j * ldp + i] *= r;
-                }
-                __syncthreads();
-                for (int c = j + 1 + (tid >> 6); c < nb; c += 4) {
-                    const double u = Ps[c * ldp + j];
-                    if (u != 0.0)
-                        for (int i = j + 1 + (tid & 63); i < m; i += 64) Ps[c * ldp + i] -= Ps[j * ldp + i] * u;
-                }
-                __syncthreads();
-            }
+            if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info);
+            __syncthreads();
+            if (tid < m - nb) row_solve_upper(Ps + nb + tid, Ps, ldp, nb);
+            __syncthreads();
             for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
             const int nc = ns - jb - nb;  // columns to the right
             if (nc > 0) {
@@ -306,17 +339,14 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
 //         scatter) solved as X^T L_kk^T = B^T on the skyline in place: strip = 32 non-empty U columns
 //         (implicit zero padding above each segment), T = L_kk^T (unit upper).
 // The 32 x ns strip lives in LDS for the whole solve: HBM traffic = one read + one write of the panel.
-constexpr int RS = 32, XS = 48;  // strip rows, LDS stride (== 16 mod 32 doubles -> conflict-free MFMA fragment reads)
+constexpr int RS = 32;  // strip rows per workgroup
+// LDS images are split in 16-wide halves ([half][k][16]): a 16x4 MFMA fragment read touches 4 k-rows x 16
+// consecutive doubles = all 64 banks once.
+__host__ __device__ inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) 64 * nsp + 2 * DB * 16); }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__restrict__ nodes,
-                                                    const int *__restrict__ prefix, int nn)
+__device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int strip, double *sm, int *s_cp, int *s_ld)
 {
-    extern __shared__ double sm[];
-    __shared__ int s_cp[RS], s_ld[RS];
-    const int ni = find_node(prefix, nn, blockIdx.x);
-    const int k = nodes[ni];
-    const int strip = blockIdx.x - prefix[ni];
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int nsp = (ns + DB - 1) & ~(DB - 1);
     const int lda = T.sn_nsupr[k];
@@ -324,11 +354,11 @@ __global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__re
     double *A = T.val + T.sn_lval[k];
     double *Uv = T.val + T.sn_uval[k];
     const double *dinv = T.dinv + T.sn_dinv[k] + (MODE == 0 ? 0 : (size_t) nblk * DB * DB);
-    double *Xs = sm;                 // [nsp][XS]
-    double *Ts = sm + (size_t) nsp * XS;  // [32][XS]
-    double *Ds = Ts + DB * XS;       // [32][XS]
+    double *Xs = sm;                          // [2][nsp][16]   strip, element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
+    double *Ts = sm + (size_t) 32 * nsp;      // [2][nsp][16]   T(0:jb, jb:jb+32), element (k, cc) at ((cc>>4)*nsp + k)*16 + (cc&15)
+    double *Ds = Ts + (size_t) 32 * nsp;      // [2][32][16]    inverse of the diagonal sub-block
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int rb = (wave & 1) * 16, cb = (wave >> 1) * 16;
+    const int rbh = wave & 1, cbh = wave >> 1;
 
     if (MODE == 0) {
         const int row0 = ns + strip * RS;
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__re
             const int r = idx & (RS - 1), c = idx >> 5;
             double v = 0.0;
             if (c < ns && row0 + r < lda) v = A[row0 + r + (size_t) c * lda];
-            Xs[c * XS + r] = v;
+            Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
         }
     } else {
         if (tid < RS) {
@@ -360,56 +390,57 @@ __global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__re
             double v = 0.0;
             const int ld = s_ld[r];
             if (c >= ld && c < ns) v = Uv[s_cp[r] + (c - ld)];
-            Xs[c * XS + r] = v;
+            Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
         }
     }
-    __syncthreads();
 
     for (int jb = 0; jb < nsp; jb += DB) {
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int kc = 0; kc < jb; kc += DB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = tid + 256 * q;
-                int kk, cc;
-                if (MODE == 0) { kk = idx & 31; cc = idx >> 5; } else { cc = idx & 31; kk = idx >> 5; }
-                const int kg = kc + kk, cg = jb + cc;
-                double v = 0.0;
-                if (kg < ns && cg < ns) v = (MODE == 0) ? A[kg + (size_t) cg * lda] : A[cg + (size_t) kg * lda];
-                Ts[kk * XS + cc] = v;
+        // stage T(0:jb, jb:jb+32) and the inverse of the diagonal sub-block
+        if (MODE == 0) {
+            for (int cc = wave; cc < DB; cc += 4) {
+                const int cg = jb + cc;
+                for (int kk = lane; kk < jb; kk += 64)
+                    Ts[((cc >> 4) * nsp + kk) * 16 + (cc & 15)] = (cg < ns) ? A[kk + (size_t) cg * lda] : 0.0;
             }
-            __syncthreads();
-#pragma unroll
-            for (int k4 = 0; k4 < DB; k4 += 4) {
-                const double a = Xs[(kc + k4 + (lane >> 4)) * XS + rb + (lane & 15)];
-                const double b = Ts[(k4 + (lane >> 4)) * XS + cb + (lane & 15)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        } else {
+            for (int idx = tid; idx < DB * jb; idx += 256) {
+                const int cc = idx & 31, kk = idx >> 5;
+                const int cg = jb + cc;
+                Ts[((cc >> 4) * nsp + kk) * 16 + (cc & 15)] = (cg < ns) ? A[cg + (size_t) kk * lda] : 0.0;
             }
-            __syncthreads();
         }
-        // rhs = X_jb - acc (each wave owns a 16x16 block of the 32x32 strip block)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Xs[(jb + cb + (lane & 15)) * XS + rb + (lane >> 4) + 4 * r] -= acc[r];
         {
             const double *dblk = dinv + (size_t) (jb / DB) * DB * DB;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx = tid + 256 * q;
                 const int kk = idx & 31, cc = idx >> 5;
-                Ds[kk * XS + cc] = dblk[cc * DB + kk];
+                Ds[((cc >> 4) * DB + kk) * 16 + (cc & 15)] = dblk[cc * DB + kk];
             }
         }
         __syncthreads();
-        d4 acc2 = (d4){0.0, 0.0, 0.0, 0.0};
+        d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+        const double *xa = Xs + ((size_t) rbh * nsp + (lane >> 4)) * 16 + (lane & 15);
+        const double *tb = Ts + ((size_t) cbh * nsp + (lane >> 4)) * 16 + (lane & 15);
+        for (int k8 = 0; k8 < jb; k8 += 8) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k8 * 16], tb[k8 * 16], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(k8 + 4) * 16], tb[(k8 + 4) * 16], acc1, 0, 0, 0);
+        }
+        // rhs = X_jb - acc (each wave owns one 16x16 block of the 32x32 strip block)
+        double *xblk = Xs + ((size_t) rbh * nsp + jb + cbh * 16 + (lane & 15)) * 16 + (lane >> 4);
 #pragma unroll
-        for (int k4 = 0; k4 < DB; k4 += 4) {
-            const double a = Xs[(jb + k4 + (lane >> 4)) * XS + rb + (lane & 15)];
-            const double b = Ds[(k4 + (lane >> 4)) * XS + cb + (lane & 15)];
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) xblk[4 * r] -= acc0[r] + acc1[r];
+        __syncthreads();
+        d4 acc2 = (d4){0.0, 0.0, 0.0, 0.0}, acc3 = (d4){0.0, 0.0, 0.0, 0.0};
+        const double *db = Ds + ((size_t) cbh * DB + (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+        for (int k8 = 0; k8 < DB; k8 += 8) {
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(jb + k8) * 16], db[k8 * 16], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(jb + k8 + 4) * 16], db[(k8 + 4) * 16], acc3, 0, 0, 0);
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Xs[(jb + cb + (lane & 15)) * XS + rb + (lane >> 4) + 4 * r] = acc2[r];
+        for (int r = 0; r < 4; ++r) xblk[4 * r] = acc2[r] + acc3[r];
         __syncthreads();
     }
 
@@ -417,14 +448,31 @@ __global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__re
         const int row0 = ns + strip * RS;
         for (int idx = tid; idx < RS * ns; idx += 256) {
             const int r = idx & (RS - 1), c = idx >> 5;
-            if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[c * XS + r];
+            if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
         }
     } else {
         for (int idx = tid; idx < RS * nsp; idx += 256) {
             const int c = idx % nsp, r = idx / nsp;
             const int ld = s_ld[r];
-            if (c >= ld && c < ns) Uv[s_cp[r] + (c - ld)] = Xs[c * XS + r];
+            if (c >= ld && c < ns) Uv[s_cp[r] + (c - ld)] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
         }
+    }
+}
+
+// L strips (blocks [0, nl)) and U column strips (blocks [nl, nl+nu)) of one level in ONE launch
+__global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__restrict__ nodes,
+                                                    const int *__restrict__ lprefix, const int *__restrict__ uprefix,
+                                                    int nn, int nl)
+{
+    extern __shared__ double sm[];
+    __shared__ int s_cp[RS], s_ld[RS];
+    if ((int) blockIdx.x < nl) {
+        const int ni = find_node(lprefix, nn, blockIdx.x);
+        panel_trsm_body<0>(T, nodes[ni], blockIdx.x - lprefix[ni], sm, s_cp, s_ld);
+    } else {
+        const int id = blockIdx.x - nl;
+        const int ni = find_node(uprefix, nn, id);
+        panel_trsm_body<1>(T, nodes[ni], id - uprefix[ni], sm, s_cp, s_ld);
     }
 }
 
@@ -443,7 +491,8 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info)
 {
-    constexpr int LDL = TMv + 16, LDU = TNv + 16;      // == 16 mod 32 doubles: conflict-free fragment reads
+    constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
+    constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
     constexpr int NBR = TMv / 32, NBC = TNv / 32;      // 16x16 MFMA blocks per wave (rows, cols)
     constexpr int LQ = TMv * KC / 256, UQ = TNv * KC / 256;  // prefetch registers per thread
     constexpr int LKS = 256 / TMv;                      // k stride of the L loader
@@ -622,37 +671,49 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
 }
 
 // ---- triangular solves --------------------------------------------------------------------------
-// x_k <- inv(L_kk) x_k (unit lower) or inv(U_kk) x_k (upper): one workgroup per supernode of the level.
+// x_k <- inv(L_kk) x_k (unit lower) or inv(U_kk) x_k (upper): one workgroup per supernode of the level,
+// blocked by 32 with the inverted diagonal sub-blocks left in T.dinv by the factorisation (what the reference's
+// DiagInv=YES solve does with Linv/Uinv, pdgstrs_lsum.c:414-520): 2 barriers per 32 columns.
 template <bool LOWER>
 __global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
                                                     int64_t ldx, int nrhs)
 {
-    extern __shared__ double xs[];  // ns x nrhs
+    extern __shared__ double xs[];  // ns x nrhs, then 32 x nrhs scratch
     const int k = nodes[blockIdx.x];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     const double *A = T.val + T.sn_lval[k];
+    const int nblk = (ns + DB - 1) / DB;
+    const double *dinv = T.dinv + T.sn_dinv[k] + (LOWER ? (size_t) nblk * DB * DB : 0);
+    double *ys = xs + (size_t) ns * nrhs;
     const int tid = threadIdx.x;
     for (int idx = tid; idx < ns * nrhs; idx += 256) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
-    if (LOWER) {
-        for (int j = 0; j < ns - 1; ++j) {
-            for (int idx = tid; idx < (ns - j - 1) * nrhs; idx += 256) {
-                const int i = j + 1 + idx % (ns - j - 1), r = idx / (ns - j - 1);
-                xs[i + r * ns] -= A[i + (size_t) j * lda] * xs[j + r * ns];
-            }
-            __syncthreads();
+    for (int bb = 0; bb < nblk; ++bb) {
+        const int b = LOWER ? bb : nblk - 1 - bb;
+        const int o = b * DB, nb = min(DB, ns - o);
+        const double *D = dinv + (size_t) b * DB * DB;
+        // y = inv(T_bb) x_b : LOWER inv(L_bb)(r,c) = D(c,r) ; UPPER inv(U_bb)(r,c) = D(r,c) ; D(i,j) at D[j*32+i]
+        for (int idx = tid; idx < nb * nrhs; idx += 256) {
+            const int r = idx % nb, q = idx / nb;
+            const double *xb = xs + o + q * ns;
+            double a = 0.0;
+            if (LOWER) { for (int c = 0; c <= r; ++c) a += D[r * DB + c] * xb[c]; }
+            else { for (int c = r; c < nb; ++c) a += D[c * DB + r] * xb[c]; }
+            ys[r + q * DB] = a;
         }
-    } else {
-        for (int j = ns - 1; j >= 0; --j) {
-            if (tid < nrhs) xs[j + tid * ns] /= A[j + (size_t) j * lda];
-            __syncthreads();
-            for (int idx = tid; idx < j * nrhs; idx += 256) {
-                const int i = idx % j, r = idx / j;
-                xs[i + r * ns] -= A[i + (size_t) j * lda] * xs[j + r * ns];
-            }
-            __syncthreads();
+        __syncthreads();
+        // x_b = y ; remaining rows -= T(rows, b) y
+        const int r0 = LOWER ? o + nb : 0, r1 = LOWER ? ns : o;
+        for (int idx = tid; idx < (r1 - r0 + nb) * nrhs; idx += 256) {
+            const int rr = idx % (r1 - r0 + nb), q = idx / (r1 - r0 + nb);
+            if (rr < nb) { xs[o + rr + q * ns] = ys[rr + q * DB]; continue; }
+            const int i = r0 + (rr - nb);
+            double a = 0.0;
+            for (int c = 0; c < nb; ++c) a += A[i + (size_t) (o + c) * lda] * ys[c + q * DB];
+            xs[i + q * ns] -= a;
         }
+        __syncthreads();
     }
     for (int idx = tid; idx < ns * nrhs; idx += 256) x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = xs[idx];
 }
@@ -1040,8 +1101,7 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
     HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
     H->st.bytes_device = (int64_t) ((hs.nnzL + hs.nnzU) * sizeof(double) + idxb);
@@ -1095,16 +1155,14 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
         const size_t lds = S.diag_lds[l];
-        const int mxp = (mx + 31) & ~31;
-        const size_t lds_tr = (size_t) (mxp * XS + 2 * 32 * XS) * sizeof(double);
+        const size_t lds_tr = trsm_lds_bytes((mx + 31) & ~31);
         ev_begin(H, H->ev_panel, H->ev_panel_used);
         hipLaunchKernelGGL(k_diag_lu, dim3(nn), dim3(256), lds, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
         hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, s, T, nodes, S.d_inv_prefix + po, nn);
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
-        if (nl) hipLaunchKernelGGL(k_panel_trsm<0>, dim3(nl), dim3(256), lds_tr, s, T, nodes, S.d_ltr_prefix + po, nn);
-        if (nu) hipLaunchKernelGGL(k_panel_trsm<1>, dim3(nu), dim3(256), lds_tr, s, T, nodes, S.d_utr_prefix + po, nn);
+        if (nl + nu) hipLaunchKernelGGL(k_panel_trsm, dim3(nl + nu), dim3(256), lds_tr, s, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
         ev_end(H, H->ev_panel, H->ev_panel_used);
-        H->st.num_launches += 2 + (nl > 0) + (nu > 0);
+        H->st.num_launches += 2 + (nl + nu > 0);
         // Schur update: group 0 = 128x128-tile supernodes, group 1 = 64x64-tile supernodes
         const int nbig = S.n_big[l];
         for (int g = 0; g < 2; ++g) {
@@ -1132,8 +1190,16 @@ static int run_solve(Handle *H, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
-    const size_t lds = (size_t) H->max_nsupc * nrhs * sizeof(double);
-    if (lds > 64 * 1024) { set_error("nrhs too large for the LDS-staged solve (max_nsupc*nrhs*8 must be <= 64 KiB)"); return SLUAMD_EINVAL; }
+    const size_t lds = (size_t) (H->max_nsupc + 32) * nrhs * sizeof(double);
+    if (lds > 64 * 1024) { set_error("nrhs too large for the LDS-staged solve ((max_nsupc+32)*nrhs*8 must be <= 64 KiB)"); return SLUAMD_EINVAL; }
+    if (!H->dinv_ready) {   // factors were uploaded already factored: build the diagonal sub-block inverses once
+        for (auto &S : H->sched)
+            for (int l = 0; l < S.nlevels; ++l) {
+                const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+                hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, s, T, S.d_nodes + n0, S.d_inv_prefix + po, nn);
+            }
+        H->dinv_ready = true;
+    }
     // forward: Z levels ascending, DAG levels ascending
     for (size_t z = 0; z < H->sched.size(); ++z) {
         LevelSched &S = H->sched[z];
@@ -1240,6 +1306,7 @@ int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
 {
     if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
     HIPCHK(hipSetDevice(h->H.device));
+    h->H.dinv_ready = false;
     return upload_values(&h->H, lu);
 }
 
@@ -1266,6 +1333,7 @@ int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info)
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
+    H->dinv_ready = true;
     H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
     H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
     H->st.tiny_pivots = res[1];
@@ -1287,6 +1355,7 @@ int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh)
     int rc = run_factor_sched(H, H->sched[zlevel], thresh);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(H->stream));
+    if (zlevel == (int) H->sched.size() - 1) H->dinv_ready = true;
     return 0;
 }
 
@@ -1444,6 +1513,7 @@ int sluamd_dResetValues(sluamd_handle_t h)
     if (!h || !h->H.d_apos) { set_error("handle has no device-side copy of A"); return SLUAMD_EINVAL; }
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
+    H->dinv_ready = false;
     HIPCHK(hipMemsetAsync(H->d_val, 0, sizeof(double) * (H->hs.nnzL + H->hs.nnzU), H->stream));
     if (H->a_nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((H->a_nnz + 255) / 256)), dim3(256), 0, H->stream,
                                      H->d_val, H->d_apos, H->d_aval, H->a_nnz);
