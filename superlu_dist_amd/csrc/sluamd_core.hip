@@ -156,133 +156,137 @@ __device__ __forceinline__ void pivot_fix(double *p, int col1based, int replace_
     *s_piv = v;
 }
 
-// Unpivoted LU of an nb x nb (nb <= 32) block held in LDS, executed by ONE wave without barriers: lane c owns
-// column c; LDS operations of a wave complete in program order.
-__device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, int replace_tiny, double thresh, int *info)
+__device__ __forceinline__ double lane_bcast(double v, int src_lane)
+{   // wave-uniform source lane (compile-time after unrolling) -> v_readlane_b32 x2, no LDS
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Unpivoted LU of the nb x nb (nb <= 32) block at P (LDS, column-major, ld), executed by ONE wave entirely in
+// registers: lane r holds row r (identity-padded to 32), pivot rows are broadcast with v_readlane.
+// s_rinv[j] receives 1/U(j,j) (1 for a zero pivot, which leaves the column unscaled like pdgstrf2.c:566-575).
+__device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, int replace_tiny, double thresh,
+                                          int *info, double *s_rinv)
 {
     const int lane = threadIdx.x & 63;
-    for (int j = 0; j < nb; ++j) {
-        double p = P[j * ld + j];
-        if (replace_tiny && fabs(p) < thresh) {
-            p = (p < 0) ? -thresh : thresh;
-            if (lane == 0) { P[j * ld + j] = p; atomicAdd(&info[1], 1); }
+    double a[DB];
+#pragma unroll
+    for (int c = 0; c < DB; ++c) a[c] = (lane < nb && c < nb) ? P[c * ld + lane] : ((c == lane) ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < DB; ++j) {
+        double p = lane_bcast(a[j], j);
+        if (j < nb) {
+            if (replace_tiny && fabs(p) < thresh) {
+                p = (p < 0) ? -thresh : thresh;
+                if (lane == j) a[j] = p;
+                if (lane == 0) atomicAdd(&info[1], 1);
+            }
+            if (p == 0.0 && lane == 0) atomicMin(&info[0], col1 + j);
         }
-        if (p == 0.0 && lane == 0) atomicMin(&info[0], col1 + j);
-        const double rinv = (p != 0.0) ? 1.0 / p : 1.0;   // zero pivot: column left unscaled (pdgstrf2.c:566-575)
-        const double u = (lane > j && lane < nb) ? P[lane * ld + j] : 0.0;
-        for (int i = j + 1; i < nb; ++i) {
-            const double l = P[j * ld + i] * rinv;
-            if (lane == j) P[j * ld + i] = l;
-            else if (lane > j && lane < nb) P[lane * ld + i] -= l * u;
+        const double rinv = (p != 0.0) ? 1.0 / p : 1.0;
+        if (lane == 0) s_rinv[j] = rinv;
+        const bool below = lane > j;
+        const double l = a[j] * rinv;
+        if (below) a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < DB; ++c) {
+            const double u = lane_bcast(a[c], j);
+            if (below) a[c] -= l * u;
+            if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the broadcast SGPRs
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int c = 0; c < DB; ++c) if (lane < nb && c < nb) P[c * ld + lane] = a[c];
 }
 
-// rows below an already factored nb x nb block: x U11 = a, one thread per row, in place.
-// element (row, j) at X[j * ld]; U11(kk, j) at U[j * ld + kk]
-__device__ __forceinline__ void row_solve_upper(double *X, const double *U, int ld, int nb)
-{
-    for (int j = 0; j < nb; ++j) {
-        double a = X[j * ld];
-        for (int kk = 0; kk < j; ++kk) a -= X[kk * ld] * U[j * ld + kk];
-        X[j * ld] = a / U[j * ld + j];
-    }
-}
-
+// Blocked right-looking LU of the diagonal block in place in HBM/L2 (the block is re-read through L2 only):
+// per 32 columns: panel -> LDS, 32x32 head factored in registers by one wave, rows below solved one per thread
+// in registers, U12 one column per thread in registers, rank-32 trailing update on fp64 MFMA.
+// NSMAX (64/128/256) fixes the LDS strides at compile time so that the unrolled substitutions address LDS with
+// immediate offsets.
+template <int NSMAX>
 __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restrict__ nodes,
                                                  int replace_tiny, double thresh, int *__restrict__ info)
 {
-    extern __shared__ double s_a[];
+    __shared__ double s_a[DB * (NSMAX + 1) + DB * NSMAX];
+    __shared__ double s_rinv[DB];
     const int k = nodes[blockIdx.x];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     double *A = T.val + T.sn_lval[k];
-    const int tid = threadIdx.x, wave = tid >> 6;
-    if (ns <= 128) {
-        // whole block in LDS, right-looking blocked by 32
-        const int ld = ns | 1;
-        double *W = s_a;
-        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; W[i + j * ld] = A[i + (size_t) j * lda]; }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *Ps = s_a;                       // column panel: element (r, c) at Ps[c * ldp + r], DB x ldp
+    constexpr int ldp = NSMAX + 1;
+    double *Us = s_a + DB * ldp;            // U12 block row: element (kk, c) at Us[kk * lus + c], DB x lus
+    constexpr int lus = NSMAX;
+    for (int jb = 0; jb < ns; jb += DB) {
+        const int nb = min(DB, ns - jb), m = ns - jb, nc = m - nb;
+        for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; Ps[c * ldp + r] = A[jb + r + (size_t) (jb + c) * lda]; }
         __syncthreads();
-        for (int jb = 0; jb < ns; jb += DB) {
-            const int m = ns - jb, nb = min(DB, m), nc = m - nb;
-            if (wave == 0) wave_lu32(W + jb * ld + jb, ld, nb, fst + jb + 1, replace_tiny, thresh, info);
-            __syncthreads();
-            if (nc > 0) {
-                if (tid < nc) row_solve_upper(W + jb * ld + jb + nb + tid, W + jb * ld + jb, ld, nb);
-                else if (tid >= 128 && tid < 128 + nc) {  // U12 column: L11 x = a (unit lower)
-                    double *col = W + (jb + nb + (tid - 128)) * ld + jb;
-                    for (int i2 = 1; i2 < nb; ++i2) {
-                        double a = col[i2];
-                        for (int kk = 0; kk < i2; ++kk) a -= W[(jb + kk) * ld + jb + i2] * col[kk];
-                        col[i2] = a;
-                    }
-                }
-                __syncthreads();
-                for (int r = (tid & 63); r < nc; r += 64) {
-                    double l[DB];
+        if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info, s_rinv);
+        __syncthreads();
+        if (tid < nc) {   // L21 row: x U11 = a   (nc > 0 implies nb == 32)
+            double x[DB];
 #pragma unroll
-                    for (int kk = 0; kk < DB; ++kk) l[kk] = (kk < nb) ? W[(jb + kk) * ld + jb + nb + r] : 0.0;
-                    for (int c = wave; c < nc; c += 4) {
-                        const double *uc = W + (jb + nb + c) * ld + jb;
-                        double a = 0.0;
+            for (int c = 0; c < DB; ++c) x[c] = Ps[c * ldp + nb + tid];
 #pragma unroll
-                        for (int kk = 0; kk < DB; ++kk) a += l[kk] * ((kk < nb) ? uc[kk] : 0.0);
-                        W[(jb + nb + c) * ld + jb + nb + r] -= a;
-                    }
-                }
-                __syncthreads();
+            for (int j = 0; j < DB; ++j) {
+                double acc = x[j];
+#pragma unroll
+                for (int kk = 0; kk < j; ++kk) acc -= x[kk] * Ps[j * ldp + kk];
+                x[j] = acc * s_rinv[j];
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int c = 0; c < DB; ++c) Ps[c * ldp + nb + tid] = x[c];
         }
-        for (int idx = tid; idx < ns * ns; idx += 256) { int i = idx % ns, j = idx / ns; A[i + (size_t) j * lda] = W[i + j * ld]; }
-    } else {
-        // 128 < ns <= 256: matrix stays in HBM/L2; Ps = column panel [c][r], Us = U12 block row [kk][c]
-        double *Ps = s_a;                       // DB x (ns|1)
-        const int ldp = ns | 1;
-        double *Us = s_a + DB * ldp;            // DB x ns
-        for (int jb = 0; jb < ns; jb += DB) {
-            const int nb = min(DB, ns - jb), m = ns - jb;
-            for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; Ps[c * ldp + r] = A[jb + r + (size_t) (jb + c) * lda]; }
-            __syncthreads();
-            if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info);
-            __syncthreads();
-            if (tid < m - nb) row_solve_upper(Ps + nb + tid, Ps, ldp, nb);
-            __syncthreads();
-            for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
-            const int nc = ns - jb - nb;  // columns to the right
-            if (nc > 0) {
-                // U12 = L11^-1 A12 : stage A12 in LDS, one thread per column does the forward substitution there
-                for (int idx = tid; idx < nb * nc; idx += 256) { int i2 = idx % nb, c = idx / nb; Us[i2 * ns + c] = A[jb + i2 + (size_t) (jb + nb + c) * lda]; }
-                __syncthreads();
-                for (int c = tid; c < nc; c += 256) {
-#pragma unroll 1
-                    for (int i2 = 1; i2 < nb; ++i2) {
-                        double a = Us[i2 * ns + c];
-#pragma unroll 4
-                        for (int kk = 0; kk < i2; ++kk) a -= Ps[kk * ldp + i2] * Us[kk * ns + c];
-                        Us[i2 * ns + c] = a;
-                    }
+        __syncthreads();
+        for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
+        if (nc > 0) {
+            // U12 = L11^-1 A12 : one thread per column, forward substitution in registers
+            for (int c = tid; c < nc; c += 256) {
+                double *col = A + jb + (size_t) (jb + nb + c) * lda;
+                double x[DB];
+#pragma unroll
+                for (int i2 = 0; i2 < DB; ++i2) x[i2] = col[i2];
+#pragma unroll
+                for (int i2 = 1; i2 < DB; ++i2) {
+                    double acc = x[i2];
+#pragma unroll
+                    for (int kk = 0; kk < i2; ++kk) acc -= Ps[kk * ldp + i2] * x[kk];
+                    x[i2] = acc;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __syncthreads();
-                for (int idx = tid; idx < nb * nc; idx += 256) { int i2 = idx % nb, c = idx / nb; A[jb + i2 + (size_t) (jb + nb + c) * lda] = Us[i2 * ns + c]; }
-                if (nb < DB) for (int idx = tid; idx < (DB - nb) * nc; idx += 256) Us[(nb + idx / nc) * ns + idx % nc] = 0.0;
-                __syncthreads();
-                // A22 -= L21 * U12 : thread = row, L21 row in registers, U12 broadcast from LDS
-                for (int r = tid; r < nc; r += 256) {
-                    double l[DB];
 #pragma unroll
-                    for (int kk = 0; kk < DB; ++kk) l[kk] = (kk < nb) ? Ps[kk * ldp + nb + r] : 0.0;
-                    double *row = A + jb + nb + r + (size_t) (jb + nb) * lda;
-                    for (int c = 0; c < nc; ++c) {
-                        double a = 0.0;
+                for (int i2 = 0; i2 < DB; ++i2) { col[i2] = x[i2]; Us[i2 * lus + c] = x[i2]; }
+            }
+            __syncthreads();
+            // A22 -= L21 U12 on MFMA: 16x16 output blocks round-robin over the 4 waves; A := U12^T, B := L21^T so
+            // that the 16 fast lanes run along rows (contiguous in the column-major block)
+            const int nt = (nc + 15) >> 4;
+            for (int t = wave; t < nt * nt; t += 4) {
+                const int ti = t % nt, tj = t / nt;          // row block, column block
+                const int rr = min(ti * 16 + (lane & 15), nc - 1), cc = min(tj * 16 + (lane & 15), nc - 1);
+                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int kk = 0; kk < DB; ++kk) a += l[kk] * Us[kk * ns + c];
-                        row[(size_t) c * lda] -= a;
+                for (int k4 = 0; k4 < DB; k4 += 4) {
+                    const int kk = k4 + (lane >> 4);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kk * lus + cc], Ps[kk * ldp + nb + rr], acc, 0, 0, 0);
+                }
+                const int row = ti * 16 + (lane & 15);
+                if (row < nc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = tj * 16 + (lane >> 4) + 4 * r;
+                        if (col < nc) A[jb + nb + row + (size_t) (jb + nb + col) * lda] -= acc[r];
                     }
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -1020,7 +1024,7 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             const int nsupc = hs.xsup[k + 1] - hs.xsup[k];
             const int rrows = t.sn_nsupr[k] - nsupc;
             S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc);
-            S.diag_lds[l] = std::max(S.diag_lds[l], sizeof(double) * (nsupc <= 128 ? (size_t) nsupc * (nsupc | 1) : (size_t) 32 * (nsupc | 1) + (size_t) 32 * nsupc));
+            S.diag_lds[l] = std::max(S.diag_lds[l], sizeof(double) * ((size_t) 32 * (nsupc | 1) + (size_t) 32 * nsupc));
             S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + 31) / 32;
             S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + 31) / 32;
             S.inv_prefix[po + 1] = S.inv_prefix[po] + 2 * ((nsupc + 31) / 32);
@@ -1100,7 +1104,6 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
     H->st.num_levels = nlev;
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
-    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
@@ -1154,10 +1157,11 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
-        const size_t lds = S.diag_lds[l];
         const size_t lds_tr = trsm_lds_bytes((mx + 31) & ~31);
         ev_begin(H, H->ev_panel, H->ev_panel_used);
-        hipLaunchKernelGGL(k_diag_lu, dim3(nn), dim3(256), lds, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        if (mx <= 64) hipLaunchKernelGGL(k_diag_lu<64>, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
         hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, s, T, nodes, S.d_inv_prefix + po, nn);
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
         if (nl + nu) hipLaunchKernelGGL(k_panel_trsm, dim3(nl + nu), dim3(256), lds_tr, s, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);

@@ -1,6 +1,9 @@
 import os, sys
 import pytest
 
+# the CPU oracle's OpenMP loops are tiny: cap its threads (must be set before libgomp starts)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
