@@ -25,6 +25,7 @@
 #include "superlu_ddefs.h"
 
 static FILE *g_out = NULL;
+static double *g_b0 = NULL;   /* copy of the first right-hand side before the solve */
 static int g_solve_count = 0;
 
 static void put(const char *name, int dtype, long long count, const void *data)
@@ -155,7 +156,13 @@ int_t __wrap_pdgstrf3d(superlu_dist_options_t *options, int m, int n, double ano
         put_intt(nm, sf->topoInfo.numLvl + 1, sf->topoInfo.eTreeTopLims);
     }
     if (g_out) dump_lu("pre", LUstruct, grid, 0);
+#ifdef USE_SLUAMD   /* slu_ref_amd: the reference pipeline with OUR numeric factorisation (oracle/ref/sluamd_binding.c) */
+    extern int_t sluamd_bind_pdgstrf3d(superlu_dist_options_t *, int, int, double, dtrf3Dpartition_t *, SCT_t *,
+                                       dLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
+    int_t r = sluamd_bind_pdgstrf3d(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
+#else
     int_t r = __real_pdgstrf3d(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
+#endif
     if (g_out) dump_lu("post", LUstruct, grid, 1);
     put_i("info", *info);
     put_i("TinyPivots", stat->TinyPivots);
@@ -308,6 +315,11 @@ int main(int argc, char *argv[])
         put_i("opt_ColPerm", options.ColPerm); put_i("opt_IterRefine", options.IterRefine);
     }
 
+    {
+        NRformat_loc *As = (NRformat_loc *) A.Store;
+        g_b0 = (double *) malloc(8 * (size_t) (As->m_loc + 1));
+        for (int_t i = 0; i < As->m_loc; ++i) g_b0[i] = b[i];
+    }
     pdgssvx3d(&options, &A, &ScalePermstruct, b, ldb, nrhs, &grid, &LUstruct, &SOLVEstruct, berr, &stat, &info);
 
     {
@@ -327,6 +339,18 @@ int main(int argc, char *argv[])
     if (info) { if (!grid.iam) printf("ERROR: INFO = %d returned from pdgssvx3d()\n", info); }
     else if (!quiet) pdinf_norm_error(grid.iam, ((NRformat_loc *) A.Store)->m_loc, nrhs, b, ldb, xtrue, ldx, grid.comm);
     if (grid.zscp.Iam == 0 && !quiet) PStatPrint(&options, &stat, &(grid.grid2d));
+    {   /* residual on the original system, computed here for the drop-in test: ||b - A x||_2 / ||b||_2 (1 rank) */
+        NRformat_loc *As = (NRformat_loc *) A.Store;
+        if (grid.nprow * grid.npcol * grid.npdep == 1 && g_b0) {
+            double rn = 0, bn = 0;
+            for (int_t i = 0; i < As->m_loc; ++i) {
+                double s = g_b0[i];
+                for (int_t e = As->rowptr[i]; e < As->rowptr[i + 1]; ++e) s -= ((double *) As->nzval)[e] * b[As->colind[e]];
+                rn += s * s; bn += g_b0[i] * g_b0[i];
+            }
+            printf("RESIDUAL %.6e INFO %d\n", sqrt(rn / bn), info);
+        }
+    }
     if (!grid.iam) printf("REFTIMES n %ld FACT %.6f s SOLVE %.6f s ops_FACT %.6e\n", (long) n, stat.utime[FACT], stat.utime[SOLVE], (double) stat.ops[FACT]);
     if (g_out) fclose(g_out);
     fclose(fp);

@@ -1,0 +1,47 @@
+"""Drop-in test: the REAL reference pipeline (pdgssvx3d: equilibration, MC64, MMD ordering, symbolic factorisation,
+pddistribute3d, pdgstrs3d, refinement -- prebuilt from /root/reference into oracle/_ref/) with its pdgstrf3d call routed
+into libsluamd.so by the binding of INTEGRATION.md (oracle/ref/sluamd_binding.c).  The triangular solve that follows
+runs the reference's own CPU code on the factors our library copied back in the reference's formats."""
+import os, re, subprocess
+import numpy as np
+import pytest
+from superlu_dist_amd import matgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AMD = os.path.join(ROOT, "oracle", "_ref", "slu_ref_amd")
+REF = os.path.join(ROOT, "oracle", "_ref", "slu_ref_dump")
+
+
+def _run(binary, args, tmp_path):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    env.pop("LD_LIBRARY_PATH", None)          # the binaries carry RUNPATH=/opt/conda/lib for MPICH
+    r = subprocess.run([binary] + args, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"RESIDUAL (\S+) INFO (\d+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    return float(m.group(1)), int(m.group(2))
+
+
+@pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF)), reason="prebuilt reference binaries not shipped")
+@pytest.mark.parametrize("kind", ["poisson_nd", "unsym_defaults", "unsym_noprep_norefine"])
+def test_reference_pipeline_with_our_pdgstrf3d(kind, tmp_path):
+    if kind == "poisson_nd":
+        N = 12
+        n, rp, ci, v = matgen.poisson3d(N)
+        perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+        np.savetxt(tmp_path / "a.perm", perm, fmt="%d")
+        flags = ["-e", "0", "-p", "0", "-i", "0", "-P", str(tmp_path / "a.perm")]
+    elif kind == "unsym_defaults":
+        n, rp, ci, v = matgen.random_unsym(400, 0.02, seed=11)
+        flags = []                              # reference defaults: Equil, LargeDiag_MC64, MMD_AT_PLUS_A, refinement
+    else:
+        n, rp, ci, v = matgen.random_unsym(300, 0.03, seed=12)
+        flags = ["-i", "0"]                     # no refinement: the raw factorisation accuracy shows
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    args = ["-r", "1", "-c", "1", "-d", "1", "-Q", "1", "-o", "none"] + flags + [str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(AMD, args, tmp_path)
+    res_ref, info_ref = _run(REF, args, tmp_path)
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10       # BASELINE.json: within 1e-10 of the reference CPU pdgssvx3d
