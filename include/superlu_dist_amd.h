@@ -159,6 +159,13 @@ int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *h, sluamd_symb_t s, const sl
 int sluamd_symb_export(sluamd_symb_t s, sluamd_int_t *xsup, int64_t *lidx_off, sluamd_int_t *lidx, int64_t *lval_off,
                        double *lval, int64_t *uidx_off, sluamd_int_t *uidx, int64_t *uval_off, double *uval);
 void sluamd_symb_free(sluamd_symb_t s);
+/* 1 x 1 x npdep grids (Z sharding): elimination-forest partition (getForests' job, supernodalForest.c; tree ids in
+ * heap order like getGridTrees, supernodal_etree.c:840-851) and a handle that stores only layer `myz`'s sub-forest
+ * plus its ancestors. */
+int sluamd_symb_partition(sluamd_symb_t s, int32_t npdep, int32_t *sn_tree);
+int sluamd_dCreateLUHandleFromSymb3D(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                     const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
+                                     const sluamd_options_t *opt, int32_t npdep, int32_t myz, const int32_t *sn_tree);
 /* re-run the device-side distribution (zero-fill + scatter of A) on such a handle: refactor loops */
 int sluamd_dResetValues(sluamd_handle_t h);
 
@@ -168,6 +175,9 @@ int sluamd_set_profile(sluamd_handle_t h, int on);         /* per-kernel-family 
 int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh); /* one Z level of pdgstrf3d.c:333-385 */
 int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny_pivots);
 int sluamd_arena(sluamd_handle_t h, double **d_val, int64_t *nnzL, int64_t *nnzU); /* value arena [L | U] in HBM */
+int sluamd_local_offsets(sluamd_handle_t h, int64_t *lval_off, int64_t *uval_off); /* [nsupers+1] each */
+/* forward (dir=+1) / backward (dir=-1) solve of one Z level on a device-resident x (multi-rank orchestration) */
+int sluamd_pdgstrs3d_level(sluamd_handle_t h, int zlevel, int dir, double *d_x, int64_t ldx, int32_t nrhs);
 int sluamd_mfma_selftest(const double *A16x4, const double *B4x16, double *D16x16);
 
 #ifdef __cplusplus

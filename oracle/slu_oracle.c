@@ -418,22 +418,25 @@ int slu_oracle_dfactor(int n, int nsupers, const int *xsup,
  * (dlsum_fmod_inv, SRC/double/pdgstrs_lsum.c:414-700; leaf/non-leaf forward solves
  * SRC/double/pdgstrs3d.c:1819-2179).  Backward step: x_k <- inv(U_kk)(x_k - sum_j U_kj x_j)
  * (dlsum_bmod_inv, SRC/double/pdgstrs_lsum.c:1362-1700; dlsumBmod SRC/double/pdgstrs3d.c:3987).
- * Message-driven scheduling in the reference only reorders independent updates. */
-void slu_oracle_dsolve(int n, int nsupers, const int *xsup,
-                       const int64_t *Lrowind_off, const int *Lrowind, const int64_t *Lnzval_off, const double *Lnzval,
-                       const int64_t *Ufstnz_off, const int *Ufstnz, const int64_t *Unzval_off, const double *Unzval,
-                       double *x, int ldx, int nrhs)
+ * Message-driven scheduling in the reference only reorders independent updates.
+ * `nodes` (ascending, may be NULL = all supernodes) restricts the sweep to one elimination forest, which is how
+ * the 3D solve walks the Z levels (pdgsTrForwardSolve3d / pdgsTrBackSolve3d, pdgstrs3d.c:7312 / :7564). */
+void slu_oracle_dsolve_fwd(int n, int nsupers, const int *xsup,
+                           const int64_t *Lrowind_off, const int *Lrowind, const int64_t *Lnzval_off, const double *Lnzval,
+                           const int64_t *Ufstnz_off, const int *Ufstnz, const int64_t *Unzval_off, const double *Unzval,
+                           double *x, int ldx, int nrhs, const int *nodes, int nnodes)
 {
+    (void) n; (void) Ufstnz_off; (void) Ufstnz; (void) Unzval_off; (void) Unzval;
     int ldt = 1, maxr = 1;
     for (int k = 0; k < nsupers; ++k) {
         if (xsup[k + 1] - xsup[k] > ldt) ldt = xsup[k + 1] - xsup[k];
-        int r = (Lrowind + Lrowind_off[k])[1];
-        if (r > maxr) maxr = r;
+        if (Lrowind_off[k + 1] > Lrowind_off[k]) { int r = (Lrowind + Lrowind_off[k])[1]; if (r > maxr) maxr = r; }
     }
     double *rtemp = (double *) malloc(sizeof(double) * (size_t) maxr * nrhs);
     double *xk = (double *) malloc(sizeof(double) * (size_t) ldt * nrhs);
-    /* forward */
-    for (int k = 0; k < nsupers; ++k) {
+    const int cnt = nodes ? nnodes : nsupers;
+    for (int t = 0; t < cnt; ++t) {
+        const int k = nodes ? nodes[t] : t;
         const int *lsub = Lrowind + Lrowind_off[k];
         const double *lusup = Lnzval + Lnzval_off[k];
         int nb = lsub[0], nsupr = lsub[1], fst = xsup[k], nsupc = xsup[k + 1] - fst;
@@ -451,8 +454,18 @@ void slu_oracle_dsolve(int n, int nsupers, const int *xsup,
             luptr += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
     }
-    /* backward */
-    for (int k = nsupers - 1; k >= 0; --k) {
+    free(rtemp); free(xk);
+}
+
+void slu_oracle_dsolve_bwd(int n, int nsupers, const int *xsup,
+                           const int64_t *Lrowind_off, const int *Lrowind, const int64_t *Lnzval_off, const double *Lnzval,
+                           const int64_t *Ufstnz_off, const int *Ufstnz, const int64_t *Unzval_off, const double *Unzval,
+                           double *x, int ldx, int nrhs, const int *nodes, int nnodes)
+{
+    (void) n;
+    const int cnt = nodes ? nnodes : nsupers;
+    for (int t = cnt - 1; t >= 0; --t) {
+        const int k = nodes ? nodes[t] : t;
         int fst = xsup[k], klst = xsup[k + 1], nsupc = klst - fst;
         if (Ufstnz_off[k + 1] > Ufstnz_off[k]) {
             const int *usub = Ufstnz + Ufstnz_off[k];
@@ -478,7 +491,15 @@ void slu_oracle_dsolve(int n, int nsupers, const int *xsup,
         const int *lsub = Lrowind + Lrowind_off[k];
         o_dtrsm_lunn(nsupc, nrhs, Lnzval + Lnzval_off[k], lsub[1], x + fst, ldx);
     }
-    free(rtemp); free(xk);
+}
+
+void slu_oracle_dsolve(int n, int nsupers, const int *xsup,
+                       const int64_t *Lrowind_off, const int *Lrowind, const int64_t *Lnzval_off, const double *Lnzval,
+                       const int64_t *Ufstnz_off, const int *Ufstnz, const int64_t *Unzval_off, const double *Unzval,
+                       double *x, int ldx, int nrhs)
+{
+    slu_oracle_dsolve_fwd(n, nsupers, xsup, Lrowind_off, Lrowind, Lnzval_off, Lnzval, Ufstnz_off, Ufstnz, Unzval_off, Unzval, x, ldx, nrhs, NULL, 0);
+    slu_oracle_dsolve_bwd(n, nsupers, xsup, Lrowind_off, Lrowind, Lnzval_off, Lnzval, Ufstnz_off, Ufstnz, Unzval_off, Unzval, x, ldx, nrhs, NULL, 0);
 }
 
 int slu_oracle_num_threads(void)

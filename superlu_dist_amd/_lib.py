@@ -83,6 +83,11 @@ def load():
     L.sluamd_arena.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sluamd_mfma_selftest.argtypes = [P_dbl, P_dbl, P_dbl]
     L.sluamd_dResetValues.argtypes = [C.c_void_p]
+    L.sluamd_symb_partition.argtypes = [C.c_void_p, C.c_int32, P_int]
+    L.sluamd_dCreateLUHandleFromSymb3D.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int,
+                                                   C.POINTER(Options), C.c_int32, C.c_int32, P_int]
+    L.sluamd_local_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.sluamd_pdgstrs3d_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_set_profile.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L

@@ -847,9 +847,16 @@ static int flatten_view(const sluamd_dLUview_t *lu, HostStruct &hs, bool want_si
     hs.xsup.assign(lu->xsup, lu->xsup + ns + 1);
     hs.lidx_off.assign(ns + 1, 0); hs.uidx_off.assign(ns + 1, 0);
     hs.lval_off.assign(ns + 1, 0); hs.uval_off.assign(ns + 1, 0);
+    hs.present.assign(ns, 1);
     for (int k = 0; k < ns; ++k) {
         const int *li = lu->Lrowind_bc_ptr[k];
-        if (!li) { set_error("L panel missing on a 1x1 grid"); return SLUAMD_ESTRUCT; }
+        if (!li) {   // panel of another Z layer's forest: not stored on this rank
+            if (lu->npdep == 1) { set_error("L panel missing on a 1x1x1 grid"); return SLUAMD_ESTRUCT; }
+            hs.present[k] = 0;
+            hs.lidx_off[k + 1] = hs.lidx_off[k]; hs.lval_off[k + 1] = hs.lval_off[k];
+            hs.uidx_off[k + 1] = hs.uidx_off[k]; hs.uval_off[k + 1] = hs.uval_off[k];
+            continue;
+        }
         const int nsupc = hs.xsup[k + 1] - hs.xsup[k];
         hs.lidx_off[k + 1] = hs.lidx_off[k] + BC_HEADER + (int64_t) li[0] * LB_DESCRIPTOR + li[1];
         hs.lval_off[k + 1] = hs.lval_off[k] + (int64_t) li[1] * nsupc;
@@ -860,6 +867,7 @@ static int flatten_view(const sluamd_dLUview_t *lu, HostStruct &hs, bool want_si
     hs.nnzL = hs.lval_off[ns]; hs.nnzU = hs.uval_off[ns];
     hs.lidx.resize(hs.lidx_off[ns]); hs.uidx.resize(hs.uidx_off[ns]);
     for (int k = 0; k < ns; ++k) {
+        if (!hs.present[k]) continue;
         std::memcpy(hs.lidx.data() + hs.lidx_off[k], lu->Lrowind_bc_ptr[k], sizeof(int) * (hs.lidx_off[k + 1] - hs.lidx_off[k]));
         if (hs.uidx_off[k + 1] > hs.uidx_off[k])
             std::memcpy(hs.uidx.data() + hs.uidx_off[k], lu->Ufstnz_br_ptr[k], sizeof(int) * (hs.uidx_off[k + 1] - hs.uidx_off[k]));
@@ -892,6 +900,13 @@ static int build_tables(Handle &H, HostTables &t)
     st.flops_schur_padded = st.flops_schur_exact = st.flops_panel = 0;
     for (int k = 0; k < ns; ++k) {
         const int nsupc = hs.xsup[k + 1] - hs.xsup[k], klst = hs.xsup[k + 1];
+        if (!hs.present[k]) {
+            t.sn_lval[k] = t.sn_uval[k] = t.sn_lidx[k] = t.sn_uidx[k] = 0; t.sn_dinv[k] = t.dinv_total;
+            t.sn_nsupr[k] = 0; t.sn_lb_off[k] = (int) t.lb_gid.size(); t.sn_nlb[k] = 0; t.sn_ub_off[k] = (int) t.ub_gid.size(); t.sn_nub[k] = 0;
+            t.sn_rt_off[k] = (int) t.rtile.size(); t.sn_nrt[k] = 0; t.sn_ct_off[k] = (int) t.ctile.size(); t.sn_nct[k] = 0;
+            t.sn_big.push_back(0);
+            continue;
+        }
         H.max_nsupc = std::max(H.max_nsupc, nsupc);
         if (nsupc > 256) { set_error("supernodes wider than 256 columns are not supported yet (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
         t.sn_dinv[k] = t.dinv_total;
@@ -1046,7 +1061,7 @@ static int upload_schedule(Handle &H, LevelSched &S)
     return 0;
 }
 
-static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
+static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const std::vector<std::vector<int>> *given_lists = nullptr)
 {
     HostTables t;
     int rc = build_tables(*H, t);
@@ -1079,7 +1094,9 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
 #undef UP
     // ---- schedules ----
     std::vector<std::vector<int>> lists;
-    if (forests && forests->maxLvl > 0 && forests->nodeList) {
+    if (given_lists) {
+        lists = *given_lists;
+    } else if (forests && forests->maxLvl > 0 && forests->nodeList) {
         for (int l = 0; l < forests->maxLvl; ++l) {
             std::vector<int> v;
             if (!forests->myZeroTrIdxs[l]) {
@@ -1090,10 +1107,13 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests)
             lists.push_back(std::move(v));
         }
     } else {
-        std::vector<int> v(hs.nsupers);
-        std::iota(v.begin(), v.end(), 0);
+        std::vector<int> v;
+        for (int k = 0; k < hs.nsupers; ++k) if (hs.present[k]) v.push_back(k);
         lists.push_back(std::move(v));
     }
+    for (auto &l : lists)
+        for (int k : l)
+            if (k < 0 || k >= hs.nsupers || !hs.present[k]) { set_error("forest node list names a supernode that is not stored on this rank"); return SLUAMD_ESTRUCT; }
     H->sched.resize(lists.size());
     int nlev = 0;
     for (size_t i = 0; i < lists.size(); ++i) {
@@ -1190,7 +1210,34 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     return 0;
 }
 
-static int run_solve(Handle *H, double *d_x, int64_t ldx, int nrhs)
+// forward / backward block solves of one Z level (one elimination forest): DAG levels ascending / descending
+static void solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs, size_t lds)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    LevelSched &S = H->sched[z];
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, d_x, ldx, nrhs);
+        const int nf = S.fwd_prefix[po + nn];
+        if (nf) hipLaunchKernelGGL(k_fwd_update, dim3(nf), dim3(256), lds, s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, d_x, ldx, nrhs);
+    }
+}
+static void solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs, size_t lds)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    LevelSched &S = H->sched[z];
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        const int nb = S.bwd_prefix[po + nn];
+        if (nb) hipLaunchKernelGGL(k_bwd_update, dim3(nb), dim3(256), 0, s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, d_x, ldx, nrhs);
+        hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, d_x, ldx, nrhs);
+    }
+}
+
+// dir: +1 forward only, -1 backward only, 0 both; zsel: one Z level or -1 = all
+static int run_solve(Handle *H, double *d_x, int64_t ldx, int nrhs, int dir = 0, int zsel = -1)
 {
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
@@ -1204,25 +1251,8 @@ static int run_solve(Handle *H, double *d_x, int64_t ldx, int nrhs)
             }
         H->dinv_ready = true;
     }
-    // forward: Z levels ascending, DAG levels ascending
-    for (size_t z = 0; z < H->sched.size(); ++z) {
-        LevelSched &S = H->sched[z];
-        for (int l = 0; l < S.nlevels; ++l) {
-            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
-            hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, d_x, ldx, nrhs);
-            const int nf = S.fwd_prefix[po + nn];
-            if (nf) hipLaunchKernelGGL(k_fwd_update, dim3(nf), dim3(256), lds, s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, d_x, ldx, nrhs);
-        }
-    }
-    for (int z = (int) H->sched.size() - 1; z >= 0; --z) {
-        LevelSched &S = H->sched[z];
-        for (int l = S.nlevels - 1; l >= 0; --l) {
-            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
-            const int nb = S.bwd_prefix[po + nn];
-            if (nb) hipLaunchKernelGGL(k_bwd_update, dim3(nb), dim3(256), 0, s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, d_x, ldx, nrhs);
-            hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, d_x, ldx, nrhs);
-        }
-    }
+    for (int z = 0; z < (int) H->sched.size(); ++z) if (zsel < 0 || zsel == z) if (dir >= 0) solve_fwd_z(H, z, d_x, ldx, nrhs, lds);
+    for (int z = (int) H->sched.size() - 1; z >= 0; --z) if (zsel < 0 || zsel == z) if (dir <= 0) solve_bwd_z(H, z, d_x, ldx, nrhs, lds);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1359,7 +1389,7 @@ int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh)
     int rc = run_factor_sched(H, H->sched[zlevel], thresh);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(H->stream));
-    if (zlevel == (int) H->sched.size() - 1) H->dinv_ready = true;
+    H->dinv_ready = true;   // inverses of every level this rank factors are written by that level's kernels
     return 0;
 }
 
@@ -1469,12 +1499,23 @@ int sluamd_arena(sluamd_handle_t h, double **d_val, int64_t *nnzL, int64_t *nnzU
     return 0;
 }
 
-int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr,
-                                   const sluamd_int_t *colind, const double *nzval,
-                                   const sluamd_int_t *perm_c_final, const sluamd_options_t *opt)
+// tree ids on the path of layer z: tree(ilvl) as getGridTrees (supernodal_etree.c:840-851)
+static void path_trees(int npdep, int myz, std::vector<int> &trees)
+{
+    int maxLvl = 1;
+    while ((1 << (maxLvl - 1)) < npdep) ++maxLvl;
+    trees.resize(maxLvl);
+    trees[0] = npdep - 1 + myz;
+    for (int i = 1; i < maxLvl; ++i) trees[i] = (trees[i - 1] - 1) / 2;
+}
+
+static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                            const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
+                            const sluamd_options_t *opt, int npdep, int myz, const int32_t *sn_tree)
 {
     if (!out || !s) { set_error("null argument"); return SLUAMD_EINVAL; }
     *out = nullptr;
+    if (npdep < 1 || (npdep & (npdep - 1)) || myz < 0 || myz >= npdep || (npdep > 1 && !sn_tree)) { set_error("bad 1x1xPz arguments"); return SLUAMD_EINVAL; }
     sluamd_options_t o;
     if (opt) o = *opt; else sluamd_default_options(&o);
     int rc = check_device(o.device);
@@ -1483,8 +1524,46 @@ int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const 
     auto *hh = new sluamd_lu_handle_s();
     Handle *H = &hh->H;
     H->opt = o;
+    H->Pz = npdep; H->myz = myz;
     HIPCHK(hipGetDevice(&H->device));
-    H->hs = sy->hs;  // structure copy (index arrays only)
+    const HostStruct &full = sy->hs;
+    const int ns = full.nsupers;
+    std::vector<uint8_t> owned;
+    std::vector<std::vector<int>> lists;
+    if (npdep == 1) {
+        H->hs = full;  // structure copy (index arrays only)
+    } else {
+        // local subset: my leaf tree + the ancestor trees on my path; A's entries of an ancestor tree live on the
+        // first layer of the group that shares it (the one that will factor it), dinit3DLUstructForest's rule
+        std::vector<int> trees;
+        path_trees(npdep, myz, trees);
+        const int maxLvl = (int) trees.size();
+        HostStruct &hs = H->hs;
+        hs.n = full.n; hs.nsupers = ns; hs.xsup = full.xsup;
+        hs.present.assign(ns, 0); owned.assign(ns, 0);
+        lists.assign(maxLvl, {});
+        for (int k = 0; k < ns; ++k)
+            for (int l = 0; l < maxLvl; ++l)
+                if (sn_tree[k] == trees[l]) {
+                    hs.present[k] = 1;
+                    if (myz % (1 << l) == 0) { owned[k] = 1; lists[l].push_back(k); }
+                }
+        hs.lidx_off.assign(ns + 1, 0); hs.uidx_off.assign(ns + 1, 0); hs.lval_off.assign(ns + 1, 0); hs.uval_off.assign(ns + 1, 0);
+        for (int k = 0; k < ns; ++k) {
+            const int p = hs.present[k];
+            hs.lidx_off[k + 1] = hs.lidx_off[k] + (p ? full.lidx_off[k + 1] - full.lidx_off[k] : 0);
+            hs.uidx_off[k + 1] = hs.uidx_off[k] + (p ? full.uidx_off[k + 1] - full.uidx_off[k] : 0);
+            hs.lval_off[k + 1] = hs.lval_off[k] + (p ? full.lval_off[k + 1] - full.lval_off[k] : 0);
+            hs.uval_off[k + 1] = hs.uval_off[k] + (p ? full.uval_off[k + 1] - full.uval_off[k] : 0);
+        }
+        hs.nnzL = hs.lval_off[ns]; hs.nnzU = hs.uval_off[ns];
+        hs.lidx.resize(hs.lidx_off[ns]); hs.uidx.resize(hs.uidx_off[ns]);
+        for (int k = 0; k < ns; ++k) {
+            if (!hs.present[k]) continue;
+            std::copy(full.lidx.begin() + full.lidx_off[k], full.lidx.begin() + full.lidx_off[k + 1], hs.lidx.begin() + hs.lidx_off[k]);
+            std::copy(full.uidx.begin() + full.uidx_off[k], full.uidx.begin() + full.uidx_off[k + 1], hs.uidx.begin() + hs.uidx_off[k]);
+        }
+    }
     const HostStruct &hs = H->hs;
     const int64_t tot = hs.nnzL + hs.nnzU;
     if (hipMalloc((void **) &H->d_val, sizeof(double) * std::max<int64_t>(tot, 1)) != hipSuccess) {
@@ -1493,20 +1572,62 @@ int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const 
     HIPCHK(hipMemset(H->d_val, 0, sizeof(double) * tot));
     {   // device-side distribution of A's values
         std::vector<int64_t> pos; std::vector<uint8_t> isu;
-        compute_scatter_positions(*sy, hs.n, rowptr, colind, perm_c_final, pos, isu);
-        const int64_t nnz = (int64_t) pos.size();
-        for (int64_t e = 0; e < nnz; ++e) if (isu[e]) pos[e] += hs.nnzL;
+        compute_scatter_positions(*sy, hs, hs.n, rowptr, colind, perm_c_final, owned.empty() ? nullptr : owned.data(), pos, isu);
+        std::vector<int64_t> pos2; std::vector<double> val2;
+        pos2.reserve(pos.size()); val2.reserve(pos.size());
+        for (size_t e = 0; e < pos.size(); ++e)
+            if (pos[e] >= 0) { pos2.push_back(pos[e] + (isu[e] ? hs.nnzL : 0)); val2.push_back(nzval[e]); }
+        const int64_t nnz = (int64_t) pos2.size();
         HIPCHK(hipMalloc((void **) &H->d_apos, sizeof(int64_t) * std::max<int64_t>(nnz, 1)));
         HIPCHK(hipMalloc((void **) &H->d_aval, sizeof(double) * std::max<int64_t>(nnz, 1)));
         H->a_nnz = nnz;
-        HIPCHK(hipMemcpy(H->d_apos, pos.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(H->d_aval, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(H->d_apos, pos2.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(H->d_aval, val2.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
         if (nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, 0, H->d_val, H->d_apos, H->d_aval, nnz);
         HIPCHK(hipDeviceSynchronize());
     }
-    rc = finish_create(H, nullptr);
+    rc = finish_create(H, nullptr, lists.empty() ? nullptr : &lists);
     if (rc) { sluamd_dDestroyLUHandle(hh); return rc; }
     *out = hh;
+    return 0;
+}
+
+int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                   const sluamd_int_t *colind, const double *nzval,
+                                   const sluamd_int_t *perm_c_final, const sluamd_options_t *opt)
+{
+    return create_from_symb(out, s, rowptr, colind, nzval, perm_c_final, opt, 1, 0, nullptr);
+}
+
+// 1 x 1 x npdep grid: this rank = Z layer `myz`; sn_tree from sluamd_symb_partition.  Stores only the layer's own
+// sub-forest and its ancestors (replicated ancestors start from zero except on their owner layer).
+int sluamd_dCreateLUHandleFromSymb3D(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                     const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
+                                     const sluamd_options_t *opt, int32_t npdep, int32_t myz, const int32_t *sn_tree)
+{
+    return create_from_symb(out, s, rowptr, colind, nzval, perm_c_final, opt, npdep, myz, sn_tree);
+}
+
+// offsets of every supernode's L panel / U row inside this rank's value arena ([L | U]; U offsets relative to the
+// U half) -- the multi-rank orchestration reduces ancestor slices with them
+int sluamd_local_offsets(sluamd_handle_t h, int64_t *lval_off, int64_t *uval_off)
+{
+    if (!h) return SLUAMD_EINVAL;
+    const HostStruct &hs = h->H.hs;
+    if (lval_off) std::copy(hs.lval_off.begin(), hs.lval_off.end(), lval_off);
+    if (uval_off) std::copy(hs.uval_off.begin(), hs.uval_off.end(), uval_off);
+    return 0;
+}
+
+// forward (dir=+1) or backward (dir=-1) block solve restricted to one Z level, device-resident x
+int sluamd_pdgstrs3d_level(sluamd_handle_t h, int zlevel, int dir, double *d_x, int64_t ldx, int32_t nrhs)
+{
+    if (!h || !d_x || zlevel < 0 || zlevel >= (int) h->H.sched.size() || (dir != 1 && dir != -1)) { set_error("bad level-solve arguments"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    int rc = run_solve(H, d_x, ldx, nrhs, dir, zlevel);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(H->stream));
     return 0;
 }
 

@@ -25,6 +25,7 @@ struct HostStruct {
     std::vector<int64_t> lval_off, uval_off;  // [nsupers+1] into the value arena halves
     std::vector<int> lidx, uidx;
     int64_t nnzL = 0, nnzU = 0;
+    std::vector<uint8_t> present;          // [nsupers] 0 = panel/row not stored on this rank (other Z layer's forest)
 };
 
 // Symbolic object behind sluamd_symb_t
@@ -41,7 +42,12 @@ struct Symb {
 };
 
 // positions of A's entries inside the value arena: out_pos[e] (into L arena if is_u[e]==0 else U arena)
-void compute_scatter_positions(const Symb &sy, int64_t n, const int *rowptr, const int *colind,
-                               const int *perm_c_final, std::vector<int64_t> &pos, std::vector<uint8_t> &is_u);
+// `hs` supplies the value offsets (it may be a local subset of sy.hs); `owned` (may be null) filters the entries
+// by destination supernode: entries whose destination is not owned get pos = -1.
+void compute_scatter_positions(const Symb &sy, const HostStruct &hs, int64_t n, const int *rowptr, const int *colind,
+                               const int *perm_c_final, const uint8_t *owned, std::vector<int64_t> &pos,
+                               std::vector<uint8_t> &is_u);
+// tree (heap-numbered, root 0) of every supernode for a 1 x 1 x npdep grid
+void partition_forests(const Symb &sy, int npdep, std::vector<int> &sn_tree);
 
 }  // namespace sluamd

@@ -236,6 +236,7 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
         if (ui) { ui[0] = nub; ui[1] = (int) (hs.uval_off[k + 1] - hs.uval_off[k]); ui[2] = q; }
     }
     sy->perm_c_final = perm;
+    hs.present.assign(ns, 1);
     *out = reinterpret_cast<sluamd_symb_t>(sy);
     return 0;
 }
@@ -286,7 +287,7 @@ int sluamd_ddistribute_host(sluamd_symb_t s, const sluamd_int_t *rowptr, const s
     HostStruct &hs = sy->hs;
     sy->lval.assign(hs.nnzL, 0.0); sy->uval.assign(hs.nnzU, 0.0);
     std::vector<int64_t> pos; std::vector<uint8_t> isu;
-    compute_scatter_positions(*sy, hs.n, rowptr, colind, perm_c_final ? perm_c_final : sy->perm_c_final.data(), pos, isu);
+    compute_scatter_positions(*sy, hs, hs.n, rowptr, colind, perm_c_final ? perm_c_final : sy->perm_c_final.data(), nullptr, pos, isu);
     for (size_t e = 0; e < pos.size(); ++e) (isu[e] ? sy->uval : sy->lval)[pos[e]] = nzval[e];
     return 0;
 }
@@ -317,10 +318,9 @@ void sluamd_symb_free(sluamd_symb_t s) { delete reinterpret_cast<Symb *>(s); }
 
 namespace sluamd {
 
-void compute_scatter_positions(const Symb &sy, int64_t n, const int *rowptr, const int *colind,
-                               const int *perm, std::vector<int64_t> &pos, std::vector<uint8_t> &is_u)
+void compute_scatter_positions(const Symb &sy, const HostStruct &hs, int64_t n, const int *rowptr, const int *colind,
+                               const int *perm, const uint8_t *owned, std::vector<int64_t> &pos, std::vector<uint8_t> &is_u)
 {
-    const HostStruct &hs = sy.hs;
     const int64_t nnz = rowptr[n];
     pos.resize(nnz); is_u.resize(nnz);
     auto rank_in = [&](int k, int row) -> int64_t {
@@ -332,6 +332,8 @@ void compute_scatter_positions(const Symb &sy, int64_t n, const int *rowptr, con
             const int pi = perm[i], pj = perm[colind[e]];
             const int s = sy.supno[pj];
             const int nsupc = hs.xsup[s + 1] - hs.xsup[s];
+            const int dest = (pi >= hs.xsup[s]) ? s : sy.supno[pi];
+            if (owned && !owned[dest]) { pos[e] = -1; is_u[e] = 0; continue; }
             if (pi >= hs.xsup[s]) {
                 const int nsupr = nsupc + (int) (sy.srow_off[s + 1] - sy.srow_off[s]);
                 const int64_t lr = (pi < hs.xsup[s + 1]) ? (pi - hs.xsup[s]) : nsupc + rank_in(s, pi);
@@ -346,4 +348,57 @@ void compute_scatter_positions(const Symb &sy, int64_t n, const int *rowptr, con
         }
 }
 
+
+// Elimination-forest partition for a 1 x 1 x npdep grid (what getForests does for the reference,
+// SRC/prec-independent/supernodalForest.c: greedy load balance "GD"; tree numbering = heap order as
+// getGridTrees, supernodal_etree.c:840-851): tree 0 = common ancestors, trees 2t+1 / 2t+2 = the two halves below.
+void partition_forests(const Symb &sy, int npdep, std::vector<int> &sn_tree)
+{
+    const HostStruct &hs = sy.hs;
+    const int ns = hs.nsupers;
+    int maxLvl = 1;
+    while ((1 << (maxLvl - 1)) < npdep) ++maxLvl;
+    sn_tree.assign(ns, 0);
+    std::vector<int> parent(ns, -1);
+    std::vector<double> w(ns, 0.0);
+    std::vector<std::vector<int>> child(ns);
+    for (int k = 0; k < ns; ++k) {
+        const int64_t r = sy.srow_off[k + 1] - sy.srow_off[k];
+        const double s = hs.xsup[k + 1] - hs.xsup[k];
+        w[k] += (2.0 / 3.0) * s * s * s + 2.0 * s * s * r + 2.0 * s * (double) r * r;
+        if (r > 0) { parent[k] = sy.supno[sy.srows[sy.srow_off[k]]]; child[parent[k]].push_back(k); }
+    }
+    for (int k = 0; k < ns; ++k) if (parent[k] >= 0) w[parent[k]] += w[k];   // subtree weights (postorder: k < parent)
+    struct Job { std::vector<int> roots; int tree, depth; };
+    std::vector<Job> stack;
+    Job top; top.tree = 0; top.depth = 0;
+    for (int k = 0; k < ns; ++k) if (parent[k] < 0) top.roots.push_back(k);
+    stack.push_back(top);
+    std::vector<int> st;
+    while (!stack.empty()) {
+        Job j = stack.back(); stack.pop_back();
+        if (j.depth == maxLvl - 1) {   // leaf tree: whole subtrees
+            st = j.roots;
+            while (!st.empty()) { int v = st.back(); st.pop_back(); sn_tree[v] = j.tree; for (int c : child[v]) st.push_back(c); }
+            continue;
+        }
+        std::vector<int> R = j.roots;
+        while (R.size() == 1 && !child[R[0]].empty()) { sn_tree[R[0]] = j.tree; R = child[R[0]]; }   // peel the common chain
+        std::sort(R.begin(), R.end(), [&](int a, int b) { return w[a] > w[b]; });
+        Job a, b; a.tree = 2 * j.tree + 1; b.tree = 2 * j.tree + 2; a.depth = b.depth = j.depth + 1;
+        double wa = 0, wb = 0;
+        for (int r : R) { if (wa <= wb) { a.roots.push_back(r); wa += w[r]; } else { b.roots.push_back(r); wb += w[r]; } }
+        stack.push_back(a); stack.push_back(b);
+    }
+}
+
 }  // namespace sluamd
+
+extern "C" int sluamd_symb_partition(sluamd_symb_t s, int32_t npdep, int32_t *sn_tree)
+{
+    if (!s || !sn_tree || npdep < 1 || (npdep & (npdep - 1))) { sluamd::set_error("npdep must be a power of two"); return SLUAMD_EINVAL; }
+    std::vector<int> t;
+    sluamd::partition_forests(*reinterpret_cast<sluamd::Symb *>(s), npdep, t);
+    std::copy(t.begin(), t.end(), sn_tree);
+    return 0;
+}

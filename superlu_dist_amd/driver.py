@@ -97,6 +97,17 @@ class Symbolic:
         _lib.check(L.sluamd_ddistribute_host(self._h, _pi(self.rowptr), _pi(self.colind), _pd(nz), _pi(self.perm_c)),
                    "sluamd_ddistribute_host")
 
+    def xsup(self):
+        xs = np.empty(self.nsupers + 1, dtype=np.int32)
+        _lib.check(_lib.load().sluamd_symb_export(self._h, _pi(xs), None, None, None, None, None, None, None, None), "sluamd_symb_export")
+        return xs
+
+    def partition(self, npdep):
+        """Tree id (heap order) of every supernode for a 1 x 1 x npdep grid."""
+        t = np.zeros(self.nsupers, dtype=np.int32)
+        _lib.check(_lib.load().sluamd_symb_partition(self._h, npdep, _pi(t)), "sluamd_symb_partition")
+        return t
+
     def flat_store(self, values=True):
         """Copy the host store out as a FlatStore (tests / CPU-baseline harness)."""
         L = _lib.load()

@@ -1,0 +1,245 @@
+"""Z-sharded (1 x 1 x Pz) orchestration of the hot path: one rank = one GPU = one Z layer.
+
+Mirrors the Z dimension of the reference's 3D algorithm:
+  * pdgstrf3d's level loop (SRC/double/pdgstrf3d.c:333-385): factor my forest of level ilvl, then the pairwise ancestor
+    reduction dreduceAllAncestors3d (SRC/double/pd3dcomm.c:1046-1081: sender = myGrid + 2^ilvl, receiver = myGrid when
+    myGrid % 2^(ilvl+1) == 0) -- here ONE send/recv per contiguous value-arena slice of the shared ancestor forests
+    followed by an add, over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests);
+  * pdgstrs3d's forward / backward sweeps over the Z levels (pdgsTrForwardSolve3d :7312, pdgsTrBackSolve3d :7564) with
+    dfsolveReduceLsum3d (:1646) / dp2pSolvedX3d (:1596) style exchanges of the ancestor parts of x.
+
+The numeric work is done by a *backend* object (duck-typed):
+    factor_level(ilvl, thresh) ; value_slices(alvl_from) -> [1-D tensors viewing the resident factors] ;
+    solve_level(ilvl, direction, x) ; info() -> (info, tiny) ; n ; tree_rows(ilvl) -> [(row0, row1), ...]
+`GpuLayer` below is the product backend (libsluamd.so).  tests/ supplies a CPU-oracle backend for the gloo tests.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+
+def max_level(npdep):
+    lvl = 1
+    while (1 << (lvl - 1)) < npdep:
+        lvl += 1
+    if (1 << (lvl - 1)) != npdep:
+        raise ValueError("npdep must be a power of two (reference: superlu_gridinit3d)")
+    return lvl
+
+
+def path_trees(npdep, z):
+    """Tree ids (heap order, root 0) handled by layer z at levels 0..maxLvl-1 (getGridTrees, supernodal_etree.c:840-851)."""
+    t = [npdep - 1 + z]
+    for _ in range(1, max_level(npdep)):
+        t.append((t[-1] - 1) // 2)
+    return t
+
+
+def runs(sorted_nodes):
+    """Contiguous runs [(k0, k1_exclusive), ...] of an ascending node list."""
+    out = []
+    for k in sorted_nodes:
+        k = int(k)
+        if out and out[-1][1] == k:
+            out[-1][1] = k + 1
+        else:
+            out.append([k, k + 1])
+    return [(a, b) for a, b in out]
+
+
+class DistComm:
+    """Point-to-point + all-reduce over torch.distributed (nccl on GPUs, gloo on CPU)."""
+
+    def __init__(self, dist, ranks=None):
+        self.dist = dist
+        self.ranks = ranks            # layer z -> global rank (identity by default)
+
+    def _r(self, z):
+        return z if self.ranks is None else self.ranks[z]
+
+    def send(self, t, dst):
+        self.dist.send(t.contiguous(), self._r(dst))
+
+    def recv(self, t, src):
+        self.dist.recv(t, self._r(src))
+
+    def allreduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def allreduce_min_int(self, v, device):
+        import torch
+        t = torch.tensor([v], dtype=torch.int64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
+
+
+def pdgstrf3d(backend, comm, z, npdep, thresh):
+    """Numeric factorisation over the Z levels; returns info (min over layers, 0 = none)."""
+    import torch
+    maxlvl = max_level(npdep)
+    for ilvl in range(maxlvl):
+        step = 1 << ilvl
+        if z % step:
+            break                                     # this layer is done (myZeroTrIdxs, supernodal_etree.c:853-869)
+        backend.factor_level(ilvl, thresh)
+        if ilvl < maxlvl - 1:
+            slices = backend.value_slices(ilvl + 1)   # factors of ALL ancestor forests above this level
+            if z % (2 * step) == 0:
+                for sl in slices:
+                    tmp = torch.empty_like(sl)
+                    comm.recv(tmp, z + step)
+                    sl += tmp                         # dzRecvLPanel/dzRecvUPanel: daxpy into the resident panel
+            else:
+                for sl in slices:
+                    comm.send(sl, z - step)
+    info, _ = backend.info()
+    big = backend.n + 1
+    g = comm.allreduce_min_int(info if info else big, backend.device)
+    return 0 if g == big else g
+
+
+def init_rhs(backend, z, npdep, xp):
+    """xp: (nrhs, n) tensor holding Pc*b everywhere; keep only the rows this layer owns (leaf forest + the ancestor
+    forests it factors); the other layers' contributions arrive through the forward reduction."""
+    import torch
+    keep = torch.zeros_like(xp)
+    for ilvl in range(max_level(npdep)):
+        if z % (1 << ilvl) == 0:
+            for a, b in backend.tree_rows(ilvl):
+                keep[:, a:b] = xp[:, a:b]
+    return keep
+
+
+def pdgstrs3d(backend, comm, z, npdep, x):
+    """In-place solve; x is a contiguous (nrhs, n) tensor (== column-major n x nrhs) prepared by init_rhs.
+    On return every layer holds the full solution."""
+    import torch
+    maxlvl = max_level(npdep)
+    # forward sweep, leaves to root
+    for ilvl in range(maxlvl):
+        step = 1 << ilvl
+        if z % step:
+            break
+        backend.solve_level(ilvl, +1, x)
+        if ilvl < maxlvl - 1:
+            rows = [r for al in range(ilvl + 1, maxlvl) for r in backend.tree_rows(al)]
+            if z % (2 * step) == 0:
+                for a, b in rows:
+                    tmp = torch.empty((x.shape[0], b - a), dtype=x.dtype, device=x.device)
+                    comm.recv(tmp, z + step)
+                    x[:, a:b] += tmp
+            else:
+                for a, b in rows:
+                    comm.send(x[:, a:b], z - step)
+    # backward sweep, root to leaves
+    for ilvl in reversed(range(maxlvl)):
+        step = 1 << ilvl
+        if z % step:
+            continue
+        if ilvl < maxlvl - 1:
+            rows = [r for al in range(ilvl + 1, maxlvl) for r in backend.tree_rows(al)]
+            if z % (2 * step) == 0:
+                if z + step < npdep:
+                    for a, b in rows:
+                        comm.send(x[:, a:b], z + step)
+            else:
+                for a, b in rows:
+                    tmp = torch.empty((x.shape[0], b - a), dtype=x.dtype, device=x.device)
+                    comm.recv(tmp, z - step)
+                    x[:, a:b] = tmp
+        backend.solve_level(ilvl, -1, x)
+    # assemble: every row is final on the layer that owns its forest
+    out = torch.zeros_like(x)
+    for ilvl in range(maxlvl):
+        if z % (1 << ilvl) == 0:
+            for a, b in backend.tree_rows(ilvl):
+                out[:, a:b] = x[:, a:b]
+    comm.allreduce_sum(out)
+    x.copy_(out)
+    return x
+
+
+class _DevArray:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, nelem):
+        self.__cuda_array_interface__ = {"shape": (int(nelem),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class GpuLayer:
+    """Product backend: one Z layer's factors resident in HBM (sluamd_dCreateLUHandleFromSymb3D)."""
+
+    def __init__(self, symb, nzval, npdep, z, device=-1, sn_tree=None):
+        import torch
+        from .driver import LUHandle, _pi, _pd
+        L = _lib.load()
+        self.L, self.symb, self.npdep, self.z, self.n = L, symb, npdep, z, symb.n
+        self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+        ns = symb.nsupers
+        if sn_tree is None:
+            sn_tree = np.zeros(ns, dtype=np.int32)
+            _lib.check(L.sluamd_symb_partition(symb._h, npdep, sn_tree.ctypes.data_as(_lib.P_int)), "sluamd_symb_partition")
+        self.sn_tree = np.ascontiguousarray(sn_tree, dtype=np.int32)
+        self.trees = path_trees(npdep, z)
+        o = LUHandle._opts(device=device)
+        nz = np.ascontiguousarray(nzval, dtype=np.float64)
+        self._h = C.c_void_p()
+        _lib.check(L.sluamd_dCreateLUHandleFromSymb3D(C.byref(self._h), symb._h, _pi(symb.rowptr), _pi(symb.colind), _pd(nz),
+                                                      _pi(symb.perm_c), C.byref(o), npdep, z,
+                                                      self.sn_tree.ctypes.data_as(_lib.P_int)), "sluamd_dCreateLUHandleFromSymb3D")
+        self.handle = LUHandle(self._h, None)
+        lo = np.zeros(ns + 1, dtype=np.int64); uo = np.zeros(ns + 1, dtype=np.int64)
+        P64 = C.POINTER(C.c_int64)
+        L.sluamd_local_offsets(self._h, lo.ctypes.data_as(P64), uo.ctypes.data_as(P64))
+        dval = C.c_void_p(); nl = C.c_int64(); nu = C.c_int64()
+        L.sluamd_arena(self._h, C.byref(dval), C.byref(nl), C.byref(nu))
+        self.lval_off, self.uval_off, self.nnzL, self.nnzU = lo, uo, nl.value, nu.value
+        tot = nl.value + nu.value
+        self.arena = torch.as_tensor(_DevArray(dval.value, max(tot, 1)), device=self.device)[:tot]
+        self.xsup = symb.xsup()
+        self._nodes = [np.nonzero(self.sn_tree == t)[0] for t in self.trees]
+
+    def tree_nodes(self, ilvl):
+        return self._nodes[ilvl]
+
+    def tree_rows(self, ilvl):
+        return [(int(self.xsup[a]), int(self.xsup[b])) for a, b in runs(self._nodes[ilvl])]
+
+    def value_slices(self, alvl_from):
+        segs = []
+        for al in range(alvl_from, len(self.trees)):
+            for a, b in runs(self._nodes[al]):
+                segs.append((int(self.lval_off[a]), int(self.lval_off[b])))
+                segs.append((self.nnzL + int(self.uval_off[a]), self.nnzL + int(self.uval_off[b])))
+        segs = sorted(s for s in segs if s[1] > s[0])
+        merged = []
+        for a, b in segs:                              # ancestors are adjacent in the local arena: few, large messages
+            if merged and merged[-1][1] == a:
+                merged[-1][1] = b
+            else:
+                merged.append([a, b])
+        return [self.arena[a:b] for a, b in merged]
+
+    def factor_level(self, ilvl, thresh):
+        _lib.check(self.L.sluamd_pdgstrf3d_level(self._h, ilvl, float(thresh)), "sluamd_pdgstrf3d_level")
+
+    def solve_level(self, ilvl, direction, x):
+        assert x.is_contiguous() and x.dtype.itemsize == 8
+        _lib.check(self.L.sluamd_pdgstrs3d_level(self._h, ilvl, direction, C.c_void_p(x.data_ptr()), x.shape[1], x.shape[0]),
+                   "sluamd_pdgstrs3d_level")
+
+    def info(self):
+        i = C.c_int32(); t = C.c_int32()
+        self.L.sluamd_factor_info(self._h, C.byref(i), C.byref(t))
+        return i.value, t.value
+
+    def reset_values(self):
+        self.handle.reset_values()
+
+    def stats(self):
+        return self.handle.stats()
+
+    def destroy(self):
+        self.handle.destroy()

@@ -82,5 +82,15 @@ def dsolve(store, x):
     return x
 
 
+def dsolve_level(store, x, nodes, direction):
+    """In-place forward (+1) / backward (-1) solve restricted to the ascending supernode list `nodes`."""
+    assert x.flags.f_contiguous and x.dtype == np.float64
+    nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+    fn = lib().slu_oracle_dsolve_fwd if direction > 0 else lib().slu_oracle_dsolve_bwd
+    fn(*store._args(), _p(x, ctypes.c_double), ctypes.c_int(x.shape[0]), ctypes.c_int(x.shape[1]),
+       _p(nodes, ctypes.c_int), ctypes.c_int(len(nodes)))
+    return x
+
+
 def num_threads():
     return lib().slu_oracle_num_threads()
