@@ -343,11 +343,15 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
 //         scatter) solved as X^T L_kk^T = B^T on the skyline in place: strip = 32 non-empty U columns
 //         (implicit zero padding above each segment), T = L_kk^T (unit upper).
 // The 32 x ns strip lives in LDS for the whole solve: HBM traffic = one read + one write of the panel.
-constexpr int RS = 32;  // strip rows per workgroup
-// LDS images are split in 16-wide halves ([half][k][16]): a 16x4 MFMA fragment read touches 4 k-rows x 16
-// consecutive doubles = all 64 banks once.
-__host__ __device__ inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) 64 * nsp + 2 * DB * 16); }
+constexpr int RS = 64;  // strip rows per workgroup: each of the 4 waves owns 16 rows for the whole solve
+// LDS images are split in 16-wide groups ([group][k][16]): a 16x4 MFMA fragment read touches 4 k-rows x 16
+// consecutive doubles = all 64 banks once.  Xs = strip (RS x nsp), Tb = double-buffered 32x32 operand block.
+__host__ __device__ inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) RS * nsp + 2 * DB * DB); }
 
+// The solve is a flat pipeline of 32x32 operand blocks ("chunks"): for every block column jb the off-diagonal
+// blocks T(kc, jb), kc = 0, 32, .. jb-32, then the inverted diagonal block inv(T_jj).  The next chunk is fetched
+// from L2 into registers while the MFMAs of the current one run; one barrier per chunk guards the LDS double
+// buffer.  A wave only ever reads and writes its own 16 strip rows, so the strip itself needs no barrier.
 template <int MODE>
 __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int strip, double *sm, int *s_cp, int *s_ld)
 {
@@ -358,16 +362,14 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     double *A = T.val + T.sn_lval[k];
     double *Uv = T.val + T.sn_uval[k];
     const double *dinv = T.dinv + T.sn_dinv[k] + (MODE == 0 ? 0 : (size_t) nblk * DB * DB);
-    double *Xs = sm;                          // [2][nsp][16]   strip, element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
-    double *Ts = sm + (size_t) 32 * nsp;      // [2][nsp][16]   T(0:jb, jb:jb+32), element (k, cc) at ((cc>>4)*nsp + k)*16 + (cc&15)
-    double *Ds = Ts + (size_t) 32 * nsp;      // [2][32][16]    inverse of the diagonal sub-block
+    double *Xs = sm;                          // [4][nsp][16]: element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
+    double *Tb = sm + (size_t) RS * nsp;      // [2 buffers][2 halves][32][16]: element (kk, cc) at ((cc>>4)*32 + kk)*16 + (cc&15)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int rbh = wave & 1, cbh = wave >> 1;
 
     if (MODE == 0) {
         const int row0 = ns + strip * RS;
         for (int idx = tid; idx < RS * nsp; idx += 256) {
-            const int r = idx & (RS - 1), c = idx >> 5;
+            const int r = idx & (RS - 1), c = idx >> 6;
             double v = 0.0;
             if (c < ns && row0 + r < lda) v = A[row0 + r + (size_t) c * lda];
             Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
@@ -398,60 +400,86 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
         }
     }
 
-    for (int jb = 0; jb < nsp; jb += DB) {
-        // stage T(0:jb, jb:jb+32) and the inverse of the diagonal sub-block
-        if (MODE == 0) {
-            for (int cc = wave; cc < DB; cc += 4) {
-                const int cg = jb + cc;
-                for (int kk = lane; kk < jb; kk += 64)
-                    Ts[((cc >> 4) * nsp + kk) * 16 + (cc & 15)] = (cg < ns) ? A[kk + (size_t) cg * lda] : 0.0;
-            }
-        } else {
-            for (int idx = tid; idx < DB * jb; idx += 256) {
-                const int cc = idx & 31, kk = idx >> 5;
-                const int cg = jb + cc;
-                Ts[((cc >> 4) * nsp + kk) * 16 + (cc & 15)] = (cg < ns) ? A[cg + (size_t) kk * lda] : 0.0;
-            }
-        }
-        {
-            const double *dblk = dinv + (size_t) (jb / DB) * DB * DB;
+    // chunk (jb, t): t < jb/32 -> T(32 t, jb) ; t == jb/32 -> inv(T_jj)
+    double pv[4];
+    const int e0 = tid & 31, e1 = tid >> 5;   // fast / slow element index of the 32x32 chunk (slow: e1 + 8q)
+    auto fetch = [&](int jb, int t) {
+        if (t * DB < jb) {
+            const int kc = t * DB;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int idx = tid + 256 * q;
-                const int kk = idx & 31, cc = idx >> 5;
-                Ds[((cc >> 4) * DB + kk) * 16 + (cc & 15)] = dblk[cc * DB + kk];
+                // MODE 0: T(k,c) = U_kk(k,c) = A[k + c*lda], k fastest ; MODE 1: T(k,c) = L_kk(c,k) = A[c + k*lda], c fastest
+                const int kg = kc + (MODE == 0 ? e0 : e1 + 8 * q), cg = jb + (MODE == 0 ? e1 + 8 * q : e0);
+                pv[q] = (kg < ns && cg < ns) ? (MODE == 0 ? A[kg + (size_t) cg * lda] : A[cg + (size_t) kg * lda]) : 0.0;
             }
-        }
-        __syncthreads();
-        d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
-        const double *xa = Xs + ((size_t) rbh * nsp + (lane >> 4)) * 16 + (lane & 15);
-        const double *tb = Ts + ((size_t) cbh * nsp + (lane >> 4)) * 16 + (lane & 15);
-        for (int k8 = 0; k8 < jb; k8 += 8) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k8 * 16], tb[k8 * 16], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(k8 + 4) * 16], tb[(k8 + 4) * 16], acc1, 0, 0, 0);
-        }
-        // rhs = X_jb - acc (each wave owns one 16x16 block of the 32x32 strip block)
-        double *xblk = Xs + ((size_t) rbh * nsp + jb + cbh * 16 + (lane & 15)) * 16 + (lane >> 4);
+        } else {
+            const double *dblk = dinv + (size_t) (jb / DB) * DB * DB;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xblk[4 * r] -= acc0[r] + acc1[r];
-        __syncthreads();
-        d4 acc2 = (d4){0.0, 0.0, 0.0, 0.0}, acc3 = (d4){0.0, 0.0, 0.0, 0.0};
-        const double *db = Ds + ((size_t) cbh * DB + (lane >> 4)) * 16 + (lane & 15);
-#pragma unroll
-        for (int k8 = 0; k8 < DB; k8 += 8) {
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(jb + k8) * 16], db[k8 * 16], acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(jb + k8 + 4) * 16], db[(k8 + 4) * 16], acc3, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) pv[q] = dblk[(e1 + 8 * q) * DB + e0];   // D(kk = e0, cc = e1 + 8q)
         }
-        __syncthreads();
+    };
+    auto stash = [&](int jb, int t, int buf) {
+        double *tb = Tb + buf * (2 * DB * 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xblk[4 * r] = acc2[r] + acc3[r];
-        __syncthreads();
+        for (int q = 0; q < 4; ++q) {
+            int kk, cc;
+            if (t * DB < jb && MODE == 1) { cc = e0; kk = e1 + 8 * q; } else { kk = e0; cc = e1 + 8 * q; }
+            tb[((cc >> 4) * DB + kk) * 16 + (cc & 15)] = pv[q];
+        }
+    };
+
+    d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *xa = Xs + ((size_t) wave * nsp + (lane >> 4)) * 16 + (lane & 15);
+    fetch(0, 0);
+    stash(0, 0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int jb = 0; jb < nsp; jb += DB) {
+        const int nt = jb / DB;
+        for (int t = 0; t <= nt; ++t) {
+            // next chunk in the flat sequence
+            int njb = jb, ntt = t + 1;
+            if (ntt > nt) { njb = jb + DB; ntt = 0; }
+            const bool more = njb < nsp;
+            if (more) fetch(njb, ntt);
+            const double *tb0 = Tb + buf * (2 * DB * 16) + (lane >> 4) * 16 + (lane & 15);
+            const double *tb1 = tb0 + DB * 16;
+            if (t < nt) {
+                const double *a = xa + (size_t) (t * DB) * 16;
+#pragma unroll
+                for (int k4 = 0; k4 < DB; k4 += 4) {
+                    const double av = a[k4 * 16];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
+                }
+            } else {
+                // rhs = X_jb - acc (own 16 rows), then X_jb = rhs * inv(T_jj)
+                double *x0 = Xs + ((size_t) wave * nsp + jb + (lane & 15)) * 16 + (lane >> 4);
+                double *x1 = x0 + 16 * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x0[4 * r] -= acc0[r]; x1[4 * r] -= acc1[r]; }
+                acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+                const double *a = xa + (size_t) jb * 16;
+#pragma unroll
+                for (int k4 = 0; k4 < DB; k4 += 4) {
+                    const double av = a[k4 * 16];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x0[4 * r] = acc0[r]; x1[4 * r] = acc1[r]; }
+                acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+            }
+            if (more) stash(njb, ntt, buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
     if (MODE == 0) {
         const int row0 = ns + strip * RS;
         for (int idx = tid; idx < RS * ns; idx += 256) {
-            const int r = idx & (RS - 1), c = idx >> 5;
+            const int r = idx & (RS - 1), c = idx >> 6;
             if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
         }
     } else {
@@ -1040,8 +1068,8 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             const int rrows = t.sn_nsupr[k] - nsupc;
             S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc);
             S.diag_lds[l] = std::max(S.diag_lds[l], sizeof(double) * ((size_t) 32 * (nsupc | 1) + (size_t) 32 * nsupc));
-            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + 31) / 32;
-            S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + 31) / 32;
+            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + RS - 1) / RS;
+            S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + RS - 1) / RS;
             S.inv_prefix[po + 1] = S.inv_prefix[po] + 2 * ((nsupc + 31) / 32);
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (rrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
