@@ -108,6 +108,9 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     // ---- subtree sizes, child counts, relaxed subtree roots ----
     std::vector<int> sz(n, 1), nchild(n, 0);
     for (int j = 0; j < n; ++j) if (parent[j] != -1) { sz[parent[j]] += sz[j]; nchild[parent[j]]++; }
+    // length of the etree chain starting at each column (upper bound of what one supernode chain can absorb)
+    std::vector<int> chain(n, 1);
+    for (int j = (int) n - 2; j >= 0; --j) if (parent[j] == j + 1) chain[j] = chain[j + 1] + 1;
     std::vector<int> relax_end(n, -1);  // relax_end[a] = b if [a,b] is a relaxed subtree
     for (int j = 0; j < n; ++j)
         if (sz[j] <= relax && (parent[j] == -1 || sz[parent[j]] > relax)) relax_end[j - sz[j] + 1] = j;
@@ -146,7 +149,11 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
             // the separator into singleton supernodes.
             double zacc = 0;
             std::vector<int> extra;
-            while (b + 1 < n && (b - a + 1) < maxsup && parent[b] == b + 1 && relax_end[b + 1] < 0) {
+            // split long chains (separators) into equal pieces <= maxsup instead of maxsup + a small remainder:
+            // the GPU Schur tiles are 128 wide, a 250+250 split fills them, a 256+8 split does not
+            const int pieces = (chain[a] + maxsup - 1) / maxsup;
+            const int cap = (chain[a] + pieces - 1) / pieces;
+            while (b + 1 < n && (b - a + 1) < cap && parent[b] == b + 1 && relax_end[b + 1] < 0) {
                 const int c = b + 1;
                 extra.clear();
                 for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != u) { mark[r] = u; extra.push_back(r); } }

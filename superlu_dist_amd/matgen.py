@@ -32,33 +32,39 @@ def poisson3d(N, nx=None, ny=None, nz=None):
     return n, rowptr.astype(np.int32), cols.astype(np.int32), vals
 
 
-def nd_perm_grid3d(nx, ny, nz, leaf=64):
-    """Return perm_c with perm_c[old] = new (SuperLU convention) for the natural grid index."""
+def nd_perm_grid3d(nx, ny, nz, leaf=64, sep_leaf=32):
+    """Return perm_c with perm_c[old] = new (SuperLU convention) for the natural grid index.
+
+    Recursive coordinate bisection (longest dimension, middle plane, separator last).  The separator plane itself is
+    ordered by the SAME bisection rule restricted to its own two dimensions (and its separator lines likewise), so
+    that the interface of every descendant sub-box with an ancestor separator is a contiguous index range: the L/U
+    blocks coupling a supernode to an ancestor separator then come in full supernode-sized pieces instead of
+    line-by-line fragments."""
     out = []
     ii, jj, kk = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
     gid = (ii * ny + jj) * nz + kk
 
-    def rec(x0, x1, y0, y1, z0, z1):
+    def rec(x0, x1, y0, y1, z0, z1, cap):
         dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
         if dx <= 0 or dy <= 0 or dz <= 0:
             return
-        if dx * dy * dz <= leaf or max(dx, dy, dz) < 3:
+        if dx * dy * dz <= cap or max(dx, dy, dz) < 3:
             out.append(gid[x0:x1, y0:y1, z0:z1].ravel())
             return
         if dx >= dy and dx >= dz:
             m = x0 + dx // 2
-            rec(x0, m, y0, y1, z0, z1); rec(m + 1, x1, y0, y1, z0, z1)
-            out.append(gid[m:m + 1, y0:y1, z0:z1].ravel())
+            rec(x0, m, y0, y1, z0, z1, cap); rec(m + 1, x1, y0, y1, z0, z1, cap)
+            rec(m, m + 1, y0, y1, z0, z1, sep_leaf)
         elif dy >= dz:
             m = y0 + dy // 2
-            rec(x0, x1, y0, m, z0, z1); rec(x0, x1, m + 1, y1, z0, z1)
-            out.append(gid[x0:x1, m:m + 1, z0:z1].ravel())
+            rec(x0, x1, y0, m, z0, z1, cap); rec(x0, x1, m + 1, y1, z0, z1, cap)
+            rec(x0, x1, m, m + 1, z0, z1, sep_leaf)
         else:
             m = z0 + dz // 2
-            rec(x0, x1, y0, y1, z0, m); rec(x0, x1, y0, y1, m + 1, z1)
-            out.append(gid[x0:x1, y0:y1, m:m + 1].ravel())
+            rec(x0, x1, y0, y1, z0, m, cap); rec(x0, x1, y0, y1, m + 1, z1, cap)
+            rec(x0, x1, y0, y1, m, m + 1, sep_leaf)
 
-    rec(0, nx, 0, ny, 0, nz)
+    rec(0, nx, 0, ny, 0, nz, leaf)
     order = np.concatenate(out)           # order[new] = old
     perm = np.empty(nx * ny * nz, dtype=np.int32)
     perm[order] = np.arange(order.size, dtype=np.int32)
