@@ -267,23 +267,45 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
             // A22 -= L21 U12 on MFMA: 16x16 output blocks round-robin over the 4 waves; A := U12^T, B := L21^T so
             // that the 16 fast lanes run along rows (contiguous in the column-major block)
             const int nt = (nc + 15) >> 4;
-            for (int t = wave; t < nt * nt; t += 4) {
-                const int ti = t % nt, tj = t / nt;          // row block, column block
-                const int rr = min(ti * 16 + (lane & 15), nc - 1), cc = min(tj * 16 + (lane & 15), nc - 1);
-                d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+            // 4 output blocks per wave iteration: 4 independent MFMA chains, and the read-modify-write of the 16
+            // destination values per lane is issued as 16 loads followed by 16 stores (one L2 round trip per group)
+            for (int t0 = wave * 4; t0 < nt * nt; t0 += 16) {
+                d4 acc[4];
+                int ti[4], tj[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int t = min(t0 + g, nt * nt - 1);
+                    ti[g] = t % nt; tj[g] = t / nt;
+                    acc[g] = (d4){0.0, 0.0, 0.0, 0.0};
+                }
 #pragma unroll
                 for (int k4 = 0; k4 < DB; k4 += 4) {
                     const int kk = k4 + (lane >> 4);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kk * lus + cc], Ps[kk * ldp + nb + rr], acc, 0, 0, 0);
-                }
-                const int row = ti * 16 + (lane & 15);
-                if (row < nc) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = tj * 16 + (lane >> 4) + 4 * r;
-                        if (col < nc) A[jb + nb + row + (size_t) (jb + nb + col) * lda] -= acc[r];
+                    for (int g = 0; g < 4; ++g) {
+                        const int rr = min(ti[g] * 16 + (lane & 15), nc - 1), cc = min(tj[g] * 16 + (lane & 15), nc - 1);
+                        acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kk * lus + cc], Ps[kk * ldp + nb + rr], acc[g], 0, 0, 0);
                     }
                 }
+                double old[4][4];
+                double *dst[4][4];
+                bool ok[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = ti[g] * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = tj[g] * 16 + (lane >> 4) + 4 * r;
+                        ok[g][r] = (t0 + g < nt * nt) && row < nc && col < nc;
+                        dst[g][r] = A + jb + nb + min(row, nc - 1) + (size_t) (jb + nb + min(col, nc - 1)) * lda;
+                        old[g][r] = ok[g][r] ? *dst[g][r] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[g][r]) *dst[g][r] = old[g][r] - acc[g][r];
             }
         }
         __syncthreads();
