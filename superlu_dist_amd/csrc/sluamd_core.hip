@@ -86,9 +86,13 @@ struct LevelSched {
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
     std::vector<int> max_nsupc;     // per level
     std::vector<size_t> diag_lds;   // per level: dynamic LDS bytes k_diag_lu needs (max over the level's nodes)
+    std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
+    std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level [big group | small group]
+    std::vector<int> u_off;         // [2*nlevels+1] offsets into ulist (2 groups per level)
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
-    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr;
+    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr;
+    int4 *d_ulist = nullptr;
 };
 
 struct Handle {
@@ -103,6 +107,9 @@ struct Handle {
     DevTables T{};
     std::vector<LevelSched> sched;  // one per Z level (forests) or a single one
     hipStream_t stream = nullptr;
+    hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
+    std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events
+    size_t ev_pool_used = 0;
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
     double *d_x = nullptr; int64_t x_cap = 0;
     int64_t *d_apos = nullptr; double *d_aval = nullptr; int64_t a_nnz = 0;  // A's entries for device-side (re)distribution
@@ -543,7 +550,9 @@ __global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__re
 template <int TMv, int TNv>
 __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
-                                                                    int ntiles, int *__restrict__ info)
+                                                                    int ntiles, int *__restrict__ info,
+                                                                    const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
+                                                                    int skip_level)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -571,16 +580,25 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
         if ((blockIdx.x >> 3) >= chunk || bid >= ntiles) return;
         bid += id_base;
     }
-    const int ni = find_node(prefix, nn, bid);
-    const int k = nodes[ni];
-    const int local = bid - prefix[ni];
-    const int nct = T.sn_nct[k];
-    const int rt = local / nct, ct = local - rt * nct;
+    // look-ahead split: `ulist` != null -> explicit (k, row tile, col tile) list of the tiles that update the NEXT
+    // level's panels ("urgent"); otherwise the full tile grid, minus those tiles when skip_level >= 0
+    int k, rt, ct;
+    if (ulist) {
+        const int4 u = ulist[bid];
+        k = u.x; rt = u.y; ct = u.z;
+    } else {
+        const int ni = find_node(prefix, nn, bid);
+        k = nodes[ni];
+        const int local = bid - prefix[ni];
+        const int nct = T.sn_nct[k];
+        rt = local / nct; ct = local - rt * nct;
+    }
     const int4 R = T.rtile[T.sn_rt_off[k] + rt];
     const int4 C = T.ctile[T.sn_ct_off[k] + ct];
     const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
     const int nr = R.z, nc = C.z;
     const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
+    if (!ulist && skip_level >= 0 && (sn_level[ib] == skip_level || sn_level[jb] == skip_level)) return;  // done by the urgent launch
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int lda = T.sn_nsupr[k];
     const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;  // global row ids of the tile rows
@@ -1044,6 +1062,8 @@ static int build_tables(Handle &H, HostTables &t)
     return 0;
 }
 
+static void build_urgent_lists(const HostTables &t, int nsupers, const std::vector<int> &lvl, LevelSched &S);
+
 // level schedule over `list` (a valid elimination order); node k's level = longest path of updates into it
 static void build_schedule(const Handle &H, const HostTables &t, const std::vector<int> &list, LevelSched &S)
 {
@@ -1097,6 +1117,36 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
         }
     }
+    build_urgent_lists(t, ns, lvl, S);
+}
+
+// tiles of level l whose destination panel belongs to level l+1 (they gate the next level's panel factorisation)
+static void build_urgent_lists(const HostTables &t, int nsupers, const std::vector<int> &lvl, LevelSched &S)
+{
+    S.sn_level = lvl;
+    S.u_off.assign(2 * S.nlevels + 1, 0);
+    std::vector<uint8_t> rflag, cflag;
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int nbig = S.n_big[l];
+        for (int g = 0; g < 2; ++g) {
+            const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
+            for (int i = b; i < e; ++i) {
+                const int k = S.nodes[i];
+                const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
+                if (!nrt || !nct) continue;
+                rflag.assign(nrt, 0); cflag.assign(nct, 0);
+                bool any = false;
+                for (int r = 0; r < nrt; ++r) { const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x]; rflag[r] = (lvl[ib] == l + 1); any |= rflag[r]; }
+                for (int c = 0; c < nct; ++c) { const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x]; cflag[c] = (lvl[jb] == l + 1); any |= cflag[c]; }
+                if (!any) continue;
+                for (int r = 0; r < nrt; ++r)
+                    for (int c = 0; c < nct; ++c)
+                        if (rflag[r] || cflag[c]) S.ulist.push_back(make_int4(k, r, c, 0));
+            }
+            S.u_off[2 * l + g + 1] = (int) S.ulist.size();
+        }
+    }
+    (void) nsupers;
 }
 
 static int upload_schedule(Handle &H, LevelSched &S)
@@ -1108,6 +1158,8 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.fwd_prefix, &S.d_fwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.bwd_prefix, &S.d_bwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.inv_prefix, &S.d_inv_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.sn_level, &S.d_sn_level)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
     return 0;
 }
 
@@ -1118,6 +1170,11 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
     if (rc) return rc;
     // ---- device uploads ----
     HIPCHK(hipStreamCreate(&H->stream));
+    {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
+    }
     HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
     const HostStruct &hs = H->hs;
     auto &K = H->d_misc;
@@ -1211,50 +1268,96 @@ static double ev_sum(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t u
     return tot;
 }
 
+static hipEvent_t next_event(Handle *H)
+{
+    if (H->ev_pool_used == H->ev_pool.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); H->ev_pool.push_back(e); }
+    return H->ev_pool[H->ev_pool_used++];
+}
+
+// One elimination forest, level by level.  Serial mode (profiling / deterministic): everything on one stream.
+// Look-ahead mode (default): the Schur update of level l is split into the tiles that feed level l+1's panels
+// ("urgent", explicit list) and the rest; the panel kernels of level l+1 run on a high-priority stream as soon as
+// the urgent tiles are done and overlap with the rest -- the GPU analogue of the reference's look-ahead pipeline
+// (dsparseTreeFactor_ASYNC, dtreeFactorization.c:381-706, num_lookaheads).
 static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
 {
     const DevTables &T = H->T;
-    hipStream_t s = H->stream;
-    auto schur = [&](bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base) {
+    const bool lookahead = !H->profile && !H->opt.deterministic && getenv("SLUAMD_NO_LOOKAHEAD") == nullptr;
+    hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
+    auto schur = [&](bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
+                     const int4 *ulist, int skip_level) {
         ev_begin(H, H->ev_schur, H->ev_schur_used);
         const int grid = ((ntile + 7) / 8) * 8;
-        if (big) hipLaunchKernelGGL((k_schur<128, 128>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info);
-        else hipLaunchKernelGGL((k_schur<64, 64>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info);
+        if (big) hipLaunchKernelGGL((k_schur<128, 128>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        else hipLaunchKernelGGL((k_schur<64, 64>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
         ev_end(H, H->ev_schur, H->ev_schur_used);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
-    for (int l = 0; l < S.nlevels; ++l) {
+    auto panel = [&](int l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
         const size_t lds_tr = trsm_lds_bytes((mx + 31) & ~31);
         ev_begin(H, H->ev_panel, H->ev_panel_used);
-        if (mx <= 64) hipLaunchKernelGGL(k_diag_lu<64>, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
-        else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
-        else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
-        hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, s, T, nodes, S.d_inv_prefix + po, nn);
+        if (mx <= 64) hipLaunchKernelGGL(k_diag_lu<64>, dim3(nn), dim3(256), 0, ps, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, ps, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, ps, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, ps, T, nodes, S.d_inv_prefix + po, nn);
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
-        if (nl + nu) hipLaunchKernelGGL(k_panel_trsm, dim3(nl + nu), dim3(256), lds_tr, s, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
+        if (nl + nu) hipLaunchKernelGGL(k_panel_trsm, dim3(nl + nu), dim3(256), lds_tr, ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
         ev_end(H, H->ev_panel, H->ev_panel_used);
         H->st.num_launches += 2 + (nl + nu > 0);
-        // Schur update: group 0 = 128x128-tile supernodes, group 1 = 64x64-tile supernodes
+    };
+    hipEvent_t ev_rest_prev = nullptr;   // rest(l-1) complete
+    if (lookahead && S.nlevels) {
+        hipEvent_t e = next_event(H);    // the panel stream must see everything queued so far on the main stream
+        hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
+    }
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
+        const int *nodes = S.d_nodes + n0;
+        if (!lookahead || l == 0) panel(l);          // (look-ahead: panel(l) for l > 0 was queued during level l-1)
+        if (lookahead) {
+            hipEvent_t e = next_event(H);
+            hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);     // Schur(l) needs panel(l)
+        }
         const int nbig = S.n_big[l];
-        for (int g = 0; g < 2; ++g) {
-            const int cnt = g == 0 ? nbig : nn - nbig;
-            if (!cnt) continue;
-            const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
-            const int *gn = nodes + (g == 0 ? 0 : nbig);
-            const int nt = S.tile_prefix[so + cnt];
-            if (!nt) continue;
-            if (!H->opt.deterministic) {
-                schur(g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0);
-            } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
-                for (int i = 0; i < cnt; ++i) {
-                    const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
-                    if (c) schur(g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i]);
+        const bool split = lookahead && l + 1 < S.nlevels;
+        // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
+        for (int pass = split ? 0 : 1; pass < 2; ++pass) {
+            for (int g = 0; g < 2; ++g) {
+                const int cnt = g == 0 ? nbig : nn - nbig;
+                if (!cnt) continue;
+                const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
+                const int *gn = nodes + (g == 0 ? 0 : nbig);
+                if (pass == 0) {
+                    const int u0 = S.u_off[2 * l + g], nu = S.u_off[2 * l + g + 1] - u0;
+                    if (nu) schur(g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1);
+                    continue;
+                }
+                const int nt = S.tile_prefix[so + cnt];
+                if (!nt) continue;
+                if (!H->opt.deterministic) {
+                    schur(g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, split ? l + 1 : -1);
+                } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
+                    for (int i = 0; i < cnt; ++i) {
+                        const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
+                        if (c) schur(g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1);
+                    }
                 }
             }
+            if (pass == 0) {
+                // panel(l+1) may start once the urgent tiles of level l AND the rest of level l-1 are complete
+                hipEvent_t eu = next_event(H);
+                hipEventRecord(eu, s); hipStreamWaitEvent(ps, eu, 0);
+                (void) ev_rest_prev;   // rest(l-1) precedes urgent(l) on stream s, so eu covers it
+                panel(l + 1);
+            }
         }
+    }
+    if (lookahead && S.nlevels) {
+        hipEvent_t e = next_event(H);
+        hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1404,6 +1507,7 @@ int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info)
     H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
     H->profile = H->opt.verbose >= 2 || getenv("SLUAMD_PROFILE") != nullptr;
     H->ev_schur_used = H->ev_panel_used = 0;
+    H->ev_pool_used = 0;
     HIPCHK(hipEventRecord(H->ev0, H->stream));
     // Z levels in order (pdgstrf3d.c:333-385); the ancestor reduction between levels is the caller's
     // collective (RCCL reduce on the arena slice) in a multi-rank run.
@@ -1433,6 +1537,7 @@ int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh)
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
     if (zlevel == 0) {
+        H->ev_pool_used = 0;
         int init[4] = {0x7fffffff, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
     }
@@ -1528,6 +1633,8 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     for (auto &e : H->ev_panel) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (H->ev0) hipEventDestroy(H->ev0);
     if (H->ev1) hipEventDestroy(H->ev1);
+    for (auto e : H->ev_pool) hipEventDestroy(e);
+    if (H->pstream) hipStreamDestroy(H->pstream);
     if (H->stream) hipStreamDestroy(H->stream);
     delete h;
 }
