@@ -108,6 +108,8 @@ struct Handle {
     std::vector<LevelSched> sched;  // one per Z level (forests) or a single one
     hipStream_t stream = nullptr;
     hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
+    hipStream_t rstream = nullptr;          // CU-masked stream for the non-urgent Schur tiles: leaves a few CUs free so
+                                            // that the (LDS-hungry) panel workgroups are not starved by the tile stream
     std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events
     size_t ev_pool_used = 0;
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
@@ -1174,6 +1176,15 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIPCHK(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, H->device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int c = 0; c < ncu; ++c) if (c % 16 != 0) mask[c / 32] |= 1u << (c % 32);   // keep every 16th CU free
+        if (getenv("SLUAMD_NO_CUMASK") || hipExtStreamCreateWithCUMask(&H->rstream, (uint32_t) mask.size(), mask.data()) != hipSuccess) {
+            (void) hipGetLastError();
+            H->rstream = nullptr;
+        }
     }
     HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
     const HostStruct &hs = H->hs;
@@ -1284,12 +1295,13 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const DevTables &T = H->T;
     const bool lookahead = !H->profile && !H->opt.deterministic && getenv("SLUAMD_NO_LOOKAHEAD") == nullptr;
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
-    auto schur = [&](bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
+    hipStream_t rs = (lookahead && H->rstream) ? H->rstream : s;
+    auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
                      const int4 *ulist, int skip_level) {
         ev_begin(H, H->ev_schur, H->ev_schur_used);
         const int grid = ((ntile + 7) / 8) * 8;
-        if (big) hipLaunchKernelGGL((k_schur<128, 128>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
-        else hipLaunchKernelGGL((k_schur<64, 64>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        if (big) hipLaunchKernelGGL((k_schur<128, 128>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        else hipLaunchKernelGGL((k_schur<64, 64>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
         ev_end(H, H->ev_schur, H->ev_schur_used);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -1308,23 +1320,33 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         ev_end(H, H->ev_panel, H->ev_panel_used);
         H->st.num_launches += 2 + (nl + nu > 0);
     };
-    hipEvent_t ev_rest_prev = nullptr;   // rest(l-1) complete
     if (lookahead && S.nlevels) {
-        hipEvent_t e = next_event(H);    // the panel stream must see everything queued so far on the main stream
+        hipEvent_t e = next_event(H);    // the side streams must see everything queued so far on the main stream
         hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
+        if (rs != s) hipStreamWaitEvent(rs, e, 0);
     }
+    bool panel_queued = false;           // panel(l) already queued on ps by the previous level's look-ahead
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
         const int *nodes = S.d_nodes + n0;
-        if (!lookahead || l == 0) panel(l);          // (look-ahead: panel(l) for l > 0 was queued during level l-1)
+        if (!panel_queued) panel(l);
+        panel_queued = false;
         if (lookahead) {
             hipEvent_t e = next_event(H);
             hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);     // Schur(l) needs panel(l)
         }
         const int nbig = S.n_big[l];
-        const bool split = lookahead && l + 1 < S.nlevels;
+        // look ahead only where the next level's panel work is small enough to live on the few CUs the masked
+        // tile stream leaves free; big (throughput-bound) panel levels run after the full Schur update instead
+        bool split = false;
+        if (lookahead && l + 1 < S.nlevels) {
+            const int po1 = S.lvl_poff[l + 1], nn1 = S.lvl_off[l + 2] - S.lvl_off[l + 1];
+            split = (S.ltr_prefix[po1 + nn1] + S.utr_prefix[po1 + nn1]) <= 1024 && nn1 <= 32;
+        }
         // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
         for (int pass = split ? 0 : 1; pass < 2; ++pass) {
+            hipStream_t st = (pass == 1 && split) ? rs : s;
+            if (st != s) { hipEvent_t e = next_event(H); hipEventRecord(e, s); hipStreamWaitEvent(st, e, 0); }
             for (int g = 0; g < 2; ++g) {
                 const int cnt = g == 0 ? nbig : nn - nbig;
                 if (!cnt) continue;
@@ -1332,26 +1354,28 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                 const int *gn = nodes + (g == 0 ? 0 : nbig);
                 if (pass == 0) {
                     const int u0 = S.u_off[2 * l + g], nu = S.u_off[2 * l + g + 1] - u0;
-                    if (nu) schur(g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1);
+                    if (nu) schur(st, g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1);
                     continue;
                 }
                 const int nt = S.tile_prefix[so + cnt];
                 if (!nt) continue;
                 if (!H->opt.deterministic) {
-                    schur(g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, split ? l + 1 : -1);
+                    schur(st, g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, split ? l + 1 : -1);
                 } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
                     for (int i = 0; i < cnt; ++i) {
                         const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
-                        if (c) schur(g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1);
+                        if (c) schur(st, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1);
                     }
                 }
             }
+            if (st != s) { hipEvent_t e = next_event(H); hipEventRecord(e, st); hipStreamWaitEvent(s, e, 0); }   // later main-stream work follows rest(l)
             if (pass == 0) {
-                // panel(l+1) may start once the urgent tiles of level l AND the rest of level l-1 are complete
+                // panel(l+1) may start once the urgent tiles of level l (and, by stream order, the rest of level
+                // l-1) are complete; it then overlaps with the rest of level l
                 hipEvent_t eu = next_event(H);
                 hipEventRecord(eu, s); hipStreamWaitEvent(ps, eu, 0);
-                (void) ev_rest_prev;   // rest(l-1) precedes urgent(l) on stream s, so eu covers it
                 panel(l + 1);
+                panel_queued = true;
             }
         }
     }
@@ -1635,6 +1659,7 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->ev1) hipEventDestroy(H->ev1);
     for (auto e : H->ev_pool) hipEventDestroy(e);
     if (H->pstream) hipStreamDestroy(H->pstream);
+    if (H->rstream) hipStreamDestroy(H->rstream);
     if (H->stream) hipStreamDestroy(H->stream);
     delete h;
 }
