@@ -549,8 +549,8 @@ __global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__re
 // Two tile configurations: 128x128 (wide supernodes, big block pairs: 4x4 MFMA blocks per wave) and 64x64
 // (everything else).  Software pipeline: the next K chunk is fetched from HBM/L2 into registers while the
 // MFMAs of the current chunk run out of the other LDS buffer (one barrier per chunk).
-template <int TMv, int TNv>
-__global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T, const int *__restrict__ nodes,
+template <int TMv, int TNv, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
@@ -558,9 +558,12 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
-    constexpr int NBR = TMv / 32, NBC = TNv / 32;      // 16x16 MFMA blocks per wave (rows, cols)
-    constexpr int LQ = TMv * KC / 256, UQ = TNv * KC / 256;  // prefetch registers per thread
-    constexpr int LKS = 256 / TMv;                      // k stride of the L loader
+    constexpr int NT = NW * 64;                         // threads per workgroup
+    constexpr int WR = (NW == 8) ? 4 : 2, WC = 2;       // wave grid (rows x cols): 4 waves = 2x2, 8 waves = 4x2
+    constexpr int NBR = TMv / (16 * WR), NBC = TNv / (16 * WC);   // 16x16 MFMA blocks per wave (rows, cols)
+    constexpr int LQ = TMv * KC / NT, UQ = TNv * KC / NT;         // prefetch registers per thread
+    constexpr int LKS = NT / TMv;                       // k stride of the L loader
+    constexpr int UJS = NT / 16;                        // column stride of the U loader
     __shared__ double Ls[2][KC * LDL];
     __shared__ double Us[2][KC * LDU];
     __shared__ int s_ind[256 + 8];
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
     const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
     const double *Uv = T.val + T.sn_uval[k];
 
-    for (int t = tid; t < TNv; t += 256) {
+    for (int t = tid; t < TNv; t += NT) {
         int cp = 0, lead = ns, jj = 0;
         if (t < nc) {
             jj = T.unzcol[uix0 + C.y + t];
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
         s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
     }
     // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
-    if (tid == 255) {
+    if (tid == NT - 1) {
         int found = 0;
         if (ib >= jb) {
             const int o = T.sn_lb_off[jb], nb = T.sn_nlb[jb];
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
-    const int rm0 = (wave & 1) * (TMv / 2), cn0 = (wave >> 1) * (TNv / 2);
+    const int rm0 = (wave % WR) * (TMv / WR), cn0 = (wave / WR) * (TNv / WC);
     d4 acc[NBC][NBR];
 #pragma unroll
     for (int a = 0; a < NBC; ++a)
@@ -655,11 +658,11 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
 
     const int kbeg = (ns - T.sn_ldu[k]) & ~3;          // U is zero above its tallest segment: skip those k
     const int li = tid % TMv, lk = tid / TMv;           // L loader: row li, k = lk + LKS*q
-    const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + 16q
+    const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + UJS*q
     double pl[LQ], pu[UQ];
     int ucp[UQ], uld[UQ];
 #pragma unroll
-    for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + 16 * q]; uld[q] = s_lead[uj + 16 * q]; }
+    for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + UJS * q]; uld[q] = s_lead[uj + UJS * q]; }
     const bool lrow_ok = li < nr;
     const double *Lrow = Lp + li;
 
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
 #pragma unroll
         for (int q = 0; q < LQ; ++q) Ls[buf][(lk + LKS * q) * LDL + li] = pl[q];
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + 16 * q] = pu[q];
+        for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + UJS * q] = pu[q];
     };
 
     fetch(kbeg);
@@ -713,15 +716,15 @@ __global__ __launch_bounds__(256, (TMv == 128 ? 2 : 4)) void k_schur(DevTables T
         // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
         const int *drows = T.lidx + T.sn_lidx[jb] + s_dinfo[1];
         const int fnz = T.xsup[ib], dn = s_dinfo[2];
-        for (int i = tid; i < dn; i += 256) s_ind[drows[i] - fnz] = i;
+        for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
         __syncthreads();
-        for (int t = tid; t < TMv; t += 256) s_rowmap[t] = (t < nr) ? s_dinfo[0] + s_ind[lsub[t] - fnz] : 0;
+        for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? s_dinfo[0] + s_ind[lsub[t] - fnz] : 0;
         const int ldv = T.sn_nsupr[jb];
-        for (int t = tid; t < TNv; t += 256) s_colmap[t] = s_jj[t] * ldv;
+        for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * ldv;
     } else {
         const int64_t d0 = T.sn_uidx[ib] + s_dinfo[0];
-        for (int t = tid; t < TMv; t += 256) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
-        for (int t = tid; t < TNv; t += 256) {
+        for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
+        for (int t = tid; t < TNv; t += NT) {
             int cm = 0;
             if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
             s_colmap[t] = cm;
@@ -1181,7 +1184,7 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
         const int ncu = prop.multiProcessorCount;
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
         for (int c = 0; c < ncu; ++c) if (c % 16 != 0) mask[c / 32] |= 1u << (c % 32);   // keep every 16th CU free
-        if (getenv("SLUAMD_NO_CUMASK") || hipExtStreamCreateWithCUMask(&H->rstream, (uint32_t) mask.size(), mask.data()) != hipSuccess) {
+        if (!getenv("SLUAMD_CUMASK") || hipExtStreamCreateWithCUMask(&H->rstream, (uint32_t) mask.size(), mask.data()) != hipSuccess) {
             (void) hipGetLastError();
             H->rstream = nullptr;
         }
@@ -1300,8 +1303,10 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                      const int4 *ulist, int skip_level) {
         ev_begin(H, H->ev_schur, H->ev_schur_used);
         const int grid = ((ntile + 7) / 8) * 8;
-        if (big) hipLaunchKernelGGL((k_schur<128, 128>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
-        else hipLaunchKernelGGL((k_schur<64, 64>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        static const bool w8 = getenv("SLUAMD_SCHUR_4WAVES") == nullptr;
+        if (big && w8) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        else if (big) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
         ev_end(H, H->ev_schur, H->ev_schur_used);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
