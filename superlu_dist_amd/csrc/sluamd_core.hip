@@ -1334,7 +1334,13 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
         const int *nodes = S.d_nodes + n0;
-        if (!panel_queued) panel(l);
+        if (!panel_queued) {
+            if (lookahead && l > 0) {   // no look-ahead was done for this level: its panels need ALL of Schur(l-1)
+                hipEvent_t e = next_event(H);
+                hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
+            }
+            panel(l);
+        }
         panel_queued = false;
         if (lookahead) {
             hipEvent_t e = next_event(H);
