@@ -1352,7 +1352,9 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         bool split = false;
         if (lookahead && l + 1 < S.nlevels) {
             const int po1 = S.lvl_poff[l + 1], nn1 = S.lvl_off[l + 2] - S.lvl_off[l + 1];
-            split = (S.ltr_prefix[po1 + nn1] + S.utr_prefix[po1 + nn1]) <= 1024 && nn1 <= 32;
+            static const int max_strips = getenv("SLUAMD_LOOKAHEAD_MAX_STRIPS") ? atoi(getenv("SLUAMD_LOOKAHEAD_MAX_STRIPS")) : (1 << 30);
+            split = (S.ltr_prefix[po1 + nn1] + S.utr_prefix[po1 + nn1]) <= max_strips;
+            (void) nn1;
         }
         // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
         for (int pass = split ? 0 : 1; pass < 2; ++pass) {
