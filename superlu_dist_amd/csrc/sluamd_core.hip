@@ -220,17 +220,17 @@ template <int NSMAX>
 __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restrict__ nodes,
                                                  int replace_tiny, double thresh, int *__restrict__ info)
 {
-    __shared__ double s_a[DB * (NSMAX + 1) + DB * NSMAX];
+    constexpr int UC = 64;                  // U12 is staged 64 columns at a time: keeps the workgroup at <= 82 KB of LDS
+    constexpr int ldp = NSMAX + 1, lus = UC;
+    __shared__ double s_a[DB * ldp + DB * lus];
     __shared__ double s_rinv[DB];
     const int k = nodes[blockIdx.x];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     double *A = T.val + T.sn_lval[k];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double *Ps = s_a;                       // column panel: element (r, c) at Ps[c * ldp + r], DB x ldp
-    constexpr int ldp = NSMAX + 1;
-    double *Us = s_a + DB * ldp;            // U12 block row: element (kk, c) at Us[kk * lus + c], DB x lus
-    constexpr int lus = NSMAX;
+    double *Ps = s_a;                       // column panel: element (r, c) at Ps[c * ldp + r]
+    double *Us = s_a + DB * ldp;            // 64-column slice of U12: element (kk, c) at Us[kk * lus + c]
     for (int jb = 0; jb < ns; jb += DB) {
         const int nb = min(DB, ns - jb), m = ns - jb, nc = m - nb;
         for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; Ps[c * ldp + r] = A[jb + r + (size_t) (jb + c) * lda]; }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
         __syncthreads();
         for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
         if (nc > 0) {
-            // U12 = L11^-1 A12 : one thread per column, forward substitution in registers
+            // U12 = L11^-1 A12 : one thread per column, forward substitution in registers, result back to HBM/L2
             for (int c = tid; c < nc; c += 256) {
                 double *col = A + jb + (size_t) (jb + nb + c) * lda;
                 double x[DB];
@@ -270,51 +270,56 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int i2 = 0; i2 < DB; ++i2) { col[i2] = x[i2]; Us[i2 * lus + c] = x[i2]; }
+                for (int i2 = 0; i2 < DB; ++i2) col[i2] = x[i2];
             }
             __syncthreads();
-            // A22 -= L21 U12 on MFMA: 16x16 output blocks round-robin over the 4 waves; A := U12^T, B := L21^T so
-            // that the 16 fast lanes run along rows (contiguous in the column-major block)
-            const int nt = (nc + 15) >> 4;
-            // 4 output blocks per wave iteration: 4 independent MFMA chains, and the read-modify-write of the 16
-            // destination values per lane is issued as 16 loads followed by 16 stores (one L2 round trip per group)
-            for (int t0 = wave * 4; t0 < nt * nt; t0 += 16) {
-                d4 acc[4];
-                int ti[4], tj[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int t = min(t0 + g, nt * nt - 1);
-                    ti[g] = t % nt; tj[g] = t / nt;
-                    acc[g] = (d4){0.0, 0.0, 0.0, 0.0};
-                }
-#pragma unroll
-                for (int k4 = 0; k4 < DB; k4 += 4) {
-                    const int kk = k4 + (lane >> 4);
+            // A22 -= L21 U12 on MFMA, 64 columns of U12 at a time; A := U12^T, B := L21^T so that the 16 fast lanes run
+            // along rows (contiguous in the column-major block).  4 output blocks per wave iteration: 4 independent
+            // MFMA chains, and the 16 destination values per lane go as 16 loads then 16 stores (one L2 round trip).
+            const int ntr = (nc + 15) >> 4;
+            for (int c0 = 0; c0 < nc; c0 += UC) {
+                const int ncc = min(UC, nc - c0), ntc = (ncc + 15) >> 4;
+                for (int idx = tid; idx < DB * ncc; idx += 256) { int i2 = idx & 31, c = idx >> 5; Us[i2 * lus + c] = A[jb + i2 + (size_t) (jb + nb + c0 + c) * lda]; }
+                __syncthreads();
+                for (int t0 = wave * 4; t0 < ntr * ntc; t0 += 16) {
+                    d4 acc[4];
+                    int ti[4], tj[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int rr = min(ti[g] * 16 + (lane & 15), nc - 1), cc = min(tj[g] * 16 + (lane & 15), nc - 1);
-                        acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kk * lus + cc], Ps[kk * ldp + nb + rr], acc[g], 0, 0, 0);
+                        const int t = min(t0 + g, ntr * ntc - 1);
+                        ti[g] = t % ntr; tj[g] = t / ntr;
+                        acc[g] = (d4){0.0, 0.0, 0.0, 0.0};
                     }
-                }
-                double old[4][4];
-                double *dst[4][4];
-                bool ok[4][4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row = ti[g] * 16 + (lane & 15);
+                    for (int k4 = 0; k4 < DB; k4 += 4) {
+                        const int kk = k4 + (lane >> 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = tj[g] * 16 + (lane >> 4) + 4 * r;
-                        ok[g][r] = (t0 + g < nt * nt) && row < nc && col < nc;
-                        dst[g][r] = A + jb + nb + min(row, nc - 1) + (size_t) (jb + nb + min(col, nc - 1)) * lda;
-                        old[g][r] = ok[g][r] ? *dst[g][r] : 0.0;
+                        for (int g = 0; g < 4; ++g) {
+                            const int rr = min(ti[g] * 16 + (lane & 15), nc - 1), cc = min(tj[g] * 16 + (lane & 15), ncc - 1);
+                            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kk * lus + cc], Ps[kk * ldp + nb + rr], acc[g], 0, 0, 0);
+                        }
                     }
+                    double old[4][4];
+                    double *dst[4][4];
+                    bool ok[4][4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = ti[g] * 16 + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = tj[g] * 16 + (lane >> 4) + 4 * r;
+                            ok[g][r] = (t0 + g < ntr * ntc) && row < nc && col < ncc;
+                            dst[g][r] = A + jb + nb + min(row, nc - 1) + (size_t) (jb + nb + c0 + min(col, ncc - 1)) * lda;
+                            old[g][r] = ok[g][r] ? *dst[g][r] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ok[g][r]) *dst[g][r] = old[g][r] - acc[g][r];
                 }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ok[g][r]) *dst[g][r] = old[g][r] - acc[g][r];
+                __syncthreads();
             }
         }
         __syncthreads();
@@ -374,18 +379,24 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
 //         scatter) solved as X^T L_kk^T = B^T on the skyline in place: strip = 32 non-empty U columns
 //         (implicit zero padding above each segment), T = L_kk^T (unit upper).
 // The 32 x ns strip lives in LDS for the whole solve: HBM traffic = one read + one write of the panel.
-constexpr int RS = 64;  // strip rows per workgroup: each of the 4 waves owns 16 rows for the whole solve
+// Strip height RSv = 64 (nsp <= 128) or 32 (nsp <= 256): either way the workgroup needs <= 82 KB of LDS, so a panel
+// workgroup fits beside ONE 128x128 Schur workgroup on a CU -- the high-priority look-ahead stream can then take any
+// slot a finishing Schur workgroup frees instead of waiting for a whole idle CU.
 // LDS images are split in 16-wide groups ([group][k][16]): a 16x4 MFMA fragment read touches 4 k-rows x 16
-// consecutive doubles = all 64 banks once.  Xs = strip (RS x nsp), Tb = double-buffered 32x32 operand block.
-__host__ __device__ inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) RS * nsp + 2 * DB * DB); }
+// consecutive doubles = all 64 banks once.  Xs = strip (RSv x nsp), Tb = double-buffered 32x32 operand block.
+__host__ __device__ inline int trsm_rs(int nsp) { return nsp > 128 ? 32 : 64; }
+__host__ __device__ inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) trsm_rs(nsp) * nsp + 2 * DB * DB); }
 
 // The solve is a flat pipeline of 32x32 operand blocks ("chunks"): for every block column jb the off-diagonal
-// blocks T(kc, jb), kc = 0, 32, .. jb-32, then the inverted diagonal block inv(T_jj).  The next chunk is fetched
-// from L2 into registers while the MFMAs of the current one run; one barrier per chunk guards the LDS double
-// buffer.  A wave only ever reads and writes its own 16 strip rows, so the strip itself needs no barrier.
-template <int MODE>
+// blocks T(kc, jb), kc = 0, 32, .. jb-32, then the inverted diagonal block inv(T_jj).  Chunks are fetched from L2
+// into registers TWO iterations ahead (the chain is latency-bound, not bandwidth-bound); one barrier per chunk guards
+// the LDS double buffer.  A wave only ever reads and writes its own 16 strip rows, so the strip needs no barrier.
+template <int MODE, int RSv>
 __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int strip, double *sm, int *s_cp, int *s_ld)
 {
+    constexpr int NT = RSv * 4;            // one wave per 16 strip rows
+    constexpr int PQ = DB * DB / NT;       // chunk elements per thread
+    constexpr int ES = NT / 32;            // slow-index stride of the chunk loader
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int nsp = (ns + DB - 1) & ~(DB - 1);
     const int lda = T.sn_nsupr[k];
@@ -393,21 +404,21 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     double *A = T.val + T.sn_lval[k];
     double *Uv = T.val + T.sn_uval[k];
     const double *dinv = T.dinv + T.sn_dinv[k] + (MODE == 0 ? 0 : (size_t) nblk * DB * DB);
-    double *Xs = sm;                          // [4][nsp][16]: element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
-    double *Tb = sm + (size_t) RS * nsp;      // [2 buffers][2 halves][32][16]: element (kk, cc) at ((cc>>4)*32 + kk)*16 + (cc&15)
+    double *Xs = sm;                          // [RSv/16][nsp][16]: element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
+    double *Tb = sm + (size_t) RSv * nsp;     // [2 buffers][2 halves][32][16]: element (kk, cc) at ((cc>>4)*32 + kk)*16 + (cc&15)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     if (MODE == 0) {
-        const int row0 = ns + strip * RS;
-        for (int idx = tid; idx < RS * nsp; idx += 256) {
-            const int r = idx & (RS - 1), c = idx >> 6;
+        const int row0 = ns + strip * RSv;
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
+            const int r = idx % RSv, c = idx / RSv;
             double v = 0.0;
             if (c < ns && row0 + r < lda) v = A[row0 + r + (size_t) c * lda];
             Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
         }
     } else {
-        if (tid < RS) {
-            const int cr = strip * RS + tid;
+        if (tid < RSv) {
+            const int cr = strip * RSv + tid;
             int cp = 0, ld = nsp;
             if (cr < T.sn_ncolu[k]) {
                 const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
@@ -422,7 +433,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
             s_cp[tid] = cp; s_ld[tid] = ld;
         }
         __syncthreads();
-        for (int idx = tid; idx < RS * nsp; idx += 256) {
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
             const int c = idx % nsp, r = idx / nsp;
             double v = 0.0;
             const int ld = s_ld[r];
@@ -432,89 +443,105 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     }
 
     // chunk (jb, t): t < jb/32 -> T(32 t, jb) ; t == jb/32 -> inv(T_jj)
-    double pv[4];
-    const int e0 = tid & 31, e1 = tid >> 5;   // fast / slow element index of the 32x32 chunk (slow: e1 + 8q)
-    auto fetch = [&](int jb, int t) {
+    const int e0 = tid & 31, e1 = tid >> 5;   // fast / slow element index of the 32x32 chunk (slow: e1 + ES*q)
+    auto fetch = [&](double *pv, int jb, int t) {
         if (t * DB < jb) {
             const int kc = t * DB;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < PQ; ++q) {
                 // MODE 0: T(k,c) = U_kk(k,c) = A[k + c*lda], k fastest ; MODE 1: T(k,c) = L_kk(c,k) = A[c + k*lda], c fastest
-                const int kg = kc + (MODE == 0 ? e0 : e1 + 8 * q), cg = jb + (MODE == 0 ? e1 + 8 * q : e0);
+                const int kg = kc + (MODE == 0 ? e0 : e1 + ES * q), cg = jb + (MODE == 0 ? e1 + ES * q : e0);
                 pv[q] = (kg < ns && cg < ns) ? (MODE == 0 ? A[kg + (size_t) cg * lda] : A[cg + (size_t) kg * lda]) : 0.0;
             }
         } else {
             const double *dblk = dinv + (size_t) (jb / DB) * DB * DB;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pv[q] = dblk[(e1 + 8 * q) * DB + e0];   // D(kk = e0, cc = e1 + 8q)
+            for (int q = 0; q < PQ; ++q) pv[q] = dblk[(e1 + ES * q) * DB + e0];   // D(kk = e0, cc = e1 + ES*q)
         }
     };
-    auto stash = [&](int jb, int t, int buf) {
+    auto stash = [&](const double *pv, int jb, int t, int buf) {
         double *tb = Tb + buf * (2 * DB * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PQ; ++q) {
             int kk, cc;
-            if (t * DB < jb && MODE == 1) { cc = e0; kk = e1 + 8 * q; } else { kk = e0; cc = e1 + 8 * q; }
+            if (t * DB < jb && MODE == 1) { cc = e0; kk = e1 + ES * q; } else { kk = e0; cc = e1 + ES * q; }
             tb[((cc >> 4) * DB + kk) * 16 + (cc & 15)] = pv[q];
         }
     };
+    auto advance = [&](int &jb, int &t) { if (++t > jb / DB) { jb += DB; t = 0; } };
 
     d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
     const double *xa = Xs + ((size_t) wave * nsp + (lane >> 4)) * 16 + (lane & 15);
-    fetch(0, 0);
-    stash(0, 0, 0);
+    auto compute = [&](int jb, int t, int buf) {
+        const double *tb0 = Tb + buf * (2 * DB * 16) + (lane >> 4) * 16 + (lane & 15);
+        const double *tb1 = tb0 + DB * 16;
+        if (t < jb / DB) {
+            const double *a = xa + (size_t) (t * DB) * 16;
+#pragma unroll
+            for (int k4 = 0; k4 < DB; k4 += 4) {
+                const double av = a[k4 * 16];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
+            }
+        } else {
+            // rhs = X_jb - acc (own 16 rows), then X_jb = rhs * inv(T_jj)
+            double *x0 = Xs + ((size_t) wave * nsp + jb + (lane & 15)) * 16 + (lane >> 4);
+            double *x1 = x0 + 16 * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0[4 * r] -= acc0[r]; x1[4 * r] -= acc1[r]; }
+            acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+            const double *a = xa + (size_t) jb * 16;
+#pragma unroll
+            for (int k4 = 0; k4 < DB; k4 += 4) {
+                const double av = a[k4 * 16];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0[4 * r] = acc0[r]; x1[4 * r] = acc1[r]; }
+            acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+    };
+
+    // software pipeline, two chunks in flight in registers (pA: chunk i+1, pB: chunk i+2, roles swap every iteration)
+    double pA[PQ], pB[PQ];
+    int cj = 0, ct = 0;            // chunk being computed
+    int nj = 0, nt = 0;            // chunk held in the "next" register set
+    int fj = 0, ft = 0;            // chunk held in the "far" register set
+    fetch(pA, 0, 0);
+    stash(pA, 0, 0, 0);
+    advance(nj, nt);
+    fj = nj; ft = nt; advance(fj, ft);
+    if (nj < nsp) fetch(pA, nj, nt);
+    if (fj < nsp) fetch(pB, fj, ft);
     __syncthreads();
     int buf = 0;
-    for (int jb = 0; jb < nsp; jb += DB) {
-        const int nt = jb / DB;
-        for (int t = 0; t <= nt; ++t) {
-            // next chunk in the flat sequence
-            int njb = jb, ntt = t + 1;
-            if (ntt > nt) { njb = jb + DB; ntt = 0; }
-            const bool more = njb < nsp;
-            if (more) fetch(njb, ntt);
-            const double *tb0 = Tb + buf * (2 * DB * 16) + (lane >> 4) * 16 + (lane & 15);
-            const double *tb1 = tb0 + DB * 16;
-            if (t < nt) {
-                const double *a = xa + (size_t) (t * DB) * 16;
-#pragma unroll
-                for (int k4 = 0; k4 < DB; k4 += 4) {
-                    const double av = a[k4 * 16];
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
-                }
-            } else {
-                // rhs = X_jb - acc (own 16 rows), then X_jb = rhs * inv(T_jj)
-                double *x0 = Xs + ((size_t) wave * nsp + jb + (lane & 15)) * 16 + (lane >> 4);
-                double *x1 = x0 + 16 * 16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { x0[4 * r] -= acc0[r]; x1[4 * r] -= acc1[r]; }
-                acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
-                const double *a = xa + (size_t) jb * 16;
-#pragma unroll
-                for (int k4 = 0; k4 < DB; k4 += 4) {
-                    const double av = a[k4 * 16];
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { x0[4 * r] = acc0[r]; x1[4 * r] = acc1[r]; }
-                acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
-            }
-            if (more) stash(njb, ntt, buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-        }
+    while (cj < nsp) {
+        // iteration with roles (next = pA, far = pB)
+        compute(cj, ct, buf);
+        if (nj < nsp) stash(pA, nj, nt, buf ^ 1);
+        cj = nj; ct = nt; nj = fj; nt = ft; advance(fj, ft);
+        if (fj < nsp) fetch(pA, fj, ft);           // pA is free again: becomes the new "far" set
+        __syncthreads();
+        buf ^= 1;
+        if (cj >= nsp) break;
+        // iteration with roles swapped (next = pB, far = pA)
+        compute(cj, ct, buf);
+        if (nj < nsp) stash(pB, nj, nt, buf ^ 1);
+        cj = nj; ct = nt; nj = fj; nt = ft; advance(fj, ft);
+        if (fj < nsp) fetch(pB, fj, ft);
+        __syncthreads();
+        buf ^= 1;
     }
 
     if (MODE == 0) {
-        const int row0 = ns + strip * RS;
-        for (int idx = tid; idx < RS * ns; idx += 256) {
-            const int r = idx & (RS - 1), c = idx >> 6;
+        const int row0 = ns + strip * RSv;
+        for (int idx = tid; idx < RSv * ns; idx += NT) {
+            const int r = idx % RSv, c = idx / RSv;
             if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
         }
     } else {
-        for (int idx = tid; idx < RS * nsp; idx += 256) {
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
             const int c = idx % nsp, r = idx / nsp;
             const int ld = s_ld[r];
             if (c >= ld && c < ns) Uv[s_cp[r] + (c - ld)] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
@@ -523,19 +550,20 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
 }
 
 // L strips (blocks [0, nl)) and U column strips (blocks [nl, nl+nu)) of one level in ONE launch
-__global__ __launch_bounds__(256) void k_panel_trsm(DevTables T, const int *__restrict__ nodes,
-                                                    const int *__restrict__ lprefix, const int *__restrict__ uprefix,
-                                                    int nn, int nl)
+template <int RSv>
+__global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *__restrict__ nodes,
+                                                        const int *__restrict__ lprefix, const int *__restrict__ uprefix,
+                                                        int nn, int nl)
 {
     extern __shared__ double sm[];
-    __shared__ int s_cp[RS], s_ld[RS];
+    __shared__ int s_cp[RSv], s_ld[RSv];
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
-        panel_trsm_body<0>(T, nodes[ni], blockIdx.x - lprefix[ni], sm, s_cp, s_ld);
+        panel_trsm_body<0, RSv>(T, nodes[ni], blockIdx.x - lprefix[ni], sm, s_cp, s_ld);
     } else {
         const int id = blockIdx.x - nl;
         const int ni = find_node(uprefix, nn, id);
-        panel_trsm_body<1>(T, nodes[ni], id - uprefix[ni], sm, s_cp, s_ld);
+        panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm, s_cp, s_ld);
     }
 }
 
@@ -1104,9 +1132,13 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     S.diag_lds.assign(S.nlevels, 0);
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i)
+            S.max_nsupc[l] = std::max(S.max_nsupc[l], hs.xsup[S.nodes[i] + 1] - hs.xsup[S.nodes[i]]);
     for (int l = 0; l < S.nlevels; ++l) {
         int po = S.lvl_poff[l];
         int so = S.lvl_soff[l];
+        const int rs = trsm_rs((S.max_nsupc[l] + 31) & ~31);   // strip height of this level's TRSM launch
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i, ++po, ++so) {
             const int k = S.nodes[i];
             if (i - S.lvl_off[l] == S.n_big[l]) ++so;      // start of the small group: its own prefix, from 0
@@ -1115,8 +1147,8 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             const int rrows = t.sn_nsupr[k] - nsupc;
             S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc);
             S.diag_lds[l] = std::max(S.diag_lds[l], sizeof(double) * ((size_t) 32 * (nsupc | 1) + (size_t) 32 * nsupc));
-            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + RS - 1) / RS;
-            S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + RS - 1) / RS;
+            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + rs - 1) / rs;
+            S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + rs - 1) / rs;
             S.inv_prefix[po + 1] = S.inv_prefix[po] + 2 * ((nsupc + 31) / 32);
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (rrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
@@ -1245,7 +1277,8 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
     H->st.num_levels = nlev;
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
-    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
     H->st.bytes_device = (int64_t) ((hs.nnzL + hs.nnzU) * sizeof(double) + idxb);
@@ -1321,7 +1354,10 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, ps, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
         hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, ps, T, nodes, S.d_inv_prefix + po, nn);
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
-        if (nl + nu) hipLaunchKernelGGL(k_panel_trsm, dim3(nl + nu), dim3(256), lds_tr, ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
+        if (nl + nu) {
+            if (trsm_rs((mx + 31) & ~31) == 32) hipLaunchKernelGGL(k_panel_trsm<32>, dim3(nl + nu), dim3(128), lds_tr, ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
+            else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nl + nu), dim3(256), lds_tr, ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
+        }
         ev_end(H, H->ev_panel, H->ev_panel_used);
         H->st.num_launches += 2 + (nl + nu > 0);
     };
