@@ -384,15 +384,19 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
 // slot a finishing Schur workgroup frees instead of waiting for a whole idle CU.
 // LDS images are split in 16-wide groups ([group][k][16]): a 16x4 MFMA fragment read touches 4 k-rows x 16
 // consecutive doubles = all 64 banks once.  Xs = strip (RSv x nsp), Tb = double-buffered 32x32 operand block.
-__host__ __device__ inline int trsm_rs(int nsp) { return nsp > 128 ? 32 : 64; }
-__host__ __device__ inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) trsm_rs(nsp) * nsp + 2 * DB * DB); }
+static inline int trsm_rs(int nsp)
+{
+    static const bool force64 = getenv("SLUAMD_TRSM_RS64") != nullptr;
+    return (nsp > 128 && !force64) ? 32 : 64;
+}
+static inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) trsm_rs(nsp) * nsp + 2 * DB * DB); }
 
 // The solve is a flat pipeline of 32x32 operand blocks ("chunks"): for every block column jb the off-diagonal
 // blocks T(kc, jb), kc = 0, 32, .. jb-32, then the inverted diagonal block inv(T_jj).  Chunks are fetched from L2
 // into registers TWO iterations ahead (the chain is latency-bound, not bandwidth-bound); one barrier per chunk guards
 // the LDS double buffer.  A wave only ever reads and writes its own 16 strip rows, so the strip needs no barrier.
 template <int MODE, int RSv>
-__device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int strip, double *sm, int *s_cp, int *s_ld)
+__device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int strip, double *sm)
 {
     constexpr int NT = RSv * 4;            // one wave per 16 strip rows
     constexpr int PQ = DB * DB / NT;       // chunk elements per thread
@@ -407,16 +411,10 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     double *Xs = sm;                          // [RSv/16][nsp][16]: element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
     double *Tb = sm + (size_t) RSv * nsp;     // [2 buffers][2 halves][32][16]: element (kk, cc) at ((cc>>4)*32 + kk)*16 + (cc&15)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-
-    if (MODE == 0) {
-        const int row0 = ns + strip * RSv;
-        for (int idx = tid; idx < RSv * nsp; idx += NT) {
-            const int r = idx % RSv, c = idx / RSv;
-            double v = 0.0;
-            if (c < ns && row0 + r < lda) v = A[row0 + r + (size_t) c * lda];
-            Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
-        }
-    } else {
+    // per-strip-row skyline metadata (MODE 1) lives in the Tb region while the pipeline is not running: the workgroup
+    // then needs exactly RSv*nsp + 2048 doubles (80 KB for nsp = 256) and two of them fit on one CU
+    int *s_cp = reinterpret_cast<int *>(Tb), *s_ld = s_cp + RSv;
+    auto locate = [&]() {
         if (tid < RSv) {
             const int cr = strip * RSv + tid;
             int cp = 0, ld = nsp;
@@ -433,6 +431,18 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
             s_cp[tid] = cp; s_ld[tid] = ld;
         }
         __syncthreads();
+    };
+
+    if (MODE == 0) {
+        const int row0 = ns + strip * RSv;
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
+            const int r = idx % RSv, c = idx / RSv;
+            double v = 0.0;
+            if (c < ns && row0 + r < lda) v = A[row0 + r + (size_t) c * lda];
+            Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
+        }
+    } else {
+        locate();
         for (int idx = tid; idx < RSv * nsp; idx += NT) {
             const int c = idx % nsp, r = idx / nsp;
             double v = 0.0;
@@ -440,6 +450,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
             if (c >= ld && c < ns) v = Uv[s_cp[r] + (c - ld)];
             Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
         }
+        __syncthreads();   // the metadata overlay is about to be overwritten by the first chunk
     }
 
     // chunk (jb, t): t < jb/32 -> T(32 t, jb) ; t == jb/32 -> inv(T_jj)
@@ -541,6 +552,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
             if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
         }
     } else {
+        locate();
         for (int idx = tid; idx < RSv * nsp; idx += NT) {
             const int c = idx % nsp, r = idx / nsp;
             const int ld = s_ld[r];
@@ -556,14 +568,13 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
                                                         int nn, int nl)
 {
     extern __shared__ double sm[];
-    __shared__ int s_cp[RSv], s_ld[RSv];
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
-        panel_trsm_body<0, RSv>(T, nodes[ni], blockIdx.x - lprefix[ni], sm, s_cp, s_ld);
+        panel_trsm_body<0, RSv>(T, nodes[ni], blockIdx.x - lprefix[ni], sm);
     } else {
         const int id = blockIdx.x - nl;
         const int ni = find_node(uprefix, nn, id);
-        panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm, s_cp, s_ld);
+        panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm);
     }
 }
 
@@ -1278,7 +1289,7 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
     H->st.bytes_device = (int64_t) ((hs.nnzL + hs.nnzU) * sizeof(double) + idxb);
