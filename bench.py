@@ -194,6 +194,17 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = F * args.steps / elapsed / 1e9
     schur_tf = st["flops_schur_exact"] / (stp["t_schur_ms"] * 1e-3) / 1e12 if stp["t_schur_ms"] > 0 else 0.0
+    # HBM traffic of the dominant kernel from PMC counters: cannot be collected inside this process (rocprofv3 --pmc
+    # needs its own passes), so the value measured on this same command line is kept under profiles/ with its provenance
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_schur.json")
+    if world == 1 and args.n == 100 and os.path.exists(pmc_path):
+        try:
+            pj = json.load(open(pmc_path))
+            traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01_pmc_schur.json: " + pj["source"]
+        except Exception:
+            pass
+    alg_bytes_per_launch = st["schur_bytes_alg"] / max(1, stp["schur_launches"])   # 16 B per updated element
     out = {
         "metric": "LU factorization GFLOP/s (pdgstrf3d) + solve time",
         "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,7 +222,8 @@ def main():
         "levels": st["num_levels"], "launches_per_factor": st["num_launches"], "setup_s": t_setup,
         "roofline": {"bound": "mfma", "kernel": "k_schur (fused gather + fp64 MFMA GEMM + scatter)",
                      "achieved": schur_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": schur_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                     "frac": schur_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "launches": int(stp["schur_launches"]),
                      "avg_launch_ms": stp["t_schur_ms"] / max(1, stp["schur_launches"]),
                      "flops_per_launch": st["flops_schur_exact"] / max(1, stp["schur_launches"]),

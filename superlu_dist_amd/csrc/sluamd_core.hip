@@ -386,8 +386,10 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
 // consecutive doubles = all 64 banks once.  Xs = strip (RSv x nsp), Tb = double-buffered 32x32 operand block.
 static inline int trsm_rs(int nsp)
 {
-    static const bool force64 = getenv("SLUAMD_TRSM_RS64") != nullptr;
-    return (nsp > 128 && !force64) ? 32 : 64;
+    // 32-row strips (80 KB of LDS, two workgroups per CU or one beside a Schur workgroup) measured ~2 % slower end to
+    // end than 64-row strips (144 KB, one per CU) on 100^3; kept selectable
+    static const bool rs32 = getenv("SLUAMD_TRSM_RS32") != nullptr;
+    return (nsp > 128 && rs32) ? 32 : 64;
 }
 static inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) trsm_rs(nsp) * nsp + 2 * DB * DB); }
 
@@ -1010,6 +1012,7 @@ static int build_tables(Handle &H, HostTables &t)
     H.max_nsupc = 0;
     auto &st = H.st;
     st.flops_schur_padded = st.flops_schur_exact = st.flops_panel = 0;
+    st.schur_bytes_alg = 0;
     for (int k = 0; k < ns; ++k) {
         const int nsupc = hs.xsup[k + 1] - hs.xsup[k], klst = hs.xsup[k + 1];
         if (!hs.present[k]) {
@@ -1099,6 +1102,7 @@ static int build_tables(Handle &H, HostTables &t)
         t.sn_nct[k] = (int) t.ctile.size() - t.sn_ct_off[k];
         const double rrows = nsupr - nsupc;
         st.flops_schur_padded += 2.0 * rrows * ldu * ncol_tot;
+        st.schur_bytes_alg += 16.0 * rrows * ncol_tot;   // read-modify-write of every updated destination element
         st.flops_schur_exact += 2.0 * rrows * exact;
         st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc + (double) nsupc * nsupc * rrows + (double) nsupc * exact;
     }
