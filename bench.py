@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--leaf", type=int, default=64)
     ap.add_argument("--relax", type=int, default=64)
     ap.add_argument("--maxsup", type=int, default=256)
-    ap.add_argument("--cpu-n", type=int, default=44)
+    ap.add_argument("--cpu-n", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
