@@ -74,6 +74,14 @@ class DistComm:
         return int(t.item())
 
 
+def _sync(backend):
+    """torch ops (adds, copies, NCCL hand-offs) run on torch's current stream, the library on its own HIP streams:
+    drain torch's stream before the next library call touches the same memory."""
+    f = getattr(backend, "sync", None)
+    if f is not None:
+        f()
+
+
 def pdgstrf3d(backend, comm, z, npdep, thresh):
     """Numeric factorisation over the Z levels; returns info (min over layers, 0 = none)."""
     import torch
@@ -93,6 +101,7 @@ def pdgstrf3d(backend, comm, z, npdep, thresh):
             else:
                 for sl in slices:
                     comm.send(sl, z - step)
+            _sync(backend)
     info, _ = backend.info()
     big = backend.n + 1
     g = comm.allreduce_min_int(info if info else big, backend.device)
@@ -108,6 +117,7 @@ def init_rhs(backend, z, npdep, xp):
         if z % (1 << ilvl) == 0:
             for a, b in backend.tree_rows(ilvl):
                 keep[:, a:b] = xp[:, a:b]
+    _sync(backend)
     return keep
 
 
@@ -132,6 +142,7 @@ def pdgstrs3d(backend, comm, z, npdep, x):
             else:
                 for a, b in rows:
                     comm.send(x[:, a:b], z - step)
+            _sync(backend)
     # backward sweep, root to leaves
     for ilvl in reversed(range(maxlvl)):
         step = 1 << ilvl
@@ -148,6 +159,7 @@ def pdgstrs3d(backend, comm, z, npdep, x):
                     tmp = torch.empty((x.shape[0], b - a), dtype=x.dtype, device=x.device)
                     comm.recv(tmp, z - step)
                     x[:, a:b] = tmp
+            _sync(backend)
         backend.solve_level(ilvl, -1, x)
     # assemble: every row is final on the layer that owns its forest
     out = torch.zeros_like(x)
@@ -157,6 +169,7 @@ def pdgstrs3d(backend, comm, z, npdep, x):
                 out[:, a:b] = x[:, a:b]
     comm.allreduce_sum(out)
     x.copy_(out)
+    _sync(backend)
     return x
 
 
@@ -229,6 +242,10 @@ class GpuLayer:
         assert x.is_contiguous() and x.dtype.itemsize == 8
         _lib.check(self.L.sluamd_pdgstrs3d_level(self._h, ilvl, direction, C.c_void_p(x.data_ptr()), x.shape[1], x.shape[0]),
                    "sluamd_pdgstrs3d_level")
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize(self.device)
 
     def info(self):
         i = C.c_int32(); t = C.c_int32()
