@@ -6,13 +6,13 @@
  * pdgssvx3d (SRC/double/pdgssvx3d.c:519) exactly like EXAMPLE/pddrive3d.c:101 does and,
  * by `ld --wrap`, records what crosses the hot-path boundary:
  *
- *   __wrap_pdgstrf3d           : LU store + 3D partition BEFORE and AFTER the real
+ *   WRAP(gstrf3d)           : LU store + 3D partition BEFORE and AFTER the real
  *                                pdgstrf3d (SRC/double/pdgstrf3d.c:121)
- *   __wrap_pdgstrs3d_newsolve  : B before/after the real pdgstrs3d_newsolve
- *   __wrap_pdgstrs3d             (SRC/double/pdgstrs3d.c:6935 / :6604), plus perm_r/perm_c
+ *   WRAP(gstrs3d_newsolve)  : B before/after the real pdgstrs3d_newsolve
+ *   WRAP(gstrs3d)             (SRC/double/pdgstrs3d.c:6935 / :6604), plus perm_r/perm_c
  *
  * Output: one container file per rank, "<out>.r<rank>.slud": a sequence of records
- *   int32 name_len | name bytes | int32 dtype (0=int32,1=int64,2=float64) | int64 count | data
+ *   int32 name_len | name bytes | int32 dtype (0=int32,1=int64,2=float64,3=complex128) | int64 count | data
  * read by tests/golden/slud.py.
  *
  * usage: mpiexec -n R*C*D slu_ref_dump -r R -c C -d D [-q colperm] [-p rowperm] [-e equil]
@@ -22,17 +22,57 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#ifdef Z_PREC   /* complex16 twin: pzgssvx3d / pzgstrf3d / pzgstrs3d (SRC/complex16) */
+#include "superlu_zdefs.h"
+typedef doublecomplex scalar_t;
+#define VAL_DTYPE 3
+#define xLUstruct_t zLUstruct_t
+#define xLocalLU_t zLocalLU_t
+#define xtrf3Dpartition_t ztrf3Dpartition_t
+#define xScalePermstruct_t zScalePermstruct_t
+#define xSOLVEstruct_t zSOLVEstruct_t
+#define pxgstrf3d pzgstrf3d
+#define pxgstrs3d pzgstrs3d
+#define pxgstrs3d_newsolve pzgstrs3d_newsolve
+#define pxgssvx3d pzgssvx3d
+#define xcreate_matrix_postfix3d zcreate_matrix_postfix3d
+#define xScalePermstructInit zScalePermstructInit
+#define xLUstructInit zLUstructInit
+#define xMalloc_dist doublecomplexMalloc_dist
+#define pxinf_norm_error pzinf_norm_error
+#define WRAP(name) __wrap_pz##name
+#define REAL(name) __real_pz##name
+#else
 #include "superlu_ddefs.h"
+typedef double scalar_t;
+#define VAL_DTYPE 2
+#define xLUstruct_t dLUstruct_t
+#define xLocalLU_t dLocalLU_t
+#define xtrf3Dpartition_t dtrf3Dpartition_t
+#define xScalePermstruct_t dScalePermstruct_t
+#define xSOLVEstruct_t dSOLVEstruct_t
+#define pxgstrf3d pdgstrf3d
+#define pxgstrs3d pdgstrs3d
+#define pxgstrs3d_newsolve pdgstrs3d_newsolve
+#define pxgssvx3d pdgssvx3d
+#define xcreate_matrix_postfix3d dcreate_matrix_postfix3d
+#define xScalePermstructInit dScalePermstructInit
+#define xLUstructInit dLUstructInit
+#define xMalloc_dist doubleMalloc_dist
+#define pxinf_norm_error pdinf_norm_error
+#define WRAP(name) __wrap_pd##name
+#define REAL(name) __real_pd##name
+#endif
 
 static FILE *g_out = NULL;
-static double *g_b0 = NULL;   /* copy of the first right-hand side before the solve */
+static scalar_t *g_b0 = NULL;   /* copy of the first right-hand side before the solve */
 static int g_solve_count = 0;
 
 static void put(const char *name, int dtype, long long count, const void *data)
 {
     if (!g_out) return;            /* -o none: timing run, nothing recorded */
     int nl = (int) strlen(name);
-    size_t esz = dtype == 0 ? 4 : 8;
+    size_t esz = dtype == 0 ? 4 : (dtype == 3 ? 16 : 8);
     fwrite(&nl, 4, 1, g_out);
     fwrite(name, 1, nl, g_out);
     fwrite(&dtype, 4, 1, g_out);
@@ -48,10 +88,10 @@ static void put_intt(const char *name, long long count, const int_t *p)
 
 /* Walk the L/U store of this rank (formats: SURVEY.md Appendix A,
  * SRC/include/superlu_defs.h:156-198) and emit flat copies + offsets. */
-static void dump_lu(const char *tag, dLUstruct_t *LUstruct, gridinfo_t *grid, int values_only)
+static void dump_lu(const char *tag, xLUstruct_t *LUstruct, gridinfo_t *grid, int values_only)
 {
     Glu_persist_t *Glu = LUstruct->Glu_persist;
-    dLocalLU_t *Llu = LUstruct->Llu;
+    xLocalLU_t *Llu = LUstruct->Llu;
     int_t *xsup = Glu->xsup;
 
     char nm[128];
@@ -99,26 +139,26 @@ static void dump_lu(const char *tag, dLUstruct_t *LUstruct, gridinfo_t *grid, in
         put_intt("Ufstnz", uoff[nlbr], uidx);
         free(lidx); free(uidx);
     }
-    double *lval = (double *) malloc(8 * (lvoff[nlbc] + 1));
-    double *uval = (double *) malloc(8 * (uvoff[nlbr] + 1));
+    scalar_t *lval = (scalar_t *) malloc(sizeof(scalar_t) * (lvoff[nlbc] + 1));
+    scalar_t *uval = (scalar_t *) malloc(sizeof(scalar_t) * (uvoff[nlbr] + 1));
     for (int_t lk = 0; lk < nlbc; ++lk)
         if (lvoff[lk + 1] > lvoff[lk])
-            memcpy(lval + lvoff[lk], Llu->Lnzval_bc_ptr[lk], 8 * (lvoff[lk + 1] - lvoff[lk]));
+            memcpy(lval + lvoff[lk], Llu->Lnzval_bc_ptr[lk], sizeof(scalar_t) * (lvoff[lk + 1] - lvoff[lk]));
     for (int_t lb = 0; lb < nlbr; ++lb)
         if (uvoff[lb + 1] > uvoff[lb])
-            memcpy(uval + uvoff[lb], Llu->Unzval_br_ptr[lb], 8 * (uvoff[lb + 1] - uvoff[lb]));
-    snprintf(nm, sizeof nm, "Lnzval_%s", tag); put(nm, 2, lvoff[nlbc], lval);
-    snprintf(nm, sizeof nm, "Unzval_%s", tag); put(nm, 2, uvoff[nlbr], uval);
+            memcpy(uval + uvoff[lb], Llu->Unzval_br_ptr[lb], sizeof(scalar_t) * (uvoff[lb + 1] - uvoff[lb]));
+    snprintf(nm, sizeof nm, "Lnzval_%s", tag); put(nm, VAL_DTYPE, lvoff[nlbc], lval);
+    snprintf(nm, sizeof nm, "Unzval_%s", tag); put(nm, VAL_DTYPE, uvoff[nlbr], uval);
     free(lval); free(uval); free(loff); free(lvoff); free(uoff); free(uvoff);
     (void) myrow;
 }
 int_t g_nsupers_dump = 0;
 
-int_t __real_pdgstrf3d(superlu_dist_options_t *, int, int, double, dtrf3Dpartition_t *, SCT_t *,
-                       dLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
+int_t REAL(gstrf3d)(superlu_dist_options_t *, int, int, double, xtrf3Dpartition_t *, SCT_t *,
+                       xLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
 
-int_t __wrap_pdgstrf3d(superlu_dist_options_t *options, int m, int n, double anorm,
-                       dtrf3Dpartition_t *part, SCT_t *SCT, dLUstruct_t *LUstruct,
+int_t WRAP(gstrf3d)(superlu_dist_options_t *options, int m, int n, double anorm,
+                       xtrf3Dpartition_t *part, SCT_t *SCT, xLUstruct_t *LUstruct,
                        gridinfo3d_t *grid3d, SuperLUStat_t *stat, int *info)
 {
     gridinfo_t *grid = &grid3d->grid2d;
@@ -157,11 +197,11 @@ int_t __wrap_pdgstrf3d(superlu_dist_options_t *options, int m, int n, double ano
     }
     if (g_out) dump_lu("pre", LUstruct, grid, 0);
 #ifdef USE_SLUAMD   /* slu_ref_amd: the reference pipeline with OUR numeric factorisation (oracle/ref/sluamd_binding.c) */
-    extern int_t sluamd_bind_pdgstrf3d(superlu_dist_options_t *, int, int, double, dtrf3Dpartition_t *, SCT_t *,
-                                       dLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
+    extern int_t sluamd_bind_pdgstrf3d(superlu_dist_options_t *, int, int, double, xtrf3Dpartition_t *, SCT_t *,
+                                       xLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
     int_t r = sluamd_bind_pdgstrf3d(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
 #else
-    int_t r = __real_pdgstrf3d(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
+    int_t r = REAL(gstrf3d)(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
 #endif
     if (g_out) dump_lu("post", LUstruct, grid, 1);
     put_i("info", *info);
@@ -170,7 +210,7 @@ int_t __wrap_pdgstrf3d(superlu_dist_options_t *options, int m, int n, double ano
     return r;
 }
 
-static void dump_solve(const char *which, int_t n, dScalePermstruct_t *SP, double *B,
+static void dump_solve(const char *which, int_t n, xScalePermstruct_t *SP, scalar_t *B,
                        int_t m_loc, int_t fst_row, int_t ldb, int nrhs, int after)
 {
     char nm[96];
@@ -185,38 +225,38 @@ static void dump_solve(const char *which, int_t n, dScalePermstruct_t *SP, doubl
         }
     }
     if (!g_out) return;
-    double *buf = (double *) malloc(8 * (size_t) (m_loc * nrhs + 1));
+    scalar_t *buf = (scalar_t *) malloc(sizeof(scalar_t) * (size_t) (m_loc * nrhs + 1));
     for (int j = 0; j < nrhs; ++j)
         for (int_t i = 0; i < m_loc; ++i) buf[i + j * m_loc] = B[i + j * ldb];
     snprintf(nm, sizeof nm, "solve%d_B_%s", g_solve_count, after ? "out" : "in");
-    put(nm, 2, (long long) m_loc * nrhs, buf);
+    put(nm, VAL_DTYPE, (long long) m_loc * nrhs, buf);
     free(buf);
 }
 
-void __real_pdgstrs3d_newsolve(superlu_dist_options_t *, int_t, dLUstruct_t *, dScalePermstruct_t *,
-                               dtrf3Dpartition_t *, gridinfo3d_t *, double *, int_t, int_t, int_t, int,
-                               dSOLVEstruct_t *, SuperLUStat_t *, int *);
-void __wrap_pdgstrs3d_newsolve(superlu_dist_options_t *options, int_t n, dLUstruct_t *LUstruct,
-                               dScalePermstruct_t *SP, dtrf3Dpartition_t *part, gridinfo3d_t *grid3d,
-                               double *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
-                               dSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
+void REAL(gstrs3d_newsolve)(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *,
+                               xtrf3Dpartition_t *, gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int,
+                               xSOLVEstruct_t *, SuperLUStat_t *, int *);
+void WRAP(gstrs3d_newsolve)(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct,
+                               xScalePermstruct_t *SP, xtrf3Dpartition_t *part, gridinfo3d_t *grid3d,
+                               scalar_t *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
+                               xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
 {
     dump_solve("newsolve", n, SP, B, m_loc, fst_row, ldb, nrhs, 0);
-    __real_pdgstrs3d_newsolve(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,
+    REAL(gstrs3d_newsolve)(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,
                               SOLVEstruct, stat, info);
     dump_solve("newsolve", n, SP, B, m_loc, fst_row, ldb, nrhs, 1);
     ++g_solve_count;
 }
-void __real_pdgstrs3d(superlu_dist_options_t *, int_t, dLUstruct_t *, dScalePermstruct_t *,
-                      dtrf3Dpartition_t *, gridinfo3d_t *, double *, int_t, int_t, int_t, int,
-                      dSOLVEstruct_t *, SuperLUStat_t *, int *);
-void __wrap_pdgstrs3d(superlu_dist_options_t *options, int_t n, dLUstruct_t *LUstruct,
-                      dScalePermstruct_t *SP, dtrf3Dpartition_t *part, gridinfo3d_t *grid3d,
-                      double *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
-                      dSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
+void REAL(gstrs3d)(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *,
+                      xtrf3Dpartition_t *, gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int,
+                      xSOLVEstruct_t *, SuperLUStat_t *, int *);
+void WRAP(gstrs3d)(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct,
+                      xScalePermstruct_t *SP, xtrf3Dpartition_t *part, gridinfo3d_t *grid3d,
+                      scalar_t *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
+                      xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
 {
     dump_solve("legacy", n, SP, B, m_loc, fst_row, ldb, nrhs, 0);
-    __real_pdgstrs3d(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,
+    REAL(gstrs3d)(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,
                      SOLVEstruct, stat, info);
     dump_solve("legacy", n, SP, B, m_loc, fst_row, ldb, nrhs, 1);
     ++g_solve_count;
@@ -227,11 +267,12 @@ int main(int argc, char *argv[])
     superlu_dist_options_t options;
     SuperLUStat_t stat;
     SuperMatrix A;
-    dScalePermstruct_t ScalePermstruct;
-    dLUstruct_t LUstruct;
-    dSOLVEstruct_t SOLVEstruct;
+    xScalePermstruct_t ScalePermstruct;
+    xLUstruct_t LUstruct;
+    xSOLVEstruct_t SOLVEstruct;
     gridinfo3d_t grid;
-    double *berr, *b, *xtrue;
+    double *berr;
+    scalar_t *b, *xtrue;
     int nprow = 1, npcol = 1, npdep = 1, nrhs = 1;
     int equil = -1, colperm = -1, rowperm = -1, ir = -1, tiny = -1, quiet = 0;
     int info, ldb, ldx;
@@ -284,17 +325,17 @@ int main(int argc, char *argv[])
             if (!g_out) { fprintf(stderr, "cannot open %s\n", fn); exit(2); }
         }
     }
-    dcreate_matrix_postfix3d(&A, nrhs, &b, &ldb, &xtrue, &ldx, fp, suffix, &grid);
+    xcreate_matrix_postfix3d(&A, nrhs, &b, &ldb, &xtrue, &ldx, fp, suffix, &grid);
     if (!(berr = doubleMalloc_dist(nrhs))) ABORT("Malloc fails for berr[].");
     int_t m = A.nrow, n = A.ncol;
-    dScalePermstructInit(m, n, &ScalePermstruct);
+    xScalePermstructInit(m, n, &ScalePermstruct);
     if (permfile) { /* ColPerm = MY_PERMC: pdgssvx3d.c:749-791 uses ScalePermstruct->perm_c as given */
         FILE *pf = fopen(permfile, "r");
         if (!pf) { fprintf(stderr, "cannot open perm file\n"); exit(2); }
         for (int_t i = 0; i < n; ++i) { long v; if (fscanf(pf, "%ld", &v) != 1) ABORT("perm file short"); ScalePermstruct.perm_c[i] = (int) v; }
         fclose(pf);
     }
-    dLUstructInit(n, &LUstruct);
+    xLUstructInit(n, &LUstruct);
     PStatInit(&stat);
 
     /* record the local slice of A, b, xtrue (NRformat_loc: supermatrix.h) */
@@ -303,12 +344,12 @@ int main(int argc, char *argv[])
         put_i("A_n", n); put_i("A_m_loc", As->m_loc); put_i("A_fst_row", As->fst_row); put_i("A_nnz_loc", As->nnz_loc);
         put_intt("A_rowptr", As->m_loc + 1, As->rowptr);
         put_intt("A_colind", As->nnz_loc, As->colind);
-        put("A_nzval", 2, As->nnz_loc, As->nzval);
-        double *tmp = (double *) malloc(8 * (size_t) (As->m_loc * nrhs + 1));
+        put("A_nzval", VAL_DTYPE, As->nnz_loc, As->nzval);
+        scalar_t *tmp = (scalar_t *) malloc(sizeof(scalar_t) * (size_t) (As->m_loc * nrhs + 1));
         for (int j = 0; j < nrhs; ++j) for (int_t i = 0; i < As->m_loc; ++i) tmp[i + j * As->m_loc] = b[i + j * ldb];
-        put("b", 2, (long long) As->m_loc * nrhs, tmp);
+        put("b", VAL_DTYPE, (long long) As->m_loc * nrhs, tmp);
         for (int j = 0; j < nrhs; ++j) for (int_t i = 0; i < As->m_loc; ++i) tmp[i + j * As->m_loc] = xtrue[i + j * ldx];
-        put("xtrue", 2, (long long) As->m_loc * nrhs, tmp);
+        put("xtrue", VAL_DTYPE, (long long) As->m_loc * nrhs, tmp);
         free(tmp);
         put_i("nrhs", nrhs);
         put_i("opt_Equil", options.Equil); put_i("opt_RowPerm", options.RowPerm);
@@ -317,16 +358,16 @@ int main(int argc, char *argv[])
 
     {
         NRformat_loc *As = (NRformat_loc *) A.Store;
-        g_b0 = (double *) malloc(8 * (size_t) (As->m_loc + 1));
+        g_b0 = (scalar_t *) malloc(sizeof(scalar_t) * (size_t) (As->m_loc + 1));
         for (int_t i = 0; i < As->m_loc; ++i) g_b0[i] = b[i];
     }
-    pdgssvx3d(&options, &A, &ScalePermstruct, b, ldb, nrhs, &grid, &LUstruct, &SOLVEstruct, berr, &stat, &info);
+    pxgssvx3d(&options, &A, &ScalePermstruct, b, ldb, nrhs, &grid, &LUstruct, &SOLVEstruct, berr, &stat, &info);
 
     {
         NRformat_loc *As = (NRformat_loc *) A.Store;
-        double *tmp = (double *) malloc(8 * (size_t) (As->m_loc * nrhs + 1));
+        scalar_t *tmp = (scalar_t *) malloc(sizeof(scalar_t) * (size_t) (As->m_loc * nrhs + 1));
         for (int j = 0; j < nrhs; ++j) for (int_t i = 0; i < As->m_loc; ++i) tmp[i + j * As->m_loc] = b[i + j * ldb];
-        put("x", 2, (long long) As->m_loc * nrhs, tmp);
+        put("x", VAL_DTYPE, (long long) As->m_loc * nrhs, tmp);
         free(tmp);
         put("berr", 2, nrhs, berr);
         put_i("final_info", info);
@@ -337,16 +378,25 @@ int main(int argc, char *argv[])
         put_i("DiagScale", ScalePermstruct.DiagScale);
     }
     if (info) { if (!grid.iam) printf("ERROR: INFO = %d returned from pdgssvx3d()\n", info); }
-    else if (!quiet) pdinf_norm_error(grid.iam, ((NRformat_loc *) A.Store)->m_loc, nrhs, b, ldb, xtrue, ldx, grid.comm);
+    else if (!quiet) pxinf_norm_error(grid.iam, ((NRformat_loc *) A.Store)->m_loc, nrhs, b, ldb, xtrue, ldx, grid.comm);
     if (grid.zscp.Iam == 0 && !quiet) PStatPrint(&options, &stat, &(grid.grid2d));
     {   /* residual on the original system, computed here for the drop-in test: ||b - A x||_2 / ||b||_2 (1 rank) */
         NRformat_loc *As = (NRformat_loc *) A.Store;
         if (grid.nprow * grid.npcol * grid.npdep == 1 && g_b0) {
             double rn = 0, bn = 0;
             for (int_t i = 0; i < As->m_loc; ++i) {
+#ifdef Z_PREC
+                double sr = g_b0[i].r, si = g_b0[i].i;
+                for (int_t e = As->rowptr[i]; e < As->rowptr[i + 1]; ++e) {
+                    doublecomplex a = ((doublecomplex *) As->nzval)[e], xx = b[As->colind[e]];
+                    sr -= a.r * xx.r - a.i * xx.i; si -= a.r * xx.i + a.i * xx.r;
+                }
+                rn += sr * sr + si * si; bn += g_b0[i].r * g_b0[i].r + g_b0[i].i * g_b0[i].i;
+#else
                 double s = g_b0[i];
                 for (int_t e = As->rowptr[i]; e < As->rowptr[i + 1]; ++e) s -= ((double *) As->nzval)[e] * b[As->colind[e]];
                 rn += s * s; bn += g_b0[i] * g_b0[i];
+#endif
             }
             printf("RESIDUAL %.6e INFO %d\n", sqrt(rn / bn), info);
         }

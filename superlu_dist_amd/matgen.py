@@ -111,9 +111,26 @@ def random_unsym(n, density=0.02, seed=0):
 
 
 def write_triplet_dat(path, n, rowptr, colind, vals):
-    """'.dat' triplet file the reference reads (SRC/double/dreadtriple.c:43-92): header 'm n nnz', 1-based."""
+    """'.dat' triplet file the reference reads (SRC/double/dreadtriple.c:43-92, complex: SRC/complex16/zreadtriple.c):
+    header 'm n nnz', 1-based, 'row col value' or 'row col re im'."""
     rows = np.repeat(np.arange(n), np.diff(rowptr))
+    cplx = np.iscomplexobj(vals)
     with open(path, "w") as f:
         f.write(f"{n} {n} {len(vals)}\n")
         for r, c, v in zip(rows, colind, vals):
-            f.write(f"{r + 1} {c + 1} {float(v)!r}\n")
+            if cplx:
+                f.write(f"{r + 1} {c + 1} {float(v.real)!r} {float(v.imag)!r}\n")
+            else:
+                f.write(f"{r + 1} {c + 1} {float(v)!r}\n")
+
+
+def complex_shift(vals, rowptr, colind, seed=0):
+    """Complex test values on an existing pattern: v*(1 + 0.3i*u) off the diagonal, diagonal += (1 + 0.5i)
+    (keeps diagonal dominance; the cg20-style 'complex grid operator' of BASELINE.json config 5)."""
+    rng = np.random.default_rng(seed)
+    n = len(rowptr) - 1
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    out = vals.astype(np.complex128) * (1.0 + 0.3j * rng.uniform(-1, 1, len(vals)))
+    d = rows == colind
+    out[d] = vals[d] * (1.0 + 0.0j) + (1.0 + 0.5j)
+    return out

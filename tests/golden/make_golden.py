@@ -19,6 +19,7 @@ from superlu_dist_amd import matgen  # noqa: E402
 from slud import read_slud  # noqa: E402
 
 DUMP = os.path.join(ROOT, "oracle", "_ref", "slu_ref_dump")
+ZDUMP = os.path.join(ROOT, "oracle", "_ref", "slu_ref_zdump")
 REF_EX = "/root/reference/EXAMPLE"
 
 # name -> dict(matrix=..., grid=(r,c,d), flags=[...], nd=bool)
@@ -38,6 +39,11 @@ CASES = {
     "unsym300": dict(matrix=("unsym", 300, 0.02, 7), grid=(1, 1, 1), flags=[]),
     # tiny-pivot replacement exercised (ReplaceTinyPivot=YES)
     "unsym120_tiny": dict(matrix=("unsym", 120, 0.05, 3), grid=(1, 1, 1), flags=["-T", "1"]),
+    # ---- complex16 (pzgssvx3d / pzgstrf3d / pzgstrs3d): BASELINE.json config 5 family ----
+    "z_cg20_1x1x1": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 1), flags=[], z=True),
+    "z_cg20_1x1x1_nrhs2": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 1), flags=["-s", "2"], z=True),
+    "z_poisson8_nd": dict(matrix=("zpoisson", 8), grid=(1, 1, 1), nd=16, flags=["-e", "0", "-p", "0", "-i", "0"], z=True),
+    "z_unsym200": dict(matrix=("zunsym", 200, 0.03, 9), grid=(1, 1, 1), flags=[], z=True),
 }
 
 
@@ -47,12 +53,14 @@ def build_case(name, spec, tmp):
     if kind == "file":
         mpath = spec["matrix"][1]
     else:
-        if kind == "poisson":
+        if kind in ("poisson", "zpoisson"):
             N = spec["matrix"][1]
             n, rp, ci, v = matgen.poisson3d(N)
         else:
             _, nn, dens, seed = spec["matrix"]
             n, rp, ci, v = matgen.random_unsym(nn, dens, seed)
+        if kind.startswith("z"):
+            v = matgen.complex_shift(v, rp, ci, seed=1)
         mpath = os.path.join(tmp, name + ".dat")
         matgen.write_triplet_dat(mpath, n, rp, ci, v)
         if spec.get("nd"):
@@ -64,7 +72,7 @@ def build_case(name, spec, tmp):
     r, c, d = spec["grid"]
     nproc = r * c * d
     outp = os.path.join(tmp, name)
-    cmd = ["/opt/conda/bin/mpiexec", "-n", str(nproc), DUMP, "-r", str(r), "-c", str(c), "-d", str(d),
+    cmd = ["/opt/conda/bin/mpiexec", "-n", str(nproc), ZDUMP if spec.get("z") else DUMP, "-r", str(r), "-c", str(c), "-d", str(d),
            "-Q", "1", "-o", outp] + flags + [mpath]
     env = dict(os.environ, OMP_NUM_THREADS="1", LD_LIBRARY_PATH="/opt/conda/lib")
     env.update(spec.get("env", {}))

@@ -2,7 +2,7 @@
 import struct
 import numpy as np
 
-_DT = {0: np.int32, 1: np.int64, 2: np.float64}
+_DT = {0: np.int32, 1: np.int64, 2: np.float64, 3: np.complex128}
 
 
 def read_slud(path):

@@ -17,6 +17,7 @@ def lib():
             subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")])
         _lib = ctypes.CDLL(_SO)
         _lib.slu_oracle_dfactor.restype = ctypes.c_int
+        _lib.slu_oracle_zfactor.restype = ctypes.c_int
         _lib.slu_oracle_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -35,11 +36,12 @@ class LUStore:
         self.Lrowind_off = np.ascontiguousarray(Lrowind_off, dtype=np.int64)
         self.Lrowind = np.ascontiguousarray(Lrowind, dtype=np.int32)
         self.Lnzval_off = np.ascontiguousarray(Lnzval_off, dtype=np.int64)
-        self.Lnzval = np.array(Lnzval, dtype=np.float64)
+        self.dtype = np.complex128 if np.iscomplexobj(Lnzval) or np.iscomplexobj(Unzval) else np.float64
+        self.Lnzval = np.array(Lnzval, dtype=self.dtype)
         self.Ufstnz_off = np.ascontiguousarray(Ufstnz_off, dtype=np.int64)
         self.Ufstnz = np.ascontiguousarray(Ufstnz, dtype=np.int32)
         self.Unzval_off = np.ascontiguousarray(Unzval_off, dtype=np.int64)
-        self.Unzval = np.array(Unzval, dtype=np.float64)
+        self.Unzval = np.array(Unzval, dtype=self.dtype)
 
     @classmethod
     def from_golden(cls, g, rank=0, which="pre"):
@@ -55,9 +57,13 @@ class LUStore:
     def _args(self):
         return (ctypes.c_int(self.n), ctypes.c_int(self.nsupers), _p(self.xsup, ctypes.c_int),
                 _p(self.Lrowind_off, ctypes.c_int64), _p(self.Lrowind, ctypes.c_int),
-                _p(self.Lnzval_off, ctypes.c_int64), _p(self.Lnzval, ctypes.c_double),
+                _p(self.Lnzval_off, ctypes.c_int64), self.Lnzval.ctypes.data_as(ctypes.c_void_p),
                 _p(self.Ufstnz_off, ctypes.c_int64), _p(self.Ufstnz, ctypes.c_int),
-                _p(self.Unzval_off, ctypes.c_int64), _p(self.Unzval, ctypes.c_double))
+                _p(self.Unzval_off, ctypes.c_int64), self.Unzval.ctypes.data_as(ctypes.c_void_p))
+
+    @property
+    def z(self):
+        return self.dtype == np.complex128
 
 
 def dfactor(store, order=None, replace_tiny=False, thresh=0.0):
@@ -67,7 +73,8 @@ def dfactor(store, order=None, replace_tiny=False, thresh=0.0):
     order = np.ascontiguousarray(order, dtype=np.int32)
     info = ctypes.c_int(0)
     flops = np.zeros(2)
-    tiny = lib().slu_oracle_dfactor(*store._args(), _p(order, ctypes.c_int), ctypes.c_int(len(order)),
+    fn = lib().slu_oracle_zfactor if store.z else lib().slu_oracle_dfactor
+    tiny = fn(*store._args(), _p(order, ctypes.c_int), ctypes.c_int(len(order)),
                                     ctypes.c_int(int(replace_tiny)), ctypes.c_double(thresh), ctypes.byref(info),
                                     _p(flops, ctypes.c_double))
     return info.value, tiny, flops
@@ -75,19 +82,22 @@ def dfactor(store, order=None, replace_tiny=False, thresh=0.0):
 
 def dsolve(store, x):
     """Solve L U x = b on the permuted system; x (n x nrhs, Fortran order) overwritten and returned."""
-    x = np.asfortranarray(np.array(x, dtype=np.float64))
+    x = np.asfortranarray(np.array(x, dtype=store.dtype))
     if x.ndim == 1:
         x = np.asfortranarray(x[:, None])
-    lib().slu_oracle_dsolve(*store._args(), _p(x, ctypes.c_double), ctypes.c_int(x.shape[0]), ctypes.c_int(x.shape[1]))
+    fn = lib().slu_oracle_zsolve if store.z else lib().slu_oracle_dsolve
+    fn(*store._args(), x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(x.shape[0]), ctypes.c_int(x.shape[1]))
     return x
 
 
 def dsolve_level(store, x, nodes, direction):
     """In-place forward (+1) / backward (-1) solve restricted to the ascending supernode list `nodes`."""
-    assert x.flags.f_contiguous and x.dtype == np.float64
+    assert x.flags.f_contiguous and x.dtype == store.dtype
     nodes = np.ascontiguousarray(nodes, dtype=np.int32)
-    fn = lib().slu_oracle_dsolve_fwd if direction > 0 else lib().slu_oracle_dsolve_bwd
-    fn(*store._args(), _p(x, ctypes.c_double), ctypes.c_int(x.shape[0]), ctypes.c_int(x.shape[1]),
+    L = lib()
+    fn = ((L.slu_oracle_zsolve_fwd if direction > 0 else L.slu_oracle_zsolve_bwd) if store.z else
+          (L.slu_oracle_dsolve_fwd if direction > 0 else L.slu_oracle_dsolve_bwd))
+    fn(*store._args(), x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(x.shape[0]), ctypes.c_int(x.shape[1]),
        _p(nodes, ctypes.c_int), ctypes.c_int(len(nodes)))
     return x
 

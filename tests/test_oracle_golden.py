@@ -5,7 +5,9 @@ import pytest
 import oracle as orc
 
 CASES_1RANK = ["g20_1x1x1", "g20_1x1x1_nrhs3", "g20_1x1x1_legacy", "poisson8_nd", "poisson10_nd", "unsym300",
-               "unsym120_tiny"]
+               "unsym120_tiny",
+               # complex16: pzgstrf3d / pzgstrs3d recorded from the reference's SRC/complex16 path
+               "z_cg20_1x1x1", "z_cg20_1x1x1_nrhs2", "z_poisson8_nd", "z_unsym200"]
 
 
 def _order(g):
@@ -38,7 +40,7 @@ def test_solve_matches_reference(golden, case):
         nrhs = int(g[f"r0__solve{s}_nrhs"][0])
         B = g[f"r0__solve{s}_B_in"].reshape((n, nrhs), order="F")
         X = g[f"r0__solve{s}_B_out"].reshape((n, nrhs), order="F")
-        xp = np.zeros((n, nrhs), order="F")
+        xp = np.zeros((n, nrhs), order="F", dtype=B.dtype)
         xp[pc[pr], :] = B                       # pdReDistribute3d_B_to_X: row perm_c[perm_r[i]] (pdgstrs3d.c:6329)
         xs = orc.dsolve(st, xp)
         got = xs                                # pdReDistribute3d_X_to_B leaves Y = Pc*X (pdgstrs3d.c:6573-6575);
