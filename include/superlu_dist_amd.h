@@ -54,6 +54,20 @@ typedef struct sluamd_dLUview {
     double **Unzval_br_ptr;         /* Llu->Unzval_br_ptr                                    */
 } sluamd_dLUview_t;
 
+/* complex16 twin (zLUstruct_t->Llu, superlu_zdefs.h): same layout, values are doublecomplex {r, i} (dcomplex.h) */
+typedef struct { double r, i; } sluamd_doublecomplex;
+typedef struct sluamd_zLUview {
+    int64_t n;
+    int32_t nsupers;
+    const sluamd_int_t *xsup;
+    int32_t nprow, npcol, npdep;
+    int32_t myrow, mycol, myzlayer;
+    sluamd_int_t **Lrowind_bc_ptr;
+    sluamd_doublecomplex **Lnzval_bc_ptr;
+    sluamd_int_t **Ufstnz_br_ptr;
+    sluamd_doublecomplex **Unzval_br_ptr;
+} sluamd_zLUview_t;
+
 /* dtrf3Dpartition_t (superlu_ddefs.h:317-337) flattened: elimination forests of this rank's Z layer.
  * May be NULL for a 1x1x1 grid: the library then derives a level schedule from the block structure. */
 typedef struct sluamd_forest_view {
@@ -119,6 +133,16 @@ int sluamd_dCopyLU2Host(sluamd_handle_t h, const sluamd_dLUview_t *lu);
  * ldx, overwritten by the solution of L U y = x.  Host-pointer and device-pointer variants. */
 int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs);
 int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nrhs);
+
+/* complex16 twins of the four entry points above and of the solve (pzgstrf3d, SRC/complex16/pzgstrf3d.c; pzgstrs3d,
+ * SRC/complex16/pzgstrs3d.c): same semantics on doublecomplex values.  Handles are shared with the double API for
+ * sluamd_dDestroyLUHandle / sluamd_get_stats. */
+int sluamd_zCreateLUHandle(sluamd_handle_t *h, const sluamd_zLUview_t *lu, const sluamd_forest_view_t *forests,
+                           const sluamd_options_t *opt);
+int sluamd_zSetValues(sluamd_handle_t h, const sluamd_zLUview_t *lu);
+int sluamd_pzgstrf3d(sluamd_handle_t h, double thresh, int *info);
+int sluamd_zCopyLU2Host(sluamd_handle_t h, const sluamd_zLUview_t *lu);
+int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, int32_t nrhs);
 
 /* Replaces dDestroyLUgpuHandle (LUgpuCHandle_interface_impl.cu:30). */
 void sluamd_dDestroyLUHandle(sluamd_handle_t h);

@@ -44,6 +44,7 @@ EXPORTS = [
     "sluamd_dCopyLU2Host", "sluamd_pdgstrs3d", "sluamd_pdgstrs3d_dev", "sluamd_dDestroyLUHandle",
     "sluamd_get_stats", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_symb_info",
     "sluamd_symb_view", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
+    "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
 ]
 
 _lib = None
@@ -83,6 +84,11 @@ def load():
     L.sluamd_arena.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sluamd_mfma_selftest.argtypes = [P_dbl, P_dbl, P_dbl]
     L.sluamd_dResetValues.argtypes = [C.c_void_p]
+    L.sluamd_zCreateLUHandle.argtypes = L.sluamd_dCreateLUHandle.argtypes     # zLUview is layout-identical to dLUview
+    L.sluamd_zSetValues.argtypes = [C.c_void_p, C.POINTER(LUView)]
+    L.sluamd_zCopyLU2Host.argtypes = [C.c_void_p, C.POINTER(LUView)]
+    L.sluamd_pzgstrf3d.argtypes = [C.c_void_p, C.c_double, P_int]
+    L.sluamd_pzgstrs3d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_symb_partition.argtypes = [C.c_void_p, C.c_int32, P_int]
     L.sluamd_dCreateLUHandleFromSymb3D.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int,
                                                    C.POINTER(Options), C.c_int32, C.c_int32, P_int]

@@ -80,6 +80,7 @@ struct LevelSched {
     std::vector<int> ltr_prefix;    // L-TRSM strips
     std::vector<int> utr_prefix;    // U-TRSM column chunks
     std::vector<int> inv_prefix;    // diagonal sub-block inversion tasks
+    std::vector<int> zltr_prefix;   // complex path: 64-row L strips (the 64-column U chunks reuse bwd_prefix)
     std::vector<int> lvl_poff;      // [nlevels+1] offset of each level's prefix arrays (size nodes_in_level+1)
     std::vector<int> lvl_soff;      // [nlevels+1] offset of each level's Schur prefix arrays (big group | small group)
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
@@ -91,7 +92,7 @@ struct LevelSched {
     std::vector<int> u_off;         // [2*nlevels+1] offsets into ulist (2 groups per level)
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
-    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr;
+    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
     int4 *d_ulist = nullptr;
 };
 
@@ -115,6 +116,7 @@ struct Handle {
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
     double *d_x = nullptr; int64_t x_cap = 0;
     int64_t *d_apos = nullptr; double *d_aval = nullptr; int64_t a_nnz = 0;  // A's entries for device-side (re)distribution
+    bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
     bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
@@ -935,6 +937,8 @@ __global__ void k_mfma_selftest(const double *A, const double *B, double *D)
     for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
 }
 
+#include "sluamd_zkernels.inc"
+
 // ================================================================================================
 //                                       HOST: planning
 // ================================================================================================
@@ -1084,7 +1088,7 @@ static int build_tables(Handle &H, HostTables &t)
             for (int b = 0; b < nub; ++b) t128c += (t.ub_ncols[ub0 + b] + 127) / 128;
             const double cells = (double) (nsupr - nsupc) * ncol_tot;
             const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * 128.0 * 128.0) : 0.0;
-            const bool big = nsupc >= 96 && util128 >= 0.5 && !getenv("SLUAMD_NO_BIG_TILES");
+            const bool big = !H.z && nsupc >= 96 && util128 >= 0.5 && !getenv("SLUAMD_NO_BIG_TILES");
             t.sn_big.push_back(big);
             const int tm = big ? 128 : 64;
             t.sn_rt_off[k] = (int) t.rtile.size();
@@ -1106,6 +1110,7 @@ static int build_tables(Handle &H, HostTables &t)
         st.flops_schur_exact += 2.0 * rrows * exact;
         st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc + (double) nsupc * nsupc * rrows + (double) nsupc * exact;
     }
+    if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; }   // complex multiply-add = 8 flop
     H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu;
     return 0;
 }
@@ -1144,7 +1149,7 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
     for (int l = 0; l < S.nlevels; ++l) S.lvl_poff[l + 1] = S.lvl_poff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 1;
     const int psz = S.lvl_poff[S.nlevels];
     S.tile_prefix.assign(S.lvl_soff[S.nlevels], 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
-    S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0);
+    S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0); S.zltr_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     S.diag_lds.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l)
@@ -1165,6 +1170,7 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + rs - 1) / rs;
             S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + rs - 1) / rs;
             S.inv_prefix[po + 1] = S.inv_prefix[po] + 2 * ((nsupc + 31) / 32);
+            S.zltr_prefix[po + 1] = S.zltr_prefix[po] + (rrows + 63) / 64;
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (rrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
         }
@@ -1210,6 +1216,7 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.fwd_prefix, &S.d_fwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.bwd_prefix, &S.d_bwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.inv_prefix, &S.d_inv_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.zltr_prefix, &S.d_zltr_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.sn_level, &S.d_sn_level)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
     return 0;
@@ -1526,26 +1533,27 @@ void sluamd_default_options(sluamd_options_t *opt)
 
 static int upload_values(Handle *H, const sluamd_dLUview_t *lu)
 {
+    // value pointers are read as raw bytes: esz = 8 (double) or 16 (doublecomplex, via the layout-identical zLUview)
     const HostStruct &hs = H->hs;
-    // stage through one pinned buffer per half to keep the number of H2D copies small
+    const size_t esz = H->z ? 16 : 8;
     const int ns = hs.nsupers;
-    std::vector<double> stage;
-    stage.resize((size_t) std::max(hs.nnzL, hs.nnzU));
+    std::vector<char> stage((size_t) std::max(hs.nnzL, hs.nnzU) * esz);
+    char *dv = reinterpret_cast<char *>(H->d_val);
     for (int k = 0; k < ns; ++k) {
         const int64_t len = hs.lval_off[k + 1] - hs.lval_off[k];
-        if (len) std::memcpy(stage.data() + hs.lval_off[k], lu->Lnzval_bc_ptr[k], sizeof(double) * len);
+        if (len) std::memcpy(stage.data() + hs.lval_off[k] * esz, lu->Lnzval_bc_ptr[k], esz * len);
     }
-    if (hs.nnzL) HIPCHK(hipMemcpy(H->d_val, stage.data(), sizeof(double) * hs.nnzL, hipMemcpyHostToDevice));
+    if (hs.nnzL) HIPCHK(hipMemcpy(dv, stage.data(), esz * hs.nnzL, hipMemcpyHostToDevice));
     for (int k = 0; k < ns; ++k) {
         const int64_t len = hs.uval_off[k + 1] - hs.uval_off[k];
-        if (len) std::memcpy(stage.data() + hs.uval_off[k], lu->Unzval_br_ptr[k], sizeof(double) * len);
+        if (len) std::memcpy(stage.data() + hs.uval_off[k] * esz, lu->Unzval_br_ptr[k], esz * len);
     }
-    if (hs.nnzU) HIPCHK(hipMemcpy(H->d_val + hs.nnzL, stage.data(), sizeof(double) * hs.nnzU, hipMemcpyHostToDevice));
+    if (hs.nnzU) HIPCHK(hipMemcpy(dv + esz * hs.nnzL, stage.data(), esz * hs.nnzU, hipMemcpyHostToDevice));
     return 0;
 }
 
-int sluamd_dCreateLUHandle(sluamd_handle_t *out, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
-                           const sluamd_options_t *opt)
+static int create_from_view(sluamd_handle_t *out, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
+                            const sluamd_options_t *opt, bool z)
 {
     if (!out) { set_error("null handle pointer"); return SLUAMD_EINVAL; }
     *out = nullptr;
@@ -1556,12 +1564,13 @@ int sluamd_dCreateLUHandle(sluamd_handle_t *out, const sluamd_dLUview_t *lu, con
     auto *hh = new sluamd_lu_handle_s();
     Handle *H = &hh->H;
     H->opt = o;
+    H->z = z;
     HIPCHK(hipGetDevice(&H->device));
     rc = flatten_view(lu, H->hs, false);
     if (rc) { delete hh; return rc; }
     H->Pz = lu->npdep; H->myz = lu->myzlayer;
     const int64_t tot = H->hs.nnzL + H->hs.nnzU;
-    if (hipMalloc((void **) &H->d_val, sizeof(double) * std::max<int64_t>(tot, 1)) != hipSuccess) {
+    if (hipMalloc((void **) &H->d_val, (z ? 16 : 8) * std::max<int64_t>(tot, 1)) != hipSuccess) {
         set_error("hipMalloc of the value arena failed"); delete hh; return SLUAMD_ENOMEM;
     }
     hipEvent_t e0, e1;
@@ -1577,6 +1586,19 @@ int sluamd_dCreateLUHandle(sluamd_handle_t *out, const sluamd_dLUview_t *lu, con
     return 0;
 }
 
+int sluamd_dCreateLUHandle(sluamd_handle_t *out, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
+                           const sluamd_options_t *opt)
+{
+    return create_from_view(out, lu, forests, opt, false);
+}
+
+// complex16 twin: zCreateLUgpuHandle (SRC/include/superlu_upacked.h, z section)
+int sluamd_zCreateLUHandle(sluamd_handle_t *out, const sluamd_zLUview_t *lu, const sluamd_forest_view_t *forests,
+                           const sluamd_options_t *opt)
+{
+    return create_from_view(out, reinterpret_cast<const sluamd_dLUview_t *>(lu), forests, opt, true);
+}
+
 int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
 {
     if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
@@ -1588,6 +1610,7 @@ int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
 int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info)
 {
     if (!h) { set_error("null handle"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("complex16 handle: call sluamd_pzgstrf3d"); return SLUAMD_EINVAL; }
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
     int init[4] = {0x7fffffff, 0, 0, 0};
@@ -1651,18 +1674,20 @@ int sluamd_dCopyLU2Host(sluamd_handle_t h, const sluamd_dLUview_t *lu)
     if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
     Handle *H = &h->H;
     const HostStruct &hs = H->hs;
+    const size_t esz = H->z ? 16 : 8;
     HIPCHK(hipSetDevice(H->device));
-    std::vector<double> stage((size_t) std::max(hs.nnzL, hs.nnzU));
+    std::vector<char> stage((size_t) std::max(hs.nnzL, hs.nnzU) * esz);
+    const char *dv = reinterpret_cast<const char *>(H->d_val);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0);
-    if (hs.nnzL) HIPCHK(hipMemcpy(stage.data(), H->d_val, sizeof(double) * hs.nnzL, hipMemcpyDeviceToHost));
+    if (hs.nnzL) HIPCHK(hipMemcpy(stage.data(), dv, esz * hs.nnzL, hipMemcpyDeviceToHost));
     for (int k = 0; k < hs.nsupers; ++k) {
         const int64_t len = hs.lval_off[k + 1] - hs.lval_off[k];
-        if (len) std::memcpy(lu->Lnzval_bc_ptr[k], stage.data() + hs.lval_off[k], sizeof(double) * len);
+        if (len) std::memcpy(lu->Lnzval_bc_ptr[k], stage.data() + hs.lval_off[k] * esz, esz * len);
     }
-    if (hs.nnzU) HIPCHK(hipMemcpy(stage.data(), H->d_val + hs.nnzL, sizeof(double) * hs.nnzU, hipMemcpyDeviceToHost));
+    if (hs.nnzU) HIPCHK(hipMemcpy(stage.data(), dv + esz * hs.nnzL, esz * hs.nnzU, hipMemcpyDeviceToHost));
     for (int k = 0; k < hs.nsupers; ++k) {
         const int64_t len = hs.uval_off[k + 1] - hs.uval_off[k];
-        if (len) std::memcpy(lu->Unzval_br_ptr[k], stage.data() + hs.uval_off[k], sizeof(double) * len);
+        if (len) std::memcpy(lu->Unzval_br_ptr[k], stage.data() + hs.uval_off[k] * esz, esz * len);
     }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); H->st.t_d2h_ms = ms;
@@ -1670,9 +1695,119 @@ int sluamd_dCopyLU2Host(sluamd_handle_t h, const sluamd_dLUview_t *lu)
     return 0;
 }
 
+int sluamd_zCopyLU2Host(sluamd_handle_t h, const sluamd_zLUview_t *lu)
+{
+    if (!h || !h->H.z) { set_error("not a complex16 handle"); return SLUAMD_EINVAL; }
+    return sluamd_dCopyLU2Host(h, reinterpret_cast<const sluamd_dLUview_t *>(lu));
+}
+
+int sluamd_zSetValues(sluamd_handle_t h, const sluamd_zLUview_t *lu)
+{
+    if (!h || !lu || !h->H.z) { set_error("not a complex16 handle"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(h->H.device));
+    return upload_values(&h->H, reinterpret_cast<const sluamd_dLUview_t *>(lu));
+}
+
+// ---- complex16 numeric factorisation and solve (serial level loop; see sluamd_zkernels.inc) ----
+static int run_factor_z(Handle *H, LevelSched &S, double thresh)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
+        const int *nodes = S.d_nodes + n0;
+        hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        const int po = S.lvl_poff[l];
+        const int nl = S.zltr_prefix[po + nn], nu = S.bwd_prefix[po + nn];   // 64-row strips / 64-column chunks
+        if (nl + nu) hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, nl);
+        H->st.num_launches += 1 + (nl + nu > 0);
+        const int so = S.lvl_soff[l] + S.n_big[l] + 1;     // complex handles have no 128-tile group
+        const int nt = S.tile_prefix[so + nn];
+        if (nt) {
+            hipLaunchKernelGGL(kz_schur, dim3(((nt + 7) / 8) * 8), dim3(256), 0, s, T, nodes, S.d_tile_prefix + so, nn, 0, nt, H->d_info);
+            H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += nt;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int sluamd_pzgstrf3d(sluamd_handle_t h, double thresh, int *info)
+{
+    if (!h || !h->H.z) { set_error("not a complex16 handle"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    int init[4] = {0x7fffffff, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
+    H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
+    HIPCHK(hipEventRecord(H->ev0, H->stream));
+    for (size_t zl = 0; zl < H->sched.size(); ++zl) {
+        int rc = run_factor_z(H, H->sched[zl], thresh);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(H->ev1, H->stream));
+    int res[4];
+    HIPCHK(hipMemcpyAsync(res, H->d_info, sizeof(res), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_factor_ms = ms;
+    H->st.tiny_pivots = res[1];
+    if (info) *info = (res[0] == 0x7fffffff) ? 0 : res[0];
+    if (res[2]) { set_error("Schur update found no destination block for " + std::to_string(res[2]) + " tiles (structure not closed)"); return SLUAMD_ESTRUCT; }
+    return 0;
+}
+
+// x: n x nrhs doublecomplex, column-major, host memory; overwritten by the solution of L U y = x
+int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, int32_t nrhs)
+{
+    if (!h || !h->H.z || !x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad complex solve arguments"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) return 0;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t need = 2 * ldx * nrhs;   // in doubles
+    if (need > H->x_cap) {
+        if (H->d_x) hipFree(H->d_x);
+        HIPCHK(hipMalloc((void **) &H->d_x, sizeof(double) * need));
+        H->x_cap = need;
+    }
+    HIPCHK(hipMemcpy(H->d_x, x, sizeof(double) * need, hipMemcpyHostToDevice));
+    const size_t lds = (size_t) H->max_nsupc * nrhs * 16;
+    if (lds > 64 * 1024) { set_error("nrhs too large for the LDS-staged complex solve"); return SLUAMD_EINVAL; }
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    zc *dx = reinterpret_cast<zc *>(H->d_x);
+    HIPCHK(hipEventRecord(H->ev0, s));
+    for (size_t zl = 0; zl < H->sched.size(); ++zl) {
+        LevelSched &S = H->sched[zl];
+        for (int l = 0; l < S.nlevels; ++l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            hipLaunchKernelGGL(kz_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, dx, ldx, nrhs);
+            const int nf = S.fwd_prefix[po + nn];
+            if (nf) hipLaunchKernelGGL(kz_fwd_update, dim3(nf), dim3(256), lds, s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, dx, ldx, nrhs);
+        }
+    }
+    for (int zl = (int) H->sched.size() - 1; zl >= 0; --zl) {
+        LevelSched &S = H->sched[zl];
+        for (int l = S.nlevels - 1; l >= 0; --l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            const int nb = S.bwd_prefix[po + nn];
+            if (nb) hipLaunchKernelGGL(kz_bwd_update, dim3(nb), dim3(256), 0, s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, dx, ldx, nrhs);
+            hipLaunchKernelGGL(kz_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, S.d_nodes + n0, dx, ldx, nrhs);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(H->ev1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_solve_ms = ms;
+    HIPCHK(hipMemcpy(x, H->d_x, sizeof(double) * need, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nrhs)
 {
     if (!h || !d_x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("complex16 handle: call sluamd_pzgstrs3d"); return SLUAMD_EINVAL; }
     if (nrhs == 0) return 0;
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));

@@ -31,11 +31,13 @@ class FlatStore:
         self.Lrowind_off = np.asarray(Lrowind_off, dtype=np.int64)
         self.Lrowind = np.ascontiguousarray(Lrowind, dtype=np.int32)
         self.Lnzval_off = np.asarray(Lnzval_off, dtype=np.int64)
-        self.Lnzval = np.array(Lnzval, dtype=np.float64)
+        self.z = bool(np.iscomplexobj(Lnzval) or np.iscomplexobj(Unzval))   # complex16 store (pzgstrf3d path)
+        vt = np.complex128 if self.z else np.float64
+        self.Lnzval = np.array(Lnzval, dtype=vt)
         self.Ufstnz_off = np.asarray(Ufstnz_off, dtype=np.int64)
         self.Ufstnz = np.ascontiguousarray(Ufstnz, dtype=np.int32)
         self.Unzval_off = np.asarray(Unzval_off, dtype=np.int64)
-        self.Unzval = np.array(Unzval, dtype=np.float64)
+        self.Unzval = np.array(Unzval, dtype=vt)
         self.grid, self.coords = grid, coords
         self._build_view()
 
@@ -59,9 +61,9 @@ class FlatStore:
                     arr[k] = C.cast(addr + int(off[k]) * elem, C.POINTER(ctype))
             return arr
         self._lp = ptrs(self.Lrowind, self.Lrowind_off, C.c_int32, 4)
-        self._lv = ptrs(self.Lnzval, self.Lnzval_off, C.c_double, 8)
+        self._lv = ptrs(self.Lnzval, self.Lnzval_off, C.c_double, self.Lnzval.itemsize)
         self._up = ptrs(self.Ufstnz, self.Ufstnz_off, C.c_int32, 4)
-        self._uv = ptrs(self.Unzval, self.Unzval_off, C.c_double, 8)
+        self._uv = ptrs(self.Unzval, self.Unzval_off, C.c_double, self.Unzval.itemsize)
         v = LUView()
         v.n, v.nsupers, v.xsup = self.n, ns, _pi(self.xsup)
         v.nprow, v.npcol, v.npdep = self.grid
@@ -144,6 +146,7 @@ class LUHandle:
     def __init__(self, h, store=None):
         self._h = h
         self.store = store
+        self.z = False
 
     @staticmethod
     def _opts(replace_tiny=False, deterministic=False, device=-1):
@@ -161,9 +164,11 @@ class LUHandle:
         keep = None
         if forests is not None:
             fv, keep = _forest_view(forests)
-        _lib.check(L.sluamd_dCreateLUHandle(C.byref(h), C.byref(store.view), None if fv is None else C.byref(fv), C.byref(o)),
-                   "sluamd_dCreateLUHandle")
+        create = L.sluamd_zCreateLUHandle if store.z else L.sluamd_dCreateLUHandle
+        _lib.check(create(C.byref(h), C.byref(store.view), None if fv is None else C.byref(fv), C.byref(o)),
+                   "sluamd_zCreateLUHandle" if store.z else "sluamd_dCreateLUHandle")
         obj = cls(h, store)
+        obj.z = store.z
         obj._keep = keep
         return obj
 
@@ -178,24 +183,37 @@ class LUHandle:
         return cls(h, None)
 
     def set_values(self, store):
-        _lib.check(_lib.load().sluamd_dSetValues(self._h, C.byref(store.view)), "sluamd_dSetValues")
+        L = _lib.load()
+        _lib.check((L.sluamd_zSetValues if self.z else L.sluamd_dSetValues)(self._h, C.byref(store.view)), "sluamd_[dz]SetValues")
 
     def pdgstrf3d(self, thresh=0.0):
+        """pdgstrf3d, or pzgstrf3d on a complex16 handle."""
+        L = _lib.load()
         info = C.c_int32(0)
-        _lib.check(_lib.load().sluamd_pdgstrf3d(self._h, float(thresh), C.byref(info)), "sluamd_pdgstrf3d")
+        _lib.check((L.sluamd_pzgstrf3d if self.z else L.sluamd_pdgstrf3d)(self._h, float(thresh), C.byref(info)), "sluamd_p[dz]gstrf3d")
         return info.value
+
+    pzgstrf3d = pdgstrf3d
 
     def copy_to_host(self, store=None):
         store = store or self.store
-        _lib.check(_lib.load().sluamd_dCopyLU2Host(self._h, C.byref(store.view)), "sluamd_dCopyLU2Host")
+        L = _lib.load()
+        _lib.check((L.sluamd_zCopyLU2Host if self.z else L.sluamd_dCopyLU2Host)(self._h, C.byref(store.view)), "sluamd_[dz]CopyLU2Host")
         return store
 
     def pdgstrs3d(self, x):
-        x = np.asfortranarray(np.array(x, dtype=np.float64))
+        """pdgstrs3d, or pzgstrs3d on a complex16 handle."""
+        x = np.asfortranarray(np.array(x, dtype=np.complex128 if self.z else np.float64))
         if x.ndim == 1:
             x = np.asfortranarray(x[:, None])
-        _lib.check(_lib.load().sluamd_pdgstrs3d(self._h, _pd(x), x.shape[0], x.shape[1]), "sluamd_pdgstrs3d")
+        L = _lib.load()
+        if self.z:
+            _lib.check(L.sluamd_pzgstrs3d(self._h, x.ctypes.data_as(C.c_void_p), x.shape[0], x.shape[1]), "sluamd_pzgstrs3d")
+        else:
+            _lib.check(L.sluamd_pdgstrs3d(self._h, _pd(x), x.shape[0], x.shape[1]), "sluamd_pdgstrs3d")
         return x
+
+    pzgstrs3d = pdgstrs3d
 
     def pdgstrs3d_dev(self, ptr, ldx, nrhs):
         _lib.check(_lib.load().sluamd_pdgstrs3d_dev(self._h, C.c_void_p(ptr), ldx, nrhs), "sluamd_pdgstrs3d_dev")

@@ -9,7 +9,9 @@ from superlu_dist_amd import _lib, driver, matgen
 
 pytestmark = pytest.mark.gpu
 
-CASES_1RANK = ["g20_1x1x1", "g20_1x1x1_nrhs3", "poisson8_nd", "poisson10_nd", "unsym300", "unsym120_tiny"]
+CASES_1RANK = ["g20_1x1x1", "g20_1x1x1_nrhs3", "poisson8_nd", "poisson10_nd", "unsym300", "unsym120_tiny",
+               # complex16 (pzgstrf3d / pzgstrs3d): cg20.cua = BASELINE.json config 5's matrix family
+               "z_cg20_1x1x1", "z_cg20_1x1x1_nrhs2", "z_poisson8_nd", "z_unsym200"]
 
 
 def test_mfma_f64_fragment_layout():
@@ -60,7 +62,7 @@ def test_solve_matches_reference(golden, case):
         nrhs = int(g[f"r0__solve{s}_nrhs"][0])
         B = g[f"r0__solve{s}_B_in"].reshape((n, nrhs), order="F")
         X = g[f"r0__solve{s}_B_out"].reshape((n, nrhs), order="F")
-        xp = np.zeros((n, nrhs), order="F"); xp[pc[pr], :] = B
+        xp = np.zeros((n, nrhs), order="F", dtype=B.dtype); xp[pc[pr], :] = B
         got = h.pdgstrs3d(xp)
         assert np.abs(got - X).max() <= 1e-10 * max(1.0, np.abs(X).max())
         s += 1
