@@ -182,6 +182,9 @@ int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *h, sluamd_symb_t s, const sl
 /* copy the store out as flat arrays + offsets (any pointer may be NULL) */
 int sluamd_symb_export(sluamd_symb_t s, sluamd_int_t *xsup, int64_t *lidx_off, sluamd_int_t *lidx, int64_t *lval_off,
                        double *lval, int64_t *uidx_off, sluamd_int_t *uidx, int64_t *uval_off, double *uval);
+int sluamd_zCreateLUHandleFromSymb(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                   const sluamd_int_t *colind, const sluamd_doublecomplex *nzval,
+                                   const sluamd_int_t *perm_c_final, const sluamd_options_t *opt);
 void sluamd_symb_free(sluamd_symb_t s);
 /* 1 x 1 x npdep grids (Z sharding): elimination-forest partition (getForests' job, supernodalForest.c; tree ids in
  * heap order like getGridTrees, supernodal_etree.c:840-851) and a handle that stores only layer `myz`'s sub-forest

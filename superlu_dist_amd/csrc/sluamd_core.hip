@@ -1892,7 +1892,7 @@ static void path_trees(int npdep, int myz, std::vector<int> &trees)
 
 static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr,
                             const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
-                            const sluamd_options_t *opt, int npdep, int myz, const int32_t *sn_tree)
+                            const sluamd_options_t *opt, int npdep, int myz, const int32_t *sn_tree, bool z = false)
 {
     if (!out || !s) { set_error("null argument"); return SLUAMD_EINVAL; }
     *out = nullptr;
@@ -1905,6 +1905,7 @@ static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_
     auto *hh = new sluamd_lu_handle_s();
     Handle *H = &hh->H;
     H->opt = o;
+    H->z = z;
     H->Pz = npdep; H->myz = myz;
     HIPCHK(hipGetDevice(&H->device));
     const HostStruct &full = sy->hs;
@@ -1947,24 +1948,30 @@ static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_
     }
     const HostStruct &hs = H->hs;
     const int64_t tot = hs.nnzL + hs.nnzU;
-    if (hipMalloc((void **) &H->d_val, sizeof(double) * std::max<int64_t>(tot, 1)) != hipSuccess) {
+    const size_t esz = z ? 16 : 8;
+    if (hipMalloc((void **) &H->d_val, esz * std::max<int64_t>(tot, 1)) != hipSuccess) {
         set_error("hipMalloc of the value arena failed"); delete hh; return SLUAMD_ENOMEM;
     }
-    HIPCHK(hipMemset(H->d_val, 0, sizeof(double) * tot));
+    HIPCHK(hipMemset(H->d_val, 0, esz * tot));
     {   // device-side distribution of A's values
         std::vector<int64_t> pos; std::vector<uint8_t> isu;
         compute_scatter_positions(*sy, hs, hs.n, rowptr, colind, perm_c_final, owned.empty() ? nullptr : owned.data(), pos, isu);
+        const int w = z ? 2 : 1;   // doubles per value
         std::vector<int64_t> pos2; std::vector<double> val2;
-        pos2.reserve(pos.size()); val2.reserve(pos.size());
+        pos2.reserve(pos.size()); val2.reserve(pos.size() * w);
         for (size_t e = 0; e < pos.size(); ++e)
-            if (pos[e] >= 0) { pos2.push_back(pos[e] + (isu[e] ? hs.nnzL : 0)); val2.push_back(nzval[e]); }
+            if (pos[e] >= 0) {
+                pos2.push_back(pos[e] + (isu[e] ? hs.nnzL : 0));
+                for (int q = 0; q < w; ++q) val2.push_back(nzval[e * w + q]);
+            }
         const int64_t nnz = (int64_t) pos2.size();
         HIPCHK(hipMalloc((void **) &H->d_apos, sizeof(int64_t) * std::max<int64_t>(nnz, 1)));
-        HIPCHK(hipMalloc((void **) &H->d_aval, sizeof(double) * std::max<int64_t>(nnz, 1)));
+        HIPCHK(hipMalloc((void **) &H->d_aval, esz * std::max<int64_t>(nnz, 1)));
         H->a_nnz = nnz;
         HIPCHK(hipMemcpy(H->d_apos, pos2.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(H->d_aval, val2.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
-        if (nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, 0, H->d_val, H->d_apos, H->d_aval, nnz);
+        HIPCHK(hipMemcpy(H->d_aval, val2.data(), esz * nnz, hipMemcpyHostToDevice));
+        if (nnz && !z) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, 0, H->d_val, H->d_apos, H->d_aval, nnz);
+        if (nnz && z) hipLaunchKernelGGL(kz_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<zc *>(H->d_val), H->d_apos, reinterpret_cast<const zc *>(H->d_aval), nnz);
         HIPCHK(hipDeviceSynchronize());
     }
     rc = finish_create(H, nullptr, lists.empty() ? nullptr : &lists);
@@ -1978,6 +1985,14 @@ int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const 
                                    const sluamd_int_t *perm_c_final, const sluamd_options_t *opt)
 {
     return create_from_symb(out, s, rowptr, colind, nzval, perm_c_final, opt, 1, 0, nullptr);
+}
+
+// complex16 values (nzval = doublecomplex[nnz] aligned with colind), 1x1x1 grid
+int sluamd_zCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                   const sluamd_int_t *colind, const sluamd_doublecomplex *nzval,
+                                   const sluamd_int_t *perm_c_final, const sluamd_options_t *opt)
+{
+    return create_from_symb(out, s, rowptr, colind, reinterpret_cast<const double *>(nzval), perm_c_final, opt, 1, 0, nullptr, true);
 }
 
 // 1 x 1 x npdep grid: this rank = Z layer `myz`; sn_tree from sluamd_symb_partition.  Stores only the layer's own
@@ -2020,9 +2035,11 @@ int sluamd_dResetValues(sluamd_handle_t h)
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
     H->dinv_ready = false;
-    HIPCHK(hipMemsetAsync(H->d_val, 0, sizeof(double) * (H->hs.nnzL + H->hs.nnzU), H->stream));
-    if (H->a_nnz) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((H->a_nnz + 255) / 256)), dim3(256), 0, H->stream,
-                                     H->d_val, H->d_apos, H->d_aval, H->a_nnz);
+    HIPCHK(hipMemsetAsync(H->d_val, 0, (H->z ? 16 : 8) * (H->hs.nnzL + H->hs.nnzU), H->stream));
+    if (H->a_nnz && !H->z) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((H->a_nnz + 255) / 256)), dim3(256), 0, H->stream,
+                                              H->d_val, H->d_apos, H->d_aval, H->a_nnz);
+    if (H->a_nnz && H->z) hipLaunchKernelGGL(kz_scatter_values, dim3((unsigned) ((H->a_nnz + 255) / 256)), dim3(256), 0, H->stream,
+                                             reinterpret_cast<zc *>(H->d_val), H->d_apos, reinterpret_cast<const zc *>(H->d_aval), H->a_nnz);
     HIPCHK(hipGetLastError());
     return 0;
 }
