@@ -89,6 +89,7 @@ def load():
     L.sluamd_zCopyLU2Host.argtypes = [C.c_void_p, C.POINTER(LUView)]
     L.sluamd_pzgstrf3d.argtypes = [C.c_void_p, C.c_double, P_int]
     L.sluamd_pzgstrs3d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    L.sluamd_zCreateLUHandleFromSymb.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, C.c_void_p, P_int, C.POINTER(Options)]
     L.sluamd_symb_partition.argtypes = [C.c_void_p, C.c_int32, P_int]
     L.sluamd_dCreateLUHandleFromSymb3D.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int,
                                                    C.POINTER(Options), C.c_int32, C.c_int32, P_int]

@@ -177,6 +177,13 @@ class LUHandle:
         L = _lib.load()
         h = C.c_void_p()
         o = cls._opts(**kw)
+        if np.iscomplexobj(nzval):
+            nz = np.ascontiguousarray(nzval, dtype=np.complex128)
+            _lib.check(L.sluamd_zCreateLUHandleFromSymb(C.byref(h), symb._h, _pi(symb.rowptr), _pi(symb.colind),
+                                                        nz.ctypes.data_as(C.c_void_p), _pi(symb.perm_c), C.byref(o)),
+                       "sluamd_zCreateLUHandleFromSymb")
+            obj = cls(h, None); obj.z = True
+            return obj
         nz = np.ascontiguousarray(nzval, dtype=np.float64)
         _lib.check(L.sluamd_dCreateLUHandleFromSymb(C.byref(h), symb._h, _pi(symb.rowptr), _pi(symb.colind), _pd(nz),
                                                     _pi(symb.perm_c), C.byref(o)), "sluamd_dCreateLUHandleFromSymb")
@@ -268,7 +275,7 @@ def pdgssvx3d(n, rowptr, colind, nzval, b, perm_c=None, relax=32, maxsup=256, re
         anorm = float(np.max(np.add.reduceat(np.abs(nzval), rp[:-1]))) if len(nzval) else 0.0
     thresh = float(np.finfo(np.float32).eps) * anorm          # pdgstrf3d.c:132-133 (single-precision epsilon)
     info = h.pdgstrf3d(thresh)
-    b = np.asfortranarray(np.array(b, dtype=np.float64))
+    b = np.asfortranarray(np.array(b, dtype=np.complex128 if np.iscomplexobj(nzval) else np.float64))
     if b.ndim == 1:
         b = np.asfortranarray(b[:, None])
     xp = np.zeros_like(b, order="F")
@@ -280,3 +287,6 @@ def pdgssvx3d(n, rowptr, colind, nzval, b, perm_c=None, relax=32, maxsup=256, re
         return x, info, st, h, symb
     h.destroy(); symb.free()
     return x, info, st
+
+
+pzgssvx3d = pdgssvx3d   # complex16 input (nzval complex) takes the pzgstrf3d / pzgstrs3d path of the same driver

@@ -80,11 +80,11 @@ def xtrue_rhs(n, rowptr, colind, vals, nrhs=1):
 
 
 def csr_matvec(n, rowptr, colind, vals, x):
-    x = np.asarray(x, dtype=np.float64)
+    x = np.asarray(x)
     if x.ndim == 1:
         x = x[:, None]
     prod = vals[:, None] * x[colind, :]
-    out = np.zeros((n, x.shape[1]))
+    out = np.zeros((n, x.shape[1]), dtype=prod.dtype)
     rows = np.repeat(np.arange(n), np.diff(rowptr))
     np.add.at(out, rows, prod)
     return np.asfortranarray(out)

@@ -174,3 +174,21 @@ def test_large_supernodes_match_oracle(N, leaf, relax, maxsup):
     x = h.pdgstrs3d(xp)[symb.perm_c, :]
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
     h.destroy()
+
+
+@pytest.mark.parametrize("shape,leaf,relax,maxsup", [((40, 40, 1), 16, 16, 64), ((12, 12, 12), 27, 32, 128)])
+def test_own_pipeline_complex16(shape, leaf, relax, maxsup):
+    """pzgssvx3d-equivalent on a complex grid operator (cg20-style 2-D 5-pt and a 3-D 7-pt): device-side distribution of
+    complex values, pzgstrf3d (split-plane MFMA Schur kernel), pzgstrs3d; residual and solution against x_true."""
+    nx, ny, nz = shape
+    n, rp, ci, v = matgen.poisson3d(0, nx, ny, nz)
+    v = matgen.complex_shift(v, rp, ci, seed=2)
+    perm = matgen.nd_perm_grid3d(nx, ny, nz, leaf=leaf)
+    rng = np.random.default_rng(0)
+    xt = (rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2)))
+    b = matgen.csr_matvec(n, rp, ci, v, xt)
+    x, info, st = driver.pzgssvx3d(n, rp, ci, v, b, perm, relax=relax, maxsup=maxsup)
+    assert info == 0
+    res = np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b)
+    assert res < 1e-10
+    assert np.abs(x - xt).max() < 1e-9 * np.abs(xt).max()
