@@ -24,8 +24,17 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (BASELINE.md sect
 PEAK_HBM_GBS = 8000.0
 
 
-def build_problem(N, leaf):
+def build_problem(N, leaf, workload="poisson3d"):
     from superlu_dist_amd import matgen
+    if workload == "zgrid2d":
+        # BASELINE.json configs[4]: "pzdrive3d complex16 on cg20.cua scaled 50x": cg20.cua is a complex operator on a 20x20
+        # grid (n = 400); scaled 50x per grid side = 1000 x 1000 5-point complex grid operator (n = 10^6).  N = grid side.
+        n, rp, ci, v = matgen.poisson3d(0, N, N, 1)
+        v = matgen.complex_shift(v, rp, ci, seed=20)
+        perm = matgen.nd_perm_grid3d(N, N, 1, leaf=leaf)
+        xt = np.where((np.arange(n) % 2) == 1, 1.0, -1.0)[:, None].astype(np.complex128)
+        b = matgen.csr_matvec(n, rp, ci, v, xt)
+        return n, rp, ci, v, perm, np.asfortranarray(xt), b
     n, rp, ci, v = matgen.poisson3d(N)
     perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
@@ -99,6 +108,9 @@ def main():
     ap.add_argument("--maxsup", type=int, default=256)
     ap.add_argument("--cpu-n", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d"],
+                    help="poisson3d = BASELINE configs[1] (default, the metric's config); zgrid2d = configs[4] family "
+                         "(complex16 2-D grid operator, use --n 1000)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +128,10 @@ def main():
         raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
 
     t_setup = time.perf_counter()
-    n, rp, ci, v, perm, xt, b = build_problem(args.n, args.leaf)
+    n, rp, ci, v, perm, xt, b = build_problem(args.n, args.leaf, args.workload)
+    zwork = args.workload == "zgrid2d"
+    if zwork and world > 1:
+        raise SystemExit("bench.py: the complex16 workload is single-GPU in round 1")
     symb = driver.Symbolic(n, rp, ci, perm, relax=args.relax, maxsup=args.maxsup)
     layer = None
     if world == 1:
@@ -181,7 +196,7 @@ def main():
     err = float(np.abs(x - xt).max())
 
     # one extra profiled step: per-kernel-family HIP-event times on the compute stream
-    if world == 1:
+    if world == 1 and not zwork:
         h.set_profile(True)
         h.reset_values(); h.pdgstrf3d(thresh)
         stp = h.stats()
@@ -209,9 +224,10 @@ def main():
         "metric": "LU factorization GFLOP/s (pdgstrf3d) + solve time",
         "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"pddrive3d-equivalent on {args.n}^3 7-point Poisson (double), 1x1x{world} grid, "
-                               f"ND perm_c (leaf {args.leaf}), relax {args.relax}, maxsup {args.maxsup}, nrhs 1",
+        "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "c128" if zwork else "f64", "data": "synthetic",
+        "config": {"workload": (f"pzdrive3d-equivalent on a {args.n}x{args.n} 5-point complex16 grid operator (cg20 family), 1x1x1 grid, "
+                                if zwork else f"pddrive3d-equivalent on {args.n}^3 7-point Poisson (double), 1x1x{world} grid, ")
+                               + f"ND perm_c (leaf {args.leaf}), relax {args.relax}, maxsup {args.maxsup}, nrhs 1",
                    "n": n, "nnz_A": int(len(v)), "nnz_LU": int(st["nnz_L"] + st["nnz_U"]), "nsupers": symb.nsupers,
                    "parallelism": "single GPU" if world == 1 else
                    f"1x1x{world} grid: Z-sharded elimination forests, ancestor panels sum-reduced over RCCL send/recv"},
@@ -229,7 +245,7 @@ def main():
                      "flops_per_launch": st["flops_schur_exact"] / max(1, stp["schur_launches"]),
                      "schur_ms": stp["t_schur_ms"], "panel_ms": stp["t_panel_ms"], "profiled_factor_ms": stp["t_factor_ms"]},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not zwork:
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.leaf, args.relax, args.maxsup)
         except Exception as e:
