@@ -197,9 +197,14 @@ int_t WRAP(gstrf3d)(superlu_dist_options_t *options, int m, int n, double anorm,
     }
     if (g_out) dump_lu("pre", LUstruct, grid, 0);
 #ifdef USE_SLUAMD   /* slu_ref_amd: the reference pipeline with OUR numeric factorisation (oracle/ref/sluamd_binding.c) */
-    extern int_t sluamd_bind_pdgstrf3d(superlu_dist_options_t *, int, int, double, xtrf3Dpartition_t *, SCT_t *,
-                                       xLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
-    int_t r = sluamd_bind_pdgstrf3d(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
+#ifdef Z_PREC
+#define BIND_NAME sluamd_bind_pzgstrf3d
+#else
+#define BIND_NAME sluamd_bind_pdgstrf3d
+#endif
+    extern int_t BIND_NAME(superlu_dist_options_t *, int, int, double, xtrf3Dpartition_t *, SCT_t *,
+                           xLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
+    int_t r = BIND_NAME(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
 #else
     int_t r = REAL(gstrf3d)(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
 #endif

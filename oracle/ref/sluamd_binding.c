@@ -14,7 +14,29 @@
 #include <math.h>
 #include <dlfcn.h>
 #include <unistd.h>
+#ifdef Z_PREC   /* complex16 twin: binds pzgstrf3d (SRC/complex16/pzgstrf3d.c) to the sluamd_z* entry points */
+#include "superlu_zdefs.h"
+#define xLUstruct_t zLUstruct_t
+#define xLocalLU_t zLocalLU_t
+#define xtrf3Dpartition_t ztrf3Dpartition_t
+#define BIND_NAME sluamd_bind_pzgstrf3d
+#define LUVIEW_T sluamd_zLUview_t
+#define VALPP(p) ((sluamd_doublecomplex **) (p))
+#define SYM_CREATE "sluamd_zCreateLUHandle"
+#define SYM_FACTOR "sluamd_pzgstrf3d"
+#define SYM_COPY "sluamd_zCopyLU2Host"
+#else
 #include "superlu_ddefs.h"
+#define xLUstruct_t dLUstruct_t
+#define xLocalLU_t dLocalLU_t
+#define xtrf3Dpartition_t dtrf3Dpartition_t
+#define BIND_NAME sluamd_bind_pdgstrf3d
+#define LUVIEW_T sluamd_dLUview_t
+#define VALPP(p) (p)
+#define SYM_CREATE "sluamd_dCreateLUHandle"
+#define SYM_FACTOR "sluamd_pdgstrf3d"
+#define SYM_COPY "sluamd_dCopyLU2Host"
+#endif
 #include "superlu_dist_amd.h"
 
 /* The library is C++/HIP; a C/MPI application binds it at run time (dlopen) so that the application's own
@@ -23,9 +45,9 @@
 static struct {
     void *so;
     void (*default_options)(sluamd_options_t *);
-    int (*create)(sluamd_handle_t *, const sluamd_dLUview_t *, const sluamd_forest_view_t *, const sluamd_options_t *);
+    int (*create)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *);
     int (*factor)(sluamd_handle_t, double, int *);
-    int (*copy2host)(sluamd_handle_t, const sluamd_dLUview_t *);
+    int (*copy2host)(sluamd_handle_t, const LUVIEW_T *);
     int (*stats)(sluamd_handle_t, sluamd_stats_t *);
     void (*destroy)(sluamd_handle_t);
     const char *(*last_error)(void);
@@ -47,30 +69,30 @@ static void sluamd_load(void)
     S.so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!S.so) { fprintf(stderr, "dlopen(%s): %s\n", path, dlerror()); ABORT("cannot load libsluamd.so"); }
     S.default_options = (void (*)(sluamd_options_t *)) dlsym(S.so, "sluamd_default_options");
-    S.create = (int (*)(sluamd_handle_t *, const sluamd_dLUview_t *, const sluamd_forest_view_t *, const sluamd_options_t *)) dlsym(S.so, "sluamd_dCreateLUHandle");
-    S.factor = (int (*)(sluamd_handle_t, double, int *)) dlsym(S.so, "sluamd_pdgstrf3d");
-    S.copy2host = (int (*)(sluamd_handle_t, const sluamd_dLUview_t *)) dlsym(S.so, "sluamd_dCopyLU2Host");
+    S.create = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *)) dlsym(S.so, SYM_CREATE);
+    S.factor = (int (*)(sluamd_handle_t, double, int *)) dlsym(S.so, SYM_FACTOR);
+    S.copy2host = (int (*)(sluamd_handle_t, const LUVIEW_T *)) dlsym(S.so, SYM_COPY);
     S.stats = (int (*)(sluamd_handle_t, sluamd_stats_t *)) dlsym(S.so, "sluamd_get_stats");
     S.destroy = (void (*)(sluamd_handle_t)) dlsym(S.so, "sluamd_dDestroyLUHandle");
     S.last_error = (const char *(*)(void)) dlsym(S.so, "sluamd_last_error");
     if (!S.create || !S.factor || !S.copy2host || !S.destroy) ABORT("libsluamd.so lacks a required symbol");
 }
 
-int_t sluamd_bind_pdgstrf3d(superlu_dist_options_t *options, int m, int n, double anorm,
-                            dtrf3Dpartition_t *trf3Dpartition, SCT_t *SCT, dLUstruct_t *LUstruct,
+int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
+                            xtrf3Dpartition_t *trf3Dpartition, SCT_t *SCT, xLUstruct_t *LUstruct,
                             gridinfo3d_t *grid3d, SuperLUStat_t *stat, int *info)
 {
     gridinfo_t *grid = &grid3d->grid2d;
     Glu_persist_t *Glu = LUstruct->Glu_persist;
-    dLocalLU_t *Llu = LUstruct->Llu;
+    xLocalLU_t *Llu = LUstruct->Llu;
     int_t nsupers = Glu->supno[n - 1] + 1;
 
-    sluamd_dLUview_t v;
+    LUVIEW_T v;
     v.n = n; v.nsupers = (int32_t) nsupers; v.xsup = Glu->xsup;
     v.nprow = grid->nprow; v.npcol = grid->npcol; v.npdep = grid3d->npdep;
     v.myrow = MYROW(grid->iam, grid); v.mycol = MYCOL(grid->iam, grid); v.myzlayer = grid3d->zscp.Iam;
-    v.Lrowind_bc_ptr = Llu->Lrowind_bc_ptr; v.Lnzval_bc_ptr = Llu->Lnzval_bc_ptr;
-    v.Ufstnz_br_ptr = Llu->Ufstnz_br_ptr;   v.Unzval_br_ptr = Llu->Unzval_br_ptr;
+    v.Lrowind_bc_ptr = Llu->Lrowind_bc_ptr; v.Lnzval_bc_ptr = VALPP(Llu->Lnzval_bc_ptr);
+    v.Ufstnz_br_ptr = Llu->Ufstnz_br_ptr;   v.Unzval_br_ptr = VALPP(Llu->Unzval_br_ptr);
 
     /* elimination forests of this layer (dtrf3Dpartition_t, superlu_ddefs.h:317-337) */
     int maxLvl = log2i(grid3d->zscp.Np) + 1, nf = (1 << maxLvl) - 1;
