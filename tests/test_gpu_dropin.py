@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AMD = os.path.join(ROOT, "oracle", "_ref", "slu_ref_amd")
 REF = os.path.join(ROOT, "oracle", "_ref", "slu_ref_dump")
+ZAMD = os.path.join(ROOT, "oracle", "_ref", "slu_ref_zamd")
+ZREF = os.path.join(ROOT, "oracle", "_ref", "slu_ref_zdump")
 
 
 def _run(binary, args, tmp_path):
@@ -50,3 +52,25 @@ def test_reference_pipeline_with_our_pdgstrf3d(kind, tmp_path):
     assert info_amd == info_ref == 0
     assert res_amd < 1e-10 and res_ref < 1e-10
     assert abs(res_amd - res_ref) < 1e-10       # BASELINE.json: within 1e-10 of the reference CPU pdgssvx3d
+
+
+@pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF)), reason="prebuilt reference binaries not shipped")
+@pytest.mark.parametrize("kind", ["zgrid_nd", "zunsym_defaults"])
+def test_reference_pipeline_with_our_pzgstrf3d(kind, tmp_path):
+    """complex16 twin: pzgssvx3d (reference) with pzgstrf3d routed into sluamd_pzgstrf3d."""
+    if kind == "zgrid_nd":
+        n, rp, ci, v = matgen.poisson3d(0, 24, 24, 1)
+        perm = matgen.nd_perm_grid3d(24, 24, 1, leaf=16)
+        np.savetxt(tmp_path / "a.perm", perm, fmt="%d")
+        flags = ["-e", "0", "-p", "0", "-i", "0", "-P", str(tmp_path / "a.perm")]
+    else:
+        n, rp, ci, v = matgen.random_unsym(300, 0.03, seed=21)
+        flags = []
+    v = matgen.complex_shift(v, rp, ci, seed=4)
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    args = ["-r", "1", "-c", "1", "-d", "1", "-Q", "1", "-o", "none"] + flags + [str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(ZAMD, args, tmp_path)
+    res_ref, info_ref = _run(ZREF, args, tmp_path)
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10
