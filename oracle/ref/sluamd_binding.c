@@ -117,6 +117,20 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     if (rc) ABORT(S.last_error());
     sluamd_stats_t st;
     S.stats(h, &st);
+    if (getenv("SLUAMD_BIND_DEBUG")) {
+        double sl = 0, su = 0; long zl = 0;
+        for (int_t k = 0; k < nsupers; ++k) {
+            int_t *li = Llu->Lrowind_bc_ptr[k];
+            if (!li) continue;
+            int nsupr = li[1], ns = Glu->xsup[k + 1] - Glu->xsup[k];
+            double *lv = (double *) Llu->Lnzval_bc_ptr[k];
+            int w = (int) (sizeof(*Llu->Lnzval_bc_ptr[k]) / sizeof(double));
+            for (int j = 0; j < ns; ++j) { double a = 0; for (int q = 0; q < w; ++q) a += fabs(lv[((size_t) j * nsupr + j) * w + q]); if (a == 0) ++zl; sl += a; }
+            if (Llu->Ufstnz_br_ptr[k]) { double *uv = (double *) Llu->Unzval_br_ptr[k]; for (int_t e = 0; e < Llu->Ufstnz_br_ptr[k][1] * w; ++e) su += fabs(uv[e]); }
+        }
+        fprintf(stderr, "[sluamd_bind] info %d nnzL %lld nnzU %lld factor_ms %.3f sum|diag| %.6e zero_diag %ld sum|U| %.6e launches %d\n",
+                *info, (long long) st.nnz_L, (long long) st.nnz_U, st.t_factor_ms, sl, zl, su, st.num_launches);
+    }
     stat->ops[FACT] += (flops_t) (st.flops_schur_padded + st.flops_panel);   /* scuStatUpdate's tally     */
     stat->TinyPivots += st.tiny_pivots;
     S.destroy(h);                                                            /* was dDestroyLUgpuHandle   */

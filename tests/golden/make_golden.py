@@ -44,6 +44,7 @@ CASES = {
     "z_cg20_1x1x1_nrhs2": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 1), flags=["-s", "2"], z=True),
     "z_poisson8_nd": dict(matrix=("zpoisson", 8), grid=(1, 1, 1), nd=16, flags=["-e", "0", "-p", "0", "-i", "0"], z=True),
     "z_unsym200": dict(matrix=("zunsym", 200, 0.03, 9), grid=(1, 1, 1), flags=[], z=True),
+    "z_grid24_nd": dict(matrix=("zgrid2d", 24), grid=(1, 1, 1), nd=16, flags=["-e", "0", "-p", "0", "-i", "0"], z=True),
 }
 
 
@@ -53,19 +54,22 @@ def build_case(name, spec, tmp):
     if kind == "file":
         mpath = spec["matrix"][1]
     else:
-        if kind in ("poisson", "zpoisson"):
+        if kind == "zgrid2d":
+            N = spec["matrix"][1]
+            n, rp, ci, v = matgen.poisson3d(0, N, N, 1)
+        elif kind in ("poisson", "zpoisson"):
             N = spec["matrix"][1]
             n, rp, ci, v = matgen.poisson3d(N)
         else:
             _, nn, dens, seed = spec["matrix"]
             n, rp, ci, v = matgen.random_unsym(nn, dens, seed)
         if kind.startswith("z"):
-            v = matgen.complex_shift(v, rp, ci, seed=1)
+            v = matgen.complex_shift(v, rp, ci, seed=4 if kind == "zgrid2d" else 1)
         mpath = os.path.join(tmp, name + ".dat")
         matgen.write_triplet_dat(mpath, n, rp, ci, v)
         if spec.get("nd"):
             N = spec["matrix"][1]
-            perm = matgen.nd_perm_grid3d(N, N, N, leaf=spec["nd"])
+            perm = matgen.nd_perm_grid3d(N, N, 1 if kind == "zgrid2d" else N, leaf=spec["nd"])
             ppath = os.path.join(tmp, name + ".perm")
             np.savetxt(ppath, perm, fmt="%d")
             flags += ["-P", ppath]

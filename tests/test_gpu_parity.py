@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 CASES_1RANK = ["g20_1x1x1", "g20_1x1x1_nrhs3", "poisson8_nd", "poisson10_nd", "unsym300", "unsym120_tiny",
                # complex16 (pzgstrf3d / pzgstrs3d): cg20.cua = BASELINE.json config 5's matrix family
-               "z_cg20_1x1x1", "z_cg20_1x1x1_nrhs2", "z_poisson8_nd", "z_unsym200"]
+               "z_cg20_1x1x1", "z_cg20_1x1x1_nrhs2", "z_poisson8_nd", "z_unsym200", "z_grid24_nd"]
 
 
 def test_mfma_f64_fragment_layout():

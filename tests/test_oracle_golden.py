@@ -7,7 +7,7 @@ import oracle as orc
 CASES_1RANK = ["g20_1x1x1", "g20_1x1x1_nrhs3", "g20_1x1x1_legacy", "poisson8_nd", "poisson10_nd", "unsym300",
                "unsym120_tiny",
                # complex16: pzgstrf3d / pzgstrs3d recorded from the reference's SRC/complex16 path
-               "z_cg20_1x1x1", "z_cg20_1x1x1_nrhs2", "z_poisson8_nd", "z_unsym200"]
+               "z_cg20_1x1x1", "z_cg20_1x1x1_nrhs2", "z_poisson8_nd", "z_unsym200", "z_grid24_nd"]
 
 
 def _order(g):
