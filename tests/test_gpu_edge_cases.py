@@ -1,0 +1,109 @@
+"""Edge cases of the hot path through the C ABI: degenerate structures, sizes at the limits, argument errors."""
+import numpy as np
+import pytest
+import oracle as orc
+from superlu_dist_amd import _lib, driver, matgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(dense):
+    n = dense.shape[0]
+    rp = [0]; ci = []; v = []
+    for i in range(n):
+        nz = np.nonzero(dense[i])[0]
+        ci += nz.tolist(); v += dense[i, nz].tolist(); rp.append(len(ci))
+    return n, np.array(rp, dtype=np.int32), np.array(ci, dtype=np.int32), np.array(v)
+
+
+def _solve_and_check(n, rp, ci, v, perm=None, relax=4, maxsup=32, nrhs=1, tol=1e-10):
+    rng = np.random.default_rng(1)
+    xt = rng.standard_normal((n, nrhs)) + (1j * rng.standard_normal((n, nrhs)) if np.iscomplexobj(v) else 0)
+    b = matgen.csr_matvec(n, rp, ci, v, xt)
+    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=relax, maxsup=maxsup)
+    assert info == 0
+    assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= tol * np.linalg.norm(b)
+    return st
+
+
+def test_one_by_one_matrix():
+    _solve_and_check(*_csr(np.array([[4.0]])))
+
+
+def test_diagonal_matrix_all_singleton_supernodes():
+    st = _solve_and_check(*_csr(np.diag(np.arange(1.0, 41.0))), relax=1, maxsup=1)
+    assert st["flops_schur_exact"] == 0.0          # no off-diagonal block anywhere: every Schur launch is empty
+
+
+def test_dense_matrix_is_one_supernode():
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((96, 96)) + 96 * np.eye(96)
+    _solve_and_check(*_csr(A), relax=128, maxsup=128)
+
+
+def test_arrow_matrix_long_panels_tiny_supernodes():
+    n = 300
+    A = np.eye(n) * 10.0
+    A[-1, :] = 1.0; A[:, -1] = 1.0; A[-1, -1] = 400.0
+    _solve_and_check(*_csr(A), relax=1, maxsup=8)
+
+
+def test_supernode_width_exactly_256_and_multi_rhs():
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((300, 300)) * 0.1 + 300 * np.eye(300)
+    st = _solve_and_check(*_csr(A), relax=256, maxsup=256, nrhs=7)
+    assert st["nnz_L"] > 0
+
+
+def test_unsymmetric_values_wide_range_of_supernode_sizes():
+    n, rp, ci, v = matgen.random_unsym(700, 0.01, seed=8)
+    _solve_and_check(n, rp, ci, v, relax=8, maxsup=48, nrhs=3)
+
+
+def test_nrhs_zero_is_a_noop_and_negative_is_rejected():
+    n, rp, ci, v = matgen.poisson3d(4)
+    symb = driver.Symbolic(n, rp, ci, None, relax=4, maxsup=16)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    assert h.pdgstrf3d(0.0) == 0
+    L = _lib.load()
+    x = np.ones(n)
+    assert L.sluamd_pdgstrs3d(h._h, x.ctypes.data_as(_lib.P_dbl), n, 0) == 0        # nrhs = 0
+    assert np.all(x == 1.0)
+    assert L.sluamd_pdgstrs3d(h._h, x.ctypes.data_as(_lib.P_dbl), n, -1) != 0       # pdgstrs3d: info = -9 for nrhs < 0
+    assert L.sluamd_pdgstrs3d(h._h, x.ctypes.data_as(_lib.P_dbl), n - 1, 1) != 0    # ldx < n
+    assert b"solve" in L.sluamd_last_error()
+    h.destroy()
+
+
+def test_supernodes_wider_than_256_are_rejected_with_a_message():
+    """SUPERLU_MAXSUP may go up to 512 in the reference (sp_ienv.c); this library states its limit instead of
+    silently mis-computing."""
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((300, 300)) * 0.1 + 300 * np.eye(300)
+    n, rp, ci, v = _csr(A)
+    symb = driver.Symbolic(n, rp, ci, None, relax=300, maxsup=300)
+    if np.diff(symb.xsup()).max() <= 256:
+        pytest.skip("symbolic did not produce a wide supernode")
+    with pytest.raises(RuntimeError, match="256"):
+        driver.LUHandle.from_symbolic(symb, v)
+
+
+def test_malformed_structure_is_rejected(golden):
+    g = golden("g20_1x1x1")
+    st = driver.FlatStore.from_golden(g, 0, "pre")
+    st.Lrowind[int(st.Lrowind_off[3]) + 1] += 5          # corrupt the LDA of panel 3
+    st._build_view()
+    with pytest.raises(RuntimeError, match="mismatch|malformed"):
+        driver.LUHandle.from_store(st)
+
+
+def test_factor_twice_after_reset_gives_identical_solution():
+    n, rp, ci, v = matgen.poisson3d(9)
+    perm = matgen.nd_perm_grid3d(9, 9, 9, leaf=27)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=16, maxsup=64)
+    h = driver.LUHandle.from_symbolic(symb, v, deterministic=True)
+    b = np.ones((n, 1))
+    h.pdgstrf3d(0.0); x1 = h.pdgstrs3d(b)
+    h.reset_values(); h.pdgstrf3d(0.0); x2 = h.pdgstrs3d(b)
+    assert np.array_equal(x1, x2)
+    h.destroy()
