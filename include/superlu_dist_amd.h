@@ -82,7 +82,8 @@ typedef struct sluamd_forest_view {
 typedef struct sluamd_options {
     int32_t device;             /* HIP device ordinal (-1 = current device)                      */
     int32_t replace_tiny_pivot; /* options->ReplaceTinyPivot == YES (superlu_defs.h:697)         */
-    int32_t deterministic;      /* 1: one supernode per Schur launch, no fp64 atomics            */
+    int32_t deterministic;      /* 1: one supernode per Schur launch -> fixed summation order of the factors (the solve
+                                 *    still accumulates lsum with fp64 atomics)                 */
     int32_t verbose;
     double  reserved[4];
 } sluamd_options_t;

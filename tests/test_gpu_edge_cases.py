@@ -97,7 +97,9 @@ def test_malformed_structure_is_rejected(golden):
         driver.LUHandle.from_store(st)
 
 
-def test_factor_twice_after_reset_gives_identical_solution():
+def test_factor_twice_after_device_reset_reproduces_the_solution():
+    """deterministic=1 fixes the summation order of the FACTORISATION (bitwise test in test_gpu_parity); the solve
+    accumulates lsum contributions with fp64 atomics, so solutions agree to rounding, not bitwise."""
     n, rp, ci, v = matgen.poisson3d(9)
     perm = matgen.nd_perm_grid3d(9, 9, 9, leaf=27)
     symb = driver.Symbolic(n, rp, ci, perm, relax=16, maxsup=64)
@@ -105,5 +107,5 @@ def test_factor_twice_after_reset_gives_identical_solution():
     b = np.ones((n, 1))
     h.pdgstrf3d(0.0); x1 = h.pdgstrs3d(b)
     h.reset_values(); h.pdgstrf3d(0.0); x2 = h.pdgstrs3d(b)
-    assert np.array_equal(x1, x2)
+    assert np.abs(x1 - x2).max() <= 1e-13 * np.abs(x1).max()
     h.destroy()
