@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
     double *Us = s_a + DB * ldp;            // 64-column slice of U12: element (kk, c) at Us[kk * lus + c]
     for (int jb = 0; jb < ns; jb += DB) {
         const int nb = min(DB, ns - jb), m = ns - jb, nc = m - nb;
+#pragma unroll 8
         for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; Ps[c * ldp + r] = A[jb + r + (size_t) (jb + c) * lda]; }
         __syncthreads();
         if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info, s_rinv);
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
             for (int c = 0; c < DB; ++c) Ps[c * ldp + nb + tid] = x[c];
         }
         __syncthreads();
+#pragma unroll 8
         for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
         if (nc > 0) {
             // U12 = L11^-1 A12 : one thread per column, forward substitution in registers, result back to HBM/L2
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
             const int ntr = (nc + 15) >> 4;
             for (int c0 = 0; c0 < nc; c0 += UC) {
                 const int ncc = min(UC, nc - c0), ntc = (ncc + 15) >> 4;
+#pragma unroll 8
                 for (int idx = tid; idx < DB * ncc; idx += 256) { int i2 = idx & 31, c = idx >> 5; Us[i2 * lus + c] = A[jb + i2 + (size_t) (jb + nb + c0 + c) * lda]; }
                 __syncthreads();
                 for (int t0 = wave * 4; t0 < ntr * ntc; t0 += 16) {
@@ -439,6 +442,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
 
     if (MODE == 0) {
         const int row0 = ns + strip * RSv;
+#pragma unroll 8
         for (int idx = tid; idx < RSv * nsp; idx += NT) {
             const int r = idx % RSv, c = idx / RSv;
             double v = 0.0;
@@ -551,6 +555,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
 
     if (MODE == 0) {
         const int row0 = ns + strip * RSv;
+#pragma unroll 8
         for (int idx = tid; idx < RSv * ns; idx += NT) {
             const int r = idx % RSv, c = idx / RSv;
             if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
@@ -817,9 +822,13 @@ __global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__re
         for (int idx = tid; idx < nb * nrhs; idx += 256) {
             const int r = idx % nb, q = idx / nb;
             const double *xb = xs + o + q * ns;
+            // fixed trip count + predication: the 32 loads of D are issued together instead of one L2 round trip each
+            double dv[DB];
+#pragma unroll
+            for (int c = 0; c < DB; ++c) dv[c] = (LOWER ? (c <= r) : (c >= r && c < nb)) ? (LOWER ? D[r * DB + c] : D[c * DB + r]) : 0.0;
             double a = 0.0;
-            if (LOWER) { for (int c = 0; c <= r; ++c) a += D[r * DB + c] * xb[c]; }
-            else { for (int c = r; c < nb; ++c) a += D[c * DB + r] * xb[c]; }
+#pragma unroll
+            for (int c = 0; c < DB; ++c) a += dv[c] * ((c < nb) ? xb[c] : 0.0);
             ys[r + q * DB] = a;
         }
         __syncthreads();
@@ -829,8 +838,12 @@ __global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__re
             const int rr = idx % (r1 - r0 + nb), q = idx / (r1 - r0 + nb);
             if (rr < nb) { xs[o + rr + q * ns] = ys[rr + q * DB]; continue; }
             const int i = r0 + (rr - nb);
+            double av[DB];
+#pragma unroll
+            for (int c = 0; c < DB; ++c) av[c] = (c < nb) ? A[i + (size_t) (o + c) * lda] : 0.0;
             double a = 0.0;
-            for (int c = 0; c < nb; ++c) a += A[i + (size_t) (o + c) * lda] * ys[c + q * DB];
+#pragma unroll
+            for (int c = 0; c < DB; ++c) a += av[c] * ys[c + q * DB];
             xs[i + q * ns] -= a;
         }
         __syncthreads();
