@@ -91,6 +91,7 @@ def test_supernodes_wider_than_256_are_rejected_with_a_message():
 def test_malformed_structure_is_rejected(golden):
     g = golden("g20_1x1x1")
     st = driver.FlatStore.from_golden(g, 0, "pre")
+    st.Lrowind = st.Lrowind.copy()                       # the fixture dict is cached for the whole session
     st.Lrowind[int(st.Lrowind_off[3]) + 1] += 5          # corrupt the LDA of panel 3
     st._build_view()
     with pytest.raises(RuntimeError, match="mismatch|malformed"):
