@@ -669,30 +669,34 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
     }
     // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
-    if (tid == NT - 1) {
-        int found = 0;
-        if (ib >= jb) {
-            const int o = T.sn_lb_off[jb], nb = T.sn_nlb[jb];
-            int lo = 0, hi = nb;
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.lbs_gid[o + mid] <= ib) lo = mid; else hi = mid; }
-            if (nb > 0 && T.lbs_gid[o + lo] == ib) {
-                const int d = o + T.lbs_idx[o + lo];
-                s_dinfo[0] = T.lb_rowoff[d]; s_dinfo[1] = T.lb_lptr[d]; s_dinfo[2] = T.lb_nbrow[d];
-                s_dbase = T.sn_lval[jb];
-                found = 1;
-            }
-        } else {
-            const int o = T.sn_ub_off[ib], nb = T.sn_nub[ib];
-            int lo = 0, hi = nb;
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_gid[o + mid] <= jb) lo = mid; else hi = mid; }
-            if (nb > 0 && T.ub_gid[o + lo] == jb) {
-                s_dinfo[0] = T.ub_iukp[o + lo];
-                s_dbase = T.sn_uval[ib];
-                found = 1;
-            }
+    if ((tid >> 6) == NW - 1) {
+        // one wave scans the gid directory of the destination panel / row with ONE coalesced load per 64 blocks and a
+        // ballot, instead of a binary search whose every step is a dependent L2 round trip
+        const int ln = tid & 63;
+        const bool ldest = ib >= jb;
+        const int o = ldest ? T.sn_lb_off[jb] : T.sn_ub_off[ib];
+        const int nb = ldest ? T.sn_nlb[jb] : T.sn_nub[ib];
+        const int *dir = ldest ? T.lbs_gid : T.ub_gid;
+        const int want = ldest ? ib : jb;
+        int pos = -1;
+        for (int base = 0; base < nb && pos < 0; base += 64) {
+            const int g = (base + ln < nb) ? dir[o + base + ln] : -1;
+            const unsigned long long m = __ballot(g == want);
+            if (m) pos = base + __ffsll((long long) m) - 1;
         }
-        s_dinfo[3] = found;
-        if (!found) atomicAdd(&info[2], 1);
+        if (ln == 0) {
+            if (pos >= 0) {
+                if (ldest) {
+                    const int d = o + T.lbs_idx[o + pos];
+                    s_dinfo[0] = T.lb_rowoff[d]; s_dinfo[1] = T.lb_lptr[d]; s_dinfo[2] = T.lb_nbrow[d];
+                    s_dbase = T.sn_lval[jb];
+                } else {
+                    s_dinfo[0] = T.ub_iukp[o + pos];
+                    s_dbase = T.sn_uval[ib];
+                }
+            } else atomicAdd(&info[2], 1);
+            s_dinfo[3] = pos >= 0;
+        }
     }
     __syncthreads();
 
