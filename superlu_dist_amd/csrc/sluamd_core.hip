@@ -396,7 +396,8 @@ static inline int trsm_rs(int nsp)
     static const bool rs32 = getenv("SLUAMD_TRSM_RS32") != nullptr;
     return (nsp > 128 && rs32) ? 32 : 64;
 }
-static inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) trsm_rs(nsp) * nsp + 2 * DB * DB); }
+constexpr int TB_SZ = DB * 48;   // doubles per operand buffer: [32][48] (c-fastest chunks) or [32][34] (k-fastest chunks)
+static inline size_t trsm_lds_bytes(int nsp) { return sizeof(double) * ((size_t) trsm_rs(nsp) * nsp + 2 * TB_SZ); }
 
 // The solve is a flat pipeline of 32x32 operand blocks ("chunks"): for every block column jb the off-diagonal
 // blocks T(kc, jb), kc = 0, 32, .. jb-32, then the inverted diagonal block inv(T_jj).  Chunks are fetched from L2
@@ -416,7 +417,9 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     double *Uv = T.val + T.sn_uval[k];
     const double *dinv = T.dinv + T.sn_dinv[k] + (MODE == 0 ? 0 : (size_t) nblk * DB * DB);
     double *Xs = sm;                          // [RSv/16][nsp][16]: element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
-    double *Tb = sm + (size_t) RSv * nsp;     // [2 buffers][2 halves][32][16]: element (kk, cc) at ((cc>>4)*32 + kk)*16 + (cc&15)
+    double *Tb = sm + (size_t) RSv * nsp;     // [2 buffers] x one 32x32 operand block; the element (kk, cc) sits at cc*34 + kk when
+                                              // the chunk was fetched k-fastest (U_kk blocks, inverse blocks) and at kk*48 + cc when it
+                                              // was fetched c-fastest (L_kk^T blocks): coalesced fetch, conflict-free stash AND fragment reads
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // per-strip-row skyline metadata (MODE 1) lives in the Tb region while the pipeline is not running: the workgroup
     // then needs exactly RSv*nsp + 2048 doubles (80 KB for nsp = 256) and two of them fit on one CU
@@ -479,12 +482,11 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
         }
     };
     auto stash = [&](const double *pv, int jb, int t, int buf) {
-        double *tb = Tb + buf * (2 * DB * 16);
+        double *tb = Tb + buf * TB_SZ;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            int kk, cc;
-            if (t * DB < jb && MODE == 1) { cc = e0; kk = e1 + ES * q; } else { kk = e0; cc = e1 + ES * q; }
-            tb[((cc >> 4) * DB + kk) * 16 + (cc & 15)] = pv[q];
+            if (t * DB < jb && MODE == 1) tb[(e1 + ES * q) * 48 + e0] = pv[q];   // (kk = e1 + ES q, cc = e0)
+            else tb[(e1 + ES * q) * 34 + e0] = pv[q];                            // (kk = e0, cc = e1 + ES q)
         }
     };
     auto advance = [&](int &jb, int &t) { if (++t > jb / DB) { jb += DB; t = 0; } };
@@ -492,15 +494,19 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
     const double *xa = Xs + ((size_t) wave * nsp + (lane >> 4)) * 16 + (lane & 15);
     auto compute = [&](int jb, int t, int buf) {
-        const double *tb0 = Tb + buf * (2 * DB * 16) + (lane >> 4) * 16 + (lane & 15);
-        const double *tb1 = tb0 + DB * 16;
+        // fragment element (kk = k4 + lane>>4, cc = half*16 + lane&15)
+        const bool cfast = (MODE == 1) && (t < jb / DB);
+        const int sk = cfast ? 48 : 1, sc = cfast ? 1 : 34;
+        const double *tb0 = Tb + buf * TB_SZ + (lane >> 4) * sk + (lane & 15) * sc;
+        const double *tb1 = tb0 + 16 * sc;
+        const int ks = 4 * sk;   // pointer step per k4
         if (t < jb / DB) {
             const double *a = xa + (size_t) (t * DB) * 16;
 #pragma unroll
             for (int k4 = 0; k4 < DB; k4 += 4) {
                 const double av = a[k4 * 16];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[(k4 >> 2) * ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[(k4 >> 2) * ks], acc1, 0, 0, 0);
             }
         } else {
             // rhs = X_jb - acc (own 16 rows), then X_jb = rhs * inv(T_jj)
@@ -513,8 +519,8 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
 #pragma unroll
             for (int k4 = 0; k4 < DB; k4 += 4) {
                 const double av = a[k4 * 16];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[k4 * 16], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[k4 * 16], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[(k4 >> 2) * ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[(k4 >> 2) * ks], acc1, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { x0[4 * r] = acc0[r]; x1[4 * r] = acc1[r]; }
@@ -1317,7 +1323,7 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
     H->st.bytes_device = (int64_t) ((hs.nnzL + hs.nnzU) * sizeof(double) + idxb);
