@@ -208,6 +208,20 @@ int sluamd_local_offsets(sluamd_handle_t h, int64_t *lval_off, int64_t *uval_off
 int sluamd_pdgstrs3d_level(sluamd_handle_t h, int zlevel, int dir, double *d_x, int64_t ldx, int32_t nrhs);
 int sluamd_mfma_selftest(const double *A16x4, const double *B4x16, double *D16x16);
 
+/* ---- cooperative factorisation of a shared ancestor forest (1 x 1 x Pz grids) ----
+ * The reference leaves the 2^zlevel layers that share an ancestor forest idle but one (pdgstrf3d.c:333-385 with
+ * myZeroTrIdxs); on xGMI-connected GPUs the idle layers are put to work instead: storage of the forest stays
+ * replicated, block column jb is kept current by rank jb % G ("owner computes", the 1-D analogue of the reference's
+ * 2-D block-cyclic grid, pdgstrf2.c / dSchCompUdt-2Ddynamic.c), and the only exchange per DAG level is a sum
+ * all-reduce of a staging buffer holding that level's factored L panels (the panel broadcast of dIBcastRecvLPanel,
+ * pd3dcomm-style).  All calls queue on the stream given to sluamd_set_stream (the caller's RCCL stream order). */
+int sluamd_set_stream(sluamd_handle_t h, void *hip_stream);
+int sluamd_coop_info(sluamd_handle_t h, int zlevel, int *dag_levels, int64_t *max_stage_doubles);
+int sluamd_coop_level_size(sluamd_handle_t h, int zlevel, int dag_level, int *nnodes, int64_t *stage_doubles);
+int sluamd_coop_panel(sluamd_handle_t h, int zlevel, int dag_level, int G, int g, double thresh, double *d_stage);
+int sluamd_coop_update(sluamd_handle_t h, int zlevel, int dag_level, int G, int g, const double *d_stage);
+int sluamd_coop_mask_u(sluamd_handle_t h, int zlevel, int G, int g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,12 @@ def load():
     L.sluamd_local_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sluamd_pdgstrs3d_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_set_profile.argtypes = [C.c_void_p, C.c_int]
+    L.sluamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.sluamd_coop_info.argtypes = [C.c_void_p, C.c_int, P_int, C.POINTER(C.c_int64)]
+    L.sluamd_coop_level_size.argtypes = [C.c_void_p, C.c_int, C.c_int, P_int, C.POINTER(C.c_int64)]
+    L.sluamd_coop_panel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    L.sluamd_coop_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sluamd_coop_mask_u.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     _lib = L
     return L
 

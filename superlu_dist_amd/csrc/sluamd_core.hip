@@ -70,6 +70,8 @@ struct DevTables {
     // tiles
     const int4 *rtile;  // (L block idx within panel, row start in block, nrows, panel row offset)
     const int4 *ctile;  // (U block idx within row, first non-empty col rank, ncols, unused)
+    // cooperative (owner-computes) mode inside one shared ancestor forest: block column jb belongs to rank jb % own_G
+    int own_G, own_g;
 };
 
 struct LevelSched {
@@ -87,6 +89,8 @@ struct LevelSched {
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
     std::vector<int> max_nsupc;     // per level
     std::vector<size_t> diag_lds;   // per level: dynamic LDS bytes k_diag_lu needs (max over the level's nodes)
+    std::vector<int> pk_prefix;     // cooperative mode: 4096-double chunks of each node's (L panel | dinv) payload
+    std::vector<int64_t> pk_off;    // ... and its offset (doubles) inside the level's staging buffer
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
     std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level [big group | small group]
     std::vector<int> u_off;         // [2*nlevels+1] offsets into ulist (2 groups per level)
@@ -94,6 +98,7 @@ struct LevelSched {
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
     int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
     int4 *d_ulist = nullptr;
+    int *d_pk_prefix = nullptr; int64_t *d_pk_off = nullptr;
 };
 
 struct Handle {
@@ -108,6 +113,7 @@ struct Handle {
     DevTables T{};
     std::vector<LevelSched> sched;  // one per Z level (forests) or a single one
     hipStream_t stream = nullptr;
+    hipStream_t user_stream = nullptr; bool has_user_stream = false;   // cooperative mode: the caller's (torch/RCCL) stream
     hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
     hipStream_t rstream = nullptr;          // CU-masked stream for the non-urgent Schur tiles: leaves a few CUs free so
                                             // that the (LDS-hungry) panel workgroups are not starved by the tile stream
@@ -133,6 +139,7 @@ struct Handle {
 // ================================================================================================
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 16;  // K chunk of the Schur GEMM pipeline
+constexpr int PKC = 4096;  // cooperative mode: doubles per pack/unpack workgroup
 
 __device__ __forceinline__ int find_node(const int *__restrict__ prefix, int nn, int id)
 {   // largest i in [0,nn) with prefix[i] <= id   (prefix has nn+1 entries)
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
     __shared__ double s_a[DB * ldp + DB * lus];
     __shared__ double s_rinv[DB];
     const int k = nodes[blockIdx.x];
+    if (T.own_G > 1 && (k % T.own_G) != T.own_g) return;   // cooperative mode: the owner of block column k factors it
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     double *A = T.val + T.sn_lval[k];
@@ -341,12 +349,16 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
     __shared__ double Xi[4][DB * (DB + 1)];
     const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
     const int task = blockIdx.x * 4 + g;
-    const bool valid = task < prefix[nn];
+    bool valid = task < prefix[nn];
     int k = 0, typ = 0, b = 0, ns = 0, lda = 1, nblk = 1;
     const double *A = nullptr;
+    int ni = 0;
     if (valid) {
-        const int ni = find_node(prefix, nn, task);
+        ni = find_node(prefix, nn, task);
         k = nodes[ni];
+        if (T.own_G > 1 && (k % T.own_G) != T.own_g) valid = false;
+    }
+    if (valid) {
         ns = T.xsup[k + 1] - T.xsup[k];
         nblk = (ns + DB - 1) / DB;
         const int rem = task - prefix[ni];
@@ -585,11 +597,50 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
     extern __shared__ double sm[];
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
+        if (T.own_G > 1 && (nodes[ni] % T.own_G) != T.own_g) return;
         panel_trsm_body<0, RSv>(T, nodes[ni], blockIdx.x - lprefix[ni], sm);
     } else {
         const int id = blockIdx.x - nl;
         const int ni = find_node(uprefix, nn, id);
         panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm);
+    }
+}
+
+// ---- cooperative (owner-computes) mode helpers ----------------------------------------------------
+// Pack (unpack = 0): the level's staging buffer receives the factored L panel + inverted diagonal sub-blocks of the
+// supernodes this rank owns, zeros elsewhere; after a sum all-reduce over the group every rank holds every panel
+// of the level.  Unpack (unpack = 1): copy the panels this rank does NOT own from the staging buffer into its arena.
+__global__ __launch_bounds__(256) void k_coop_pack(DevTables T, const int *__restrict__ nodes, const int *__restrict__ cprefix,
+                                                   const int64_t *__restrict__ off, int nn, double *__restrict__ stage, int unpack)
+{
+    const int ni = find_node(cprefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const bool mine = (k % T.own_G) == T.own_g;
+    if (unpack && mine) return;
+    const int ns = T.xsup[k + 1] - T.xsup[k];
+    const int64_t lsz = (int64_t) T.sn_nsupr[k] * ns, tot = lsz + (int64_t) 2 * ((ns + DB - 1) / DB) * DB * DB;
+    const int64_t e0 = (int64_t) (blockIdx.x - cprefix[ni]) * PKC;
+    const int64_t e1 = (e0 + PKC < tot) ? e0 + PKC : tot;
+    double *Lp = T.val + T.sn_lval[k], *Dp = T.dinv + T.sn_dinv[k], *Sp = stage + off[ni];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        double *p = (e < lsz) ? Lp + e : Dp + (e - lsz);
+        if (unpack) *p = Sp[e]; else Sp[e] = mine ? *p : 0.0;
+    }
+}
+
+// Zero the U blocks (k, jb) this rank does not own (jb % G != g): after a sum all-reduce of the forest's U rows
+// every rank holds the complete factor.
+__global__ __launch_bounds__(256) void k_coop_mask_u(DevTables T, const int *__restrict__ nodes)
+{
+    const int k = nodes[blockIdx.x];
+    double *U = T.val + T.sn_uval[k];
+    const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+    for (int b = 0; b < nub; ++b) {
+        const int jb = T.ub_gid[ub0 + b];
+        if ((jb % T.own_G) == T.own_g) continue;
+        const int64_t ip = T.sn_uidx[k] + T.ub_iukp[ub0 + b];
+        const int start = T.ucolptr[ip], nnz = T.uidx[ip - 1];
+        for (int e = threadIdx.x; e < nnz; e += 256) U[start + e] = 0.0;
     }
 }
 
@@ -657,6 +708,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
     const int nr = R.z, nc = C.z;
     const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
+    if (T.own_G > 1 && (jb % T.own_G) != T.own_g) return;   // cooperative mode: owner of destination block column jb
     if (!ulist && skip_level >= 0 && (sn_level[ib] == skip_level || sn_level[jb] == skip_level)) return;  // done by the urgent launch
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int lda = T.sn_nsupr[k];
@@ -1173,6 +1225,7 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
     const int psz = S.lvl_poff[S.nlevels];
     S.tile_prefix.assign(S.lvl_soff[S.nlevels], 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0); S.zltr_prefix.assign(psz, 0);
+    S.pk_prefix.assign(psz, 0); S.pk_off.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     S.diag_lds.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l)
@@ -1193,6 +1246,11 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
             S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (rrows + rs - 1) / rs;
             S.utr_prefix[po + 1] = S.utr_prefix[po] + (t.sn_ncolu[k] + rs - 1) / rs;
             S.inv_prefix[po + 1] = S.inv_prefix[po] + 2 * ((nsupc + 31) / 32);
+            {
+                const int64_t pay = (int64_t) t.sn_nsupr[k] * nsupc + (int64_t) 2 * ((nsupc + 31) / 32) * 32 * 32;
+                S.pk_prefix[po + 1] = S.pk_prefix[po] + (int) ((pay + PKC - 1) / PKC);
+                S.pk_off[po + 1] = S.pk_off[po] + pay;
+            }
             S.zltr_prefix[po + 1] = S.zltr_prefix[po] + (rrows + 63) / 64;
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (rrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (t.sn_ncolu[k] + 63) / 64;
@@ -1242,6 +1300,8 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.zltr_prefix, &S.d_zltr_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.sn_level, &S.d_sn_level)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.pk_prefix, &S.d_pk_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.pk_off, &S.d_pk_off)) return SLUAMD_EHIP;
     return 0;
 }
 
@@ -1682,6 +1742,142 @@ int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh)
     return 0;
 }
 
+// ---- cooperative (owner-computes) factorisation of one shared ancestor forest ----------------------------------
+// The G = 2^zlevel ranks that share the forest of Z level `zlevel` all hold its panels (replicated storage).  Block
+// column jb (L panel jb and the U blocks (*, jb)) is kept current by rank jb % G only:
+//   sluamd_coop_panel  : owners factor the diagonal blocks + L panels of DAG level l, then everybody packs the
+//                        level's staging buffer (own panels | zeros) -> caller sum-all-reduces it over the group;
+//   sluamd_coop_update : unpack the other owners' panels, U-panel TRSM, Schur update of the destinations I own.
+// Everything is queued on the caller's stream (sluamd_set_stream) without host synchronisation, so the RCCL
+// all-reduce of the staging buffer orders naturally between the two calls.
+int sluamd_set_stream(sluamd_handle_t h, void *stream)
+{
+    if (!h) { set_error("null handle"); return SLUAMD_EINVAL; }
+    h->H.user_stream = reinterpret_cast<hipStream_t>(stream);
+    h->H.has_user_stream = true;
+    return 0;
+}
+
+int sluamd_coop_info(sluamd_handle_t h, int zlevel, int *nlevels, int64_t *max_stage)
+{
+    if (!h || zlevel < 0 || zlevel >= (int) h->H.sched.size()) { set_error("bad level"); return SLUAMD_EINVAL; }
+    const LevelSched &S = h->H.sched[zlevel];
+    int64_t mx = 0;
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int nn = S.lvl_off[l + 1] - S.lvl_off[l];
+        mx = std::max(mx, S.pk_off[S.lvl_poff[l] + nn]);
+    }
+    if (nlevels) *nlevels = S.nlevels;
+    if (max_stage) *max_stage = mx;
+    return 0;
+}
+
+int sluamd_coop_level_size(sluamd_handle_t h, int zlevel, int l, int *nnodes, int64_t *stage_doubles)
+{
+    if (!h || zlevel < 0 || zlevel >= (int) h->H.sched.size() || l < 0 || l >= h->H.sched[zlevel].nlevels) { set_error("bad level"); return SLUAMD_EINVAL; }
+    const LevelSched &S = h->H.sched[zlevel];
+    const int nn = S.lvl_off[l + 1] - S.lvl_off[l];
+    if (nnodes) *nnodes = nn;
+    if (stage_doubles) *stage_doubles = S.pk_off[S.lvl_poff[l] + nn];
+    return 0;
+}
+
+static int coop_check(sluamd_handle_t h, int zlevel, int l, int G, int g)
+{
+    if (!h || zlevel < 0 || zlevel >= (int) h->H.sched.size() || G < 1 || g < 0 || g >= G) { set_error("bad cooperative-level arguments"); return SLUAMD_EINVAL; }
+    if (l >= h->H.sched[zlevel].nlevels || l < -1) { set_error("bad DAG level"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("cooperative mode is double precision only"); return SLUAMD_EINVAL; }
+    return 0;
+}
+
+int sluamd_coop_panel(sluamd_handle_t h, int zlevel, int l, int G, int g, double thresh, double *d_stage)
+{
+    int rc = coop_check(h, zlevel, l, G, g);
+    if (rc) return rc;
+    if (l < 0 || !d_stage) { set_error("bad cooperative-level arguments"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    LevelSched &S = H->sched[zlevel];
+    DevTables T = H->T; T.own_G = G; T.own_g = g;
+    hipStream_t cs = H->has_user_stream ? H->user_stream : H->stream;
+    const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+    const int *nodes = S.d_nodes + n0;
+    bool any = false;
+    for (int i = 0; i < nn; ++i) any |= (S.nodes[n0 + i] % G) == g;
+    if (any) {
+        const int mx = S.max_nsupc[l];
+        if (mx <= 64) hipLaunchKernelGGL(k_diag_lu<64>, dim3(nn), dim3(256), 0, cs, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, cs, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, cs, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        hipLaunchKernelGGL(k_diag_inv, dim3((S.inv_prefix[po + nn] + 3) / 4), dim3(128), 0, cs, T, nodes, S.d_inv_prefix + po, nn);
+        const int nl = S.ltr_prefix[po + nn];
+        if (nl) {
+            const size_t lds_tr = trsm_lds_bytes((mx + 31) & ~31);
+            if (trsm_rs((mx + 31) & ~31) == 32) hipLaunchKernelGGL(k_panel_trsm<32>, dim3(nl), dim3(128), lds_tr, cs, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
+            else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nl), dim3(256), lds_tr, cs, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
+        }
+    }
+    if (G > 1) hipLaunchKernelGGL(k_coop_pack, dim3(S.pk_prefix[po + nn]), dim3(256), 0, cs, T, nodes, S.d_pk_prefix + po, S.d_pk_off + po, nn, d_stage, 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int sluamd_coop_update(sluamd_handle_t h, int zlevel, int l, int G, int g, const double *d_stage)
+{
+    int rc = coop_check(h, zlevel, l, G, g);
+    if (rc) return rc;
+    if (l < 0) { set_error("bad cooperative-level arguments"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    LevelSched &S = H->sched[zlevel];
+    DevTables T = H->T; T.own_G = G; T.own_g = g;
+    hipStream_t cs = H->has_user_stream ? H->user_stream : H->stream;
+    const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+    const int *nodes = S.d_nodes + n0;
+    if (G > 1) {
+        if (!d_stage) { set_error("null staging buffer"); return SLUAMD_EINVAL; }
+        hipLaunchKernelGGL(k_coop_pack, dim3(S.pk_prefix[po + nn]), dim3(256), 0, cs, T, nodes, S.d_pk_prefix + po, S.d_pk_off + po, nn, const_cast<double *>(d_stage), 1);
+    }
+    const int mx = S.max_nsupc[l];
+    const int nu = S.utr_prefix[po + nn];
+    if (nu) {   // U strips only: nl = 0 sends every workgroup down the U branch
+        const size_t lds_tr = trsm_lds_bytes((mx + 31) & ~31);
+        if (trsm_rs((mx + 31) & ~31) == 32) hipLaunchKernelGGL(k_panel_trsm<32>, dim3(nu), dim3(128), lds_tr, cs, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, 0);
+        else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nu), dim3(256), lds_tr, cs, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, 0);
+    }
+    const int nbig = S.n_big[l];
+    for (int grp = 0; grp < 2; ++grp) {
+        const int cnt = grp == 0 ? nbig : nn - nbig;
+        if (!cnt) continue;
+        const int so = S.lvl_soff[l] + (grp == 0 ? 0 : nbig + 1);
+        const int *gn = nodes + (grp == 0 ? 0 : nbig);
+        const int nt = S.tile_prefix[so + cnt];
+        if (!nt) continue;
+        const int grid = ((nt + 7) / 8) * 8;
+        if (grp == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1);
+        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1);
+    }
+    H->dinv_ready = true;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// zero the U blocks of the forest this rank does not own; the caller then sum-all-reduces the forest's U rows
+int sluamd_coop_mask_u(sluamd_handle_t h, int zlevel, int G, int g)
+{
+    int rc = coop_check(h, zlevel, -1, G, g);
+    if (rc) return rc;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    LevelSched &S = H->sched[zlevel];
+    if (G == 1 || S.nodes.empty()) return 0;
+    DevTables T = H->T; T.own_G = G; T.own_g = g;
+    hipStream_t cs = H->has_user_stream ? H->user_stream : H->stream;
+    hipLaunchKernelGGL(k_coop_mask_u, dim3((unsigned) S.nodes.size()), dim3(256), 0, cs, T, S.d_nodes);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny)
 {
     if (!h) return SLUAMD_EINVAL;
@@ -1951,7 +2147,8 @@ static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_
             for (int l = 0; l < maxLvl; ++l)
                 if (sn_tree[k] == trees[l]) {
                     hs.present[k] = 1;
-                    if (myz % (1 << l) == 0) { owned[k] = 1; lists[l].push_back(k); }
+                    lists[l].push_back(k);                 // schedule on every rank of the sharing group (cooperative mode)
+                    if (myz % (1 << l) == 0) owned[k] = 1;   // A's entries only on the group's first layer
                 }
         hs.lidx_off.assign(ns + 1, 0); hs.uidx_off.assign(ns + 1, 0); hs.lval_off.assign(ns + 1, 0); hs.uval_off.assign(ns + 1, 0);
         for (int k = 0; k < ns; ++k) {

@@ -49,27 +49,57 @@ def runs(sorted_nodes):
 
 
 class DistComm:
-    """Point-to-point + all-reduce over torch.distributed (nccl on GPUs, gloo on CPU)."""
+    """Point-to-point + all-reduce over torch.distributed (nccl on GPUs, gloo on CPU).
 
-    def __init__(self, dist, ranks=None):
+    npdep > 1 also creates the sub-communicators of the cooperative factorisation: for every Z level ilvl >= 1 the
+    groups of 2^ilvl consecutive layers that share one ancestor forest (dist.new_group is collective: every rank
+    creates every group, in the same order).  host_staging=True bounces device tensors through host memory (gloo
+    without GPU support: the single-GPU multi-process tests)."""
+
+    def __init__(self, dist, ranks=None, npdep=1, host_staging=False):
         self.dist = dist
         self.ranks = ranks            # layer z -> global rank (identity by default)
+        self.host_staging = host_staging
+        self.groups = {}
+        if npdep > 1:
+            for ilvl in range(1, max_level(npdep)):
+                G = 1 << ilvl
+                for z0 in range(0, npdep, G):
+                    if G == npdep and ranks is None:
+                        self.groups[(ilvl, z0)] = None                       # the world group
+                    else:
+                        self.groups[(ilvl, z0)] = dist.new_group([self._r(z) for z in range(z0, z0 + G)])
+
+    def group(self, ilvl, z0):
+        return ("g", self.groups[(ilvl, z0)])
 
     def _r(self, z):
         return z if self.ranks is None else self.ranks[z]
 
     def send(self, t, dst):
-        self.dist.send(t.contiguous(), self._r(dst))
+        t = t.contiguous()
+        self.dist.send(t.cpu() if self.host_staging else t, self._r(dst))
 
     def recv(self, t, src):
-        self.dist.recv(t, self._r(src))
+        if self.host_staging:
+            tmp = t.cpu()
+            self.dist.recv(tmp, self._r(src))
+            t.copy_(tmp)
+        else:
+            self.dist.recv(t, self._r(src))
 
-    def allreduce_sum(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+    def allreduce_sum(self, t, group=None):
+        pg = group[1] if group is not None else None
+        if self.host_staging:
+            tmp = t.cpu()
+            self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM, group=pg)
+            t.copy_(tmp)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=pg)
 
     def allreduce_min_int(self, v, device):
         import torch
-        t = torch.tensor([v], dtype=torch.int64, device=device)
+        t = torch.tensor([v], dtype=torch.int64, device="cpu" if self.host_staging else device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return int(t.item())
 
@@ -106,6 +136,48 @@ def pdgstrf3d(backend, comm, z, npdep, thresh):
     big = backend.n + 1
     g = comm.allreduce_min_int(info if info else big, backend.device)
     return 0 if g == big else g
+
+
+def pdgstrf3d_coop(backend, comm, z, npdep, thresh):
+    """Numeric factorisation over the Z levels with COOPERATIVE ancestor forests: the 2^ilvl layers that share the
+    forest of level ilvl factor it together instead of leaving all but one idle (what pdgstrf3d.c:333-385 does on a
+    1 x 1 x Pz grid).  Storage of the forest is replicated in the group; block column jb is kept current by group
+    member jb % G.  Per Z level:
+      1. sum all-reduce over the group of the forests of levels >= ilvl (replaces the pairwise dreduceAllAncestors3d:
+         every member's copy holds the partial Schur updates it applied, A's entries sit on the group's first layer);
+         members other than the first then zero their copies of the HIGHER forests, so that the next level's sum
+         counts every contribution exactly once;
+      2. per DAG level of the forest: owners factor diagonal blocks + L panels -> all-reduce of the packed panels
+         (the panel broadcast) -> everyone: U-panel TRSM + Schur update of the destinations it owns;
+      3. the U blocks are completed everywhere by masking the non-owned ones and a final sum all-reduce.
+    Returns info (min over layers, 0 = none).  The solve (pdgstrs3d below) is unchanged: the first layer of each group
+    holds the complete factors of its forest."""
+    maxlvl = max_level(npdep)
+    backend.factor_level(0, thresh)
+    for ilvl in range(1, maxlvl):
+        G = 1 << ilvl
+        z0 = z - z % G
+        g = z - z0
+        grp = comm.group(ilvl, z0)
+        for sl in backend.value_slices(ilvl):
+            comm.allreduce_sum(sl, grp)
+        if g != 0:
+            for sl in backend.value_slices(ilvl + 1):
+                sl.zero_()
+        nlev, max_stage = backend.coop_info(ilvl)
+        stage = backend.stage_buffer(max_stage)
+        for l in range(nlev):
+            sz = backend.coop_panel(ilvl, l, G, g, thresh, stage)
+            comm.allreduce_sum(stage[:sz], grp)
+            backend.coop_update(ilvl, l, G, g, stage)
+        backend.coop_mask_u(ilvl, G, g)
+        for sl in backend.u_slices(ilvl):
+            comm.allreduce_sum(sl, grp)
+    _sync(backend)
+    info, _ = backend.info()
+    big = backend.n + 1
+    gmin = comm.allreduce_min_int(info if info else big, backend.device)
+    return 0 if gmin == big else gmin
 
 
 def init_rhs(backend, z, npdep, xp):
@@ -237,6 +309,43 @@ class GpuLayer:
 
     def factor_level(self, ilvl, thresh):
         _lib.check(self.L.sluamd_pdgstrf3d_level(self._h, ilvl, float(thresh)), "sluamd_pdgstrf3d_level")
+
+    # ---- cooperative mode (grid3d.pdgstrf3d_coop): everything queues on torch's current stream ----
+    def coop_info(self, ilvl):
+        import torch
+        self.L.sluamd_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        nl = C.c_int32(); mx = C.c_int64()
+        _lib.check(self.L.sluamd_coop_info(self._h, ilvl, C.byref(nl), C.byref(mx)), "sluamd_coop_info")
+        self._stage_sz = []
+        for l in range(nl.value):
+            nn = C.c_int32(); sz = C.c_int64()
+            self.L.sluamd_coop_level_size(self._h, ilvl, l, C.byref(nn), C.byref(sz))
+            self._stage_sz.append(sz.value)
+        return nl.value, mx.value
+
+    def stage_buffer(self, ndoubles):
+        import torch
+        if getattr(self, "_stage", None) is None or self._stage.numel() < ndoubles:
+            self._stage = torch.empty(max(int(ndoubles), 1), dtype=torch.float64, device=self.device)
+        return self._stage
+
+    def coop_panel(self, ilvl, l, G, g, thresh, stage):
+        _lib.check(self.L.sluamd_coop_panel(self._h, ilvl, l, G, g, float(thresh), C.c_void_p(stage.data_ptr())), "sluamd_coop_panel")
+        return self._stage_sz[l]
+
+    def coop_update(self, ilvl, l, G, g, stage):
+        _lib.check(self.L.sluamd_coop_update(self._h, ilvl, l, G, g, C.c_void_p(stage.data_ptr())), "sluamd_coop_update")
+
+    def coop_mask_u(self, ilvl, G, g):
+        _lib.check(self.L.sluamd_coop_mask_u(self._h, ilvl, G, g), "sluamd_coop_mask_u")
+
+    def u_slices(self, ilvl):
+        out = []
+        for a, b in runs(self._nodes[ilvl]):
+            lo, hi = self.nnzL + int(self.uval_off[a]), self.nnzL + int(self.uval_off[b])
+            if hi > lo:
+                out.append(self.arena[lo:hi])
+        return out
 
     def solve_level(self, ilvl, direction, x):
         assert x.is_contiguous() and x.dtype.itemsize == 8

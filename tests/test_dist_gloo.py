@@ -14,7 +14,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, N, nrhs, out_path):
+def _worker(rank, world, port, N, nrhs, out_path, coop=False):
     sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,8 +26,8 @@ def _worker(rank, world, port, N, nrhs, out_path):
     perm = matgen.nd_perm_grid3d(N, N, N, leaf=16)
     symb = driver.Symbolic(n, rp, ci, perm, relax=8, maxsup=32)
     layer = OracleLayer(symb, v, world, rank)
-    comm = grid3d.DistComm(dist)
-    info = grid3d.pdgstrf3d(layer, comm, rank, world, 0.0)
+    comm = grid3d.DistComm(dist, npdep=world if coop else 1)
+    info = (grid3d.pdgstrf3d_coop if coop else grid3d.pdgstrf3d)(layer, comm, rank, world, 0.0)
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, nrhs)
     xp = np.zeros((nrhs, n)); xp[:, symb.perm_c] = b.T                       # (Pc b)^T
     x = grid3d.init_rhs(layer, rank, world, torch.from_numpy(xp))
@@ -44,6 +44,17 @@ def _worker(rank, world, port, N, nrhs, out_path):
 def test_z_sharded_factor_and_solve_gloo(world, N, nrhs, tmp_path):
     out = str(tmp_path / "r0.npz")
     mp.spawn(_worker, args=(world, _free_port(), N, nrhs, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert int(r["info"]) == 0
+    assert float(r["res"]) < 1e-12
+    assert np.abs(r["sol"] - r["xt"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("world,N,nrhs", [(2, 8, 1), (4, 10, 2)])
+def test_z_sharded_cooperative_ancestors_gloo(world, N, nrhs, tmp_path):
+    """Same system, ancestor forests factored cooperatively by the layers that share them (grid3d.pdgstrf3d_coop)."""
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, nrhs, out, True), nprocs=world, join=True)
     r = np.load(out)
     assert int(r["info"]) == 0
     assert float(r["res"]) < 1e-12

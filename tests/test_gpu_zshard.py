@@ -15,6 +15,7 @@ class ThreadComm:
         self.slots = [None] * world
         self.lock = threading.Lock()
         self.tls = threading.local()
+        self.gbar = {}
 
     def bind(self, z):
         self.tls.z = z
@@ -25,12 +26,28 @@ class ThreadComm:
     def recv(self, t, src):
         t.copy_(self.q[(src, self.tls.z)].get(timeout=120))
 
-    def allreduce_sum(self, t):
+    def group(self, ilvl, z0):
+        G = 1 << ilvl
+        with self.lock:
+            if (z0, G) not in self.gbar:
+                self.gbar[(z0, G)] = threading.Barrier(G)
+        return (z0, G)
+
+    def allreduce_sum(self, t, group=None):
+        import torch
+        z0, G = group if group is not None else (0, len(self.slots))
+        bar = self.gbar[(z0, G)] if group is not None else self.bar
+        torch.cuda.synchronize()
         self.slots[self.tls.z] = t.clone()
-        self.bar.wait()
-        tot = sum(self.slots[1:], self.slots[0].clone())
-        self.bar.wait()
+        torch.cuda.synchronize()
+        bar.wait()
+        tot = self.slots[z0].clone()
+        for zz in range(z0 + 1, z0 + G):
+            tot += self.slots[zz]
+        torch.cuda.synchronize()
+        bar.wait()
         t.copy_(tot)
+        torch.cuda.synchronize()
 
     def allreduce_min_int(self, v, device):
         self.slots[self.tls.z] = v
@@ -40,8 +57,9 @@ class ThreadComm:
         return m
 
 
-@pytest.mark.parametrize("npdep,N,nrhs", [(2, 12, 1), (4, 14, 2)])
-def test_z_sharded_on_one_gpu(npdep, N, nrhs):
+@pytest.mark.parametrize("npdep,N,nrhs,coop", [(2, 12, 1, False), (4, 14, 2, False), (2, 12, 1, True), (4, 14, 2, True),
+                                                 (8, 16, 1, True)])
+def test_z_sharded_on_one_gpu(npdep, N, nrhs, coop):
     import torch
     from superlu_dist_amd import driver, grid3d, matgen
     n, rp, ci, v = matgen.poisson3d(N)
@@ -58,17 +76,18 @@ def test_z_sharded_on_one_gpu(npdep, N, nrhs):
         try:
             comm.bind(z)
             layer = grid3d.GpuLayer(symb, v, npdep, z)
-            info = grid3d.pdgstrf3d(layer, comm, z, npdep, 0.0)
+            info = (grid3d.pdgstrf3d_coop if coop else grid3d.pdgstrf3d)(layer, comm, z, npdep, 0.0)
             x = grid3d.init_rhs(layer, z, npdep, torch.from_numpy(xp).to(layer.device))
             grid3d.pdgstrs3d(layer, comm, z, npdep, x)
             results[z] = (info, x.cpu().numpy(), layer.stats()["nnz_L"])
             layer.destroy()
         except Exception as e:                      # surface worker failures in the main thread
             errors.append(e)
-            try:
-                comm.bar.abort()
-            except Exception:
-                pass
+            for bar in [comm.bar] + list(comm.gbar.values()):
+                try:
+                    bar.abort()
+                except Exception:
+                    pass
 
     ths = [threading.Thread(target=run, args=(z,)) for z in range(npdep)]
     [t.start() for t in ths]; [t.join() for t in ths]

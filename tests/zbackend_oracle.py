@@ -45,6 +45,57 @@ class OracleLayer:
         if info and not self._info:
             self._info = info
 
+    # ---- cooperative mode: one supernode per "DAG level" (sequential order is a valid schedule) ----
+    def coop_info(self, ilvl):
+        nodes = self._nodes[ilvl]
+        mx = max([int(self.store.Lnzval_off[k + 1] - self.store.Lnzval_off[k]) for k in nodes], default=0)
+        return len(nodes), mx
+
+    def stage_buffer(self, ndoubles):
+        return torch.zeros(max(int(ndoubles), 1), dtype=torch.float64)
+
+    def coop_panel(self, ilvl, l, G, g, thresh, stage):
+        k = int(self._nodes[ilvl][l])
+        info, _ = orc.dfactor_coop(self.store, [k], 1, G, g, False, thresh)
+        if info and not self._info:
+            self._info = info
+        a, b = int(self.store.Lnzval_off[k]), int(self.store.Lnzval_off[k + 1])
+        if k % G == g:
+            stage[:b - a] = self._tl[a:b]
+        else:
+            stage[:b - a] = 0.0
+        return b - a
+
+    def coop_update(self, ilvl, l, G, g, stage):
+        k = int(self._nodes[ilvl][l])
+        a, b = int(self.store.Lnzval_off[k]), int(self.store.Lnzval_off[k + 1])
+        if k % G != g:
+            self._tl[a:b] = stage[:b - a]
+        orc.dfactor_coop(self.store, [k], 2, G, g)
+
+    def _u_block_ranges(self, k):
+        st = self.store
+        ui = st.Ufstnz[st.Ufstnz_off[k]:st.Ufstnz_off[k + 1]]
+        out = []
+        if len(ui) == 0:
+            return out
+        klst = int(self.xsup[k + 1]); p = 3; r = int(st.Unzval_off[k])
+        for _ in range(int(ui[0])):
+            jb = int(ui[p]); nsj = int(self.xsup[jb + 1] - self.xsup[jb])
+            nnz = int((klst - ui[p + 2:p + 2 + nsj]).sum())
+            out.append((jb, r, r + nnz)); r += nnz; p += 2 + nsj
+        return out
+
+    def coop_mask_u(self, ilvl, G, g):
+        for k in self._nodes[ilvl]:
+            for jb, a, b in self._u_block_ranges(int(k)):
+                if jb % G != g:
+                    self._tu[a:b] = 0.0
+
+    def u_slices(self, ilvl):
+        out = [self._tu[int(self.store.Unzval_off[a]):int(self.store.Unzval_off[b])] for a, b in grid3d.runs(self._nodes[ilvl])]
+        return [s for s in out if s.numel()]
+
     def solve_level(self, ilvl, direction, x):
         xf = x.numpy().T                            # (n, nrhs) Fortran-order view of the (nrhs, n) tensor
         assert xf.flags.f_contiguous
