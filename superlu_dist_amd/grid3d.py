@@ -314,6 +314,10 @@ class GpuLayer:
     def coop_info(self, ilvl):
         import torch
         self.L.sluamd_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        cache = self.__dict__.setdefault("_coop_cache", {})
+        if ilvl in cache:
+            self._stage_sz = cache[ilvl][2]
+            return cache[ilvl][0], cache[ilvl][1]
         nl = C.c_int32(); mx = C.c_int64()
         _lib.check(self.L.sluamd_coop_info(self._h, ilvl, C.byref(nl), C.byref(mx)), "sluamd_coop_info")
         self._stage_sz = []
@@ -321,6 +325,7 @@ class GpuLayer:
             nn = C.c_int32(); sz = C.c_int64()
             self.L.sluamd_coop_level_size(self._h, ilvl, l, C.byref(nn), C.byref(sz))
             self._stage_sz.append(sz.value)
+        cache[ilvl] = (nl.value, mx.value, self._stage_sz)
         return nl.value, mx.value
 
     def stage_buffer(self, ndoubles):
