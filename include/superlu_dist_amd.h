@@ -218,6 +218,10 @@ int sluamd_mfma_selftest(const double *A16x4, const double *B4x16, double *D16x1
 int sluamd_set_stream(sluamd_handle_t h, void *hip_stream);
 int sluamd_coop_info(sluamd_handle_t h, int zlevel, int *dag_levels, int64_t *max_stage_doubles);
 int sluamd_coop_level_size(sluamd_handle_t h, int zlevel, int dag_level, int *nnodes, int64_t *stage_doubles);
+int sluamd_coop_level_nodes(sluamd_handle_t h, int zlevel, int dag_level, int *nodes_out);
+/* d_stage == NULL in the next two calls: no pack / unpack; the caller broadcasts the owner's panel from the ranges below */
+int sluamd_coop_panel_ptrs(sluamd_handle_t h, int k, double **d_lpanel, int64_t *lpanel_doubles, double **d_dinv,
+                           int64_t *dinv_doubles);
 int sluamd_coop_panel(sluamd_handle_t h, int zlevel, int dag_level, int G, int g, double thresh, double *d_stage);
 int sluamd_coop_update(sluamd_handle_t h, int zlevel, int dag_level, int G, int g, const double *d_stage);
 int sluamd_coop_mask_u(sluamd_handle_t h, int zlevel, int G, int g);

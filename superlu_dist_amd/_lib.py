@@ -101,6 +101,8 @@ def load():
     L.sluamd_coop_level_size.argtypes = [C.c_void_p, C.c_int, C.c_int, P_int, C.POINTER(C.c_int64)]
     L.sluamd_coop_panel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
     L.sluamd_coop_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sluamd_coop_level_nodes.argtypes = [C.c_void_p, C.c_int, C.c_int, P_int]
+    L.sluamd_coop_panel_ptrs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.sluamd_coop_mask_u.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     _lib = L
     return L

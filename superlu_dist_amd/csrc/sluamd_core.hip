@@ -131,6 +131,7 @@ struct Handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // host tables kept for stats
     std::vector<int> h_nsupr, h_ldu, h_ncolu;
+    std::vector<int64_t> h_sn_dinv;
     int max_nsupc = 0;
 };
 
@@ -1337,6 +1338,7 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
 #define UP(field, vec, type) { type *p_; if (upload(K, vec, &p_)) return SLUAMD_EHIP; T.field = p_; }
     UP(sn_lval, t.sn_lval, int64_t) UP(sn_uval, t.sn_uval, int64_t) UP(sn_lidx, t.sn_lidx, int64_t) UP(sn_uidx, t.sn_uidx, int64_t)
     UP(sn_dinv, t.sn_dinv, int64_t)
+    H->h_sn_dinv = t.sn_dinv;
     {
         double *dv;
         if (hipMalloc((void **) &dv, sizeof(double) * std::max<int64_t>(t.dinv_total, 1)) != hipSuccess) { set_error("hipMalloc(dinv) failed"); return SLUAMD_ENOMEM; }
@@ -1782,6 +1784,27 @@ int sluamd_coop_level_size(sluamd_handle_t h, int zlevel, int l, int *nnodes, in
     return 0;
 }
 
+int sluamd_coop_level_nodes(sluamd_handle_t h, int zlevel, int l, int *nodes_out)
+{
+    if (!h || !nodes_out || zlevel < 0 || zlevel >= (int) h->H.sched.size() || l < 0 || l >= h->H.sched[zlevel].nlevels) { set_error("bad level"); return SLUAMD_EINVAL; }
+    const LevelSched &S = h->H.sched[zlevel];
+    std::copy(S.nodes.begin() + S.lvl_off[l], S.nodes.begin() + S.lvl_off[l + 1], nodes_out);
+    return 0;
+}
+
+// device ranges holding supernode k's factored L panel (diagonal block first) and its inverted diagonal sub-blocks
+int sluamd_coop_panel_ptrs(sluamd_handle_t h, int k, double **d_lpanel, int64_t *lpanel_doubles, double **d_dinv, int64_t *dinv_doubles)
+{
+    if (!h || k < 0 || k >= h->H.hs.nsupers || !h->H.hs.present[k]) { set_error("bad supernode"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    const int ns = H->hs.xsup[k + 1] - H->hs.xsup[k];
+    if (d_lpanel) *d_lpanel = H->d_val + H->hs.lval_off[k];
+    if (lpanel_doubles) *lpanel_doubles = H->hs.lval_off[k + 1] - H->hs.lval_off[k];
+    if (d_dinv) *d_dinv = H->T.dinv + H->h_sn_dinv[k];
+    if (dinv_doubles) *dinv_doubles = (int64_t) 2 * ((ns + 31) / 32) * 32 * 32;
+    return 0;
+}
+
 static int coop_check(sluamd_handle_t h, int zlevel, int l, int G, int g)
 {
     if (!h || zlevel < 0 || zlevel >= (int) h->H.sched.size() || G < 1 || g < 0 || g >= G) { set_error("bad cooperative-level arguments"); return SLUAMD_EINVAL; }
@@ -1794,7 +1817,7 @@ int sluamd_coop_panel(sluamd_handle_t h, int zlevel, int l, int G, int g, double
 {
     int rc = coop_check(h, zlevel, l, G, g);
     if (rc) return rc;
-    if (l < 0 || !d_stage) { set_error("bad cooperative-level arguments"); return SLUAMD_EINVAL; }
+    if (l < 0) { set_error("bad cooperative-level arguments"); return SLUAMD_EINVAL; }
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
     LevelSched &S = H->sched[zlevel];
@@ -1817,7 +1840,8 @@ int sluamd_coop_panel(sluamd_handle_t h, int zlevel, int l, int G, int g, double
             else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nl), dim3(256), lds_tr, cs, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl);
         }
     }
-    if (G > 1) hipLaunchKernelGGL(k_coop_pack, dim3(S.pk_prefix[po + nn]), dim3(256), 0, cs, T, nodes, S.d_pk_prefix + po, S.d_pk_off + po, nn, d_stage, 0);
+    // d_stage == NULL: the caller broadcasts the owners' panels straight out of the arena (sluamd_coop_panel_ptrs)
+    if (G > 1 && d_stage) hipLaunchKernelGGL(k_coop_pack, dim3(S.pk_prefix[po + nn]), dim3(256), 0, cs, T, nodes, S.d_pk_prefix + po, S.d_pk_off + po, nn, d_stage, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1834,8 +1858,7 @@ int sluamd_coop_update(sluamd_handle_t h, int zlevel, int l, int G, int g, const
     hipStream_t cs = H->has_user_stream ? H->user_stream : H->stream;
     const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
     const int *nodes = S.d_nodes + n0;
-    if (G > 1) {
-        if (!d_stage) { set_error("null staging buffer"); return SLUAMD_EINVAL; }
+    if (G > 1 && d_stage) {
         hipLaunchKernelGGL(k_coop_pack, dim3(S.pk_prefix[po + nn]), dim3(256), 0, cs, T, nodes, S.d_pk_prefix + po, S.d_pk_off + po, nn, const_cast<double *>(d_stage), 1);
     }
     const int mx = S.max_nsupc[l];

@@ -9,7 +9,7 @@ Mirrors the Z dimension of the reference's 3D algorithm:
     dfsolveReduceLsum3d (:1646) / dp2pSolvedX3d (:1596) style exchanges of the ancestor parts of x.
 
 The numeric work is done by a *backend* object (duck-typed):
-    factor_level(ilvl, thresh) ; value_slices(alvl_from) -> [1-D tensors viewing the resident factors] ;
+    factor_level(ilvl, thresh) ; value_slices(alvl_from[, alvl_to]) -> [1-D tensors viewing the resident factors] ;
     solve_level(ilvl, direction, x) ; info() -> (info, tiny) ; n ; tree_rows(ilvl) -> [(row0, row1), ...]
 `GpuLayer` below is the product backend (libsluamd.so).  tests/ supplies a CPU-oracle backend for the gloo tests.
 """
@@ -97,6 +97,24 @@ class DistComm:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=pg)
 
+    def reduce_sum(self, t, dst, group=None):
+        pg = group[1] if group is not None else None
+        if self.host_staging:
+            tmp = t.cpu()
+            self.dist.reduce(tmp, self._r(dst), op=self.dist.ReduceOp.SUM, group=pg)
+            t.copy_(tmp)
+        else:
+            self.dist.reduce(t, self._r(dst), op=self.dist.ReduceOp.SUM, group=pg)
+
+    def broadcast(self, t, src, group=None):
+        pg = group[1] if group is not None else None
+        if self.host_staging:
+            tmp = t.cpu()
+            self.dist.broadcast(tmp, self._r(src), group=pg)
+            t.copy_(tmp)
+        else:
+            self.dist.broadcast(t, self._r(src), group=pg)
+
     def allreduce_min_int(self, v, device):
         import torch
         t = torch.tensor([v], dtype=torch.int64, device="cpu" if self.host_staging else device)
@@ -143,13 +161,14 @@ def pdgstrf3d_coop(backend, comm, z, npdep, thresh):
     forest of level ilvl factor it together instead of leaving all but one idle (what pdgstrf3d.c:333-385 does on a
     1 x 1 x Pz grid).  Storage of the forest is replicated in the group; block column jb is kept current by group
     member jb % G.  Per Z level:
-      1. sum all-reduce over the group of the forests of levels >= ilvl (replaces the pairwise dreduceAllAncestors3d:
-         every member's copy holds the partial Schur updates it applied, A's entries sit on the group's first layer);
-         members other than the first then zero their copies of the HIGHER forests, so that the next level's sum
-         counts every contribution exactly once;
-      2. per DAG level of the forest: owners factor diagonal blocks + L panels -> all-reduce of the packed panels
-         (the panel broadcast) -> everyone: U-panel TRSM + Schur update of the destinations it owns;
-      3. the U blocks are completed everywhere by masking the non-owned ones and a final sum all-reduce.
+      1. sum all-reduce over the group of THIS level's forest only: every member's copy holds exactly the partial Schur
+         updates that member applied so far (A's entries sit on the group's first layer), so the sum over the group is
+         the assembled forest -- what dreduceAllAncestors3d achieves pairwise -- and the copies of the HIGHER forests
+         are not exchanged at all until their own level, where the (larger) group contains every contributor;
+      2. per DAG level of the forest: owners factor diagonal blocks + L panels -> panel exchange (a broadcast from the
+         owner when the level holds one supernode, else one sum all-reduce of the packed panels; the reference's
+         dIBcastRecvLPanel) -> everyone: U-panel TRSM + Schur update of the destinations it owns;
+      3. the U blocks are completed on the group's first layer: mask the non-owned ones, sum-reduce to that layer.
     Returns info (min over layers, 0 = none).  The solve (pdgstrs3d below) is unchanged: the first layer of each group
     holds the complete factors of its forest."""
     maxlvl = max_level(npdep)
@@ -159,20 +178,24 @@ def pdgstrf3d_coop(backend, comm, z, npdep, thresh):
         z0 = z - z % G
         g = z - z0
         grp = comm.group(ilvl, z0)
-        for sl in backend.value_slices(ilvl):
+        for sl in backend.value_slices(ilvl, ilvl + 1):
             comm.allreduce_sum(sl, grp)
-        if g != 0:
-            for sl in backend.value_slices(ilvl + 1):
-                sl.zero_()
         nlev, max_stage = backend.coop_info(ilvl)
         stage = backend.stage_buffer(max_stage)
         for l in range(nlev):
-            sz = backend.coop_panel(ilvl, l, G, g, thresh, stage)
-            comm.allreduce_sum(stage[:sz], grp)
-            backend.coop_update(ilvl, l, G, g, stage)
+            nodes = backend.coop_level_nodes(ilvl, l)
+            if len(nodes) == 1:      # the usual case near the top of a separator: broadcast straight out of the arena
+                backend.coop_panel(ilvl, l, G, g, thresh, None)
+                for t in backend.panel_tensors(int(nodes[0])):
+                    comm.broadcast(t, z0 + int(nodes[0]) % G, grp)
+                backend.coop_update(ilvl, l, G, g, None)
+            else:                    # many (small) panels with different owners: one packed sum all-reduce
+                sz = backend.coop_panel(ilvl, l, G, g, thresh, stage)
+                comm.allreduce_sum(stage[:sz], grp)
+                backend.coop_update(ilvl, l, G, g, stage)
         backend.coop_mask_u(ilvl, G, g)
         for sl in backend.u_slices(ilvl):
-            comm.allreduce_sum(sl, grp)
+            comm.reduce_sum(sl, z0, grp)              # only the group's first layer solves with this forest
     _sync(backend)
     info, _ = backend.info()
     big = backend.n + 1
@@ -292,9 +315,9 @@ class GpuLayer:
     def tree_rows(self, ilvl):
         return [(int(self.xsup[a]), int(self.xsup[b])) for a, b in runs(self._nodes[ilvl])]
 
-    def value_slices(self, alvl_from):
+    def value_slices(self, alvl_from, alvl_to=None):
         segs = []
-        for al in range(alvl_from, len(self.trees)):
+        for al in range(alvl_from, len(self.trees) if alvl_to is None else alvl_to):
             for a, b in runs(self._nodes[al]):
                 segs.append((int(self.lval_off[a]), int(self.lval_off[b])))
                 segs.append((self.nnzL + int(self.uval_off[a]), self.nnzL + int(self.uval_off[b])))
@@ -328,6 +351,27 @@ class GpuLayer:
         cache[ilvl] = (nl.value, mx.value, self._stage_sz)
         return nl.value, mx.value
 
+    def coop_level_nodes(self, ilvl, l):
+        key = (ilvl, l)
+        c = self.__dict__.setdefault("_lvl_nodes", {})
+        if key not in c:
+            nn = C.c_int32(); sz = C.c_int64()
+            self.L.sluamd_coop_level_size(self._h, ilvl, l, C.byref(nn), C.byref(sz))
+            buf = np.zeros(nn.value, dtype=np.int32)
+            _lib.check(self.L.sluamd_coop_level_nodes(self._h, ilvl, l, buf.ctypes.data_as(_lib.P_int)), "sluamd_coop_level_nodes")
+            c[key] = buf
+        return c[key]
+
+    def panel_tensors(self, k):
+        import torch
+        c = self.__dict__.setdefault("_panel_t", {})
+        if k not in c:
+            pl = C.c_void_p(); nl = C.c_int64(); pd = C.c_void_p(); nd = C.c_int64()
+            _lib.check(self.L.sluamd_coop_panel_ptrs(self._h, k, C.byref(pl), C.byref(nl), C.byref(pd), C.byref(nd)), "sluamd_coop_panel_ptrs")
+            c[k] = [torch.as_tensor(_DevArray(pl.value, nl.value), device=self.device),
+                    torch.as_tensor(_DevArray(pd.value, nd.value), device=self.device)]
+        return c[k]
+
     def stage_buffer(self, ndoubles):
         import torch
         if getattr(self, "_stage", None) is None or self._stage.numel() < ndoubles:
@@ -335,11 +379,13 @@ class GpuLayer:
         return self._stage
 
     def coop_panel(self, ilvl, l, G, g, thresh, stage):
-        _lib.check(self.L.sluamd_coop_panel(self._h, ilvl, l, G, g, float(thresh), C.c_void_p(stage.data_ptr())), "sluamd_coop_panel")
+        sp = C.c_void_p(stage.data_ptr()) if stage is not None else None
+        _lib.check(self.L.sluamd_coop_panel(self._h, ilvl, l, G, g, float(thresh), sp), "sluamd_coop_panel")
         return self._stage_sz[l]
 
     def coop_update(self, ilvl, l, G, g, stage):
-        _lib.check(self.L.sluamd_coop_update(self._h, ilvl, l, G, g, C.c_void_p(stage.data_ptr())), "sluamd_coop_update")
+        sp = C.c_void_p(stage.data_ptr()) if stage is not None else None
+        _lib.check(self.L.sluamd_coop_update(self._h, ilvl, l, G, g, sp), "sluamd_coop_update")
 
     def coop_mask_u(self, ilvl, G, g):
         _lib.check(self.L.sluamd_coop_mask_u(self._h, ilvl, G, g), "sluamd_coop_mask_u")

@@ -49,6 +49,22 @@ class ThreadComm:
         t.copy_(tot)
         torch.cuda.synchronize()
 
+    def reduce_sum(self, t, dst, group=None):
+        self.allreduce_sum(t, group)                 # emulation: a reduce is an all-reduce whose other copies are unused
+
+    def broadcast(self, t, src, group=None):
+        import torch
+        z0, G = group if group is not None else (0, len(self.slots))
+        bar = self.gbar[(z0, G)] if group is not None else self.bar
+        torch.cuda.synchronize()
+        if self.tls.z == src:
+            self.slots[src] = t
+        bar.wait()
+        if self.tls.z != src:
+            t.copy_(self.slots[src])
+        torch.cuda.synchronize()
+        bar.wait()
+
     def allreduce_min_int(self, v, device):
         self.slots[self.tls.z] = v
         self.bar.wait()

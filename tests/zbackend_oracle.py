@@ -32,9 +32,9 @@ class OracleLayer:
     def tree_rows(self, ilvl):
         return [(int(self.xsup[a]), int(self.xsup[b])) for a, b in grid3d.runs(self._nodes[ilvl])]
 
-    def value_slices(self, alvl_from):
+    def value_slices(self, alvl_from, alvl_to=None):
         out = []
-        for al in range(alvl_from, len(self.trees)):
+        for al in range(alvl_from, len(self.trees) if alvl_to is None else alvl_to):
             for a, b in grid3d.runs(self._nodes[al]):
                 out.append(self._tl[int(self.store.Lnzval_off[a]):int(self.store.Lnzval_off[b])])
                 out.append(self._tu[int(self.store.Unzval_off[a]):int(self.store.Unzval_off[b])])
@@ -51,6 +51,12 @@ class OracleLayer:
         mx = max([int(self.store.Lnzval_off[k + 1] - self.store.Lnzval_off[k]) for k in nodes], default=0)
         return len(nodes), mx
 
+    def coop_level_nodes(self, ilvl, l):
+        return self._nodes[ilvl][l:l + 1]
+
+    def panel_tensors(self, k):
+        return [self._tl[int(self.store.Lnzval_off[k]):int(self.store.Lnzval_off[k + 1])]]
+
     def stage_buffer(self, ndoubles):
         return torch.zeros(max(int(ndoubles), 1), dtype=torch.float64)
 
@@ -60,16 +66,17 @@ class OracleLayer:
         if info and not self._info:
             self._info = info
         a, b = int(self.store.Lnzval_off[k]), int(self.store.Lnzval_off[k + 1])
-        if k % G == g:
-            stage[:b - a] = self._tl[a:b]
-        else:
-            stage[:b - a] = 0.0
+        if stage is not None:
+            if k % G == g:
+                stage[:b - a] = self._tl[a:b]
+            else:
+                stage[:b - a] = 0.0
         return b - a
 
     def coop_update(self, ilvl, l, G, g, stage):
         k = int(self._nodes[ilvl][l])
         a, b = int(self.store.Lnzval_off[k]), int(self.store.Lnzval_off[k + 1])
-        if k % G != g:
+        if stage is not None and k % G != g:
             self._tl[a:b] = stage[:b - a]
         orc.dfactor_coop(self.store, [k], 2, G, g)
 
