@@ -208,6 +208,18 @@ int sluamd_local_offsets(sluamd_handle_t h, int64_t *lval_off, int64_t *uval_off
 int sluamd_pdgstrs3d_level(sluamd_handle_t h, int zlevel, int dir, double *d_x, int64_t ldx, int32_t nrhs);
 int sluamd_mfma_selftest(const double *A16x4, const double *B4x16, double *D16x16);
 
+/* ---- iterative refinement: pdgsrfs3d (SRC/double/pdgsrfs.c:345-510) with its SpMV pdgsmv (SRC/double/pdgsmv.c) on the
+ * device, SURVEY 8(f)-2.  The ORIGINAL matrix (CSR, 0-based) and perm_c are attached once; the factors in the handle are
+ * those of Pc A Pc^T (Equil=NO, NOROWPERM -- the boundary's convention).  B, X: original ordering, column-major; X holds
+ * the initial solution and is refined in place; berr[nrhs] = componentwise backward errors; *steps = refinement steps of
+ * the last right-hand side (stat->RefineSteps).  Stopping rule as the reference: berr > eps, berr*2 <= previous, < 20. */
+int sluamd_dAttachMatrix(sluamd_handle_t h, sluamd_int_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                         const double *nzval, const sluamd_int_t *perm_c);
+int sluamd_pdgsrfs3d(sluamd_handle_t h, const double *B, int64_t ldb, double *X, int64_t ldx, int32_t nrhs, double *berr,
+                     int32_t *steps);
+int sluamd_pdgsrfs3d_dev(sluamd_handle_t h, const double *d_B, int64_t ldb, double *d_X, int64_t ldx, int32_t nrhs,
+                         double *berr, int32_t *steps);
+
 /* ---- cooperative factorisation of a shared ancestor forest (1 x 1 x Pz grids) ----
  * The reference leaves the 2^zlevel layers that share an ancestor forest idle but one (pdgstrf3d.c:333-385 with
  * myZeroTrIdxs); on xGMI-connected GPUs the idle layers are put to work instead: storage of the forest stays

@@ -376,6 +376,7 @@ int main(int argc, char *argv[])
         free(tmp);
         put("berr", 2, nrhs, berr);
         put_i("final_info", info);
+        put_i("RefineSteps", stat.RefineSteps);
         put_d("utime_FACT", stat.utime[FACT]); put_d("utime_SOLVE", stat.utime[SOLVE]);
         put_d("ops_FACT", stat.ops[FACT]); put_d("ops_SOLVE", stat.ops[SOLVE]);
         if (ScalePermstruct.DiagScale == ROW || ScalePermstruct.DiagScale == BOTH) put("R", 2, m, ScalePermstruct.R);

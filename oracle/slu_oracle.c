@@ -40,6 +40,7 @@
 #define DIVS(a, b) ((a) / (b))
 #define IS_TINY(x, th) (fabs(x) < (th))                       /* pdgstrf2.c:544-560 */
 #define TINY_REPLACEMENT(x, th) (((x) < 0) ? -(th) : (th))
+#define ABS1(x) fabs(x)
 #include "slu_oracle_body.inc"
 #undef T
 #undef FN
@@ -48,6 +49,7 @@
 #undef DIVS
 #undef IS_TINY
 #undef TINY_REPLACEMENT
+#undef ABS1
 
 /* ---- complex16: SRC/complex16 (doublecomplex {r,i} == C99 double _Complex in memory) ---- */
 #include <complex.h>
@@ -73,6 +75,7 @@ static zc_t z_div(zc_t a, zc_t b)
 /* pzgstrf2.c Local_Zgstrf2: |re|+|im| < thresh and both parts non-zero; replacement keeps the sign of the real part */
 #define IS_TINY(x, th) ((fabs(creal(x)) + fabs(cimag(x))) < (th) && creal(x) != 0.0 && cimag(x) != 0.0)
 #define TINY_REPLACEMENT(x, th) ((creal(x) < 0) ? -(th) : (th))
+#define ABS1(x) (fabs(creal(x)) + fabs(cimag(x)))   /* slud_z_abs1, dcomplex_dist.c */
 #include "slu_oracle_body.inc"
 
 int slu_oracle_num_threads(void)

@@ -45,6 +45,9 @@ EXPORTS = [
     "sluamd_get_stats", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_symb_info",
     "sluamd_symb_view", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
     "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
+    "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",
+    "sluamd_set_stream", "sluamd_coop_info", "sluamd_coop_level_size", "sluamd_coop_level_nodes", "sluamd_coop_panel_ptrs",
+    "sluamd_coop_panel", "sluamd_coop_update", "sluamd_coop_mask_u",
 ]
 
 _lib = None
@@ -96,6 +99,9 @@ def load():
     L.sluamd_local_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sluamd_pdgstrs3d_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_set_profile.argtypes = [C.c_void_p, C.c_int]
+    L.sluamd_dAttachMatrix.argtypes = [C.c_void_p, C.c_int32, P_int, P_int, P_dbl, P_int]
+    L.sluamd_pdgsrfs3d.argtypes = [C.c_void_p, P_dbl, C.c_int64, P_dbl, C.c_int64, C.c_int32, P_dbl, P_int]
+    L.sluamd_pdgsrfs3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, P_dbl, P_int]
     L.sluamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.sluamd_coop_info.argtypes = [C.c_void_p, C.c_int, P_int, C.POINTER(C.c_int64)]
     L.sluamd_coop_level_size.argtypes = [C.c_void_p, C.c_int, C.c_int, P_int, C.POINTER(C.c_int64)]

@@ -122,6 +122,9 @@ struct Handle {
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
     double *d_x = nullptr; int64_t x_cap = 0;
     int64_t *d_apos = nullptr; double *d_aval = nullptr; int64_t a_nnz = 0;  // A's entries for device-side (re)distribution
+    // iterative refinement (sluamd_dAttachMatrix): the ORIGINAL matrix in CSR + perm_c, and work vectors
+    int *d_rfs_rp = nullptr, *d_rfs_ci = nullptr, *d_rfs_pc = nullptr; double *d_rfs_av = nullptr;
+    double *d_rfs_work = nullptr; unsigned long long *d_rfs_s = nullptr; int64_t rfs_nnz = 0;
     bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
     bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
     bool profile = false;                                   // per-kernel-family HIP-event timing
@@ -605,6 +608,51 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
         const int ni = find_node(uprefix, nn, id);
         panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm);
     }
+}
+
+// ---- iterative refinement (pdgsrfs3d, SRC/double/pdgsrfs.c:345-510) --------------------------------
+// One pass over the CSR matrix does both of the reference's pdgsmv calls (abs = 0 and abs = 1, pdgsmv.c): residual
+// r = b - A x (stored permuted, r_perm[perm_c[i]] = r_i: the right-hand side of the triangular solves on Pc A Pc^T),
+// temp = |A||x| + |b|, and the componentwise backward error max_i |r_i| / temp_i with the SAFE1/SAFE2 guards
+// (:463-469), reduced per workgroup and combined with an integer atomicMax (non-negative doubles order like
+// their bit patterns).  HBM-bound: 12 B per nonzero + 32 B per row.
+__global__ __launch_bounds__(256) void k_rfs_residual(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                      const double *__restrict__ av, const double *__restrict__ x,
+                                                      const double *__restrict__ b, const int *__restrict__ pc,
+                                                      double *__restrict__ r_perm, unsigned long long *__restrict__ s_out,
+                                                      double safe1, double safe2)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double q = 0.0;
+    if (i < n) {
+        double ax = 0.0, t = 0.0;
+        for (int e = rp[i]; e < rp[i + 1]; ++e) {
+            const double a = av[e], xv = x[ci[e]];
+            ax += a * xv;
+            t += fabs(a) * fabs(xv);
+        }
+        const double r = b[i] - ax;
+        t += fabs(b[i]);
+        r_perm[pc[i]] = r;
+        if (t > safe2) q = fabs(r) / t;
+        else if (t != 0.0) q = (safe1 + fabs(r)) / t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q = fmax(q, __shfl_xor(q, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(s_out, (unsigned long long) __double_as_longlong(q));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rfs_update(int n, const int *__restrict__ pc, const double *__restrict__ dx_perm,
+                                                    double *__restrict__ x)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] += dx_perm[pc[i]];
 }
 
 // ---- cooperative (owner-computes) mode helpers ----------------------------------------------------
@@ -2063,6 +2111,96 @@ int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nr
     return 0;
 }
 
+// ---- iterative refinement: pdgsrfs3d (SRC/double/pdgsrfs.c:345-510), SURVEY 8(f)-2 ----
+int sluamd_dAttachMatrix(sluamd_handle_t h, sluamd_int_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                         const double *nzval, const sluamd_int_t *perm_c)
+{
+    if (!h || !rowptr || !colind || !nzval || !perm_c || n != h->H.hs.n) { set_error("bad matrix arguments"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("iterative refinement is double precision only in this round"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t nnz = rowptr[n];
+    for (void *p : {(void *) H->d_rfs_rp, (void *) H->d_rfs_ci, (void *) H->d_rfs_pc, (void *) H->d_rfs_av, (void *) H->d_rfs_work, (void *) H->d_rfs_s})
+        if (p) hipFree(p);
+    HIPCHK(hipMalloc((void **) &H->d_rfs_rp, sizeof(int) * (n + 1)));
+    HIPCHK(hipMalloc((void **) &H->d_rfs_ci, sizeof(int) * std::max<int64_t>(nnz, 1)));
+    HIPCHK(hipMalloc((void **) &H->d_rfs_av, sizeof(double) * std::max<int64_t>(nnz, 1)));
+    HIPCHK(hipMalloc((void **) &H->d_rfs_pc, sizeof(int) * n));
+    HIPCHK(hipMalloc((void **) &H->d_rfs_work, sizeof(double) * 3 * (size_t) n));   // r_perm | b | x
+    HIPCHK(hipMalloc((void **) &H->d_rfs_s, sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(H->d_rfs_rp, rowptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(H->d_rfs_ci, colind, sizeof(int) * nnz, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(H->d_rfs_av, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(H->d_rfs_pc, perm_c, sizeof(int) * n, hipMemcpyHostToDevice));
+    H->rfs_nnz = nnz;
+    return 0;
+}
+
+// d_B, d_X: device-resident, original ordering, column-major; X holds the initial solution and is refined in place
+int sluamd_pdgsrfs3d_dev(sluamd_handle_t h, const double *d_B, int64_t ldb, double *d_X, int64_t ldx, int32_t nrhs,
+                         double *berr, int32_t *steps)
+{
+    if (!h || !d_B || !d_X || !berr || nrhs < 0 || ldb < h->H.hs.n || ldx < h->H.hs.n) { set_error("bad refinement arguments"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    if (!H->d_rfs_rp) { set_error("no matrix attached: call sluamd_dAttachMatrix first"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(H->device));
+    const int n = H->hs.n;
+    const int ITMAX = 20;                                   // pdgsrfs.c:371
+    const double eps = 0x1p-53, safmin = 2.2250738585072014e-308;
+    const double safe1 = (double) (n + 1) * safmin, safe2 = safe1 / eps;
+    double *r_perm = H->d_rfs_work;
+    hipStream_t s = H->stream;
+    const dim3 grid((n + 255) / 256), blk(256);
+    int count = 0;
+    for (int j = 0; j < nrhs; ++j) {
+        const double *Bc = d_B + (size_t) j * ldb;
+        double *Xc = d_X + (size_t) j * ldx;
+        double lstres = 3.0;
+        count = 0;
+        for (;;) {
+            HIPCHK(hipMemsetAsync(H->d_rfs_s, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k_rfs_residual, grid, blk, 0, s, n, H->d_rfs_rp, H->d_rfs_ci, H->d_rfs_av, Xc, Bc, H->d_rfs_pc, r_perm, H->d_rfs_s, safe1, safe2);
+            double sv = 0.0;
+            HIPCHK(hipMemcpyAsync(&sv, H->d_rfs_s, sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            berr[j] = sv;
+            if (sv > eps && sv * 2 <= lstres && count < ITMAX) {
+                int rc = run_solve(H, r_perm, n, 1);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_rfs_update, grid, blk, 0, s, n, H->d_rfs_pc, r_perm, Xc);
+                lstres = sv;
+                ++count;
+            } else break;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (steps) *steps = count;
+    return 0;
+}
+
+int sluamd_pdgsrfs3d(sluamd_handle_t h, const double *B, int64_t ldb, double *X, int64_t ldx, int32_t nrhs, double *berr,
+                     int32_t *steps)
+{
+    if (!h || !B || !X || !berr || nrhs < 0 || ldb < h->H.hs.n || ldx < h->H.hs.n) { set_error("bad refinement arguments"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) { if (steps) *steps = 0; return 0; }
+    Handle *H = &h->H;
+    if (!H->d_rfs_rp) { set_error("no matrix attached: call sluamd_dAttachMatrix first"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(H->device));
+    const int n = H->hs.n;
+    double *d_b = H->d_rfs_work + n, *d_x = H->d_rfs_work + 2 * (size_t) n;
+    int last = 0;
+    for (int j = 0; j < nrhs; ++j) {   // one column at a time through the two resident work vectors
+        HIPCHK(hipMemcpy(d_b, B + (size_t) j * ldb, sizeof(double) * n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_x, X + (size_t) j * ldx, sizeof(double) * n, hipMemcpyHostToDevice));
+        int rc = sluamd_pdgsrfs3d_dev(h, d_b, n, d_x, n, 1, berr + j, &last);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(X + (size_t) j * ldx, d_x, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    if (steps) *steps = last;
+    return 0;
+}
+
 int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs)
 {
     if (!h || !x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
@@ -2093,6 +2231,8 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_info) hipFree(H->d_info);
     if (H->d_x) hipFree(H->d_x);
     if (H->d_apos) hipFree(H->d_apos);
+    for (void *q : {(void *) H->d_rfs_rp, (void *) H->d_rfs_ci, (void *) H->d_rfs_pc, (void *) H->d_rfs_av, (void *) H->d_rfs_work, (void *) H->d_rfs_s})
+        if (q) hipFree(q);
     if (H->d_aval) hipFree(H->d_aval);
     for (auto &e : H->ev_schur) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : H->ev_panel) { hipEventDestroy(e.first); hipEventDestroy(e.second); }

@@ -228,6 +228,22 @@ class LUHandle:
     def reset_values(self):
         _lib.check(_lib.load().sluamd_dResetValues(self._h), "sluamd_dResetValues")
 
+    def attach_matrix(self, n, rowptr, colind, nzval, perm_c):
+        """Device copy of the ORIGINAL matrix (CSR) + perm_c for pdgsrfs3d."""
+        rp = np.ascontiguousarray(rowptr, dtype=np.int32); ci = np.ascontiguousarray(colind, dtype=np.int32)
+        v = np.ascontiguousarray(nzval, dtype=np.float64); pc = np.ascontiguousarray(perm_c, dtype=np.int32)
+        _lib.check(_lib.load().sluamd_dAttachMatrix(self._h, int(n), _pi(rp), _pi(ci), _pd(v), _pi(pc)), "sluamd_dAttachMatrix")
+
+    def pdgsrfs3d(self, b, x):
+        """Iterative refinement of x (original ordering) for the attached matrix; returns (x, berr[nrhs], steps)."""
+        b = np.asfortranarray(np.array(b, dtype=np.float64)); x = np.asfortranarray(np.array(x, dtype=np.float64))
+        if b.ndim == 1:
+            b = np.asfortranarray(b[:, None]); x = np.asfortranarray(x[:, None])
+        berr = np.zeros(b.shape[1]); steps = C.c_int32(0)
+        _lib.check(_lib.load().sluamd_pdgsrfs3d(self._h, _pd(b), b.shape[0], _pd(x), x.shape[0], b.shape[1], _pd(berr),
+                                                C.byref(steps)), "sluamd_pdgsrfs3d")
+        return x, berr, steps.value
+
     def set_profile(self, on=True):
         _lib.load().sluamd_set_profile(self._h, int(on))
 
@@ -264,10 +280,11 @@ def _forest_view(forests):
 
 
 def pdgssvx3d(n, rowptr, colind, nzval, b, perm_c=None, relax=32, maxsup=256, replace_tiny=False, anorm=None,
-              keep=False):
+              keep=False, refine=False):
     """Solve A x = b through the GPU hot path: symbolic (host) -> device-resident distribute -> pdgstrf3d ->
     pdgstrs3d, with Equil = NO, RowPerm = NOROWPERM, ColPerm = MY_PERMC/NATURAL, IterRefine = NOREFINE
-    (the timing configuration of BASELINE.md section 4).  Returns (x, info, stats[, handle, symb])."""
+    (the timing configuration of BASELINE.md section 4); refine=True adds IterRefine = SLU_DOUBLE (pdgsrfs3d on the device,
+    double precision only) and puts `berr` / `refine_steps` into the stats.  Returns (x, info, stats[, handle, symb])."""
     symb = Symbolic(n, rowptr, colind, perm_c, relax, maxsup)
     h = LUHandle.from_symbolic(symb, nzval, replace_tiny=replace_tiny)
     if anorm is None:
@@ -283,6 +300,10 @@ def pdgssvx3d(n, rowptr, colind, nzval, b, perm_c=None, relax=32, maxsup=256, re
     y = h.pdgstrs3d(xp)
     x = np.asfortranarray(y[symb.perm_c, :])                   # Pc^T y
     st = h.stats()
+    if refine:
+        h.attach_matrix(n, rowptr, colind, nzval, symb.perm_c)
+        x, berr, steps = h.pdgsrfs3d(b, x)
+        st["berr"] = berr; st["refine_steps"] = steps
     if keep:
         return x, info, st, h, symb
     h.destroy(); symb.free()

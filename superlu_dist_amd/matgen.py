@@ -90,7 +90,7 @@ def csr_matvec(n, rowptr, colind, vals, x):
     return np.asfortranarray(out)
 
 
-def random_unsym(n, density=0.02, seed=0):
+def random_unsym(n, density=0.02, seed=0, diag_scale=None):
     rng = np.random.default_rng(seed)
     nnz_off = int(density * n * n)
     r = rng.integers(0, n, nnz_off); c = rng.integers(0, n, nnz_off)
@@ -102,6 +102,8 @@ def random_unsym(n, density=0.02, seed=0):
     rowsum = np.zeros(n); np.add.at(rowsum, r, np.abs(v))
     colsum = np.zeros(n); np.add.at(colsum, c, np.abs(v))
     d = np.maximum(rowsum, colsum) + 1.0
+    if diag_scale is not None:          # NOT diagonally dominant: unpivoted LU loses digits -> exercises iterative refinement
+        d = diag_scale * d
     rows = np.concatenate([r, np.arange(n)]); cols = np.concatenate([c, np.arange(n)])
     vals = np.concatenate([v, d])
     order = np.lexsort((cols, rows))

@@ -39,6 +39,10 @@ CASES = {
     "unsym300": dict(matrix=("unsym", 300, 0.02, 7), grid=(1, 1, 1), flags=[]),
     # tiny-pivot replacement exercised (ReplaceTinyPivot=YES)
     "unsym120_tiny": dict(matrix=("unsym", 120, 0.05, 3), grid=(1, 1, 1), flags=["-T", "1"]),
+    # iterative refinement (pdgsrfs3d, IterRefine=SLU_DOUBLE) on the un-equilibrated, un-row-permuted system
+    "poisson8_nd_refine": dict(matrix=("poisson", 8), grid=(1, 1, 1), nd=16, flags=["-e", "0", "-p", "0", "-i", "2"]),
+    "weakdiag150_refine": dict(matrix=("weakdiag", 150, 0.04, 11), grid=(1, 1, 1), flags=["-e", "0", "-p", "0", "-i", "2", "-T", "1"]),
+    "weakdiag150_refine_nrhs2": dict(matrix=("weakdiag", 150, 0.04, 11), grid=(1, 1, 1), flags=["-e", "0", "-p", "0", "-i", "2", "-T", "1", "-s", "2"]),
     # ---- complex16 (pzgssvx3d / pzgstrf3d / pzgstrs3d): BASELINE.json config 5 family ----
     "z_cg20_1x1x1": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 1), flags=[], z=True),
     "z_cg20_1x1x1_nrhs2": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 1), flags=["-s", "2"], z=True),
@@ -60,6 +64,9 @@ def build_case(name, spec, tmp):
         elif kind in ("poisson", "zpoisson"):
             N = spec["matrix"][1]
             n, rp, ci, v = matgen.poisson3d(N)
+        elif kind == "weakdiag":
+            _, nn, dens, seed = spec["matrix"]
+            n, rp, ci, v = matgen.random_unsym(nn, dens, seed, diag_scale=0.008)
         else:
             _, nn, dens, seed = spec["matrix"]
             n, rp, ci, v = matgen.random_unsym(nn, dens, seed)

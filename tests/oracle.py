@@ -113,5 +113,23 @@ def dsolve_level(store, x, nodes, direction):
     return x
 
 
+def dgsrfs(store, rowptr, colind, nzval, perm_c, B, X):
+    """Iterative refinement (pdgsrfs3d restatement) of X (n x nrhs, Fortran order, updated in place and returned) for the
+    ORIGINAL CSR matrix A, with `store` = factors of Pc A Pc^T.  Returns (X, berr[nrhs], steps of the last rhs)."""
+    B = np.asfortranarray(np.array(B, dtype=store.dtype)); X = np.asfortranarray(np.array(X, dtype=store.dtype))
+    if B.ndim == 1:
+        B = np.asfortranarray(B[:, None]); X = np.asfortranarray(X[:, None])
+    nrhs = B.shape[1]
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32); colind = np.ascontiguousarray(colind, dtype=np.int32)
+    nzval = np.ascontiguousarray(nzval, dtype=store.dtype); perm_c = np.ascontiguousarray(perm_c, dtype=np.int32)
+    berr = np.zeros(nrhs)
+    fn = lib().slu_oracle_zgsrfs if store.z else lib().slu_oracle_dgsrfs
+    fn.restype = ctypes.c_int
+    steps = fn(*store._args(), _p(rowptr, ctypes.c_int), _p(colind, ctypes.c_int), nzval.ctypes.data_as(ctypes.c_void_p),
+               _p(perm_c, ctypes.c_int), B.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(B.shape[0]),
+               X.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(X.shape[0]), ctypes.c_int(nrhs), _p(berr, ctypes.c_double))
+    return X, berr, steps
+
+
 def num_threads():
     return lib().slu_oracle_num_threads()

@@ -1,0 +1,64 @@
+"""Iterative refinement on the device (sluamd_pdgsrfs3d: SpMV + residual + backward error kernels around the GPU triangular
+solves) against the reference's pdgsrfs3d: the golden fixtures recorded with IterRefine=SLU_DOUBLE, and the CPU oracle on
+generated systems."""
+import numpy as np
+import pytest
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.0 ** -53
+
+
+@pytest.mark.parametrize("case", ["poisson8_nd_refine", "weakdiag150_refine", "weakdiag150_refine_nrhs2"])
+def test_refinement_matches_reference_fixture(golden, case):
+    from superlu_dist_amd import driver
+    g = golden(case)
+    fs = driver.FlatStore.from_golden(g, which="pre")
+    n, nrhs = fs.n, int(g["r0__nrhs"][0])
+    h = driver.LUHandle.from_store(fs, replace_tiny=bool(g["r0__ReplaceTinyPivot"][0]))
+    info = h.pdgstrf3d(float(g["r0__thresh"][0]))
+    assert info == 0
+    pc = g["r0__perm_c"]
+    rp, ci, v = g["r0__A_rowptr"], g["r0__A_colind"], g["r0__A_nzval"]
+    B = g["r0__b"].reshape((n, nrhs), order="F")
+    xp = np.zeros((n, nrhs), order="F"); xp[pc, :] = B
+    X0 = np.asfortranarray(h.pdgstrs3d(xp)[pc, :])
+    h.attach_matrix(n, rp, ci, v, pc)
+    X, berr, steps = h.pdgsrfs3d(B, X0)
+    Xref = g["r0__x"].reshape((n, nrhs), order="F")
+    assert abs(steps - int(g["r0__RefineSteps"][0])) <= 1          # the stopping test sits at the eps level
+    assert np.all(berr <= 4 * EPS)
+    assert np.abs(X - Xref).max() <= 1e-12 * max(1.0, np.abs(Xref).max())
+    h.destroy()
+
+
+@pytest.mark.parametrize("N,scale", [(12, None), (0, 0.01)])
+def test_refinement_against_oracle(N, scale):
+    from superlu_dist_amd import driver, matgen
+    if N:
+        n, rp, ci, v = matgen.poisson3d(N)
+        perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+    else:
+        n, rp, ci, v = matgen.random_unsym(400, 0.02, 5, diag_scale=scale)
+        perm = None
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    x, info, st, h, symb = driver.pdgssvx3d(n, rp, ci, v, b, perm_c=perm, relax=8, maxsup=64, keep=True, refine=True)
+    assert info == 0
+    # oracle: same factors (copied back from the device), same initial solve, then the restated pdgsrfs3d
+    symb.distribute_host(v)
+    fs = symb.flat_store()
+    ost = orc.LUStore(fs.n, fs.xsup, fs.Lrowind_off, fs.Lrowind, fs.Lnzval_off, fs.Lnzval, fs.Ufstnz_off, fs.Ufstnz,
+                      fs.Unzval_off, fs.Unzval)
+    anorm = float(np.max(np.add.reduceat(np.abs(v), rp[:-1])))
+    orc.dfactor(ost, None, False, float(np.finfo(np.float32).eps) * anorm)
+    pc = symb.perm_c
+    xp = np.zeros_like(b, order="F"); xp[pc, :] = b
+    X0 = np.asfortranarray(orc.dsolve(ost, xp)[pc, :])
+    Xo, berr_o, steps_o = orc.dgsrfs(ost, rp, ci, v, pc, b, X0)
+    assert abs(st["refine_steps"] - steps_o) <= 1
+    assert np.all(st["berr"] <= 4 * EPS) and np.all(berr_o <= 4 * EPS)
+    assert np.abs(x - Xo).max() <= 1e-11 * max(1.0, np.abs(Xo).max())
+    res = np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b)
+    assert res < 1e-14
+    h.destroy(); symb.free()

@@ -46,3 +46,27 @@ def test_solve_matches_reference(golden, case):
         got = xs                                # pdReDistribute3d_X_to_B leaves Y = Pc*X (pdgstrs3d.c:6573-6575);
                                                 # pdgssvx3d applies Pc^T afterwards
         assert np.abs(got - X).max() <= 1e-11 * max(1.0, np.abs(X).max())
+
+
+REFINE_CASES = ["poisson8_nd_refine", "weakdiag150_refine", "weakdiag150_refine_nrhs2"]
+
+
+@pytest.mark.parametrize("case", REFINE_CASES)
+def test_iterative_refinement_matches_reference(golden, case):
+    """pdgsrfs3d (IterRefine=SLU_DOUBLE, Equil=NO, NOROWPERM): same step count, berr and refined x as the reference."""
+    g = golden(case)
+    assert int(g["r0__opt_IterRefine"][0]) == 2 and int(g["r0__opt_Equil"][0]) == 0 and int(g["r0__opt_RowPerm"][0]) == 0
+    st = orc.LUStore.from_golden(g, 0, "post")
+    n = st.n
+    nrhs = int(g["r0__nrhs"][0])
+    pc = g["r0__perm_c"]
+    rp, ci, v = g["r0__A_rowptr"], g["r0__A_colind"], g["r0__A_nzval"]
+    B = g["r0__b"].reshape((n, nrhs), order="F")
+    xp = np.zeros((n, nrhs), order="F"); xp[pc, :] = B
+    X0 = np.asfortranarray(orc.dsolve(st, xp)[pc, :])          # initial solve: Pc^T (LU)^-1 Pc b
+    X, berr, steps = orc.dgsrfs(st, rp, ci, v, pc, B, X0)
+    Xref = g["r0__x"].reshape((n, nrhs), order="F")
+    assert steps == int(g["r0__RefineSteps"][0])
+    assert np.allclose(berr, g["r0__berr"], rtol=0.5, atol=1e-17)      # both at the eps level; ratio within 2x
+    assert np.abs(X - Xref).max() <= 1e-12 * max(1.0, np.abs(Xref).max())
+    assert np.abs(X - Xref).max() < np.abs(X0 - Xref).max() or np.abs(X0 - Xref).max() < 1e-14
