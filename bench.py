@@ -211,6 +211,21 @@ def main():
     else:
         stp = dict(h.stats(), t_schur_ms=0.0, t_panel_ms=0.0)
 
+    # accuracy row: one untimed pass of IterRefine=SLU_DOUBLE (pdgsrfs3d on the device) on the last solution
+    accuracy = None
+    if world == 1 and not zwork:
+        try:
+            h.attach_matrix(n, rp, ci, v, symb.perm_c)
+            L.sluamd_device_synchronize(); t_r = time.perf_counter()
+            xr, berr, rsteps = h.pdgsrfs3d(b, x)
+            L.sluamd_device_synchronize(); t_r = time.perf_counter() - t_r
+            accuracy = {"iter_refine": "SLU_DOUBLE (pdgsrfs3d on the device)", "berr": float(berr.max()), "steps": int(rsteps),
+                        "refine_ms": 1e3 * t_r,
+                        "residual_after": float(np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, xr)) / np.linalg.norm(b)),
+                        "max_abs_err_vs_xtrue_after": float(np.abs(xr - xt).max())}
+        except Exception as e:
+            accuracy = {"error": str(e)[:200]}
+
     st = h.stats()
     F = symb.flops if world > 1 else st["flops_schur_exact"] + st["flops_panel"]   # whole-matrix flop count either way
     ms_per_step = 1e3 * elapsed / args.steps
@@ -243,7 +258,7 @@ def main():
         "flops_per_step": F, "flops_schur_padded": st["flops_schur_padded"],
         "factor_ms": float(np.mean(fact_ms)), "solve_ms": float(np.mean(solve_ms)),
         "factor_gflops_kernel_only": F / (np.mean(fact_ms) * 1e-3) / 1e9,
-        "residual": res, "max_abs_err_vs_xtrue": err, "info": int(info),
+        "residual": res, "max_abs_err_vs_xtrue": err, "info": int(info), "accuracy": accuracy,
         "levels": st["num_levels"], "launches_per_factor": st["num_launches"], "setup_s": t_setup,
         "roofline": {"bound": "mfma", "kernel": "k_schur (fused gather + fp64 MFMA GEMM + scatter)",
                      "achieved": schur_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
