@@ -259,7 +259,7 @@ def main():
         "factor_ms": float(np.mean(fact_ms)), "solve_ms": float(np.mean(solve_ms)),
         "factor_gflops_kernel_only": F / (np.mean(fact_ms) * 1e-3) / 1e9,
         "residual": res, "max_abs_err_vs_xtrue": err, "info": int(info), "accuracy": accuracy,
-        "levels": st["num_levels"], "launches_per_factor": st["num_launches"], "setup_s": t_setup,
+        "levels": st["num_levels"], "fused_level_pairs": st["reserved_i"], "launches_per_factor": st["num_launches"], "setup_s": t_setup,
         "roofline": {"bound": "mfma", "kernel": "k_schur (fused gather + fp64 MFMA GEMM + scatter)",
                      "achieved": schur_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": schur_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",

@@ -91,6 +91,8 @@ struct LevelSched {
     std::vector<size_t> diag_lds;   // per level: dynamic LDS bytes k_diag_lu needs (max over the level's nodes)
     std::vector<int> pk_prefix;     // cooperative mode: 4096-double chunks of each node's (L panel | dinv) payload
     std::vector<int64_t> pk_off;    // ... and its offset (doubles) inside the level's staging buffer
+    std::vector<uint8_t> pair;      // per level: 0 plain, 1 first of a K-fused pair (only its urgent tiles run, the rest is
+                                    // deferred), 2 second (its tiles also accumulate the deferred update of level l-1)
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
     std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level [big group | small group]
     std::vector<int> u_off;         // [2*nlevels+1] offsets into ulist (2 groups per level)
@@ -135,6 +137,7 @@ struct Handle {
     // host tables kept for stats
     std::vector<int> h_nsupr, h_ldu, h_ncolu;
     std::vector<int64_t> h_sn_dinv;
+    std::vector<int> h_fuse_prev; int *d_fuse_prev = nullptr; int fused_levels = 0;   // K-fused chain pairs (k -> k-1 or -1)
     int max_nsupc = 0;
 };
 
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
-                                                                    int skip_level)
+                                                                    int skip_level, const int *__restrict__ fuse_prev)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -725,6 +728,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     __shared__ int s_colmap[TNv];
     __shared__ int s_cptr[TNv];   // value offset of tile column j inside U(k,:)
     __shared__ int s_lead[TNv];   // ns - seg (leading zeros) of tile column j
+    __shared__ int s_cptr2[TNv];  // the same two for the fused predecessor supernode (K-fused chain update)
+    __shared__ int s_lead2[TNv];
     __shared__ int s_jj[TNv];     // column id inside supernode jb
     __shared__ int64_t s_dbase;
     __shared__ int s_dinfo[4];
@@ -766,14 +771,35 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
     const double *Uv = T.val + T.sn_uval[k];
 
+    // K-fused chain update: supernode ka = k-1 is the previous piece of the same dense separator chain (identical
+    // block structure below k, verified by the host); its update of this tile was deferred and is accumulated here in
+    // the same registers -> ONE scatter for K = |ka| + |k| columns.  Rows of the tile sit |ka| further down in ka's
+    // panel (its extra first block is k itself), and U block C.x of row k is block C.x + 1 of row ka.
+    const int ka = fuse_prev ? fuse_prev[k] : -1;
+    int nsa = 0, ldaa = 0, kbega = 0;
+    const double *Lpa = nullptr, *Uva = nullptr;
+    int64_t uix0a = 0;
+    if (ka >= 0) {
+        nsa = T.xsup[k] - T.xsup[ka];
+        ldaa = T.sn_nsupr[ka];
+        Lpa = T.val + T.sn_lval[ka] + R.w + nsa;
+        Uva = T.val + T.sn_uval[ka];
+        uix0a = T.sn_uidx[ka] + T.ub_iukp[T.sn_ub_off[ka] + C.x + 1];
+        kbega = (nsa - T.sn_ldu[ka]) & ~3;
+    }
     for (int t = tid; t < TNv; t += NT) {
-        int cp = 0, lead = ns, jj = 0;
+        int cp = 0, lead = ns, jj = 0, cp2 = 0, lead2 = nsa;
         if (t < nc) {
             jj = T.unzcol[uix0 + C.y + t];
             lead = ns - (klst - T.uidx[uix0 + jj]);
             cp = T.ucolptr[uix0 + jj];
+            if (ka >= 0) {
+                lead2 = nsa - (T.xsup[k] - T.uidx[uix0a + jj]);
+                cp2 = T.ucolptr[uix0a + jj];
+            }
         }
         s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
+        s_cptr2[t] = cp2; s_lead2[t] = lead2;
     }
     // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
     if ((tid >> 6) == NW - 1) {
@@ -815,25 +841,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
 #pragma unroll
         for (int b = 0; b < NBR; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int kbeg = (ns - T.sn_ldu[k]) & ~3;          // U is zero above its tallest segment: skip those k
     const int li = tid % TMv, lk = tid / TMv;           // L loader: row li, k = lk + LKS*q
     const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + UJS*q
     double pl[LQ], pu[UQ];
     int ucp[UQ], uld[UQ];
-#pragma unroll
-    for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + UJS * q]; uld[q] = s_lead[uj + UJS * q]; }
     const bool lrow_ok = li < nr;
-    const double *Lrow = Lp + li;
+    // per-source state of the K loop (source 0 = fused predecessor ka, source 1 = k itself)
+    int ns_s = ns, lda_s = lda;
+    const double *Lrow = Lp + li, *Uvs = Uv;
 
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < LQ; ++q) {
             const int kg = k0 + lk + LKS * q;
-            pl[q] = (lrow_ok && kg < ns) ? Lrow[(size_t) kg * lda] : 0.0;
+            pl[q] = (lrow_ok && kg < ns_s) ? Lrow[(size_t) kg * lda_s] : 0.0;
         }
         const int kg = k0 + uk;
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) pu[q] = (kg >= uld[q] && kg < ns) ? Uv[ucp[q] + (kg - uld[q])] : 0.0;
+        for (int q = 0; q < UQ; ++q) pu[q] = (kg >= uld[q] && kg < ns_s) ? Uvs[ucp[q] + (kg - uld[q])] : 0.0;
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -842,30 +867,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + UJS * q] = pu[q];
     };
 
-    fetch(kbeg);
-    stash(0);
-    __syncthreads();
     int buf = 0;
-    for (int k0 = kbeg; k0 < ns; k0 += KC) {
-        const bool more = k0 + KC < ns;
-        if (more) fetch(k0 + KC);
-        const double *Lb = Ls[buf], *Ub = Us[buf];
+    for (int src = (ka >= 0) ? 0 : 1; src < 2; ++src) {
+        int kbeg;
+        if (src == 0) {
+            ns_s = nsa; lda_s = ldaa; Lrow = Lpa + li; Uvs = Uva; kbeg = kbega;
 #pragma unroll
-        for (int k4 = 0; k4 < KC; k4 += 4) {
-            const int kr = k4 + (lane >> 4);
-            double a[NBC], b[NBR];
+            for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr2[uj + UJS * q]; uld[q] = s_lead2[uj + UJS * q]; }
+        } else {
+            ns_s = ns; lda_s = lda; Lrow = Lp + li; Uvs = Uv;
+            kbeg = (ns - T.sn_ldu[k]) & ~3;              // U is zero above its tallest segment: skip those k
 #pragma unroll
-            for (int c = 0; c < NBC; ++c) a[c] = Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
-#pragma unroll
-            for (int r = 0; r < NBR; ++r) b[r] = Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
-#pragma unroll
-            for (int c = 0; c < NBC; ++c)
-#pragma unroll
-                for (int r = 0; r < NBR; ++r) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[r], acc[c][r], 0, 0, 0);
+            for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + UJS * q]; uld[q] = s_lead[uj + UJS * q]; }
         }
-        if (more) stash(buf ^ 1);
+        // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
+        fetch(kbeg);
+        stash(buf);
         __syncthreads();
-        buf ^= 1;
+        for (int k0 = kbeg; k0 < ns_s; k0 += KC) {
+            const bool more = k0 + KC < ns_s;
+            if (more) fetch(k0 + KC);
+            const double *Lb = Ls[buf], *Ub = Us[buf];
+#pragma unroll
+            for (int k4 = 0; k4 < KC; k4 += 4) {
+                const int kr = k4 + (lane >> 4);
+                double a[NBC], b[NBR];
+#pragma unroll
+                for (int c = 0; c < NBC; ++c) a[c] = Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
+#pragma unroll
+                for (int r = 0; r < NBR; ++r) b[r] = Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
+#pragma unroll
+                for (int c = 0; c < NBC; ++c)
+#pragma unroll
+                    for (int r = 0; r < NBR; ++r) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[r], acc[c][r], 0, 0, 0);
+            }
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
     // ---- scatter (epilogue) ----------------------------------------------------------------------
@@ -1242,7 +1281,35 @@ static int build_tables(Handle &H, HostTables &t)
 static void build_urgent_lists(const HostTables &t, int nsupers, const std::vector<int> &lvl, LevelSched &S);
 
 // level schedule over `list` (a valid elimination order); node k's level = longest path of updates into it
-static void build_schedule(const Handle &H, const HostTables &t, const std::vector<int> &list, LevelSched &S)
+// true when supernode b = a+1 continues the same dense separator chain as a: a's L panel is [diag a | block b (all of
+// b's rows) | exactly b's off-diagonal blocks, same rows], a's U row is [block b (all columns) | exactly b's blocks with
+// the same non-empty columns].  Then the update of a into anything beyond b can be accumulated into b's tiles.
+static bool chain_nests(const HostStruct &hs, const HostTables &t, int a, int b)
+{
+    if (b != a + 1 || !t.sn_big[a] || !t.sn_big[b]) return false;
+    const int sa = hs.xsup[a + 1] - hs.xsup[a], sb = hs.xsup[b + 1] - hs.xsup[b];
+    const int la = t.sn_lb_off[a], lb = t.sn_lb_off[b];
+    if (t.sn_nlb[a] != t.sn_nlb[b] + 1 || t.sn_nlb[b] < 2) return false;
+    if (t.lb_gid[la + 1] != b || t.lb_nbrow[la + 1] != sb) return false;
+    for (int i = 1; i < t.sn_nlb[b]; ++i) {
+        const int x = la + 1 + i, y = lb + i;
+        if (t.lb_gid[x] != t.lb_gid[y] || t.lb_nbrow[x] != t.lb_nbrow[y] || t.lb_rowoff[x] != t.lb_rowoff[y] + sa) return false;
+        const int *ra = hs.lidx.data() + hs.lidx_off[a] + t.lb_lptr[x], *rb = hs.lidx.data() + hs.lidx_off[b] + t.lb_lptr[y];
+        if (!std::equal(ra, ra + t.lb_nbrow[x], rb)) return false;
+    }
+    const int ua = t.sn_ub_off[a], ub = t.sn_ub_off[b];
+    if (t.sn_nub[a] != t.sn_nub[b] + 1 || t.sn_nub[b] < 1) return false;
+    if (t.ub_gid[ua] != b || t.ub_ncols[ua] != sb) return false;
+    for (int i = 0; i < t.sn_nub[b]; ++i) {
+        const int x = ua + 1 + i, y = ub + i;
+        if (t.ub_gid[x] != t.ub_gid[y] || t.ub_ncols[x] != t.ub_ncols[y]) return false;
+        const int *ca = t.unzcol.data() + hs.uidx_off[a] + t.ub_iukp[x], *cb = t.unzcol.data() + hs.uidx_off[b] + t.ub_iukp[y];
+        if (!std::equal(ca, ca + t.ub_ncols[x], cb)) return false;
+    }
+    return true;
+}
+
+static void build_schedule(Handle &H, const HostTables &t, const std::vector<int> &list, LevelSched &S)
 {
     const HostStruct &hs = H.hs;
     const int ns = hs.nsupers;
@@ -1306,6 +1373,29 @@ static void build_schedule(const Handle &H, const HostTables &t, const std::vect
         }
     }
     build_urgent_lists(t, ns, lvl, S);
+    // K-fused chain pairs: levels l, l+1 whose supernodes are (a_i, a_i + 1) pieces of the same dense chains
+    S.pair.assign(S.nlevels, 0);
+    if (H.h_fuse_prev.empty()) H.h_fuse_prev.assign(ns, -1);
+    if (!getenv("SLUAMD_NO_FUSE") && !H.opt.deterministic && !H.z) {
+        for (int l = 0; l + 1 < S.nlevels;) {
+            const int n0 = S.lvl_off[l + 1] - S.lvl_off[l], n1 = S.lvl_off[l + 2] - S.lvl_off[l + 1];
+            bool ok = n0 == n1 && S.n_big[l] == n0 && S.n_big[l + 1] == n1;
+            for (int i = S.lvl_off[l + 1]; ok && i < S.lvl_off[l + 2]; ++i) {
+                const int b = S.nodes[i];
+                ok = b > 0 && lvl[b - 1] == l && chain_nests(hs, t, b - 1, b);
+            }
+            if (getenv("SLUAMD_FUSE_DEBUG")) {
+                int nest = 0, prevl = 0;
+                for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) { const int b = S.nodes[i]; if (b > 0 && lvl[b - 1] == l) { ++prevl; if (chain_nests(hs, t, b - 1, b)) ++nest; } }
+                fprintf(stderr, "fuse: level %d n0=%d big0=%d | level %d n1=%d big1=%d prev-in-level=%d nests=%d -> %s\n", l, n0, S.n_big[l], l + 1, n1, S.n_big[l + 1], prevl, nest, ok ? "PAIR" : "no");
+            }
+            if (!ok) { ++l; continue; }
+            S.pair[l] = 1; S.pair[l + 1] = 2;
+            for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) H.h_fuse_prev[S.nodes[i]] = S.nodes[i] - 1;
+            H.fused_levels += 1;
+            l += 2;
+        }
+    }
 }
 
 // tiles of level l whose destination panel belongs to level l+1 (they gate the next level's panel factorisation)
@@ -1430,6 +1520,8 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
         nlev += H->sched[i].nlevels;
     }
     H->st.num_levels = nlev;
+    if (H->fused_levels) { if (upload(H->d_misc, H->h_fuse_prev, &H->d_fuse_prev)) return SLUAMD_EHIP; }
+    H->st.reserved_i = H->fused_levels;   // K-fused level pairs (diagnostic)
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -1487,14 +1579,15 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const bool lookahead = !H->profile && !H->opt.deterministic && getenv("SLUAMD_NO_LOOKAHEAD") == nullptr;
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     hipStream_t rs = (lookahead && H->rstream) ? H->rstream : s;
+    const int *fuse = nullptr;           // set per level: K-fused chain pairs (second level of a pair)
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
                      const int4 *ulist, int skip_level) {
         ev_begin(H, H->ev_schur, H->ev_schur_used);
         const int grid = ((ntile + 7) / 8) * 8;
         static const bool w8 = getenv("SLUAMD_SCHUR_4WAVES") == nullptr;
-        if (big && w8) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
-        else if (big) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
-        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        if (big && w8) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, fuse);
+        else if (big) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, fuse);
+        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, fuse);
         ev_end(H, H->ev_schur, H->ev_schur_used);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -1547,8 +1640,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             split = (S.ltr_prefix[po1 + nn1] + S.utr_prefix[po1 + nn1]) <= max_strips;
             (void) nn1;
         }
+        // K-fused pairs: the first level runs only its urgent tiles (everything the partner's panels need); the rest of
+        // its update is accumulated by the partner level's tiles (fuse != null), one scatter for both
+        const bool defer = H->d_fuse_prev && S.pair[l] == 1;
+        fuse = (H->d_fuse_prev && S.pair[l] == 2) ? H->d_fuse_prev : nullptr;
         // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
-        for (int pass = split ? 0 : 1; pass < 2; ++pass) {
+        for (int pass = (split || defer) ? 0 : 1; pass < (defer ? 1 : 2); ++pass) {
             hipStream_t st = (pass == 1 && split) ? rs : s;
             if (st != s) { hipEvent_t e = next_event(H); hipEventRecord(e, s); hipStreamWaitEvent(st, e, 0); }
             for (int g = 0; g < 2; ++g) {
@@ -1573,7 +1670,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                 }
             }
             if (st != s) { hipEvent_t e = next_event(H); hipEventRecord(e, st); hipStreamWaitEvent(s, e, 0); }   // later main-stream work follows rest(l)
-            if (pass == 0) {
+            if (pass == 0 && split) {
                 // panel(l+1) may start once the urgent tiles of level l (and, by stream order, the rest of level
                 // l-1) are complete; it then overlaps with the rest of level l
                 hipEvent_t eu = next_event(H);
@@ -1925,8 +2022,8 @@ int sluamd_coop_update(sluamd_handle_t h, int zlevel, int l, int G, int g, const
         const int nt = S.tile_prefix[so + cnt];
         if (!nt) continue;
         const int grid = ((nt + 7) / 8) * 8;
-        if (grp == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1);
-        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1);
+        if (grp == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1, (const int *) nullptr);
+        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1, (const int *) nullptr);
     }
     H->dinv_ready = true;
     HIPCHK(hipGetLastError());

@@ -146,8 +146,8 @@ def test_small_tile_configuration_agrees(golden, monkeypatch):
     assert np.abs(outs[0].Unzval - outs[1].Unzval).max() <= 1e-12 * 6.0
 
 
-@pytest.mark.parametrize("N,leaf,relax,maxsup", [(24, 64, 64, 256), (20, 27, 20, 200), (22, 64, 48, 130)])
-def test_large_supernodes_match_oracle(N, leaf, relax, maxsup):
+@pytest.mark.parametrize("N,leaf,relax,maxsup", [(24, 64, 64, 256), (20, 27, 20, 200), (22, 64, 48, 130), (28, 64, 64, 128)])
+def test_large_supernodes_match_oracle(N, leaf, relax, maxsup, monkeypatch):
     """Wide supernodes: blocked diagonal LU (ns > 128), multi-block MFMA TRSMs, 64x64 Schur tiles with several
     row/column tiles per block pair; every L/U value against the CPU oracle."""
     n, rp, ci, v = matgen.poisson3d(N)
@@ -173,7 +173,22 @@ def test_large_supernodes_match_oracle(N, leaf, relax, maxsup):
     xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
     x = h.pdgstrs3d(xp)[symb.perm_c, :]
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
+    fused = h.stats()["reserved_i"]
     h.destroy()
+    if N == 28:
+        # the top separator is a dense chain of >= 6 supernodes: consecutive pieces are K-fused (one scatter for two
+        # supernodes' updates); the same factorisation with fusion disabled must agree to summation-order accuracy
+        assert fused >= 2
+        monkeypatch.setenv("SLUAMD_NO_FUSE", "1")
+        symb.distribute_host(v)
+        fs2 = symb.flat_store()
+        h2 = driver.LUHandle.from_store(fs2)
+        assert h2.stats()["reserved_i"] == 0
+        assert h2.pdgstrf3d(0.0) == 0
+        h2.copy_to_host()
+        assert np.abs(fs2.Lnzval - fs.Lnzval).max() <= 1e-12 * scale
+        assert np.abs(fs2.Unzval - fs.Unzval).max() <= 1e-12 * scale
+        h2.destroy()
 
 
 @pytest.mark.parametrize("shape,leaf,relax,maxsup", [((40, 40, 1), 16, 16, 64), ((12, 12, 12), 27, 32, 128)])
