@@ -72,6 +72,12 @@ struct DevTables {
     const int4 *ctile;  // (U block idx within row, first non-empty col rank, ncols, unused)
     // cooperative (owner-computes) mode inside one shared ancestor forest: block column jb belongs to rank jb % own_G
     int own_G, own_g;
+    // K-fused updates (null when disabled): fuse_prev[k] = the supernode whose deferred update k's tiles also accumulate
+    // (or -1), defer[k] = 1 when k's non-urgent tiles are skipped (its partner applies them); for a fused k:
+    // pair_rowmap[pair_roff[k] + r] = row of the predecessor's L panel holding the same global row as row r of k's panel
+    // (-1: absent), pair_colinfo[2*(pair_coff[k] + c)] = (value offset, leading zeros) of k's c-th non-empty U column
+    // inside the predecessor's U row (leading zeros = predecessor width when absent)
+    const int *fuse_prev, *defer, *pair_roff, *pair_coff, *pair_rowmap, *pair_colinfo;
 };
 
 struct LevelSched {
@@ -91,8 +97,7 @@ struct LevelSched {
     std::vector<size_t> diag_lds;   // per level: dynamic LDS bytes k_diag_lu needs (max over the level's nodes)
     std::vector<int> pk_prefix;     // cooperative mode: 4096-double chunks of each node's (L panel | dinv) payload
     std::vector<int64_t> pk_off;    // ... and its offset (doubles) inside the level's staging buffer
-    std::vector<uint8_t> pair;      // per level: 0 plain, 1 first of a K-fused pair (only its urgent tiles run, the rest is
-                                    // deferred), 2 second (its tiles also accumulate the deferred update of level l-1)
+    std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
     std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level [big group | small group]
     std::vector<int> u_off;         // [2*nlevels+1] offsets into ulist (2 groups per level)
@@ -137,7 +142,9 @@ struct Handle {
     // host tables kept for stats
     std::vector<int> h_nsupr, h_ldu, h_ncolu;
     std::vector<int64_t> h_sn_dinv;
-    std::vector<int> h_fuse_prev; int *d_fuse_prev = nullptr; int fused_levels = 0;   // K-fused chain pairs (k -> k-1 or -1)
+    // K-fused updates (see DevTables): host images, built by build_schedule
+    std::vector<int> h_fuse_prev, h_defer, h_pair_roff, h_pair_coff, h_pair_rowmap, h_pair_colinfo;
+    int fused_pairs = 0;
     int max_nsupc = 0;
 };
 
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
-                                                                    int skip_level, const int *__restrict__ fuse_prev)
+                                                                    int skip_level)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -764,6 +771,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
     if (T.own_G > 1 && (jb % T.own_G) != T.own_g) return;   // cooperative mode: owner of destination block column jb
     if (!ulist && skip_level >= 0 && (sn_level[ib] == skip_level || sn_level[jb] == skip_level)) return;  // done by the urgent launch
+    if (!ulist && T.defer && T.defer[k]) return;   // K-fused: the partner supernode's tiles apply this update
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int lda = T.sn_nsupr[k];
     const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;  // global row ids of the tile rows
@@ -771,21 +779,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
     const double *Uv = T.val + T.sn_uval[k];
 
-    // K-fused chain update: supernode ka = k-1 is the previous piece of the same dense separator chain (identical
-    // block structure below k, verified by the host); its update of this tile was deferred and is accumulated here in
-    // the same registers -> ONE scatter for K = |ka| + |k| columns.  Rows of the tile sit |ka| further down in ka's
-    // panel (its extra first block is k itself), and U block C.x of row k is block C.x + 1 of row ka.
-    const int ka = fuse_prev ? fuse_prev[k] : -1;
-    int nsa = 0, ldaa = 0, kbega = 0;
+    // K-fused update: the deferred update of supernode ka (k's predecessor, k = parent(ka), consecutive levels) is
+    // accumulated here in the same registers -> ONE prologue and ONE scatter for K = |ka| + |k| columns.  ka's block
+    // structure beyond k is a subset of k's: host-built maps give, per panel row / non-empty U column of k, where the
+    // same global row / column sits in ka's panel / U row (or that it is absent = zeros).
+    const int ka = T.fuse_prev ? T.fuse_prev[k] : -1;
+    int nsa = 0, ldaa = 0, kbega = 0, ra = -1;
     const double *Lpa = nullptr, *Uva = nullptr;
-    int64_t uix0a = 0;
+    const int *cinfo = nullptr;
     if (ka >= 0) {
         nsa = T.xsup[k] - T.xsup[ka];
         ldaa = T.sn_nsupr[ka];
-        Lpa = T.val + T.sn_lval[ka] + R.w + nsa;
+        Lpa = T.val + T.sn_lval[ka];
         Uva = T.val + T.sn_uval[ka];
-        uix0a = T.sn_uidx[ka] + T.ub_iukp[T.sn_ub_off[ka] + C.x + 1];
         kbega = (nsa - T.sn_ldu[ka]) & ~3;
+        cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[k] + T.ub_stcol[ub] + C.y);
+        if (tid % TMv < nr) ra = T.pair_rowmap[T.pair_roff[k] + R.w + tid % TMv];
     }
     for (int t = tid; t < TNv; t += NT) {
         int cp = 0, lead = ns, jj = 0, cp2 = 0, lead2 = nsa;
@@ -793,10 +802,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
             jj = T.unzcol[uix0 + C.y + t];
             lead = ns - (klst - T.uidx[uix0 + jj]);
             cp = T.ucolptr[uix0 + jj];
-            if (ka >= 0) {
-                lead2 = nsa - (T.xsup[k] - T.uidx[uix0a + jj]);
-                cp2 = T.ucolptr[uix0a + jj];
-            }
+            if (ka >= 0) { cp2 = cinfo[2 * t]; lead2 = cinfo[2 * t + 1]; }
         }
         s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
         s_cptr2[t] = cp2; s_lead2[t] = lead2;
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + UJS*q
     double pl[LQ], pu[UQ];
     int ucp[UQ], uld[UQ];
-    const bool lrow_ok = li < nr;
+    bool lrow_ok = li < nr;
     // per-source state of the K loop (source 0 = fused predecessor ka, source 1 = k itself)
     int ns_s = ns, lda_s = lda;
     const double *Lrow = Lp + li, *Uvs = Uv;
@@ -871,11 +877,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     for (int src = (ka >= 0) ? 0 : 1; src < 2; ++src) {
         int kbeg;
         if (src == 0) {
-            ns_s = nsa; lda_s = ldaa; Lrow = Lpa + li; Uvs = Uva; kbeg = kbega;
+            ns_s = nsa; lda_s = ldaa; Lrow = Lpa + max(ra, 0); Uvs = Uva; kbeg = kbega; lrow_ok = ra >= 0;
 #pragma unroll
             for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr2[uj + UJS * q]; uld[q] = s_lead2[uj + UJS * q]; }
         } else {
-            ns_s = ns; lda_s = lda; Lrow = Lp + li; Uvs = Uv;
+            ns_s = ns; lda_s = lda; Lrow = Lp + li; Uvs = Uv; lrow_ok = li < nr;
             kbeg = (ns - T.sn_ldu[k]) & ~3;              // U is zero above its tallest segment: skip those k
 #pragma unroll
             for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + UJS * q]; uld[q] = s_lead[uj + UJS * q]; }
@@ -1281,32 +1287,58 @@ static int build_tables(Handle &H, HostTables &t)
 static void build_urgent_lists(const HostTables &t, int nsupers, const std::vector<int> &lvl, LevelSched &S);
 
 // level schedule over `list` (a valid elimination order); node k's level = longest path of updates into it
-// true when supernode b = a+1 continues the same dense separator chain as a: a's L panel is [diag a | block b (all of
-// b's rows) | exactly b's off-diagonal blocks, same rows], a's U row is [block b (all columns) | exactly b's blocks with
-// the same non-empty columns].  Then the update of a into anything beyond b can be accumulated into b's tiles.
-static bool chain_nests(const HostStruct &hs, const HostTables &t, int a, int b)
+// K-fused pair (a, b = a+1): b's tiles will also accumulate a's deferred update.  Needs every row / column of a's
+// structure beyond b to exist in b's structure (true when b is a's parent in the supernodal elimination tree); builds
+// the row map (per panel row of b: row in a's panel or -1) and the column info (per non-empty U column of row b:
+// value offset and leading zeros inside a's U row).  Rejects pairs whose a is much smaller than b (the fused tiles
+// would multiply mostly zeros).
+static bool build_pair_maps(const HostStruct &hs, const HostTables &t, int a, int b, std::vector<int> &rowmap, std::vector<int> &colinfo)
 {
-    if (b != a + 1 || !t.sn_big[a] || !t.sn_big[b]) return false;
-    const int sa = hs.xsup[a + 1] - hs.xsup[a], sb = hs.xsup[b + 1] - hs.xsup[b];
+    const int sa = hs.xsup[a + 1] - hs.xsup[a];
+    const int nsupr_b = t.sn_nsupr[b], ncolu_b = t.sn_ncolu[b];
+    rowmap.assign(nsupr_b, -1);
+    colinfo.assign(2 * (size_t) ncolu_b, 0);
+    for (int c = 0; c < ncolu_b; ++c) colinfo[2 * c + 1] = sa;
     const int la = t.sn_lb_off[a], lb = t.sn_lb_off[b];
-    if (t.sn_nlb[a] != t.sn_nlb[b] + 1 || t.sn_nlb[b] < 2) return false;
-    if (t.lb_gid[la + 1] != b || t.lb_nbrow[la + 1] != sb) return false;
-    for (int i = 1; i < t.sn_nlb[b]; ++i) {
-        const int x = la + 1 + i, y = lb + i;
-        if (t.lb_gid[x] != t.lb_gid[y] || t.lb_nbrow[x] != t.lb_nbrow[y] || t.lb_rowoff[x] != t.lb_rowoff[y] + sa) return false;
-        const int *ra = hs.lidx.data() + hs.lidx_off[a] + t.lb_lptr[x], *rb = hs.lidx.data() + hs.lidx_off[b] + t.lb_lptr[y];
-        if (!std::equal(ra, ra + t.lb_nbrow[x], rb)) return false;
+    int rows_a = 0, cols_a = 0;
+    for (int x = 1; x < t.sn_nlb[a]; ++x) {
+        const int g = t.lb_gid[la + x];
+        if (g == b) continue;                      // a's update of b itself: the urgent tiles
+        int y = -1;
+        for (int q = 1; q < t.sn_nlb[b]; ++q) if (t.lb_gid[lb + q] == g) { y = q; break; }
+        if (y < 0) return false;
+        const int *ra = hs.lidx.data() + hs.lidx_off[a] + t.lb_lptr[la + x], *rb = hs.lidx.data() + hs.lidx_off[b] + t.lb_lptr[lb + y];
+        const int na = t.lb_nbrow[la + x], nb = t.lb_nbrow[lb + y];
+        for (int i = 0; i < na; ++i) {
+            const int *f = std::find(rb, rb + nb, ra[i]);
+            if (f == rb + nb) return false;
+            rowmap[t.lb_rowoff[lb + y] + (int) (f - rb)] = t.lb_rowoff[la + x] + i;
+        }
+        rows_a += na;
     }
     const int ua = t.sn_ub_off[a], ub = t.sn_ub_off[b];
-    if (t.sn_nub[a] != t.sn_nub[b] + 1 || t.sn_nub[b] < 1) return false;
-    if (t.ub_gid[ua] != b || t.ub_ncols[ua] != sb) return false;
-    for (int i = 0; i < t.sn_nub[b]; ++i) {
-        const int x = ua + 1 + i, y = ub + i;
-        if (t.ub_gid[x] != t.ub_gid[y] || t.ub_ncols[x] != t.ub_ncols[y]) return false;
-        const int *ca = t.unzcol.data() + hs.uidx_off[a] + t.ub_iukp[x], *cb = t.unzcol.data() + hs.uidx_off[b] + t.ub_iukp[y];
-        if (!std::equal(ca, ca + t.ub_ncols[x], cb)) return false;
+    const int klst_a = hs.xsup[a + 1];
+    for (int x = 0; x < t.sn_nub[a]; ++x) {
+        const int g = t.ub_gid[ua + x];
+        if (g == b) continue;
+        int y = -1;
+        for (int q = 0; q < t.sn_nub[b]; ++q) if (t.ub_gid[ub + q] == g) { y = q; break; }
+        if (y < 0) return false;
+        const int64_t pa = hs.uidx_off[a] + t.ub_iukp[ua + x], pb = hs.uidx_off[b] + t.ub_iukp[ub + y];
+        const int *ca = t.unzcol.data() + pa, *cb = t.unzcol.data() + pb;
+        const int na = t.ub_ncols[ua + x], nb = t.ub_ncols[ub + y];
+        for (int i = 0; i < na; ++i) {
+            const int *f = std::find(cb, cb + nb, ca[i]);
+            if (f == cb + nb) return false;
+            const int c = t.ub_stcol[ub + y] + (int) (f - cb), jj = ca[i];
+            colinfo[2 * c] = t.ucolptr[pa + jj];
+            colinfo[2 * c + 1] = sa - (klst_a - hs.uidx[pa + jj]);
+        }
+        cols_a += na;
     }
-    return true;
+    const int rows_b = nsupr_b - (hs.xsup[b + 1] - hs.xsup[b]);
+    static const int pct = getenv("SLUAMD_FUSE_MIN_PCT") ? atoi(getenv("SLUAMD_FUSE_MIN_PCT")) : 75;
+    return rows_a > 0 && cols_a > 0 && 100 * (int64_t) rows_a >= (int64_t) pct * rows_b && 100 * (int64_t) cols_a >= (int64_t) pct * ncolu_b;
 }
 
 static void build_schedule(Handle &H, const HostTables &t, const std::vector<int> &list, LevelSched &S)
@@ -1373,32 +1405,25 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
         }
     }
     build_urgent_lists(t, ns, lvl, S);
-    // K-fused chain pairs: levels l, l+1 whose supernodes are (a_i, a_i + 1) pieces of the same dense chains
-    S.pair.assign(S.nlevels, 0);
-    if (H.h_fuse_prev.empty()) H.h_fuse_prev.assign(ns, -1);
+    // K-fused pairs (a, a+1) in consecutive levels; pairs are disjoint (a fused supernode is not deferred itself)
+    S.lvl_defer.assign(S.nlevels, 0);
+    if (H.h_fuse_prev.empty()) { H.h_fuse_prev.assign(ns, -1); H.h_defer.assign(ns, 0); H.h_pair_roff.assign(ns, -1); H.h_pair_coff.assign(ns, -1); }
     if (!getenv("SLUAMD_NO_FUSE") && !H.opt.deterministic && !H.z) {
-        for (int l = 0; l + 1 < S.nlevels;) {
-            const int n0 = S.lvl_off[l + 1] - S.lvl_off[l], n1 = S.lvl_off[l + 2] - S.lvl_off[l + 1];
-            bool ok = n0 == n1 && S.n_big[l] == n0 && S.n_big[l + 1] == n1;
-            for (int i = S.lvl_off[l + 1]; ok && i < S.lvl_off[l + 2]; ++i) {
-                const int b = S.nodes[i];
-                ok = b > 0 && lvl[b - 1] == l && chain_nests(hs, t, b - 1, b);
+        std::vector<int> rowmap, colinfo;
+        for (int l = 0; l + 1 < S.nlevels; ++l)
+            for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) {
+                const int b = S.nodes[i], a = b - 1;
+                if (a < 0 || lvl[a] != l || !t.sn_big[a] || !t.sn_big[b] || H.h_fuse_prev[a] >= 0) continue;
+                if (!build_pair_maps(hs, t, a, b, rowmap, colinfo)) continue;
+                H.h_fuse_prev[b] = a; H.h_defer[a] = 1;
+                H.h_pair_roff[b] = (int) H.h_pair_rowmap.size(); H.h_pair_coff[b] = (int) (H.h_pair_colinfo.size() / 2);
+                H.h_pair_rowmap.insert(H.h_pair_rowmap.end(), rowmap.begin(), rowmap.end());
+                H.h_pair_colinfo.insert(H.h_pair_colinfo.end(), colinfo.begin(), colinfo.end());
+                S.lvl_defer[l] = 1;
+                H.fused_pairs += 1;
             }
-            if (getenv("SLUAMD_FUSE_DEBUG")) {
-                int nest = 0, prevl = 0;
-                for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) { const int b = S.nodes[i]; if (b > 0 && lvl[b - 1] == l) { ++prevl; if (chain_nests(hs, t, b - 1, b)) ++nest; } }
-                fprintf(stderr, "fuse: level %d n0=%d big0=%d | level %d n1=%d big1=%d prev-in-level=%d nests=%d -> %s\n", l, n0, S.n_big[l], l + 1, n1, S.n_big[l + 1], prevl, nest, ok ? "PAIR" : "no");
-            }
-            if (!ok) { ++l; continue; }
-            S.pair[l] = 1; S.pair[l + 1] = 2;
-            for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) H.h_fuse_prev[S.nodes[i]] = S.nodes[i] - 1;
-            H.fused_levels += 1;
-            l += 2;
-        }
     }
 }
-
-// tiles of level l whose destination panel belongs to level l+1 (they gate the next level's panel factorisation)
 static void build_urgent_lists(const HostTables &t, int nsupers, const std::vector<int> &lvl, LevelSched &S)
 {
     S.sn_level = lvl;
@@ -1520,8 +1545,13 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
         nlev += H->sched[i].nlevels;
     }
     H->st.num_levels = nlev;
-    if (H->fused_levels) { if (upload(H->d_misc, H->h_fuse_prev, &H->d_fuse_prev)) return SLUAMD_EHIP; }
-    H->st.reserved_i = H->fused_levels;   // K-fused level pairs (diagnostic)
+    if (H->fused_pairs) {
+        int *p0, *p1, *p2, *p3, *p4, *p5;
+        if (upload(H->d_misc, H->h_fuse_prev, &p0) || upload(H->d_misc, H->h_defer, &p1) || upload(H->d_misc, H->h_pair_roff, &p2) ||
+            upload(H->d_misc, H->h_pair_coff, &p3) || upload(H->d_misc, H->h_pair_rowmap, &p4) || upload(H->d_misc, H->h_pair_colinfo, &p5)) return SLUAMD_EHIP;
+        T.fuse_prev = p0; T.defer = p1; T.pair_roff = p2; T.pair_coff = p3; T.pair_rowmap = p4; T.pair_colinfo = p5;
+    }
+    H->st.reserved_i = H->fused_pairs;   // K-fused supernode pairs (diagnostic)
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -1579,15 +1609,14 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const bool lookahead = !H->profile && !H->opt.deterministic && getenv("SLUAMD_NO_LOOKAHEAD") == nullptr;
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     hipStream_t rs = (lookahead && H->rstream) ? H->rstream : s;
-    const int *fuse = nullptr;           // set per level: K-fused chain pairs (second level of a pair)
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
                      const int4 *ulist, int skip_level) {
         ev_begin(H, H->ev_schur, H->ev_schur_used);
         const int grid = ((ntile + 7) / 8) * 8;
         static const bool w8 = getenv("SLUAMD_SCHUR_4WAVES") == nullptr;
-        if (big && w8) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, fuse);
-        else if (big) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, fuse);
-        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, fuse);
+        if (big && w8) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        else if (big) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
         ev_end(H, H->ev_schur, H->ev_schur_used);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -1640,12 +1669,11 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             split = (S.ltr_prefix[po1 + nn1] + S.utr_prefix[po1 + nn1]) <= max_strips;
             (void) nn1;
         }
-        // K-fused pairs: the first level runs only its urgent tiles (everything the partner's panels need); the rest of
-        // its update is accumulated by the partner level's tiles (fuse != null), one scatter for both
-        const bool defer = H->d_fuse_prev && S.pair[l] == 1;
-        fuse = (H->d_fuse_prev && S.pair[l] == 2) ? H->d_fuse_prev : nullptr;
+        // K-fused pairs: a deferred supernode runs only its urgent tiles (everything the next level's panels need), so the
+        // urgent pass is needed even without look-ahead; the rest of its update is accumulated by its partner's tiles
+        const bool urgent_pass = split || (T.defer && S.lvl_defer[l]);
         // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
-        for (int pass = (split || defer) ? 0 : 1; pass < (defer ? 1 : 2); ++pass) {
+        for (int pass = urgent_pass ? 0 : 1; pass < 2; ++pass) {
             hipStream_t st = (pass == 1 && split) ? rs : s;
             if (st != s) { hipEvent_t e = next_event(H); hipEventRecord(e, s); hipStreamWaitEvent(st, e, 0); }
             for (int g = 0; g < 2; ++g) {
@@ -1660,8 +1688,14 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                 }
                 const int nt = S.tile_prefix[so + cnt];
                 if (!nt) continue;
+                if (T.defer && S.lvl_defer[l]) {   // nothing to launch when every supernode of the group is deferred
+                    bool all = true;
+                    const int i0 = n0 + (g == 0 ? 0 : nbig);
+                    for (int i = 0; i < cnt && all; ++i) all = H->h_defer[S.nodes[i0 + i]] != 0;
+                    if (all) continue;
+                }
                 if (!H->opt.deterministic) {
-                    schur(st, g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, split ? l + 1 : -1);
+                    schur(st, g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, urgent_pass ? l + 1 : -1);
                 } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
                     for (int i = 0; i < cnt; ++i) {
                         const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
@@ -1966,7 +2000,7 @@ int sluamd_coop_panel(sluamd_handle_t h, int zlevel, int l, int G, int g, double
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
     LevelSched &S = H->sched[zlevel];
-    DevTables T = H->T; T.own_G = G; T.own_g = g;
+    DevTables T = H->T; T.own_G = G; T.own_g = g; T.fuse_prev = nullptr; T.defer = nullptr;
     hipStream_t cs = H->has_user_stream ? H->user_stream : H->stream;
     const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
     const int *nodes = S.d_nodes + n0;
@@ -1999,7 +2033,7 @@ int sluamd_coop_update(sluamd_handle_t h, int zlevel, int l, int G, int g, const
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
     LevelSched &S = H->sched[zlevel];
-    DevTables T = H->T; T.own_G = G; T.own_g = g;
+    DevTables T = H->T; T.own_G = G; T.own_g = g; T.fuse_prev = nullptr; T.defer = nullptr;
     hipStream_t cs = H->has_user_stream ? H->user_stream : H->stream;
     const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
     const int *nodes = S.d_nodes + n0;
@@ -2022,8 +2056,8 @@ int sluamd_coop_update(sluamd_handle_t h, int zlevel, int l, int G, int g, const
         const int nt = S.tile_prefix[so + cnt];
         if (!nt) continue;
         const int grid = ((nt + 7) / 8) * 8;
-        if (grp == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1, (const int *) nullptr);
-        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1, (const int *) nullptr);
+        if (grp == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1);
+        else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, cs, T, gn, S.d_tile_prefix + so, cnt, 0, nt, H->d_info, (const int4 *) nullptr, S.d_sn_level, -1);
     }
     H->dinv_ready = true;
     HIPCHK(hipGetLastError());
@@ -2039,7 +2073,7 @@ int sluamd_coop_mask_u(sluamd_handle_t h, int zlevel, int G, int g)
     HIPCHK(hipSetDevice(H->device));
     LevelSched &S = H->sched[zlevel];
     if (G == 1 || S.nodes.empty()) return 0;
-    DevTables T = H->T; T.own_G = G; T.own_g = g;
+    DevTables T = H->T; T.own_G = G; T.own_g = g; T.fuse_prev = nullptr; T.defer = nullptr;
     hipStream_t cs = H->has_user_stream ? H->user_stream : H->stream;
     hipLaunchKernelGGL(k_coop_mask_u, dim3((unsigned) S.nodes.size()), dim3(256), 0, cs, T, S.d_nodes);
     HIPCHK(hipGetLastError());
