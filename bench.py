@@ -235,10 +235,11 @@ def main():
     # needs its own passes), so the value measured on this same command line is kept under profiles/ with its provenance
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_schur.json")
-    if world == 1 and args.n == 100 and os.path.exists(pmc_path):
+    if world == 1 and args.n == 100 and not zwork and os.path.exists(pmc_path):
         try:
             pj = json.load(open(pmc_path))
-            traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01_pmc_schur.json: " + pj["source"]
+            traffic = pj["traffic_bytes_per_factorisation"] / max(1, stp["schur_launches"])   # per launch, like `achieved`
+            traffic_src = "profiles/r01_pmc_schur.json: " + pj["source"]
         except Exception:
             pass
     alg_bytes_per_launch = st["schur_bytes_alg"] / max(1, stp["schur_launches"])   # 16 B per updated element
