@@ -1556,6 +1556,7 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
     H->st.bytes_device = (int64_t) ((hs.nnzL + hs.nnzU) * sizeof(double) + idxb);
@@ -2137,7 +2138,8 @@ static int run_factor_z(Handle *H, LevelSched &S, double thresh)
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
         const int *nodes = S.d_nodes + n0;
-        hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), 0, s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info);
+        const int ldp = S.max_nsupc[l] | 1;
+        hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), zdiag_lds_bytes(S.max_nsupc[l]), s, T, nodes, H->opt.replace_tiny_pivot, thresh, H->d_info, ldp);
         const int po = S.lvl_poff[l];
         const int nl = S.zltr_prefix[po + nn], nu = S.bwd_prefix[po + nn];   // 64-row strips / 64-column chunks
         if (nl + nu) hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, nl);
