@@ -113,6 +113,14 @@ def main():
                          "(complex16 2-D grid operator, use --n 1000)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: re-launch under torch.distributed.run, one rank per GPU
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        argv = ["--grid-side" if a == "--n" else a for a in sys.argv[1:]]   # torchrun's parser trips over the prefix "--n"
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv)
+
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
