@@ -72,11 +72,12 @@ struct DevTables {
     const int4 *ctile;  // (U block idx within row, first non-empty col rank, ncols, unused)
     // cooperative (owner-computes) mode inside one shared ancestor forest: block column jb belongs to rank jb % own_G
     int own_G, own_g;
-    // K-fused updates (null when disabled): fuse_prev[k] = the supernode whose deferred update k's tiles also accumulate
-    // (or -1), defer[k] = 1 when k's non-urgent tiles are skipped (its partner applies them); for a fused k:
-    // pair_rowmap[pair_roff[k] + r] = row of the predecessor's L panel holding the same global row as row r of k's panel
-    // (-1: absent), pair_colinfo[2*(pair_coff[k] + c)] = (value offset, leading zeros) of k's c-th non-empty U column
-    // inside the predecessor's U row (leading zeros = predecessor width when absent)
+    // K-fused updates (null when disabled): fuse_prev[3k + j], j = 0..2 = the up to three predecessor supernodes (k-1,
+    // k-2, k-3 of the same chain; -1 = none) whose deferred updates k's tiles also accumulate; defer[k] = 1 when k's
+    // non-urgent tiles are skipped (a later chain member applies them).  Per (k, j): pair_rowmap[pair_roff[3k+j] + r] =
+    // row of that predecessor's L panel holding the same global row as row r of k's panel (-1: absent);
+    // pair_colinfo[2*(pair_coff[3k+j] + c)] = (value offset, leading zeros) of k's c-th non-empty U column inside the
+    // predecessor's U row (leading zeros = predecessor width when absent)
     const int *fuse_prev, *defer, *pair_roff, *pair_coff, *pair_rowmap, *pair_colinfo;
 };
 
@@ -779,33 +780,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
     const double *Uv = T.val + T.sn_uval[k];
 
-    // K-fused update: the deferred update of supernode ka (k's predecessor, k = parent(ka), consecutive levels) is
-    // accumulated here in the same registers -> ONE prologue and ONE scatter for K = |ka| + |k| columns.  ka's block
-    // structure beyond k is a subset of k's: host-built maps give, per panel row / non-empty U column of k, where the
-    // same global row / column sits in ka's panel / U row (or that it is absent = zeros).
-    const int ka = T.fuse_prev ? T.fuse_prev[k] : -1;
-    int nsa = 0, ldaa = 0, kbega = 0, ra = -1;
-    const double *Lpa = nullptr, *Uva = nullptr;
-    const int *cinfo = nullptr;
-    if (ka >= 0) {
-        nsa = T.xsup[k] - T.xsup[ka];
-        ldaa = T.sn_nsupr[ka];
-        Lpa = T.val + T.sn_lval[ka];
-        Uva = T.val + T.sn_uval[ka];
-        kbega = (nsa - T.sn_ldu[ka]) & ~3;
-        cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[k] + T.ub_stcol[ub] + C.y);
-        if (tid % TMv < nr) ra = T.pair_rowmap[T.pair_roff[k] + R.w + tid % TMv];
-    }
+    // K-fused update: the deferred updates of up to three predecessors of k in its chain (k = parent(k-1) = ..., consecutive
+    // levels) are accumulated here in the same registers -> ONE prologue and ONE scatter for K = sum of their widths.  A
+    // predecessor's block structure beyond k is a subset of k's: host-built maps give, per panel row / non-empty U
+    // column of k, where the same global row / column sits in its panel / U row (or that it is absent = zeros).
+    int nprev = 0;
+    if (T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
     for (int t = tid; t < TNv; t += NT) {
-        int cp = 0, lead = ns, jj = 0, cp2 = 0, lead2 = nsa;
+        int cp = 0, lead = ns, jj = 0;
         if (t < nc) {
             jj = T.unzcol[uix0 + C.y + t];
             lead = ns - (klst - T.uidx[uix0 + jj]);
             cp = T.ucolptr[uix0 + jj];
-            if (ka >= 0) { cp2 = cinfo[2 * t]; lead2 = cinfo[2 * t + 1]; }
         }
         s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
-        s_cptr2[t] = cp2; s_lead2[t] = lead2;
     }
     // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
     if ((tid >> 6) == NW - 1) {
@@ -874,10 +862,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     };
 
     int buf = 0;
-    for (int src = (ka >= 0) ? 0 : 1; src < 2; ++src) {
+    for (int src = 0; src <= nprev; ++src) {       // farthest predecessor first, k itself last
         int kbeg;
-        if (src == 0) {
-            ns_s = nsa; lda_s = ldaa; Lrow = Lpa + max(ra, 0); Uvs = Uva; kbeg = kbega; lrow_ok = ra >= 0;
+        if (src < nprev) {
+            const int pj = 3 * k + (nprev - 1 - src);
+            const int ks = T.fuse_prev[pj];
+            const int nss = T.xsup[ks + 1] - T.xsup[ks];
+            const int *cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[pj] + T.ub_stcol[ub] + C.y);
+            const int ra = (li < nr) ? T.pair_rowmap[T.pair_roff[pj] + R.w + li] : -1;
+            for (int t = tid; t < TNv; t += NT) {
+                s_cptr2[t] = (t < nc) ? cinfo[2 * t] : 0;
+                s_lead2[t] = (t < nc) ? cinfo[2 * t + 1] : nss;
+            }
+            __syncthreads();
+            ns_s = nss; lda_s = T.sn_nsupr[ks]; Lrow = T.val + T.sn_lval[ks] + max(ra, 0); Uvs = T.val + T.sn_uval[ks];
+            kbeg = (nss - T.sn_ldu[ks]) & ~3; lrow_ok = ra >= 0;
 #pragma unroll
             for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr2[uj + UJS * q]; uld[q] = s_lead2[uj + UJS * q]; }
         } else {
@@ -1287,8 +1286,9 @@ static int build_tables(Handle &H, HostTables &t)
 static void build_urgent_lists(const HostTables &t, int nsupers, const std::vector<int> &lvl, LevelSched &S);
 
 // level schedule over `list` (a valid elimination order); node k's level = longest path of updates into it
-// K-fused pair (a, b = a+1): b's tiles will also accumulate a's deferred update.  Needs every row / column of a's
-// structure beyond b to exist in b's structure (true when b is a's parent in the supernodal elimination tree); builds
+// K-fused source a of supernode b (a < b members of one chain): b's tiles will also accumulate a's deferred update.  Needs
+// every row / column of a's structure beyond b to exist in b's structure (true when b is an ancestor of a in the supernodal
+// elimination tree); builds
 // the row map (per panel row of b: row in a's panel or -1) and the column info (per non-empty U column of row b:
 // value offset and leading zeros inside a's U row).  Rejects pairs whose a is much smaller than b (the fused tiles
 // would multiply mostly zeros).
@@ -1303,7 +1303,7 @@ static bool build_pair_maps(const HostStruct &hs, const HostTables &t, int a, in
     int rows_a = 0, cols_a = 0;
     for (int x = 1; x < t.sn_nlb[a]; ++x) {
         const int g = t.lb_gid[la + x];
-        if (g == b) continue;                      // a's update of b itself: the urgent tiles
+        if (g <= b) continue;                      // a's updates of the chain members up to b: their urgent tiles
         int y = -1;
         for (int q = 1; q < t.sn_nlb[b]; ++q) if (t.lb_gid[lb + q] == g) { y = q; break; }
         if (y < 0) return false;
@@ -1320,7 +1320,7 @@ static bool build_pair_maps(const HostStruct &hs, const HostTables &t, int a, in
     const int klst_a = hs.xsup[a + 1];
     for (int x = 0; x < t.sn_nub[a]; ++x) {
         const int g = t.ub_gid[ua + x];
-        if (g == b) continue;
+        if (g <= b) continue;
         int y = -1;
         for (int q = 0; q < t.sn_nub[b]; ++q) if (t.ub_gid[ub + q] == g) { y = q; break; }
         if (y < 0) return false;
@@ -1405,20 +1405,36 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
         }
     }
     build_urgent_lists(t, ns, lvl, S);
-    // K-fused pairs (a, a+1) in consecutive levels; pairs are disjoint (a fused supernode is not deferred itself)
+    // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
+    // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates
     S.lvl_defer.assign(S.nlevels, 0);
-    if (H.h_fuse_prev.empty()) { H.h_fuse_prev.assign(ns, -1); H.h_defer.assign(ns, 0); H.h_pair_roff.assign(ns, -1); H.h_pair_coff.assign(ns, -1); }
+    if (H.h_fuse_prev.empty()) { H.h_fuse_prev.assign(3 * (size_t) ns, -1); H.h_defer.assign(ns, 0); H.h_pair_roff.assign(3 * (size_t) ns, -1); H.h_pair_coff.assign(3 * (size_t) ns, -1); }
     if (!getenv("SLUAMD_NO_FUSE") && !H.opt.deterministic && !H.z) {
-        std::vector<int> rowmap, colinfo;
+        static const int maxprev = getenv("SLUAMD_FUSE_MAX_PREV") ? std::max(1, std::min(3, atoi(getenv("SLUAMD_FUSE_MAX_PREV")))) : 1;   // measured: pairs beat groups of 3-4 end to end (longer urgent tiles sit on the panel chain)
+        std::vector<int> rowmap[3], colinfo[3];
         for (int l = 0; l + 1 < S.nlevels; ++l)
             for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) {
                 const int b = S.nodes[i], a = b - 1;
-                if (a < 0 || lvl[a] != l || !t.sn_big[a] || !t.sn_big[b] || H.h_fuse_prev[a] >= 0) continue;
-                if (!build_pair_maps(hs, t, a, b, rowmap, colinfo)) continue;
-                H.h_fuse_prev[b] = a; H.h_defer[a] = 1;
-                H.h_pair_roff[b] = (int) H.h_pair_rowmap.size(); H.h_pair_coff[b] = (int) (H.h_pair_colinfo.size() / 2);
-                H.h_pair_rowmap.insert(H.h_pair_rowmap.end(), rowmap.begin(), rowmap.end());
-                H.h_pair_colinfo.insert(H.h_pair_colinfo.end(), colinfo.begin(), colinfo.end());
+                if (a < 0 || lvl[a] != l || !t.sn_big[a] || !t.sn_big[b]) continue;
+                int srcs[3] = {a, -1, -1}, nsrc = 1;
+                for (int j = 0; j < 3 && H.h_fuse_prev[3 * (size_t) a + j] >= 0; ++j) {
+                    if (nsrc == maxprev) { nsrc = -1; break; }       // a already closes a full group: b starts a new one later
+                    srcs[nsrc++] = H.h_fuse_prev[3 * (size_t) a + j];
+                }
+                if (nsrc < 0) continue;
+                bool ok = true;
+                for (int j = 0; j < nsrc && ok; ++j) ok = build_pair_maps(hs, t, srcs[j], b, rowmap[j], colinfo[j]);
+                if (!ok) {   // the far members do not fit b: fall back to the plain pair when a is not fused itself
+                    if (nsrc > 1 || !build_pair_maps(hs, t, a, b, rowmap[0], colinfo[0])) continue;
+                }
+                for (int j = 0; j < nsrc; ++j) {
+                    const size_t pj = 3 * (size_t) b + j;
+                    H.h_fuse_prev[pj] = srcs[j];
+                    H.h_pair_roff[pj] = (int) H.h_pair_rowmap.size(); H.h_pair_coff[pj] = (int) (H.h_pair_colinfo.size() / 2);
+                    H.h_pair_rowmap.insert(H.h_pair_rowmap.end(), rowmap[j].begin(), rowmap[j].end());
+                    H.h_pair_colinfo.insert(H.h_pair_colinfo.end(), colinfo[j].begin(), colinfo[j].end());
+                }
+                H.h_defer[a] = 1;
                 S.lvl_defer[l] = 1;
                 H.fused_pairs += 1;
             }
