@@ -123,8 +123,6 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipStream_t user_stream = nullptr; bool has_user_stream = false;   // cooperative mode: the caller's (torch/RCCL) stream
     hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
-    hipStream_t rstream = nullptr;          // CU-masked stream for the non-urgent Schur tiles: leaves a few CUs free so
-                                            // that the (LDS-hungry) panel workgroups are not starved by the tile stream
     std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events
     size_t ev_pool_used = 0;
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
@@ -1496,15 +1494,6 @@ static int finish_create(Handle *H, const sluamd_forest_view_t *forests, const s
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIPCHK(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, H->device));
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int c = 0; c < ncu; ++c) if (c % 16 != 0) mask[c / 32] |= 1u << (c % 32);   // keep every 16th CU free
-        if (!getenv("SLUAMD_CUMASK") || hipExtStreamCreateWithCUMask(&H->rstream, (uint32_t) mask.size(), mask.data()) != hipSuccess) {
-            (void) hipGetLastError();
-            H->rstream = nullptr;
-        }
     }
     HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
     const HostStruct &hs = H->hs;
@@ -1625,7 +1614,6 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const DevTables &T = H->T;
     const bool lookahead = !H->profile && !H->opt.deterministic && getenv("SLUAMD_NO_LOOKAHEAD") == nullptr;
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
-    hipStream_t rs = (lookahead && H->rstream) ? H->rstream : s;
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
                      const int4 *ulist, int skip_level) {
         ev_begin(H, H->ev_schur, H->ev_schur_used);
@@ -1658,7 +1646,6 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     if (lookahead && S.nlevels) {
         hipEvent_t e = next_event(H);    // the side streams must see everything queued so far on the main stream
         hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
-        if (rs != s) hipStreamWaitEvent(rs, e, 0);
     }
     bool panel_queued = false;           // panel(l) already queued on ps by the previous level's look-ahead
     for (int l = 0; l < S.nlevels; ++l) {
@@ -1677,8 +1664,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);     // Schur(l) needs panel(l)
         }
         const int nbig = S.n_big[l];
-        // look ahead only where the next level's panel work is small enough to live on the few CUs the masked
-        // tile stream leaves free; big (throughput-bound) panel levels run after the full Schur update instead
+        // look-ahead split of this level's Schur update (SLUAMD_LOOKAHEAD_MAX_STRIPS bounds the panel work overlapped)
         bool split = false;
         if (lookahead && l + 1 < S.nlevels) {
             const int po1 = S.lvl_poff[l + 1], nn1 = S.lvl_off[l + 2] - S.lvl_off[l + 1];
@@ -1691,8 +1677,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const bool urgent_pass = split || (T.defer && S.lvl_defer[l]);
         // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
         for (int pass = urgent_pass ? 0 : 1; pass < 2; ++pass) {
-            hipStream_t st = (pass == 1 && split) ? rs : s;
-            if (st != s) { hipEvent_t e = next_event(H); hipEventRecord(e, s); hipStreamWaitEvent(st, e, 0); }
+            hipStream_t st = s;   // every Schur launch stays on the main stream (side streams for the bulk tiles measured slower)
             for (int g = 0; g < 2; ++g) {
                 const int cnt = g == 0 ? nbig : nn - nbig;
                 if (!cnt) continue;
@@ -1720,7 +1705,6 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                     }
                 }
             }
-            if (st != s) { hipEvent_t e = next_event(H); hipEventRecord(e, st); hipStreamWaitEvent(s, e, 0); }   // later main-stream work follows rest(l)
             if (pass == 0 && split) {
                 // panel(l+1) may start once the urgent tiles of level l (and, by stream order, the rest of level
                 // l-1) are complete; it then overlaps with the rest of level l
@@ -2389,7 +2373,6 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->ev1) hipEventDestroy(H->ev1);
     for (auto e : H->ev_pool) hipEventDestroy(e);
     if (H->pstream) hipStreamDestroy(H->pstream);
-    if (H->rstream) hipStreamDestroy(H->rstream);
     if (H->stream) hipStreamDestroy(H->stream);
     delete h;
 }
