@@ -50,7 +50,7 @@ def test_z_sharded_factor_and_solve_gloo(world, N, nrhs, tmp_path):
     assert np.abs(r["sol"] - r["xt"]).max() < 1e-10
 
 
-@pytest.mark.parametrize("world,N,nrhs", [(2, 8, 1), (4, 10, 2)])
+@pytest.mark.parametrize("world,N,nrhs", [(2, 8, 1), (4, 10, 2), (8, 12, 1)])
 def test_z_sharded_cooperative_ancestors_gloo(world, N, nrhs, tmp_path):
     """Same system, ancestor forests factored cooperatively by the layers that share them (grid3d.pdgstrf3d_coop)."""
     out = str(tmp_path / "r0.npz")
