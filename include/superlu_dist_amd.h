@@ -187,25 +187,16 @@ int sluamd_zCreateLUHandleFromSymb(sluamd_handle_t *h, sluamd_symb_t s, const sl
                                    const sluamd_int_t *colind, const sluamd_doublecomplex *nzval,
                                    const sluamd_int_t *perm_c_final, const sluamd_options_t *opt);
 void sluamd_symb_free(sluamd_symb_t s);
-/* 1 x 1 x npdep grids (Z sharding): elimination-forest partition (getForests' job, supernodalForest.c; tree ids in
- * heap order like getGridTrees, supernodal_etree.c:840-851) and a handle that stores only layer `myz`'s sub-forest
- * plus its ancestors. */
+/* elimination-forest partition for npdep Z layers (getForests' job, supernodalForest.c; tree ids in heap order like
+ * getGridTrees, supernodal_etree.c:840-851): sn_tree[k] = forest of supernode k (see sluamd_dCreateLUHandleFromSymbGrid) */
 int sluamd_symb_partition(sluamd_symb_t s, int32_t npdep, int32_t *sn_tree);
-int sluamd_dCreateLUHandleFromSymb3D(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
-                                     const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
-                                     const sluamd_options_t *opt, int32_t npdep, int32_t myz, const int32_t *sn_tree);
 /* re-run the device-side distribution (zero-fill + scatter of A) on such a handle: refactor loops */
 int sluamd_dResetValues(sluamd_handle_t h);
 
-/* ---- auxiliary (timing / multi-rank orchestration / tests) ---- */
+/* ---- auxiliary (timing / tests) ---- */
 int sluamd_device_synchronize(void);
 int sluamd_set_profile(sluamd_handle_t h, int on);         /* per-kernel-family HIP-event timing in stats */
-int sluamd_pdgstrf3d_level(sluamd_handle_t h, int zlevel, double thresh); /* one Z level of pdgstrf3d.c:333-385 */
 int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny_pivots);
-int sluamd_arena(sluamd_handle_t h, double **d_val, int64_t *nnzL, int64_t *nnzU); /* value arena [L | U] in HBM */
-int sluamd_local_offsets(sluamd_handle_t h, int64_t *lval_off, int64_t *uval_off); /* [nsupers+1] each */
-/* forward (dir=+1) / backward (dir=-1) solve of one Z level on a device-resident x (multi-rank orchestration) */
-int sluamd_pdgstrs3d_level(sluamd_handle_t h, int zlevel, int dir, double *d_x, int64_t ldx, int32_t nrhs);
 int sluamd_mfma_selftest(const double *A16x4, const double *B4x16, double *D16x16);
 
 /* ---- iterative refinement: pdgsrfs3d (SRC/double/pdgsrfs.c:345-510) with its SpMV pdgsmv (SRC/double/pdgsmv.c) on the
@@ -220,23 +211,69 @@ int sluamd_pdgsrfs3d(sluamd_handle_t h, const double *B, int64_t ldb, double *X,
 int sluamd_pdgsrfs3d_dev(sluamd_handle_t h, const double *d_B, int64_t ldb, double *d_X, int64_t ldx, int32_t nrhs,
                          double *berr, int32_t *steps);
 
-/* ---- cooperative factorisation of a shared ancestor forest (1 x 1 x Pz grids) ----
- * The reference leaves the 2^zlevel layers that share an ancestor forest idle but one (pdgstrf3d.c:333-385 with
- * myZeroTrIdxs); on xGMI-connected GPUs the idle layers are put to work instead: storage of the forest stays
- * replicated, block column jb is kept current by rank jb % G ("owner computes", the 1-D analogue of the reference's
- * 2-D block-cyclic grid, pdgstrf2.c / dSchCompUdt-2Ddynamic.c), and the only exchange per DAG level is a sum
- * all-reduce of a staging buffer holding that level's factored L panels (the panel broadcast of dIBcastRecvLPanel,
- * pd3dcomm-style).  All calls queue on the stream given to sluamd_set_stream (the caller's RCCL stream order). */
-int sluamd_set_stream(sluamd_handle_t h, void *hip_stream);
-int sluamd_coop_info(sluamd_handle_t h, int zlevel, int *dag_levels, int64_t *max_stage_doubles);
-int sluamd_coop_level_size(sluamd_handle_t h, int zlevel, int dag_level, int *nnodes, int64_t *stage_doubles);
-int sluamd_coop_level_nodes(sluamd_handle_t h, int zlevel, int dag_level, int *nodes_out);
-/* d_stage == NULL in the next two calls: no pack / unpack; the caller broadcasts the owner's panel from the ranges below */
-int sluamd_coop_panel_ptrs(sluamd_handle_t h, int k, double **d_lpanel, int64_t *lpanel_doubles, double **d_dinv,
-                           int64_t *dinv_doubles);
-int sluamd_coop_panel(sluamd_handle_t h, int zlevel, int dag_level, int G, int g, double thresh, double *d_stage);
-int sluamd_coop_update(sluamd_handle_t h, int zlevel, int dag_level, int G, int g, const double *d_stage);
-int sluamd_coop_mask_u(sluamd_handle_t h, int zlevel, int G, int g);
+/* ------------------------------------------------------------------------------------------------
+ * Process grids: nprow x npcol x npdep ranks, one rank per GPU (gridinfo3d_t, superlu_defs.h:385-420).
+ *
+ * The reference exchanges panels with MPI inside pdgstrf3d / pdgstrs3d:
+ *   - inside a 2-D layer, per supernode k: the factored diagonal block goes down process column k % Pc and along process
+ *     row k % Pr (dDiagFactIBCast, dtrfCommWrapper.c:32-118), the L panel along the process rows and the U panel down the
+ *     process columns (dIBcastRecvLPanel / dIBcastRecvUPanel, dtrfCommWrapper.c:377-548, dcommunication_aux.c:32-430);
+ *   - between layers, after every level of the elimination forest: the pairwise sum of the replicated ancestor panels
+ *     (dreduceAllAncestors3d, pd3dcomm.c:1046-1081) and MPI_Allreduce(MIN) of info (pdgstrf3d.c:388-392);
+ *   - in the solve: x_k down the process column, lsum along the process row, and the Z exchanges of the ancestor part of
+ *     x (pdgstrs3d.c:1405-1535, :7180-7181).
+ * Here all of it runs inside the library, in C, over a communicator object: RCCL called directly (ncclSend / ncclRecv
+ * groups on the library's HIP streams, so an exchange overlaps the Schur tiles of the previous level), or a transport
+ * supplied by the application (MPI in the reference-side binding of INTEGRATION.md), or an in-process world (tests).
+ * World rank of grid position (row, col, z) = (z * nprow + row) * npcol + col  (layer-major, superlu_grid3d.c).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct sluamd_comm_s *sluamd_comm_t;
+
+#define SLUAMD_UNIQUE_ID_BYTES 128
+/* RCCL: rank 0 calls sluamd_comm_rccl_unique_id and ships the 128 bytes to every rank by any means (MPI_Bcast, a file,
+ * a torch.distributed store); every rank then calls sluamd_comm_create_rccl (collective: ncclCommInitRank). */
+int sluamd_comm_rccl_unique_id(void *id128);
+int sluamd_comm_create_rccl(sluamd_comm_t *comm, const void *id128, int nprow, int npcol, int npdep, int myrow, int mycol,
+                            int myz, int device);
+
+/* Application-supplied transport on HOST buffers (the library stages device ranges through pinned memory).  isend / irecv
+ * start one message to / from world rank `peer` (messages between one pair of ranks match in the order they were
+ * started); waitall completes every message started since the last waitall; allreduce_min_i32 runs over the whole grid.
+ * All return 0 on success. */
+typedef struct sluamd_comm_callbacks {
+    void *ctx;
+    int (*isend)(void *ctx, const void *buf, int64_t bytes, int peer);
+    int (*irecv)(void *ctx, void *buf, int64_t bytes, int peer);
+    int (*waitall)(void *ctx);
+    int (*allreduce_min_i32)(void *ctx, int32_t *v);
+} sluamd_comm_callbacks_t;
+int sluamd_comm_create_callbacks(sluamd_comm_t *comm, const sluamd_comm_callbacks_t *cb, int nprow, int npcol, int npdep,
+                                 int myrow, int mycol, int myz);
+
+/* In-process world: comms[nprow*npcol*npdep] (indexed by world rank), one per thread; any number of ranks per device. */
+int sluamd_comm_create_local(sluamd_comm_t *comms, int nprow, int npcol, int npdep);
+int sluamd_comm_rank(sluamd_comm_t comm);
+int sluamd_comm_size(sluamd_comm_t comm);
+void sluamd_comm_destroy(sluamd_comm_t comm);
+
+/* sluamd_dCreateLUHandle for one rank of a process grid (collective over `comm`): `lu` is that rank's dLocalLU_t view
+ * (pointer arrays of ceil(nsupers/npcol) block columns and ceil(nsupers/nprow) block rows, local index lk = k / npcol,
+ * lb = k / nprow; superlu_defs.h:270-279), `forests` its dtrf3Dpartition_t (required when npdep > 1).  The index arrays
+ * of the panels a rank will receive are exchanged once here (the reference ships them with every panel message,
+ * dIBcast_LPanel, dcommunication_aux.c:32-60).  The handle then works with the single-rank entry points:
+ * sluamd_pdgstrf3d / sluamd_pdgstrs3d[_dev] / sluamd_dCopyLU2Host / sluamd_dSetValues become collective calls.
+ * `comm` must outlive the handle. */
+int sluamd_dCreateLUHandleGrid(sluamd_handle_t *h, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
+                               const sluamd_options_t *opt, sluamd_comm_t comm);
+/* Same from the library's own symbolic factorisation (every rank holds the complete structure `s`; no structure exchange):
+ * the store of this rank's grid position is built and A's values are distributed on the device (pddistribute3d +
+ * dinit3DLUstructForest, pddistribute3d.c:1357, pd3dcomm.c:334-800).  sn_tree (sluamd_symb_partition) may be NULL when
+ * npdep == 1. */
+int sluamd_dCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
+                                       const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
+                                       const sluamd_options_t *opt, const int32_t *sn_tree, sluamd_comm_t comm);
+/* Grid solve semantics (pdgstrs3d between pdReDistribute3d_B_to_X and pdReDistribute3d_X_to_B): every rank passes the
+ * COMPLETE permuted right-hand side x = Pc*Pr*b (n x nrhs, replicated) and every rank receives the complete solution. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,403 @@
+// oracle/emul/engine_cpu.cpp -- TEST INFRASTRUCTURE: serial CPU restatement of the eng:: interface
+// (superlu_dist_amd/csrc/sluamd_internal.h), one plain loop nest per kernel of sluamd_kernels.hip, consuming the SAME
+// device tables (DevTables, level schedules, tile lists, exchange staging).  Linked with the library's host sources into
+// oracle/libsluamd_emul.so so that `-m "not gpu"` tests can run the planning and the multi-rank orchestration
+// (Z forests + ancestor reduction, XY block-cyclic panel exchange, distributed solve) against the golden fixtures
+// without a GPU.  The product library (libsluamd.so) never links this file.
+//
+// Arithmetic follows the reference routines each kernel replaces: Local_Dgstrf2 (pdgstrf2.c:508-601), dLPanelTrSolve
+// (dtrfCommWrapper.c:120-223), dTrs2_GatherTrsmScatter (pdgstrf2.c:757-840), dblock_gemm_scatter + dscatter_l +
+// scatter_u (dscatter3d.c:81-189, dscatter.c:109-194, dscatter3d.c:555-631), dlsum_fmod_inv / dlsum_bmod_inv
+// (pdgstrs_lsum.c:414, :1362) -- with the kernels' blocking by 32 (inverted diagonal sub-blocks) kept.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "sluamd_internal.h"
+
+namespace sluamd {
+namespace eng {
+
+static int find_node(const int *prefix, int nn, int id)
+{
+    int lo = 0, hi = nn;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (prefix[mid] <= id) lo = mid; else hi = mid; }
+    return lo;
+}
+
+int setup() { return 0; }
+
+void diag_lu(hipStream_t, const DevTables &T, const int *nodes, int nn, int, int replace_tiny, double thresh, int *info)
+{
+    for (int i = 0; i < nn; ++i) {
+        const int k = nodes[i];
+        if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_dlda[k];
+        double *A = T.val + T.sn_dptr[k];
+        for (int j = 0; j < ns; ++j) {
+            double p = A[j + (size_t) j * lda];
+            if (replace_tiny && std::fabs(p) < thresh) { p = (p < 0) ? -thresh : thresh; A[j + (size_t) j * lda] = p; info[1] += 1; }
+            if (p == 0.0) info[0] = std::min(info[0], fst + j + 1);
+            const double rinv = (p != 0.0) ? 1.0 / p : 1.0;
+            for (int r = j + 1; r < ns; ++r) A[r + (size_t) j * lda] *= rinv;
+            for (int c = j + 1; c < ns; ++c) {
+                const double u = A[j + (size_t) c * lda];
+                for (int r = j + 1; r < ns; ++r) A[r + (size_t) c * lda] -= A[r + (size_t) j * lda] * u;
+            }
+        }
+    }
+}
+
+void diag_inv(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask)
+{
+    for (int task = 0; task < ntask; ++task) {
+        const int ni = find_node(prefix, nn, task);
+        const int k = nodes[ni];
+        if (!(T.sn_flags[k] & SNF_HAS_DIAG)) continue;
+        const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB;
+        const int rem = task - prefix[ni], typ = rem / nblk, b = rem - typ * nblk, o = b * DB;
+        const int lda = T.sn_dlda[k];
+        const double *A = T.val + T.sn_dptr[k];
+        double Bs[DB][DB], X[DB][DB];
+        for (int i = 0; i < DB; ++i)
+            for (int c = 0; c < DB; ++c) {
+                double v = (i == c) ? 1.0 : 0.0;
+                if (o + i < ns && o + c < ns && i <= c) {
+                    if (typ == 0) v = A[o + i + (size_t) (o + c) * lda];
+                    else if (i < c) v = A[o + c + (size_t) (o + i) * lda];
+                }
+                Bs[i][c] = v;
+            }
+        for (int c = 0; c < DB; ++c)
+            for (int i = c; i >= 0; --i) {
+                double a = (i == c) ? 1.0 : 0.0;
+                for (int jj = i + 1; jj <= c; ++jj) a -= Bs[i][jj] * X[jj][c];
+                X[i][c] = a / Bs[i][i];
+            }
+        double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB;
+        for (int c = 0; c < DB; ++c) for (int i = 0; i < DB; ++i) dst[c * DB + i] = (i <= c) ? X[i][c] : 0.0;
+    }
+}
+
+// X (1 x ns row vector, zero-padded to nsp) <- X * T^-1, T upper triangular given by tfun(kk, cc) and its inverted 32x32
+// diagonal blocks D(kk, cc) = dinv[blk][cc * 32 + kk]
+template <class TF>
+static void row_trsm(double *x, int ns, int nsp, const double *dinv, TF tfun)
+{
+    for (int jb = 0; jb < nsp; jb += DB) {
+        double rhs[DB], out[DB];
+        for (int c = 0; c < DB; ++c) {
+            double a = x[jb + c];
+            for (int kk = 0; kk < jb; ++kk) a -= x[kk] * tfun(kk, jb + c);
+            rhs[c] = a;
+        }
+        const double *D = dinv + (size_t) (jb / DB) * DB * DB;
+        for (int c = 0; c < DB; ++c) { double a = 0; for (int kk = 0; kk < DB; ++kk) a += rhs[kk] * D[c * DB + kk]; out[c] = a; }
+        for (int c = 0; c < DB; ++c) x[jb + c] = out[c];
+    }
+    (void) ns;
+}
+
+void panel_trsm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs, int)
+{
+    std::vector<double> x;
+    for (int w = 0; w < nl + nu; ++w) {
+        const bool lmode = w < nl;
+        const int id = lmode ? w : w - nl;
+        const int ni = find_node(lmode ? lprefix : uprefix, nn, id);
+        const int k = nodes[ni];
+        const int strip = id - (lmode ? lprefix : uprefix)[ni];
+        const int klst = T.xsup[k + 1], ns = klst - T.xsup[k], nsp = (ns + DB - 1) & ~(DB - 1), nblk = nsp / DB;
+        const int lda = T.sn_nsupr[k], ldd = T.sn_dlda[k];
+        double *A = T.val + T.sn_lval[k];
+        const double *Dg = T.val + T.sn_dptr[k];
+        double *Uv = T.val + T.sn_uval[k];
+        x.assign(nsp, 0.0);
+        if (lmode) {
+            const double *dinv = T.dinv + T.sn_dinv[k];
+            auto tf = [&](int kk, int cc) { return (kk < ns && cc < ns) ? Dg[kk + (size_t) cc * ldd] : 0.0; };
+            for (int r = 0; r < rs; ++r) {
+                const int row = T.sn_ldiag[k] + strip * rs + r;
+                if (row >= lda) break;
+                for (int c = 0; c < nsp; ++c) x[c] = c < ns ? A[row + (size_t) c * lda] : 0.0;
+                row_trsm(x.data(), ns, nsp, dinv, tf);
+                for (int c = 0; c < ns; ++c) A[row + (size_t) c * lda] = x[c];
+            }
+        } else {
+            const double *dinv = T.dinv + T.sn_dinv[k] + (size_t) nblk * DB * DB;
+            auto tf = [&](int kk, int cc) { return (kk < ns && cc < ns) ? Dg[cc + (size_t) kk * ldd] : 0.0; };   // L_kk^T
+            for (int r = 0; r < rs; ++r) {
+                const int cr = strip * rs + r;
+                if (cr >= T.sn_ncolu[k]) break;
+                const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+                int lo = 0, hi = nub;
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= cr) lo = mid; else hi = mid; }
+                const int b = ub0 + lo;
+                const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+                const int jj = T.unzcol[u0 + (cr - T.ub_stcol[b])];
+                const int ld = ns - (klst - T.uidx[u0 + jj]);
+                const int cp = T.ucolptr[u0 + jj];
+                for (int c = 0; c < nsp; ++c) x[c] = (c >= ld && c < ns) ? Uv[cp + (c - ld)] : 0.0;
+                row_trsm(x.data(), ns, nsp, dinv, tf);
+                for (int c = ld; c < ns; ++c) Uv[cp + (c - ld)] = x[c];
+            }
+        }
+    }
+}
+
+void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
+           const int4 *ulist, const int *sn_level, int skip_level)
+{
+    (void) cfg;
+    std::vector<double> acc, lrow;
+    std::vector<int> rowmap, colmap;
+    for (int bid0 = 0; bid0 < ntiles; ++bid0) {
+        const int bid = bid0 + id_base;
+        int k, rt, ct;
+        if (ulist) { k = ulist[bid].x; rt = ulist[bid].y; ct = ulist[bid].z; }
+        else {
+            const int ni = find_node(prefix, nn, bid);
+            k = nodes[ni];
+            const int local = bid - prefix[ni], nct = T.sn_nct[k];
+            rt = local / nct; ct = local - rt * nct;
+        }
+        const int4 R = T.rtile[T.sn_rt_off[k] + rt], C = T.ctile[T.sn_ct_off[k] + ct];
+        const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
+        const int nr = R.z, nc = C.z;
+        const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
+        if (!ulist && skip_level >= 0 && (sn_level[ib] == skip_level || sn_level[jb] == skip_level)) continue;
+        if (!ulist && T.defer && T.defer[k]) continue;
+        const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
+        const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
+        const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
+        acc.assign((size_t) nr * nc, 0.0);
+        int nprev = 0;
+        if (T.fuse_prev) while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev;
+        for (int src = 0; src <= nprev; ++src) {
+            if (src < nprev) {
+                const int pj = 3 * k + (nprev - 1 - src);
+                const int ks = T.fuse_prev[pj];
+                const int nss = T.xsup[ks + 1] - T.xsup[ks], ldas = T.sn_nsupr[ks];
+                const int *cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[pj] + T.ub_stcol[ub] + C.y);
+                const double *Ls = T.val + T.sn_lval[ks], *Us = T.val + T.sn_uval[ks];
+                for (int c = 0; c < nc; ++c) {
+                    const int cp = cinfo[2 * c], lead = cinfo[2 * c + 1];
+                    for (int r = 0; r < nr; ++r) {
+                        const int ra = T.pair_rowmap[T.pair_roff[pj] + R.w + r];
+                        if (ra < 0) continue;
+                        double a = 0;
+                        for (int kk = lead; kk < nss; ++kk) a += Ls[ra + (size_t) kk * ldas] * Us[cp + (kk - lead)];
+                        acc[r + (size_t) c * nr] += a;
+                    }
+                }
+            } else {
+                const int lda = T.sn_nsupr[k];
+                const double *Lp = T.val + T.sn_lval[k] + R.w, *Uv = T.val + T.sn_uval[k];
+                for (int c = 0; c < nc; ++c) {
+                    const int jj = T.unzcol[uix0 + C.y + c];
+                    const int lead = ns - (klst - T.uidx[uix0 + jj]), cp = T.ucolptr[uix0 + jj];
+                    for (int r = 0; r < nr; ++r) {
+                        double a = 0;
+                        for (int kk = lead; kk < ns; ++kk) a += Lp[r + (size_t) kk * lda] * Uv[cp + (kk - lead)];
+                        acc[r + (size_t) c * nr] += a;
+                    }
+                }
+            }
+        }
+        // destination lookup + scatter
+        const bool ldest = ib >= jb;
+        const int o = ldest ? T.sn_lb_off[jb] : T.sn_ub_off[ib];
+        const int nb = ldest ? T.sn_nlb[jb] : T.sn_nub[ib];
+        const int *dir = ldest ? T.lbs_gid : T.ub_gid;
+        const int want = ldest ? ib : jb;
+        int pos = -1;
+        for (int q = 0; q < nb; ++q) if (dir[o + q] == want) { pos = q; break; }
+        if (pos < 0) { info[2] += 1; continue; }
+        if (ldest) {
+            const int d = o + T.lbs_idx[o + pos];
+            const int rowoff = T.lb_rowoff[d], dn = T.lb_nbrow[d];
+            const int *drows = T.lidx + T.sn_lidx[jb] + T.lb_lptr[d];
+            double *dst = T.val + T.sn_lval[jb];
+            const int ldv = T.sn_nsupr[jb];
+            for (int r = 0; r < nr; ++r) {
+                int di = -1;
+                for (int q = 0; q < dn; ++q) if (drows[q] == lsub[r]) { di = q; break; }
+                if (di < 0) { std::fprintf(stderr, "engine_cpu: destination row missing\n"); std::abort(); }
+                for (int c = 0; c < nc; ++c) {
+                    const int jj = T.unzcol[uix0 + C.y + c];
+                    dst[rowoff + di + (size_t) jj * ldv] -= acc[r + (size_t) c * nr];
+                }
+            }
+        } else {
+            const int64_t d0 = T.sn_uidx[ib] + T.ub_iukp[o + pos];
+            double *dst = T.val + T.sn_uval[ib];
+            for (int c = 0; c < nc; ++c) {
+                const int jj = T.unzcol[uix0 + C.y + c];
+                const int cm = T.ucolptr[d0 + jj] - T.uidx[d0 + jj];
+                for (int r = 0; r < nr; ++r) dst[cm + lsub[r]] -= acc[r + (size_t) c * nr];
+            }
+        }
+    }
+}
+
+void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int)
+{
+    std::vector<double> xs, ys(DB);
+    for (int i0 = 0; i0 < nn; ++i0) {
+        const int k = nodes[i0];
+        if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_dlda[k], nblk = (ns + DB - 1) / DB;
+        const double *A = T.val + T.sn_dptr[k];
+        const double *dinv = T.dinv + T.sn_dinv[k] + (lower ? (size_t) nblk * DB * DB : 0);
+        for (int q = 0; q < nrhs; ++q) {
+            double *xk = x + fst + (int64_t) q * ldx;
+            for (int bb = 0; bb < nblk; ++bb) {
+                const int b = lower ? bb : nblk - 1 - bb, o = b * DB, nb = std::min(DB, ns - o);
+                const double *D = dinv + (size_t) b * DB * DB;
+                for (int r = 0; r < nb; ++r) {
+                    double a = 0;
+                    for (int c = 0; c < nb; ++c) {
+                        const double dv = lower ? (c <= r ? D[r * DB + c] : 0.0) : (c >= r ? D[c * DB + r] : 0.0);
+                        a += dv * xk[o + c];
+                    }
+                    ys[r] = a;
+                }
+                for (int r = 0; r < nb; ++r) xk[o + r] = ys[r];
+                const int r0 = lower ? o + nb : 0, r1 = lower ? ns : o;
+                for (int i = r0; i < r1; ++i) {
+                    double a = 0;
+                    for (int c = 0; c < nb; ++c) a += A[i + (size_t) (o + c) * lda] * ys[c];
+                    xk[i] -= a;
+                }
+            }
+        }
+    }
+}
+
+void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int)
+{
+    for (int w = 0; w < nwork; ++w) {
+        const int ni = find_node(prefix, nn, w);
+        const int k = nodes[ni], strip = w - prefix[ni];
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
+        const int *lsub = T.lidx + T.sn_lidx[k];
+        for (int t = 0; t < 256; ++t) {
+            const int row = T.sn_ldiag[k] + strip * 256 + t;
+            if (row >= lda) break;
+            int p = BC_HEADER, base = 0, grow = -1;
+            for (int b = 0; b < lsub[0]; ++b) {
+                const int nbrow = lsub[p + 1];
+                if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
+                base += nbrow; p += LB_DESCRIPTOR + nbrow;
+            }
+            const double *L = T.val + T.sn_lval[k] + row;
+            for (int r = 0; r < nrhs; ++r) {
+                double acc = 0;
+                for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * x[fst + kk + (int64_t) r * ldx];
+                x[grow + (int64_t) r * ldx] -= acc;
+            }
+        }
+    }
+}
+
+void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs)
+{
+    for (int w = 0; w < nwork; ++w) {
+        const int ni = find_node(prefix, nn, w);
+        const int k = nodes[ni], chunk = w - prefix[ni];
+        const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
+        const int ncol = std::min(64, T.sn_ncolu[k] - chunk * 64);
+        const double *Uv = T.val + T.sn_uval[k];
+        for (int t = 0; t < ncol; ++t) {
+            const int c = chunk * 64 + t;
+            const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+            int lo = 0, hi = nub;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
+            const int b = ub0 + lo;
+            const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+            const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
+            const int ld = ns - (klst - T.uidx[u0 + jj]), cp = T.ucolptr[u0 + jj], gc = T.xsup[T.ub_gid[b]] + jj;
+            for (int r = 0; r < nrhs; ++r) {
+                const double xv = x[gc + (int64_t) r * ldx];
+                for (int i = ld; i < ns; ++i) x[fst + i + (int64_t) r * ldx] -= Uv[cp + (i - ld)] * xv;
+            }
+        }
+    }
+}
+
+void scatter_values(hipStream_t, double *val, const int64_t *pos, const double *a, int64_t nnz)
+{
+    for (int64_t e = 0; e < nnz; ++e) val[pos[e]] = a[e];
+}
+
+void rfs_residual(hipStream_t, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
+                  double *r_perm, unsigned long long *s_out, double safe1, double safe2)
+{
+    double best = 0;
+    for (int i = 0; i < n; ++i) {
+        double ax = 0, t = 0;
+        for (int e = rp[i]; e < rp[i + 1]; ++e) { ax += av[e] * x[ci[e]]; t += std::fabs(av[e]) * std::fabs(x[ci[e]]); }
+        const double r = b[i] - ax;
+        t += std::fabs(b[i]);
+        r_perm[pc[i]] = r;
+        double q = 0;
+        if (t > safe2) q = std::fabs(r) / t; else if (t != 0.0) q = (safe1 + std::fabs(r)) / t;
+        best = std::max(best, q);
+    }
+    double cur; std::memcpy(&cur, s_out, 8);
+    if (best > cur) std::memcpy(s_out, &best, 8);
+}
+
+void rfs_update(hipStream_t, int n, const int *pc, const double *dx_perm, double *x)
+{
+    for (int i = 0; i < n; ++i) x[i] += dx_perm[pc[i]];
+}
+
+void axpy(hipStream_t, int64_t n, double a, const double *x, double *y)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] += a * x[i];
+}
+
+void pack_diag(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage)
+{
+    for (int w = 0; w < nwork; ++w) {
+        const int ni = find_node(prefix, nn, w);
+        const int k = nodes[ni], ns = T.xsup[k + 1] - T.xsup[k];
+        const int e0 = (w - prefix[ni]) * 1024, e1 = std::min(e0 + 1024, ns * ns);
+        const double *A = T.val + T.sn_dptr[k];
+        const int lda = T.sn_dlda[k];
+        double *S = stage + off[ni];
+        for (int e = e0; e < e1; ++e) S[e] = A[(e % ns) + (size_t) (e / ns) * lda];
+    }
+}
+
+void xseg_copy(hipStream_t, double *x, int64_t ldx, int nrhs, const int *runs, int nruns, int64_t total, double *buf, int mode)
+{
+    for (int q = 0; q < nrhs; ++q)
+        for (int r = 0; r < nruns; ++r)
+            for (int i = 0; i < runs[3 * r + 1]; ++i) {
+                double *xp = x + runs[3 * r] + i + (int64_t) q * ldx;
+                double *bp = buf + runs[3 * r + 2] + i + (int64_t) q * total;
+                if (mode == 0) *bp = *xp; else if (mode == 1) *xp = *bp; else if (mode == 2) *xp += *bp; else { *bp = *xp; *xp = 0.0; }
+            }
+}
+
+int mfma_selftest(const double *A, const double *B, double *D)
+{
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double a = 0; for (int k = 0; k < 4; ++k) a += A[i * 4 + k] * B[k * 16 + j]; D[i * 16 + j] = a; }
+    return 0;
+}
+
+// complex16: not restated here (the multi-rank paths this build exists for are double precision)
+static void no_z() { std::fprintf(stderr, "engine_cpu: complex16 kernels are not emulated\n"); std::abort(); }
+void zdiag_lu(hipStream_t, const DevTables &, const int *, int, int, int, double, int *) { no_z(); }
+void zpanel_trsm(hipStream_t, const DevTables &, const int *, const int *, const int *, int, int, int) { no_z(); }
+void zschur(hipStream_t, const DevTables &, const int *, const int *, int, int, int, int *) { no_z(); }
+void zsolve_diag(hipStream_t, bool, const DevTables &, const int *, int, void *, int64_t, int, int) { no_z(); }
+void zfwd_update(hipStream_t, const DevTables &, const int *, const int *, int, int, void *, int64_t, int, int) { no_z(); }
+void zbwd_update(hipStream_t, const DevTables &, const int *, const int *, int, int, void *, int64_t, int) { no_z(); }
+void zscatter_values(hipStream_t, void *, const int64_t *, const void *, int64_t) { no_z(); }
+
+}  // namespace eng
+}  // namespace sluamd

@@ -46,25 +46,33 @@ EXPORTS = [
     "sluamd_symb_view", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
     "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
     "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",
-    "sluamd_set_stream", "sluamd_coop_info", "sluamd_coop_level_size", "sluamd_coop_level_nodes", "sluamd_coop_panel_ptrs",
-    "sluamd_coop_panel", "sluamd_coop_update", "sluamd_coop_mask_u",
+    "sluamd_comm_rccl_unique_id", "sluamd_comm_create_rccl", "sluamd_comm_create_callbacks", "sluamd_comm_create_local",
+    "sluamd_comm_rank", "sluamd_comm_size", "sluamd_comm_destroy", "sluamd_dCreateLUHandleGrid",
+    "sluamd_dCreateLUHandleFromSymbGrid",
 ]
+
+# sluamd_comm_callbacks_t
+ISEND_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+IRECV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+WAITALL_T = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALLMIN_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32))
+
+
+class CommCallbacks(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("isend", ISEND_T), ("irecv", IRECV_T), ("waitall", WAITALL_T),
+                ("allreduce_min_i32", ALLMIN_T)]
+
 
 _lib = None
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_SO):
-        raise RuntimeError(f"{_SO} not built: run `make -C superlu_dist_amd/csrc` (or __graft_entry__.build()); "
-                           "there is no CPU fallback for the hot path")
-    L = C.CDLL(_SO)
+def bind(L):
+    """Declare the C ABI's signatures on an opened library object."""
     L.sluamd_last_error.restype = C.c_char_p
     L.sluamd_dDestroyLUHandle.restype = None
     L.sluamd_symb_free.restype = None
     L.sluamd_default_options.restype = None
+    L.sluamd_comm_destroy.restype = None
     L.sluamd_dsymbfact.argtypes = [C.POINTER(C.c_void_p), C.c_int64, P_int, P_int, P_int, C.c_int32, C.c_int32, P_int]
     L.sluamd_symb_info.argtypes = [C.c_void_p, P_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), P_dbl]
@@ -74,17 +82,18 @@ def load():
     P64 = C.POINTER(C.c_int64)
     L.sluamd_symb_export.argtypes = [C.c_void_p, P_int, P64, P_int, P64, P_dbl, P64, P_int, P64, P_dbl]
     L.sluamd_dCreateLUHandle.argtypes = [C.POINTER(C.c_void_p), C.POINTER(LUView), C.POINTER(ForestView), C.POINTER(Options)]
+    L.sluamd_dCreateLUHandleGrid.argtypes = [C.POINTER(C.c_void_p), C.POINTER(LUView), C.POINTER(ForestView), C.POINTER(Options), C.c_void_p]
     L.sluamd_dCreateLUHandleFromSymb.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int, C.POINTER(Options)]
+    L.sluamd_dCreateLUHandleFromSymbGrid.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int, C.POINTER(Options),
+                                                     P_int, C.c_void_p]
     L.sluamd_dSetValues.argtypes = [C.c_void_p, C.POINTER(LUView)]
     L.sluamd_pdgstrf3d.argtypes = [C.c_void_p, C.c_double, P_int]
-    L.sluamd_pdgstrf3d_level.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.sluamd_factor_info.argtypes = [C.c_void_p, P_int, P_int]
     L.sluamd_dCopyLU2Host.argtypes = [C.c_void_p, C.POINTER(LUView)]
     L.sluamd_pdgstrs3d.argtypes = [C.c_void_p, P_dbl, C.c_int64, C.c_int32]
     L.sluamd_pdgstrs3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_dDestroyLUHandle.argtypes = [C.c_void_p]
     L.sluamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
-    L.sluamd_arena.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.sluamd_mfma_selftest.argtypes = [P_dbl, P_dbl, P_dbl]
     L.sluamd_dResetValues.argtypes = [C.c_void_p]
     L.sluamd_zCreateLUHandle.argtypes = L.sluamd_dCreateLUHandle.argtypes     # zLUview is layout-identical to dLUview
@@ -94,24 +103,29 @@ def load():
     L.sluamd_pzgstrs3d.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_zCreateLUHandleFromSymb.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, C.c_void_p, P_int, C.POINTER(Options)]
     L.sluamd_symb_partition.argtypes = [C.c_void_p, C.c_int32, P_int]
-    L.sluamd_dCreateLUHandleFromSymb3D.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int,
-                                                   C.POINTER(Options), C.c_int32, C.c_int32, P_int]
-    L.sluamd_local_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    L.sluamd_pdgstrs3d_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_set_profile.argtypes = [C.c_void_p, C.c_int]
     L.sluamd_dAttachMatrix.argtypes = [C.c_void_p, C.c_int32, P_int, P_int, P_dbl, P_int]
     L.sluamd_pdgsrfs3d.argtypes = [C.c_void_p, P_dbl, C.c_int64, P_dbl, C.c_int64, C.c_int32, P_dbl, P_int]
     L.sluamd_pdgsrfs3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, P_dbl, P_int]
-    L.sluamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-    L.sluamd_coop_info.argtypes = [C.c_void_p, C.c_int, P_int, C.POINTER(C.c_int64)]
-    L.sluamd_coop_level_size.argtypes = [C.c_void_p, C.c_int, C.c_int, P_int, C.POINTER(C.c_int64)]
-    L.sluamd_coop_panel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
-    L.sluamd_coop_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    L.sluamd_coop_level_nodes.argtypes = [C.c_void_p, C.c_int, C.c_int, P_int]
-    L.sluamd_coop_panel_ptrs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
-    L.sluamd_coop_mask_u.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
-    _lib = L
+    L.sluamd_comm_rccl_unique_id.argtypes = [C.c_void_p]
+    L.sluamd_comm_create_rccl.argtypes = [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 7
+    L.sluamd_comm_create_callbacks.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CommCallbacks)] + [C.c_int] * 6
+    L.sluamd_comm_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+    L.sluamd_comm_rank.argtypes = [C.c_void_p]
+    L.sluamd_comm_size.argtypes = [C.c_void_p]
+    L.sluamd_comm_destroy.argtypes = [C.c_void_p]
     return L
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RuntimeError(f"{_SO} not built: run `make -C superlu_dist_amd/csrc` (or __graft_entry__.build()); "
+                           "there is no CPU fallback for the hot path")
+    _lib = bind(C.CDLL(_SO))
+    return _lib
 
 
 def check(rc, what=""):

@@ -1,0 +1,567 @@
+// sluamd_api.cpp -- the C ABI of include/superlu_dist_amd.h (handle life cycle, value upload / download, factor / solve /
+// refinement entry points).  No CPU fallback: every entry point fails when no HIP device is present.
+#include <algorithm>
+#include <cstring>
+#include "sluamd_comm.h"
+#include "sluamd_plan.h"
+
+using namespace sluamd;
+
+namespace sluamd {
+
+// ---- bounded pinned staging: own slot values <-> caller's panel / skyline arrays -------------------------------------
+static int ensure_pinned(Handle *H)
+{
+    if (H->h_pinned) return 0;
+    const size_t want = (size_t) 64 << 20;
+    HIPCHK(hipHostMalloc(&H->h_pinned, want, hipHostMallocDefault));
+    H->pinned_bytes = want;
+    return 0;
+}
+
+// dir = 0: host -> device (upload), 1: device -> host.  Own slots are contiguous in the arena in own_*_order, so the
+// copies go through the pinned buffer in runs of whole slots (slots larger than the buffer are split).
+static int copy_values(Handle *H, const sluamd_dLUview_t *lu, int dir)
+{
+    const HostStruct &hs = H->hs;
+    const Grid &g = H->grid;
+    const size_t esz = H->z ? 16 : 8;
+    int rc = ensure_pinned(H);
+    if (rc) return rc;
+    char *pin = reinterpret_cast<char *>(H->h_pinned);
+    const size_t cap = H->pinned_bytes;
+    char *dv = reinterpret_cast<char *>(H->d_val);
+    struct Piece { char *host; size_t bytes; };
+    std::vector<Piece> pieces;
+    size_t fill = 0; int64_t dev_byte = -1;   // byte offset in the arena of the first staged byte
+    auto flush = [&]() -> int {
+        if (!fill) return 0;
+        if (dir == 0) {
+            size_t o = 0;
+            for (auto &p : pieces) { std::memcpy(pin + o, p.host, p.bytes); o += p.bytes; }
+            HIPCHK(hipMemcpy(dv + dev_byte, pin, fill, hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(hipMemcpy(pin, dv + dev_byte, fill, hipMemcpyDeviceToHost));
+            size_t o = 0;
+            for (auto &p : pieces) { std::memcpy(p.host, pin + o, p.bytes); o += p.bytes; }
+        }
+        pieces.clear(); fill = 0; dev_byte = -1;
+        return 0;
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<int> &order = pass == 0 ? H->own_l_order : H->own_u_order;
+        for (int k : order) {
+            const int64_t len = pass == 0 ? hs.lval_len[k] : hs.uval_len[k];
+            if (!len) continue;
+            const int64_t off = pass == 0 ? hs.lval_off[k] : hs.uval_off[k];
+            char *hp = reinterpret_cast<char *>(pass == 0 ? (void *) lu->Lnzval_bc_ptr[k / g.Pc] : (void *) lu->Unzval_br_ptr[k / g.Pr]);
+            if (!hp) { set_error("value array missing for a stored panel"); return SLUAMD_ESTRUCT; }
+            size_t done = 0;
+            const size_t total = (size_t) len * esz;
+            while (done < total) {
+                const int64_t byte_off = off * (int64_t) esz + (int64_t) done;
+                if (fill && (dev_byte + (int64_t) fill != byte_off || fill == cap)) { if ((rc = flush())) return rc; }
+                if (!fill) dev_byte = byte_off;
+                const size_t n = std::min(total - done, cap - fill);
+                pieces.push_back({hp + done, n});
+                fill += n; done += n;
+            }
+        }
+        if ((rc = flush())) return rc;
+    }
+    return 0;
+}
+
+static int timed_copy(Handle *H, const sluamd_dLUview_t *lu, int dir)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    int rc = copy_values(H, lu, dir);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    (dir == 0 ? H->st.t_h2d_ms : H->st.t_d2h_ms) = ms;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
+
+static int create_from_view(sluamd_handle_t *out, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
+                            const sluamd_options_t *opt, bool z, Comm *comm)
+{
+    if (!out) { set_error("null handle pointer"); return SLUAMD_EINVAL; }
+    *out = nullptr;
+    sluamd_options_t o;
+    if (opt) o = *opt; else sluamd_default_options(&o);
+    int rc = check_device(o.device);
+    if (rc) return rc;
+    auto *hh = new sluamd_lu_handle_s();
+    Handle *H = &hh->H;
+    H->opt = o;
+    H->z = z;
+    H->comm = comm;
+    read_env(H->env);
+    auto fail = [&](int code) { sluamd_dDestroyLUHandle(hh); return code; };
+    if (hipGetDevice(&H->device) != hipSuccess) { set_error("hipGetDevice failed"); return fail(SLUAMD_EHIP); }
+    SlotInput in;
+    HostTables t;
+    if ((rc = slots_from_view(*H, lu, forests, comm, in))) return fail(rc);
+    if ((rc = plan_and_upload(H, in, t))) return fail(rc);
+    if ((rc = timed_copy(H, lu, 0))) return fail(rc);
+    *out = hh;
+    return 0;
+}
+
+// positions of A's entries inside the value arena of this rank's store (device-side pddistribute3d): -1 = not stored
+// here (other process row / column, other layer's forest, or a replicated ancestor whose A entries live on the first
+// layer of its group -- dinit3DLUstructForest's rule, pd3dcomm.c:334-800)
+static int scatter_positions(const Handle &H, const Symb &sy, const HostTables &t, const int *rowptr, const int *colind, const int *perm,
+                             std::vector<int64_t> &pos)
+{
+    const HostStruct &hs = H.hs;
+    const Grid &g = H.grid;
+    const int64_t n = hs.n;
+    const int ns = hs.nsupers;
+    std::vector<uint8_t> mine(ns, 0);   // A's entries destined to supernode k's panel / row are kept on this layer
+    for (size_t zl = 0; zl < H.forest_nodes.size(); ++zl)
+        if (g.z % (1 << zl) == 0) for (int k : H.forest_nodes[zl]) mine[k] = 1;
+    pos.assign((size_t) rowptr[n], -1);
+    for (int64_t i = 0; i < n; ++i)
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const int pi = perm[i], pj = perm[colind[e]];
+            const int s = sy.supno[pj];
+            if (pi >= hs.xsup[s]) {       // L(:, s), row pi
+                if (!mine[s] || g.kcol(s) != g.c) continue;
+                const int ib = sy.supno[pi];
+                if (g.krow(ib) != g.r) continue;
+                const int o = t.sn_lb_off[s], nb = t.sn_nlb[s];
+                const int *dir = t.lbs_gid.data() + o;
+                const int *f = std::lower_bound(dir, dir + nb, ib);
+                if (f == dir + nb || *f != ib) { set_error("A entry outside the symbolic structure of L"); return SLUAMD_ESTRUCT; }
+                const int b = o + t.lbs_idx[o + (int) (f - dir)];
+                const int *rows = hs.lidx.data() + hs.lidx_off[s] + t.lb_lptr[b];
+                const int *fr = std::lower_bound(rows, rows + t.lb_nbrow[b], pi);
+                if (fr == rows + t.lb_nbrow[b] || *fr != pi) { fr = std::find(rows, rows + t.lb_nbrow[b], pi); if (fr == rows + t.lb_nbrow[b]) { set_error("A entry outside the symbolic structure of L"); return SLUAMD_ESTRUCT; } }
+                pos[e] = hs.lval_off[s] + t.lb_rowoff[b] + (fr - rows) + (int64_t) (pj - hs.xsup[s]) * t.sn_nsupr[s];
+            } else {                       // U(r, s), r = supernode of row pi
+                const int r = sy.supno[pi];
+                if (!mine[r] || g.krow(r) != g.r || g.kcol(s) != g.c) continue;
+                const int o = t.sn_ub_off[r], nb = t.sn_nub[r];
+                const int *dir = t.ub_gid.data() + o;
+                const int *f = std::lower_bound(dir, dir + nb, s);
+                if (f == dir + nb || *f != s) { set_error("A entry outside the symbolic structure of U"); return SLUAMD_ESTRUCT; }
+                const int64_t ip = hs.uidx_off[r] + t.ub_iukp[o + (int) (f - dir)] + (pj - hs.xsup[s]);
+                const int fst = hs.uidx[ip];
+                if (pi < fst) { set_error("A entry above the skyline of U"); return SLUAMD_ESTRUCT; }
+                pos[e] = hs.uval_off[r] + t.ucolptr[ip] + (pi - fst);
+            }
+        }
+    return 0;
+}
+
+static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind, const double *nzval,
+                            const sluamd_int_t *perm_c_final, const sluamd_options_t *opt, const Grid &g, const int32_t *sn_tree, Comm *comm,
+                            bool z)
+{
+    if (!out || !s || !rowptr || !colind || !nzval || !perm_c_final) { set_error("null argument"); return SLUAMD_EINVAL; }
+    *out = nullptr;
+    if (g.size() > 1 && !comm) { set_error("a process grid with more than one rank needs a communicator"); return SLUAMD_EINVAL; }
+    sluamd_options_t o;
+    if (opt) o = *opt; else sluamd_default_options(&o);
+    int rc = check_device(o.device);
+    if (rc) return rc;
+    Symb *sy = reinterpret_cast<Symb *>(s);
+    auto *hh = new sluamd_lu_handle_s();
+    Handle *H = &hh->H;
+    H->opt = o;
+    H->z = z;
+    H->comm = comm;
+    read_env(H->env);
+    auto fail = [&](int code) { sluamd_dDestroyLUHandle(hh); return code; };
+    if (hipGetDevice(&H->device) != hipSuccess) { set_error("hipGetDevice failed"); return fail(SLUAMD_EHIP); }
+    SlotInput in;
+    HostTables t;
+    if ((rc = slots_from_symb(*H, *sy, g, sn_tree, in))) return fail(rc);
+    if ((rc = plan_and_upload(H, in, t))) return fail(rc);
+    {   // device-side distribution of A's values (the arena is zero-filled)
+        std::vector<int64_t> pos;
+        if ((rc = scatter_positions(*H, *sy, t, rowptr, colind, perm_c_final, pos))) return fail(rc);
+        const int w = z ? 2 : 1;   // doubles per value
+        std::vector<int64_t> pos2; std::vector<double> val2;
+        pos2.reserve(pos.size()); val2.reserve(pos.size() * w);
+        for (size_t e = 0; e < pos.size(); ++e)
+            if (pos[e] >= 0) { pos2.push_back(pos[e]); for (int q = 0; q < w; ++q) val2.push_back(nzval[e * w + q]); }
+        const int64_t nnz = (int64_t) pos2.size();
+        const size_t esz = z ? 16 : 8;
+        if (hipMalloc((void **) &H->d_apos, sizeof(int64_t) * std::max<int64_t>(nnz, 1)) != hipSuccess ||
+            hipMalloc((void **) &H->d_aval, esz * std::max<int64_t>(nnz, 1)) != hipSuccess) { set_error("hipMalloc failed"); return fail(SLUAMD_ENOMEM); }
+        H->a_nnz = nnz;
+        if (nnz) {
+            if (hipMemcpy(H->d_apos, pos2.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(H->d_aval, val2.data(), esz * nnz, hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return fail(SLUAMD_EHIP); }
+            if (z) eng::zscatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, nnz);
+            else eng::scatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, nnz);
+        }
+        if (hipStreamSynchronize(H->stream) != hipSuccess) { set_error("distribution kernel failed"); return fail(SLUAMD_EHIP); }
+    }
+    *out = hh;
+    return 0;
+}
+
+}  // namespace sluamd
+
+extern "C" {
+
+const char *sluamd_last_error(void) { return get_error().c_str(); }
+
+int sluamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void sluamd_default_options(sluamd_options_t *opt)
+{
+    std::memset(opt, 0, sizeof(*opt));
+    opt->device = -1;
+}
+
+int sluamd_dCreateLUHandle(sluamd_handle_t *out, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests, const sluamd_options_t *opt)
+{
+    return create_from_view(out, lu, forests, opt, false, nullptr);
+}
+
+int sluamd_dCreateLUHandleGrid(sluamd_handle_t *out, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests, const sluamd_options_t *opt,
+                               sluamd_comm_t comm)
+{
+    if (!comm) { set_error("null communicator"); return SLUAMD_EINVAL; }
+    return create_from_view(out, lu, forests, opt, false, comm->c);
+}
+
+// complex16 twin: zCreateLUgpuHandle (SRC/include/superlu_upacked.h, z section)
+int sluamd_zCreateLUHandle(sluamd_handle_t *out, const sluamd_zLUview_t *lu, const sluamd_forest_view_t *forests, const sluamd_options_t *opt)
+{
+    return create_from_view(out, reinterpret_cast<const sluamd_dLUview_t *>(lu), forests, opt, true, nullptr);
+}
+
+int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
+{
+    if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(h->H.device));
+    h->H.dinv_ready = false;
+    return timed_copy(&h->H, lu, 0);
+}
+
+int sluamd_zSetValues(sluamd_handle_t h, const sluamd_zLUview_t *lu)
+{
+    if (!h || !lu || !h->H.z) { set_error("not a complex16 handle"); return SLUAMD_EINVAL; }
+    return sluamd_dSetValues(h, reinterpret_cast<const sluamd_dLUview_t *>(lu));
+}
+
+int sluamd_pdgstrf3d(sluamd_handle_t h, double thresh, int *info)
+{
+    if (!h) { set_error("null handle"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("complex16 handle: call sluamd_pzgstrf3d"); return SLUAMD_EINVAL; }
+    return run_factor(&h->H, thresh, info);
+}
+
+int sluamd_pzgstrf3d(sluamd_handle_t h, double thresh, int *info)
+{
+    if (!h || !h->H.z) { set_error("not a complex16 handle"); return SLUAMD_EINVAL; }
+    return run_factor(&h->H, thresh, info);
+}
+
+int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny)
+{
+    if (!h) return SLUAMD_EINVAL;
+    int res[4];
+    HIPCHK(hipMemcpy(res, h->H.d_info, sizeof(res), hipMemcpyDeviceToHost));
+    if (info) *info = (res[0] == 0x7fffffff) ? 0 : res[0];
+    if (tiny) *tiny = res[1];
+    return 0;
+}
+
+int sluamd_dCopyLU2Host(sluamd_handle_t h, const sluamd_dLUview_t *lu)
+{
+    if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(h->H.device));
+    HIPCHK(hipStreamSynchronize(h->H.stream));
+    return timed_copy(&h->H, lu, 1);
+}
+
+int sluamd_zCopyLU2Host(sluamd_handle_t h, const sluamd_zLUview_t *lu)
+{
+    if (!h || !h->H.z) { set_error("not a complex16 handle"); return SLUAMD_EINVAL; }
+    return sluamd_dCopyLU2Host(h, reinterpret_cast<const sluamd_dLUview_t *>(lu));
+}
+
+// x: n x nrhs doublecomplex, column-major, host memory; overwritten by the solution of L U y = x
+int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, int32_t nrhs)
+{
+    if (!h || !h->H.z || !x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad complex solve arguments"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) return 0;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t need = 2 * ldx * nrhs;   // in doubles
+    if (need > H->x_cap) {
+        if (H->d_x) hipFree(H->d_x);
+        H->d_x = nullptr; H->x_cap = 0;
+        HIPCHK(hipMalloc((void **) &H->d_x, sizeof(double) * need));
+        H->x_cap = need;
+    }
+    HIPCHK(hipMemcpy(H->d_x, x, sizeof(double) * need, hipMemcpyHostToDevice));
+    const int ch = std::max(1, (150 * 1024) / std::max(H->max_nsupc * 16, 1));
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    HIPCHK(hipEventRecord(H->ev0, s));
+    for (int j0 = 0; j0 < nrhs; j0 += ch) {
+        const int nr = std::min(ch, nrhs - j0);
+        void *dx = H->d_x + (size_t) 2 * j0 * ldx;
+        for (size_t zl = 0; zl < H->sched.size(); ++zl) {
+            LevelSched &S = H->sched[zl];
+            for (int l = 0; l < S.nlevels; ++l) {
+                const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+                eng::zsolve_diag(s, true, T, S.d_nodes + n0, nn, dx, ldx, nr, S.max_nsupc[l]);
+                eng::zfwd_update(s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, S.fwd_prefix[po + nn], dx, ldx, nr, S.max_nsupc[l]);
+            }
+        }
+        for (int zl = (int) H->sched.size() - 1; zl >= 0; --zl) {
+            LevelSched &S = H->sched[zl];
+            for (int l = S.nlevels - 1; l >= 0; --l) {
+                const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+                eng::zbwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], dx, ldx, nr);
+                eng::zsolve_diag(s, false, T, S.d_nodes + n0, nn, dx, ldx, nr, S.max_nsupc[l]);
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(H->ev1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_solve_ms = ms;
+    HIPCHK(hipMemcpy(x, H->d_x, sizeof(double) * need, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nrhs)
+{
+    if (!h || !d_x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("complex16 handle: call sluamd_pzgstrs3d"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) return 0;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    HIPCHK(hipEventRecord(H->ev0, H->stream));
+    int rc = run_solve_dev(H, d_x, ldx, nrhs);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(H->ev1, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_solve_ms = ms;
+    return 0;
+}
+
+int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs)
+{
+    if (!h || !x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) return 0;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t need = ldx * nrhs;
+    if (need > H->x_cap) {
+        if (H->d_x) hipFree(H->d_x);
+        H->d_x = nullptr; H->x_cap = 0;
+        HIPCHK(hipMalloc((void **) &H->d_x, sizeof(double) * need));
+        H->x_cap = need;
+    }
+    HIPCHK(hipMemcpy(H->d_x, x, sizeof(double) * need, hipMemcpyHostToDevice));
+    int rc = sluamd_pdgstrs3d_dev(h, H->d_x, ldx, nrhs);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(x, H->d_x, sizeof(double) * need, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- iterative refinement: pdgsrfs3d (SRC/double/pdgsrfs.c:345-510), SURVEY 8(f)-2 ----
+static void free_rfs(Handle *H)
+{
+    void **ps[] = {(void **) &H->d_rfs_rp, (void **) &H->d_rfs_ci, (void **) &H->d_rfs_pc, (void **) &H->d_rfs_av, (void **) &H->d_rfs_work, (void **) &H->d_rfs_s};
+    for (void **p : ps) { if (*p) hipFree(*p); *p = nullptr; }
+    H->rfs_nnz = 0;
+}
+
+int sluamd_dAttachMatrix(sluamd_handle_t h, sluamd_int_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind, const double *nzval,
+                         const sluamd_int_t *perm_c)
+{
+    if (!h || !rowptr || !colind || !nzval || !perm_c || n != h->H.hs.n) { set_error("bad matrix arguments"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("iterative refinement is double precision only"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t nnz = rowptr[n];
+    free_rfs(H);
+    auto bail = [&](const char *what) { set_error(std::string(what) + " failed in sluamd_dAttachMatrix"); free_rfs(H); return SLUAMD_EHIP; };
+    if (hipMalloc((void **) &H->d_rfs_rp, sizeof(int) * (n + 1)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **) &H->d_rfs_ci, sizeof(int) * std::max<int64_t>(nnz, 1)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **) &H->d_rfs_av, sizeof(double) * std::max<int64_t>(nnz, 1)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **) &H->d_rfs_pc, sizeof(int) * n) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void **) &H->d_rfs_work, sizeof(double) * 3 * (size_t) n) != hipSuccess) return bail("hipMalloc");   // r_perm | b | x
+    if (hipMalloc((void **) &H->d_rfs_s, sizeof(unsigned long long)) != hipSuccess) return bail("hipMalloc");
+    if (hipMemcpy(H->d_rfs_rp, rowptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    if (hipMemcpy(H->d_rfs_ci, colind, sizeof(int) * nnz, hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    if (hipMemcpy(H->d_rfs_av, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    if (hipMemcpy(H->d_rfs_pc, perm_c, sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    H->rfs_nnz = nnz;
+    return 0;
+}
+
+// d_B, d_X: device-resident, original ordering, column-major; X holds the initial solution and is refined in place
+int sluamd_pdgsrfs3d_dev(sluamd_handle_t h, const double *d_B, int64_t ldb, double *d_X, int64_t ldx, int32_t nrhs, double *berr, int32_t *steps)
+{
+    if (!h || !d_B || !d_X || !berr || nrhs < 0 || ldb < h->H.hs.n || ldx < h->H.hs.n) { set_error("bad refinement arguments"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    if (!H->d_rfs_rp) { set_error("no matrix attached: call sluamd_dAttachMatrix first"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(H->device));
+    const int n = (int) H->hs.n;
+    const int ITMAX = 20;                                   // pdgsrfs.c:371
+    const double eps = 0x1p-53, safmin = 2.2250738585072014e-308;
+    const double safe1 = (double) (n + 1) * safmin, safe2 = safe1 / eps;
+    double *r_perm = H->d_rfs_work;
+    hipStream_t s = H->stream;
+    int count = 0;
+    for (int j = 0; j < nrhs; ++j) {
+        const double *Bc = d_B + (size_t) j * ldb;
+        double *Xc = d_X + (size_t) j * ldx;
+        double lstres = 3.0;
+        count = 0;
+        for (;;) {
+            HIPCHK(hipMemsetAsync(H->d_rfs_s, 0, sizeof(unsigned long long), s));
+            eng::rfs_residual(s, n, H->d_rfs_rp, H->d_rfs_ci, H->d_rfs_av, Xc, Bc, H->d_rfs_pc, r_perm, H->d_rfs_s, safe1, safe2);
+            double sv = 0.0;
+            HIPCHK(hipMemcpyAsync(&sv, H->d_rfs_s, sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            berr[j] = sv;
+            if (sv > eps && sv * 2 <= lstres && count < ITMAX) {
+                int rc = run_solve_dev(H, r_perm, n, 1);
+                if (rc) return rc;
+                eng::rfs_update(s, n, H->d_rfs_pc, r_perm, Xc);
+                lstres = sv;
+                ++count;
+            } else break;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (steps) *steps = count;
+    return 0;
+}
+
+int sluamd_pdgsrfs3d(sluamd_handle_t h, const double *B, int64_t ldb, double *X, int64_t ldx, int32_t nrhs, double *berr, int32_t *steps)
+{
+    if (!h || !B || !X || !berr || nrhs < 0 || ldb < h->H.hs.n || ldx < h->H.hs.n) { set_error("bad refinement arguments"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) { if (steps) *steps = 0; return 0; }
+    Handle *H = &h->H;
+    if (!H->d_rfs_rp) { set_error("no matrix attached: call sluamd_dAttachMatrix first"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t n = H->hs.n;
+    double *d_b = H->d_rfs_work + n, *d_x = H->d_rfs_work + 2 * (size_t) n;
+    int last = 0;
+    for (int j = 0; j < nrhs; ++j) {   // one column at a time through the two resident work vectors
+        HIPCHK(hipMemcpy(d_b, B + (size_t) j * ldb, sizeof(double) * n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_x, X + (size_t) j * ldx, sizeof(double) * n, hipMemcpyHostToDevice));
+        int rc = sluamd_pdgsrfs3d_dev(h, d_b, n, d_x, n, 1, berr + j, &last);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(X + (size_t) j * ldx, d_x, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    if (steps) *steps = last;
+    return 0;
+}
+
+void sluamd_dDestroyLUHandle(sluamd_handle_t h)
+{
+    if (!h) return;
+    Handle *H = &h->H;
+    hipSetDevice(H->device);
+    if (H->stream) hipStreamSynchronize(H->stream);
+    if (H->pstream) hipStreamSynchronize(H->pstream);
+    for (void *p : H->d_misc) hipFree(p);
+    if (H->d_val) hipFree(H->d_val);
+    if (H->d_info) hipFree(H->d_info);
+    if (H->d_x) hipFree(H->d_x);
+    if (H->d_xtmp) hipFree(H->d_xtmp);
+    if (H->d_apos) hipFree(H->d_apos);
+    if (H->d_aval) hipFree(H->d_aval);
+    if (H->h_pinned) hipHostFree(H->h_pinned);
+    free_rfs(H);
+    for (auto &e : H->ev_schur) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : H->ev_panel) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (H->ev0) hipEventDestroy(H->ev0);
+    if (H->ev1) hipEventDestroy(H->ev1);
+    for (auto e : H->ev_pool) hipEventDestroy(e);
+    if (H->pstream) hipStreamDestroy(H->pstream);
+    if (H->stream) hipStreamDestroy(H->stream);
+    delete h;
+}
+
+int sluamd_get_stats(sluamd_handle_t h, sluamd_stats_t *out)
+{
+    if (!h || !out) return SLUAMD_EINVAL;
+    *out = h->H.st;
+    return 0;
+}
+
+int sluamd_dCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                                   const double *nzval, const sluamd_int_t *perm_c_final, const sluamd_options_t *opt)
+{
+    return create_from_symb(out, s, rowptr, colind, nzval, perm_c_final, opt, Grid{}, nullptr, nullptr, false);
+}
+
+// complex16 values (nzval = doublecomplex[nnz] aligned with colind), 1x1x1 grid
+int sluamd_zCreateLUHandleFromSymb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                                   const sluamd_doublecomplex *nzval, const sluamd_int_t *perm_c_final, const sluamd_options_t *opt)
+{
+    return create_from_symb(out, s, rowptr, colind, reinterpret_cast<const double *>(nzval), perm_c_final, opt, Grid{}, nullptr, nullptr, true);
+}
+
+int sluamd_dCreateLUHandleFromSymbGrid(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                                       const double *nzval, const sluamd_int_t *perm_c_final, const sluamd_options_t *opt,
+                                       const int32_t *sn_tree, sluamd_comm_t comm)
+{
+    if (!comm) { set_error("null communicator"); return SLUAMD_EINVAL; }
+    return create_from_symb(out, s, rowptr, colind, nzval, perm_c_final, opt, comm->c->grid, sn_tree, comm->c, false);
+}
+
+// Device-side re-distribution of A's values into the resident store (handles made by sluamd_dCreateLUHandleFromSymb*):
+// zero-fill + scatter, asynchronous on the handle's stream.
+int sluamd_dResetValues(sluamd_handle_t h)
+{
+    if (!h || !h->H.d_apos) { set_error("handle has no device-side copy of A"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    H->dinv_ready = false;
+    HIPCHK(hipMemsetAsync(H->d_val, 0, (H->z ? 16 : 8) * (size_t) H->own_len, H->stream));
+    if (H->a_nnz && !H->z) eng::scatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, H->a_nnz);
+    if (H->a_nnz && H->z) eng::zscatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, H->a_nnz);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int sluamd_device_synchronize(void)
+{
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+int sluamd_set_profile(sluamd_handle_t h, int on)
+{
+    if (!h) return SLUAMD_EINVAL;
+    h->H.opt.verbose = on ? 2 : 0;
+    return 0;
+}
+
+// test hook: MFMA fp64 fragment layout check
+int sluamd_mfma_selftest(const double *A, const double *B, double *D)
+{
+    int rc = check_device(-1);
+    if (rc) return rc;
+    return eng::mfma_selftest(A, B, D);
+}
+
+}  // extern "C"

@@ -1,0 +1,572 @@
+// sluamd_factor.cpp -- numeric drivers: pdgstrf3d (Z-level loop, per-level panel pipeline with look-ahead, XY panel
+// exchange, Z ancestor reduction) and pdgstrs3d (level-set forward / backward sweeps with the matching exchanges).
+// All device work goes through eng:: (sluamd_kernels.hip), all communication through Comm (sluamd_comm.h).
+#include <algorithm>
+#include <cstring>
+#include "sluamd_comm.h"
+#include "sluamd_plan.h"
+
+namespace sluamd {
+
+static void ev_begin(Handle *H, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t &used, hipStream_t s)
+{
+    if (!H->profile) return;
+    if (used == v.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); v.emplace_back(a, b); }
+    hipEventRecord(v[used].first, s);
+}
+static void ev_end(Handle *H, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t &used, hipStream_t s)
+{
+    if (!H->profile) return;
+    hipEventRecord(v[used].second, s);
+    ++used;
+}
+static double ev_sum(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t used)
+{
+    double tot = 0;
+    for (size_t i = 0; i < used; ++i) { float ms = 0; hipEventElapsedTime(&ms, v[i].first, v[i].second); tot += ms; }
+    return tot;
+}
+static hipEvent_t next_event(Handle *H)
+{
+    if (H->ev_pool_used == H->ev_pool.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); H->ev_pool.push_back(e); }
+    return H->ev_pool[H->ev_pool_used++];
+}
+
+// one grouped exchange of contiguous arena ranges on stream s
+static int exchange(Handle *H, const std::vector<XMsg> &sends, const std::vector<XMsg> &recvs, hipStream_t s)
+{
+    if (sends.empty() && recvs.empty()) return 0;
+    Comm *c = H->comm;
+    int rc = c->begin();
+    if (rc) return rc;
+    for (auto &m : sends) if ((rc = c->send(H->d_val + m.off, m.len * 8, m.peer))) return rc;
+    for (auto &m : recvs) if ((rc = c->recv(H->d_val + m.off, m.len * 8, m.peer))) return rc;
+    return c->end(s);
+}
+
+// One elimination forest, level by level.  Serial mode (profiling / deterministic): everything on one stream.
+// Look-ahead mode (default): the Schur update of level l is split into the tiles that feed level l+1's panels
+// ("urgent", explicit list) and the rest; the panel kernels of level l+1 -- and on an XY layer their two exchange
+// phases -- run on a high-priority stream as soon as the urgent tiles are done and overlap with the rest: the GPU form of
+// the reference's look-ahead pipeline (dsparseTreeFactor_ASYNC, dtreeFactorization.c:381-706, num_lookaheads).
+static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
+{
+    const DevTables &T = H->T;
+    const bool xy = H->grid.Pr * H->grid.Pc > 1;
+    const bool lookahead = !H->profile && !H->opt.deterministic && !H->env.no_lookahead;
+    hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
+    int rc_x = 0;
+    auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
+                     const int4 *ulist, int skip_level) {
+        ev_begin(H, H->ev_schur, H->ev_schur_used, st);
+        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        ev_end(H, H->ev_schur, H->ev_schur_used, st);
+        H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
+    };
+    auto panel = [&](int l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        const int *nodes = S.d_nodes + n0;
+        const int mx = S.max_nsupc[l];
+        ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
+        eng::diag_lu(ps, T, nodes, nn, mx, H->opt.replace_tiny_pivot, thresh, H->d_info);                    // Local_Dgstrf2
+        if (xy) {   // dDiagFactIBCast (dtrfCommWrapper.c:32-118): diagonal blocks down the process column and along the process row
+            eng::pack_diag(ps, T, nodes, S.d_dg_prefix + po, S.d_dg_off + po, nn, S.dg_prefix[po + nn], H->d_val + S.dg_stage_off[l]);
+            if (!rc_x) rc_x = exchange(H, S.x_diag_send[l], S.x_diag_recv[l], ps);
+        }
+        eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);
+        const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
+        eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);   // dLPanelTrSolve + dUPanelTrSolve
+        if (xy && !rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // dIBcastRecvLPanel / dIBcastRecvUPanel
+        ev_end(H, H->ev_panel, H->ev_panel_used, ps);
+        H->st.num_launches += 2 + (nl + nu > 0);
+    };
+    if (lookahead && S.nlevels) {
+        hipEvent_t e = next_event(H);    // the side stream must see everything queued so far on the main stream
+        hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
+    }
+    bool panel_queued = false;           // panel(l) already queued on ps by the previous level's look-ahead
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
+        const int *nodes = S.d_nodes + n0;
+        if (!panel_queued) {
+            if (lookahead && l > 0) {   // no look-ahead was done for this level: its panels need ALL of Schur(l-1)
+                hipEvent_t e = next_event(H);
+                hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
+            }
+            panel(l);
+        }
+        panel_queued = false;
+        if (lookahead) {
+            hipEvent_t e = next_event(H);
+            hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);     // Schur(l) needs panel(l)
+        }
+        const int nbig = S.n_big[l];
+        // look-ahead split of this level's Schur update (SLUAMD_LOOKAHEAD_MAX_STRIPS bounds the panel work overlapped)
+        bool split = false;
+        if (lookahead && l + 1 < S.nlevels) {
+            const int po1 = S.lvl_poff[l + 1], nn1 = S.lvl_off[l + 2] - S.lvl_off[l + 1];
+            split = (S.ltr_prefix[po1 + nn1] + S.utr_prefix[po1 + nn1]) <= H->env.lookahead_max_strips;
+        }
+        // K-fused pairs: a deferred supernode runs only its urgent tiles (everything the next level's panels need), so the
+        // urgent pass is needed even without look-ahead; the rest of its update is accumulated by its partner's tiles
+        const bool urgent_pass = split || (T.defer && S.lvl_defer[l]);
+        hipEvent_t eu = nullptr;
+        // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
+        for (int pass = urgent_pass ? 0 : 1; pass < 2; ++pass) {
+            for (int g = 0; g < 2; ++g) {
+                const int cnt = g == 0 ? nbig : nn - nbig;
+                if (!cnt) continue;
+                const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
+                const int *gn = nodes + (g == 0 ? 0 : nbig);
+                if (pass == 0) {
+                    const int u0 = S.u_off[2 * l + g], nu = S.u_off[2 * l + g + 1] - u0;
+                    if (nu) schur(s, g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1);
+                    continue;
+                }
+                const int nt = S.tile_prefix[so + cnt];
+                if (!nt) continue;
+                if (T.defer && S.lvl_defer[l]) {   // nothing to launch when every supernode of the group is deferred
+                    bool all = true;
+                    const int i0 = n0 + (g == 0 ? 0 : nbig);
+                    for (int i = 0; i < cnt && all; ++i) all = H->h_defer[S.nodes[i0 + i]] != 0;
+                    if (all) continue;
+                }
+                if (!H->opt.deterministic) {
+                    schur(s, g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, urgent_pass ? l + 1 : -1);
+                } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
+                    for (int i = 0; i < cnt; ++i) {
+                        const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
+                        if (c) schur(s, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1);
+                    }
+                }
+            }
+            if (pass == 0 && split) { eu = next_event(H); hipEventRecord(eu, s); }
+        }
+        if (split) {
+            // panel(l+1) may start once the urgent tiles of level l (and, by stream order, the rest of level l-1) are
+            // complete; it then overlaps with the rest of level l, which is already queued on the main stream (a
+            // host-staged exchange inside panel() blocks the host, not the GPU)
+            hipStreamWaitEvent(ps, eu, 0);
+            panel(l + 1);
+            panel_queued = true;
+        }
+        if (rc_x) return rc_x;
+    }
+    if (lookahead && S.nlevels) {
+        hipEvent_t e = next_event(H);
+        hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);
+    }
+    HIPCHK(hipGetLastError());
+    return rc_x;
+}
+
+// complex16 (serial level loop; see sluamd_zkernels.inc)
+static int run_factor_z(Handle *H, LevelSched &S, double thresh)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
+        const int *nodes = S.d_nodes + n0;
+        eng::zdiag_lu(s, T, nodes, nn, S.max_nsupc[l], H->opt.replace_tiny_pivot, thresh, H->d_info);
+        const int po = S.lvl_poff[l];
+        const int nl = S.zltr_prefix[po + nn], nu = S.bwd_prefix[po + nn];   // 64-row strips / 64-column chunks
+        eng::zpanel_trsm(s, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, nl, nu);
+        H->st.num_launches += 1 + (nl + nu > 0);
+        const int so = S.lvl_soff[l] + S.n_big[l] + 1;     // complex handles have no 128-tile group
+        const int nt = S.tile_prefix[so + nn];
+        if (nt) {
+            eng::zschur(s, T, nodes, S.d_tile_prefix + so, nn, 0, nt, H->d_info);
+            H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += nt;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int ensure_xtmp(Handle *H, int64_t doubles)
+{
+    if (doubles <= H->xtmp_cap) return 0;
+    if (H->d_xtmp) hipFree(H->d_xtmp);
+    H->d_xtmp = nullptr; H->xtmp_cap = 0;
+    if (hipMalloc((void **) &H->d_xtmp, sizeof(double) * (size_t) doubles) != hipSuccess) { set_error("hipMalloc of the exchange buffer failed"); return SLUAMD_ENOMEM; }
+    H->xtmp_cap = doubles;
+    return 0;
+}
+
+// own-slot ranges [L | U] of the ancestor forests above Z level zl: contiguous by construction of the arena
+static void ancestor_ranges(const Handle *H, int zl, std::vector<std::pair<int64_t, int64_t>> &out)
+{
+    out.clear();
+    const HostStruct &hs = H->hs;
+    const Grid &g = H->grid;
+    for (int pass = 0; pass < 2; ++pass) {
+        int64_t first = -1, len = 0;
+        for (size_t a = zl + 1; a < H->forest_nodes.size(); ++a)
+            for (int k : H->forest_nodes[a]) {
+                if (pass == 0 && g.kcol(k) == g.c && hs.lval_len[k]) { if (first < 0 || hs.lval_off[k] < first) first = hs.lval_off[k]; len += hs.lval_len[k]; }
+                if (pass == 1 && g.krow(k) == g.r && hs.uval_len[k]) { if (first < 0 || hs.uval_off[k] < first) first = hs.uval_off[k]; len += hs.uval_len[k]; }
+            }
+        if (len) out.emplace_back(first, len);
+    }
+}
+
+// dreduceAllAncestors3d (pd3dcomm.c:1046-1081) after Z level zl: the layer myz + 2^zl sends its copies of every ancestor
+// forest to layer myz (myz % 2^(zl+1) == 0), which adds them (dzRecvLPanel / dzRecvUPanel: daxpy) -- as whole arena ranges,
+// in bounded chunks through one staging buffer.
+static int reduce_ancestors(Handle *H, int zl)
+{
+    const Grid &g = H->grid;
+    const int step = 1 << zl;
+    if (zl + 1 >= (int) H->forest_nodes.size() || (g.z % step) != 0) return 0;
+    std::vector<std::pair<int64_t, int64_t>> rg;
+    ancestor_ranges(H, zl, rg);
+    const bool receiver = (g.z % (2 * step)) == 0;
+    const int peer = g.rank_of(g.r, g.c, receiver ? g.z + step : g.z - step);
+    if (receiver && g.z + step >= g.Pz) return 0;
+    const int64_t CH = (int64_t) 1 << 25;   // 32 Mi doubles = 256 MiB per message
+    hipStream_t s = H->stream;
+    Comm *c = H->comm;
+    for (auto &r : rg)
+        for (int64_t o = 0; o < r.second; o += CH) {
+            const int64_t len = std::min(CH, r.second - o);
+            int rc = c->begin();
+            if (rc) return rc;
+            if (receiver) {
+                if ((rc = ensure_xtmp(H, std::min(CH, r.second)))) return rc;
+                if ((rc = c->recv(H->d_xtmp, len * 8, peer))) return rc;
+                if ((rc = c->end(s))) return rc;
+                eng::axpy(s, len, 1.0, H->d_xtmp, H->d_val + r.first + o);
+                if (!c->stream_ordered()) continue;
+                HIPCHK(hipStreamSynchronize(s));   // the staging buffer is reused by the next chunk's receive
+            } else {
+                if ((rc = c->send(H->d_val + r.first + o, len * 8, peer))) return rc;
+                if ((rc = c->end(s))) return rc;
+            }
+        }
+    return 0;
+}
+
+int run_factor(Handle *H, double thresh, int *info)
+{
+    HIPCHK(hipSetDevice(H->device));
+    const Grid &g = H->grid;
+    if (g.size() > 1 && !H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
+    int init[4] = {0x7fffffff, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
+    H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
+    H->profile = H->opt.verbose >= 2 || H->env.profile;
+    H->ev_schur_used = H->ev_panel_used = 0;
+    H->ev_pool_used = 0;
+    HIPCHK(hipEventRecord(H->ev0, H->stream));
+    // Z levels in order (pdgstrf3d.c:333-385): factor my forest of the level, then the ancestor reduction
+    int rc = 0;
+    for (size_t zl = 0; zl < H->sched.size(); ++zl) {
+        if (H->z_active[zl]) {
+            rc = H->z ? run_factor_z(H, H->sched[zl], thresh) : run_factor_sched(H, H->sched[zl], thresh);
+            if (rc) return rc;
+        }
+        if (g.Pz > 1 && (rc = reduce_ancestors(H, (int) zl))) return rc;
+    }
+    HIPCHK(hipEventRecord(H->ev1, H->stream));
+    int res[4];
+    HIPCHK(hipMemcpyAsync(res, H->d_info, sizeof(res), hipMemcpyDeviceToHost, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_factor_ms = ms;
+    H->dinv_ready = true;
+    H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
+    H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
+    H->st.tiny_pivots = res[1];
+    int linfo = (res[0] == 0x7fffffff) ? 0 : res[0];
+    int missing = res[2];
+    if (g.size() > 1) {   // info = first zero pivot over the whole grid (MPI_Allreduce MIN, pdgstrf3d.c:388-392)
+        int v = linfo ? linfo : 0x7fffffff;
+        if ((rc = H->comm->allreduce_min(&v))) return rc;
+        linfo = (v == 0x7fffffff) ? 0 : v;
+        int m = -missing;
+        if ((rc = H->comm->allreduce_min(&m))) return rc;
+        missing = -m;
+    }
+    if (info) *info = linfo;
+    if (missing) { set_error("Schur update found no destination block for " + std::to_string(missing) + " tiles (structure not closed)"); return SLUAMD_ESTRUCT; }
+    return 0;
+}
+
+// ================================================================================================
+//                                     triangular solves
+// ================================================================================================
+int ensure_dinv(Handle *H)
+{
+    if (H->dinv_ready) return 0;
+    // factors were uploaded already factored: build the diagonal sub-block inverses once (owners only have the blocks)
+    if (H->grid.Pr * H->grid.Pc > 1) { set_error("solve before factorisation is not supported on an XY grid"); return SLUAMD_EINVAL; }
+    for (auto &S : H->sched)
+        for (int l = 0; l < S.nlevels; ++l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            eng::diag_inv(H->stream, H->T, S.d_nodes + n0, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);
+        }
+    H->dinv_ready = true;
+    return 0;
+}
+
+struct XRuns { int *d = nullptr; int n = 0; int64_t total = 0; };
+
+// transient device image of a run list: (row0, nrows, rows before) triples; freed by the caller (to_free)
+static int make_runs(hipStream_t s, const std::vector<std::pair<int, int>> &runs, XRuns &o, std::vector<int *> &to_free)
+{
+    std::vector<int> h;
+    int64_t tot = 0;
+    for (auto &r : runs) { h.push_back(r.first); h.push_back(r.second); h.push_back((int) tot); tot += r.second; }
+    o.n = (int) runs.size(); o.total = tot; o.d = nullptr;
+    if (h.empty()) return 0;
+    HIPCHK(hipMalloc((void **) &o.d, sizeof(int) * h.size()));
+    to_free.push_back(o.d);
+    HIPCHK(hipMemcpyAsync(o.d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // h goes out of scope
+    return 0;
+}
+
+// exchange of x segments with a set of peers: send = pack (mode 0, or 3 = pack and clear) -> grouped send/recv -> unpack
+// (mode 1 = overwrite, 2 = accumulate)
+static int xseg_exchange(Handle *H, double *d_x, int64_t ldx, int nrhs, const std::vector<LevelSched::XSeg> &snd, int pack_mode,
+                         const std::vector<LevelSched::XSeg> &rcv, int unpack_mode, hipStream_t s)
+{
+    if (snd.empty() && rcv.empty()) return 0;
+    int64_t need = 0;
+    for (auto &m : snd) need += m.total * nrhs;
+    for (auto &m : rcv) need += m.total * nrhs;
+    int rc = ensure_xtmp(H, need);
+    if (rc) return rc;
+    std::vector<XRuns> rs(snd.size()), rr(rcv.size());
+    std::vector<int *> to_free;
+    auto mk = [&](const LevelSched::XSeg &m, XRuns &o) -> int { return make_runs(s, m.runs, o, to_free); };
+    int64_t off = 0;
+    Comm *c = H->comm;
+    for (size_t i = 0; i < snd.size(); ++i) { if ((rc = mk(snd[i], rs[i]))) return rc; }
+    for (size_t i = 0; i < rcv.size(); ++i) { if ((rc = mk(rcv[i], rr[i]))) return rc; }
+    std::vector<int64_t> so(snd.size()), ro(rcv.size());
+    for (size_t i = 0; i < snd.size(); ++i) { so[i] = off; eng::xseg_copy(s, d_x, ldx, nrhs, rs[i].d, rs[i].n, rs[i].total, H->d_xtmp + off, pack_mode); off += snd[i].total * nrhs; }
+    for (size_t i = 0; i < rcv.size(); ++i) { ro[i] = off; off += rcv[i].total * nrhs; }
+    if ((rc = c->begin())) return rc;
+    for (size_t i = 0; i < snd.size(); ++i) if ((rc = c->send(H->d_xtmp + so[i], snd[i].total * nrhs * 8, snd[i].peer))) return rc;
+    for (size_t i = 0; i < rcv.size(); ++i) if ((rc = c->recv(H->d_xtmp + ro[i], rcv[i].total * nrhs * 8, rcv[i].peer))) return rc;
+    if ((rc = c->end(s))) return rc;
+    for (size_t i = 0; i < rcv.size(); ++i) eng::xseg_copy(s, d_x, ldx, nrhs, rr[i].d, rr[i].n, rr[i].total, H->d_xtmp + ro[i], unpack_mode);
+    HIPCHK(hipStreamSynchronize(s));   // the staging buffer and the run lists are reused by the next exchange
+    for (int *p : to_free) hipFree(p);
+    return 0;
+}
+
+// forward / backward block solves of one Z level (one elimination forest): DAG levels ascending / descending.
+// XY layers: before the diagonal solves of a level the partial sums of x_k held by the process row k % Pr are reduced to
+// the diagonal owner (dlsum_fmod_inv's lsum reduction, pdgstrs_lsum.c:414-960 / dlsumReducePrK), afterwards x_k goes down
+// the process column k % Pc (dbCastXk2Pck, pdgstrs3d.c).  Non-owners use their entries of x as the lsum accumulators.
+static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    LevelSched &S = H->sched[z];
+    const bool xy = H->grid.Pr * H->grid.Pc > 1;
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        int rc;
+        if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
+        eng::solve_diag(s, true, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
+        if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;
+        eng::fwd_update(s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, S.fwd_prefix[po + nn], d_x, ldx, nrhs, S.max_nsupc[l]);
+    }
+    return 0;
+}
+static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    LevelSched &S = H->sched[z];
+    const bool xy = H->grid.Pr * H->grid.Pc > 1;
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        int rc;
+        eng::bwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, ldx, nrhs);
+        if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
+        eng::solve_diag(s, false, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
+        if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;
+    }
+    return 0;
+}
+
+static int max_rhs_chunk(const Handle *H)
+{   // the diagonal solve stages (max_nsupc + 32) x nrhs doubles in LDS (<= 150 KiB of the 160 KiB per workgroup)
+    const int per = (H->max_nsupc + 32) * 8;
+    return std::max(1, (150 * 1024) / std::max(per, 1));
+}
+
+int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
+{
+    int rc = ensure_dinv(H);
+    if (rc) return rc;
+    const int ch = max_rhs_chunk(H);
+    for (int j0 = 0; j0 < nrhs; j0 += ch) {
+        const int nr = std::min(ch, nrhs - j0);
+        double *x = d_x + (size_t) j0 * ldx;
+        for (int z = 0; z < (int) H->sched.size(); ++z) if ((rc = solve_fwd_z(H, z, x, ldx, nr))) return rc;
+        for (int z = (int) H->sched.size() - 1; z >= 0; --z) if ((rc = solve_bwd_z(H, z, x, ldx, nr))) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// rows of the forests of Z levels [a0, a1) whose x entries this rank holds in role `role`:
+//   0 = lsum accumulators / b of the process row (k % Pr == myrow), 1 = solved x of the process column (k % Pc == mycol),
+//   2 = diagonal owner only
+static void forest_runs(const Handle *H, int a0, int a1, int role, LevelSched::XSeg &out)
+{
+    const HostStruct &hs = H->hs;
+    const Grid &g = H->grid;
+    std::vector<int> ks;
+    for (int a = a0; a < a1 && a < (int) H->forest_nodes.size(); ++a)
+        for (int k : H->forest_nodes[a]) {
+            const bool rr = g.krow(k) == g.r, cc = g.kcol(k) == g.c;
+            if ((role == 0 && rr) || (role == 1 && cc) || (role == 2 && rr && cc)) ks.push_back(k);
+        }
+    std::sort(ks.begin(), ks.end());
+    out.runs.clear(); out.total = 0;
+    for (int k : ks) {
+        const int row0 = hs.xsup[k], nr = hs.xsup[k + 1] - hs.xsup[k];
+        if (!out.runs.empty() && out.runs.back().first + out.runs.back().second == row0) out.runs.back().second += nr;
+        else out.runs.emplace_back(row0, nr);
+        out.total += nr;
+    }
+}
+
+// pdgstrs3d on the grid: d_x holds the COMPLETE permuted right-hand side on entry (replicated) and the complete solution
+// on return.  Z sweeps as pdgsTrForwardSolve3d / pdgsTrBackSolve3d (pdgstrs3d.c:7312, :7564): forward reduction of the
+// ancestor rows to the partner layer (dfsolveReduceLsum3d :1646), backward hand-down of the solved ancestors
+// (dp2pSolvedX3d :1596).
+int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
+{
+    const Grid &g = H->grid;
+    if (g.size() == 1) return run_solve_local(H, d_x, ldx, nrhs);
+    if (!H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
+    if (!H->dinv_ready) { set_error("grid solve needs the factorisation to have run on this handle"); return SLUAMD_EINVAL; }
+    const int nzl = (int) H->sched.size();
+    hipStream_t s = H->stream;
+    const int ch = max_rhs_chunk(H);
+    int rc;
+    for (int j0 = 0; j0 < nrhs; j0 += ch) {
+        const int nr = std::min(ch, nrhs - j0);
+        double *x = d_x + (size_t) j0 * ldx;
+        // keep b only where it is consumed: at the diagonal owner, on the layer that factors the forest; everything else
+        // starts as a zero accumulator (rows of other layers' forests are never touched)
+        {
+            LevelSched::XSeg keep;
+            std::vector<int> ks;
+            for (int zl = 0; zl < nzl; ++zl) if (H->z_active[zl]) for (int k : H->forest_nodes[zl]) if (g.krow(k) == g.r && g.kcol(k) == g.c) ks.push_back(k);
+            std::sort(ks.begin(), ks.end());
+            for (int k : ks) {
+                const int row0 = H->hs.xsup[k], n1 = H->hs.xsup[k + 1] - row0;
+                if (!keep.runs.empty() && keep.runs.back().first + keep.runs.back().second == row0) keep.runs.back().second += n1; else keep.runs.emplace_back(row0, n1);
+                keep.total += n1;
+            }
+            if ((rc = ensure_xtmp(H, std::max<int64_t>(keep.total * nr, 1)))) return rc;
+            XRuns kr;
+            std::vector<int *> to_free;
+            if ((rc = make_runs(s, keep.runs, kr, to_free))) return rc;
+            eng::xseg_copy(s, x, ldx, nr, kr.d, kr.n, kr.total, H->d_xtmp, 0);
+            for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.n, s));
+            eng::xseg_copy(s, x, ldx, nr, kr.d, kr.n, kr.total, H->d_xtmp, 1);
+            HIPCHK(hipStreamSynchronize(s));
+            for (int *p : to_free) hipFree(p);
+        }
+        // ---- forward sweep, leaves to root ----
+        for (int zl = 0; zl < nzl; ++zl) {
+            const int step = 1 << zl;
+            if (g.z % step) break;
+            if (H->z_active[zl] && (rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
+            if (zl + 1 < nzl) {
+                LevelSched::XSeg seg;
+                forest_runs(H, zl + 1, nzl, 0, seg);
+                const bool receiver = (g.z % (2 * step)) == 0;
+                if (receiver && g.z + step >= g.Pz) continue;
+                seg.peer = g.rank_of(g.r, g.c, receiver ? g.z + step : g.z - step);
+                std::vector<LevelSched::XSeg> one(1, seg), none;
+                if (seg.total && (rc = receiver ? xseg_exchange(H, x, ldx, nr, none, 0, one, 2, s) : xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s))) return rc;
+            }
+        }
+        // ---- backward sweep, root to leaves ----
+        for (int zl = nzl - 1; zl >= 0; --zl) {
+            const int step = 1 << zl;
+            if (g.z % step) continue;
+            if (zl + 1 < nzl) {
+                LevelSched::XSeg seg;
+                forest_runs(H, zl + 1, nzl, 1, seg);
+                const bool sender = (g.z % (2 * step)) == 0;
+                if (!(sender && g.z + step >= g.Pz)) {
+                    seg.peer = g.rank_of(g.r, g.c, sender ? g.z + step : g.z - step);
+                    std::vector<LevelSched::XSeg> one(1, seg), none;
+                    if (seg.total && (rc = sender ? xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldx, nr, none, 0, one, 1, s))) return rc;
+                }
+            }
+            if (H->z_active[zl] && (rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
+        }
+        // ---- assemble: every x_k is final at its diagonal owner on the layer that factored its forest; gather on world
+        //      rank 0, then hand the complete vector to everyone ----
+        {
+            LevelSched::XSeg mine;
+            {
+                std::vector<int> ks;
+                for (int zl = 0; zl < nzl; ++zl) if (H->z_active[zl]) for (int k : H->forest_nodes[zl]) if (g.krow(k) == g.r && g.kcol(k) == g.c) ks.push_back(k);
+                std::sort(ks.begin(), ks.end());
+                for (int k : ks) {
+                    const int row0 = H->hs.xsup[k], n1 = H->hs.xsup[k + 1] - row0;
+                    if (!mine.runs.empty() && mine.runs.back().first + mine.runs.back().second == row0) mine.runs.back().second += n1; else mine.runs.emplace_back(row0, n1);
+                    mine.total += n1;
+                }
+            }
+            // every rank learns every rank's run list by recomputing it: ownership is a pure function of (k, grid, forests),
+            // but the forests of other layers are not known here -> ship the run lists (host) to rank 0 first
+            Comm *c = H->comm;
+            const int P = g.size(), me = g.rank();
+            std::vector<int> flat;
+            for (auto &r : mine.runs) { flat.push_back(r.first); flat.push_back(r.second); }
+            std::vector<std::vector<int>> all(P);
+            {
+                std::vector<int64_t> lens(P, 0);
+                int64_t mylen = (int64_t) flat.size();
+                if ((rc = c->hbegin())) return rc;
+                if (me != 0) { if ((rc = c->hsend(&mylen, 8, 0))) return rc; }
+                else for (int p = 1; p < P; ++p) if ((rc = c->hrecv(&lens[p], 8, p))) return rc;
+                if ((rc = c->hend())) return rc;
+                if ((rc = c->hbegin())) return rc;
+                if (me != 0) { if ((rc = c->hsend(flat.data(), mylen * 4, 0))) return rc; }
+                else for (int p = 1; p < P; ++p) { all[p].resize((size_t) lens[p]); if ((rc = c->hrecv(all[p].data(), lens[p] * 4, p))) return rc; }
+                if ((rc = c->hend())) return rc;
+            }
+            if (me != 0) {
+                mine.peer = 0;
+                std::vector<LevelSched::XSeg> one(1, mine), none;
+                if (mine.total && (rc = xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s))) return rc;
+            } else {
+                std::vector<LevelSched::XSeg> rcv, none;
+                for (int p = 1; p < P; ++p) {
+                    LevelSched::XSeg m; m.peer = p;
+                    for (size_t i = 0; i + 1 < all[p].size(); i += 2) { m.runs.emplace_back(all[p][i], all[p][i + 1]); m.total += all[p][i + 1]; }
+                    if (m.total) rcv.push_back(std::move(m));
+                }
+                if ((rc = xseg_exchange(H, x, ldx, nr, none, 0, rcv, 1, s))) return rc;
+            }
+            // complete vector from rank 0 to everyone
+            if ((rc = c->begin())) return rc;
+            for (int q = 0; q < nr; ++q) {
+                if (me == 0) { for (int p = 1; p < P; ++p) if ((rc = c->send(x + (size_t) q * ldx, H->hs.n * 8, p))) return rc; }
+                else if ((rc = c->recv(x + (size_t) q * ldx, H->hs.n * 8, 0))) return rc;
+            }
+            if ((rc = c->end(s))) return rc;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sluamd

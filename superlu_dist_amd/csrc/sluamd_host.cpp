@@ -1,0 +1,301 @@
+// sluamd_host.cpp -- host side of the MI355X (gfx950) implementation of the 3D supernodal LU hot path.
+//
+// Flattens the caller's reference-format L/U store (superlu_dist_amd.h) into per-supernode "slots", uploads it ONCE to
+// HBM (index arenas + value arena stay resident for factor and solve), builds device-side block directories, tile lists,
+// an elimination-DAG level schedule per Z level and -- on XY block-cyclic layers -- the per-level panel exchange plan.
+// The numeric drivers (pdgstrf3d, pdgstrs3d, pdgsrfs3d) queue kernels through the eng:: interface (sluamd_kernels.hip)
+// and panel exchanges through Comm (sluamd_comm.h).
+//
+// There is NO CPU fallback in the product library: every entry point fails when no HIP device is present.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+#include "sluamd_comm.h"
+#include "sluamd_internal.h"
+#include "sluamd_plan.h"
+
+namespace sluamd {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const std::string &get_error() { return g_err; }
+
+int check_device(int dev)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible: this library has no CPU fallback"); return SLUAMD_ENODEVICE; }
+    if (dev >= 0) { HIPCHK(hipSetDevice(dev)); }
+    return 0;
+}
+
+void read_env(Handle::Env &e)
+{
+    e.no_lookahead = getenv("SLUAMD_NO_LOOKAHEAD") != nullptr;
+    e.no_fuse = getenv("SLUAMD_NO_FUSE") != nullptr;
+    e.no_big_tiles = getenv("SLUAMD_NO_BIG_TILES") != nullptr;
+    e.schur_4waves = getenv("SLUAMD_SCHUR_4WAVES") != nullptr;
+    e.trsm_rs32 = getenv("SLUAMD_TRSM_RS32") != nullptr;
+    e.profile = getenv("SLUAMD_PROFILE") != nullptr;
+    if (const char *v = getenv("SLUAMD_FUSE_MIN_PCT")) e.fuse_min_pct = atoi(v);
+    if (const char *v = getenv("SLUAMD_FUSE_MAX_PREV")) e.fuse_max_prev = std::max(1, std::min(3, atoi(v)));
+    if (const char *v = getenv("SLUAMD_LOOKAHEAD_MAX_STRIPS")) e.lookahead_max_strips = atoi(v);
+}
+
+int trsm_rs(const Handle &H, int nsp) { return (nsp > 128 && H.env.trsm_rs32) ? 32 : 64; }
+
+// ================================================================================================
+//                           slot structures from the caller's view
+// ================================================================================================
+// Z-level node lists of this layer's path: forests (dtrf3Dpartition_t) or one list with every supernode
+static int lists_from_forests(const sluamd_forest_view_t *forests, int nsupers, int npdep, SlotInput &in)
+{
+    in.lists.clear(); in.z_active.clear();
+    if (forests && forests->maxLvl > 0 && forests->nodeList) {
+        for (int l = 0; l < forests->maxLvl; ++l) {
+            std::vector<int> v;
+            const int f = forests->myTreeIdxs[l];
+            if (f >= 0 && f < forests->numForests && forests->nNodes[f] > 0 && forests->nodeList[f])
+                v.assign(forests->nodeList[f], forests->nodeList[f] + forests->nNodes[f]);
+            std::sort(v.begin(), v.end());
+            in.lists.push_back(std::move(v));
+            in.z_active.push_back(forests->myZeroTrIdxs[l] ? 0 : 1);
+        }
+    } else {
+        if (npdep > 1) { set_error("npdep > 1 needs the elimination forests (sluamd_forest_view_t) of this layer"); return SLUAMD_EINVAL; }
+        std::vector<int> v(nsupers);
+        std::iota(v.begin(), v.end(), 0);
+        in.lists.push_back(std::move(v));
+        in.z_active.push_back(1);
+    }
+    for (auto &l : in.lists)
+        for (int k : l)
+            if (k < 0 || k >= nsupers) { set_error("forest node list names a supernode outside [0, nsupers)"); return SLUAMD_ESTRUCT; }
+    return 0;
+}
+
+static void add_succ_from_slot(SlotInput &in, int k, const std::vector<int> &li, const std::vector<int> &ui, int nsupers, const int *xsup)
+{
+    auto &s = in.succ[k];
+    if (li.size() >= (size_t) BC_HEADER) {
+        int p = BC_HEADER;
+        for (int b = 0; b < li[0] && p + 1 < (int) li.size(); ++b) { if (li[p] > k) s.push_back(li[p]); p += LB_DESCRIPTOR + li[p + 1]; }
+    }
+    if (ui.size() >= (size_t) BR_HEADER) {
+        int p = BR_HEADER;
+        for (int b = 0; b < ui[0] && p < (int) ui.size(); ++b) {
+            const int jb = ui[p];
+            if (jb < 0 || jb >= nsupers) break;
+            s.push_back(jb);
+            p += UB_DESCRIPTOR + (xsup[jb + 1] - xsup[jb]);
+        }
+    }
+}
+
+static void finish_succ(SlotInput &in)
+{
+    for (auto &s : in.succ) { std::sort(s.begin(), s.end()); s.erase(std::unique(s.begin(), s.end()), s.end()); }
+}
+
+// message = [count][k, len, ints...]*
+static void pack_slots(const std::vector<std::vector<int>> &idx, const std::vector<int> &ks, std::vector<int> &msg)
+{
+    msg.clear();
+    msg.push_back((int) ks.size());
+    for (int k : ks) { msg.push_back(k); msg.push_back((int) idx[k].size()); msg.insert(msg.end(), idx[k].begin(), idx[k].end()); }
+}
+static int unpack_slots(const std::vector<int> &msg, std::vector<std::vector<int>> &idx, int nsupers)
+{
+    size_t p = 0;
+    if (msg.empty()) return 0;
+    const int cnt = msg[p++];
+    for (int i = 0; i < cnt; ++i) {
+        if (p + 2 > msg.size()) { set_error("truncated structure message"); return SLUAMD_ESTRUCT; }
+        const int k = msg[p++], len = msg[p++];
+        if (k < 0 || k >= nsupers || len < 0 || p + len > msg.size()) { set_error("bad structure message"); return SLUAMD_ESTRUCT; }
+        idx[k].assign(msg.begin() + p, msg.begin() + p + len);
+        p += len;
+    }
+    return 0;
+}
+
+// one grouped exchange of variable-length int messages: sends[i] -> peers_s[i]; receives one message from every peers_r[i]
+static int exchange_ints(Comm *comm, const std::vector<int> &peers_s, const std::vector<const std::vector<int> *> &sends,
+                         const std::vector<int> &peers_r, std::vector<std::vector<int>> &recvs)
+{
+    std::vector<int64_t> slen(peers_s.size()), rlen(peers_r.size(), 0);
+    int rc = comm->hbegin();
+    if (rc) return rc;
+    for (size_t i = 0; i < peers_s.size(); ++i) { slen[i] = (int64_t) sends[i]->size(); if ((rc = comm->hsend(&slen[i], sizeof(int64_t), peers_s[i]))) return rc; }
+    for (size_t i = 0; i < peers_r.size(); ++i) if ((rc = comm->hrecv(&rlen[i], sizeof(int64_t), peers_r[i]))) return rc;
+    if ((rc = comm->hend())) return rc;
+    recvs.resize(peers_r.size());
+    if ((rc = comm->hbegin())) return rc;
+    for (size_t i = 0; i < peers_s.size(); ++i) if ((rc = comm->hsend(sends[i]->data(), slen[i] * (int64_t) sizeof(int), peers_s[i]))) return rc;
+    for (size_t i = 0; i < peers_r.size(); ++i) { recvs[i].resize((size_t) rlen[i]); if ((rc = comm->hrecv(recvs[i].data(), rlen[i] * (int64_t) sizeof(int), peers_r[i]))) return rc; }
+    return comm->hend();
+}
+
+int slots_from_view(Handle &H, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests, Comm *comm, SlotInput &in)
+{
+    if (!lu || !lu->xsup || lu->nsupers <= 0) { set_error("invalid LU view"); return SLUAMD_EINVAL; }
+    Grid &g = H.grid;
+    g = Grid{lu->nprow, lu->npcol, lu->npdep, lu->myrow, lu->mycol, lu->myzlayer};
+    if (g.Pr < 1 || g.Pc < 1 || g.Pz < 1 || g.r < 0 || g.r >= g.Pr || g.c < 0 || g.c >= g.Pc || g.z < 0 || g.z >= g.Pz) { set_error("bad grid coordinates in the LU view"); return SLUAMD_EINVAL; }
+    if (g.size() > 1) {
+        if (!comm) { set_error("a process grid with more than one rank needs a communicator: use sluamd_dCreateLUHandleGrid"); return SLUAMD_EINVAL; }
+        const Grid &cg = comm->grid;
+        if (cg.Pr != g.Pr || cg.Pc != g.Pc || cg.Pz != g.Pz || cg.r != g.r || cg.c != g.c || cg.z != g.z) { set_error("communicator grid does not match the LU view's grid"); return SLUAMD_EINVAL; }
+    }
+    const int ns = lu->nsupers;
+    HostStruct &hs = H.hs;
+    hs.n = lu->n; hs.nsupers = ns;
+    hs.xsup.assign(lu->xsup, lu->xsup + ns + 1);
+    int rc = lists_from_forests(forests, ns, g.Pz, in);
+    if (rc) return rc;
+    hs.present.assign(ns, 0);
+    for (auto &l : in.lists) for (int k : l) hs.present[k] = 1;
+    in.lidx.assign(ns, {}); in.uidx.assign(ns, {}); in.succ.assign(ns, {});
+    std::vector<int> own_l, own_u;
+    for (int k = 0; k < ns; ++k) {
+        if (!hs.present[k]) continue;
+        if (g.kcol(k) == g.c) {
+            const int *li = lu->Lrowind_bc_ptr[k / g.Pc];
+            if (li) {
+                if (li[0] < 0 || li[1] < 0) { set_error("malformed L block column header"); return SLUAMD_ESTRUCT; }
+                in.lidx[k].assign(li, li + BC_HEADER + (int64_t) li[0] * LB_DESCRIPTOR + li[1]);
+            } else if (g.krow(k) == g.r) { set_error("L panel with the diagonal block missing on its owner"); return SLUAMD_ESTRUCT; }
+            own_l.push_back(k);
+        }
+        if (g.krow(k) == g.r) {
+            const int *ui = lu->Ufstnz_br_ptr[k / g.Pr];
+            if (ui) {
+                if (ui[2] < BR_HEADER) { set_error("malformed U block row header"); return SLUAMD_ESTRUCT; }
+                in.uidx[k].assign(ui, ui + ui[2]);
+            }
+            own_u.push_back(k);
+        }
+    }
+    for (int k = 0; k < ns; ++k) if (hs.present[k]) add_succ_from_slot(in, k, in.lidx[k], in.uidx[k], ns, hs.xsup.data());
+    if (g.Pr * g.Pc > 1) {
+        // the index arrays of the panels this rank will receive (the reference ships them inside every panel message,
+        // dIBcast_LPanel dcommunication_aux.c:32-60) + the block graph of the other parts, once
+        std::vector<int> lmsg, umsg, gmsg;
+        pack_slots(in.lidx, own_l, lmsg);
+        pack_slots(in.uidx, own_u, umsg);
+        {   // block graph of my own slots: [count][k, n, gids...]*
+            std::vector<std::vector<int>> mine(ns);
+            std::vector<int> ks;
+            SlotInput tmp; tmp.succ.assign(ns, {});
+            for (int k : own_l) add_succ_from_slot(tmp, k, in.lidx[k], {}, ns, hs.xsup.data());
+            for (int k : own_u) add_succ_from_slot(tmp, k, {}, in.uidx[k], ns, hs.xsup.data());
+            finish_succ(tmp);
+            for (int k = 0; k < ns; ++k) if (!tmp.succ[k].empty()) { ks.push_back(k); mine[k] = tmp.succ[k]; }
+            pack_slots(mine, ks, gmsg);
+        }
+        std::vector<int> ps, pr;
+        std::vector<const std::vector<int> *> sends;
+        std::vector<int> kind;   // of each receive: 0 = L slots, 1 = U slots, 2 = graph
+        for (int c2 = 0; c2 < g.Pc; ++c2) if (c2 != g.c) { ps.push_back(g.rank_of(g.r, c2, g.z)); sends.push_back(&lmsg); }
+        for (int r2 = 0; r2 < g.Pr; ++r2) if (r2 != g.r) { ps.push_back(g.rank_of(r2, g.c, g.z)); sends.push_back(&umsg); }
+        for (int r2 = 0; r2 < g.Pr; ++r2) for (int c2 = 0; c2 < g.Pc; ++c2) if (r2 != g.r || c2 != g.c) { ps.push_back(g.rank_of(r2, c2, g.z)); sends.push_back(&gmsg); }
+        for (int c2 = 0; c2 < g.Pc; ++c2) if (c2 != g.c) { pr.push_back(g.rank_of(g.r, c2, g.z)); kind.push_back(0); }
+        for (int r2 = 0; r2 < g.Pr; ++r2) if (r2 != g.r) { pr.push_back(g.rank_of(r2, g.c, g.z)); kind.push_back(1); }
+        for (int r2 = 0; r2 < g.Pr; ++r2) for (int c2 = 0; c2 < g.Pc; ++c2) if (r2 != g.r || c2 != g.c) { pr.push_back(g.rank_of(r2, c2, g.z)); kind.push_back(2); }
+        std::vector<std::vector<int>> recvs;
+        if ((rc = exchange_ints(comm, ps, sends, pr, recvs))) return rc;
+        std::vector<std::vector<int>> gr(ns);
+        for (size_t i = 0; i < recvs.size(); ++i) {
+            if (kind[i] == 0) rc = unpack_slots(recvs[i], in.lidx, ns);
+            else if (kind[i] == 1) rc = unpack_slots(recvs[i], in.uidx, ns);
+            else {
+                for (auto &v : gr) v.clear();
+                rc = unpack_slots(recvs[i], gr, ns);
+                for (int k = 0; k < ns && !rc; ++k) in.succ[k].insert(in.succ[k].end(), gr[k].begin(), gr[k].end());
+            }
+            if (rc) return rc;
+        }
+    }
+    finish_succ(in);
+    return 0;
+}
+
+// ================================================================================================
+//                           slot structures from the library's own symbolic factorisation
+// ================================================================================================
+int slots_from_symb(Handle &H, const Symb &sy, const Grid &g, const int32_t *sn_tree, SlotInput &in)
+{
+    const HostStruct &full = sy.hs;
+    const int ns = full.nsupers;
+    H.grid = g;
+    HostStruct &hs = H.hs;
+    hs.n = full.n; hs.nsupers = ns; hs.xsup = full.xsup;
+    in.lists.clear(); in.z_active.clear();
+    if (g.Pz == 1) {
+        std::vector<int> v(ns); std::iota(v.begin(), v.end(), 0);
+        in.lists.push_back(std::move(v)); in.z_active.push_back(1);
+    } else {
+        if (!sn_tree) { set_error("npdep > 1 needs sn_tree (sluamd_symb_partition)"); return SLUAMD_EINVAL; }
+        // tree ids on the path of layer z (getGridTrees, supernodal_etree.c:840-851): leaf Pz - 1 + z, then parents
+        int maxLvl = 1;
+        while ((1 << (maxLvl - 1)) < g.Pz) ++maxLvl;
+        std::vector<int> trees(maxLvl);
+        trees[0] = g.Pz - 1 + g.z;
+        for (int i = 1; i < maxLvl; ++i) trees[i] = (trees[i - 1] - 1) / 2;
+        in.lists.assign(maxLvl, {});
+        for (int k = 0; k < ns; ++k)
+            for (int l = 0; l < maxLvl; ++l) if (sn_tree[k] == trees[l]) in.lists[l].push_back(k);
+        for (int l = 0; l < maxLvl; ++l) in.z_active.push_back((g.z % (1 << l)) == 0);   // myZeroTrIdxs, supernodal_etree.c:853-869
+    }
+    hs.present.assign(ns, 0);
+    for (auto &l : in.lists) for (int k : l) hs.present[k] = 1;
+    in.lidx.assign(ns, {}); in.uidx.assign(ns, {}); in.succ.assign(ns, {});
+    for (int k = 0; k < ns; ++k) {
+        if (!hs.present[k]) continue;
+        const int *li = full.lidx.data() + full.lidx_off[k];
+        const int64_t ulen = full.uidx_off[k + 1] - full.uidx_off[k];
+        const int *ui = ulen ? full.uidx.data() + full.uidx_off[k] : nullptr;
+        {   // rows of the block rows ib with ib % Pr == myrow
+            auto &o = in.lidx[k];
+            o.assign(BC_HEADER, 0);
+            int p = BC_HEADER, nb = 0, nr = 0;
+            for (int b = 0; b < li[0]; ++b) {
+                const int gid = li[p], nbrow = li[p + 1];
+                if (g.krow(gid) == g.r) { o.insert(o.end(), li + p, li + p + LB_DESCRIPTOR + nbrow); ++nb; nr += nbrow; }
+                if (gid > k) in.succ[k].push_back(gid);
+                p += LB_DESCRIPTOR + nbrow;
+            }
+            o[0] = nb; o[1] = nr;
+            if (!nb) o.clear();
+        }
+        if (ui) {   // blocks jb with jb % Pc == mycol
+            auto &o = in.uidx[k];
+            o.assign(BR_HEADER, 0);
+            int p = BR_HEADER, nb = 0, nnz = 0;
+            const int klst = full.xsup[k + 1];
+            for (int b = 0; b < ui[0]; ++b) {
+                const int jb = ui[p], nsj = full.xsup[jb + 1] - full.xsup[jb];
+                if (g.kcol(jb) == g.c) {
+                    o.insert(o.end(), ui + p, ui + p + UB_DESCRIPTOR + nsj);
+                    int bn = 0;
+                    for (int jj = 0; jj < nsj; ++jj) bn += klst - ui[p + UB_DESCRIPTOR + jj];
+                    o[o.size() - UB_DESCRIPTOR - nsj + 1] = bn;
+                    ++nb; nnz += bn;
+                }
+                in.succ[k].push_back(jb);
+                p += UB_DESCRIPTOR + nsj;
+            }
+            o[0] = nb; o[1] = nnz; o[2] = (int) o.size();
+            if (!nb) o.clear();
+        }
+    }
+    finish_succ(in);
+    return 0;
+}
+
+}  // namespace sluamd

@@ -1,9 +1,17 @@
-// Internal types shared by the host planner (sluamd_core.hip) and the symbolic producer
-// (sluamd_symb.cpp).  Not part of the C ABI.
+// Internal types shared by the host planner / drivers (sluamd_host.cpp, sluamd_dist.cpp, sluamd_comm*.cpp), the symbolic
+// producer (sluamd_symb.cpp) and the gfx950 kernels (sluamd_kernels.hip).  Not part of the C ABI.
+//
+// Layering: the host files never launch a kernel themselves; every device operation goes through the `eng::` functions
+// declared at the bottom of this header and implemented in sluamd_kernels.hip (hand-written HIP).  The CPU test build
+// under oracle/emul/ links the SAME host files against a serial restatement of that interface so that the multi-rank
+// orchestration (Z forests, XY block-cyclic panel exchange) is covered by `-m "not gpu"` tests; the product library has
+// no CPU path.
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
+#include <sluamd_rt.h>   // resolved through the include path: HIP runtime API (product) -- oracle/emul/ supplies a host shim of the same name for the test build
 #include "superlu_dist_amd.h"
 
 namespace sluamd {
@@ -12,20 +20,50 @@ constexpr int BC_HEADER = 2;      // reference superlu_defs.h:169
 constexpr int LB_DESCRIPTOR = 2;  // :170
 constexpr int BR_HEADER = 3;      // :190
 constexpr int UB_DESCRIPTOR = 2;  // :191
+constexpr int DB = 32;            // diagonal sub-block size of the blocked panel kernels / solves
+constexpr int KC = 16;            // K chunk of the Schur GEMM pipeline
 
 void set_error(const std::string &msg);
+const std::string &get_error();
 
-// Host copy of one rank's L/U *structure* (index arrays only), flattened over GLOBAL supernode ids.
-// Round 1 supports 1 x 1 x Pz grids, so every supernode's panel/row is local (possibly as a zero replica).
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ::sluamd::set_error(std::string(#expr) + " failed: " + hipGetErrorString(e_));   \
+            return SLUAMD_EHIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+// 3D process grid of the reference (gridinfo3d_t, superlu_defs.h:385-420): 2-D block-cyclic layers (PROW/PCOL/PNUM,
+// superlu_defs.h:270-279) replicated along Z.  World rank = (z * Pr + r) * Pc + c (layer-major, superlu_grid3d.c).
+struct Grid {
+    int Pr = 1, Pc = 1, Pz = 1, r = 0, c = 0, z = 0;
+    int size() const { return Pr * Pc * Pz; }
+    int rank() const { return rank_of(r, c, z); }
+    int rank_of(int rr, int cc, int zz) const { return (zz * Pr + rr) * Pc + cc; }
+    int krow(int k) const { return k % Pr; }   // PROW
+    int kcol(int k) const { return k % Pc; }   // PCOL
+};
+
+// Host copy of the L/U *structure* this rank works with, indexed by GLOBAL supernode id.
+//   Symb (sluamd_symb.cpp): the complete structure of a 1 x 1 grid, value offsets ascending in k, U offsets relative to
+//     the U half.
+//   Handle: one "L slot" and one "U slot" per supernode of this rank's forests.  The L slot of k is the image of the
+//     part of panel k stored by process (myrow, k % Pc) (rows of the block rows ib with ib % Pr == myrow); the U slot
+//     is the image of the part of block row k stored by (k % Pr, mycol).  A slot is OWN when that process is this rank
+//     (values live in the resident arena) or REMOTE (index array received at creation, values received per level into
+//     the scratch region of the arena).  Value offsets are ABSOLUTE offsets into the value arena.
 struct HostStruct {
     int64_t n = 0;
     int nsupers = 0;
-    std::vector<int> xsup;                 // [nsupers+1]
+    std::vector<int> xsup;                    // [nsupers+1]
     std::vector<int64_t> lidx_off, uidx_off;  // [nsupers+1] into lidx/uidx
-    std::vector<int64_t> lval_off, uval_off;  // [nsupers+1] into the value arena halves
+    std::vector<int64_t> lval_off, uval_off;  // Symb: [nsupers+1] ascending; Handle: [nsupers+1], entry k = absolute arena offset
+    std::vector<int64_t> lval_len, uval_len;  // Handle only: [nsupers] doubles (elements) of each slot
     std::vector<int> lidx, uidx;
-    int64_t nnzL = 0, nnzU = 0;
-    std::vector<uint8_t> present;          // [nsupers] 0 = panel/row not stored on this rank (other Z layer's forest)
+    int64_t nnzL = 0, nnzU = 0;               // own stored elements
+    std::vector<uint8_t> present;             // [nsupers] 0 = not in any forest of this rank's Z layer
 };
 
 // Symbolic object behind sluamd_symb_t
@@ -41,13 +79,195 @@ struct Symb {
     double flops = 0;
 };
 
-// positions of A's entries inside the value arena: out_pos[e] (into L arena if is_u[e]==0 else U arena)
-// `hs` supplies the value offsets (it may be a local subset of sy.hs); `owned` (may be null) filters the entries
-// by destination supernode: entries whose destination is not owned get pos = -1.
+// positions of A's entries inside the host store of a Symb (sluamd_ddistribute_host): out_pos[e] into L values if
+// is_u[e]==0 else U values; `owned` (may be null) filters by destination supernode
 void compute_scatter_positions(const Symb &sy, const HostStruct &hs, int64_t n, const int *rowptr, const int *colind,
                                const int *perm_c_final, const uint8_t *owned, std::vector<int64_t> &pos,
                                std::vector<uint8_t> &is_u);
 // tree (heap-numbered, root 0) of every supernode for a 1 x 1 x npdep grid
 void partition_forests(const Symb &sy, int npdep, std::vector<int> &sn_tree);
 
+// ------------------------------------------------------------------------------------------------
+// Device-side tables (all pointers into HBM).  SoA per supernode / per block.
+// ------------------------------------------------------------------------------------------------
+enum : int {
+    SNF_OWN_DIAG = 1,   // this rank factors the diagonal block of k (k % Pr == myrow && k % Pc == mycol)
+    SNF_HAS_DIAG = 2,   // the factored diagonal block is available here (owner, or received: column / row peers)
+    SNF_L_OWN = 4,      // the L slot is this rank's own storage (k % Pc == mycol)
+    SNF_U_OWN = 8,      // the U slot is this rank's own storage (k % Pr == myrow)
+};
+
+struct DevTables {
+    double *val;          // value arena: [own L slots | own U slots | remote-slot scratch | diagonal-block scratch]
+    const int *lidx;      // Lrowind images
+    const int *uidx;      // Ufstnz images
+    const int *ucolptr;   // parallel to uidx: value offset (within the row) of each U column
+    const int *unzcol;    // parallel to uidx: compact list of non-empty column ids of each U block
+    const int *xsup;
+    // per supernode
+    const int64_t *sn_lval, *sn_uval;  // offsets into val
+    const int64_t *sn_lidx, *sn_uidx;  // offsets into lidx / uidx
+    const int *sn_nsupr;               // LDA of the L slot
+    const int *sn_flags;               // SNF_*
+    const int *sn_ldiag;               // rows of the diagonal block at the top of the L slot (nsupc when k % Pr == myrow, else 0)
+    const int64_t *sn_dptr;            // offset into val of the nsupc x nsupc diagonal block (inside the L slot or in the scratch)
+    const int *sn_dlda;                // ... and its leading dimension
+    double *dinv;                      // inverted 32x32 diagonal sub-blocks of U_kk and L_kk^T (workspace)
+    const int64_t *sn_dinv;            // offset of supernode k's blocks in dinv
+    const int *sn_ldu;                 // max U segment height of block row k (this slot)
+    const int *sn_ncolu;               // total non-empty U columns of block row k (this slot)
+    const int *sn_lb_off, *sn_nlb;     // L block table range
+    const int *sn_ub_off, *sn_nub;     // U block table range
+    const int *sn_rt_off, *sn_nrt;     // row-tile range
+    const int *sn_ct_off, *sn_nct;     // col-tile range
+    // per L block (stored order) + gid-sorted directory
+    const int *lb_gid, *lb_nbrow, *lb_rowoff, *lb_lptr;
+    const int *lbs_gid, *lbs_idx;
+    // per U block (sorted by gid)
+    const int *ub_gid, *ub_ncols, *ub_iukp, *ub_stcol;
+    // tiles
+    const int4 *rtile;  // (L block idx within slot, row start in block, nrows, slot row offset)
+    const int4 *ctile;  // (U block idx within row, first non-empty col rank, ncols, unused)
+    // K-fused updates (null when disabled): fuse_prev[3k + j], j = 0..2 = the up to three predecessor supernodes (k-1,
+    // k-2, k-3 of the same chain; -1 = none) whose deferred updates k's tiles also accumulate; defer[k] = 1 when k's
+    // non-urgent tiles are skipped (a later chain member applies them).  Per (k, j): pair_rowmap[pair_roff[3k+j] + r] =
+    // row of that predecessor's L panel holding the same global row as row r of k's panel (-1: absent);
+    // pair_colinfo[2*(pair_coff[3k+j] + c)] = (value offset, leading zeros) of k's c-th non-empty U column inside the
+    // predecessor's U row (leading zeros = predecessor width when absent)
+    const int *fuse_prev, *defer, *pair_roff, *pair_coff, *pair_rowmap, *pair_colinfo;
+};
+
+// One exchange message of the XY panel exchange: a contiguous range of the value arena sent to / received from one peer
+struct XMsg { int peer; int64_t off, len; };   // world rank, arena offset, doubles
+
+struct LevelSched {
+    int nlevels = 0;
+    std::vector<int> lvl_off;       // [nlevels+1] into nodes
+    std::vector<int> nodes;         // supernodes sorted by level (big-tile supernodes first inside a level)
+    std::vector<int> tile_prefix;   // per node (aligned with nodes), exclusive prefix WITHIN its level (+1 total slot per level)
+    std::vector<int> ltr_prefix;    // L-TRSM strips
+    std::vector<int> utr_prefix;    // U-TRSM column chunks
+    std::vector<int> inv_prefix;    // diagonal sub-block inversion tasks
+    std::vector<int> zltr_prefix;   // complex path: 64-row L strips (the 64-column U chunks reuse bwd_prefix)
+    std::vector<int> lvl_poff;      // [nlevels+1] offset of each level's prefix arrays (size nodes_in_level+1)
+    std::vector<int> lvl_soff;      // [nlevels+1] offset of each level's Schur prefix arrays (big group | small group)
+    std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
+    std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
+    std::vector<int> max_nsupc;     // per level
+    std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
+    std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
+    std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level [big group | small group]
+    std::vector<int> u_off;         // [2*nlevels+1] offsets into ulist (2 groups per level)
+    // ---- XY block-cyclic exchange plan (empty on a 1 x 1 layer): per level, in ascending supernode order ----
+    std::vector<int> dg_prefix;               // per node (lvl_poff layout): 1024-double chunks of the own diagonal blocks to pack
+    std::vector<int64_t> dg_off;              // ... and their offsets inside the level's diagonal staging range
+    std::vector<std::vector<XMsg>> x_diag_send, x_diag_recv;     // phase 1: packed diagonal blocks (column + row peers)
+    std::vector<std::vector<XMsg>> x_panel_send, x_panel_recv;   // phase 2: L slots along the process row, U slots down the column
+    std::vector<int64_t> dg_stage_off;        // [nlevels] arena offset of the level's packed own diagonal blocks
+    // solve exchange plan: per level, x segments (as [first row, rows) runs) reduced to / broadcast from the diagonal owners
+    struct XSeg { int peer; std::vector<std::pair<int, int>> runs; int64_t total = 0; };
+    std::vector<std::vector<XSeg>> xs_red_send, xs_red_recv, xs_bc_send, xs_bc_recv;
+    // device copies
+    int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
+    int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
+    int4 *d_ulist = nullptr;
+    int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
+};
+
+struct Comm;   // sluamd_comm.h
+
+struct Handle {
+    int device = 0;
+    sluamd_options_t opt{};
+    HostStruct hs;
+    Grid grid;
+    int Pz = 1, myz = 0;
+    // environment switches, read ONCE at creation (they may differ per handle)
+    struct Env {
+        bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false;
+        int fuse_min_pct = 75, fuse_max_prev = 1, lookahead_max_strips = 1 << 30;
+    } env;
+    // device arenas
+    double *d_val = nullptr;
+    int64_t arena_len = 0;          // elements (doubles, or doublecomplex for z) of the whole arena
+    int64_t own_len = 0;            // ... of the resident part [own L | own U]
+    int *d_lidx = nullptr, *d_uidx = nullptr, *d_ucolptr = nullptr, *d_unzcol = nullptr, *d_xsup = nullptr;
+    std::vector<void *> d_misc;  // everything else to free
+    DevTables T{};
+    std::vector<LevelSched> sched;  // one per Z level (forests) or a single one
+    std::vector<std::vector<int>> forest_nodes;   // ascending supernodes of the forest of every Z level on this layer's path (even when not factored here)
+    std::vector<uint8_t> z_active;  // [Z levels] this layer factors that level's forest (!myZeroTrIdxs)
+    std::vector<int> own_l_order, own_u_order;   // own L / U slots in value-arena order
+    hipStream_t stream = nullptr;
+    hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
+    std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events
+    size_t ev_pool_used = 0;
+    int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
+    double *d_x = nullptr; int64_t x_cap = 0;
+    double *d_xtmp = nullptr; int64_t xtmp_cap = 0;   // exchange staging of the distributed solve / ancestor reduction
+    int64_t *d_apos = nullptr; double *d_aval = nullptr; int64_t a_nnz = 0;  // A's entries for device-side (re)distribution
+    // iterative refinement (sluamd_dAttachMatrix): the ORIGINAL matrix in CSR + perm_c, and work vectors
+    int *d_rfs_rp = nullptr, *d_rfs_ci = nullptr, *d_rfs_pc = nullptr; double *d_rfs_av = nullptr;
+    double *d_rfs_work = nullptr; unsigned long long *d_rfs_s = nullptr; int64_t rfs_nnz = 0;
+    void *h_pinned = nullptr; size_t pinned_bytes = 0;      // bounded pinned staging buffer (value upload / download)
+    bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
+    bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
+    bool profile = false;                                   // per-kernel-family HIP-event timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
+    size_t ev_schur_used = 0, ev_panel_used = 0;
+    sluamd_stats_t st{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // host tables kept for stats / planning
+    std::vector<int> h_nsupr, h_ldu, h_ncolu, h_flags, h_ldiag;
+    std::vector<int64_t> h_sn_dinv, h_dptr;
+    // K-fused updates (see DevTables): host images, built by build_schedule
+    std::vector<int> h_fuse_prev, h_defer, h_pair_roff, h_pair_coff, h_pair_rowmap, h_pair_colinfo;
+    int fused_pairs = 0;
+    int max_nsupc = 0;
+    Comm *comm = nullptr;           // not owned; set by sluamd_dCreateLUHandleGrid / sluamd_attach_comm
+};
+
+// ------------------------------------------------------------------------------------------------
+// Engine: every device operation of the hot path.  sluamd_kernels.hip implements these as gfx950 kernel launches on
+// `s`; all pointer arguments are device pointers.
+// ------------------------------------------------------------------------------------------------
+namespace eng {
+int setup();   // one-time function attributes (dynamic LDS limits)
+void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
+void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask);
+// L strips (work units [0, nl)) and U column strips ([nl, nl + nu)); strip height rs = 32 or 64
+void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu,
+                int rs, int max_nsupc);
+// cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
+void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
+           const int4 *ulist, const int *sn_level, int skip_level);
+void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs,
+                int max_nsupc);
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs);
+void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz);
+void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
+                  double *r_perm, unsigned long long *s_out, double safe1, double safe2);
+void rfs_update(hipStream_t s, int n, const int *pc, const double *dx_perm, double *x);
+// y[i] += a * x[i]  (ancestor reduction: dzRecvLPanel / dzRecvUPanel's daxpy, pd3dcomm.c:189-331)
+void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y);
+// XY exchange helpers: own diagonal blocks of a level -> contiguous staging range (ns x ns, lda = ns each)
+void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage);
+// x segments <-> contiguous buffer; mode 0: buf = x, 1: x = buf, 2: x += buf, 3: buf = x then x = 0
+void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs /*device: (row0, nrows, rows before) triples*/, int nruns, int64_t total,
+               double *buf, int mode);
+int mfma_selftest(const double *A, const double *B, double *D);   // host pointers
+// complex16 twins (1 x 1 x 1 grids)
+void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
+void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
+void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info);
+void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int max_nsupc);
+void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs,
+                 int max_nsupc);
+void zbwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs);
+void zscatter_values(hipStream_t s, void *val, const int64_t *pos, const void *a, int64_t nnz);
+}  // namespace eng
+
 }  // namespace sluamd
+
+struct sluamd_lu_handle_s { sluamd::Handle H; };

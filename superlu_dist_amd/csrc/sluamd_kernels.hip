@@ -1,0 +1,1121 @@
+// sluamd_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the 3D supernodal LU hot path + their launchers
+// (the `eng::` interface of sluamd_internal.h).  Per level of the elimination-DAG schedule:
+//     k_diag_lu      unpivoted LU of every diagonal block of the level   (Local_Dgstrf2, pdgstrf2.c:508)
+//     k_panel_trsm<0> L(:,k) <- L(:,k) U_kk^-1                           (dLPanelTrSolve, dtrfCommWrapper.c:120)
+//     k_panel_trsm<1> U(k,:) <- L_kk^-1 U(k,:) directly on the skyline   (dTrs2_GatherTrsmScatter, pdgstrf2.c:804)
+//     k_schur        A(I,J) -= L(I,k) U(k,J): fused gather -> fp64 MFMA GEMM -> scatter, no bigU/bigV
+//                    round trip (dRgather_L/U dgather.c:133-398 + dblock_gemm_scatter dscatter3d.c:81-189
+//                    + dscatter_l dscatter.c:109 + scatter_u dscatter3d.c:555)
+// and for pdgstrs3d the level-set forward/backward block solves (dlsum_fmod_inv / dlsum_bmod_inv,
+// pdgstrs_lsum.c:414 / :1362).
+//
+// On an XY block-cyclic layer (nprow * npcol > 1) the same kernels run on "slots": the L slot of supernode k is this
+// process row's part of panel k (own storage or the image received from process column k % Pc), the U slot this process
+// column's part of block row k; the diagonal block may sit at the top of the L slot or in a scratch range
+// (DevTables::sn_dptr / sn_dlda / sn_ldiag).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "sluamd_internal.h"
+
+namespace sluamd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int find_node(const int *__restrict__ prefix, int nn, int id)
+{   // largest i in [0,nn) with prefix[i] <= id   (prefix has nn+1 entries)
+    int lo = 0, hi = nn;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= id) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void atomic_sub_f64(double *p, double v)
+{
+    unsafeAtomicAdd(p, -v);  // global_atomic_add_f64 (hardware fp64 atomic on gfx950)
+}
+
+// ---- diagonal block LU ----------------------------------------------------------------------------
+// One workgroup per supernode of the level.  Arithmetic = right-looking elimination without pivoting as
+// Local_Dgstrf2 (pdgstrf2.c:508-601; tiny-pivot replacement :544-560, zero-pivot info :568-571).
+//   ns <= 128 : whole block factored inside LDS (rank-1 updates).
+//   ns  > 128 : blocked by 32 columns: LDS-resident column panel, U12 = L11^-1 A12 per thread-column,
+//               rank-32 trailing update with the panel rows held in registers.
+// Afterwards the workgroup inverts the 32x32 diagonal sub-blocks of U_kk and of L_kk^T (unit) into
+// T.dinv; the panel TRSM kernels use them (block TRSM with inverted 32x32 diagonal blocks).
+
+__device__ __forceinline__ void pivot_fix(double *p, int col1based, int replace_tiny, double thresh, int *info, double *s_piv)
+{
+    double v = *p;
+    if (replace_tiny && fabs(v) < thresh) { v = (v < 0) ? -thresh : thresh; *p = v; atomicAdd(&info[1], 1); }
+    if (v == 0.0) atomicMin(&info[0], col1based);
+    *s_piv = v;
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane)
+{   // wave-uniform source lane (compile-time after unrolling) -> v_readlane_b32 x2, no LDS
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Unpivoted LU of the nb x nb (nb <= 32) block at P (LDS, column-major, ld), executed by ONE wave entirely in
+// registers: lane r holds row r (identity-padded to 32), pivot rows are broadcast with v_readlane.
+// s_rinv[j] receives 1/U(j,j) (1 for a zero pivot, which leaves the column unscaled like pdgstrf2.c:566-575).
+__device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, int replace_tiny, double thresh,
+                                          int *info, double *s_rinv)
+{
+    const int lane = threadIdx.x & 63;
+    double a[DB];
+#pragma unroll
+    for (int c = 0; c < DB; ++c) a[c] = (lane < nb && c < nb) ? P[c * ld + lane] : ((c == lane) ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < DB; ++j) {
+        double p = lane_bcast(a[j], j);
+        if (j < nb) {
+            if (replace_tiny && fabs(p) < thresh) {
+                p = (p < 0) ? -thresh : thresh;
+                if (lane == j) a[j] = p;
+                if (lane == 0) atomicAdd(&info[1], 1);
+            }
+            if (p == 0.0 && lane == 0) atomicMin(&info[0], col1 + j);
+        }
+        const double rinv = (p != 0.0) ? 1.0 / p : 1.0;
+        if (lane == 0) s_rinv[j] = rinv;
+        const bool below = lane > j;
+        const double l = a[j] * rinv;
+        if (below) a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < DB; ++c) {
+            const double u = lane_bcast(a[c], j);
+            if (below) a[c] -= l * u;
+            if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the broadcast SGPRs
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < DB; ++c) if (lane < nb && c < nb) P[c * ld + lane] = a[c];
+}
+
+// Blocked right-looking LU of the diagonal block in place in HBM/L2 (the block is re-read through L2 only):
+// per 32 columns: panel -> LDS, 32x32 head factored in registers by one wave, rows below solved one per thread
+// in registers, U12 one column per thread in registers, rank-32 trailing update on fp64 MFMA.
+// NSMAX (64/128/256) fixes the LDS strides at compile time so that the unrolled substitutions address LDS with
+// immediate offsets.
+template <int NSMAX>
+__global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restrict__ nodes,
+                                                 int replace_tiny, double thresh, int *__restrict__ info)
+{
+    constexpr int UC = 64;                  // U12 is staged 64 columns at a time: keeps the workgroup at <= 82 KB of LDS
+    constexpr int ldp = NSMAX + 1, lus = UC;
+    __shared__ double s_a[DB * ldp + DB * lus];
+    __shared__ double s_rinv[DB];
+    const int k = nodes[blockIdx.x];
+    if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;           // XY grid: the owner of the diagonal block factors it
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_dlda[k];
+    double *A = T.val + T.sn_dptr[k];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *Ps = s_a;                       // column panel: element (r, c) at Ps[c * ldp + r]
+    double *Us = s_a + DB * ldp;            // 64-column slice of U12: element (kk, c) at Us[kk * lus + c]
+    for (int jb = 0; jb < ns; jb += DB) {
+        const int nb = min(DB, ns - jb), m = ns - jb, nc = m - nb;
+#pragma unroll 8
+        for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; Ps[c * ldp + r] = A[jb + r + (size_t) (jb + c) * lda]; }
+        __syncthreads();
+        if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info, s_rinv);
+        __syncthreads();
+        if (tid < nc) {   // L21 row: x U11 = a   (nc > 0 implies nb == 32)
+            double x[DB];
+#pragma unroll
+            for (int c = 0; c < DB; ++c) x[c] = Ps[c * ldp + nb + tid];
+#pragma unroll
+            for (int j = 0; j < DB; ++j) {
+                double acc = x[j];
+#pragma unroll
+                for (int kk = 0; kk < j; ++kk) acc -= x[kk] * Ps[j * ldp + kk];
+                x[j] = acc * s_rinv[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < DB; ++c) Ps[c * ldp + nb + tid] = x[c];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int idx = tid; idx < m * nb; idx += 256) { int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
+        if (nc > 0) {
+            // U12 = L11^-1 A12 : one thread per column, forward substitution in registers, result back to HBM/L2
+            for (int c = tid; c < nc; c += 256) {
+                double *col = A + jb + (size_t) (jb + nb + c) * lda;
+                double x[DB];
+#pragma unroll
+                for (int i2 = 0; i2 < DB; ++i2) x[i2] = col[i2];
+#pragma unroll
+                for (int i2 = 1; i2 < DB; ++i2) {
+                    double acc = x[i2];
+#pragma unroll
+                    for (int kk = 0; kk < i2; ++kk) acc -= Ps[kk * ldp + i2] * x[kk];
+                    x[i2] = acc;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < DB; ++i2) col[i2] = x[i2];
+            }
+            __syncthreads();
+            // A22 -= L21 U12 on MFMA, 64 columns of U12 at a time; A := U12^T, B := L21^T so that the 16 fast lanes run
+            // along rows (contiguous in the column-major block).  4 output blocks per wave iteration: 4 independent
+            // MFMA chains, and the 16 destination values per lane go as 16 loads then 16 stores (one L2 round trip).
+            const int ntr = (nc + 15) >> 4;
+            for (int c0 = 0; c0 < nc; c0 += UC) {
+                const int ncc = min(UC, nc - c0), ntc = (ncc + 15) >> 4;
+#pragma unroll 8
+                for (int idx = tid; idx < DB * ncc; idx += 256) { int i2 = idx & 31, c = idx >> 5; Us[i2 * lus + c] = A[jb + i2 + (size_t) (jb + nb + c0 + c) * lda]; }
+                __syncthreads();
+                for (int t0 = wave * 4; t0 < ntr * ntc; t0 += 16) {
+                    d4 acc[4];
+                    int ti[4], tj[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int t = min(t0 + g, ntr * ntc - 1);
+                        ti[g] = t % ntr; tj[g] = t / ntr;
+                        acc[g] = (d4){0.0, 0.0, 0.0, 0.0};
+                    }
+#pragma unroll
+                    for (int k4 = 0; k4 < DB; k4 += 4) {
+                        const int kk = k4 + (lane >> 4);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int rr = min(ti[g] * 16 + (lane & 15), nc - 1), cc = min(tj[g] * 16 + (lane & 15), ncc - 1);
+                            acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kk * lus + cc], Ps[kk * ldp + nb + rr], acc[g], 0, 0, 0);
+                        }
+                    }
+                    double old[4][4];
+                    double *dst[4][4];
+                    bool ok[4][4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = ti[g] * 16 + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = tj[g] * 16 + (lane >> 4) + 4 * r;
+                            ok[g][r] = (t0 + g < ntr * ntc) && row < nc && col < ncc;
+                            dst[g][r] = A + jb + nb + min(row, nc - 1) + (size_t) (jb + nb + c0 + min(col, ncc - 1)) * lda;
+                            old[g][r] = ok[g][r] ? *dst[g][r] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ok[g][r]) *dst[g][r] = old[g][r] - acc[g][r];
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Inverses of the 32x32 diagonal sub-blocks of U_kk (typ 0) and L_kk^T (typ 1, unit), identity-padded past
+// ns, written to T.dinv; 4 sub-blocks per 128-thread workgroup, one thread per column of an inverse
+// (back substitution with the block and the private solution column staged in LDS).
+__global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__restrict__ nodes,
+                                                  const int *__restrict__ prefix, int nn)
+{
+    __shared__ double Bs[4][DB * (DB + 1)];
+    __shared__ double Xi[4][DB * (DB + 1)];
+    const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int task = blockIdx.x * 4 + g;
+    bool valid = task < prefix[nn];
+    int k = 0, typ = 0, b = 0, ns = 0, lda = 1, nblk = 1;
+    const double *A = nullptr;
+    int ni = 0;
+    if (valid) {
+        ni = find_node(prefix, nn, task);
+        k = nodes[ni];
+        if (!(T.sn_flags[k] & SNF_HAS_DIAG)) valid = false;
+    }
+    if (valid) {
+        ns = T.xsup[k + 1] - T.xsup[k];
+        nblk = (ns + DB - 1) / DB;
+        const int rem = task - prefix[ni];
+        typ = rem / nblk; b = rem - typ * nblk;
+        lda = T.sn_dlda[k];
+        A = T.val + T.sn_dptr[k];
+    }
+    const int o = b * DB;
+    if (valid) {
+        for (int i = 0; i < DB; ++i) {
+            double v = (i == c) ? 1.0 : 0.0;
+            if (o + i < ns && o + c < ns && i <= c) {
+                if (typ == 0) v = A[o + i + (size_t) (o + c) * lda];               // U(i,c)
+                else if (i < c) v = A[o + c + (size_t) (o + i) * lda];            // L(c,i) = (L^T)(i,c)
+            }
+            Bs[g][i * (DB + 1) + c] = v;
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        for (int i = c; i >= 0; --i) {
+            double a = (i == c) ? 1.0 : 0.0;
+            for (int jj = i + 1; jj <= c; ++jj) a -= Bs[g][i * (DB + 1) + jj] * Xi[g][jj * (DB + 1) + c];
+            Xi[g][i * (DB + 1) + c] = a / Bs[g][i * (DB + 1) + i];
+        }
+        double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB + c * DB;
+        for (int i = 0; i < DB; ++i) dst[i] = (i <= c) ? Xi[g][i * (DB + 1) + c] : 0.0;
+    }
+}
+
+// ---- panel TRSMs: blocked by 32 with inverted diagonal sub-blocks, GEMM parts on fp64 MFMA ---------------
+// MODE 0  L(:,k) <- L(:,k) U_kk^-1        (dLPanelTrSolve, dtrfCommWrapper.c:120-223: TRSM R,U,N,N)
+//         strip = 32 panel rows; T = U_kk.
+// MODE 1  U(k,:) <- L_kk^-1 U(k,:)        (dTrs2_GatherTrsmScatter, pdgstrf2.c:804-840: gather, TRSM L,L,N,U,
+//         scatter) solved as X^T L_kk^T = B^T on the skyline in place: strip = 32 non-empty U columns
+//         (implicit zero padding above each segment), T = L_kk^T (unit upper).
+// The 32 x ns strip lives in LDS for the whole solve: HBM traffic = one read + one write of the panel.
+// Strip height RSv = 64 (nsp <= 128) or 32 (nsp <= 256): either way the workgroup needs <= 82 KB of LDS, so a panel
+// workgroup fits beside ONE 128x128 Schur workgroup on a CU -- the high-priority look-ahead stream can then take any
+// slot a finishing Schur workgroup frees instead of waiting for a whole idle CU.
+// LDS images are split in 16-wide groups ([group][k][16]): a 16x4 MFMA fragment read touches 4 k-rows x 16
+// consecutive doubles = all 64 banks once.  Xs = strip (RSv x nsp), Tb = double-buffered 32x32 operand block.
+// (32-row strips -- 80 KB of LDS, two workgroups per CU or one beside a Schur workgroup -- measured ~2 % slower end to end
+// than 64-row strips -- 144 KB, one per CU -- on 100^3; the host picks, Handle::Env::trsm_rs32)
+constexpr int TB_SZ = DB * 48;   // doubles per operand buffer: [32][48] (c-fastest chunks) or [32][34] (k-fastest chunks)
+static inline size_t trsm_lds_bytes(int rs, int nsp) { return sizeof(double) * ((size_t) rs * nsp + 2 * TB_SZ); }
+
+// The solve is a flat pipeline of 32x32 operand blocks ("chunks"): for every block column jb the off-diagonal
+// blocks T(kc, jb), kc = 0, 32, .. jb-32, then the inverted diagonal block inv(T_jj).  Chunks are fetched from L2
+// into registers TWO iterations ahead (the chain is latency-bound, not bandwidth-bound); one barrier per chunk guards
+// the LDS double buffer.  A wave only ever reads and writes its own 16 strip rows, so the strip needs no barrier.
+template <int MODE, int RSv>
+__device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int strip, double *sm)
+{
+    constexpr int NT = RSv * 4;            // one wave per 16 strip rows
+    constexpr int PQ = DB * DB / NT;       // chunk elements per thread
+    constexpr int ES = NT / 32;            // slow-index stride of the chunk loader
+    const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
+    const int nsp = (ns + DB - 1) & ~(DB - 1);
+    const int lda = T.sn_nsupr[k];            // L slot (MODE 0 strips)
+    const int ldd = T.sn_dlda[k];             // diagonal block: top of the L slot on its owner row, scratch image elsewhere
+    const int nblk = nsp / DB;
+    double *A = T.val + T.sn_lval[k];
+    const double *Dg = T.val + T.sn_dptr[k];
+    double *Uv = T.val + T.sn_uval[k];
+    const double *dinv = T.dinv + T.sn_dinv[k] + (MODE == 0 ? 0 : (size_t) nblk * DB * DB);
+    double *Xs = sm;                          // [RSv/16][nsp][16]: element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
+    double *Tb = sm + (size_t) RSv * nsp;     // [2 buffers] x one 32x32 operand block; the element (kk, cc) sits at cc*34 + kk when
+                                              // the chunk was fetched k-fastest (U_kk blocks, inverse blocks) and at kk*48 + cc when it
+                                              // was fetched c-fastest (L_kk^T blocks): coalesced fetch, conflict-free stash AND fragment reads
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // per-strip-row skyline metadata (MODE 1) lives in the Tb region while the pipeline is not running: the workgroup
+    // then needs exactly RSv*nsp + 2048 doubles (80 KB for nsp = 256) and two of them fit on one CU
+    int *s_cp = reinterpret_cast<int *>(Tb), *s_ld = s_cp + RSv;
+    auto locate = [&]() {
+        if (tid < RSv) {
+            const int cr = strip * RSv + tid;
+            int cp = 0, ld = nsp;
+            if (cr < T.sn_ncolu[k]) {
+                const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+                int lo = 0, hi = nub;
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= cr) lo = mid; else hi = mid; }
+                const int b = ub0 + lo;
+                const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+                const int jj = T.unzcol[u0 + (cr - T.ub_stcol[b])];
+                ld = ns - (klst - T.uidx[u0 + jj]);
+                cp = T.ucolptr[u0 + jj];
+            }
+            s_cp[tid] = cp; s_ld[tid] = ld;
+        }
+        __syncthreads();
+    };
+
+    if (MODE == 0) {
+        const int row0 = T.sn_ldiag[k] + strip * RSv;
+#pragma unroll 8
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
+            const int r = idx % RSv, c = idx / RSv;
+            double v = 0.0;
+            if (c < ns && row0 + r < lda) v = A[row0 + r + (size_t) c * lda];
+            Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
+        }
+    } else {
+        locate();
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
+            const int c = idx % nsp, r = idx / nsp;
+            double v = 0.0;
+            const int ld = s_ld[r];
+            if (c >= ld && c < ns) v = Uv[s_cp[r] + (c - ld)];
+            Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = v;
+        }
+        __syncthreads();   // the metadata overlay is about to be overwritten by the first chunk
+    }
+
+    // chunk (jb, t): t < jb/32 -> T(32 t, jb) ; t == jb/32 -> inv(T_jj)
+    const int e0 = tid & 31, e1 = tid >> 5;   // fast / slow element index of the 32x32 chunk (slow: e1 + ES*q)
+    auto fetch = [&](double *pv, int jb, int t) {
+        if (t * DB < jb) {
+            const int kc = t * DB;
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) {
+                // MODE 0: T(k,c) = U_kk(k,c) = A[k + c*lda], k fastest ; MODE 1: T(k,c) = L_kk(c,k) = A[c + k*lda], c fastest
+                const int kg = kc + (MODE == 0 ? e0 : e1 + ES * q), cg = jb + (MODE == 0 ? e1 + ES * q : e0);
+                pv[q] = (kg < ns && cg < ns) ? (MODE == 0 ? Dg[kg + (size_t) cg * ldd] : Dg[cg + (size_t) kg * ldd]) : 0.0;
+            }
+        } else {
+            const double *dblk = dinv + (size_t) (jb / DB) * DB * DB;
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) pv[q] = dblk[(e1 + ES * q) * DB + e0];   // D(kk = e0, cc = e1 + ES*q)
+        }
+    };
+    auto stash = [&](const double *pv, int jb, int t, int buf) {
+        double *tb = Tb + buf * TB_SZ;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            if (t * DB < jb && MODE == 1) tb[(e1 + ES * q) * 48 + e0] = pv[q];   // (kk = e1 + ES q, cc = e0)
+            else tb[(e1 + ES * q) * 34 + e0] = pv[q];                            // (kk = e0, cc = e1 + ES q)
+        }
+    };
+    auto advance = [&](int &jb, int &t) { if (++t > jb / DB) { jb += DB; t = 0; } };
+
+    d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *xa = Xs + ((size_t) wave * nsp + (lane >> 4)) * 16 + (lane & 15);
+    auto compute = [&](int jb, int t, int buf) {
+        // fragment element (kk = k4 + lane>>4, cc = half*16 + lane&15)
+        const bool cfast = (MODE == 1) && (t < jb / DB);
+        const int sk = cfast ? 48 : 1, sc = cfast ? 1 : 34;
+        const double *tb0 = Tb + buf * TB_SZ + (lane >> 4) * sk + (lane & 15) * sc;
+        const double *tb1 = tb0 + 16 * sc;
+        const int ks = 4 * sk;   // pointer step per k4
+        if (t < jb / DB) {
+            const double *a = xa + (size_t) (t * DB) * 16;
+#pragma unroll
+            for (int k4 = 0; k4 < DB; k4 += 4) {
+                const double av = a[k4 * 16];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[(k4 >> 2) * ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[(k4 >> 2) * ks], acc1, 0, 0, 0);
+            }
+        } else {
+            // rhs = X_jb - acc (own 16 rows), then X_jb = rhs * inv(T_jj)
+            double *x0 = Xs + ((size_t) wave * nsp + jb + (lane & 15)) * 16 + (lane >> 4);
+            double *x1 = x0 + 16 * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0[4 * r] -= acc0[r]; x1[4 * r] -= acc1[r]; }
+            acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+            const double *a = xa + (size_t) jb * 16;
+#pragma unroll
+            for (int k4 = 0; k4 < DB; k4 += 4) {
+                const double av = a[k4 * 16];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb0[(k4 >> 2) * ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb1[(k4 >> 2) * ks], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0[4 * r] = acc0[r]; x1[4 * r] = acc1[r]; }
+            acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+    };
+
+    // software pipeline, two chunks in flight in registers (pA: chunk i+1, pB: chunk i+2, roles swap every iteration)
+    double pA[PQ], pB[PQ];
+    int cj = 0, ct = 0;            // chunk being computed
+    int nj = 0, nt = 0;            // chunk held in the "next" register set
+    int fj = 0, ft = 0;            // chunk held in the "far" register set
+    fetch(pA, 0, 0);
+    stash(pA, 0, 0, 0);
+    advance(nj, nt);
+    fj = nj; ft = nt; advance(fj, ft);
+    if (nj < nsp) fetch(pA, nj, nt);
+    if (fj < nsp) fetch(pB, fj, ft);
+    __syncthreads();
+    int buf = 0;
+    while (cj < nsp) {
+        // iteration with roles (next = pA, far = pB)
+        compute(cj, ct, buf);
+        if (nj < nsp) stash(pA, nj, nt, buf ^ 1);
+        cj = nj; ct = nt; nj = fj; nt = ft; advance(fj, ft);
+        if (fj < nsp) fetch(pA, fj, ft);           // pA is free again: becomes the new "far" set
+        __syncthreads();
+        buf ^= 1;
+        if (cj >= nsp) break;
+        // iteration with roles swapped (next = pB, far = pA)
+        compute(cj, ct, buf);
+        if (nj < nsp) stash(pB, nj, nt, buf ^ 1);
+        cj = nj; ct = nt; nj = fj; nt = ft; advance(fj, ft);
+        if (fj < nsp) fetch(pB, fj, ft);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    if (MODE == 0) {
+        const int row0 = T.sn_ldiag[k] + strip * RSv;
+#pragma unroll 8
+        for (int idx = tid; idx < RSv * ns; idx += NT) {
+            const int r = idx % RSv, c = idx / RSv;
+            if (row0 + r < lda) A[row0 + r + (size_t) c * lda] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
+        }
+    } else {
+        locate();
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
+            const int c = idx % nsp, r = idx / nsp;
+            const int ld = s_ld[r];
+            if (c >= ld && c < ns) Uv[s_cp[r] + (c - ld)] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
+        }
+    }
+}
+
+// L strips (blocks [0, nl)) and U column strips (blocks [nl, nl+nu)) of one level in ONE launch
+template <int RSv>
+__global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *__restrict__ nodes,
+                                                        const int *__restrict__ lprefix, const int *__restrict__ uprefix,
+                                                        int nn, int nl)
+{
+    extern __shared__ double sm[];
+    if ((int) blockIdx.x < nl) {
+        const int ni = find_node(lprefix, nn, blockIdx.x);
+        panel_trsm_body<0, RSv>(T, nodes[ni], blockIdx.x - lprefix[ni], sm);
+    } else {
+        const int id = blockIdx.x - nl;
+        const int ni = find_node(uprefix, nn, id);
+        panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm);
+    }
+}
+
+// ---- iterative refinement (pdgsrfs3d, SRC/double/pdgsrfs.c:345-510) --------------------------------
+// One pass over the CSR matrix does both of the reference's pdgsmv calls (abs = 0 and abs = 1, pdgsmv.c): residual
+// r = b - A x (stored permuted, r_perm[perm_c[i]] = r_i: the right-hand side of the triangular solves on Pc A Pc^T),
+// temp = |A||x| + |b|, and the componentwise backward error max_i |r_i| / temp_i with the SAFE1/SAFE2 guards
+// (:463-469), reduced per workgroup and combined with an integer atomicMax (non-negative doubles order like
+// their bit patterns).  HBM-bound: 12 B per nonzero + 32 B per row.
+__global__ __launch_bounds__(256) void k_rfs_residual(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                      const double *__restrict__ av, const double *__restrict__ x,
+                                                      const double *__restrict__ b, const int *__restrict__ pc,
+                                                      double *__restrict__ r_perm, unsigned long long *__restrict__ s_out,
+                                                      double safe1, double safe2)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double q = 0.0;
+    if (i < n) {
+        double ax = 0.0, t = 0.0;
+        for (int e = rp[i]; e < rp[i + 1]; ++e) {
+            const double a = av[e], xv = x[ci[e]];
+            ax += a * xv;
+            t += fabs(a) * fabs(xv);
+        }
+        const double r = b[i] - ax;
+        t += fabs(b[i]);
+        r_perm[pc[i]] = r;
+        if (t > safe2) q = fabs(r) / t;
+        else if (t != 0.0) q = (safe1 + fabs(r)) / t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q = fmax(q, __shfl_xor(q, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(s_out, (unsigned long long) __double_as_longlong(q));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rfs_update(int n, const int *__restrict__ pc, const double *__restrict__ dx_perm,
+                                                    double *__restrict__ x)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] += dx_perm[pc[i]];
+}
+
+// ---- Schur complement update: fused gather -> MFMA fp64 GEMM -> scatter ---------------------------
+// One workgroup (4 waves) per 64x64 tile of one (L block, U block) pair of one supernode of the level.
+// MFMA v_mfma_f64_16x16x4_f64 computes D[i][j] = sum_k A[i][k] B[k][j] with lane l holding
+// A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[(l>>4)+4r][l&15].  We feed A := U^T (i = tile column) and
+// B := L^T (j = tile row) so that the 16 fast lanes of every accumulator register run along tile ROWS:
+// the scatter then writes 128-byte runs of a destination column (column-major L panel / U skyline).
+
+// Two tile configurations: 128x128 (wide supernodes, big block pairs: 4x4 MFMA blocks per wave) and 64x64
+// (everything else).  Software pipeline: the next K chunk is fetched from HBM/L2 into registers while the
+// MFMAs of the current chunk run out of the other LDS buffer (one barrier per chunk).
+template <int TMv, int TNv, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void k_schur(DevTables T, const int *__restrict__ nodes,
+                                                                    const int *__restrict__ prefix, int nn, int id_base,
+                                                                    int ntiles, int *__restrict__ info,
+                                                                    const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
+                                                                    int skip_level)
+{
+    constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
+    constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
+    constexpr int NT = NW * 64;                         // threads per workgroup
+    constexpr int WR = (NW == 8) ? 4 : 2, WC = 2;       // wave grid (rows x cols): 4 waves = 2x2, 8 waves = 4x2
+    constexpr int NBR = TMv / (16 * WR), NBC = TNv / (16 * WC);   // 16x16 MFMA blocks per wave (rows, cols)
+    constexpr int LQ = TMv * KC / NT, UQ = TNv * KC / NT;         // prefetch registers per thread
+    constexpr int LKS = NT / TMv;                       // k stride of the L loader
+    constexpr int UJS = NT / 16;                        // column stride of the U loader
+    __shared__ double Ls[2][KC * LDL];
+    __shared__ double Us[2][KC * LDU];
+    __shared__ int s_ind[256 + 8];
+    __shared__ int s_rowmap[TMv];
+    __shared__ int s_colmap[TNv];
+    __shared__ int s_cptr[TNv];   // value offset of tile column j inside U(k,:)
+    __shared__ int s_lead[TNv];   // ns - seg (leading zeros) of tile column j
+    __shared__ int s_cptr2[TNv];  // the same two for the fused predecessor supernode (K-fused chain update)
+    __shared__ int s_lead2[TNv];
+    __shared__ int s_jj[TNv];     // column id inside supernode jb
+    __shared__ int64_t s_dbase;
+    __shared__ int s_dinfo[4];
+
+    const int tid = threadIdx.x;
+    // XCD-aware mapping: workgroup b runs on XCD b%8; give every XCD a contiguous range of tiles so that the
+    // row tile (L rows) shared by consecutive tiles stays in ONE XCD's L2
+    int bid;
+    {
+        const int chunk = (ntiles + 7) >> 3;
+        bid = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= chunk || bid >= ntiles) return;
+        bid += id_base;
+    }
+    // look-ahead split: `ulist` != null -> explicit (k, row tile, col tile) list of the tiles that update the NEXT
+    // level's panels ("urgent"); otherwise the full tile grid, minus those tiles when skip_level >= 0
+    int k, rt, ct;
+    if (ulist) {
+        const int4 u = ulist[bid];
+        k = u.x; rt = u.y; ct = u.z;
+    } else {
+        const int ni = find_node(prefix, nn, bid);
+        k = nodes[ni];
+        const int local = bid - prefix[ni];
+        const int nct = T.sn_nct[k];
+        rt = local / nct; ct = local - rt * nct;
+    }
+    const int4 R = T.rtile[T.sn_rt_off[k] + rt];
+    const int4 C = T.ctile[T.sn_ct_off[k] + ct];
+    const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
+    const int nr = R.z, nc = C.z;
+    const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
+    if (!ulist && skip_level >= 0 && (sn_level[ib] == skip_level || sn_level[jb] == skip_level)) return;  // done by the urgent launch
+    if (!ulist && T.defer && T.defer[k]) return;   // K-fused: the partner supernode's tiles apply this update
+    const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
+    const int lda = T.sn_nsupr[k];
+    const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;  // global row ids of the tile rows
+    const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
+    const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
+    const double *Uv = T.val + T.sn_uval[k];
+
+    // K-fused update: the deferred updates of up to three predecessors of k in its chain (k = parent(k-1) = ..., consecutive
+    // levels) are accumulated here in the same registers -> ONE prologue and ONE scatter for K = sum of their widths.  A
+    // predecessor's block structure beyond k is a subset of k's: host-built maps give, per panel row / non-empty U
+    // column of k, where the same global row / column sits in its panel / U row (or that it is absent = zeros).
+    int nprev = 0;
+    if (T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
+    for (int t = tid; t < TNv; t += NT) {
+        int cp = 0, lead = ns, jj = 0;
+        if (t < nc) {
+            jj = T.unzcol[uix0 + C.y + t];
+            lead = ns - (klst - T.uidx[uix0 + jj]);
+            cp = T.ucolptr[uix0 + jj];
+        }
+        s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
+    }
+    // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
+    if ((tid >> 6) == NW - 1) {
+        // one wave scans the gid directory of the destination panel / row with ONE coalesced load per 64 blocks and a
+        // ballot, instead of a binary search whose every step is a dependent L2 round trip
+        const int ln = tid & 63;
+        const bool ldest = ib >= jb;
+        const int o = ldest ? T.sn_lb_off[jb] : T.sn_ub_off[ib];
+        const int nb = ldest ? T.sn_nlb[jb] : T.sn_nub[ib];
+        const int *dir = ldest ? T.lbs_gid : T.ub_gid;
+        const int want = ldest ? ib : jb;
+        int pos = -1;
+        for (int base = 0; base < nb && pos < 0; base += 64) {
+            const int g = (base + ln < nb) ? dir[o + base + ln] : -1;
+            const unsigned long long m = __ballot(g == want);
+            if (m) pos = base + __ffsll((long long) m) - 1;
+        }
+        if (ln == 0) {
+            if (pos >= 0) {
+                if (ldest) {
+                    const int d = o + T.lbs_idx[o + pos];
+                    s_dinfo[0] = T.lb_rowoff[d]; s_dinfo[1] = T.lb_lptr[d]; s_dinfo[2] = T.lb_nbrow[d];
+                    s_dbase = T.sn_lval[jb];
+                } else {
+                    s_dinfo[0] = T.ub_iukp[o + pos];
+                    s_dbase = T.sn_uval[ib];
+                }
+            } else atomicAdd(&info[2], 1);
+            s_dinfo[3] = pos >= 0;
+        }
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int rm0 = (wave % WR) * (TMv / WR), cn0 = (wave / WR) * (TNv / WC);
+    d4 acc[NBC][NBR];
+#pragma unroll
+    for (int a = 0; a < NBC; ++a)
+#pragma unroll
+        for (int b = 0; b < NBR; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int li = tid % TMv, lk = tid / TMv;           // L loader: row li, k = lk + LKS*q
+    const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + UJS*q
+    double pl[LQ], pu[UQ];
+    int ucp[UQ], uld[UQ];
+    bool lrow_ok = li < nr;
+    // per-source state of the K loop (source 0 = fused predecessor ka, source 1 = k itself)
+    int ns_s = ns, lda_s = lda;
+    const double *Lrow = Lp + li, *Uvs = Uv;
+
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) {
+            const int kg = k0 + lk + LKS * q;
+            pl[q] = (lrow_ok && kg < ns_s) ? Lrow[(size_t) kg * lda_s] : 0.0;
+        }
+        const int kg = k0 + uk;
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) pu[q] = (kg >= uld[q] && kg < ns_s) ? Uvs[ucp[q] + (kg - uld[q])] : 0.0;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) Ls[buf][(lk + LKS * q) * LDL + li] = pl[q];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + UJS * q] = pu[q];
+    };
+
+    int buf = 0;
+    for (int src = 0; src <= nprev; ++src) {       // farthest predecessor first, k itself last
+        int kbeg;
+        if (src < nprev) {
+            const int pj = 3 * k + (nprev - 1 - src);
+            const int ks = T.fuse_prev[pj];
+            const int nss = T.xsup[ks + 1] - T.xsup[ks];
+            const int *cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[pj] + T.ub_stcol[ub] + C.y);
+            const int ra = (li < nr) ? T.pair_rowmap[T.pair_roff[pj] + R.w + li] : -1;
+            for (int t = tid; t < TNv; t += NT) {
+                s_cptr2[t] = (t < nc) ? cinfo[2 * t] : 0;
+                s_lead2[t] = (t < nc) ? cinfo[2 * t + 1] : nss;
+            }
+            __syncthreads();
+            ns_s = nss; lda_s = T.sn_nsupr[ks]; Lrow = T.val + T.sn_lval[ks] + max(ra, 0); Uvs = T.val + T.sn_uval[ks];
+            kbeg = (nss - T.sn_ldu[ks]) & ~3; lrow_ok = ra >= 0;
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr2[uj + UJS * q]; uld[q] = s_lead2[uj + UJS * q]; }
+        } else {
+            ns_s = ns; lda_s = lda; Lrow = Lp + li; Uvs = Uv; lrow_ok = li < nr;
+            kbeg = (ns - T.sn_ldu[k]) & ~3;              // U is zero above its tallest segment: skip those k
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + UJS * q]; uld[q] = s_lead[uj + UJS * q]; }
+        }
+        // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
+        fetch(kbeg);
+        stash(buf);
+        __syncthreads();
+        for (int k0 = kbeg; k0 < ns_s; k0 += KC) {
+            const bool more = k0 + KC < ns_s;
+            if (more) fetch(k0 + KC);
+            const double *Lb = Ls[buf], *Ub = Us[buf];
+#pragma unroll
+            for (int k4 = 0; k4 < KC; k4 += 4) {
+                const int kr = k4 + (lane >> 4);
+                double a[NBC], b[NBR];
+#pragma unroll
+                for (int c = 0; c < NBC; ++c) a[c] = Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
+#pragma unroll
+                for (int r = 0; r < NBR; ++r) b[r] = Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
+#pragma unroll
+                for (int c = 0; c < NBC; ++c)
+#pragma unroll
+                    for (int r = 0; r < NBR; ++r) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[r], acc[c][r], 0, 0, 0);
+            }
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---- scatter (epilogue) ----------------------------------------------------------------------
+    if (!s_dinfo[3]) return;
+    double *dst = T.val + s_dbase;
+    if (ib >= jb) {
+        // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
+        const int *drows = T.lidx + T.sn_lidx[jb] + s_dinfo[1];
+        const int fnz = T.xsup[ib], dn = s_dinfo[2];
+        for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
+        __syncthreads();
+        for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? s_dinfo[0] + s_ind[lsub[t] - fnz] : 0;
+        const int ldv = T.sn_nsupr[jb];
+        for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * ldv;
+    } else {
+        const int64_t d0 = T.sn_uidx[ib] + s_dinfo[0];
+        for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
+        for (int t = tid; t < TNv; t += NT) {
+            int cm = 0;
+            if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
+            s_colmap[t] = cm;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < NBC; ++ci)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = cn0 + 16 * ci + (lane >> 4) + 4 * r;
+            if (col < nc) {
+                double *dcol = dst + s_colmap[col];
+#pragma unroll
+                for (int ri = 0; ri < NBR; ++ri) {
+                    const int row = rm0 + 16 * ri + (lane & 15);
+                    if (row < nr) atomic_sub_f64(dcol + s_rowmap[row], acc[ci][ri][r]);
+                }
+            }
+        }
+}
+
+// ---- triangular solves --------------------------------------------------------------------------
+// x_k <- inv(L_kk) x_k (unit lower) or inv(U_kk) x_k (upper): one workgroup per supernode of the level,
+// blocked by 32 with the inverted diagonal sub-blocks left in T.dinv by the factorisation (what the reference's
+// DiagInv=YES solve does with Linv/Uinv, pdgstrs_lsum.c:414-520): 2 barriers per 32 columns.
+template <bool LOWER>
+__global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
+                                                    int64_t ldx, int nrhs)
+{
+    extern __shared__ double xs[];  // ns x nrhs, then 32 x nrhs scratch
+    const int k = nodes[blockIdx.x];
+    if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;           // x_k is solved by the owner of the diagonal block
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_dlda[k];
+    const double *A = T.val + T.sn_dptr[k];
+    const int nblk = (ns + DB - 1) / DB;
+    const double *dinv = T.dinv + T.sn_dinv[k] + (LOWER ? (size_t) nblk * DB * DB : 0);
+    double *ys = xs + (size_t) ns * nrhs;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < ns * nrhs; idx += 256) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    __syncthreads();
+    for (int bb = 0; bb < nblk; ++bb) {
+        const int b = LOWER ? bb : nblk - 1 - bb;
+        const int o = b * DB, nb = min(DB, ns - o);
+        const double *D = dinv + (size_t) b * DB * DB;
+        // y = inv(T_bb) x_b : LOWER inv(L_bb)(r,c) = D(c,r) ; UPPER inv(U_bb)(r,c) = D(r,c) ; D(i,j) at D[j*32+i]
+        for (int idx = tid; idx < nb * nrhs; idx += 256) {
+            const int r = idx % nb, q = idx / nb;
+            const double *xb = xs + o + q * ns;
+            // fixed trip count + predication: the 32 loads of D are issued together instead of one L2 round trip each
+            double dv[DB];
+#pragma unroll
+            for (int c = 0; c < DB; ++c) dv[c] = (LOWER ? (c <= r) : (c >= r && c < nb)) ? (LOWER ? D[r * DB + c] : D[c * DB + r]) : 0.0;
+            double a = 0.0;
+#pragma unroll
+            for (int c = 0; c < DB; ++c) a += dv[c] * ((c < nb) ? xb[c] : 0.0);
+            ys[r + q * DB] = a;
+        }
+        __syncthreads();
+        // x_b = y ; remaining rows -= T(rows, b) y
+        const int r0 = LOWER ? o + nb : 0, r1 = LOWER ? ns : o;
+        for (int idx = tid; idx < (r1 - r0 + nb) * nrhs; idx += 256) {
+            const int rr = idx % (r1 - r0 + nb), q = idx / (r1 - r0 + nb);
+            if (rr < nb) { xs[o + rr + q * ns] = ys[rr + q * DB]; continue; }
+            const int i = r0 + (rr - nb);
+            double av[DB];
+#pragma unroll
+            for (int c = 0; c < DB; ++c) av[c] = (c < nb) ? A[i + (size_t) (o + c) * lda] : 0.0;
+            double a = 0.0;
+#pragma unroll
+            for (int c = 0; c < DB; ++c) a += av[c] * ys[c + q * DB];
+            xs[i + q * ns] -= a;
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < ns * nrhs; idx += 256) x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = xs[idx];
+}
+
+// lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414):
+// one thread per panel row, 256-row strips; x_k staged in LDS.
+__global__ __launch_bounds__(256) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                    int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+{
+    extern __shared__ double xk[];  // ns x nrhs
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int strip = blockIdx.x - prefix[ni];
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_nsupr[k];
+    for (int idx = threadIdx.x; idx < ns * nrhs; idx += 256) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    __syncthreads();
+    const int row = T.sn_ldiag[k] + strip * 256 + threadIdx.x;
+    if (row >= lda) return;
+    const double *L = T.val + T.sn_lval[k] + row;
+    // global row id of panel row `row`: rows are listed block after block, 2 descriptor ints per block
+    // -> precomputed flat map is not stored; walk the (few) blocks
+    const int *lsub = T.lidx + T.sn_lidx[k];
+    int p = BC_HEADER, base = 0, grow = -1;
+    const int nb = lsub[0];
+    for (int b = 0; b < nb; ++b) {
+        const int nbrow = lsub[p + 1];
+        if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
+        base += nbrow; p += LB_DESCRIPTOR + nbrow;
+    }
+    for (int r = 0; r < nrhs; ++r) {
+        double acc = 0.0;
+        for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * xk[kk + r * ns];
+        atomic_sub_f64(x + grow + (int64_t) r * ldx, acc);
+    }
+}
+
+// x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362):
+// lanes run along the rows of supernode k (coalesced over the skyline segments), the 4 waves split the columns.
+__global__ __launch_bounds__(256) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                    int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+{
+    __shared__ int s_cp[64], s_ld[64], s_gc[64];
+    __shared__ double s_red[4][64];
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int chunk = blockIdx.x - prefix[ni];
+    const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
+    const int ncol = min(64, T.sn_ncolu[k] - chunk * 64);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 64) {
+        int cp = 0, ld = ns, gc = 0;
+        if (tid < ncol) {
+            const int c = chunk * 64 + tid;
+            const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+            int lo = 0, hi = nub;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
+            const int b = ub0 + lo;
+            const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+            const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
+            ld = ns - (klst - T.uidx[u0 + jj]);
+            cp = T.ucolptr[u0 + jj];
+            gc = T.xsup[T.ub_gid[b]] + jj;
+        }
+        s_cp[tid] = cp; s_ld[tid] = ld; s_gc[tid] = gc;
+    }
+    __syncthreads();
+    const double *Uv = T.val + T.sn_uval[k];
+    for (int r = 0; r < nrhs; ++r) {
+        for (int rb = 0; rb < ns; rb += 64) {
+            const int i = rb + lane;
+            double acc = 0.0;
+            for (int c = wave; c < ncol; c += 4) {
+                const int ld = s_ld[c];
+                if (i < ns && i >= ld) acc += Uv[s_cp[c] + (i - ld)] * x[s_gc[c] + (int64_t) r * ldx];
+            }
+            s_red[wave][lane] = acc;
+            __syncthreads();
+            if (wave == 0 && i < ns) {
+                const double s = s_red[0][lane] + s_red[1][lane] + s_red[2][lane] + s_red[3][lane];
+                if (s != 0.0) atomic_sub_f64(x + fst + i + (int64_t) r * ldx, s);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// A's entries -> value arena (device-side pddistribute): val[pos[e]] = a[e]
+__global__ void k_scatter_values(double *__restrict__ val, const int64_t *__restrict__ pos, const double *__restrict__ a, int64_t nnz)
+{
+    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) val[pos[e]] = a[e];
+}
+
+// MFMA layout self-test (used by tests): D = A(16x4) * B(4x16)
+__global__ void k_mfma_selftest(const double *A, const double *B, double *D)
+{
+    const int l = threadIdx.x;
+    d4 acc = (d4){0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+#include "sluamd_zkernels.inc"
+
+// ---- exchange helpers (XY block-cyclic layers, Z ancestor reduction, distributed solve) ---------------------------
+// y += a x : the daxpy of dzRecvLPanel / dzRecvUPanel (pd3dcomm.c:189-331) on a whole forest slice; HBM-bound, 24 B/element
+__global__ __launch_bounds__(256) void k_axpy(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) y[i] += a * x[i];
+}
+
+// Own diagonal blocks of one level -> contiguous staging range (ns x ns, lda = ns each): the payload of dDiagFactIBCast
+// (dtrfCommWrapper.c:32-118).  One workgroup per 1024-element chunk.
+constexpr int DGC = 1024;
+__global__ __launch_bounds__(256) void k_pack_diag(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                   const int64_t *__restrict__ off, int nn, double *__restrict__ stage)
+{
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int ns = T.xsup[k + 1] - T.xsup[k];
+    const int e0 = (blockIdx.x - prefix[ni]) * DGC, e1 = min(e0 + DGC, ns * ns);
+    const double *A = T.val + T.sn_dptr[k];
+    const int lda = T.sn_dlda[k];
+    double *S = stage + off[ni];
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) S[e] = A[(e % ns) + (size_t) (e / ns) * lda];
+}
+
+// x segments (runs of rows, all nrhs columns) <-> one contiguous total x nrhs column-major buffer (runs concatenated).
+// mode 0: buf = x ; 1: x = buf ; 2: x += buf ; 3: buf = x, x = 0
+__global__ __launch_bounds__(256) void k_xseg_copy(double *__restrict__ x, int64_t ldx, int nrhs, const int *__restrict__ runs, int nruns,
+                                                   int64_t total, double *__restrict__ buf, int mode)
+{
+    // runs: (row0, nrows, prefix) triples; prefix = rows before this run
+    for (int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x; e < total * nrhs; e += (int64_t) gridDim.x * 256) {
+        const int64_t row = e % total; const int q = (int) (e / total);
+        int lo = 0, hi = nruns;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (runs[3 * mid + 2] <= row) lo = mid; else hi = mid; }
+        double *xp = x + runs[3 * lo] + (row - runs[3 * lo + 2]) + (int64_t) q * ldx;
+        double *bp = buf + row + (int64_t) q * total;
+        if (mode == 0) *bp = *xp;
+        else if (mode == 1) *xp = *bp;
+        else if (mode == 2) *xp += *bp;
+        else { *bp = *xp; *xp = 0.0; }
+    }
+}
+
+// ================================================================================================
+//                              eng:: launchers (sluamd_internal.h)
+// ================================================================================================
+namespace eng {
+
+int setup()
+{
+    // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    return 0;
+}
+
+void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx, int replace_tiny, double thresh, int *info)
+{
+    if (nn <= 0) return;
+    if (mx <= 64) hipLaunchKernelGGL(k_diag_lu<64>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
+    else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
+    else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
+}
+
+void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask)
+{
+    if (ntask > 0) hipLaunchKernelGGL(k_diag_inv, dim3((ntask + 3) / 4), dim3(128), 0, s, T, nodes, prefix, nn);
+}
+
+void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs,
+                int mx)
+{
+    if (nl + nu <= 0) return;
+    const size_t lds = trsm_lds_bytes(rs, (mx + 31) & ~31);
+    if (rs == 32) hipLaunchKernelGGL(k_panel_trsm<32>, dim3(nl + nu), dim3(128), lds, s, T, nodes, lprefix, uprefix, nn, nl);
+    else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nl + nu), dim3(256), lds, s, T, nodes, lprefix, uprefix, nn, nl);
+}
+
+void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
+           const int4 *ulist, const int *sn_level, int skip_level)
+{
+    if (ntiles <= 0) return;
+    const int grid = ((ntiles + 7) / 8) * 8;
+    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
+    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
+    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
+}
+
+void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int mx)
+{
+    if (nn <= 0) return;
+    const size_t lds = (size_t) (mx + 32) * nrhs * sizeof(double);
+    if (lower) hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
+    else hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
+}
+
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx)
+{
+    if (nwork > 0) hipLaunchKernelGGL(k_fwd_update, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
+}
+
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs)
+{
+    if (nwork > 0) hipLaunchKernelGGL(k_bwd_update, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
+}
+
+void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)
+{
+    if (nnz > 0) hipLaunchKernelGGL(k_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, s, val, pos, a, nnz);
+}
+
+void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
+                  double *r_perm, unsigned long long *s_out, double safe1, double safe2)
+{
+    hipLaunchKernelGGL(k_rfs_residual, dim3((n + 255) / 256), dim3(256), 0, s, n, rp, ci, av, x, b, pc, r_perm, s_out, safe1, safe2);
+}
+
+void rfs_update(hipStream_t s, int n, const int *pc, const double *dx_perm, double *x)
+{
+    hipLaunchKernelGGL(k_rfs_update, dim3((n + 255) / 256), dim3(256), 0, s, n, pc, dx_perm, x);
+}
+
+void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y)
+{
+    if (n <= 0) return;
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned) (nb < 8192 ? nb : 8192)), dim3(256), 0, s, n, a, x, y);
+}
+
+void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage)
+{
+    if (nwork > 0) hipLaunchKernelGGL(k_pack_diag, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, off, nn, stage);
+}
+
+void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs, int nruns, int64_t total, double *buf, int mode)
+{
+    if (total <= 0 || nruns <= 0) return;
+    const int64_t nb = (total * nrhs + 255) / 256;
+    hipLaunchKernelGGL(k_xseg_copy, dim3((unsigned) (nb < 4096 ? nb : 4096)), dim3(256), 0, s, x, ldx, nrhs, runs, nruns, total, buf, mode);
+}
+
+int mfma_selftest(const double *A, const double *B, double *D)
+{
+    double *dA, *dB, *dD;
+    HIPCHK(hipMalloc((void **) &dA, 64 * 8)); HIPCHK(hipMalloc((void **) &dB, 64 * 8)); HIPCHK(hipMalloc((void **) &dD, 256 * 8));
+    HIPCHK(hipMemcpy(dA, A, 64 * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dB, B, 64 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    HIPCHK(hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dB); hipFree(dD);
+    return 0;
+}
+
+// ---- complex16 ----
+void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx, int replace_tiny, double thresh, int *info)
+{
+    if (nn > 0) hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), zdiag_lds_bytes(mx), s, T, nodes, replace_tiny, thresh, info, mx | 1);
+}
+void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
+{
+    if (nl + nu > 0) hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
+}
+void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info)
+{
+    if (ntiles > 0) hipLaunchKernelGGL(kz_schur, dim3(((ntiles + 7) / 8) * 8), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info);
+}
+void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int mx)
+{
+    if (nn <= 0) return;
+    const size_t lds = (size_t) mx * nrhs * 16;
+    if (lower) hipLaunchKernelGGL(kz_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, nodes, reinterpret_cast<zc *>(x), ldx, nrhs);
+    else hipLaunchKernelGGL(kz_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, nodes, reinterpret_cast<zc *>(x), ldx, nrhs);
+}
+void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs, int mx)
+{
+    if (nwork > 0) hipLaunchKernelGGL(kz_fwd_update, dim3(nwork), dim3(256), (size_t) mx * nrhs * 16, s, T, nodes, prefix, nn, reinterpret_cast<zc *>(x), ldx, nrhs);
+}
+void zbwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs)
+{
+    if (nwork > 0) hipLaunchKernelGGL(kz_bwd_update, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, reinterpret_cast<zc *>(x), ldx, nrhs);
+}
+void zscatter_values(hipStream_t s, void *val, const int64_t *pos, const void *a, int64_t nnz)
+{
+    if (nnz > 0) hipLaunchKernelGGL(kz_scatter_values, dim3((unsigned) ((nnz + 255) / 256)), dim3(256), 0, s, reinterpret_cast<zc *>(val), pos, reinterpret_cast<const zc *>(a), nnz);
+}
+
+}  // namespace eng
+}  // namespace sluamd

@@ -1,0 +1,616 @@
+// sluamd_plan.cpp -- creation-time planning: slot structures -> level schedules (elimination DAG), value-arena layout
+// (own slots ordered by Z level, DAG level, supernode so that every exchange moves ONE contiguous range), device block
+// tables / tile lists (dSchurComplementSetup's job, dtrfAux.c:102-491, done once), XY panel-exchange plans.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include "sluamd_comm.h"
+#include "sluamd_plan.h"
+
+namespace sluamd {
+
+static inline int nsupc_of(const HostStruct &hs, int k) { return hs.xsup[k + 1] - hs.xsup[k]; }
+
+// ---- DAG levels of one forest: lvl[j] = 1 + max lvl[k] over the supernodes k of the list that update j -------------
+static void dag_levels(const SlotInput &in, const std::vector<int> &list, int ns, std::vector<int> &lvl, int &nlevels)
+{
+    lvl.assign(ns, -1);
+    for (int k : list) lvl[k] = 0;
+    int maxl = 0;
+    for (int k : list) {   // ascending: every predecessor of k has a smaller id
+        const int l1 = lvl[k] + 1;
+        for (int g : in.succ[k]) if (lvl[g] >= 0 && lvl[g] < l1) lvl[g] = l1;
+        maxl = std::max(maxl, lvl[k]);
+    }
+    nlevels = list.empty() ? 0 : maxl + 1;
+}
+
+// ---- block tables, tile lists, flop tallies (host images of DevTables) ---------------------------------------------
+static int build_tables(Handle &H, HostTables &t)
+{
+    const HostStruct &hs = H.hs;
+    const Grid &g = H.grid;
+    const int ns = hs.nsupers;
+    t.sn_lval.resize(ns); t.sn_uval.resize(ns); t.sn_lidx.resize(ns); t.sn_uidx.resize(ns); t.sn_dinv.assign(ns, 0); t.sn_dptr.assign(ns, 0);
+    t.sn_nsupr.assign(ns, 0); t.sn_flags.assign(ns, 0); t.sn_ldiag.assign(ns, 0); t.sn_dlda.assign(ns, 1); t.sn_ldu.assign(ns, 0); t.sn_ncolu.assign(ns, 0);
+    t.sn_lb_off.resize(ns); t.sn_nlb.assign(ns, 0); t.sn_ub_off.resize(ns); t.sn_nub.assign(ns, 0);
+    t.sn_rt_off.resize(ns); t.sn_nrt.assign(ns, 0); t.sn_ct_off.resize(ns); t.sn_nct.assign(ns, 0);
+    t.ucolptr.assign(hs.uidx.size(), 0); t.unzcol.assign(hs.uidx.size(), 0);
+    t.sn_big.assign(ns, 0);
+    H.max_nsupc = 0;
+    auto &st = H.st;
+    st.flops_schur_padded = st.flops_schur_exact = st.flops_panel = 0;
+    st.schur_bytes_alg = 0;
+    for (int k = 0; k < ns; ++k) {
+        const int nsupc = nsupc_of(hs, k), klst = hs.xsup[k + 1];
+        t.sn_lval[k] = hs.lval_off[k]; t.sn_uval[k] = hs.uval_off[k];
+        t.sn_lidx[k] = hs.lidx_off[k]; t.sn_uidx[k] = hs.uidx_off[k];
+        t.sn_lb_off[k] = (int) t.lb_gid.size(); t.sn_ub_off[k] = (int) t.ub_gid.size();
+        t.sn_rt_off[k] = (int) t.rtile.size(); t.sn_ct_off[k] = (int) t.ctile.size();
+        t.sn_dinv[k] = t.dinv_total;
+        if (!hs.present[k]) continue;
+        H.max_nsupc = std::max(H.max_nsupc, nsupc);
+        if (nsupc > 256) { set_error("supernodes wider than 256 columns are not supported yet (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
+        const bool l_own = g.kcol(k) == g.c, u_own = g.krow(k) == g.r;
+        int fl = 0;
+        if (l_own) fl |= SNF_L_OWN;
+        if (u_own) fl |= SNF_U_OWN;
+        if (l_own && u_own) fl |= SNF_OWN_DIAG;
+        if (l_own || u_own) fl |= SNF_HAS_DIAG;
+        t.sn_flags[k] = fl;
+        if (fl & SNF_HAS_DIAG) t.dinv_total += (int64_t) 2 * ((nsupc + 31) / 32) * 32 * 32;
+        const int *li = hs.lidx.data() + hs.lidx_off[k];      // always >= BC_HEADER ints (empty slots carry {0, 0})
+        const int nb = li[0], nsupr = li[1];
+        t.sn_nsupr[k] = nsupr;
+        t.sn_nlb[k] = nb;
+        const int ldiag = (u_own && nb > 0) ? nsupc : 0;      // the process row of k holds the diagonal block at the top of its part
+        t.sn_ldiag[k] = ldiag;
+        int p = BC_HEADER, rowoff = 0;
+        std::vector<std::pair<int, int>> dir;
+        for (int b = 0; b < nb; ++b) {
+            const int gid = li[p], nbrow = li[p + 1];
+            if (gid < k || gid >= ns || nbrow <= 0 || rowoff + nbrow > nsupr) { set_error("malformed L block"); return SLUAMD_ESTRUCT; }
+            if (g.krow(gid) != g.r) { set_error("L block stored on the wrong process row"); return SLUAMD_ESTRUCT; }
+            if (b == 0 && u_own && (gid != k || nbrow != nsupc)) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
+            if (b > 0 && gid == k) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
+            t.lb_gid.push_back(gid); t.lb_nbrow.push_back(nbrow); t.lb_rowoff.push_back(rowoff); t.lb_lptr.push_back(p + LB_DESCRIPTOR);
+            dir.emplace_back(gid, b);
+            rowoff += nbrow; p += LB_DESCRIPTOR + nbrow;
+        }
+        if (rowoff != nsupr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
+        if ((int64_t) nsupr * nsupc != hs.lval_len[k]) { set_error("L panel value count mismatch"); return SLUAMD_ESTRUCT; }
+        std::sort(dir.begin(), dir.end());
+        for (auto &d : dir) { t.lbs_gid.push_back(d.first); t.lbs_idx.push_back(d.second); }
+        // U block row
+        int nub = 0, ldu = 0, ncol_tot = 0;
+        double exact = 0;
+        if (hs.uidx_off[k + 1] > hs.uidx_off[k]) {
+            const int *ui = hs.uidx.data() + hs.uidx_off[k];
+            int *cp = t.ucolptr.data() + hs.uidx_off[k];
+            int *nz = t.unzcol.data() + hs.uidx_off[k];
+            nub = ui[0];
+            int iukp = BR_HEADER; int64_t rukp = 0; int prev = k;
+            for (int b = 0; b < nub; ++b) {
+                const int jb = ui[iukp];
+                if (jb <= prev || jb >= ns) { set_error("U blocks must be sorted by block column"); return SLUAMD_ESTRUCT; }
+                if (g.kcol(jb) != g.c) { set_error("U block stored on the wrong process column"); return SLUAMD_ESTRUCT; }
+                prev = jb;
+                const int nsj = nsupc_of(hs, jb);
+                int nc = 0;
+                for (int jj = 0; jj < nsj; ++jj) {
+                    const int seg = klst - ui[iukp + UB_DESCRIPTOR + jj];
+                    if (seg < 0 || seg > nsupc) { set_error("bad U segment"); return SLUAMD_ESTRUCT; }
+                    cp[iukp + UB_DESCRIPTOR + jj] = (int) rukp;
+                    if (seg) { nz[iukp + UB_DESCRIPTOR + nc] = jj; ++nc; rukp += seg; ldu = std::max(ldu, seg); exact += seg; }
+                }
+                t.ub_gid.push_back(jb); t.ub_ncols.push_back(nc); t.ub_iukp.push_back(iukp + UB_DESCRIPTOR); t.ub_stcol.push_back(ncol_tot);
+                ncol_tot += nc;
+                iukp += UB_DESCRIPTOR + nsj;
+            }
+            if (rukp != hs.uval_len[k]) { set_error("U value count mismatch"); return SLUAMD_ESTRUCT; }
+        }
+        t.sn_nub[k] = nub; t.sn_ldu[k] = ldu; t.sn_ncolu[k] = ncol_tot;
+        {   // tile configuration + tile lists of supernode k
+            const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k];
+            const int bfirst = ldiag ? 1 : 0;
+            long t128r = 0, t128c = 0;
+            for (int b = bfirst; b < nb; ++b) t128r += (t.lb_nbrow[lb0 + b] + 127) / 128;
+            for (int b = 0; b < nub; ++b) t128c += (t.ub_ncols[ub0 + b] + 127) / 128;
+            const double cells = (double) (nsupr - ldiag) * ncol_tot;
+            const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * 128.0 * 128.0) : 0.0;
+            const bool big = !H.z && nsupc >= 96 && util128 >= 0.5 && !H.env.no_big_tiles;
+            t.sn_big[k] = big;
+            const int tm = big ? 128 : 64;
+            for (int b = bfirst; b < nb; ++b) {
+                const int nbrow = t.lb_nbrow[lb0 + b], ro = t.lb_rowoff[lb0 + b];
+                for (int r0 = 0; r0 < nbrow; r0 += tm) t.rtile.push_back(make_int4(b, r0, std::min(tm, nbrow - r0), ro + r0));
+            }
+            t.sn_nrt[k] = (int) t.rtile.size() - t.sn_rt_off[k];
+            for (int b = 0; b < nub; ++b) {
+                const int nc = t.ub_ncols[ub0 + b];
+                for (int c0 = 0; c0 < nc; c0 += tm) t.ctile.push_back(make_int4(b, c0, std::min(tm, nc - c0), 0));
+            }
+            t.sn_nct[k] = (int) t.ctile.size() - t.sn_ct_off[k];
+        }
+        const double rrows = nsupr - ldiag;
+        st.flops_schur_padded += 2.0 * rrows * ldu * ncol_tot;
+        st.schur_bytes_alg += 16.0 * rrows * ncol_tot;   // read-modify-write of every updated destination element
+        st.flops_schur_exact += 2.0 * rrows * exact;
+        if (fl & SNF_OWN_DIAG) st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc;
+        if (l_own) st.flops_panel += (double) nsupc * nsupc * rrows;
+        if (u_own) st.flops_panel += (double) nsupc * exact;
+    }
+    if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; }   // complex multiply-add = 8 flop
+    H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu; H.h_flags = t.sn_flags; H.h_ldiag = t.sn_ldiag;
+    return 0;
+}
+
+// K-fused source a of supernode b (a < b members of one chain): b's tiles will also accumulate a's deferred update.  Needs
+// every row / column of a's structure beyond b to exist in b's structure (true when b is an ancestor of a in the supernodal
+// elimination tree); builds the row map (per panel row of b: row in a's panel or -1) and the column info (per non-empty U
+// column of row b: value offset and leading zeros inside a's U row).  Rejects pairs whose a is much smaller than b (the
+// fused tiles would multiply mostly zeros).
+static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, std::vector<int> &rowmap, std::vector<int> &colinfo)
+{
+    const HostStruct &hs = H.hs;
+    const int sa = nsupc_of(hs, a);
+    const int nsupr_b = t.sn_nsupr[b], ncolu_b = t.sn_ncolu[b];
+    rowmap.assign(nsupr_b, -1);
+    colinfo.assign(2 * (size_t) ncolu_b, 0);
+    for (int c = 0; c < ncolu_b; ++c) colinfo[2 * c + 1] = sa;
+    const int la = t.sn_lb_off[a], lb = t.sn_lb_off[b];
+    int rows_a = 0, cols_a = 0;
+    for (int x = 1; x < t.sn_nlb[a]; ++x) {
+        const int g = t.lb_gid[la + x];
+        if (g <= b) continue;                      // a's updates of the chain members up to b: their urgent tiles
+        int y = -1;
+        for (int q = 1; q < t.sn_nlb[b]; ++q) if (t.lb_gid[lb + q] == g) { y = q; break; }
+        if (y < 0) return false;
+        const int *ra = hs.lidx.data() + hs.lidx_off[a] + t.lb_lptr[la + x], *rb = hs.lidx.data() + hs.lidx_off[b] + t.lb_lptr[lb + y];
+        const int na = t.lb_nbrow[la + x], nb = t.lb_nbrow[lb + y];
+        for (int i = 0; i < na; ++i) {
+            const int *f = std::find(rb, rb + nb, ra[i]);
+            if (f == rb + nb) return false;
+            rowmap[t.lb_rowoff[lb + y] + (int) (f - rb)] = t.lb_rowoff[la + x] + i;
+        }
+        rows_a += na;
+    }
+    const int ua = t.sn_ub_off[a], ub = t.sn_ub_off[b];
+    const int klst_a = hs.xsup[a + 1];
+    for (int x = 0; x < t.sn_nub[a]; ++x) {
+        const int g = t.ub_gid[ua + x];
+        if (g <= b) continue;
+        int y = -1;
+        for (int q = 0; q < t.sn_nub[b]; ++q) if (t.ub_gid[ub + q] == g) { y = q; break; }
+        if (y < 0) return false;
+        const int64_t pa = hs.uidx_off[a] + t.ub_iukp[ua + x], pb = hs.uidx_off[b] + t.ub_iukp[ub + y];
+        const int *ca = t.unzcol.data() + pa, *cb = t.unzcol.data() + pb;
+        const int na = t.ub_ncols[ua + x], nb = t.ub_ncols[ub + y];
+        for (int i = 0; i < na; ++i) {
+            const int *f = std::find(cb, cb + nb, ca[i]);
+            if (f == cb + nb) return false;
+            const int c = t.ub_stcol[ub + y] + (int) (f - cb), jj = ca[i];
+            colinfo[2 * c] = t.ucolptr[pa + jj];
+            colinfo[2 * c + 1] = sa - (klst_a - hs.uidx[pa + jj]);
+        }
+        cols_a += na;
+    }
+    const int rows_b = nsupr_b - nsupc_of(hs, b);
+    const int pct = H.env.fuse_min_pct;
+    return rows_a > 0 && cols_a > 0 && 100 * (int64_t) rows_a >= (int64_t) pct * rows_b && 100 * (int64_t) cols_a >= (int64_t) pct * ncolu_b;
+}
+
+static void build_urgent_lists(const HostTables &t, const std::vector<int> &lvl, LevelSched &S)
+{
+    S.sn_level = lvl;
+    S.u_off.assign(2 * S.nlevels + 1, 0);
+    std::vector<uint8_t> rflag, cflag;
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int nbig = S.n_big[l];
+        for (int g = 0; g < 2; ++g) {
+            const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
+            for (int i = b; i < e; ++i) {
+                const int k = S.nodes[i];
+                const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
+                if (!nrt || !nct) continue;
+                rflag.assign(nrt, 0); cflag.assign(nct, 0);
+                bool any = false;
+                for (int r = 0; r < nrt; ++r) { const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x]; rflag[r] = (lvl[ib] == l + 1); any |= rflag[r]; }
+                for (int c = 0; c < nct; ++c) { const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x]; cflag[c] = (lvl[jb] == l + 1); any |= cflag[c]; }
+                if (!any) continue;
+                for (int r = 0; r < nrt; ++r)
+                    for (int c = 0; c < nct; ++c)
+                        if (rflag[r] || cflag[c]) S.ulist.push_back(make_int4(k, r, c, 0));
+            }
+            S.u_off[2 * l + g + 1] = (int) S.ulist.size();
+        }
+    }
+}
+
+// Level schedule of one forest (lvl / nlevels from dag_levels): node order, per-level work-unit prefix arrays, urgent tile
+// lists, K-fused pairs.
+static void build_schedule(Handle &H, const HostTables &t, const std::vector<int> &list, const std::vector<int> &lvl, int nlevels, LevelSched &S)
+{
+    const HostStruct &hs = H.hs;
+    const int ns = hs.nsupers;
+    S.nlevels = nlevels;
+    S.lvl_off.assign(S.nlevels + 1, 0);
+    for (int k : list) S.lvl_off[lvl[k] + 1]++;
+    for (int l = 0; l < S.nlevels; ++l) S.lvl_off[l + 1] += S.lvl_off[l];
+    S.nodes.resize(list.size());
+    std::vector<int> fill(S.lvl_off.begin(), S.lvl_off.end() - (S.nlevels ? 1 : 0));
+    for (int pass = 1; pass >= 0; --pass)   // big-tile supernodes first inside each level
+        for (int k : list) if ((int) t.sn_big[k] == pass) S.nodes[fill[lvl[k]]++] = k;
+    S.n_big.assign(S.nlevels, 0);
+    for (int k : list) if (t.sn_big[k]) S.n_big[lvl[k]]++;
+    S.lvl_soff.assign(S.nlevels + 1, 0);
+    for (int l = 0; l < S.nlevels; ++l) S.lvl_soff[l + 1] = S.lvl_soff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 2;
+    S.lvl_poff.assign(S.nlevels + 1, 0);
+    for (int l = 0; l < S.nlevels; ++l) S.lvl_poff[l + 1] = S.lvl_poff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 1;
+    const int psz = S.lvl_poff[S.nlevels];
+    S.tile_prefix.assign(S.lvl_soff[S.nlevels], 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
+    S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0); S.zltr_prefix.assign(psz, 0);
+    S.dg_prefix.assign(psz, 0); S.dg_off.assign(psz, 0);
+    S.max_nsupc.assign(S.nlevels, 0);
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i)
+            S.max_nsupc[l] = std::max(S.max_nsupc[l], nsupc_of(hs, S.nodes[i]));
+    for (int l = 0; l < S.nlevels; ++l) {
+        int po = S.lvl_poff[l];
+        int so = S.lvl_soff[l];
+        const int rs = trsm_rs(H, (S.max_nsupc[l] + 31) & ~31);   // strip height of this level's TRSM launch
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i, ++po, ++so) {
+            const int k = S.nodes[i];
+            if (i - S.lvl_off[l] == S.n_big[l]) ++so;      // start of the small group: its own prefix, from 0
+            S.tile_prefix[so + 1] = S.tile_prefix[so] + t.sn_nrt[k] * t.sn_nct[k];
+            const int nsupc = nsupc_of(hs, k);
+            const int fl = t.sn_flags[k];
+            const int rrows = t.sn_nsupr[k] - t.sn_ldiag[k];
+            const int lrows = (fl & SNF_L_OWN) ? rrows : 0;                 // L TRSM / forward update: the owner of the L slot
+            const int ucols = (fl & SNF_U_OWN) ? t.sn_ncolu[k] : 0;         // U TRSM / backward update: the owner of the U slot
+            S.ltr_prefix[po + 1] = S.ltr_prefix[po] + (lrows + rs - 1) / rs;
+            S.utr_prefix[po + 1] = S.utr_prefix[po] + (ucols + rs - 1) / rs;
+            S.inv_prefix[po + 1] = S.inv_prefix[po] + ((fl & SNF_HAS_DIAG) ? 2 * ((nsupc + 31) / 32) : 0);
+            S.zltr_prefix[po + 1] = S.zltr_prefix[po] + (lrows + 63) / 64;
+            S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 255) / 256;
+            S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
+        }
+    }
+    build_urgent_lists(t, lvl, S);
+    // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
+    // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
+    // (1 x 1 layers only: on an XY grid a deferred supernode's received panels would have to outlive two exchange phases.)
+    S.lvl_defer.assign(S.nlevels, 0);
+    if (H.h_fuse_prev.empty()) { H.h_fuse_prev.assign(3 * (size_t) ns, -1); H.h_defer.assign(ns, 0); H.h_pair_roff.assign(3 * (size_t) ns, -1); H.h_pair_coff.assign(3 * (size_t) ns, -1); }
+    if (!H.env.no_fuse && !H.opt.deterministic && !H.z && H.grid.Pr * H.grid.Pc == 1) {
+        const int maxprev = H.env.fuse_max_prev;   // measured: pairs beat groups of 3-4 end to end (longer urgent tiles sit on the panel chain)
+        std::vector<int> rowmap[3], colinfo[3];
+        for (int l = 0; l + 1 < S.nlevels; ++l)
+            for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) {
+                const int b = S.nodes[i], a = b - 1;
+                if (a < 0 || lvl[a] != l || !t.sn_big[a] || !t.sn_big[b]) continue;
+                int srcs[3] = {a, -1, -1}, nsrc = 1;
+                for (int j = 0; j < 3 && H.h_fuse_prev[3 * (size_t) a + j] >= 0; ++j) {
+                    if (nsrc == maxprev) { nsrc = -1; break; }       // a already closes a full group: b starts a new one later
+                    srcs[nsrc++] = H.h_fuse_prev[3 * (size_t) a + j];
+                }
+                if (nsrc < 0) continue;
+                bool ok = true;
+                for (int j = 0; j < nsrc && ok; ++j) ok = build_pair_maps(H, t, srcs[j], b, rowmap[j], colinfo[j]);
+                if (!ok) {   // the far members do not fit b: fall back to the plain pair when a is not fused itself
+                    if (nsrc > 1 || !build_pair_maps(H, t, a, b, rowmap[0], colinfo[0])) continue;
+                }
+                for (int j = 0; j < nsrc; ++j) {
+                    const size_t pj = 3 * (size_t) b + j;
+                    H.h_fuse_prev[pj] = srcs[j];
+                    H.h_pair_roff[pj] = (int) H.h_pair_rowmap.size(); H.h_pair_coff[pj] = (int) (H.h_pair_colinfo.size() / 2);
+                    H.h_pair_rowmap.insert(H.h_pair_rowmap.end(), rowmap[j].begin(), rowmap[j].end());
+                    H.h_pair_colinfo.insert(H.h_pair_colinfo.end(), colinfo[j].begin(), colinfo[j].end());
+                }
+                H.h_defer[a] = 1;
+                S.lvl_defer[l] = 1;
+                H.fused_pairs += 1;
+            }
+    }
+}
+
+static int upload_schedule(Handle &H, LevelSched &S)
+{
+    if (upload(H.d_misc, S.nodes, &S.d_nodes)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.tile_prefix, &S.d_tile_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.ltr_prefix, &S.d_ltr_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.utr_prefix, &S.d_utr_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.fwd_prefix, &S.d_fwd_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.bwd_prefix, &S.d_bwd_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.inv_prefix, &S.d_inv_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.zltr_prefix, &S.d_zltr_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.sn_level, &S.d_sn_level)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.dg_prefix, &S.d_dg_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.dg_off, &S.d_dg_off)) return SLUAMD_EHIP;
+    return 0;
+}
+
+static void add_runs(std::vector<std::pair<int, int>> &runs, int64_t &total, int row0, int nrows)
+{
+    if (!runs.empty() && runs.back().first + runs.back().second == row0) runs.back().second += nrows;
+    else runs.emplace_back(row0, nrows);
+    total += nrows;
+}
+
+int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
+{
+    HostStruct &hs = H->hs;
+    const Grid &g = H->grid;
+    const int ns = hs.nsupers;
+    const bool xy = g.Pr * g.Pc > 1;
+    if (H->z && g.size() > 1) { set_error("complex16 handles support 1 x 1 x 1 grids only"); return SLUAMD_EINVAL; }
+    const int nz = (int) in.lists.size();
+    H->Pz = g.Pz; H->myz = g.z;
+    H->forest_nodes = in.lists;
+    H->z_active = in.z_active;
+
+    // ---- 1. index arenas (slot images) ----
+    hs.lidx_off.assign(ns + 1, 0); hs.uidx_off.assign(ns + 1, 0);
+    for (int k = 0; k < ns; ++k) {
+        hs.lidx_off[k + 1] = hs.lidx_off[k] + (hs.present[k] ? std::max<int64_t>((int64_t) in.lidx[k].size(), BC_HEADER) : 0);
+        hs.uidx_off[k + 1] = hs.uidx_off[k] + (hs.present[k] ? (int64_t) in.uidx[k].size() : 0);
+    }
+    hs.lidx.assign(hs.lidx_off[ns], 0); hs.uidx.assign(hs.uidx_off[ns], 0);
+    hs.lval_len.assign(ns, 0); hs.uval_len.assign(ns, 0);
+    for (int k = 0; k < ns; ++k) {
+        if (!hs.present[k]) continue;
+        if (!in.lidx[k].empty()) {
+            if ((int64_t) in.lidx[k].size() != BC_HEADER + (int64_t) in.lidx[k][0] * LB_DESCRIPTOR + in.lidx[k][1]) { set_error("L index array length mismatch"); return SLUAMD_ESTRUCT; }
+            std::copy(in.lidx[k].begin(), in.lidx[k].end(), hs.lidx.begin() + hs.lidx_off[k]);
+            hs.lval_len[k] = (int64_t) in.lidx[k][1] * nsupc_of(hs, k);
+        }
+        if (!in.uidx[k].empty()) {
+            if (in.uidx[k].size() < (size_t) BR_HEADER || in.uidx[k][2] != (int) in.uidx[k].size()) { set_error("U index array length mismatch"); return SLUAMD_ESTRUCT; }
+            std::copy(in.uidx[k].begin(), in.uidx[k].end(), hs.uidx.begin() + hs.uidx_off[k]);
+            hs.uval_len[k] = in.uidx[k][1];
+        }
+        in.lidx[k] = std::vector<int>(); in.uidx[k] = std::vector<int>();
+    }
+
+    // ---- 2. DAG levels per Z level ----
+    std::vector<std::vector<int>> lvl(nz);
+    std::vector<int> nlev(nz, 0);
+    for (int zl = 0; zl < nz; ++zl) dag_levels(in, in.lists[zl], ns, lvl[zl], nlev[zl]);
+
+    // ---- 3. value arena layout ----
+    // own slots: [L: zl 0 (level 0 | level 1 | ...) | zl 1 ... ][U: same order] -> one contiguous range per (zl, level) and
+    // per ancestor forest; then, on XY layers, two parity copies of the per-level scratch for received slots / diagonal blocks
+    hs.lval_off.assign(ns + 1, 0); hs.uval_off.assign(ns + 1, 0);
+    std::vector<std::vector<std::vector<int>>> lev_nodes(nz);   // [zl][level] ascending supernodes
+    for (int zl = 0; zl < nz; ++zl) {
+        lev_nodes[zl].assign(std::max(nlev[zl], 1), {});
+        for (int k : in.lists[zl]) lev_nodes[zl][std::max(lvl[zl][k], 0)].push_back(k);
+    }
+    int64_t cur = 0;
+    H->own_l_order.clear(); H->own_u_order.clear();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int zl = 0; zl < nz; ++zl)
+            for (auto &nodes : lev_nodes[zl])
+                for (int k : nodes) {
+                    if (pass == 0 && g.kcol(k) == g.c) { hs.lval_off[k] = cur; cur += hs.lval_len[k]; H->own_l_order.push_back(k); }
+                    if (pass == 1 && g.krow(k) == g.r) { hs.uval_off[k] = cur; cur += hs.uval_len[k]; H->own_u_order.push_back(k); }
+                }
+        if (pass == 0) hs.nnzL = cur; else hs.nnzU = cur - hs.nnzL;
+    }
+    H->own_len = cur;
+    // scratch sizes (max over levels): remote L + remote U slots; diagonal blocks (own staging + received)
+    int64_t rmax = 0, dmax = 0;
+    if (xy)
+        for (int zl = 0; zl < nz; ++zl) {
+            if (!in.z_active[zl]) continue;
+            for (auto &nodes : lev_nodes[zl]) {
+                int64_t rr = 0, dd = 0;
+                for (int k : nodes) {
+                    const bool l_own = g.kcol(k) == g.c, u_own = g.krow(k) == g.r;
+                    if (!l_own) rr += hs.lval_len[k];
+                    if (!u_own) rr += hs.uval_len[k];
+                    if (l_own || u_own) dd += (int64_t) nsupc_of(hs, k) * nsupc_of(hs, k);
+                }
+                rmax = std::max(rmax, rr); dmax = std::max(dmax, dd);
+            }
+        }
+    const int64_t rbase[2] = {cur, cur + rmax};
+    const int64_t dbase[2] = {cur + 2 * rmax, cur + 2 * rmax + dmax};
+    H->arena_len = cur + 2 * rmax + 2 * dmax;
+
+    // ---- 4. per-level exchange plan + offsets of the remote slots / scratch diagonal blocks ----
+    H->sched.assign(nz, LevelSched());
+    std::vector<int64_t> dptr(ns, 0);
+    std::vector<int> dlda(ns, 1);
+    for (int k = 0; k < ns; ++k) { dptr[k] = hs.lval_off[k]; dlda[k] = 1; }
+    struct LevelX { std::vector<XMsg> ds, dr, ps, pr; int64_t dstage = 0; std::vector<LevelSched::XSeg> rs, rr, bs, br; };
+    std::vector<std::vector<LevelX>> lx(nz);
+    for (int zl = 0; zl < nz; ++zl) {
+        if (!in.z_active[zl]) continue;
+        lx[zl].resize(nlev[zl]);
+        for (int l = 0; l < nlev[zl]; ++l) {
+            const auto &nodes = lev_nodes[zl][l];
+            LevelX &X = lx[zl][l];
+            if (!xy) continue;
+            const int par = l & 1;
+            // -- phase 1: diagonal blocks (dDiagFactIBCast): owner -> its process column and its process row
+            int64_t doff = dbase[par];
+            X.dstage = doff;
+            int64_t own_d = 0;
+            for (int k : nodes) if (g.kcol(k) == g.c && g.krow(k) == g.r) own_d += (int64_t) nsupc_of(hs, k) * nsupc_of(hs, k);
+            if (own_d) {
+                for (int r2 = 0; r2 < g.Pr; ++r2) if (r2 != g.r) X.ds.push_back({g.rank_of(r2, g.c, g.z), doff, own_d});
+                for (int c2 = 0; c2 < g.Pc; ++c2) if (c2 != g.c) X.ds.push_back({g.rank_of(g.r, c2, g.z), doff, own_d});
+            }
+            doff += own_d;
+            for (int r2 = 0; r2 < g.Pr; ++r2) {   // from the owners in my process column
+                if (r2 == g.r) continue;
+                int64_t len = 0;
+                for (int k : nodes) if (g.kcol(k) == g.c && g.krow(k) == r2) { const int s = nsupc_of(hs, k); dptr[k] = doff + len; dlda[k] = s; len += (int64_t) s * s; }
+                if (len) X.dr.push_back({g.rank_of(r2, g.c, g.z), doff, len});
+                doff += len;
+            }
+            for (int c2 = 0; c2 < g.Pc; ++c2) {   // from the owners in my process row
+                if (c2 == g.c) continue;
+                int64_t len = 0;
+                for (int k : nodes) if (g.krow(k) == g.r && g.kcol(k) == c2) { const int s = nsupc_of(hs, k); dptr[k] = doff + len; dlda[k] = s; len += (int64_t) s * s; }
+                if (len) X.dr.push_back({g.rank_of(g.r, c2, g.z), doff, len});
+                doff += len;
+            }
+            // -- phase 2: L slots along the process row, U slots down the process column (dIBcast_LPanel / dIBcast_UPanel)
+            int64_t lfirst = -1, llen = 0, ufirst = -1, ulen = 0;
+            for (int k : nodes) {
+                if (g.kcol(k) == g.c) { if (lfirst < 0) lfirst = hs.lval_off[k]; llen += hs.lval_len[k]; }
+                if (g.krow(k) == g.r) { if (ufirst < 0) ufirst = hs.uval_off[k]; ulen += hs.uval_len[k]; }
+            }
+            if (llen) for (int c2 = 0; c2 < g.Pc; ++c2) if (c2 != g.c) X.ps.push_back({g.rank_of(g.r, c2, g.z), lfirst, llen});
+            if (ulen) for (int r2 = 0; r2 < g.Pr; ++r2) if (r2 != g.r) X.ps.push_back({g.rank_of(r2, g.c, g.z), ufirst, ulen});
+            int64_t roff = rbase[par];
+            for (int c2 = 0; c2 < g.Pc; ++c2) {
+                if (c2 == g.c) continue;
+                int64_t len = 0;
+                for (int k : nodes) if (g.kcol(k) == c2) { hs.lval_off[k] = roff + len; len += hs.lval_len[k]; }
+                if (len) X.pr.push_back({g.rank_of(g.r, c2, g.z), roff, len});
+                roff += len;
+            }
+            for (int r2 = 0; r2 < g.Pr; ++r2) {
+                if (r2 == g.r) continue;
+                int64_t len = 0;
+                for (int k : nodes) if (g.krow(k) == r2) { hs.uval_off[k] = roff + len; len += hs.uval_len[k]; }
+                if (len) X.pr.push_back({g.rank_of(r2, g.c, g.z), roff, len});
+                roff += len;
+            }
+            // -- solve: lsum of x_k reduced along process row k % Pr to the diagonal owner; x_k broadcast down column k % Pc
+            for (int c2 = 0; c2 < g.Pc; ++c2) {
+                if (c2 == g.c) continue;
+                LevelSched::XSeg snd, rcv; snd.peer = rcv.peer = g.rank_of(g.r, c2, g.z);
+                for (int k : nodes) {
+                    if (g.krow(k) != g.r) continue;
+                    if (g.kcol(k) == c2) add_runs(snd.runs, snd.total, hs.xsup[k], nsupc_of(hs, k));
+                    if (g.kcol(k) == g.c) add_runs(rcv.runs, rcv.total, hs.xsup[k], nsupc_of(hs, k));
+                }
+                if (snd.total) X.rs.push_back(std::move(snd));
+                if (rcv.total) X.rr.push_back(std::move(rcv));
+            }
+            for (int r2 = 0; r2 < g.Pr; ++r2) {
+                if (r2 == g.r) continue;
+                LevelSched::XSeg snd, rcv; snd.peer = rcv.peer = g.rank_of(r2, g.c, g.z);
+                for (int k : nodes) {
+                    if (g.kcol(k) != g.c) continue;
+                    if (g.krow(k) == g.r) add_runs(snd.runs, snd.total, hs.xsup[k], nsupc_of(hs, k));
+                    if (g.krow(k) == r2) add_runs(rcv.runs, rcv.total, hs.xsup[k], nsupc_of(hs, k));
+                }
+                if (snd.total) X.bs.push_back(std::move(snd));
+                if (rcv.total) X.br.push_back(std::move(rcv));
+            }
+        }
+    }
+
+    // ---- 5. block tables, tiles ----
+    int rc = build_tables(*H, t);
+    if (rc) return rc;
+    for (int k = 0; k < ns; ++k) {
+        if (!hs.present[k]) continue;
+        // the owner factors the diagonal block in place at the top of its own L slot; its column / row peers read the image
+        // received in exchange phase 1 (the L slot image of a row peer arrives only in phase 2, after its U TRSM)
+        if (t.sn_flags[k] & SNF_OWN_DIAG) { t.sn_dptr[k] = hs.lval_off[k]; t.sn_dlda[k] = std::max(t.sn_nsupr[k], 1); }
+        else { t.sn_dptr[k] = dptr[k]; t.sn_dlda[k] = dlda[k]; }
+    }
+    H->h_dptr = t.sn_dptr;
+
+    // ---- 6. schedules ----
+    int nlevtot = 0;
+    for (int zl = 0; zl < nz; ++zl) {
+        if (!in.z_active[zl]) continue;
+        LevelSched &S = H->sched[zl];
+        build_schedule(*H, t, in.lists[zl], lvl[zl], nlev[zl], S);
+        nlevtot += S.nlevels;
+        // exchange plan into the schedule; own diagonal blocks of each level packed in ascending supernode order
+        if (xy) {
+            S.x_diag_send.resize(S.nlevels); S.x_diag_recv.resize(S.nlevels); S.x_panel_send.resize(S.nlevels); S.x_panel_recv.resize(S.nlevels);
+            S.xs_red_send.resize(S.nlevels); S.xs_red_recv.resize(S.nlevels); S.xs_bc_send.resize(S.nlevels); S.xs_bc_recv.resize(S.nlevels);
+            S.dg_stage_off.assign(S.nlevels, 0);
+            for (int l = 0; l < S.nlevels; ++l) {
+                LevelX &X = lx[zl][l];
+                S.x_diag_send[l] = X.ds; S.x_diag_recv[l] = X.dr; S.x_panel_send[l] = X.ps; S.x_panel_recv[l] = X.pr;
+                S.xs_red_send[l] = X.rs; S.xs_red_recv[l] = X.rr; S.xs_bc_send[l] = X.bs; S.xs_bc_recv[l] = X.br;
+                S.dg_stage_off[l] = X.dstage;
+                // pack offsets follow ASCENDING supernode order (what the receivers assume), whatever the launch order
+                const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+                std::vector<int64_t> off_of(nn, 0);
+                {
+                    std::vector<int> order(nn);
+                    std::iota(order.begin(), order.end(), 0);
+                    std::sort(order.begin(), order.end(), [&](int a, int b) { return S.nodes[n0 + a] < S.nodes[n0 + b]; });
+                    int64_t o = 0;
+                    for (int i : order) {
+                        const int k = S.nodes[n0 + i];
+                        off_of[i] = o;
+                        if (t.sn_flags[k] & SNF_OWN_DIAG) o += (int64_t) nsupc_of(hs, k) * nsupc_of(hs, k);
+                    }
+                }
+                for (int i = 0; i < nn; ++i) {
+                    const int k = S.nodes[n0 + i];
+                    const int64_t sz = (t.sn_flags[k] & SNF_OWN_DIAG) ? (int64_t) nsupc_of(hs, k) * nsupc_of(hs, k) : 0;
+                    S.dg_prefix[po + i + 1] = S.dg_prefix[po + i] + (int) ((sz + 1023) / 1024);
+                    S.dg_off[po + i] = off_of[i];
+                }
+            }
+        }
+    }
+    H->st.num_levels = nlevtot;
+
+    // ---- 7. device allocations + uploads ----
+    const size_t esz = H->z ? 16 : 8;
+    if (hipMalloc((void **) &H->d_val, esz * (size_t) std::max<int64_t>(H->arena_len, 1)) != hipSuccess) { set_error("hipMalloc of the value arena failed"); return SLUAMD_ENOMEM; }
+    HIPCHK(hipMemset(H->d_val, 0, esz * (size_t) H->arena_len));
+    HIPCHK(hipStreamCreate(&H->stream));
+    {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
+    }
+    HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
+    auto &K = H->d_misc;
+    DevTables &T = H->T;
+    T.val = H->d_val;
+    if (upload(K, hs.lidx, &H->d_lidx) || upload(K, hs.uidx, &H->d_uidx) || upload(K, t.ucolptr, &H->d_ucolptr) ||
+        upload(K, t.unzcol, &H->d_unzcol) || upload(K, hs.xsup, &H->d_xsup)) return SLUAMD_EHIP;
+    T.lidx = H->d_lidx; T.uidx = H->d_uidx; T.ucolptr = H->d_ucolptr; T.unzcol = H->d_unzcol; T.xsup = H->d_xsup;
+#define UP(field, vec, type) { type *p_; if (upload(K, vec, &p_)) return SLUAMD_EHIP; T.field = p_; }
+    UP(sn_lval, t.sn_lval, int64_t) UP(sn_uval, t.sn_uval, int64_t) UP(sn_lidx, t.sn_lidx, int64_t) UP(sn_uidx, t.sn_uidx, int64_t)
+    UP(sn_dinv, t.sn_dinv, int64_t) UP(sn_dptr, t.sn_dptr, int64_t)
+    H->h_sn_dinv = t.sn_dinv;
+    {
+        double *dv;
+        if (hipMalloc((void **) &dv, esz * (size_t) std::max<int64_t>(t.dinv_total, 1)) != hipSuccess) { set_error("hipMalloc(dinv) failed"); return SLUAMD_ENOMEM; }
+        K.push_back(dv); T.dinv = dv;
+    }
+    UP(sn_nsupr, t.sn_nsupr, int) UP(sn_flags, t.sn_flags, int) UP(sn_ldiag, t.sn_ldiag, int) UP(sn_dlda, t.sn_dlda, int)
+    UP(sn_ldu, t.sn_ldu, int) UP(sn_ncolu, t.sn_ncolu, int)
+    UP(sn_lb_off, t.sn_lb_off, int) UP(sn_nlb, t.sn_nlb, int) UP(sn_ub_off, t.sn_ub_off, int) UP(sn_nub, t.sn_nub, int)
+    UP(sn_rt_off, t.sn_rt_off, int) UP(sn_nrt, t.sn_nrt, int) UP(sn_ct_off, t.sn_ct_off, int) UP(sn_nct, t.sn_nct, int)
+    UP(lb_gid, t.lb_gid, int) UP(lb_nbrow, t.lb_nbrow, int) UP(lb_rowoff, t.lb_rowoff, int) UP(lb_lptr, t.lb_lptr, int)
+    UP(lbs_gid, t.lbs_gid, int) UP(lbs_idx, t.lbs_idx, int)
+    UP(ub_gid, t.ub_gid, int) UP(ub_ncols, t.ub_ncols, int) UP(ub_iukp, t.ub_iukp, int) UP(ub_stcol, t.ub_stcol, int)
+    UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4)
+#undef UP
+    for (auto &S : H->sched) if (upload_schedule(*H, S)) return SLUAMD_EHIP;
+    if (H->fused_pairs) {
+        int *p0, *p1, *p2, *p3, *p4, *p5;
+        if (upload(K, H->h_fuse_prev, &p0) || upload(K, H->h_defer, &p1) || upload(K, H->h_pair_roff, &p2) ||
+            upload(K, H->h_pair_coff, &p3) || upload(K, H->h_pair_rowmap, &p4) || upload(K, H->h_pair_colinfo, &p5)) return SLUAMD_EHIP;
+        T.fuse_prev = p0; T.defer = p1; T.pair_roff = p2; T.pair_coff = p3; T.pair_rowmap = p4; T.pair_colinfo = p5;
+    }
+    H->st.reserved_i = H->fused_pairs;   // K-fused supernode pairs (diagnostic)
+    HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
+    rc = eng::setup();
+    if (rc) return rc;
+    H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
+    const size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
+    H->st.bytes_device = (int64_t) ((size_t) H->arena_len * esz + idxb);
+    return 0;
+}
+
+}  // namespace sluamd

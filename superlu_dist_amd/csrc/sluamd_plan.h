@@ -1,0 +1,57 @@
+// sluamd_plan.h -- internal: creation-time planning (slot structures -> device tables, schedules, exchange plans)
+#pragma once
+#include <algorithm>
+#include "sluamd_internal.h"
+
+namespace sluamd {
+
+struct Comm;
+
+// What both producers (caller's dLocalLU_t view + structure exchange, or the library's own symbolic factorisation)
+// hand to the planner, indexed by GLOBAL supernode id.
+struct SlotInput {
+    std::vector<std::vector<int>> lidx, uidx;   // slot index arrays in the reference formats (empty = no blocks)
+    std::vector<std::vector<int>> succ;         // block graph: gids (> k) of every block of L(:,k) and U(k,:), ALL process rows / columns
+    std::vector<std::vector<int>> lists;        // per Z level of this layer's path: ascending supernodes of the forest
+    std::vector<uint8_t> z_active;              // per Z level: this layer factors it
+};
+
+struct HostTables {
+    std::vector<int64_t> sn_lval, sn_uval, sn_lidx, sn_uidx, sn_dinv, sn_dptr;
+    int64_t dinv_total = 0;
+    std::vector<int> sn_nsupr, sn_flags, sn_ldiag, sn_dlda, sn_ldu, sn_ncolu, sn_lb_off, sn_nlb, sn_ub_off, sn_nub, sn_rt_off, sn_nrt, sn_ct_off, sn_nct;
+    std::vector<int> lb_gid, lb_nbrow, lb_rowoff, lb_lptr, lbs_gid, lbs_idx;
+    std::vector<int> ub_gid, ub_ncols, ub_iukp, ub_stcol;
+    std::vector<int> ucolptr, unzcol;
+    std::vector<int4> rtile, ctile;
+    std::vector<uint8_t> sn_big;   // 1: supernode uses the 128x128 Schur tile configuration
+};
+
+template <class Tv>
+static int upload(std::vector<void *> &keep, const std::vector<Tv> &h, Tv **d)
+{
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(Tv);
+    HIPCHK(hipMalloc((void **) d, bytes));
+    keep.push_back(*d);
+    if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(Tv), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int check_device(int dev);
+void read_env(Handle::Env &e);
+int trsm_rs(const Handle &H, int nsp);
+
+int slots_from_view(Handle &H, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests, Comm *comm, SlotInput &in);
+int slots_from_symb(Handle &H, const Symb &sy, const Grid &g, const int32_t *sn_tree, SlotInput &in);
+
+// Planner: H.hs / H.grid / in -> value-arena layout, device tables, schedules, exchange plans; allocates the arena
+// (zero-filled) and uploads everything but the values.  `t` is left filled for the value producers.
+int plan_and_upload(Handle *H, SlotInput &in, HostTables &t);
+
+// drivers (sluamd_factor.cpp)
+int run_factor(Handle *H, double thresh, int *info);
+int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs);
+int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs);   // single-rank sweep over every schedule (refinement)
+int ensure_dinv(Handle *H);
+
+}  // namespace sluamd

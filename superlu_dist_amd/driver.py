@@ -20,8 +20,8 @@ def _pd(a):
 
 
 class FlatStore:
-    """A 1 x 1 x Pz rank's L/U store as flat arrays + offsets (what tests/golden holds), exposed to the C ABI
-    through the reference's pointer-array view (Lrowind_bc_ptr[lk], Lnzval_bc_ptr[lk], ...)."""
+    """One rank's L/U store as flat arrays + offsets over its LOCAL block columns / rows (what tests/golden holds),
+    exposed to the C ABI through the reference's pointer-array view (Lrowind_bc_ptr[lk], Lnzval_bc_ptr[lk], ...)."""
 
     def __init__(self, n, xsup, Lrowind_off, Lrowind, Lnzval_off, Lnzval, Ufstnz_off, Ufstnz, Unzval_off, Unzval,
                  grid=(1, 1, 1), coords=(0, 0, 0)):
@@ -54,9 +54,10 @@ class FlatStore:
         ns = self.nsupers
 
         def ptrs(base, off, ctype, elem):
-            arr = (C.POINTER(ctype) * ns)()
+            nloc = len(off) - 1          # ceil(nsupers / npcol) block columns or ceil(nsupers / nprow) block rows
+            arr = (C.POINTER(ctype) * max(nloc, 1))()
             addr = base.ctypes.data
-            for k in range(ns):
+            for k in range(nloc):
                 if off[k + 1] > off[k]:
                     arr[k] = C.cast(addr + int(off[k]) * elem, C.POINTER(ctype))
             return arr
