@@ -247,6 +247,13 @@ void WRAP(gstrs3d_newsolve)(superlu_dist_options_t *options, int_t n, xLUstruct_
                                xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
 {
     dump_solve("newsolve", n, SP, B, m_loc, fst_row, ldb, nrhs, 0);
+#if defined(USE_SLUAMD) && !defined(Z_PREC)   /* slu_ref_amd: OUR triangular solves on the device-resident factors (SLUAMD_BIND_SOLVE=0: the reference's) */
+    extern void sluamd_bind_pdgstrs3d_newsolve(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *, xtrf3Dpartition_t *,
+                                               gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int, xSOLVEstruct_t *, SuperLUStat_t *, int *);
+    if (!getenv("SLUAMD_BIND_SOLVE") || atoi(getenv("SLUAMD_BIND_SOLVE")))
+        sluamd_bind_pdgstrs3d_newsolve(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs, SOLVEstruct, stat, info);
+    else
+#endif
     REAL(gstrs3d_newsolve)(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,
                               SOLVEstruct, stat, info);
     dump_solve("newsolve", n, SP, B, m_loc, fst_row, ldb, nrhs, 1);
@@ -261,6 +268,13 @@ void WRAP(gstrs3d)(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstru
                       xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
 {
     dump_solve("legacy", n, SP, B, m_loc, fst_row, ldb, nrhs, 0);
+#if defined(USE_SLUAMD) && !defined(Z_PREC)
+    extern void sluamd_bind_pdgstrs3d(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *, xtrf3Dpartition_t *,
+                                      gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int, xSOLVEstruct_t *, SuperLUStat_t *, int *);
+    if (!getenv("SLUAMD_BIND_SOLVE") || atoi(getenv("SLUAMD_BIND_SOLVE")))
+        sluamd_bind_pdgstrs3d(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs, SOLVEstruct, stat, info);
+    else
+#endif
     REAL(gstrs3d)(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,
                      SOLVEstruct, stat, info);
     dump_solve("legacy", n, SP, B, m_loc, fst_row, ldb, nrhs, 1);
@@ -386,26 +400,40 @@ int main(int argc, char *argv[])
     if (info) { if (!grid.iam) printf("ERROR: INFO = %d returned from pdgssvx3d()\n", info); }
     else if (!quiet) pxinf_norm_error(grid.iam, ((NRformat_loc *) A.Store)->m_loc, nrhs, b, ldb, xtrue, ldx, grid.comm);
     if (grid.zscp.Iam == 0 && !quiet) PStatPrint(&options, &stat, &(grid.grid2d));
-    {   /* residual on the original system, computed here for the drop-in test: ||b - A x||_2 / ||b||_2 (1 rank) */
+    {   /* residual on the original system, computed here for the drop-in tests: ||b - A x||_2 / ||b||_2 (A, b, x are
+         * distributed by rows over all ranks of the 3D grid: gather x, reduce the two sums) */
         NRformat_loc *As = (NRformat_loc *) A.Store;
-        if (grid.nprow * grid.npcol * grid.npdep == 1 && g_b0) {
-            double rn = 0, bn = 0;
+        int P; MPI_Comm_size(grid.comm, &P);
+        int *cnt = (int *) malloc(sizeof(int) * 2 * P), *dsp = cnt + P;
+        int mine = (int) As->m_loc;
+        MPI_Allgather(&mine, 1, MPI_INT, cnt, 1, MPI_INT, grid.comm);
+        int tot = 0;
+        for (int q = 0; q < P; ++q) { dsp[q] = tot; tot += cnt[q]; }
+        if (tot == n && g_b0) {
+            const int w = (int) (sizeof(scalar_t) / sizeof(double));
+            for (int q = 0; q < P; ++q) { cnt[q] *= w; dsp[q] *= w; }
+            scalar_t *xf = (scalar_t *) malloc(sizeof(scalar_t) * (size_t) (n + 1));
+            MPI_Allgatherv(b, mine * w, MPI_DOUBLE, xf, cnt, dsp, MPI_DOUBLE, grid.comm);
+            double loc[2] = {0, 0}, glob[2];
             for (int_t i = 0; i < As->m_loc; ++i) {
 #ifdef Z_PREC
                 double sr = g_b0[i].r, si = g_b0[i].i;
                 for (int_t e = As->rowptr[i]; e < As->rowptr[i + 1]; ++e) {
-                    doublecomplex a = ((doublecomplex *) As->nzval)[e], xx = b[As->colind[e]];
+                    doublecomplex a = ((doublecomplex *) As->nzval)[e], xx = xf[As->colind[e]];
                     sr -= a.r * xx.r - a.i * xx.i; si -= a.r * xx.i + a.i * xx.r;
                 }
-                rn += sr * sr + si * si; bn += g_b0[i].r * g_b0[i].r + g_b0[i].i * g_b0[i].i;
+                loc[0] += sr * sr + si * si; loc[1] += g_b0[i].r * g_b0[i].r + g_b0[i].i * g_b0[i].i;
 #else
                 double s = g_b0[i];
-                for (int_t e = As->rowptr[i]; e < As->rowptr[i + 1]; ++e) s -= ((double *) As->nzval)[e] * b[As->colind[e]];
-                rn += s * s; bn += g_b0[i] * g_b0[i];
+                for (int_t e = As->rowptr[i]; e < As->rowptr[i + 1]; ++e) s -= ((double *) As->nzval)[e] * xf[As->colind[e]];
+                loc[0] += s * s; loc[1] += g_b0[i] * g_b0[i];
 #endif
             }
-            printf("RESIDUAL %.6e INFO %d\n", sqrt(rn / bn), info);
+            MPI_Allreduce(loc, glob, 2, MPI_DOUBLE, MPI_SUM, grid.comm);
+            if (!grid.iam) printf("RESIDUAL %.6e INFO %d\n", sqrt(glob[0] / glob[1]), info);
+            free(xf);
         }
+        free(cnt);
     }
     if (!grid.iam) printf("REFTIMES n %ld FACT %.6f s SOLVE %.6f s ops_FACT %.6e\n", (long) n, stat.utime[FACT], stat.utime[SOLVE], (double) stat.ops[FACT]);
     if (g_out) fclose(g_out);

@@ -4,21 +4,32 @@
  * reference's public headers only to unpack dLUstruct_t / gridinfo3d_t / dtrf3Dpartition_t into the plain-pointer
  * views of include/superlu_dist_amd.h.
  *
- * Built into oracle/_ref/slu_ref_amd (oracle/ref/Makefile) where `ld --wrap=pdgstrf3d` routes the reference's own
- * pdgssvx3d to it: the reference's pre-processing, distribution, triangular solve and refinement run unchanged on
- * the factors our library writes back in the reference's panel / skyline formats.  Test infrastructure only.
+ *   sluamd_bind_pdgstrf3d            replaces pdgstrf3d            (SRC/double/pdgstrf3d.c:121)
+ *   sluamd_bind_pdgstrs3d[_newsolve] replace  pdgstrs3d[_newsolve] (SRC/double/pdgstrs3d.c:6604 / :6935)
+ *
+ * on ANY nprow x npcol x npdep grid: the library runs the whole 3D algorithm (XY panel exchange, Z ancestor reduction,
+ * distributed triangular solves) itself over a transport; here the transport is the application's MPI (grid3d->comm)
+ * through the sluamd_comm_callbacks_t hooks, so several ranks may even share one GPU.  A node with one GPU per rank
+ * passes an RCCL communicator instead (sluamd_comm_create_rccl) and nothing else changes.
+ *
+ * Built into oracle/_ref/slu_ref_amd (oracle/ref/Makefile) where `ld --wrap=pdgstrf3d --wrap=pdgstrs3d_newsolve
+ * --wrap=pdgstrs3d` routes the reference's own pdgssvx3d to it: the reference's pre-processing, distribution and
+ * refinement loop run unchanged around our factorisation and our solves.  Test infrastructure only.
  */
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <limits.h>
 #include <dlfcn.h>
 #include <unistd.h>
-#ifdef Z_PREC   /* complex16 twin: binds pzgstrf3d (SRC/complex16/pzgstrf3d.c) to the sluamd_z* entry points */
+#ifdef Z_PREC   /* complex16 twin: binds pzgstrf3d (SRC/complex16/pzgstrf3d.c) to the sluamd_z* entry points (1 x 1 x 1 grids) */
 #include "superlu_zdefs.h"
 #define xLUstruct_t zLUstruct_t
 #define xLocalLU_t zLocalLU_t
 #define xtrf3Dpartition_t ztrf3Dpartition_t
+#define xScalePermstruct_t zScalePermstruct_t
+#define xSOLVEstruct_t zSOLVEstruct_t
 #define BIND_NAME sluamd_bind_pzgstrf3d
 #define LUVIEW_T sluamd_zLUview_t
 #define VALPP(p) ((sluamd_doublecomplex **) (p))
@@ -30,6 +41,8 @@
 #define xLUstruct_t dLUstruct_t
 #define xLocalLU_t dLocalLU_t
 #define xtrf3Dpartition_t dtrf3Dpartition_t
+#define xScalePermstruct_t dScalePermstruct_t
+#define xSOLVEstruct_t dSOLVEstruct_t
 #define BIND_NAME sluamd_bind_pdgstrf3d
 #define LUVIEW_T sluamd_dLUview_t
 #define VALPP(p) (p)
@@ -46,10 +59,14 @@ static struct {
     void *so;
     void (*default_options)(sluamd_options_t *);
     int (*create)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *);
+    int (*create_grid)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t);
     int (*factor)(sluamd_handle_t, double, int *);
     int (*copy2host)(sluamd_handle_t, const LUVIEW_T *);
+    int (*solve)(sluamd_handle_t, double *, int64_t, int32_t);
     int (*stats)(sluamd_handle_t, sluamd_stats_t *);
     void (*destroy)(sluamd_handle_t);
+    int (*comm_create)(sluamd_comm_t *, const sluamd_comm_callbacks_t *, int, int, int, int, int, int);
+    void (*comm_destroy)(sluamd_comm_t);
     const char *(*last_error)(void);
 } S;
 
@@ -70,12 +87,75 @@ static void sluamd_load(void)
     if (!S.so) { fprintf(stderr, "dlopen(%s): %s\n", path, dlerror()); ABORT("cannot load libsluamd.so"); }
     S.default_options = (void (*)(sluamd_options_t *)) dlsym(S.so, "sluamd_default_options");
     S.create = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *)) dlsym(S.so, SYM_CREATE);
+    S.create_grid = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t)) dlsym(S.so, "sluamd_dCreateLUHandleGrid");
     S.factor = (int (*)(sluamd_handle_t, double, int *)) dlsym(S.so, SYM_FACTOR);
     S.copy2host = (int (*)(sluamd_handle_t, const LUVIEW_T *)) dlsym(S.so, SYM_COPY);
+    S.solve = (int (*)(sluamd_handle_t, double *, int64_t, int32_t)) dlsym(S.so, "sluamd_pdgstrs3d");
     S.stats = (int (*)(sluamd_handle_t, sluamd_stats_t *)) dlsym(S.so, "sluamd_get_stats");
     S.destroy = (void (*)(sluamd_handle_t)) dlsym(S.so, "sluamd_dDestroyLUHandle");
+    S.comm_create = (int (*)(sluamd_comm_t *, const sluamd_comm_callbacks_t *, int, int, int, int, int, int)) dlsym(S.so, "sluamd_comm_create_callbacks");
+    S.comm_destroy = (void (*)(sluamd_comm_t)) dlsym(S.so, "sluamd_comm_destroy");
     S.last_error = (const char *(*)(void)) dlsym(S.so, "sluamd_last_error");
-    if (!S.create || !S.factor || !S.copy2host || !S.destroy) ABORT("libsluamd.so lacks a required symbol");
+    if (!S.create || !S.create_grid || !S.factor || !S.copy2host || !S.solve || !S.destroy || !S.comm_create) ABORT("libsluamd.so lacks a required symbol");
+}
+
+/* ---- MPI transport for sluamd_comm_callbacks_t (host buffers; the library stages device ranges) ---- */
+static struct {
+    MPI_Comm comm;          /* grid3d->comm */
+    int *mpi_rank_of;       /* library world rank (z * Pr + r) * Pc + c  ->  rank in grid3d->comm */
+    MPI_Request *req; int nreq, cap;
+} M;
+
+static int m_push(MPI_Request r)
+{
+    if (M.nreq == M.cap) { M.cap = M.cap ? 2 * M.cap : 64; M.req = (MPI_Request *) realloc(M.req, sizeof(MPI_Request) * M.cap); }
+    M.req[M.nreq++] = r;
+    return 0;
+}
+static int m_isend(void *ctx, const void *buf, int64_t bytes, int peer)
+{
+    (void) ctx;
+    for (int64_t o = 0; o < bytes; o += INT_MAX) {   /* MPI counts are int */
+        MPI_Request r; int n = (int) (bytes - o < INT_MAX ? bytes - o : INT_MAX);
+        if (MPI_Isend((const char *) buf + o, n, MPI_BYTE, M.mpi_rank_of[peer], 4711, M.comm, &r) != MPI_SUCCESS) return 1;
+        m_push(r);
+    }
+    return 0;
+}
+static int m_irecv(void *ctx, void *buf, int64_t bytes, int peer)
+{
+    (void) ctx;
+    for (int64_t o = 0; o < bytes; o += INT_MAX) {
+        MPI_Request r; int n = (int) (bytes - o < INT_MAX ? bytes - o : INT_MAX);
+        if (MPI_Irecv((char *) buf + o, n, MPI_BYTE, M.mpi_rank_of[peer], 4711, M.comm, &r) != MPI_SUCCESS) return 1;
+        m_push(r);
+    }
+    return 0;
+}
+static int m_waitall(void *ctx)
+{
+    (void) ctx;
+    int rc = M.nreq ? MPI_Waitall(M.nreq, M.req, MPI_STATUSES_IGNORE) : MPI_SUCCESS;
+    M.nreq = 0;
+    return rc != MPI_SUCCESS;
+}
+static int m_allmin(void *ctx, int32_t *v)
+{
+    (void) ctx;
+    int in = *v, out = 0;
+    if (MPI_Allreduce(&in, &out, 1, MPI_INT, MPI_MIN, M.comm) != MPI_SUCCESS) return 1;
+    *v = out;
+    return 0;
+}
+
+/* the device-resident factors stay alive between pdgstrf3d and the solves (pdgssvx3d calls pdgstrs3d once, pdgsrfs3d
+ * once per refinement step); released when the next factorisation starts or at exit */
+static struct { sluamd_handle_t h; sluamd_comm_t comm; int n; } G;
+
+static void sluamd_bind_release(void)
+{
+    if (G.h) { S.destroy(G.h); G.h = NULL; }
+    if (G.comm) { S.comm_destroy(G.comm); G.comm = NULL; }
 }
 
 int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
@@ -86,11 +166,13 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     Glu_persist_t *Glu = LUstruct->Glu_persist;
     xLocalLU_t *Llu = LUstruct->Llu;
     int_t nsupers = Glu->supno[n - 1] + 1;
+    const int Pr = grid->nprow, Pc = grid->npcol, Pz = grid3d->npdep;
+    const int myrow = MYROW(grid->iam, grid), mycol = MYCOL(grid->iam, grid), myz = grid3d->zscp.Iam;
 
     LUVIEW_T v;
     v.n = n; v.nsupers = (int32_t) nsupers; v.xsup = Glu->xsup;
-    v.nprow = grid->nprow; v.npcol = grid->npcol; v.npdep = grid3d->npdep;
-    v.myrow = MYROW(grid->iam, grid); v.mycol = MYCOL(grid->iam, grid); v.myzlayer = grid3d->zscp.Iam;
+    v.nprow = Pr; v.npcol = Pc; v.npdep = Pz;
+    v.myrow = myrow; v.mycol = mycol; v.myzlayer = myz;
     v.Lrowind_bc_ptr = Llu->Lrowind_bc_ptr; v.Lnzval_bc_ptr = VALPP(Llu->Lnzval_bc_ptr);
     v.Ufstnz_br_ptr = Llu->Ufstnz_br_ptr;   v.Unzval_br_ptr = VALPP(Llu->Unzval_br_ptr);
 
@@ -103,42 +185,103 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     sluamd_forest_view_t fv = { maxLvl, trf3Dpartition->myTreeIdxs, trf3Dpartition->myZeroTrIdxs, nf, nNodes, lists };
 
     sluamd_load();
+    static int registered = 0;
+    if (!registered) { atexit(sluamd_bind_release); registered = 1; }
+    sluamd_bind_release();
     sluamd_options_t o;
     S.default_options(&o);
     o.replace_tiny_pivot = (options->ReplaceTinyPivot == YES);
 
-    sluamd_handle_t h = NULL;
-    int rc = S.create(&h, &v, &fv, &o);                                    /* was dCreateLUgpuHandle    */
+    int rc;
+    if (Pr * Pc * Pz > 1) {
+#ifdef Z_PREC
+        ABORT("complex16 binding: 1 x 1 x 1 grids only");
+#else
+        /* library world rank of every MPI rank of grid3d->comm */
+        int P; MPI_Comm_size(grid3d->comm, &P);
+        int mine = (myz * Pr + myrow) * Pc + mycol;
+        int *all = (int *) malloc(sizeof(int) * P);
+        MPI_Allgather(&mine, 1, MPI_INT, all, 1, MPI_INT, grid3d->comm);
+        M.comm = grid3d->comm;
+        M.mpi_rank_of = (int *) realloc(M.mpi_rank_of, sizeof(int) * P);
+        for (int q = 0; q < P; ++q) M.mpi_rank_of[all[q]] = q;
+        free(all);
+        sluamd_comm_callbacks_t cb = { NULL, m_isend, m_irecv, m_waitall, m_allmin };
+        rc = S.comm_create(&G.comm, &cb, Pr, Pc, Pz, myrow, mycol, myz);
+        if (rc) ABORT(S.last_error());
+        rc = S.create_grid(&G.h, &v, &fv, &o, G.comm);                       /* was dCreateLUgpuHandle    */
+#endif
+    } else {
+        rc = S.create(&G.h, &v, &fv, &o);
+    }
     if (rc) ABORT(S.last_error());
+    G.n = n;
     double thresh = smach_dist("Epsilon") * anorm;                           /* pdgstrf3d.c:132-133       */
-    rc = S.factor(h, thresh, info);                                          /* was pdgstrf3d_LUv1        */
+    rc = S.factor(G.h, thresh, info);                                        /* was pdgstrf3d_LUv1: collective, info already MIN over the grid */
     if (rc) ABORT(S.last_error());
-    rc = S.copy2host(h, &v);                                                 /* was dCopyLUGPU2Host       */
+    rc = S.copy2host(G.h, &v);                                               /* was dCopyLUGPU2Host       */
     if (rc) ABORT(S.last_error());
     sluamd_stats_t st;
-    S.stats(h, &st);
-    if (getenv("SLUAMD_BIND_DEBUG")) {
-        double sl = 0, su = 0; long zl = 0;
-        for (int_t k = 0; k < nsupers; ++k) {
-            int_t *li = Llu->Lrowind_bc_ptr[k];
-            if (!li) continue;
-            int nsupr = li[1], ns = Glu->xsup[k + 1] - Glu->xsup[k];
-            double *lv = (double *) Llu->Lnzval_bc_ptr[k];
-            int w = (int) (sizeof(*Llu->Lnzval_bc_ptr[k]) / sizeof(double));
-            for (int j = 0; j < ns; ++j) { double a = 0; for (int q = 0; q < w; ++q) a += fabs(lv[((size_t) j * nsupr + j) * w + q]); if (a == 0) ++zl; sl += a; }
-            if (Llu->Ufstnz_br_ptr[k]) { double *uv = (double *) Llu->Unzval_br_ptr[k]; for (int_t e = 0; e < Llu->Ufstnz_br_ptr[k][1] * w; ++e) su += fabs(uv[e]); }
-        }
-        fprintf(stderr, "[sluamd_bind] info %d nnzL %lld nnzU %lld factor_ms %.3f sum|diag| %.6e zero_diag %ld sum|U| %.6e launches %d\n",
-                *info, (long long) st.nnz_L, (long long) st.nnz_U, st.t_factor_ms, sl, zl, su, st.num_launches);
-    }
+    S.stats(G.h, &st);
+    if (getenv("SLUAMD_BIND_DEBUG"))
+        fprintf(stderr, "[sluamd_bind] rank (%d,%d,%d) info %d nnzL %lld nnzU %lld factor_ms %.3f launches %d\n", myrow, mycol, myz,
+                *info, (long long) st.nnz_L, (long long) st.nnz_U, st.t_factor_ms, st.num_launches);
     stat->ops[FACT] += (flops_t) (st.flops_schur_padded + st.flops_panel);   /* scuStatUpdate's tally     */
     stat->TinyPivots += st.tiny_pivots;
-    S.destroy(h);                                                            /* was dDestroyLUgpuHandle   */
     free(nNodes); free(lists);
-    /* *info: minimum over the 3D grid, as pdgstrf3d.c:388-392 */
-    if (*info == 0) *info = n + 1;
-    int g; MPI_Allreduce(info, &g, 1, MPI_INT, MPI_MIN, grid3d->comm);
-    *info = (g == n + 1) ? 0 : g;
     (void) m; (void) SCT;
     return 0;
 }
+
+#ifndef Z_PREC
+/* pdgstrs3d / pdgstrs3d_newsolve (pdgstrs3d.c:6604 / :6935): B holds this rank's m_loc rows (from fst_row) of the
+ * right-hand side in the ORIGINAL row order, replicated on every Z layer; on return the same rows of the solution of the
+ * permuted system.  The reference redistributes B -> x blocks (pdReDistribute3d_B_to_X, :6265), solves, and redistributes
+ * back (:6404); here: gather the complete permuted right-hand side (row i of B goes to row perm_c[perm_r[i]]), one
+ * collective library solve on the device-resident factors, keep the local rows. */
+static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, double *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
+                       SuperLUStat_t *stat, int *info)
+{
+    *info = 0;
+    if (n < 0) { *info = -1; return; }
+    if (nrhs < 0) { *info = -9; return; }
+    if (!G.h || G.n != n) ABORT("sluamd binding: pdgstrs3d called without a factorisation on the device");
+    if (nrhs == 0) return;
+    gridinfo_t *grid = &grid3d->grid2d;
+    int P2; MPI_Comm_size(grid->comm, &P2);
+    int *cnt = (int *) malloc(sizeof(int) * 2 * P2), *dsp = cnt + P2;
+    int mine = (int) m_loc;
+    MPI_Allgather(&mine, 1, MPI_INT, cnt, 1, MPI_INT, grid->comm);
+    int tot = 0;
+    for (int q = 0; q < P2; ++q) { dsp[q] = tot; tot += cnt[q]; }
+    if (tot != n || dsp[grid->iam] != fst_row) ABORT("sluamd binding: unexpected row distribution of B");
+    double *col = (double *) malloc(sizeof(double) * (size_t) n), *xp = (double *) malloc(sizeof(double) * (size_t) n * nrhs);
+    double t0 = SuperLU_timer_();
+    for (int j = 0; j < nrhs; ++j) {
+        MPI_Allgatherv(B + (size_t) j * ldb, (int) m_loc, MPI_DOUBLE, col, cnt, dsp, MPI_DOUBLE, grid->comm);
+        for (int_t i = 0; i < n; ++i) xp[SP->perm_c[SP->perm_r[i]] + (size_t) j * n] = col[i];
+    }
+    /* refinement-step right-hand sides are only valid on layer 0 (pdgsrfs3d works on the layer-0 2-D grid): take layer 0's */
+    if (grid3d->npdep > 1) MPI_Bcast(xp, (int) ((size_t) n * nrhs), MPI_DOUBLE, 0, grid3d->zscp.comm);
+    if (S.solve(G.h, xp, n, nrhs)) ABORT(S.last_error());
+    for (int j = 0; j < nrhs; ++j)
+        for (int_t i = 0; i < m_loc; ++i) B[i + (size_t) j * ldb] = xp[fst_row + i + (size_t) j * n];
+    stat->utime[SOLVE] = SuperLU_timer_() - t0;
+    free(col); free(xp); free(cnt);
+}
+
+void sluamd_bind_pdgstrs3d_newsolve(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct, xScalePermstruct_t *SP,
+                                    xtrf3Dpartition_t *part, gridinfo3d_t *grid3d, double *B, int_t m_loc, int_t fst_row, int_t ldb,
+                                    int nrhs, xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
+{
+    (void) options; (void) LUstruct; (void) part; (void) SOLVEstruct;
+    bind_solve(n, SP, grid3d, B, m_loc, fst_row, ldb, nrhs, stat, info);
+}
+void sluamd_bind_pdgstrs3d(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct, xScalePermstruct_t *SP,
+                           xtrf3Dpartition_t *part, gridinfo3d_t *grid3d, double *B, int_t m_loc, int_t fst_row, int_t ldb,
+                           int nrhs, xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
+{
+    (void) options; (void) LUstruct; (void) part; (void) SOLVEstruct;
+    bind_solve(n, SP, grid3d, B, m_loc, fst_row, ldb, nrhs, stat, info);
+}
+#endif

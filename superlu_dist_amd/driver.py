@@ -280,6 +280,16 @@ def _forest_view(forests):
     return fv, (mt, mz, lists, nn, arr)
 
 
+def pivot_thresh(n, rowptr, colind, nzval):
+    """thresh = smach_dist("Epsilon") * anorm of pdgstrf3d (pdgstrf3d.c:132-133): single-precision epsilon in LAPACK's
+    slamch('E') sense (FLT_EPSILON * 0.5 = 2^-24, smach_dist.c:64) times the 1-norm of A (max column sum,
+    dcomputeA_Norm(notran), pdgssvx3d.c)."""
+    if len(nzval) == 0:
+        return 0.0
+    colsum = np.bincount(np.asarray(colind), weights=np.abs(nzval), minlength=int(n))
+    return 0.5 * float(np.finfo(np.float32).eps) * float(colsum.max())
+
+
 def pdgssvx3d(n, rowptr, colind, nzval, b, perm_c=None, relax=32, maxsup=256, replace_tiny=False, anorm=None,
               keep=False, refine=False):
     """Solve A x = b through the GPU hot path: symbolic (host) -> device-resident distribute -> pdgstrf3d ->
@@ -288,10 +298,7 @@ def pdgssvx3d(n, rowptr, colind, nzval, b, perm_c=None, relax=32, maxsup=256, re
     double precision only) and puts `berr` / `refine_steps` into the stats.  Returns (x, info, stats[, handle, symb])."""
     symb = Symbolic(n, rowptr, colind, perm_c, relax, maxsup)
     h = LUHandle.from_symbolic(symb, nzval, replace_tiny=replace_tiny)
-    if anorm is None:
-        rp = np.asarray(rowptr)
-        anorm = float(np.max(np.add.reduceat(np.abs(nzval), rp[:-1]))) if len(nzval) else 0.0
-    thresh = float(np.finfo(np.float32).eps) * anorm          # pdgstrf3d.c:132-133 (single-precision epsilon)
+    thresh = pivot_thresh(n, rowptr, colind, nzval) if anorm is None else 0.5 * float(np.finfo(np.float32).eps) * anorm
     info = h.pdgstrf3d(thresh)
     b = np.asfortranarray(np.array(b, dtype=np.complex128 if np.iscomplexobj(nzval) else np.float64))
     if b.ndim == 1:

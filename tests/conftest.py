@@ -25,3 +25,18 @@ def golden():
             cache[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
         return cache[name]
     return load
+
+
+@pytest.fixture()
+def emul():
+    """Bind the ctypes layer to oracle/libsluamd_emul.so (the library's HOST sources + a serial CPU restatement of the
+    kernels: test infrastructure, built by `make -C oracle`) for the duration of one test."""
+    import ctypes, subprocess
+    from superlu_dist_amd import _lib
+    so = os.path.join(ROOT, "oracle", "libsluamd_emul.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsluamd_emul.so"])
+    saved = _lib._lib
+    _lib._lib = _lib.bind(ctypes.CDLL(so))
+    yield _lib._lib
+    _lib._lib = saved

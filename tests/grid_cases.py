@@ -1,0 +1,104 @@
+"""Shared bodies of the process-grid tests: the same checks run against the product library on a GPU (test_gpu_grid.py)
+and against the CPU test build of the library's host sources (oracle/libsluamd_emul.so, test_grid_emul.py).
+Ranks are threads of this process over the library's in-process transport (sluamd_comm_create_local)."""
+import numpy as np
+from superlu_dist_amd import driver, grid3d, matgen
+
+GRID_FIXTURES = ["g20_1x1x2", "poisson8_nd_1x1x2", "g20_2x1x1", "g20_2x2x2"]
+
+
+def forests_of(g, rank):
+    p = f"r{rank}__"
+    ml = int(g[p + "maxLvl"][0])
+    return dict(maxLvl=ml, myTreeIdxs=g[p + "myTreeIdxs"], myZeroTrIdxs=g[p + "myZeroTrIdxs"],
+                nodeLists=[g[p + f"forest{f}_nodeList"] if int(g[p + f"forest{f}_nNodes"][0]) > 0 else None
+                           for f in range((1 << ml) - 1)])
+
+
+def check_fixture_grid(g):
+    """Every rank's post-pdgstrf3d L/U values against the reference's per-rank record (1e-12 * ||A||_max), info, and
+    every recorded pdgstrs3d call against the reference's output (layer 0 holds the result; 1e-10 relative)."""
+    P = int(g["nranks"][0])
+    Pr, Pc, Pz = [int(v) for v in g["grid"]]
+    comms = grid3d.local_comms(Pr, Pc, Pz)
+    n = int(g["r0__n"][0])
+    pr_, pc_ = g["r0__perm_r"], g["r0__perm_c"]
+    scale = max(max(np.abs(g[f"r{q}__Lnzval_pre"]).max() if len(g[f"r{q}__Lnzval_pre"]) else 0.0 for q in range(P)), 1e-300)
+
+    def rank_body(rank):
+        p = f"r{rank}__"
+        r, c, z = int(g[p + "myrow"][0]), int(g[p + "mycol"][0]), int(g[p + "myz"][0])
+        w = (z * Pr + r) * Pc + c
+        st = driver.FlatStore.from_golden(g, rank, "pre")
+        h = grid3d.GridHandle.from_store(st, forests_of(g, rank), comms[w], replace_tiny=bool(g[p + "ReplaceTinyPivot"][0]))
+        info = h.pdgstrf3d(float(g[p + "thresh"][0]))
+        h.copy_to_host(st)
+        assert info == int(g[p + "info"][0])
+        eL = np.abs(st.Lnzval - g[p + "Lnzval_post"]).max() if len(st.Lnzval) else 0.0
+        eU = np.abs(st.Unzval - g[p + "Unzval_post"]).max() if len(st.Unzval) else 0.0
+        assert eL <= 1e-12 * scale and eU <= 1e-12 * scale, (rank, eL, eU)
+        sols = []
+        si = 0
+        while f"r0__solve{si}_B_in" in g:
+            nrhs = int(g[f"r0__solve{si}_nrhs"][0])
+            B = np.zeros((n, nrhs), order="F")
+            for q in range(Pr * Pc):     # layer 0 holds the 2-D row distribution of B
+                f0 = int(g[f"r{q}__solve{si}_fst_row"][0]); ml = int(g[f"r{q}__solve{si}_m_loc"][0])
+                B[f0:f0 + ml, :] = g[f"r{q}__solve{si}_B_in"].reshape((ml, nrhs), order="F")
+            xp = np.zeros((n, nrhs), order="F"); xp[pc_[pr_], :] = B
+            y = h.pdgstrs3d(xp)
+            if z == 0:
+                f0 = int(g[p + f"solve{si}_fst_row"][0]); ml = int(g[p + f"solve{si}_m_loc"][0])
+                X = g[p + f"solve{si}_B_out"].reshape((ml, nrhs), order="F")
+                assert np.abs(y[f0:f0 + ml, :] - X).max() <= 1e-10 * max(1.0, np.abs(X).max())
+            sols.append(y)
+            si += 1
+        assert si >= 1
+        h.destroy()
+        return sols
+
+    sols = grid3d.run_ranks(P, rank_body)
+    for q in range(1, P):               # every rank received the complete solution
+        for a, b in zip(sols[0], sols[q]):
+            assert np.array_equal(a, b)
+
+
+def check_own_pipeline(N, grid, nrhs=1, leaf=27, relax=16, maxsup=64, unsym=False, refactor=False):
+    """Library's own symbolic factorisation + device-side distribution on a Pr x Pc x Pz grid: residual on the original
+    system < 1e-10 and the solution equal (1e-10) to the single-rank one."""
+    Pr, Pc, Pz = grid
+    P = Pr * Pc * Pz
+    n, rp, ci, v = matgen.poisson3d(N)
+    if unsym:
+        rng = np.random.default_rng(N)
+        v = v * (1.0 + 0.3 * rng.random(v.size))
+        v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, nrhs)
+    x1, info1, _ = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=relax, maxsup=maxsup)
+    assert info1 == 0
+    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+    sn_tree = symb.partition(Pz) if Pz > 1 else None
+    comms = grid3d.local_comms(Pr, Pc, Pz)
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+
+    def rank_body(rank):
+        h = grid3d.GridHandle.from_symbolic(symb, v, comms[rank], sn_tree)
+        info = h.pdgstrf3d(0.0)
+        y = h.pdgstrs3d(xp)
+        if refactor:                    # device-side re-distribution + second factorisation reproduce the solution
+            h.reset_values()
+            assert h.pdgstrf3d(0.0) == 0
+            y2 = h.pdgstrs3d(xp)
+            assert np.abs(y2 - y).max() <= 1e-12 * np.abs(y).max()
+        h.destroy()
+        return info, y
+
+    out = grid3d.run_ranks(P, rank_body)
+    for info, y in out:
+        assert info == 0
+        x = y[symb.perm_c, :]
+        res = np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b)
+        assert res < 1e-10
+        assert np.abs(x - x1).max() <= 1e-10 * np.abs(x1).max()
+    symb.free()

@@ -80,17 +80,6 @@ def dfactor(store, order=None, replace_tiny=False, thresh=0.0):
     return info.value, tiny, flops
 
 
-def dfactor_coop(store, order, phase, G, g, replace_tiny=False, thresh=0.0):
-    """One phase of the cooperative (owner-computes, block column jb % G) factorisation; returns (info, tiny)."""
-    order = np.ascontiguousarray(order, dtype=np.int32)
-    info = ctypes.c_int(0)
-    fn = lib().slu_oracle_dfactor_coop
-    fn.restype = ctypes.c_int
-    tiny = fn(*store._args(), _p(order, ctypes.c_int), ctypes.c_int(len(order)), ctypes.c_int(phase), ctypes.c_int(G),
-              ctypes.c_int(g), ctypes.c_int(int(replace_tiny)), ctypes.c_double(thresh), ctypes.byref(info))
-    return info.value, tiny
-
-
 def dsolve(store, x):
     """Solve L U x = b on the permuted system; x (n x nrhs, Fortran order) overwritten and returned."""
     x = np.asfortranarray(np.array(x, dtype=store.dtype))

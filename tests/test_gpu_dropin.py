@@ -1,7 +1,9 @@
 """Drop-in test: the REAL reference pipeline (pdgssvx3d: equilibration, MC64, MMD ordering, symbolic factorisation,
 pddistribute3d, pdgstrs3d, refinement -- prebuilt from /root/reference into oracle/_ref/) with its pdgstrf3d call routed
 into libsluamd.so by the binding of INTEGRATION.md (oracle/ref/sluamd_binding.c).  The triangular solve that follows
-runs the reference's own CPU code on the factors our library copied back in the reference's formats."""
+and every refinement-step solve (pdgstrs3d / pdgstrs3d_newsolve) run in libsluamd.so on the device-resident factors
+(SLUAMD_BIND_SOLVE=0 keeps the reference's CPU solves on the factors copied back in the reference's formats), on 1x1x1 and,
+through mpiexec with the binding's MPI transport, on 1x1x2 / 2x1x1 / 2x2x2 grids whose ranks share the box's GPU."""
 import os, re, subprocess
 import numpy as np
 import pytest
@@ -15,11 +17,16 @@ ZAMD = os.path.join(ROOT, "oracle", "_ref", "slu_ref_zamd")
 ZREF = os.path.join(ROOT, "oracle", "_ref", "slu_ref_zdump")
 
 
-def _run(binary, args, tmp_path, threads="4"):
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def _run(binary, args, tmp_path, threads="4", nproc=1, extra_env=None):
     env = dict(os.environ, OMP_NUM_THREADS=threads)
     env.pop("LD_LIBRARY_PATH", None)          # the binaries carry RUNPATH=/opt/conda/lib for MPICH
+    env.update(extra_env or {})
+    cmd = [binary] + args if nproc == 1 else [MPIEXEC, "-n", str(nproc), binary] + args
     for attempt in range(3):                  # MPICH singleton start-up on the box is occasionally flaky: retry
-        r = subprocess.run([binary] + args, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
         if r.returncode == 0:
             break
         if "MPI" in r.stderr and "nit" in r.stderr and attempt == 2:
@@ -47,11 +54,39 @@ def test_reference_pipeline_with_our_pdgstrf3d(kind, tmp_path):
         flags = ["-i", "0"]                     # no refinement: the raw factorisation accuracy shows
     matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
     args = ["-r", "1", "-c", "1", "-d", "1", "-Q", "1", "-o", "none"] + flags + [str(tmp_path / "a.dat")]
-    res_amd, info_amd = _run(AMD, args, tmp_path)
+    res_amd, info_amd = _run(AMD, args, tmp_path)                                    # our factor + our solves
+    res_fac, info_fac = _run(AMD, args, tmp_path, extra_env={"SLUAMD_BIND_SOLVE": "0"})   # our factor, reference solves
     res_ref, info_ref = _run(REF, args, tmp_path)
+    assert info_amd == info_fac == info_ref == 0
+    assert res_amd < 1e-10 and res_fac < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10       # BASELINE.json: within 1e-10 of the reference CPU pdgssvx3d
+    assert abs(res_fac - res_ref) < 1e-10
+
+
+@pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
+@pytest.mark.parametrize("grid", [(1, 1, 2), (2, 1, 1), (2, 2, 2)])
+@pytest.mark.parametrize("kind", ["poisson_nd_norefine", "unsym_defaults"])
+def test_reference_pipeline_on_process_grids(grid, kind, tmp_path):
+    """mpiexec -n R*C*D slu_ref_amd -r R -c C -d D: the reference's pdgssvx3d on a process grid with pdgstrf3d AND
+    pdgstrs3d[_newsolve] bound to the library over the binding's MPI transport (XY panel exchange, Z ancestor reduction
+    and the distributed solves run in libsluamd.so); residual parity with the untouched reference on the same grid."""
+    if kind == "poisson_nd_norefine":
+        N = 10
+        n, rp, ci, v = matgen.poisson3d(N)
+        perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+        np.savetxt(tmp_path / "a.perm", perm, fmt="%d")
+        flags = ["-e", "0", "-p", "0", "-i", "0", "-P", str(tmp_path / "a.perm")]
+    else:
+        n, rp, ci, v = matgen.random_unsym(400, 0.02, seed=11)
+        flags = []
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    r, c, d = grid
+    args = ["-r", str(r), "-c", str(c), "-d", str(d), "-Q", "1", "-o", "none"] + flags + [str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(AMD, args, tmp_path, threads="1", nproc=r * c * d)
+    res_ref, info_ref = _run(REF, args, tmp_path, threads="1", nproc=r * c * d)
     assert info_amd == info_ref == 0
     assert res_amd < 1e-10 and res_ref < 1e-10
-    assert abs(res_amd - res_ref) < 1e-10       # BASELINE.json: within 1e-10 of the reference CPU pdgssvx3d
+    assert abs(res_amd - res_ref) < 1e-10
 
 
 @pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF)), reason="prebuilt reference binaries not shipped")

@@ -1,0 +1,58 @@
+"""CPU coverage of the library's multi-rank HOST logic (planning, XY panel-exchange plans, Z ancestor reduction,
+distributed solve, C-level transports): the library's own host sources linked against the serial kernel restatement
+(oracle/libsluamd_emul.so, built by `make -C oracle`), pinned to the per-rank records of the real reference on
+1x1x2, 2x1x1 and 2x2x2 grids.  The GPU twin of this file is test_gpu_grid.py (same bodies, product library)."""
+import os, subprocess, sys
+import numpy as np
+import pytest
+import grid_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("case", grid_cases.GRID_FIXTURES)
+def test_grid_fixture_per_rank_parity(emul, golden, case):
+    grid_cases.check_fixture_grid(golden(case))
+
+
+@pytest.mark.parametrize("case", ["g20_1x1x1", "poisson10_nd", "unsym300", "unsym120_tiny"])
+def test_single_rank_fixture_parity(emul, golden, case):
+    """1x1x1 through the same planner (slot model with one process row / column)."""
+    from superlu_dist_amd import driver
+    g = golden(case)
+    st = driver.FlatStore.from_golden(g, 0, "pre")
+    h = driver.LUHandle.from_store(st, replace_tiny=bool(g["r0__ReplaceTinyPivot"][0]))
+    assert h.pdgstrf3d(float(g["r0__thresh"][0])) == int(g["r0__info"][0])
+    h.copy_to_host()
+    scale = max(np.abs(g["r0__Lnzval_pre"]).max(), np.abs(g["r0__Unzval_pre"]).max())
+    assert np.abs(st.Lnzval - g["r0__Lnzval_post"]).max() <= 1e-12 * scale
+    assert np.abs(st.Unzval - g["r0__Unzval_post"]).max() <= 1e-12 * scale
+    h.destroy()
+
+
+@pytest.mark.parametrize("N,grid,nrhs,unsym", [(8, (1, 1, 2), 1, False), (8, (2, 2, 1), 2, True), (10, (2, 2, 2), 1, True),
+                                                (8, (1, 2, 4), 1, False), (8, (3, 2, 1), 1, True), (8, (1, 1, 8), 3, False)])
+def test_own_pipeline_on_grids(emul, N, grid, nrhs, unsym):
+    grid_cases.check_own_pipeline(N, grid, nrhs=nrhs, unsym=unsym, refactor=(grid == (2, 2, 2)))
+
+
+def test_grid_without_communicator_is_rejected(emul, golden):
+    """A rank of a multi-rank grid cannot be factored alone: the old silent-wrong-factors path is an error now."""
+    from superlu_dist_amd import driver
+    g = golden("g20_1x1x2")
+    st = driver.FlatStore.from_golden(g, 0, "pre")
+    with pytest.raises(RuntimeError, match="communicator"):
+        driver.LUHandle.from_store(st, forests=grid_cases.forests_of(g, 0))
+
+
+@pytest.mark.parametrize("world,grid", [(2, (1, 1, 2)), (2, (2, 1, 1)), (4, (2, 2, 1))])
+def test_gloo_processes_through_the_callback_transport(world, grid, tmp_path):
+    """Real processes (torch.distributed gloo, world size > 1) driving the C orchestration through
+    sluamd_comm_create_callbacks -- the same path the reference-side MPI binding uses."""
+    port = 29500 + (os.getpid() % 400) + world
+    script = os.path.join(ROOT, "tests", "grid_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script, "--engine", "emul", "--grid", *[str(v) for v in grid], "--side", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "GRID_WORKER_OK" in r.stdout
