@@ -92,14 +92,19 @@ def cpu_baseline(N, leaf, relax, maxsup, want_reference=True):
                 matgen.write_triplet_dat(mpath, n, rp, ci, v)
                 np.savetxt(ppath, perm, fmt="%d")
                 sweep, spent, best = [], 0.0, None
-                for th in sorted({t for t in (8, 32, host_cores) if t <= host_cores} | {min(8, host_cores)}):
-                    if spent > 100.0:            # bounded: the whole CPU leg stays within a couple of minutes
+                for th in [t for t in (32, 64, 16, 8) if t <= host_cores] or [host_cores]:   # 32 first: round 1's setting
+                    if spent > 70.0:             # bounded: the whole CPU leg stays within a couple of minutes
                         break
                     env = dict(os.environ, OMP_NUM_THREADS=str(th), SUPERLU_MAXSUP=str(maxsup), SUPERLU_RELAX=str(relax))
                     env.pop("LD_LIBRARY_PATH", None)     # the binary carries RUNPATH=/opt/conda/lib for MPICH
                     t0 = time.perf_counter()
-                    r = subprocess.run([ref_bin, "-r", "1", "-c", "1", "-d", "1", "-e", "0", "-p", "0", "-i", "0", "-Q", "1",
-                                        "-P", ppath, "-o", "none", mpath], env=env, capture_output=True, text=True, timeout=150)
+                    try:
+                        r = subprocess.run([ref_bin, "-r", "1", "-c", "1", "-d", "1", "-e", "0", "-p", "0", "-i", "0", "-Q", "1",
+                                            "-P", ppath, "-o", "none", mpath], env=env, capture_output=True, text=True, timeout=110)
+                    except subprocess.TimeoutExpired:
+                        spent += time.perf_counter() - t0
+                        sweep.append({"threads": th, "timeout_s": 110})
+                        continue
                     spent += time.perf_counter() - t0
                     line = [l for l in r.stdout.splitlines() if l.startswith("REFTIMES")]
                     if r.returncode == 0 and line:
