@@ -125,7 +125,11 @@ int LocalComm::run(hipStream_t s, bool sync_stream)
         if (m->bytes != o.bytes) { set_error("LocalComm: message size mismatch (" + std::to_string(m->bytes) + " sent, " + std::to_string(o.bytes) + " expected)"); return SLUAMD_EINVAL; }
         if (o.bytes) {
             if (o.host) std::memcpy(o.p, m->ptr, (size_t) o.bytes);
-            else HIPCHK(hipMemcpy(o.p, m->ptr, (size_t) o.bytes, hipMemcpyDeviceToDevice));
+            else {   // on the caller's stream (a device-to-device hipMemcpy on the null stream is neither host-synchronous nor
+                     // ordered with non-blocking streams), completed before the sender is released
+                HIPCHK(hipMemcpyAsync(o.p, m->ptr, (size_t) o.bytes, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
         }
         {
             std::lock_guard<std::mutex> lk(w->mu);
