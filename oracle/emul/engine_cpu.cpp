@@ -241,35 +241,121 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
     }
 }
 
-void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int)
+void full_inv(hipStream_t, const DevTables &T, const int *nodes, int nn)
 {
-    std::vector<double> xs, ys(DB);
     for (int i0 = 0; i0 < nn; ++i0) {
         const int k = nodes[i0];
         if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
-        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_dlda[k], nblk = (ns + DB - 1) / DB;
+        const int ns = T.xsup[k + 1] - T.xsup[k], lda = T.sn_dlda[k], nblk = (ns + DB - 1) / DB;
         const double *A = T.val + T.sn_dptr[k];
-        const double *dinv = T.dinv + T.sn_dinv[k] + (lower ? (size_t) nblk * DB * DB : 0);
+        for (int typ = 0; typ < 2; ++typ) {
+            const double *dinv = T.dinv + T.sn_dinv[k] + (size_t) typ * nblk * DB * DB;
+            double *out = T.inv + T.sn_inv[k] + (typ == 0 ? (size_t) ns * ns : 0);
+            auto M = [&](int r, int c) { return (r < ns && c < ns) ? (typ == 0 ? A[r + (size_t) c * lda] : A[c + (size_t) r * lda]) : 0.0; };
+            auto Xat = [&](int r, int c) { return typ == 0 ? out + r + (size_t) c * ns : out + c + (size_t) r * ns; };
+            for (int e = 0; e < ns * ns; ++e) { const int r = e % ns, c = e / ns; if (r > c) *Xat(r, c) = 0.0; }
+            for (int i = nblk - 1; i >= 0; --i) {
+                const double *D = dinv + (size_t) i * DB * DB;
+                for (int kk = 0; kk < DB; ++kk) for (int cc = 0; cc < DB; ++cc)
+                    if (i * DB + kk < ns && i * DB + cc < ns) *Xat(i * DB + kk, i * DB + cc) = D[cc * DB + kk];
+                for (int j = i + 1; j < nblk; ++j) {
+                    double S[DB][DB];
+                    for (int r = 0; r < DB; ++r) for (int c = 0; c < DB; ++c) {
+                        double a = 0.0;
+                        if (j * DB + c < ns) for (int q = (i + 1) * DB; q < std::min((j + 1) * DB, ns); ++q) a += M(i * DB + r, q) * *Xat(q, j * DB + c);
+                        S[r][c] = a;
+                    }
+                    for (int r = 0; r < DB; ++r) for (int c = 0; c < DB; ++c)
+                        if (i * DB + r < ns && j * DB + c < ns) { double a = 0.0; for (int q = 0; q < DB; ++q) a += D[q * DB + r] * S[q][c]; *Xat(i * DB + r, j * DB + c) = -a; }
+                }
+            }
+        }
+    }
+}
+
+void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int)
+{
+    std::vector<double> xs;
+    for (int i0 = 0; i0 < nn; ++i0) {
+        const int k = nodes[i0];
+        if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+        const double *Ti = T.inv + T.sn_inv[k] + (lower ? 0 : (size_t) ns * ns);
         for (int q = 0; q < nrhs; ++q) {
             double *xk = x + fst + (int64_t) q * ldx;
-            for (int bb = 0; bb < nblk; ++bb) {
-                const int b = lower ? bb : nblk - 1 - bb, o = b * DB, nb = std::min(DB, ns - o);
-                const double *D = dinv + (size_t) b * DB * DB;
-                for (int r = 0; r < nb; ++r) {
-                    double a = 0;
-                    for (int c = 0; c < nb; ++c) {
-                        const double dv = lower ? (c <= r ? D[r * DB + c] : 0.0) : (c >= r ? D[c * DB + r] : 0.0);
-                        a += dv * xk[o + c];
-                    }
-                    ys[r] = a;
+            xs.assign(xk, xk + ns);
+            for (int i = 0; i < ns; ++i) {
+                double a = 0.0;
+                if (lower) for (int j = 0; j <= i; ++j) a += Ti[i + (size_t) j * ns] * xs[j];
+                else for (int j = i; j < ns; ++j) a += Ti[i + (size_t) j * ns] * xs[j];
+                xk[i] = a;
+            }
+        }
+    }
+}
+
+void fwd_fused(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx, int nrhs,
+               int)
+{
+    std::vector<double> yk;
+    for (int w = 0; w < nwork; ++w) {
+        const int ni = find_node(prefix, nn, w);
+        const int k = nodes[ni], strip = w - prefix[ni];
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
+        const double *Li = T.inv + T.sn_inv[k];
+        const int *lsub = T.lidx + T.sn_lidx[k];
+        for (int r = 0; r < nrhs; ++r) {
+            yk.assign(ns, 0.0);
+            for (int i = 0; i < ns; ++i) { double a = 0; for (int j = 0; j <= i; ++j) a += Li[i + (size_t) j * ns] * x[fst + j + (int64_t) r * ldx]; yk[i] = a; }
+            if (strip == 0) for (int i = 0; i < ns; ++i) y[fst + i + (int64_t) r * ldx] = yk[i];
+            for (int t = 0; t < 256; ++t) {
+                const int row = T.sn_ldiag[k] + strip * 256 + t;
+                if (row >= lda) break;
+                int p = BC_HEADER, base = 0, grow = -1;
+                for (int b = 0; b < lsub[0]; ++b) {
+                    const int nbrow = lsub[p + 1];
+                    if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
+                    base += nbrow; p += LB_DESCRIPTOR + nbrow;
                 }
-                for (int r = 0; r < nb; ++r) xk[o + r] = ys[r];
-                const int r0 = lower ? o + nb : 0, r1 = lower ? ns : o;
-                for (int i = r0; i < r1; ++i) {
-                    double a = 0;
-                    for (int c = 0; c < nb; ++c) a += A[i + (size_t) (o + c) * lda] * ys[c];
-                    xk[i] -= a;
-                }
+                const double *L = T.val + T.sn_lval[k] + row;
+                double acc = 0;
+                for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * yk[kk];
+                x[grow + (int64_t) r * ldx] -= acc;
+            }
+        }
+    }
+}
+
+void bwd_fused(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, const double *y, int64_t ldx,
+               int nrhs)
+{
+    std::vector<double> v;
+    for (int w = 0; w < nwork; ++w) {
+        const int ni = find_node(prefix, nn, w);
+        const int k = nodes[ni], chunk = w - prefix[ni];
+        const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
+        const int ncol = std::max(0, std::min(256, T.sn_ncolu[k] - chunk * 256));
+        const double *Uv = T.val + T.sn_uval[k];
+        const double *Ui = T.inv + T.sn_inv[k] + (size_t) ns * ns;
+        for (int r = 0; r < nrhs; ++r) {
+            v.assign(ns, 0.0);
+            if (chunk == 0) for (int i = 0; i < ns; ++i) v[i] = y[fst + i + (int64_t) r * ldx];
+            for (int t = 0; t < ncol; ++t) {
+                const int c = chunk * 256 + t;
+                const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+                int lo = 0, hi = nub;
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
+                const int b = ub0 + lo;
+                const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+                const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
+                const int ld = ns - (klst - T.uidx[u0 + jj]), cp = T.ucolptr[u0 + jj], gc = T.xsup[T.ub_gid[b]] + jj;
+                const double xv = x[gc + (int64_t) r * ldx];
+                for (int i = ld; i < ns; ++i) v[i] -= Uv[cp + (i - ld)] * xv;
+            }
+            for (int i = 0; i < ns; ++i) {
+                double a = 0;
+                for (int j = i; j < ns; ++j) a += Ui[i + (size_t) j * ns] * v[j];
+                x[fst + i + (int64_t) r * ldx] += a;
             }
         }
     }

@@ -248,7 +248,7 @@ int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
 {
     if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
     HIPCHK(hipSetDevice(h->H.device));
-    h->H.dinv_ready = false;
+    h->H.dinv_ready = false; h->H.inv_ready = false;
     return timed_copy(&h->H, lu, 0);
 }
 
@@ -486,6 +486,7 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_info) hipFree(H->d_info);
     if (H->d_x) hipFree(H->d_x);
     if (H->d_xtmp) hipFree(H->d_xtmp);
+    if (H->d_y) hipFree(H->d_y);
     if (H->d_apos) hipFree(H->d_apos);
     if (H->d_aval) hipFree(H->d_aval);
     if (H->h_pinned) hipHostFree(H->h_pinned);
@@ -535,7 +536,7 @@ int sluamd_dResetValues(sluamd_handle_t h)
     if (!h || !h->H.d_apos) { set_error("handle has no device-side copy of A"); return SLUAMD_EINVAL; }
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
-    H->dinv_ready = false;
+    H->dinv_ready = false; H->inv_ready = false;
     HIPCHK(hipMemsetAsync(H->d_val, 0, (H->z ? 16 : 8) * (size_t) H->own_len, H->stream));
     if (H->a_nnz && !H->z) eng::scatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, H->a_nnz);
     if (H->a_nnz && H->z) eng::zscatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, H->a_nnz);

@@ -274,7 +274,7 @@ int run_factor(Handle *H, double thresh, int *info)
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
-    H->dinv_ready = true;
+    H->dinv_ready = true; H->inv_ready = false;
     H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
     H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
     H->st.tiny_pivots = res[1];
@@ -307,6 +307,20 @@ int ensure_dinv(Handle *H)
             eng::diag_inv(H->stream, H->T, S.d_nodes + n0, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);
         }
     H->dinv_ready = true;
+    return 0;
+}
+
+// Linv / Uinv of every owned diagonal block, once per factorisation (pdCompute_Diag_Inv, pdgstrs.c:842)
+int ensure_inv(Handle *H)
+{
+    if (H->inv_ready) return 0;
+    int rc = ensure_dinv(H);
+    if (rc) return rc;
+    for (size_t zl = 0; zl < H->sched.size(); ++zl) {
+        LevelSched &S = H->sched[zl];
+        if (!S.nodes.empty()) eng::full_inv(H->stream, H->T, S.d_nodes, (int) S.nodes.size());
+    }
+    H->inv_ready = true;
     return 0;
 }
 
@@ -395,22 +409,52 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     return 0;
 }
 
+// single-layer (1 x 1 process layer) sweeps: ONE fused launch per level and direction
+static void solve_fwd_fused(Handle *H, int z, double *d_x, double *d_y, int64_t ldx, int nrhs)
+{
+    LevelSched &S = H->sched[z];
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        eng::fwd_fused(H->stream, H->T, S.d_nodes + n0, S.d_ffwd_prefix + po, nn, S.ffwd_prefix[po + nn], d_x, d_y, ldx, nrhs, S.max_nsupc[l]);
+    }
+}
+static void solve_bwd_fused(Handle *H, int z, double *d_x, const double *d_y, int64_t ldx, int nrhs)
+{
+    LevelSched &S = H->sched[z];
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        eng::bwd_fused(H->stream, H->T, S.d_nodes + n0, S.d_fbwd_prefix + po, nn, S.fbwd_prefix[po + nn], d_x, d_y, ldx, nrhs);
+    }
+}
+static int ensure_y(Handle *H, int64_t doubles)
+{
+    if (doubles <= H->y_cap) return 0;
+    if (H->d_y) hipFree(H->d_y);
+    H->d_y = nullptr; H->y_cap = 0;
+    if (hipMalloc((void **) &H->d_y, sizeof(double) * (size_t) doubles) != hipSuccess) { set_error("hipMalloc of the solve work vector failed"); return SLUAMD_ENOMEM; }
+    H->y_cap = doubles;
+    return 0;
+}
+
 static int max_rhs_chunk(const Handle *H)
 {   // the diagonal solve stages (max_nsupc + 32) x nrhs doubles in LDS (<= 150 KiB of the 160 KiB per workgroup)
-    const int per = (H->max_nsupc + 32) * 8;
+    const int per = 2 * H->max_nsupc * 8;           // k_fwd_fused: x_k and y_k
     return std::max(1, (150 * 1024) / std::max(per, 1));
 }
 
 int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
 {
-    int rc = ensure_dinv(H);
+    int rc = ensure_inv(H);
     if (rc) return rc;
     const int ch = max_rhs_chunk(H);
+    if ((rc = ensure_y(H, ldx * std::min(ch, nrhs)))) return rc;
+    hipStream_t s = H->stream;
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
         double *x = d_x + (size_t) j0 * ldx;
-        for (int z = 0; z < (int) H->sched.size(); ++z) if ((rc = solve_fwd_z(H, z, x, ldx, nr))) return rc;
-        for (int z = (int) H->sched.size() - 1; z >= 0; --z) if ((rc = solve_bwd_z(H, z, x, ldx, nr))) return rc;
+        for (int z = 0; z < (int) H->sched.size(); ++z) solve_fwd_fused(H, z, x, H->d_y, ldx, nr);
+        for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.n, s));
+        for (int z = (int) H->sched.size() - 1; z >= 0; --z) solve_bwd_fused(H, z, x, H->d_y, ldx, nr);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -449,10 +493,13 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
     if (g.size() == 1) return run_solve_local(H, d_x, ldx, nrhs);
     if (!H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
     if (!H->dinv_ready) { set_error("grid solve needs the factorisation to have run on this handle"); return SLUAMD_EINVAL; }
+    const bool fused = g.Pr * g.Pc == 1;     // 1 x 1 layers: one fused launch per level and direction (x consumed, y = forward solution)
     const int nzl = (int) H->sched.size();
     hipStream_t s = H->stream;
     const int ch = max_rhs_chunk(H);
     int rc;
+    if ((rc = ensure_inv(H))) return rc;
+    if (fused && (rc = ensure_y(H, ldx * std::min(ch, nrhs)))) return rc;
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
         double *x = d_x + (size_t) j0 * ldx;
@@ -482,7 +529,10 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
         for (int zl = 0; zl < nzl; ++zl) {
             const int step = 1 << zl;
             if (g.z % step) break;
-            if (H->z_active[zl] && (rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
+            if (H->z_active[zl]) {
+                if (fused) solve_fwd_fused(H, zl, x, H->d_y, ldx, nr);
+                else if ((rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
+            }
             if (zl + 1 < nzl) {
                 LevelSched::XSeg seg;
                 forest_runs(H, zl + 1, nzl, 0, seg);
@@ -494,6 +544,7 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
             }
         }
         // ---- backward sweep, root to leaves ----
+        if (fused) for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.n, s));
         for (int zl = nzl - 1; zl >= 0; --zl) {
             const int step = 1 << zl;
             if (g.z % step) continue;
@@ -507,7 +558,10 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
                     if (seg.total && (rc = sender ? xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldx, nr, none, 0, one, 1, s))) return rc;
                 }
             }
-            if (H->z_active[zl] && (rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
+            if (H->z_active[zl]) {
+                if (fused) solve_bwd_fused(H, zl, x, H->d_y, ldx, nr);
+                else if ((rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
+            }
         }
         // ---- assemble: every x_k is final at its diagonal owner on the layer that factored its forest; gather on world
         //      rank 0, then hand the complete vector to everyone ----

@@ -113,6 +113,8 @@ struct DevTables {
     const int64_t *sn_dptr;            // offset into val of the nsupc x nsupc diagonal block (inside the L slot or in the scratch)
     const int *sn_dlda;                // ... and its leading dimension
     double *dinv;                      // inverted 32x32 diagonal sub-blocks of U_kk and L_kk^T (workspace)
+    double *inv;                       // full inverses Linv | Uinv (ns x ns each, ld = ns) of the diagonal blocks this rank owns (solve)
+    const int64_t *sn_inv;             // offset of supernode k's pair in inv
     const int64_t *sn_dinv;            // offset of supernode k's blocks in dinv
     const int *sn_ldu;                 // max U segment height of block row k (this slot)
     const int *sn_ncolu;               // total non-empty U columns of block row k (this slot)
@@ -153,6 +155,7 @@ struct LevelSched {
     std::vector<int> lvl_soff;      // [nlevels+1] offset of each level's Schur prefix arrays (big group | small group)
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
+    std::vector<int> ffwd_prefix, fbwd_prefix;  // fused single-layer solve: 256-row L strips / 256-column U chunks, at least one per supernode
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
@@ -170,6 +173,7 @@ struct LevelSched {
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
     int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
+    int *d_ffwd_prefix = nullptr, *d_fbwd_prefix = nullptr;
     int4 *d_ulist = nullptr;
     int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
 };
@@ -185,7 +189,7 @@ struct Handle {
     // environment switches, read ONCE at creation (they may differ per handle)
     struct Env {
         bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false;
-        int fuse_min_pct = 75, fuse_max_prev = 1, lookahead_max_strips = 1 << 30;
+        int fuse_min_pct = 75, fuse_max_prev = 1, lookahead_max_strips = 1 << 30, reserve_cus = 0;
     } env;
     // device arenas
     double *d_val = nullptr;
@@ -212,6 +216,8 @@ struct Handle {
     void *h_pinned = nullptr; size_t pinned_bytes = 0;      // bounded pinned staging buffer (value upload / download)
     bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
     bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
+    bool inv_ready = false;                                 // T.inv (Linv / Uinv) too
+    double *d_y = nullptr; int64_t y_cap = 0;               // forward solution of the fused single-layer solve
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
     size_t ev_schur_used = 0, ev_panel_used = 0;
@@ -241,6 +247,13 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
            const int4 *ulist, const int *sn_level, int skip_level);
+// Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
+void full_inv(hipStream_t s, const DevTables &T, const int *nodes, int nn);
+// fused level kernels of the single-layer solve: forward (x consumed, y = forward solution), backward (x zeroed before, receives the solution)
+void fwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx,
+               int nrhs, int max_nsupc);
+void bwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, const double *y,
+               int64_t ldx, int nrhs);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs,
                 int max_nsupc);

@@ -224,8 +224,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
 __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__restrict__ nodes,
                                                   const int *__restrict__ prefix, int nn)
 {
-    __shared__ double Bs[4][DB * (DB + 1)];
-    __shared__ double Xi[4][DB * (DB + 1)];
+    __shared__ double Bs[4][DB * (DB + 1)];     // 34 KB: the workgroup fits beside two Schur workgroups on a CU
     const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
     const int task = blockIdx.x * 4 + g;
     bool valid = task < prefix[nn];
@@ -258,13 +257,21 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
     }
     __syncthreads();
     if (valid) {
-        for (int i = c; i >= 0; --i) {
+        // column c of the inverse by back substitution, the private solution column in registers (static indices: rows past
+        // c stay zero, so the sums may run over the full width)
+        double xi[DB];
+#pragma unroll
+        for (int i = 0; i < DB; ++i) xi[i] = 0.0;
+#pragma unroll
+        for (int i = DB - 1; i >= 0; --i) {
             double a = (i == c) ? 1.0 : 0.0;
-            for (int jj = i + 1; jj <= c; ++jj) a -= Bs[g][i * (DB + 1) + jj] * Xi[g][jj * (DB + 1) + c];
-            Xi[g][i * (DB + 1) + c] = a / Bs[g][i * (DB + 1) + i];
+#pragma unroll
+            for (int jj = i + 1; jj < DB; ++jj) a -= Bs[g][i * (DB + 1) + jj] * xi[jj];
+            xi[i] = (i <= c) ? a / Bs[g][i * (DB + 1) + i] : 0.0;
         }
         double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB + c * DB;
-        for (int i = 0; i < DB; ++i) dst[i] = (i <= c) ? Xi[g][i * (DB + 1) + c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < DB; ++i) dst[i] = xi[i];
     }
 }
 
@@ -771,61 +778,210 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         }
 }
 
+// ---- full inverses of the diagonal blocks (pdCompute_Diag_Inv, SRC/double/pdgstrs.c:842: Linv / Uinv via dtrtri) -----
+// One workgroup per (supernode, typ): typ 0 -> Uinv = inv(U_kk) (upper), typ 1 -> Linv = inv(L_kk) (unit lower), both dense
+// ns x ns, column-major, ld = ns, at T.inv + T.sn_inv[k] (Linv first, then Uinv).  Blocked by 32 on top of the inverted
+// 32 x 32 diagonal sub-blocks the factorisation left in T.dinv: for the upper-triangular M (U_kk, or L_kk^T for typ 1)
+//     X_ii = inv(M_ii),   X_ij = -X_ii * sum_{k=i+1..j} M_ik X_kj   (j > i, block rows from the bottom up)
+// X is read back from the output array itself (written by this workgroup in earlier steps).
+__global__ __launch_bounds__(256) void k_full_inv(DevTables T, const int *__restrict__ nodes, int nn)
+{
+    __shared__ double Ss[DB * (DB + 1)];
+    const int k = nodes[blockIdx.x >> 1];
+    const int typ = blockIdx.x & 1;
+    if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;
+    const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB;
+    const int lda = T.sn_dlda[k];
+    const double *A = T.val + T.sn_dptr[k];
+    const double *dinv = T.dinv + T.sn_dinv[k] + (size_t) typ * nblk * DB * DB;
+    double *out = T.inv + T.sn_inv[k] + (typ == 0 ? (size_t) ns * ns : 0);
+    const int tid = threadIdx.x;
+    // M(r, c): typ 0 = U(r, c) = A[r + c lda]; typ 1 = L^T(r, c) = L(c, r) = A[c + r lda].  X(r, c) stored at out[r + c ns]
+    // (typ 0) or transposed at out[c + r ns] (typ 1: Linv = X^T)
+    auto M = [&](int r, int c) -> double { return (r < ns && c < ns) ? (typ == 0 ? A[r + (size_t) c * lda] : A[c + (size_t) r * lda]) : 0.0; };
+    auto Xat = [&](int r, int c) -> double * { return typ == 0 ? out + r + (size_t) c * ns : out + c + (size_t) r * ns; };
+    // zero the strictly "other" triangle once
+    for (int e = tid; e < ns * ns; e += 256) { const int r = e % ns, c = e / ns; if (r > c) *Xat(r, c) = 0.0; }
+    for (int i = nblk - 1; i >= 0; --i) {
+        const double *D = dinv + (size_t) i * DB * DB;   // inv(M_ii)(kk, cc) at D[cc * 32 + kk]
+        for (int e = tid; e < DB * DB; e += 256) {
+            const int kk = e & 31, cc = e >> 5;
+            if (i * DB + kk < ns && i * DB + cc < ns) *Xat(i * DB + kk, i * DB + cc) = D[cc * DB + kk];
+        }
+        for (int j = i + 1; j < nblk; ++j) {
+            // S = sum_{k=i+1..j} M_ik X_kj  (rows k > i of X are complete)
+            for (int e = tid; e < DB * DB; e += 256) {
+                const int r = e & 31, c = e >> 5;
+                double a = 0.0;
+                if (j * DB + c < ns)
+                    for (int q = (i + 1) * DB; q < min((j + 1) * DB, ns); ++q) a += M(i * DB + r, q) * *Xat(q, j * DB + c);
+                Ss[r * (DB + 1) + c] = a;
+            }
+            __syncthreads();
+            for (int e = tid; e < DB * DB; e += 256) {
+                const int r = e & 31, c = e >> 5;
+                if (i * DB + r < ns && j * DB + c < ns) {
+                    double a = 0.0;
+#pragma unroll 8
+                    for (int q = 0; q < DB; ++q) a += D[q * DB + r] * Ss[q * (DB + 1) + c];
+                    *Xat(i * DB + r, j * DB + c) = -a;
+                }
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    (void) nn;
+}
+
 // ---- triangular solves --------------------------------------------------------------------------
-// x_k <- inv(L_kk) x_k (unit lower) or inv(U_kk) x_k (upper): one workgroup per supernode of the level,
-// blocked by 32 with the inverted diagonal sub-blocks left in T.dinv by the factorisation (what the reference's
-// DiagInv=YES solve does with Linv/Uinv, pdgstrs_lsum.c:414-520): 2 barriers per 32 columns.
+// x_k <- Linv x_k (unit lower) or Uinv x_k: one workgroup per supernode of the level, ONE dense triangular GEMV with the full
+// inverse (what the reference's DiagInv=YES solve does with Linv / Uinv, pdgstrs_lsum.c:414-520) -- no dependent chain
+// inside the block.  Used on XY layers, where the exchanges separate the diagonal solve from the updates.
 template <bool LOWER>
 __global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
                                                     int64_t ldx, int nrhs)
 {
-    extern __shared__ double xs[];  // ns x nrhs, then 32 x nrhs scratch
+    extern __shared__ double xs[];  // ns x nrhs
     const int k = nodes[blockIdx.x];
     if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;           // x_k is solved by the owner of the diagonal block
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
-    const int lda = T.sn_dlda[k];
-    const double *A = T.val + T.sn_dptr[k];
-    const int nblk = (ns + DB - 1) / DB;
-    const double *dinv = T.dinv + T.sn_dinv[k] + (LOWER ? (size_t) nblk * DB * DB : 0);
-    double *ys = xs + (size_t) ns * nrhs;
+    const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
     const int tid = threadIdx.x;
     for (int idx = tid; idx < ns * nrhs; idx += 256) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
-    for (int bb = 0; bb < nblk; ++bb) {
-        const int b = LOWER ? bb : nblk - 1 - bb;
-        const int o = b * DB, nb = min(DB, ns - o);
-        const double *D = dinv + (size_t) b * DB * DB;
-        // y = inv(T_bb) x_b : LOWER inv(L_bb)(r,c) = D(c,r) ; UPPER inv(U_bb)(r,c) = D(r,c) ; D(i,j) at D[j*32+i]
-        for (int idx = tid; idx < nb * nrhs; idx += 256) {
-            const int r = idx % nb, q = idx / nb;
-            const double *xb = xs + o + q * ns;
-            // fixed trip count + predication: the 32 loads of D are issued together instead of one L2 round trip each
-            double dv[DB];
+    for (int idx = tid; idx < ns * nrhs; idx += 256) {
+        const int i = idx % ns, q = idx / ns;
+        const double *xq = xs + q * ns;
+        double a = 0.0;
+        if (LOWER) { for (int j2 = 0; j2 <= i; ++j2) a += Ti[i + (size_t) j2 * ns] * xq[j2]; }
+        else { for (int j2 = i; j2 < ns; ++j2) a += Ti[i + (size_t) j2 * ns] * xq[j2]; }
+        x[fst + i + (int64_t) q * ldx] = a;
+    }
+}
+
+// ---- fused level kernels of the single-layer solve (1 x 1 process layers) -----------------------------------------------
+// Forward, ONE launch per level (dlsum_fmod_inv + the leaf/non-leaf local solves, pdgstrs_lsum.c:414, pdgstrs3d.c:1819-2179):
+// workgroup = (supernode k, 256-row strip of its L panel).  Every strip recomputes y_k = Linv x_k itself (ns^2 flops out of
+// L2 -- cheaper than a second dependent launch), strip 0 stores it to y, then lsum_i -= L_ik y_k for the strip's rows
+// (fp64 atomics into x: rows of later levels only).  x holds b + lsum and is consumed; y receives the forward solution.
+__global__ __launch_bounds__(256) void k_fwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
+                                                   double *__restrict__ x, double *__restrict__ y, int64_t ldx, int nrhs)
+{
+    extern __shared__ double sm[];  // xk[ns * nrhs] | yk[ns * nrhs]
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int strip = blockIdx.x - prefix[ni];
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_nsupr[k];
+    double *xk = sm, *yk = sm + (size_t) ns * nrhs;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < ns * nrhs; idx += 256) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    __syncthreads();
+    const double *Li = T.inv + T.sn_inv[k];
+    for (int idx = tid; idx < ns * nrhs; idx += 256) {
+        const int i = idx % ns, q = idx / ns;
+        const double *xq = xk + q * ns;
+        double a0 = 0.0, a1 = 0.0;
+        int j2 = 0;
+        for (; j2 + 1 <= i; j2 += 2) { a0 += Li[i + (size_t) j2 * ns] * xq[j2]; a1 += Li[i + (size_t) (j2 + 1) * ns] * xq[j2 + 1]; }
+        if (j2 <= i) a0 += Li[i + (size_t) j2 * ns] * xq[j2];
+        yk[idx] = a0 + a1;
+    }
+    __syncthreads();
+    if (strip == 0) for (int idx = tid; idx < ns * nrhs; idx += 256) y[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = yk[idx];
+    const int row = T.sn_ldiag[k] + strip * 256 + tid;
+    if (row >= lda) return;
+    const double *L = T.val + T.sn_lval[k] + row;
+    const int *lsub = T.lidx + T.sn_lidx[k];
+    int p = BC_HEADER, base = 0, grow = -1;
+    const int nb = lsub[0];
+    for (int b = 0; b < nb; ++b) {
+        const int nbrow = lsub[p + 1];
+        if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
+        base += nbrow; p += LB_DESCRIPTOR + nbrow;
+    }
+    for (int r = 0; r < nrhs; ++r) {
+        const double *yq = yk + r * ns;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int kk = 0;
+        for (; kk + 8 <= ns; kk += 8) {
+            double lv[8];
 #pragma unroll
-            for (int c = 0; c < DB; ++c) dv[c] = (LOWER ? (c <= r) : (c >= r && c < nb)) ? (LOWER ? D[r * DB + c] : D[c * DB + r]) : 0.0;
-            double a = 0.0;
+            for (int u = 0; u < 8; ++u) lv[u] = L[(size_t) (kk + u) * lda];     // 8 independent loads in flight per thread
 #pragma unroll
-            for (int c = 0; c < DB; ++c) a += dv[c] * ((c < nb) ? xb[c] : 0.0);
-            ys[r + q * DB] = a;
+            for (int u = 0; u < 8; ++u) acc[u] += lv[u] * yq[kk + u];
         }
-        __syncthreads();
-        // x_b = y ; remaining rows -= T(rows, b) y
-        const int r0 = LOWER ? o + nb : 0, r1 = LOWER ? ns : o;
-        for (int idx = tid; idx < (r1 - r0 + nb) * nrhs; idx += 256) {
-            const int rr = idx % (r1 - r0 + nb), q = idx / (r1 - r0 + nb);
-            if (rr < nb) { xs[o + rr + q * ns] = ys[rr + q * DB]; continue; }
-            const int i = r0 + (rr - nb);
-            double av[DB];
-#pragma unroll
-            for (int c = 0; c < DB; ++c) av[c] = (c < nb) ? A[i + (size_t) (o + c) * lda] : 0.0;
-            double a = 0.0;
-#pragma unroll
-            for (int c = 0; c < DB; ++c) a += av[c] * ys[c + q * DB];
-            xs[i + q * ns] -= a;
+        for (; kk < ns; ++kk) acc[0] += L[(size_t) kk * lda] * yq[kk];
+        const double a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        atomic_sub_f64(x + grow + (int64_t) r * ldx, a);
+    }
+}
+
+// Backward, ONE launch per level (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode k, chunk of 256 non-empty U
+// columns).  s = U(k, chunk) x_cols (lanes along the rows of k: coalesced over the skyline segments; the 4 waves split the
+// columns), v = (chunk 0 ? y_k : 0) - s, x_k += Uinv v (linearity: every chunk applies Uinv to its own partial sum, so no
+// second launch and no inter-workgroup reduction).  x starts at zero and receives the solution.
+constexpr int BWC = 256;
+__global__ __launch_bounds__(256) void k_bwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
+                                                   double *__restrict__ x, const double *__restrict__ y, int64_t ldx, int nrhs)
+{
+    __shared__ int s_cp[BWC], s_ld[BWC], s_gc[BWC];
+    __shared__ double s_red[4][64];
+    __shared__ double s_v[256];
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int chunk = blockIdx.x - prefix[ni];
+    const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
+    const int ncol = max(0, min(BWC, T.sn_ncolu[k] - chunk * BWC));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < ncol) {
+        const int c = chunk * BWC + tid;
+        const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+        int lo = 0, hi = nub;
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
+        const int b = ub0 + lo;
+        const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+        const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
+        s_ld[tid] = ns - (klst - T.uidx[u0 + jj]);
+        s_cp[tid] = T.ucolptr[u0 + jj];
+        s_gc[tid] = T.xsup[T.ub_gid[b]] + jj;
+    }
+    __syncthreads();
+    const double *Uv = T.val + T.sn_uval[k];
+    const double *Ui = T.inv + T.sn_inv[k] + (size_t) ns * ns;
+    for (int r = 0; r < nrhs; ++r) {
+        const double *xr = x + (int64_t) r * ldx;
+        for (int rb = 0; rb < ns; rb += 64) {
+            const int i = rb + lane;
+            double a0 = 0.0, a1 = 0.0;
+            int c = wave;
+            for (; c + 4 < ncol; c += 8) {
+                const int l0 = s_ld[c], l1 = s_ld[c + 4];
+                const double u0 = (i < ns && i >= l0) ? Uv[s_cp[c] + (i - l0)] : 0.0;
+                const double u1 = (i < ns && i >= l1) ? Uv[s_cp[c + 4] + (i - l1)] : 0.0;
+                a0 += u0 * xr[s_gc[c]]; a1 += u1 * xr[s_gc[c + 4]];
+            }
+            if (c < ncol) { const int l0 = s_ld[c]; if (i < ns && i >= l0) a0 += Uv[s_cp[c] + (i - l0)] * xr[s_gc[c]]; }
+            s_red[wave][lane] = a0 + a1;
+            __syncthreads();
+            if (wave == 0 && i < ns) {
+                const double s = (s_red[0][lane] + s_red[1][lane]) + (s_red[2][lane] + s_red[3][lane]);
+                s_v[i] = (chunk == 0 ? y[fst + i + (int64_t) r * ldx] : 0.0) - s;
+            }
+            __syncthreads();
+        }
+        if (tid < ns) {
+            const int i = tid;
+            double a0 = 0.0, a1 = 0.0;
+            int j2 = i;
+            for (; j2 + 1 < ns; j2 += 2) { a0 += Ui[i + (size_t) j2 * ns] * s_v[j2]; a1 += Ui[i + (size_t) (j2 + 1) * ns] * s_v[j2 + 1]; }
+            if (j2 < ns) a0 += Ui[i + (size_t) j2 * ns] * s_v[j2];
+            unsafeAtomicAdd(x + fst + i + (int64_t) r * ldx, a0 + a1);
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < ns * nrhs; idx += 256) x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = xs[idx];
 }
 
 // lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414):
@@ -985,6 +1141,7 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     return 0;
 }
 
@@ -1020,10 +1177,27 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
     else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
 }
 
+void full_inv(hipStream_t s, const DevTables &T, const int *nodes, int nn)
+{
+    if (nn > 0) hipLaunchKernelGGL(k_full_inv, dim3(2 * nn), dim3(256), 0, s, T, nodes, nn);
+}
+
+void fwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx,
+               int nrhs, int mx)
+{
+    if (nwork > 0) hipLaunchKernelGGL(k_fwd_fused, dim3(nwork), dim3(256), (size_t) 2 * mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, y, ldx, nrhs);
+}
+
+void bwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, const double *y,
+               int64_t ldx, int nrhs)
+{
+    if (nwork > 0) hipLaunchKernelGGL(k_bwd_fused, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, y, ldx, nrhs);
+}
+
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int mx)
 {
     if (nn <= 0) return;
-    const size_t lds = (size_t) (mx + 32) * nrhs * sizeof(double);
+    const size_t lds = (size_t) mx * nrhs * sizeof(double);
     if (lower) hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
     else hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
 }

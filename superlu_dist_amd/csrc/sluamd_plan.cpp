@@ -31,7 +31,7 @@ static int build_tables(Handle &H, HostTables &t)
     const HostStruct &hs = H.hs;
     const Grid &g = H.grid;
     const int ns = hs.nsupers;
-    t.sn_lval.resize(ns); t.sn_uval.resize(ns); t.sn_lidx.resize(ns); t.sn_uidx.resize(ns); t.sn_dinv.assign(ns, 0); t.sn_dptr.assign(ns, 0);
+    t.sn_lval.resize(ns); t.sn_uval.resize(ns); t.sn_lidx.resize(ns); t.sn_uidx.resize(ns); t.sn_dinv.assign(ns, 0); t.sn_dptr.assign(ns, 0); t.sn_inv.assign(ns, 0);
     t.sn_nsupr.assign(ns, 0); t.sn_flags.assign(ns, 0); t.sn_ldiag.assign(ns, 0); t.sn_dlda.assign(ns, 1); t.sn_ldu.assign(ns, 0); t.sn_ncolu.assign(ns, 0);
     t.sn_lb_off.resize(ns); t.sn_nlb.assign(ns, 0); t.sn_ub_off.resize(ns); t.sn_nub.assign(ns, 0);
     t.sn_rt_off.resize(ns); t.sn_nrt.assign(ns, 0); t.sn_ct_off.resize(ns); t.sn_nct.assign(ns, 0);
@@ -47,7 +47,7 @@ static int build_tables(Handle &H, HostTables &t)
         t.sn_lidx[k] = hs.lidx_off[k]; t.sn_uidx[k] = hs.uidx_off[k];
         t.sn_lb_off[k] = (int) t.lb_gid.size(); t.sn_ub_off[k] = (int) t.ub_gid.size();
         t.sn_rt_off[k] = (int) t.rtile.size(); t.sn_ct_off[k] = (int) t.ctile.size();
-        t.sn_dinv[k] = t.dinv_total;
+        t.sn_dinv[k] = t.dinv_total; t.sn_inv[k] = t.inv_total;
         if (!hs.present[k]) continue;
         H.max_nsupc = std::max(H.max_nsupc, nsupc);
         if (nsupc > 256) { set_error("supernodes wider than 256 columns are not supported yet (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
@@ -59,6 +59,7 @@ static int build_tables(Handle &H, HostTables &t)
         if (l_own || u_own) fl |= SNF_HAS_DIAG;
         t.sn_flags[k] = fl;
         if (fl & SNF_HAS_DIAG) t.dinv_total += (int64_t) 2 * ((nsupc + 31) / 32) * 32 * 32;
+        if (fl & SNF_OWN_DIAG) t.inv_total += (int64_t) 2 * nsupc * nsupc;
         const int *li = hs.lidx.data() + hs.lidx_off[k];      // always >= BC_HEADER ints (empty slots carry {0, 0})
         const int nb = li[0], nsupr = li[1];
         t.sn_nsupr[k] = nsupr;
@@ -251,6 +252,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     S.tile_prefix.assign(S.lvl_soff[S.nlevels], 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0); S.zltr_prefix.assign(psz, 0);
     S.dg_prefix.assign(psz, 0); S.dg_off.assign(psz, 0);
+    S.ffwd_prefix.assign(psz, 0); S.fbwd_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l)
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i)
@@ -274,6 +276,8 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.zltr_prefix[po + 1] = S.zltr_prefix[po] + (lrows + 63) / 64;
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
+            S.ffwd_prefix[po + 1] = S.ffwd_prefix[po] + std::max(1, (lrows + 255) / 256);
+            S.fbwd_prefix[po + 1] = S.fbwd_prefix[po] + std::max(1, (ucols + 255) / 256);
         }
     }
     build_urgent_lists(t, lvl, S);
@@ -327,6 +331,8 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.sn_level, &S.d_sn_level)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_prefix, &S.d_dg_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.ffwd_prefix, &S.d_ffwd_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.fbwd_prefix, &S.d_fbwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_off, &S.d_dg_off)) return SLUAMD_EHIP;
     return 0;
 }
@@ -565,7 +571,16 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     const size_t esz = H->z ? 16 : 8;
     if (hipMalloc((void **) &H->d_val, esz * (size_t) std::max<int64_t>(H->arena_len, 1)) != hipSuccess) { set_error("hipMalloc of the value arena failed"); return SLUAMD_ENOMEM; }
     HIPCHK(hipMemset(H->d_val, 0, esz * (size_t) H->arena_len));
-    HIPCHK(hipStreamCreate(&H->stream));
+    if (H->env.reserve_cus > 0) {
+        // keep `reserve_cus` compute units out of the main (Schur tile) stream: the panel kernels of the look-ahead stream then
+        // always find a free CU (LDS for a whole TRSM strip / diagonal block) instead of waiting for a Schur workgroup to retire
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, H->device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0);
+        for (int i = 0; i < ncu; ++i) if (i >= H->env.reserve_cus) mask[i >> 5] |= 1u << (i & 31);
+        HIPCHK(hipExtStreamCreateWithCUMask(&H->stream, (uint32_t) mask.size(), mask.data()));
+    } else HIPCHK(hipStreamCreate(&H->stream));
     {
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -580,12 +595,17 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     T.lidx = H->d_lidx; T.uidx = H->d_uidx; T.ucolptr = H->d_ucolptr; T.unzcol = H->d_unzcol; T.xsup = H->d_xsup;
 #define UP(field, vec, type) { type *p_; if (upload(K, vec, &p_)) return SLUAMD_EHIP; T.field = p_; }
     UP(sn_lval, t.sn_lval, int64_t) UP(sn_uval, t.sn_uval, int64_t) UP(sn_lidx, t.sn_lidx, int64_t) UP(sn_uidx, t.sn_uidx, int64_t)
-    UP(sn_dinv, t.sn_dinv, int64_t) UP(sn_dptr, t.sn_dptr, int64_t)
+    UP(sn_dinv, t.sn_dinv, int64_t) UP(sn_dptr, t.sn_dptr, int64_t) UP(sn_inv, t.sn_inv, int64_t)
     H->h_sn_dinv = t.sn_dinv;
     {
         double *dv;
         if (hipMalloc((void **) &dv, esz * (size_t) std::max<int64_t>(t.dinv_total, 1)) != hipSuccess) { set_error("hipMalloc(dinv) failed"); return SLUAMD_ENOMEM; }
         K.push_back(dv); T.dinv = dv;
+    }
+    if (!H->z) {   // Linv / Uinv of the owned diagonal blocks (solve); complex handles use their own first-correct solves
+        double *iv;
+        if (hipMalloc((void **) &iv, sizeof(double) * (size_t) std::max<int64_t>(t.inv_total, 1)) != hipSuccess) { set_error("hipMalloc(inv) failed"); return SLUAMD_ENOMEM; }
+        K.push_back(iv); T.inv = iv;
     }
     UP(sn_nsupr, t.sn_nsupr, int) UP(sn_flags, t.sn_flags, int) UP(sn_ldiag, t.sn_ldiag, int) UP(sn_dlda, t.sn_dlda, int)
     UP(sn_ldu, t.sn_ldu, int) UP(sn_ncolu, t.sn_ncolu, int)
@@ -609,7 +629,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     if (rc) return rc;
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     const size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
-    H->st.bytes_device = (int64_t) ((size_t) H->arena_len * esz + idxb);
+    H->st.bytes_device = (int64_t) ((size_t) H->arena_len * esz + idxb + (size_t) (t.dinv_total + t.inv_total) * 8);
     return 0;
 }
 

@@ -17,8 +17,8 @@ struct SlotInput {
 };
 
 struct HostTables {
-    std::vector<int64_t> sn_lval, sn_uval, sn_lidx, sn_uidx, sn_dinv, sn_dptr;
-    int64_t dinv_total = 0;
+    std::vector<int64_t> sn_lval, sn_uval, sn_lidx, sn_uidx, sn_dinv, sn_dptr, sn_inv;
+    int64_t dinv_total = 0, inv_total = 0;
     std::vector<int> sn_nsupr, sn_flags, sn_ldiag, sn_dlda, sn_ldu, sn_ncolu, sn_lb_off, sn_nlb, sn_ub_off, sn_nub, sn_rt_off, sn_nrt, sn_ct_off, sn_nct;
     std::vector<int> lb_gid, lb_nbrow, lb_rowoff, lb_lptr, lbs_gid, lbs_idx;
     std::vector<int> ub_gid, ub_ncols, ub_iukp, ub_stcol;
@@ -53,5 +53,6 @@ int run_factor(Handle *H, double thresh, int *info);
 int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs);
 int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs);   // single-rank sweep over every schedule (refinement)
 int ensure_dinv(Handle *H);
+int ensure_inv(Handle *H);
 
 }  // namespace sluamd
