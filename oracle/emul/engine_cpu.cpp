@@ -241,7 +241,7 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
     }
 }
 
-void full_inv(hipStream_t, const DevTables &T, const int *nodes, int nn)
+void full_inv(hipStream_t, const DevTables &T, const int *nodes, const int *, int nn, int, int)
 {
     for (int i0 = 0; i0 < nn; ++i0) {
         const int k = nodes[i0];

@@ -318,7 +318,7 @@ int ensure_inv(Handle *H)
     if (rc) return rc;
     for (size_t zl = 0; zl < H->sched.size(); ++zl) {
         LevelSched &S = H->sched[zl];
-        if (!S.nodes.empty()) eng::full_inv(H->stream, H->T, S.d_nodes, (int) S.nodes.size());
+        if (!S.nodes.empty()) eng::full_inv(H->stream, H->T, S.d_nodes, S.d_finv_prefix, (int) S.nodes.size(), S.finv_prefix.back(), H->max_nsupc);
     }
     H->inv_ready = true;
     return 0;

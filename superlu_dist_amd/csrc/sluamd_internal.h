@@ -155,6 +155,7 @@ struct LevelSched {
     std::vector<int> lvl_soff;      // [nlevels+1] offset of each level's Schur prefix arrays (big group | small group)
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
+    std::vector<int> finv_prefix;   // flat over `nodes` (+1): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> ffwd_prefix, fbwd_prefix;  // fused single-layer solve: 256-row L strips / 256-column U chunks, at least one per supernode
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
@@ -173,7 +174,7 @@ struct LevelSched {
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
     int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
-    int *d_ffwd_prefix = nullptr, *d_fbwd_prefix = nullptr;
+    int *d_ffwd_prefix = nullptr, *d_fbwd_prefix = nullptr, *d_finv_prefix = nullptr;
     int4 *d_ulist = nullptr;
     int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
 };
@@ -248,7 +249,7 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
            const int4 *ulist, const int *sn_level, int skip_level);
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
-void full_inv(hipStream_t s, const DevTables &T, const int *nodes, int nn);
+void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 // fused level kernels of the single-layer solve: forward (x consumed, y = forward solution), backward (x zeroed before, receives the solution)
 void fwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx,
                int nrhs, int max_nsupc);

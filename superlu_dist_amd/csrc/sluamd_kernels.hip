@@ -278,6 +278,8 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
 // ---- panel TRSMs: blocked by 32 with inverted diagonal sub-blocks, GEMM parts on fp64 MFMA ---------------
 // MODE 0  L(:,k) <- L(:,k) U_kk^-1        (dLPanelTrSolve, dtrfCommWrapper.c:120-223: TRSM R,U,N,N)
 //         strip = 32 panel rows; T = U_kk.
+// MODE 3  Uinv = I U_kk^-1 and MODE 2  Linv^T = I (L_kk^T)^-1: the SAME solves on strips of the identity give the full
+//         inverses of the diagonal block (pdCompute_Diag_Inv, pdgstrs.c:842: dtrtri), stored at T.inv for the solve.
 // MODE 1  U(k,:) <- L_kk^-1 U(k,:)        (dTrs2_GatherTrsmScatter, pdgstrf2.c:804-840: gather, TRSM L,L,N,U,
 //         scatter) solved as X^T L_kk^T = B^T on the skyline in place: strip = 32 non-empty U columns
 //         (implicit zero padding above each segment), T = L_kk^T (unit upper).
@@ -310,7 +312,8 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     double *A = T.val + T.sn_lval[k];
     const double *Dg = T.val + T.sn_dptr[k];
     double *Uv = T.val + T.sn_uval[k];
-    const double *dinv = T.dinv + T.sn_dinv[k] + (MODE == 0 ? 0 : (size_t) nblk * DB * DB);
+    constexpr bool TU = (MODE == 0 || MODE == 3);     // T = U_kk (k-fastest chunks); otherwise T = L_kk^T (c-fastest chunks)
+    const double *dinv = T.dinv + T.sn_dinv[k] + (TU ? 0 : (size_t) nblk * DB * DB);
     double *Xs = sm;                          // [RSv/16][nsp][16]: element (r, c) at ((r>>4)*nsp + c)*16 + (r&15)
     double *Tb = sm + (size_t) RSv * nsp;     // [2 buffers] x one 32x32 operand block; the element (kk, cc) sits at cc*34 + kk when
                                               // the chunk was fetched k-fastest (U_kk blocks, inverse blocks) and at kk*48 + cc when it
@@ -338,7 +341,13 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
         __syncthreads();
     };
 
-    if (MODE == 0) {
+    if (MODE >= 2) {   // strip of the identity
+        const int row0 = strip * RSv;
+        for (int idx = tid; idx < RSv * nsp; idx += NT) {
+            const int r = idx % RSv, c = idx / RSv;
+            Xs[((r >> 4) * nsp + c) * 16 + (r & 15)] = (row0 + r == c && c < ns) ? 1.0 : 0.0;
+        }
+    } else if (MODE == 0) {
         const int row0 = T.sn_ldiag[k] + strip * RSv;
 #pragma unroll 8
         for (int idx = tid; idx < RSv * nsp; idx += NT) {
@@ -367,8 +376,8 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
 #pragma unroll
             for (int q = 0; q < PQ; ++q) {
                 // MODE 0: T(k,c) = U_kk(k,c) = A[k + c*lda], k fastest ; MODE 1: T(k,c) = L_kk(c,k) = A[c + k*lda], c fastest
-                const int kg = kc + (MODE == 0 ? e0 : e1 + ES * q), cg = jb + (MODE == 0 ? e1 + ES * q : e0);
-                pv[q] = (kg < ns && cg < ns) ? (MODE == 0 ? Dg[kg + (size_t) cg * ldd] : Dg[cg + (size_t) kg * ldd]) : 0.0;
+                const int kg = kc + (TU ? e0 : e1 + ES * q), cg = jb + (TU ? e1 + ES * q : e0);
+                pv[q] = (kg < ns && cg < ns) ? (TU ? Dg[kg + (size_t) cg * ldd] : Dg[cg + (size_t) kg * ldd]) : 0.0;
             }
         } else {
             const double *dblk = dinv + (size_t) (jb / DB) * DB * DB;
@@ -380,7 +389,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
         double *tb = Tb + buf * TB_SZ;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            if (t * DB < jb && MODE == 1) tb[(e1 + ES * q) * 48 + e0] = pv[q];   // (kk = e1 + ES q, cc = e0)
+            if (t * DB < jb && !TU) tb[(e1 + ES * q) * 48 + e0] = pv[q];   // (kk = e1 + ES q, cc = e0)
             else tb[(e1 + ES * q) * 34 + e0] = pv[q];                            // (kk = e0, cc = e1 + ES q)
         }
     };
@@ -390,7 +399,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
     const double *xa = Xs + ((size_t) wave * nsp + (lane >> 4)) * 16 + (lane & 15);
     auto compute = [&](int jb, int t, int buf) {
         // fragment element (kk = k4 + lane>>4, cc = half*16 + lane&15)
-        const bool cfast = (MODE == 1) && (t < jb / DB);
+        const bool cfast = !TU && (t < jb / DB);
         const int sk = cfast ? 48 : 1, sc = cfast ? 1 : 34;
         const double *tb0 = Tb + buf * TB_SZ + (lane >> 4) * sk + (lane & 15) * sc;
         const double *tb1 = tb0 + 16 * sc;
@@ -454,7 +463,15 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
         buf ^= 1;
     }
 
-    if (MODE == 0) {
+    if (MODE >= 2) {
+        double *out = T.inv + T.sn_inv[k] + (MODE == 3 ? (size_t) ns * ns : 0);
+        const int row0 = strip * RSv;
+        for (int idx = tid; idx < RSv * ns; idx += NT) {
+            const int r = idx % RSv, c = idx / RSv;
+            // MODE 3: Uinv(row, c) at [row + c ns]; MODE 2: X' = (L^T)^-1 = Linv^T -> Linv(c, row) at [c + row ns]
+            if (row0 + r < ns) out[MODE == 3 ? (row0 + r) + (size_t) c * ns : c + (size_t) (row0 + r) * ns] = Xs[((r >> 4) * nsp + c) * 16 + (r & 15)];
+        }
+    } else if (MODE == 0) {
         const int row0 = T.sn_ldiag[k] + strip * RSv;
 #pragma unroll 8
         for (int idx = tid; idx < RSv * ns; idx += NT) {
@@ -486,6 +503,19 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
         const int ni = find_node(uprefix, nn, id);
         panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm);
     }
+}
+
+// Linv / Uinv of the owned diagonal blocks of a node list: work unit = (supernode, typ, 64-row strip of the identity)
+__global__ __launch_bounds__(256) void k_full_inv(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn)
+{
+    extern __shared__ double sm[];
+    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int k = nodes[ni];
+    const int ns = T.xsup[k + 1] - T.xsup[k];
+    const int per = (ns + 63) / 64;
+    const int u = blockIdx.x - prefix[ni];
+    if (u < per) panel_trsm_body<2, 64>(T, k, u, sm);
+    else panel_trsm_body<3, 64>(T, k, u - per, sm);
 }
 
 // ---- iterative refinement (pdgsrfs3d, SRC/double/pdgsrfs.c:345-510) --------------------------------
@@ -778,63 +808,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         }
 }
 
-// ---- full inverses of the diagonal blocks (pdCompute_Diag_Inv, SRC/double/pdgstrs.c:842: Linv / Uinv via dtrtri) -----
-// One workgroup per (supernode, typ): typ 0 -> Uinv = inv(U_kk) (upper), typ 1 -> Linv = inv(L_kk) (unit lower), both dense
-// ns x ns, column-major, ld = ns, at T.inv + T.sn_inv[k] (Linv first, then Uinv).  Blocked by 32 on top of the inverted
-// 32 x 32 diagonal sub-blocks the factorisation left in T.dinv: for the upper-triangular M (U_kk, or L_kk^T for typ 1)
-//     X_ii = inv(M_ii),   X_ij = -X_ii * sum_{k=i+1..j} M_ik X_kj   (j > i, block rows from the bottom up)
-// X is read back from the output array itself (written by this workgroup in earlier steps).
-__global__ __launch_bounds__(256) void k_full_inv(DevTables T, const int *__restrict__ nodes, int nn)
-{
-    __shared__ double Ss[DB * (DB + 1)];
-    const int k = nodes[blockIdx.x >> 1];
-    const int typ = blockIdx.x & 1;
-    if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;
-    const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB;
-    const int lda = T.sn_dlda[k];
-    const double *A = T.val + T.sn_dptr[k];
-    const double *dinv = T.dinv + T.sn_dinv[k] + (size_t) typ * nblk * DB * DB;
-    double *out = T.inv + T.sn_inv[k] + (typ == 0 ? (size_t) ns * ns : 0);
-    const int tid = threadIdx.x;
-    // M(r, c): typ 0 = U(r, c) = A[r + c lda]; typ 1 = L^T(r, c) = L(c, r) = A[c + r lda].  X(r, c) stored at out[r + c ns]
-    // (typ 0) or transposed at out[c + r ns] (typ 1: Linv = X^T)
-    auto M = [&](int r, int c) -> double { return (r < ns && c < ns) ? (typ == 0 ? A[r + (size_t) c * lda] : A[c + (size_t) r * lda]) : 0.0; };
-    auto Xat = [&](int r, int c) -> double * { return typ == 0 ? out + r + (size_t) c * ns : out + c + (size_t) r * ns; };
-    // zero the strictly "other" triangle once
-    for (int e = tid; e < ns * ns; e += 256) { const int r = e % ns, c = e / ns; if (r > c) *Xat(r, c) = 0.0; }
-    for (int i = nblk - 1; i >= 0; --i) {
-        const double *D = dinv + (size_t) i * DB * DB;   // inv(M_ii)(kk, cc) at D[cc * 32 + kk]
-        for (int e = tid; e < DB * DB; e += 256) {
-            const int kk = e & 31, cc = e >> 5;
-            if (i * DB + kk < ns && i * DB + cc < ns) *Xat(i * DB + kk, i * DB + cc) = D[cc * DB + kk];
-        }
-        for (int j = i + 1; j < nblk; ++j) {
-            // S = sum_{k=i+1..j} M_ik X_kj  (rows k > i of X are complete)
-            for (int e = tid; e < DB * DB; e += 256) {
-                const int r = e & 31, c = e >> 5;
-                double a = 0.0;
-                if (j * DB + c < ns)
-                    for (int q = (i + 1) * DB; q < min((j + 1) * DB, ns); ++q) a += M(i * DB + r, q) * *Xat(q, j * DB + c);
-                Ss[r * (DB + 1) + c] = a;
-            }
-            __syncthreads();
-            for (int e = tid; e < DB * DB; e += 256) {
-                const int r = e & 31, c = e >> 5;
-                if (i * DB + r < ns && j * DB + c < ns) {
-                    double a = 0.0;
-#pragma unroll 8
-                    for (int q = 0; q < DB; ++q) a += D[q * DB + r] * Ss[q * (DB + 1) + c];
-                    *Xat(i * DB + r, j * DB + c) = -a;
-                }
-            }
-            __syncthreads();
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    (void) nn;
-}
-
 // ---- triangular solves --------------------------------------------------------------------------
 // x_k <- Linv x_k (unit lower) or Uinv x_k: one workgroup per supernode of the level, ONE dense triangular GEMV with the full
 // inverse (what the reference's DiagInv=YES solve does with Linv / Uinv, pdgstrs_lsum.c:414-520) -- no dependent chain
@@ -880,14 +853,28 @@ __global__ __launch_bounds__(256) void k_fwd_fused(DevTables T, const int *__res
     for (int idx = tid; idx < ns * nrhs; idx += 256) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
     const double *Li = T.inv + T.sn_inv[k];
-    for (int idx = tid; idx < ns * nrhs; idx += 256) {
-        const int i = idx % ns, q = idx / ns;
-        const double *xq = xk + q * ns;
-        double a0 = 0.0, a1 = 0.0;
-        int j2 = 0;
-        for (; j2 + 1 <= i; j2 += 2) { a0 += Li[i + (size_t) j2 * ns] * xq[j2]; a1 += Li[i + (size_t) (j2 + 1) * ns] * xq[j2 + 1]; }
-        if (j2 <= i) a0 += Li[i + (size_t) j2 * ns] * xq[j2];
-        yk[idx] = a0 + a1;
+    // y_k = Linv x_k: thread = row, the column loop runs to the wave's last row (uniform bound; Linv stores explicit zeros
+    // above the diagonal) and is unrolled by 16 so that 16 L2 loads are in flight per thread
+    for (int i0 = 0; i0 < ns; i0 += 256) {
+        const int i = i0 + tid;
+        const int jend = min(ns, ((i0 + (tid | 63)) + 1));
+        for (int q = 0; q < nrhs; ++q) {
+            const double *xq = xk + q * ns;
+            double acc[4] = {0, 0, 0, 0};
+            if (i < ns) {
+                const double *Lr = Li + i;
+                int j2 = 0;
+                for (; j2 + 16 <= jend; j2 += 16) {
+                    double lv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) lv[u] = Lr[(size_t) (j2 + u) * ns];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * xq[j2 + u];
+                }
+                for (; j2 < jend; ++j2) acc[0] += Lr[(size_t) j2 * ns] * xq[j2];
+                yk[i + q * ns] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            }
+        }
     }
     __syncthreads();
     if (strip == 0) for (int idx = tid; idx < ns * nrhs; idx += 256) y[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = yk[idx];
@@ -904,18 +891,17 @@ __global__ __launch_bounds__(256) void k_fwd_fused(DevTables T, const int *__res
     }
     for (int r = 0; r < nrhs; ++r) {
         const double *yq = yk + r * ns;
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double acc[4] = {0, 0, 0, 0};
         int kk = 0;
-        for (; kk + 8 <= ns; kk += 8) {
-            double lv[8];
+        for (; kk + 16 <= ns; kk += 16) {
+            double lv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) lv[u] = L[(size_t) (kk + u) * lda];     // 8 independent loads in flight per thread
+            for (int u = 0; u < 16; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);   // streamed once: 16 loads in flight
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += lv[u] * yq[kk + u];
+            for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * yq[kk + u];
         }
         for (; kk < ns; ++kk) acc[0] += L[(size_t) kk * lda] * yq[kk];
-        const double a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-        atomic_sub_f64(x + grow + (int64_t) r * ldx, a);
+        atomic_sub_f64(x + grow + (int64_t) r * ldx, (acc[0] + acc[1]) + (acc[2] + acc[3]));
     }
 }
 
@@ -928,7 +914,8 @@ __global__ __launch_bounds__(256) void k_bwd_fused(DevTables T, const int *__res
                                                    double *__restrict__ x, const double *__restrict__ y, int64_t ldx, int nrhs)
 {
     __shared__ int s_cp[BWC], s_ld[BWC], s_gc[BWC];
-    __shared__ double s_red[4][64];
+    __shared__ double s_xc[BWC];
+    __shared__ double s_red[4][256];
     __shared__ double s_v[256];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
@@ -952,33 +939,45 @@ __global__ __launch_bounds__(256) void k_bwd_fused(DevTables T, const int *__res
     const double *Uv = T.val + T.sn_uval[k];
     const double *Ui = T.inv + T.sn_inv[k] + (size_t) ns * ns;
     for (int r = 0; r < nrhs; ++r) {
-        const double *xr = x + (int64_t) r * ldx;
-        for (int rb = 0; rb < ns; rb += 64) {
-            const int i = rb + lane;
-            double a0 = 0.0, a1 = 0.0;
-            int c = wave;
-            for (; c + 4 < ncol; c += 8) {
-                const int l0 = s_ld[c], l1 = s_ld[c + 4];
-                const double u0 = (i < ns && i >= l0) ? Uv[s_cp[c] + (i - l0)] : 0.0;
-                const double u1 = (i < ns && i >= l1) ? Uv[s_cp[c + 4] + (i - l1)] : 0.0;
-                a0 += u0 * xr[s_gc[c]]; a1 += u1 * xr[s_gc[c + 4]];
+        if (tid < ncol) s_xc[tid] = x[s_gc[tid] + (int64_t) r * ldx];      // solved x of this chunk's columns: one gather
+        __syncthreads();
+        // s = U(k, chunk) x_cols: wave w takes the chunk's columns [64 w, 64 w + 64); lane l accumulates the rows l, l + 64,
+        // l + 128, l + 192 of supernode k (four independent coalesced loads per column)
+        double a[4] = {0, 0, 0, 0};
+        const int c0 = wave * 64, c1 = min(ncol, c0 + 64);
+        for (int c = c0; c < c1; ++c) {
+            const int ld = s_ld[c];
+            const double *col = Uv + s_cp[c] - ld;
+            const double xv = s_xc[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                if (i >= ld && i < ns) a[q] += __builtin_nontemporal_load(col + i) * xv;
             }
-            if (c < ncol) { const int l0 = s_ld[c]; if (i < ns && i >= l0) a0 += Uv[s_cp[c] + (i - l0)] * xr[s_gc[c]]; }
-            s_red[wave][lane] = a0 + a1;
-            __syncthreads();
-            if (wave == 0 && i < ns) {
-                const double s = (s_red[0][lane] + s_red[1][lane]) + (s_red[2][lane] + s_red[3][lane]);
-                s_v[i] = (chunk == 0 ? y[fst + i + (int64_t) r * ldx] : 0.0) - s;
-            }
-            __syncthreads();
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_red[wave][lane + 64 * q] = a[q];
+        __syncthreads();
+        if (tid < ns) {
+            const double sv = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+            s_v[tid] = (chunk == 0 ? y[fst + tid + (int64_t) r * ldx] : 0.0) - sv;
+        }
+        __syncthreads();
+        // x_k += Uinv v: thread = row i, columns from the wave's first row (uniform bound; explicit zeros below the diagonal)
         if (tid < ns) {
             const int i = tid;
-            double a0 = 0.0, a1 = 0.0;
-            int j2 = i;
-            for (; j2 + 1 < ns; j2 += 2) { a0 += Ui[i + (size_t) j2 * ns] * s_v[j2]; a1 += Ui[i + (size_t) (j2 + 1) * ns] * s_v[j2 + 1]; }
-            if (j2 < ns) a0 += Ui[i + (size_t) j2 * ns] * s_v[j2];
-            unsafeAtomicAdd(x + fst + i + (int64_t) r * ldx, a0 + a1);
+            const double *Ur = Ui + i;
+            double acc[4] = {0, 0, 0, 0};
+            int j2 = (tid & ~63);
+            for (; j2 + 16 <= ns; j2 += 16) {
+                double uv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) uv[u] = Ur[(size_t) (j2 + u) * ns];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u & 3] += uv[u] * s_v[j2 + u];
+            }
+            for (; j2 < ns; ++j2) acc[0] += Ur[(size_t) j2 * ns] * s_v[j2];
+            unsafeAtomicAdd(x + fst + i + (int64_t) r * ldx, (acc[0] + acc[1]) + (acc[2] + acc[3]));
         }
         __syncthreads();
     }
@@ -1137,6 +1136,7 @@ int setup()
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_full_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
@@ -1177,9 +1177,9 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
     else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
 }
 
-void full_inv(hipStream_t s, const DevTables &T, const int *nodes, int nn)
+void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int mx)
 {
-    if (nn > 0) hipLaunchKernelGGL(k_full_inv, dim3(2 * nn), dim3(256), 0, s, T, nodes, nn);
+    if (nwork > 0) hipLaunchKernelGGL(k_full_inv, dim3(nwork), dim3(256), trsm_lds_bytes(64, (mx + 31) & ~31), s, T, nodes, prefix, nn);
 }
 
 void fwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx,

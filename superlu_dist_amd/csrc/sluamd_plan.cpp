@@ -280,6 +280,11 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.fbwd_prefix[po + 1] = S.fbwd_prefix[po] + std::max(1, (ucols + 255) / 256);
         }
     }
+    S.finv_prefix.assign(S.nodes.size() + 1, 0);
+    for (size_t i = 0; i < S.nodes.size(); ++i) {
+        const int k = S.nodes[i];
+        S.finv_prefix[i + 1] = S.finv_prefix[i] + ((t.sn_flags[k] & SNF_OWN_DIAG) ? 2 * ((nsupc_of(hs, k) + 63) / 64) : 0);
+    }
     build_urgent_lists(t, lvl, S);
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
     // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
@@ -332,6 +337,7 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_prefix, &S.d_dg_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.ffwd_prefix, &S.d_ffwd_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.finv_prefix, &S.d_finv_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.fbwd_prefix, &S.d_fbwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_off, &S.d_dg_off)) return SLUAMD_EHIP;
     return 0;
