@@ -146,6 +146,46 @@ void panel_trsm(hipStream_t, const DevTables &T, const int *nodes, const int *lp
     }
 }
 
+void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
+{
+    std::vector<double> x, o;
+    for (int w = 0; w < nl + nu; ++w) {
+        const bool lmode = w < nl;
+        const int id = lmode ? w : w - nl;
+        const int ni = find_node(lmode ? lprefix : uprefix, nn, id);
+        const int k = nodes[ni];
+        const int strip = id - (lmode ? lprefix : uprefix)[ni];
+        const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
+        const int lda = T.sn_nsupr[k];
+        double *A = T.val + T.sn_lval[k];
+        double *Uv = T.val + T.sn_uval[k];
+        const double *Li = T.inv + T.sn_inv[k], *Ui = Li + (size_t) ns * ns;
+        x.assign(ns, 0.0); o.assign(ns, 0.0);
+        for (int r = 0; r < 64; ++r) {
+            if (lmode) {
+                const int row = T.sn_ldiag[k] + strip * 64 + r;
+                if (row >= lda) break;
+                for (int c = 0; c < ns; ++c) x[c] = A[row + (size_t) c * lda];
+                for (int n = 0; n < ns; ++n) { double a = 0; for (int kk = 0; kk <= n; ++kk) a += x[kk] * Ui[kk + (size_t) n * ns]; o[n] = a; }
+                for (int c = 0; c < ns; ++c) A[row + (size_t) c * lda] = o[c];
+            } else {
+                const int cr = strip * 64 + r;
+                if (cr >= T.sn_ncolu[k]) break;
+                const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+                int lo = 0, hi = nub;
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= cr) lo = mid; else hi = mid; }
+                const int b = ub0 + lo;
+                const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+                const int jj = T.unzcol[u0 + (cr - T.ub_stcol[b])];
+                const int ld = ns - (klst - T.uidx[u0 + jj]), cp = T.ucolptr[u0 + jj];
+                for (int c = 0; c < ns; ++c) x[c] = (c >= ld) ? Uv[cp + (c - ld)] : 0.0;
+                for (int n = 0; n < ns; ++n) { double a = 0; for (int kk = 0; kk <= n; ++kk) a += Li[n + (size_t) kk * ns] * x[kk]; o[n] = a; }
+                for (int c = ld; c < ns; ++c) Uv[cp + (c - ld)] = o[c];
+            }
+        }
+    }
+}
+
 void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
            const int4 *ulist, const int *sn_level, int skip_level)
 {

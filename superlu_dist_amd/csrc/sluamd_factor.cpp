@@ -54,6 +54,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const DevTables &T = H->T;
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     const bool lookahead = !H->profile && !H->opt.deterministic && !H->env.no_lookahead;
+    const bool gemm_panels = !xy && !H->env.trsm_panels;
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     int rc_x = 0;
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
@@ -75,10 +76,13 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         }
         eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
-        eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);   // dLPanelTrSolve + dUPanelTrSolve
+        if (gemm_panels) {   // 1 x 1 layer: full inverses (also what the solve uses) + chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
+            eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);
+            eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu);
+        } else eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);
         if (xy && !rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // dIBcastRecvLPanel / dIBcastRecvUPanel
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);
-        H->st.num_launches += 2 + (nl + nu > 0);
+        H->st.num_launches += 2 + (nl + nu > 0) + (gemm_panels ? 1 : 0);
     };
     if (lookahead && S.nlevels) {
         hipEvent_t e = next_event(H);    // the side stream must see everything queued so far on the main stream
@@ -274,7 +278,7 @@ int run_factor(Handle *H, double thresh, int *info)
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
-    H->dinv_ready = true; H->inv_ready = false;
+    H->dinv_ready = true; H->inv_ready = (g.Pr * g.Pc == 1) && !H->env.trsm_panels && !H->z;
     H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
     H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
     H->st.tiny_pivots = res[1];
@@ -316,10 +320,11 @@ int ensure_inv(Handle *H)
     if (H->inv_ready) return 0;
     int rc = ensure_dinv(H);
     if (rc) return rc;
-    for (size_t zl = 0; zl < H->sched.size(); ++zl) {
-        LevelSched &S = H->sched[zl];
-        if (!S.nodes.empty()) eng::full_inv(H->stream, H->T, S.d_nodes, S.d_finv_prefix, (int) S.nodes.size(), S.finv_prefix.back(), H->max_nsupc);
-    }
+    for (auto &S : H->sched)
+        for (int l = 0; l < S.nlevels; ++l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            eng::full_inv(H->stream, H->T, S.d_nodes + n0, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], S.max_nsupc[l]);
+        }
     H->inv_ready = true;
     return 0;
 }

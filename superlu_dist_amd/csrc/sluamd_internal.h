@@ -155,7 +155,7 @@ struct LevelSched {
     std::vector<int> lvl_soff;      // [nlevels+1] offset of each level's Schur prefix arrays (big group | small group)
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
-    std::vector<int> finv_prefix;   // flat over `nodes` (+1): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
+    std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> ffwd_prefix, fbwd_prefix;  // fused single-layer solve: 256-row L strips / 256-column U chunks, at least one per supernode
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
@@ -189,7 +189,7 @@ struct Handle {
     int Pz = 1, myz = 0;
     // environment switches, read ONCE at creation (they may differ per handle)
     struct Env {
-        bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false;
+        bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, trsm_panels = false;
         int fuse_min_pct = 75, fuse_max_prev = 1, lookahead_max_strips = 1 << 30, reserve_cus = 0;
     } env;
     // device arenas
@@ -245,6 +245,8 @@ void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *pr
 // L strips (work units [0, nl)) and U column strips ([nl, nl + nu)); strip height rs = 32 or 64
 void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu,
                 int rs, int max_nsupc);
+// the same two panel solves as GEMMs with the full inverses T.inv (1 x 1 layers; 64-high work units)
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
            const int4 *ulist, const int *sn_level, int skip_level);

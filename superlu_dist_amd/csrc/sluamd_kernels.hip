@@ -505,6 +505,107 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
     }
 }
 
+// ---- panel solves as GEMMs with the full inverse (1 x 1 layers) ------------------------------------------------------------
+// L(:,k) <- L(:,k) Uinv  and  U(k,:) <- Linv U(k,:)  (the same dLPanelTrSolve / dTrs2_GatherTrsmScatter results) without the
+// dependent chain of a blocked substitution: every 32-column block of the result is an independent product with the
+// triangular inverse.  One wave owns 16 panel rows (MODE 0) or 16 skyline columns (MODE 1) and keeps them in registers as
+// MFMA operand fragments for the whole solve (64 doubles per lane for ns = 256), so the update is in place without any
+// hazard, there is no LDS strip (many waves per SIMD instead of one workgroup per CU) and no barrier.  Operand roles as in
+// k_schur: D = Tinv^T-fragment x strip-fragment, so that the 16 fast lanes of every accumulator register run along panel rows
+// (128-byte runs of an L column / contiguous pieces of a skyline segment).
+template <int MODE>
+__device__ __forceinline__ void panel_gemm_wave(const DevTables &T, int k, int unit)
+{
+    const int lane = threadIdx.x & 63;
+    const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
+    const int nblk = (ns + DB - 1) / DB;
+    const int li = lane & 15, lk = lane >> 4;
+    double a[64];
+    // ---- load the wave's 16 rows: a[q] = X(row li, column 4 q + lk) ----
+    const int lda = T.sn_nsupr[k];
+    double *A = T.val + T.sn_lval[k];
+    double *Uv = T.val + T.sn_uval[k];
+    int row = 0, cp = 0, ld = ns;
+    bool valid;
+    if (MODE == 0) {
+        row = T.sn_ldiag[k] + unit * 16 + li;
+        valid = row < lda;
+    } else {
+        const int cr = unit * 16 + li;
+        valid = cr < T.sn_ncolu[k];
+        if (valid) {
+            const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
+            int lo = 0, hi = nub;
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= cr) lo = mid; else hi = mid; }
+            const int b = ub0 + lo;
+            const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
+            const int jj = T.unzcol[u0 + (cr - T.ub_stcol[b])];
+            ld = ns - (klst - T.uidx[u0 + jj]);
+            cp = T.ucolptr[u0 + jj];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+        const int c = 4 * q + lk;
+        double v = 0.0;
+        if (q < nblk * 8) {
+            if (MODE == 0) { if (valid && c < ns) v = A[row + (size_t) c * lda]; }
+            else { if (valid && c >= ld && c < ns) v = Uv[cp + (c - ld)]; }
+        }
+        a[q] = v;
+    }
+    // Tinv(kk, n): MODE 0 -> Uinv(kk, n) at Ui[kk + n ns]; MODE 1 -> (Linv^T)(kk, n) = Linv(n, kk) at Li[n + kk ns]
+    const double *Ti = T.inv + T.sn_inv[k] + (MODE == 0 ? (size_t) ns * ns : 0);
+    for (int jb = 0; jb < nblk; ++jb) {
+        d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+        const int n0 = jb * DB + li, n1 = n0 + 16;
+        const bool ok0 = n0 < ns, ok1 = n1 < ns;
+        const int nq = (jb + 1) * 8;     // K = columns [0, 32 (jb + 1)) of the strip (Tinv is upper triangular)
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {     // fully unrolled: a[] stays in registers (static indices)
+            if (q < nq) {
+                const int kk = 4 * q + lk;
+                double t0 = 0.0, t1 = 0.0;
+                if (kk < ns) {
+                    if (MODE == 0) { if (ok0) t0 = Ti[kk + (size_t) n0 * ns]; if (ok1) t1 = Ti[kk + (size_t) n1 * ns]; }
+                    else { if (ok0) t0 = Ti[n0 + (size_t) kk * ns]; if (ok1) t1 = Ti[n1 + (size_t) kk * ns]; }
+                }
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, a[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, a[q], acc1, 0, 0, 0);
+            }
+            if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 16 Tinv loads hoisted ahead of their MFMAs
+        }
+        // D[(lk + 4 r)][li] = X_new(row li, column jb*32 + 16 h + lk + 4 r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c0 = jb * DB + lk + 4 * r, c1 = c0 + 16;
+            if (MODE == 0) {
+                if (valid && c0 < ns) A[row + (size_t) c0 * lda] = acc0[r];
+                if (valid && c1 < ns) A[row + (size_t) c1 * lda] = acc1[r];
+            } else {
+                if (valid && c0 >= ld && c0 < ns) Uv[cp + (c0 - ld)] = acc0[r];
+                if (valid && c1 >= ld && c1 < ns) Uv[cp + (c1 - ld)] = acc1[r];
+            }
+        }
+    }
+}
+
+// L units (workgroups [0, nl)) and U units ([nl, nl + nu)) of one level in ONE launch; workgroup = 4 waves = 64 rows / columns
+// (the same 64-high work units as k_panel_trsm<64>)
+__global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__restrict__ nodes, const int *__restrict__ lprefix,
+                                                    const int *__restrict__ uprefix, int nn, int nl)
+{
+    const int wave = threadIdx.x >> 6;
+    if ((int) blockIdx.x < nl) {
+        const int ni = find_node(lprefix, nn, blockIdx.x);
+        panel_gemm_wave<0>(T, nodes[ni], (blockIdx.x - lprefix[ni]) * 4 + wave);
+    } else {
+        const int id = blockIdx.x - nl;
+        const int ni = find_node(uprefix, nn, id);
+        panel_gemm_wave<1>(T, nodes[ni], (id - uprefix[ni]) * 4 + wave);
+    }
+}
+
 // Linv / Uinv of the owned diagonal blocks of a node list: work unit = (supernode, typ, 64-row strip of the identity)
 __global__ __launch_bounds__(256) void k_full_inv(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn)
 {
@@ -945,7 +1046,27 @@ __global__ __launch_bounds__(256) void k_bwd_fused(DevTables T, const int *__res
         // l + 128, l + 192 of supernode k (four independent coalesced loads per column)
         double a[4] = {0, 0, 0, 0};
         const int c0 = wave * 64, c1 = min(ncol, c0 + 64);
-        for (int c = c0; c < c1; ++c) {
+        int c = c0;
+        for (; c + 4 <= c1; c += 4) {      // 4 columns x 4 row blocks = 16 independent coalesced loads in flight per lane
+            double uv[4][4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int ld = s_ld[c + cc];
+                const double *col = Uv + s_cp[c + cc] - ld;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = lane + 64 * q;
+                    uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const double xv = s_xc[c + cc];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] += uv[cc][q] * xv;
+            }
+        }
+        for (; c < c1; ++c) {
             const int ld = s_ld[c];
             const double *col = Uv + s_cp[c] - ld;
             const double xv = s_xc[c];
@@ -1175,6 +1296,11 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
     if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
     else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
     else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
+}
+
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
+{
+    if (nl + nu > 0) hipLaunchKernelGGL(k_panel_gemm, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int mx)

@@ -252,7 +252,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     S.tile_prefix.assign(S.lvl_soff[S.nlevels], 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0); S.zltr_prefix.assign(psz, 0);
     S.dg_prefix.assign(psz, 0); S.dg_off.assign(psz, 0);
-    S.ffwd_prefix.assign(psz, 0); S.fbwd_prefix.assign(psz, 0);
+    S.ffwd_prefix.assign(psz, 0); S.fbwd_prefix.assign(psz, 0); S.finv_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l)
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i)
@@ -277,13 +277,9 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
             S.ffwd_prefix[po + 1] = S.ffwd_prefix[po] + std::max(1, (lrows + 255) / 256);
+            S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 63) / 64) : 0);
             S.fbwd_prefix[po + 1] = S.fbwd_prefix[po] + std::max(1, (ucols + 255) / 256);
         }
-    }
-    S.finv_prefix.assign(S.nodes.size() + 1, 0);
-    for (size_t i = 0; i < S.nodes.size(); ++i) {
-        const int k = S.nodes[i];
-        S.finv_prefix[i + 1] = S.finv_prefix[i] + ((t.sn_flags[k] & SNF_OWN_DIAG) ? 2 * ((nsupc_of(hs, k) + 63) / 64) : 0);
     }
     build_urgent_lists(t, lvl, S);
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
