@@ -513,10 +513,13 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
 // hazard, there is no LDS strip (many waves per SIMD instead of one workgroup per CU) and no barrier.  Operand roles as in
 // k_schur: D = Tinv^T-fragment x strip-fragment, so that the 16 fast lanes of every accumulator register run along panel rows
 // (128-byte runs of an L column / contiguous pieces of a skyline segment).
+constexpr int PGK = 64;                        // K chunk of the inverse staged in LDS
+constexpr int PG_LDS = PGK * 48;               // doubles: [64][48] (c-fastest, MODE 1) or [32][66] (k-fastest, MODE 0)
 template <int MODE>
-__device__ __forceinline__ void panel_gemm_wave(const DevTables &T, int k, int unit)
+__device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int unit64, double *Ts)
 {
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int unit = unit64 * 4 + wave;
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int nblk = (ns + DB - 1) / DB;
     const int li = lane & 15, lk = lane >> 4;
@@ -554,26 +557,40 @@ __device__ __forceinline__ void panel_gemm_wave(const DevTables &T, int k, int u
         }
         a[q] = v;
     }
-    // Tinv(kk, n): MODE 0 -> Uinv(kk, n) at Ui[kk + n ns]; MODE 1 -> (Linv^T)(kk, n) = Linv(n, kk) at Li[n + kk ns]
+    // Tinv(kk, n): MODE 0 -> Uinv(kk, n) at Ui[kk + n ns] (kk fastest); MODE 1 -> (Linv^T)(kk, n) = Linv(n, kk) at Li[n + kk ns] (n fastest)
     const double *Ti = T.inv + T.sn_inv[k] + (MODE == 0 ? (size_t) ns * ns : 0);
     for (int jb = 0; jb < nblk; ++jb) {
         d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
-        const int n0 = jb * DB + li, n1 = n0 + 16;
-        const bool ok0 = n0 < ns, ok1 = n1 < ns;
-        const int nq = (jb + 1) * 8;     // K = columns [0, 32 (jb + 1)) of the strip (Tinv is upper triangular)
 #pragma unroll
-        for (int q = 0; q < 64; ++q) {     // fully unrolled: a[] stays in registers (static indices)
-            if (q < nq) {
-                const int kk = 4 * q + lk;
-                double t0 = 0.0, t1 = 0.0;
-                if (kk < ns) {
-                    if (MODE == 0) { if (ok0) t0 = Ti[kk + (size_t) n0 * ns]; if (ok1) t1 = Ti[kk + (size_t) n1 * ns]; }
-                    else { if (ok0) t0 = Ti[n0 + (size_t) kk * ns]; if (ok1) t1 = Ti[n1 + (size_t) kk * ns]; }
+        for (int kc = 0; kc < 4; ++kc) {          // K chunks of 64 strip columns: [0, 32 (jb + 1)) in all (Tinv is upper triangular)
+            if (kc * 2 <= jb) {
+                __syncthreads();                   // the previous chunk's fragment reads are done
+                const int k0 = kc * PGK;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < PGK * DB / 256; ++e) {
+                        const int idx = tid + 256 * e, kk = idx & (PGK - 1), np = idx >> 6;
+                        const int kg = k0 + kk, n = jb * DB + np;
+                        Ts[np * (PGK + 2) + kk] = (kg < ns && n < ns) ? Ti[kg + (size_t) n * ns] : 0.0;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < PGK * DB / 256; ++e) {
+                        const int idx = tid + 256 * e, np = idx & 31, kk = idx >> 5;
+                        const int kg = k0 + kk, n = jb * DB + np;
+                        Ts[kk * 48 + np] = (kg < ns && n < ns) ? Ti[n + (size_t) kg * ns] : 0.0;
+                    }
                 }
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, a[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, a[q], acc1, 0, 0, 0);
+                __syncthreads();
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) {
+                    const int kl = 4 * qq + lk;
+                    const double t0 = MODE == 0 ? Ts[li * (PGK + 2) + kl] : Ts[kl * 48 + li];
+                    const double t1 = MODE == 0 ? Ts[(16 + li) * (PGK + 2) + kl] : Ts[kl * 48 + 16 + li];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, a[16 * kc + qq], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, a[16 * kc + qq], acc1, 0, 0, 0);
+                }
             }
-            if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 16 Tinv loads hoisted ahead of their MFMAs
         }
         // D[(lk + 4 r)][li] = X_new(row li, column jb*32 + 16 h + lk + 4 r)
 #pragma unroll
@@ -595,14 +612,14 @@ __device__ __forceinline__ void panel_gemm_wave(const DevTables &T, int k, int u
 __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__restrict__ nodes, const int *__restrict__ lprefix,
                                                     const int *__restrict__ uprefix, int nn, int nl)
 {
-    const int wave = threadIdx.x >> 6;
+    __shared__ double Ts[PG_LDS];
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
-        panel_gemm_wave<0>(T, nodes[ni], (blockIdx.x - lprefix[ni]) * 4 + wave);
+        panel_gemm_wg<0>(T, nodes[ni], blockIdx.x - lprefix[ni], Ts);
     } else {
         const int id = blockIdx.x - nl;
         const int ni = find_node(uprefix, nn, id);
-        panel_gemm_wave<1>(T, nodes[ni], (id - uprefix[ni]) * 4 + wave);
+        panel_gemm_wg<1>(T, nodes[ni], id - uprefix[ni], Ts);
     }
 }
 
