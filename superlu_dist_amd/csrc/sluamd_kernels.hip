@@ -953,14 +953,20 @@ __global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__re
 }
 
 // ---- fused level kernels of the single-layer solve (1 x 1 process layers) -----------------------------------------------
+// The sweeps are bound by load latency, not bandwidth (one dependent launch per level of the elimination DAG), so the kernels
+// are shaped for loads in flight: 1024-thread workgroups, every thread issues ONE batch of 16 independent loads per phase.
+//
 // Forward, ONE launch per level (dlsum_fmod_inv + the leaf/non-leaf local solves, pdgstrs_lsum.c:414, pdgstrs3d.c:1819-2179):
-// workgroup = (supernode k, 256-row strip of its L panel).  Every strip recomputes y_k = Linv x_k itself (ns^2 flops out of
+// workgroup = (supernode k, 64-row strip of its L panel).  Every strip recomputes y_k = Linv x_k itself (ns^2 flops out of
 // L2 -- cheaper than a second dependent launch), strip 0 stores it to y, then lsum_i -= L_ik y_k for the strip's rows
 // (fp64 atomics into x: rows of later levels only).  x holds b + lsum and is consumed; y receives the forward solution.
-__global__ __launch_bounds__(256) void k_fwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
-                                                   double *__restrict__ x, double *__restrict__ y, int64_t ldx, int nrhs)
+constexpr int SFR = 64;     // panel rows per forward workgroup
+__global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
+                                                    double *__restrict__ x, double *__restrict__ y, int64_t ldx, int nrhs)
 {
     extern __shared__ double sm[];  // xk[ns * nrhs] | yk[ns * nrhs]
+    __shared__ double s_red[16][64 + 1];
+    __shared__ double s_part[4][256];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int strip = blockIdx.x - prefix[ni];
@@ -968,73 +974,96 @@ __global__ __launch_bounds__(256) void k_fwd_fused(DevTables T, const int *__res
     const int lda = T.sn_nsupr[k];
     double *xk = sm, *yk = sm + (size_t) ns * nrhs;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += 256) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    for (int idx = tid; idx < ns * nrhs; idx += 1024) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
     const double *Li = T.inv + T.sn_inv[k];
-    // y_k = Linv x_k: thread = row, the column loop runs to the wave's last row (uniform bound; Linv stores explicit zeros
-    // above the diagonal) and is unrolled by 16 so that 16 L2 loads are in flight per thread
-    for (int i0 = 0; i0 < ns; i0 += 256) {
-        const int i = i0 + tid;
-        const int jend = min(ns, ((i0 + (tid | 63)) + 1));
+    // y_k = Linv x_k: thread = (row i, quarter of the columns); Linv stores explicit zeros above the diagonal, column
+    // blocks entirely above the thread's wave are skipped
+    {
+        const int i = tid & 255, part = tid >> 8;
+        const int jlim = min(ns, (i | 63) + 1);              // columns beyond the wave's last row are zero
         for (int q = 0; q < nrhs; ++q) {
             const double *xq = xk + q * ns;
             double acc[4] = {0, 0, 0, 0};
             if (i < ns) {
                 const double *Lr = Li + i;
-                int j2 = 0;
-                for (; j2 + 16 <= jend; j2 += 16) {
-                    double lv[16];
+                for (int j0 = part * 64; j0 < jlim; j0 += 256) {
+                    const int j1 = min(j0 + 64, jlim);
+                    int j2 = j0;
+                    for (; j2 + 16 <= j1; j2 += 16) {
+                        double lv[16];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) lv[u] = Lr[(size_t) (j2 + u) * ns];
+                        for (int u = 0; u < 16; ++u) lv[u] = Lr[(size_t) (j2 + u) * ns];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * xq[j2 + u];
+                        for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * xq[j2 + u];
+                    }
+                    for (; j2 < j1; ++j2) acc[0] += Lr[(size_t) j2 * ns] * xq[j2];
                 }
-                for (; j2 < jend; ++j2) acc[0] += Lr[(size_t) j2 * ns] * xq[j2];
-                yk[i + q * ns] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
             }
+            s_part[part][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            __syncthreads();
+            if (tid < ns) yk[tid + q * ns] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+            __syncthreads();
         }
     }
-    __syncthreads();
-    if (strip == 0) for (int idx = tid; idx < ns * nrhs; idx += 256) y[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = yk[idx];
-    const int row = T.sn_ldiag[k] + strip * 256 + tid;
-    if (row >= lda) return;
+    if (strip == 0) for (int idx = tid; idx < ns * nrhs; idx += 1024) y[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = yk[idx];
+    // rows of the strip: thread = (row r of 64, one of 16 column slices): one batch of <= 16 loads per thread
+    const int r = tid & 63, part = tid >> 6;
+    const int row = T.sn_ldiag[k] + strip * SFR + r;
+    const bool rvalid = row < lda;
     const double *L = T.val + T.sn_lval[k] + row;
-    const int *lsub = T.lidx + T.sn_lidx[k];
-    int p = BC_HEADER, base = 0, grow = -1;
-    const int nb = lsub[0];
-    for (int b = 0; b < nb; ++b) {
-        const int nbrow = lsub[p + 1];
-        if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
-        base += nbrow; p += LB_DESCRIPTOR + nbrow;
-    }
-    for (int r = 0; r < nrhs; ++r) {
-        const double *yq = yk + r * ns;
-        double acc[4] = {0, 0, 0, 0};
-        int kk = 0;
-        for (; kk + 16 <= ns; kk += 16) {
-            double lv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);   // streamed once: 16 loads in flight
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * yq[kk + u];
+    int grow = 0;
+    if (rvalid && part == 0) {
+        const int *lsub = T.lidx + T.sn_lidx[k];
+        int p = BC_HEADER, base = 0;
+        const int nb = lsub[0];
+        for (int b = 0; b < nb; ++b) {
+            const int nbrow = lsub[p + 1];
+            if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
+            base += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
-        for (; kk < ns; ++kk) acc[0] += L[(size_t) kk * lda] * yq[kk];
-        atomic_sub_f64(x + grow + (int64_t) r * ldx, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+    }
+    const int cpp = (ns + 15) >> 4;               // columns per slice
+    const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
+    for (int q = 0; q < nrhs; ++q) {
+        const double *yq = yk + q * ns;
+        double acc[4] = {0, 0, 0, 0};
+        if (rvalid) {
+            int kk = ka;
+            for (; kk + 16 <= kb; kk += 16) {
+                double lv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * yq[kk + u];
+            }
+            for (; kk < kb; ++kk) acc[0] += __builtin_nontemporal_load(L + (size_t) kk * lda) * yq[kk];
+        }
+        s_red[part][r] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();
+        if (part == 0 && rvalid) {
+            double a = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < 16; ++p2) a += s_red[p2][r];
+            atomic_sub_f64(x + grow + (int64_t) q * ldx, a);
+        }
+        __syncthreads();
     }
 }
 
-// Backward, ONE launch per level (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode k, chunk of 256 non-empty U
-// columns).  s = U(k, chunk) x_cols (lanes along the rows of k: coalesced over the skyline segments; the 4 waves split the
+// Backward, ONE launch per level (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode k, chunk of 64 non-empty U
+// columns).  s = U(k, chunk) x_cols (lanes along the rows of k: coalesced over the skyline segments; the 16 waves split the
 // columns), v = (chunk 0 ? y_k : 0) - s, x_k += Uinv v (linearity: every chunk applies Uinv to its own partial sum, so no
 // second launch and no inter-workgroup reduction).  x starts at zero and receives the solution.
-constexpr int BWC = 256;
-__global__ __launch_bounds__(256) void k_bwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
-                                                   double *__restrict__ x, const double *__restrict__ y, int64_t ldx, int nrhs)
+constexpr int BWC = 64;
+__global__ __launch_bounds__(1024) void k_bwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
+                                                    double *__restrict__ x, const double *__restrict__ y, int64_t ldx, int nrhs)
 {
     __shared__ int s_cp[BWC], s_ld[BWC], s_gc[BWC];
     __shared__ double s_xc[BWC];
-    __shared__ double s_red[4][256];
+    __shared__ double s_red[16][256];
     __shared__ double s_v[256];
+    __shared__ double s_part[4][256];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int chunk = blockIdx.x - prefix[ni];
@@ -1059,17 +1088,17 @@ __global__ __launch_bounds__(256) void k_bwd_fused(DevTables T, const int *__res
     for (int r = 0; r < nrhs; ++r) {
         if (tid < ncol) s_xc[tid] = x[s_gc[tid] + (int64_t) r * ldx];      // solved x of this chunk's columns: one gather
         __syncthreads();
-        // s = U(k, chunk) x_cols: wave w takes the chunk's columns [64 w, 64 w + 64); lane l accumulates the rows l, l + 64,
-        // l + 128, l + 192 of supernode k (four independent coalesced loads per column)
-        double a[4] = {0, 0, 0, 0};
-        const int c0 = wave * 64, c1 = min(ncol, c0 + 64);
-        int c = c0;
-        for (; c + 4 <= c1; c += 4) {      // 4 columns x 4 row blocks = 16 independent coalesced loads in flight per lane
+        // s = U(k, chunk) x_cols: wave w takes the chunk's columns 4 w .. 4 w + 3; lane l accumulates the rows l, l + 64,
+        // l + 128, l + 192 of supernode k: ONE batch of 16 independent coalesced loads per lane
+        {
+            double a[4] = {0, 0, 0, 0};
             double uv[4][4];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const int ld = s_ld[c + cc];
-                const double *col = Uv + s_cp[c + cc] - ld;
+                const int c = wave * 4 + cc;
+                const bool cok = c < ncol;
+                const int ld = cok ? s_ld[c] : ns;
+                const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = lane + 64 * q;
@@ -1078,45 +1107,47 @@ __global__ __launch_bounds__(256) void k_bwd_fused(DevTables T, const int *__res
             }
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const double xv = s_xc[c + cc];
+                const int c = wave * 4 + cc;
+                const double xv = (c < ncol) ? s_xc[c] : 0.0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[q] += uv[cc][q] * xv;
             }
-        }
-        for (; c < c1; ++c) {
-            const int ld = s_ld[c];
-            const double *col = Uv + s_cp[c] - ld;
-            const double xv = s_xc[c];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = lane + 64 * q;
-                if (i >= ld && i < ns) a[q] += __builtin_nontemporal_load(col + i) * xv;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s_red[wave][lane + 64 * q] = a[q];
-        __syncthreads();
-        if (tid < ns) {
-            const double sv = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
-            s_v[tid] = (chunk == 0 ? y[fst + tid + (int64_t) r * ldx] : 0.0) - sv;
+            for (int q = 0; q < 4; ++q) s_red[wave][lane + 64 * q] = a[q];
         }
         __syncthreads();
-        // x_k += Uinv v: thread = row i, columns from the wave's first row (uniform bound; explicit zeros below the diagonal)
-        if (tid < ns) {
-            const int i = tid;
-            const double *Ur = Ui + i;
+        if (tid < 256) {
+            double sv = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) sv += s_red[w][tid];
+            s_v[tid] = (tid < ns) ? (chunk == 0 ? y[fst + tid + (int64_t) r * ldx] : 0.0) - sv : 0.0;
+        }
+        __syncthreads();
+        // x_k += Uinv v: thread = (row i, quarter of the columns); explicit zeros below the diagonal, column blocks entirely
+        // left of the thread's wave are skipped
+        {
+            const int i = tid & 255, part = tid >> 8;
             double acc[4] = {0, 0, 0, 0};
-            int j2 = (tid & ~63);
-            for (; j2 + 16 <= ns; j2 += 16) {
-                double uv[16];
+            if (i < ns) {
+                const double *Ur = Ui + i;
+                const int jlo = i & ~63;
+                for (int j0 = jlo + part * 64; j0 < ns; j0 += 256) {
+                    const int j1 = min(j0 + 64, ns);
+                    int j2 = j0;
+                    for (; j2 + 16 <= j1; j2 += 16) {
+                        double uw[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) uv[u] = Ur[(size_t) (j2 + u) * ns];
+                        for (int u = 0; u < 16; ++u) uw[u] = Ur[(size_t) (j2 + u) * ns];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u & 3] += uv[u] * s_v[j2 + u];
+                        for (int u = 0; u < 16; ++u) acc[u & 3] += uw[u] * s_v[j2 + u];
+                    }
+                    for (; j2 < j1; ++j2) acc[0] += Ur[(size_t) j2 * ns] * s_v[j2];
+                }
             }
-            for (; j2 < ns; ++j2) acc[0] += Ur[(size_t) j2 * ns] * s_v[j2];
-            unsafeAtomicAdd(x + fst + i + (int64_t) r * ldx, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+            s_part[part][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
+        __syncthreads();
+        if (tid < ns) unsafeAtomicAdd(x + fst + tid + (int64_t) r * ldx, (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]));
         __syncthreads();
     }
 }
@@ -1328,13 +1359,13 @@ void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *pr
 void fwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx,
                int nrhs, int mx)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_fwd_fused, dim3(nwork), dim3(256), (size_t) 2 * mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, y, ldx, nrhs);
+    if (nwork > 0) hipLaunchKernelGGL(k_fwd_fused, dim3(nwork), dim3(1024), (size_t) 2 * mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, y, ldx, nrhs);
 }
 
 void bwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, const double *y,
                int64_t ldx, int nrhs)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_bwd_fused, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, y, ldx, nrhs);
+    if (nwork > 0) hipLaunchKernelGGL(k_bwd_fused, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, y, ldx, nrhs);
 }
 
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int mx)
