@@ -444,7 +444,7 @@ static int ensure_y(Handle *H, int64_t doubles)
 static int max_rhs_chunk(const Handle *H)
 {   // the diagonal solve stages (max_nsupc + 32) x nrhs doubles in LDS (<= 150 KiB of the 160 KiB per workgroup)
     const int per = 2 * H->max_nsupc * 8;           // k_fwd_fused: x_k and y_k
-    return std::max(1, (150 * 1024) / std::max(per, 1));
+    return std::max(1, (128 * 1024) / std::max(per, 1));
 }
 
 int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
