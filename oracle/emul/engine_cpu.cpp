@@ -348,8 +348,8 @@ void fwd_fused(hipStream_t, const DevTables &T, const int *nodes, const int *pre
             yk.assign(ns, 0.0);
             for (int i = 0; i < ns; ++i) { double a = 0; for (int j = 0; j <= i; ++j) a += Li[i + (size_t) j * ns] * x[fst + j + (int64_t) r * ldx]; yk[i] = a; }
             if (strip == 0) for (int i = 0; i < ns; ++i) y[fst + i + (int64_t) r * ldx] = yk[i];
-            for (int t = 0; t < 64; ++t) {
-                const int row = T.sn_ldiag[k] + strip * 64 + t;
+            for (int t = 0; t < 256; ++t) {
+                const int row = T.sn_ldiag[k] + strip * 256 + t;
                 if (row >= lda) break;
                 int p = BC_HEADER, base = 0, grow = -1;
                 for (int b = 0; b < lsub[0]; ++b) {
@@ -374,14 +374,14 @@ void bwd_fused(hipStream_t, const DevTables &T, const int *nodes, const int *pre
         const int ni = find_node(prefix, nn, w);
         const int k = nodes[ni], chunk = w - prefix[ni];
         const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
-        const int ncol = std::max(0, std::min(64, T.sn_ncolu[k] - chunk * 64));
+        const int ncol = std::max(0, std::min(256, T.sn_ncolu[k] - chunk * 256));
         const double *Uv = T.val + T.sn_uval[k];
         const double *Ui = T.inv + T.sn_inv[k] + (size_t) ns * ns;
         for (int r = 0; r < nrhs; ++r) {
             v.assign(ns, 0.0);
             if (chunk == 0) for (int i = 0; i < ns; ++i) v[i] = y[fst + i + (int64_t) r * ldx];
             for (int t = 0; t < ncol; ++t) {
-                const int c = chunk * 64 + t;
+                const int c = chunk * 256 + t;
                 const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
                 int lo = 0, hi = nub;
                 while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }

@@ -156,7 +156,7 @@ struct LevelSched {
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
-    std::vector<int> ffwd_prefix, fbwd_prefix;  // fused single-layer solve: 64-row L strips / 64-column U chunks, at least one per supernode
+    std::vector<int> ffwd_prefix, fbwd_prefix;  // fused single-layer solve: 256-row L strips / 256-column U chunks, at least one per supernode
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)

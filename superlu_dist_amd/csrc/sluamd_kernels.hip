@@ -960,12 +960,12 @@ __global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__re
 // workgroup = (supernode k, 64-row strip of its L panel).  Every strip recomputes y_k = Linv x_k itself (ns^2 flops out of
 // L2 -- cheaper than a second dependent launch), strip 0 stores it to y, then lsum_i -= L_ik y_k for the strip's rows
 // (fp64 atomics into x: rows of later levels only).  x holds b + lsum and is consumed; y receives the forward solution.
-constexpr int SFR = 64;     // panel rows per forward workgroup
+constexpr int SFR = 256;    // panel rows per forward workgroup (more strips = more redundant Linv GEMVs: measured slower)
 __global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
                                                     double *__restrict__ x, double *__restrict__ y, int64_t ldx, int nrhs)
 {
     extern __shared__ double sm[];  // xk[ns * nrhs] | yk[ns * nrhs]
-    __shared__ double s_red[16][64 + 1];
+    __shared__ double s_red[4][256];
     __shared__ double s_part[4][256];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
@@ -1007,8 +1007,8 @@ __global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__re
         }
     }
     if (strip == 0) for (int idx = tid; idx < ns * nrhs; idx += 1024) y[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = yk[idx];
-    // rows of the strip: thread = (row r of 64, one of 16 column slices): one batch of <= 16 loads per thread
-    const int r = tid & 63, part = tid >> 6;
+    // rows of the strip: thread = (row r of 256, one of 4 column slices): <= 4 batches of 16 loads per thread
+    const int r = tid & 255, part = tid >> 8;
     const int row = T.sn_ldiag[k] + strip * SFR + r;
     const bool rvalid = row < lda;
     const double *L = T.val + T.sn_lval[k] + row;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__re
             base += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
     }
-    const int cpp = (ns + 15) >> 4;               // columns per slice
+    const int cpp = (ns + 3) >> 2;                // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
     for (int q = 0; q < nrhs; ++q) {
         const double *yq = yk + q * ns;
@@ -1042,10 +1042,7 @@ __global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__re
         s_red[part][r] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
         if (part == 0 && rvalid) {
-            double a = 0.0;
-#pragma unroll
-            for (int p2 = 0; p2 < 16; ++p2) a += s_red[p2][r];
-            atomic_sub_f64(x + grow + (int64_t) q * ldx, a);
+            atomic_sub_f64(x + grow + (int64_t) q * ldx, (s_red[0][r] + s_red[1][r]) + (s_red[2][r] + s_red[3][r]));
         }
         __syncthreads();
     }
@@ -1055,7 +1052,7 @@ __global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__re
 // columns).  s = U(k, chunk) x_cols (lanes along the rows of k: coalesced over the skyline segments; the 16 waves split the
 // columns), v = (chunk 0 ? y_k : 0) - s, x_k += Uinv v (linearity: every chunk applies Uinv to its own partial sum, so no
 // second launch and no inter-workgroup reduction).  x starts at zero and receives the solution.
-constexpr int BWC = 64;
+constexpr int BWC = 256;
 __global__ __launch_bounds__(1024) void k_bwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
                                                     double *__restrict__ x, const double *__restrict__ y, int64_t ldx, int nrhs)
 {
@@ -1088,29 +1085,32 @@ __global__ __launch_bounds__(1024) void k_bwd_fused(DevTables T, const int *__re
     for (int r = 0; r < nrhs; ++r) {
         if (tid < ncol) s_xc[tid] = x[s_gc[tid] + (int64_t) r * ldx];      // solved x of this chunk's columns: one gather
         __syncthreads();
-        // s = U(k, chunk) x_cols: wave w takes the chunk's columns 4 w .. 4 w + 3; lane l accumulates the rows l, l + 64,
-        // l + 128, l + 192 of supernode k: ONE batch of 16 independent coalesced loads per lane
+        // s = U(k, chunk) x_cols: wave w takes the chunk's columns 16 w .. 16 w + 15; lane l accumulates the rows l, l + 64,
+        // l + 128, l + 192 of supernode k: 4 batches of 16 independent coalesced loads per lane
         {
             double a[4] = {0, 0, 0, 0};
-            double uv[4][4];
+            for (int cb = 0; cb < 16; cb += 4) {
+                if (wave * 16 + cb >= ncol) break;
+                double uv[4][4];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = wave * 4 + cc;
-                const bool cok = c < ncol;
-                const int ld = cok ? s_ld[c] : ns;
-                const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = wave * 16 + cb + cc;
+                    const bool cok = c < ncol;
+                    const int ld = cok ? s_ld[c] : ns;
+                    const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = lane + 64 * q;
-                    uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = lane + 64 * q;
+                        uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+                    }
                 }
-            }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = wave * 4 + cc;
-                const double xv = (c < ncol) ? s_xc[c] : 0.0;
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = wave * 16 + cb + cc;
+                    const double xv = (c < ncol) ? s_xc[c] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] += uv[cc][q] * xv;
+                    for (int q = 0; q < 4; ++q) a[q] += uv[cc][q] * xv;
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) s_red[wave][lane + 64 * q] = a[q];

@@ -276,9 +276,9 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.zltr_prefix[po + 1] = S.zltr_prefix[po] + (lrows + 63) / 64;
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
-            S.ffwd_prefix[po + 1] = S.ffwd_prefix[po] + std::max(1, (lrows + 63) / 64);     // SFR / BWC of the fused solve kernels
+            S.ffwd_prefix[po + 1] = S.ffwd_prefix[po] + std::max(1, (lrows + 255) / 256);   // SFR / BWC of the fused solve kernels
             S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 63) / 64) : 0);
-            S.fbwd_prefix[po + 1] = S.fbwd_prefix[po] + std::max(1, (ucols + 63) / 64);
+            S.fbwd_prefix[po + 1] = S.fbwd_prefix[po] + std::max(1, (ucols + 255) / 256);
         }
     }
     build_urgent_lists(t, lvl, S);
