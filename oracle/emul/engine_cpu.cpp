@@ -334,73 +334,6 @@ void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, i
     }
 }
 
-void fwd_fused(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx, int nrhs,
-               int)
-{
-    std::vector<double> yk;
-    for (int w = 0; w < nwork; ++w) {
-        const int ni = find_node(prefix, nn, w);
-        const int k = nodes[ni], strip = w - prefix[ni];
-        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
-        const double *Li = T.inv + T.sn_inv[k];
-        const int *lsub = T.lidx + T.sn_lidx[k];
-        for (int r = 0; r < nrhs; ++r) {
-            yk.assign(ns, 0.0);
-            for (int i = 0; i < ns; ++i) { double a = 0; for (int j = 0; j <= i; ++j) a += Li[i + (size_t) j * ns] * x[fst + j + (int64_t) r * ldx]; yk[i] = a; }
-            if (strip == 0) for (int i = 0; i < ns; ++i) y[fst + i + (int64_t) r * ldx] = yk[i];
-            for (int t = 0; t < 256; ++t) {
-                const int row = T.sn_ldiag[k] + strip * 256 + t;
-                if (row >= lda) break;
-                int p = BC_HEADER, base = 0, grow = -1;
-                for (int b = 0; b < lsub[0]; ++b) {
-                    const int nbrow = lsub[p + 1];
-                    if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
-                    base += nbrow; p += LB_DESCRIPTOR + nbrow;
-                }
-                const double *L = T.val + T.sn_lval[k] + row;
-                double acc = 0;
-                for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * yk[kk];
-                x[grow + (int64_t) r * ldx] -= acc;
-            }
-        }
-    }
-}
-
-void bwd_fused(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, const double *y, int64_t ldx,
-               int nrhs)
-{
-    std::vector<double> v;
-    for (int w = 0; w < nwork; ++w) {
-        const int ni = find_node(prefix, nn, w);
-        const int k = nodes[ni], chunk = w - prefix[ni];
-        const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
-        const int ncol = std::max(0, std::min(256, T.sn_ncolu[k] - chunk * 256));
-        const double *Uv = T.val + T.sn_uval[k];
-        const double *Ui = T.inv + T.sn_inv[k] + (size_t) ns * ns;
-        for (int r = 0; r < nrhs; ++r) {
-            v.assign(ns, 0.0);
-            if (chunk == 0) for (int i = 0; i < ns; ++i) v[i] = y[fst + i + (int64_t) r * ldx];
-            for (int t = 0; t < ncol; ++t) {
-                const int c = chunk * 256 + t;
-                const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
-                int lo = 0, hi = nub;
-                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
-                const int b = ub0 + lo;
-                const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
-                const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
-                const int ld = ns - (klst - T.uidx[u0 + jj]), cp = T.ucolptr[u0 + jj], gc = T.xsup[T.ub_gid[b]] + jj;
-                const double xv = x[gc + (int64_t) r * ldx];
-                for (int i = ld; i < ns; ++i) v[i] -= Uv[cp + (i - ld)] * xv;
-            }
-            for (int i = 0; i < ns; ++i) {
-                double a = 0;
-                for (int j = i; j < ns; ++j) a += Ui[i + (size_t) j * ns] * v[j];
-                x[fst + i + (int64_t) r * ldx] += a;
-            }
-        }
-    }
-}
-
 void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int)
 {
     for (int w = 0; w < nwork; ++w) {
@@ -408,8 +341,8 @@ void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
         const int k = nodes[ni], strip = w - prefix[ni];
         const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
         const int *lsub = T.lidx + T.sn_lidx[k];
-        for (int t = 0; t < 256; ++t) {
-            const int row = T.sn_ldiag[k] + strip * 256 + t;
+        for (int t = 0; t < 64; ++t) {
+            const int row = T.sn_ldiag[k] + strip * 64 + t;
             if (row >= lda) break;
             int p = BC_HEADER, base = 0, grow = -1;
             for (int b = 0; b < lsub[0]; ++b) {

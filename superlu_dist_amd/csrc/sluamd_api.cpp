@@ -322,7 +322,7 @@ int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, in
             for (int l = 0; l < S.nlevels; ++l) {
                 const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
                 eng::zsolve_diag(s, true, T, S.d_nodes + n0, nn, dx, ldx, nr, S.max_nsupc[l]);
-                eng::zfwd_update(s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, S.fwd_prefix[po + nn], dx, ldx, nr, S.max_nsupc[l]);
+                eng::zfwd_update(s, T, S.d_nodes + n0, S.d_zfwd_prefix + po, nn, S.zfwd_prefix[po + nn], dx, ldx, nr, S.max_nsupc[l]);
             }
         }
         for (int zl = (int) H->sched.size() - 1; zl >= 0; --zl) {
@@ -486,7 +486,6 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_info) hipFree(H->d_info);
     if (H->d_x) hipFree(H->d_x);
     if (H->d_xtmp) hipFree(H->d_xtmp);
-    if (H->d_y) hipFree(H->d_y);
     if (H->d_apos) hipFree(H->d_apos);
     if (H->d_aval) hipFree(H->d_aval);
     if (H->h_pinned) hipHostFree(H->h_pinned);

@@ -414,36 +414,9 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     return 0;
 }
 
-// single-layer (1 x 1 process layer) sweeps: ONE fused launch per level and direction
-static void solve_fwd_fused(Handle *H, int z, double *d_x, double *d_y, int64_t ldx, int nrhs)
-{
-    LevelSched &S = H->sched[z];
-    for (int l = 0; l < S.nlevels; ++l) {
-        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
-        eng::fwd_fused(H->stream, H->T, S.d_nodes + n0, S.d_ffwd_prefix + po, nn, S.ffwd_prefix[po + nn], d_x, d_y, ldx, nrhs, S.max_nsupc[l]);
-    }
-}
-static void solve_bwd_fused(Handle *H, int z, double *d_x, const double *d_y, int64_t ldx, int nrhs)
-{
-    LevelSched &S = H->sched[z];
-    for (int l = S.nlevels - 1; l >= 0; --l) {
-        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
-        eng::bwd_fused(H->stream, H->T, S.d_nodes + n0, S.d_fbwd_prefix + po, nn, S.fbwd_prefix[po + nn], d_x, d_y, ldx, nrhs);
-    }
-}
-static int ensure_y(Handle *H, int64_t doubles)
-{
-    if (doubles <= H->y_cap) return 0;
-    if (H->d_y) hipFree(H->d_y);
-    H->d_y = nullptr; H->y_cap = 0;
-    if (hipMalloc((void **) &H->d_y, sizeof(double) * (size_t) doubles) != hipSuccess) { set_error("hipMalloc of the solve work vector failed"); return SLUAMD_ENOMEM; }
-    H->y_cap = doubles;
-    return 0;
-}
-
 static int max_rhs_chunk(const Handle *H)
 {   // the diagonal solve stages (max_nsupc + 32) x nrhs doubles in LDS (<= 150 KiB of the 160 KiB per workgroup)
-    const int per = 2 * H->max_nsupc * 8;           // k_fwd_fused: x_k and y_k
+    const int per = H->max_nsupc * 8;               // x_k staged in LDS by the diagonal solve / forward update
     return std::max(1, (128 * 1024) / std::max(per, 1));
 }
 
@@ -452,14 +425,11 @@ int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
     int rc = ensure_inv(H);
     if (rc) return rc;
     const int ch = max_rhs_chunk(H);
-    if ((rc = ensure_y(H, ldx * std::min(ch, nrhs)))) return rc;
-    hipStream_t s = H->stream;
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
         double *x = d_x + (size_t) j0 * ldx;
-        for (int z = 0; z < (int) H->sched.size(); ++z) solve_fwd_fused(H, z, x, H->d_y, ldx, nr);
-        for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.n, s));
-        for (int z = (int) H->sched.size() - 1; z >= 0; --z) solve_bwd_fused(H, z, x, H->d_y, ldx, nr);
+        for (int z = 0; z < (int) H->sched.size(); ++z) if ((rc = solve_fwd_z(H, z, x, ldx, nr))) return rc;
+        for (int z = (int) H->sched.size() - 1; z >= 0; --z) if ((rc = solve_bwd_z(H, z, x, ldx, nr))) return rc;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -498,13 +468,11 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
     if (g.size() == 1) return run_solve_local(H, d_x, ldx, nrhs);
     if (!H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
     if (!H->dinv_ready) { set_error("grid solve needs the factorisation to have run on this handle"); return SLUAMD_EINVAL; }
-    const bool fused = g.Pr * g.Pc == 1;     // 1 x 1 layers: one fused launch per level and direction (x consumed, y = forward solution)
     const int nzl = (int) H->sched.size();
     hipStream_t s = H->stream;
     const int ch = max_rhs_chunk(H);
     int rc;
     if ((rc = ensure_inv(H))) return rc;
-    if (fused && (rc = ensure_y(H, ldx * std::min(ch, nrhs)))) return rc;
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
         double *x = d_x + (size_t) j0 * ldx;
@@ -534,10 +502,7 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
         for (int zl = 0; zl < nzl; ++zl) {
             const int step = 1 << zl;
             if (g.z % step) break;
-            if (H->z_active[zl]) {
-                if (fused) solve_fwd_fused(H, zl, x, H->d_y, ldx, nr);
-                else if ((rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
-            }
+            if (H->z_active[zl] && (rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
             if (zl + 1 < nzl) {
                 LevelSched::XSeg seg;
                 forest_runs(H, zl + 1, nzl, 0, seg);
@@ -549,7 +514,6 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
             }
         }
         // ---- backward sweep, root to leaves ----
-        if (fused) for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.n, s));
         for (int zl = nzl - 1; zl >= 0; --zl) {
             const int step = 1 << zl;
             if (g.z % step) continue;
@@ -563,10 +527,7 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
                     if (seg.total && (rc = sender ? xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldx, nr, none, 0, one, 1, s))) return rc;
                 }
             }
-            if (H->z_active[zl]) {
-                if (fused) solve_bwd_fused(H, zl, x, H->d_y, ldx, nr);
-                else if ((rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
-            }
+            if (H->z_active[zl] && (rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
         }
         // ---- assemble: every x_k is final at its diagonal owner on the layer that factored its forest; gather on world
         //      rank 0, then hand the complete vector to everyone ----

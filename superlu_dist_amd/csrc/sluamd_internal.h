@@ -154,9 +154,9 @@ struct LevelSched {
     std::vector<int> lvl_poff;      // [nlevels+1] offset of each level's prefix arrays (size nodes_in_level+1)
     std::vector<int> lvl_soff;      // [nlevels+1] offset of each level's Schur prefix arrays (big group | small group)
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
-    std::vector<int> fwd_prefix, bwd_prefix;  // solve work units
+    std::vector<int> fwd_prefix, bwd_prefix;  // solve work units: 64-row L strips / 64-column U chunks
+    std::vector<int> zfwd_prefix;             // complex path: 256-row L strips
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
-    std::vector<int> ffwd_prefix, fbwd_prefix;  // fused single-layer solve: 256-row L strips / 256-column U chunks, at least one per supernode
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
@@ -174,7 +174,7 @@ struct LevelSched {
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
     int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
-    int *d_ffwd_prefix = nullptr, *d_fbwd_prefix = nullptr, *d_finv_prefix = nullptr;
+    int *d_finv_prefix = nullptr, *d_zfwd_prefix = nullptr;
     int4 *d_ulist = nullptr;
     int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
 };
@@ -218,7 +218,6 @@ struct Handle {
     bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
     bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
     bool inv_ready = false;                                 // T.inv (Linv / Uinv) too
-    double *d_y = nullptr; int64_t y_cap = 0;               // forward solution of the fused single-layer solve
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
     size_t ev_schur_used = 0, ev_panel_used = 0;
@@ -252,11 +251,6 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
            const int4 *ulist, const int *sn_level, int skip_level);
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
-// fused level kernels of the single-layer solve: forward (x consumed, y = forward solution), backward (x zeroed before, receives the solution)
-void fwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx,
-               int nrhs, int max_nsupc);
-void bwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, const double *y,
-               int64_t ldx, int nrhs);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs,
                 int max_nsupc);

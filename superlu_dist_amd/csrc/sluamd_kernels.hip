@@ -931,89 +931,73 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
 // inverse (what the reference's DiagInv=YES solve does with Linv / Uinv, pdgstrs_lsum.c:414-520) -- no dependent chain
 // inside the block.  Used on XY layers, where the exchanges separate the diagonal solve from the updates.
 template <bool LOWER>
-__global__ __launch_bounds__(256) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
-                                                    int64_t ldx, int nrhs)
+__global__ __launch_bounds__(1024) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
+                                                     int64_t ldx, int nrhs)
 {
     extern __shared__ double xs[];  // ns x nrhs
+    __shared__ double s_part[4][256];
     const int k = nodes[blockIdx.x];
     if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;           // x_k is solved by the owner of the diagonal block
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += 256) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    for (int idx = tid; idx < ns * nrhs; idx += 1024) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
-    for (int idx = tid; idx < ns * nrhs; idx += 256) {
-        const int i = idx % ns, q = idx / ns;
+    // thread = (row i, quarter of the columns): <= 4 batches of 16 L2 loads; the inverse stores explicit zeros in the other
+    // triangle, column blocks entirely outside the wave's rows are skipped
+    const int i = tid & 255, part = tid >> 8;
+    for (int q = 0; q < nrhs; ++q) {
         const double *xq = xs + q * ns;
-        double a = 0.0;
-        if (LOWER) { for (int j2 = 0; j2 <= i; ++j2) a += Ti[i + (size_t) j2 * ns] * xq[j2]; }
-        else { for (int j2 = i; j2 < ns; ++j2) a += Ti[i + (size_t) j2 * ns] * xq[j2]; }
-        x[fst + i + (int64_t) q * ldx] = a;
+        double acc[4] = {0, 0, 0, 0};
+        if (i < ns) {
+            const double *Tr = Ti + i;
+            const int jlo = LOWER ? 0 : (i & ~63), jhi = LOWER ? min(ns, (i | 63) + 1) : ns;
+            for (int j0 = jlo + part * 64; j0 < jhi; j0 += 256) {
+                const int j1 = min(j0 + 64, jhi);
+                int j2 = j0;
+                for (; j2 + 16 <= j1; j2 += 16) {
+                    double tv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) tv[u] = Tr[(size_t) (j2 + u) * ns];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc[u & 3] += tv[u] * xq[j2 + u];
+                }
+                for (; j2 < j1; ++j2) acc[0] += Tr[(size_t) j2 * ns] * xq[j2];
+            }
+        }
+        s_part[part][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();
+        if (tid < ns) x[fst + tid + (int64_t) q * ldx] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+        __syncthreads();
     }
 }
 
-// ---- fused level kernels of the single-layer solve (1 x 1 process layers) -----------------------------------------------
-// The sweeps are bound by load latency, not bandwidth (one dependent launch per level of the elimination DAG), so the kernels
-// are shaped for loads in flight: 1024-thread workgroups, every thread issues ONE batch of 16 independent loads per phase.
+// The sweeps are bound by load latency and per-CU bandwidth, not by HBM (one dependent launch per level of the elimination
+// DAG), so the update kernels are shaped for parallelism: small work units (64 panel rows / 64 skyline columns -> several
+// hundred workgroups for a top-level supernode) of 1024 threads, every thread issuing ONE batch of <= 16 independent loads.
 //
-// Forward, ONE launch per level (dlsum_fmod_inv + the leaf/non-leaf local solves, pdgstrs_lsum.c:414, pdgstrs3d.c:1819-2179):
-// workgroup = (supernode k, 64-row strip of its L panel).  Every strip recomputes y_k = Linv x_k itself (ns^2 flops out of
-// L2 -- cheaper than a second dependent launch), strip 0 stores it to y, then lsum_i -= L_ik y_k for the strip's rows
-// (fp64 atomics into x: rows of later levels only).  x holds b + lsum and is consumed; y receives the forward solution.
-constexpr int SFR = 256;    // panel rows per forward workgroup (more strips = more redundant Linv GEMVs: measured slower)
-__global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
-                                                    double *__restrict__ x, double *__restrict__ y, int64_t ldx, int nrhs)
+// lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414): workgroup = (supernode,
+// 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
+__global__ __launch_bounds__(1024) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                     int nn, double *__restrict__ x, int64_t ldx, int nrhs)
 {
-    extern __shared__ double sm[];  // xk[ns * nrhs] | yk[ns * nrhs]
-    __shared__ double s_red[4][256];
-    __shared__ double s_part[4][256];
+    extern __shared__ double xk[];  // ns x nrhs
+    __shared__ double s_red[16][64 + 1];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int strip = blockIdx.x - prefix[ni];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
-    double *xk = sm, *yk = sm + (size_t) ns * nrhs;
     const int tid = threadIdx.x;
     for (int idx = tid; idx < ns * nrhs; idx += 1024) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
-    const double *Li = T.inv + T.sn_inv[k];
-    // y_k = Linv x_k: thread = (row i, quarter of the columns); Linv stores explicit zeros above the diagonal, column
-    // blocks entirely above the thread's wave are skipped
-    {
-        const int i = tid & 255, part = tid >> 8;
-        const int jlim = min(ns, (i | 63) + 1);              // columns beyond the wave's last row are zero
-        for (int q = 0; q < nrhs; ++q) {
-            const double *xq = xk + q * ns;
-            double acc[4] = {0, 0, 0, 0};
-            if (i < ns) {
-                const double *Lr = Li + i;
-                for (int j0 = part * 64; j0 < jlim; j0 += 256) {
-                    const int j1 = min(j0 + 64, jlim);
-                    int j2 = j0;
-                    for (; j2 + 16 <= j1; j2 += 16) {
-                        double lv[16];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) lv[u] = Lr[(size_t) (j2 + u) * ns];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * xq[j2 + u];
-                    }
-                    for (; j2 < j1; ++j2) acc[0] += Lr[(size_t) j2 * ns] * xq[j2];
-                }
-            }
-            s_part[part][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            __syncthreads();
-            if (tid < ns) yk[tid + q * ns] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
-            __syncthreads();
-        }
-    }
-    if (strip == 0) for (int idx = tid; idx < ns * nrhs; idx += 1024) y[fst + (idx % ns) + (int64_t) (idx / ns) * ldx] = yk[idx];
-    // rows of the strip: thread = (row r of 256, one of 4 column slices): <= 4 batches of 16 loads per thread
-    const int r = tid & 255, part = tid >> 8;
-    const int row = T.sn_ldiag[k] + strip * SFR + r;
+    const int r = tid & 63, part = tid >> 6;
+    const int row = T.sn_ldiag[k] + strip * 64 + r;
     const bool rvalid = row < lda;
     const double *L = T.val + T.sn_lval[k] + row;
     int grow = 0;
     if (rvalid && part == 0) {
+        // global row id of slot row `row`: rows are listed block after block, 2 descriptor ints per block: walk the (few) blocks
         const int *lsub = T.lidx + T.sn_lidx[k];
         int p = BC_HEADER, base = 0;
         const int nb = lsub[0];
@@ -1023,10 +1007,10 @@ __global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__re
             base += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
     }
-    const int cpp = (ns + 3) >> 2;                // columns per slice
+    const int cpp = (ns + 15) >> 4;               // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
     for (int q = 0; q < nrhs; ++q) {
-        const double *yq = yk + q * ns;
+        const double *xq = xk + q * ns;
         double acc[4] = {0, 0, 0, 0};
         if (rvalid) {
             int kk = ka;
@@ -1035,40 +1019,39 @@ __global__ __launch_bounds__(1024) void k_fwd_fused(DevTables T, const int *__re
 #pragma unroll
                 for (int u = 0; u < 16; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * yq[kk + u];
+                for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * xq[kk + u];
             }
-            for (; kk < kb; ++kk) acc[0] += __builtin_nontemporal_load(L + (size_t) kk * lda) * yq[kk];
+            for (; kk < kb; ++kk) acc[0] += __builtin_nontemporal_load(L + (size_t) kk * lda) * xq[kk];
         }
         s_red[part][r] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
         if (part == 0 && rvalid) {
-            atomic_sub_f64(x + grow + (int64_t) q * ldx, (s_red[0][r] + s_red[1][r]) + (s_red[2][r] + s_red[3][r]));
+            double a = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < 16; ++p2) a += s_red[p2][r];
+            atomic_sub_f64(x + grow + (int64_t) q * ldx, a);
         }
         __syncthreads();
     }
 }
 
-// Backward, ONE launch per level (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode k, chunk of 64 non-empty U
-// columns).  s = U(k, chunk) x_cols (lanes along the rows of k: coalesced over the skyline segments; the 16 waves split the
-// columns), v = (chunk 0 ? y_k : 0) - s, x_k += Uinv v (linearity: every chunk applies Uinv to its own partial sum, so no
-// second launch and no inter-workgroup reduction).  x starts at zero and receives the solution.
-constexpr int BWC = 256;
-__global__ __launch_bounds__(1024) void k_bwd_fused(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn,
-                                                    double *__restrict__ x, const double *__restrict__ y, int64_t ldx, int nrhs)
+// x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
+// lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
+// (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
+__global__ __launch_bounds__(1024) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                     int nn, double *__restrict__ x, int64_t ldx, int nrhs)
 {
-    __shared__ int s_cp[BWC], s_ld[BWC], s_gc[BWC];
-    __shared__ double s_xc[BWC];
+    __shared__ int s_cp[64], s_ld[64], s_gc[64];
+    __shared__ double s_xc[64];
     __shared__ double s_red[16][256];
-    __shared__ double s_v[256];
-    __shared__ double s_part[4][256];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int chunk = blockIdx.x - prefix[ni];
     const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
-    const int ncol = max(0, min(BWC, T.sn_ncolu[k] - chunk * BWC));
+    const int ncol = min(64, T.sn_ncolu[k] - chunk * 64);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < ncol) {
-        const int c = chunk * BWC + tid;
+        const int c = chunk * 64 + tid;
         const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
         int lo = 0, hi = nub;
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
@@ -1081,157 +1064,42 @@ __global__ __launch_bounds__(1024) void k_bwd_fused(DevTables T, const int *__re
     }
     __syncthreads();
     const double *Uv = T.val + T.sn_uval[k];
-    const double *Ui = T.inv + T.sn_inv[k] + (size_t) ns * ns;
     for (int r = 0; r < nrhs; ++r) {
         if (tid < ncol) s_xc[tid] = x[s_gc[tid] + (int64_t) r * ldx];      // solved x of this chunk's columns: one gather
         __syncthreads();
-        // s = U(k, chunk) x_cols: wave w takes the chunk's columns 16 w .. 16 w + 15; lane l accumulates the rows l, l + 64,
-        // l + 128, l + 192 of supernode k: 4 batches of 16 independent coalesced loads per lane
         {
             double a[4] = {0, 0, 0, 0};
-            for (int cb = 0; cb < 16; cb += 4) {
-                if (wave * 16 + cb >= ncol) break;
-                double uv[4][4];
+            double uv[4][4];
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int c = wave * 16 + cb + cc;
-                    const bool cok = c < ncol;
-                    const int ld = cok ? s_ld[c] : ns;
-                    const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = wave * 4 + cc;
+                const bool cok = c < ncol;
+                const int ld = cok ? s_ld[c] : ns;
+                const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = lane + 64 * q;
-                        uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int i = lane + 64 * q;
+                    uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
                 }
+            }
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int c = wave * 16 + cb + cc;
-                    const double xv = (c < ncol) ? s_xc[c] : 0.0;
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = wave * 4 + cc;
+                const double xv = (c < ncol) ? s_xc[c] : 0.0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) a[q] += uv[cc][q] * xv;
-                }
+                for (int q = 0; q < 4; ++q) a[q] += uv[cc][q] * xv;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) s_red[wave][lane + 64 * q] = a[q];
         }
         __syncthreads();
-        if (tid < 256) {
+        if (tid < ns) {
             double sv = 0.0;
 #pragma unroll
             for (int w = 0; w < 16; ++w) sv += s_red[w][tid];
-            s_v[tid] = (tid < ns) ? (chunk == 0 ? y[fst + tid + (int64_t) r * ldx] : 0.0) - sv : 0.0;
+            if (sv != 0.0) atomic_sub_f64(x + fst + tid + (int64_t) r * ldx, sv);
         }
         __syncthreads();
-        // x_k += Uinv v: thread = (row i, quarter of the columns); explicit zeros below the diagonal, column blocks entirely
-        // left of the thread's wave are skipped
-        {
-            const int i = tid & 255, part = tid >> 8;
-            double acc[4] = {0, 0, 0, 0};
-            if (i < ns) {
-                const double *Ur = Ui + i;
-                const int jlo = i & ~63;
-                for (int j0 = jlo + part * 64; j0 < ns; j0 += 256) {
-                    const int j1 = min(j0 + 64, ns);
-                    int j2 = j0;
-                    for (; j2 + 16 <= j1; j2 += 16) {
-                        double uw[16];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) uw[u] = Ur[(size_t) (j2 + u) * ns];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) acc[u & 3] += uw[u] * s_v[j2 + u];
-                    }
-                    for (; j2 < j1; ++j2) acc[0] += Ur[(size_t) j2 * ns] * s_v[j2];
-                }
-            }
-            s_part[part][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        }
-        __syncthreads();
-        if (tid < ns) unsafeAtomicAdd(x + fst + tid + (int64_t) r * ldx, (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]));
-        __syncthreads();
-    }
-}
-
-// lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414):
-// one thread per panel row, 256-row strips; x_k staged in LDS.
-__global__ __launch_bounds__(256) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                    int nn, double *__restrict__ x, int64_t ldx, int nrhs)
-{
-    extern __shared__ double xk[];  // ns x nrhs
-    const int ni = find_node(prefix, nn, blockIdx.x);
-    const int k = nodes[ni];
-    const int strip = blockIdx.x - prefix[ni];
-    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
-    const int lda = T.sn_nsupr[k];
-    for (int idx = threadIdx.x; idx < ns * nrhs; idx += 256) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
-    __syncthreads();
-    const int row = T.sn_ldiag[k] + strip * 256 + threadIdx.x;
-    if (row >= lda) return;
-    const double *L = T.val + T.sn_lval[k] + row;
-    // global row id of panel row `row`: rows are listed block after block, 2 descriptor ints per block
-    // -> precomputed flat map is not stored; walk the (few) blocks
-    const int *lsub = T.lidx + T.sn_lidx[k];
-    int p = BC_HEADER, base = 0, grow = -1;
-    const int nb = lsub[0];
-    for (int b = 0; b < nb; ++b) {
-        const int nbrow = lsub[p + 1];
-        if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
-        base += nbrow; p += LB_DESCRIPTOR + nbrow;
-    }
-    for (int r = 0; r < nrhs; ++r) {
-        double acc = 0.0;
-        for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * xk[kk + r * ns];
-        atomic_sub_f64(x + grow + (int64_t) r * ldx, acc);
-    }
-}
-
-// x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362):
-// lanes run along the rows of supernode k (coalesced over the skyline segments), the 4 waves split the columns.
-__global__ __launch_bounds__(256) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                    int nn, double *__restrict__ x, int64_t ldx, int nrhs)
-{
-    __shared__ int s_cp[64], s_ld[64], s_gc[64];
-    __shared__ double s_red[4][64];
-    const int ni = find_node(prefix, nn, blockIdx.x);
-    const int k = nodes[ni];
-    const int chunk = blockIdx.x - prefix[ni];
-    const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
-    const int ncol = min(64, T.sn_ncolu[k] - chunk * 64);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < 64) {
-        int cp = 0, ld = ns, gc = 0;
-        if (tid < ncol) {
-            const int c = chunk * 64 + tid;
-            const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
-            int lo = 0, hi = nub;
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
-            const int b = ub0 + lo;
-            const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
-            const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
-            ld = ns - (klst - T.uidx[u0 + jj]);
-            cp = T.ucolptr[u0 + jj];
-            gc = T.xsup[T.ub_gid[b]] + jj;
-        }
-        s_cp[tid] = cp; s_ld[tid] = ld; s_gc[tid] = gc;
-    }
-    __syncthreads();
-    const double *Uv = T.val + T.sn_uval[k];
-    for (int r = 0; r < nrhs; ++r) {
-        for (int rb = 0; rb < ns; rb += 64) {
-            const int i = rb + lane;
-            double acc = 0.0;
-            for (int c = wave; c < ncol; c += 4) {
-                const int ld = s_ld[c];
-                if (i < ns && i >= ld) acc += Uv[s_cp[c] + (i - ld)] * x[s_gc[c] + (int64_t) r * ldx];
-            }
-            s_red[wave][lane] = acc;
-            __syncthreads();
-            if (wave == 0 && i < ns) {
-                const double s = s_red[0][lane] + s_red[1][lane] + s_red[2][lane] + s_red[3][lane];
-                if (s != 0.0) atomic_sub_f64(x + fst + i + (int64_t) r * ldx, s);
-            }
-            __syncthreads();
-        }
     }
 }
 
@@ -1307,10 +1175,9 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_full_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));   // + 17 KB static
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     return 0;
 }
 
@@ -1356,34 +1223,22 @@ void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *pr
     if (nwork > 0) hipLaunchKernelGGL(k_full_inv, dim3(nwork), dim3(256), trsm_lds_bytes(64, (mx + 31) & ~31), s, T, nodes, prefix, nn);
 }
 
-void fwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, double *y, int64_t ldx,
-               int nrhs, int mx)
-{
-    if (nwork > 0) hipLaunchKernelGGL(k_fwd_fused, dim3(nwork), dim3(1024), (size_t) 2 * mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, y, ldx, nrhs);
-}
-
-void bwd_fused(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, const double *y,
-               int64_t ldx, int nrhs)
-{
-    if (nwork > 0) hipLaunchKernelGGL(k_bwd_fused, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, y, ldx, nrhs);
-}
-
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int mx)
 {
     if (nn <= 0) return;
     const size_t lds = (size_t) mx * nrhs * sizeof(double);
-    if (lower) hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
-    else hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
+    if (lower) hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(1024), lds, s, T, nodes, x, ldx, nrhs);
+    else hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(1024), lds, s, T, nodes, x, ldx, nrhs);
 }
 
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_fwd_update, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
+    if (nwork > 0) hipLaunchKernelGGL(k_fwd_update, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
 }
 
 void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_bwd_update, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
+    if (nwork > 0) hipLaunchKernelGGL(k_bwd_update, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
 }
 
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)

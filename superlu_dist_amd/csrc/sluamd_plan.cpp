@@ -252,7 +252,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     S.tile_prefix.assign(S.lvl_soff[S.nlevels], 0); S.ltr_prefix.assign(psz, 0); S.utr_prefix.assign(psz, 0);
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0); S.zltr_prefix.assign(psz, 0);
     S.dg_prefix.assign(psz, 0); S.dg_off.assign(psz, 0);
-    S.ffwd_prefix.assign(psz, 0); S.fbwd_prefix.assign(psz, 0); S.finv_prefix.assign(psz, 0);
+    S.finv_prefix.assign(psz, 0); S.zfwd_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l)
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i)
@@ -274,11 +274,10 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.utr_prefix[po + 1] = S.utr_prefix[po] + (ucols + rs - 1) / rs;
             S.inv_prefix[po + 1] = S.inv_prefix[po] + ((fl & SNF_HAS_DIAG) ? 2 * ((nsupc + 31) / 32) : 0);
             S.zltr_prefix[po + 1] = S.zltr_prefix[po] + (lrows + 63) / 64;
-            S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 255) / 256;
+            S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 63) / 64;
+            S.zfwd_prefix[po + 1] = S.zfwd_prefix[po] + (lrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
-            S.ffwd_prefix[po + 1] = S.ffwd_prefix[po] + std::max(1, (lrows + 255) / 256);   // SFR / BWC of the fused solve kernels
             S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 63) / 64) : 0);
-            S.fbwd_prefix[po + 1] = S.fbwd_prefix[po] + std::max(1, (ucols + 255) / 256);
         }
     }
     build_urgent_lists(t, lvl, S);
@@ -332,9 +331,8 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.sn_level, &S.d_sn_level)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_prefix, &S.d_dg_prefix)) return SLUAMD_EHIP;
-    if (upload(H.d_misc, S.ffwd_prefix, &S.d_ffwd_prefix)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.zfwd_prefix, &S.d_zfwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.finv_prefix, &S.d_finv_prefix)) return SLUAMD_EHIP;
-    if (upload(H.d_misc, S.fbwd_prefix, &S.d_fbwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_off, &S.d_dg_off)) return SLUAMD_EHIP;
     return 0;
 }
