@@ -344,12 +344,7 @@ void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
         for (int t = 0; t < 64; ++t) {
             const int row = T.sn_ldiag[k] + strip * 64 + t;
             if (row >= lda) break;
-            int p = BC_HEADER, base = 0, grow = -1;
-            for (int b = 0; b < lsub[0]; ++b) {
-                const int nbrow = lsub[p + 1];
-                if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
-                base += nbrow; p += LB_DESCRIPTOR + nbrow;
-            }
+            const int grow = T.lrow[T.sn_lrow[k] + row];
             const double *L = T.val + T.sn_lval[k] + row;
             for (int r = 0; r < nrhs; ++r) {
                 double acc = 0;
@@ -370,13 +365,8 @@ void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
         const double *Uv = T.val + T.sn_uval[k];
         for (int t = 0; t < ncol; ++t) {
             const int c = chunk * 64 + t;
-            const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
-            int lo = 0, hi = nub;
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
-            const int b = ub0 + lo;
-            const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
-            const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
-            const int ld = ns - (klst - T.uidx[u0 + jj]), cp = T.ucolptr[u0 + jj], gc = T.xsup[T.ub_gid[b]] + jj;
+            const int64_t cidx = T.sn_ucol[k] + c;
+            const int ld = T.ucol_ld[cidx], cp = T.ucol_cp[cidx], gc = T.ucol_gc[cidx];
             for (int r = 0; r < nrhs; ++r) {
                 const double xv = x[gc + (int64_t) r * ldx];
                 for (int i = ld; i < ns; ++i) x[fst + i + (int64_t) r * ldx] -= Uv[cp + (i - ld)] * xv;

@@ -122,6 +122,11 @@ struct DevTables {
     const int *sn_ub_off, *sn_nub;     // U block table range
     const int *sn_rt_off, *sn_nrt;     // row-tile range
     const int *sn_ct_off, *sn_nct;     // col-tile range
+    // flat maps that replace dependent index walks in the latency-bound kernels: global row id of every L slot row
+    // (lrow[sn_lrow[k] + slot row]) and, per non-empty U column in rank order (ucol_*[sn_ucol[k] + c]): value offset inside the
+    // row, leading zeros (ns - segment), global column
+    const int *lrow; const int64_t *sn_lrow;
+    const int *ucol_cp, *ucol_ld, *ucol_gc; const int64_t *sn_ucol;
     // per L block (stored order) + gid-sorted directory
     const int *lb_gid, *lb_nbrow, *lb_rowoff, *lb_lptr;
     const int *lbs_gid, *lbs_idx;

@@ -326,16 +326,7 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
         if (tid < RSv) {
             const int cr = strip * RSv + tid;
             int cp = 0, ld = nsp;
-            if (cr < T.sn_ncolu[k]) {
-                const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
-                int lo = 0, hi = nub;
-                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= cr) lo = mid; else hi = mid; }
-                const int b = ub0 + lo;
-                const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
-                const int jj = T.unzcol[u0 + (cr - T.ub_stcol[b])];
-                ld = ns - (klst - T.uidx[u0 + jj]);
-                cp = T.ucolptr[u0 + jj];
-            }
+            if (cr < T.sn_ncolu[k]) { ld = T.ucol_ld[T.sn_ucol[k] + cr]; cp = T.ucol_cp[T.sn_ucol[k] + cr]; }
             s_cp[tid] = cp; s_ld[tid] = ld;
         }
         __syncthreads();
@@ -536,16 +527,7 @@ __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int uni
     } else {
         const int cr = unit * 16 + li;
         valid = cr < T.sn_ncolu[k];
-        if (valid) {
-            const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
-            int lo = 0, hi = nub;
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= cr) lo = mid; else hi = mid; }
-            const int b = ub0 + lo;
-            const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
-            const int jj = T.unzcol[u0 + (cr - T.ub_stcol[b])];
-            ld = ns - (klst - T.uidx[u0 + jj]);
-            cp = T.ucolptr[u0 + jj];
-        }
+        if (valid) { ld = T.ucol_ld[T.sn_ucol[k] + cr]; cp = T.ucol_cp[T.sn_ucol[k] + cr]; }
     }
 #pragma unroll
     for (int q = 0; q < 64; ++q) {
@@ -995,18 +977,7 @@ __global__ __launch_bounds__(1024) void k_fwd_update(DevTables T, const int *__r
     const int row = T.sn_ldiag[k] + strip * 64 + r;
     const bool rvalid = row < lda;
     const double *L = T.val + T.sn_lval[k] + row;
-    int grow = 0;
-    if (rvalid && part == 0) {
-        // global row id of slot row `row`: rows are listed block after block, 2 descriptor ints per block: walk the (few) blocks
-        const int *lsub = T.lidx + T.sn_lidx[k];
-        int p = BC_HEADER, base = 0;
-        const int nb = lsub[0];
-        for (int b = 0; b < nb; ++b) {
-            const int nbrow = lsub[p + 1];
-            if (row < base + nbrow) { grow = lsub[p + LB_DESCRIPTOR + (row - base)]; break; }
-            base += nbrow; p += LB_DESCRIPTOR + nbrow;
-        }
-    }
+    const int grow = (rvalid && part == 0) ? T.lrow[T.sn_lrow[k] + row] : 0;   // flat map: no walk over the slot's block descriptors
     const int cpp = (ns + 15) >> 4;               // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
     for (int q = 0; q < nrhs; ++q) {
@@ -1051,16 +1022,8 @@ __global__ __launch_bounds__(1024) void k_bwd_update(DevTables T, const int *__r
     const int ncol = min(64, T.sn_ncolu[k] - chunk * 64);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < ncol) {
-        const int c = chunk * 64 + tid;
-        const int ub0 = T.sn_ub_off[k], nub = T.sn_nub[k];
-        int lo = 0, hi = nub;
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (T.ub_stcol[ub0 + mid] <= c) lo = mid; else hi = mid; }
-        const int b = ub0 + lo;
-        const int64_t u0 = T.sn_uidx[k] + T.ub_iukp[b];
-        const int jj = T.unzcol[u0 + (c - T.ub_stcol[b])];
-        s_ld[tid] = ns - (klst - T.uidx[u0 + jj]);
-        s_cp[tid] = T.ucolptr[u0 + jj];
-        s_gc[tid] = T.xsup[T.ub_gid[b]] + jj;
+        const int64_t ci = T.sn_ucol[k] + chunk * 64 + tid;
+        s_ld[tid] = T.ucol_ld[ci]; s_cp[tid] = T.ucol_cp[ci]; s_gc[tid] = T.ucol_gc[ci];
     }
     __syncthreads();
     const double *Uv = T.val + T.sn_uval[k];

@@ -37,6 +37,7 @@ static int build_tables(Handle &H, HostTables &t)
     t.sn_rt_off.resize(ns); t.sn_nrt.assign(ns, 0); t.sn_ct_off.resize(ns); t.sn_nct.assign(ns, 0);
     t.ucolptr.assign(hs.uidx.size(), 0); t.unzcol.assign(hs.uidx.size(), 0);
     t.sn_big.assign(ns, 0);
+    t.sn_lrow.assign(ns, 0); t.sn_ucol.assign(ns, 0);
     H.max_nsupc = 0;
     auto &st = H.st;
     st.flops_schur_padded = st.flops_schur_exact = st.flops_panel = 0;
@@ -48,6 +49,7 @@ static int build_tables(Handle &H, HostTables &t)
         t.sn_lb_off[k] = (int) t.lb_gid.size(); t.sn_ub_off[k] = (int) t.ub_gid.size();
         t.sn_rt_off[k] = (int) t.rtile.size(); t.sn_ct_off[k] = (int) t.ctile.size();
         t.sn_dinv[k] = t.dinv_total; t.sn_inv[k] = t.inv_total;
+        t.sn_lrow[k] = (int64_t) t.lrow.size(); t.sn_ucol[k] = (int64_t) t.ucol_cp.size();
         if (!hs.present[k]) continue;
         H.max_nsupc = std::max(H.max_nsupc, nsupc);
         if (nsupc > 256) { set_error("supernodes wider than 256 columns are not supported yet (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
@@ -75,6 +77,7 @@ static int build_tables(Handle &H, HostTables &t)
             if (b == 0 && u_own && (gid != k || nbrow != nsupc)) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
             if (b > 0 && gid == k) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
             t.lb_gid.push_back(gid); t.lb_nbrow.push_back(nbrow); t.lb_rowoff.push_back(rowoff); t.lb_lptr.push_back(p + LB_DESCRIPTOR);
+            t.lrow.insert(t.lrow.end(), li + p + LB_DESCRIPTOR, li + p + LB_DESCRIPTOR + nbrow);
             dir.emplace_back(gid, b);
             rowoff += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
@@ -102,7 +105,10 @@ static int build_tables(Handle &H, HostTables &t)
                     const int seg = klst - ui[iukp + UB_DESCRIPTOR + jj];
                     if (seg < 0 || seg > nsupc) { set_error("bad U segment"); return SLUAMD_ESTRUCT; }
                     cp[iukp + UB_DESCRIPTOR + jj] = (int) rukp;
-                    if (seg) { nz[iukp + UB_DESCRIPTOR + nc] = jj; ++nc; rukp += seg; ldu = std::max(ldu, seg); exact += seg; }
+                    if (seg) {
+                        t.ucol_cp.push_back((int) rukp); t.ucol_ld.push_back(nsupc - seg); t.ucol_gc.push_back(hs.xsup[jb] + jj);
+                        nz[iukp + UB_DESCRIPTOR + nc] = jj; ++nc; rukp += seg; ldu = std::max(ldu, seg); exact += seg;
+                    }
                 }
                 t.ub_gid.push_back(jb); t.ub_ncols.push_back(nc); t.ub_iukp.push_back(iukp + UB_DESCRIPTOR); t.ub_stcol.push_back(ncol_tot);
                 ncol_tot += nc;
@@ -615,6 +621,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     UP(lbs_gid, t.lbs_gid, int) UP(lbs_idx, t.lbs_idx, int)
     UP(ub_gid, t.ub_gid, int) UP(ub_ncols, t.ub_ncols, int) UP(ub_iukp, t.ub_iukp, int) UP(ub_stcol, t.ub_stcol, int)
     UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4)
+    UP(lrow, t.lrow, int) UP(sn_lrow, t.sn_lrow, int64_t) UP(ucol_cp, t.ucol_cp, int) UP(ucol_ld, t.ucol_ld, int) UP(ucol_gc, t.ucol_gc, int) UP(sn_ucol, t.sn_ucol, int64_t)
 #undef UP
     for (auto &S : H->sched) if (upload_schedule(*H, S)) return SLUAMD_EHIP;
     if (H->fused_pairs) {

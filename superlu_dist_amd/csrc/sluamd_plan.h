@@ -23,6 +23,8 @@ struct HostTables {
     std::vector<int> lb_gid, lb_nbrow, lb_rowoff, lb_lptr, lbs_gid, lbs_idx;
     std::vector<int> ub_gid, ub_ncols, ub_iukp, ub_stcol;
     std::vector<int> ucolptr, unzcol;
+    std::vector<int> lrow, ucol_cp, ucol_ld, ucol_gc;
+    std::vector<int64_t> sn_lrow, sn_ucol;
     std::vector<int4> rtile, ctile;
     std::vector<uint8_t> sn_big;   // 1: supernode uses the 128x128 Schur tile configuration
 };
