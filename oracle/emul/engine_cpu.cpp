@@ -355,7 +355,7 @@ void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
     }
 }
 
-void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs)
+void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int)
 {
     for (int w = 0; w < nwork; ++w) {
         const int ni = find_node(prefix, nn, w);

@@ -406,7 +406,7 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
-        eng::bwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, ldx, nrhs);
+        eng::bwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, ldx, nrhs, S.max_nsupc[l]);
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
         eng::solve_diag(s, false, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;

@@ -259,7 +259,7 @@ void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *pr
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs,
                 int max_nsupc);
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs);
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc);
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz);
 void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
                   double *r_perm, unsigned long long *s_out, double safe1, double safe2);

@@ -912,18 +912,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
 // x_k <- Linv x_k (unit lower) or Uinv x_k: one workgroup per supernode of the level, ONE dense triangular GEMV with the full
 // inverse (what the reference's DiagInv=YES solve does with Linv / Uinv, pdgstrs_lsum.c:414-520) -- no dependent chain
 // inside the block.  Used on XY layers, where the exchanges separate the diagonal solve from the updates.
-template <bool LOWER>
-__global__ __launch_bounds__(1024) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
-                                                     int64_t ldx, int nrhs)
+template <bool LOWER, int NT>   // NT = 1024, or 256 for levels whose supernodes are at most 64 wide (one column quarter)
+__global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
+                                                   int64_t ldx, int nrhs)
 {
     extern __shared__ double xs[];  // ns x nrhs
-    __shared__ double s_part[4][256];
+    __shared__ double s_part[NT / 256][256];
     const int k = nodes[blockIdx.x];
     if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;           // x_k is solved by the owner of the diagonal block
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += 1024) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
     // thread = (row i, quarter of the columns): <= 4 batches of 16 L2 loads; the inverse stores explicit zeros in the other
     // triangle, column blocks entirely outside the wave's rows are skipped
@@ -949,7 +949,11 @@ __global__ __launch_bounds__(1024) void k_solve_diag(DevTables T, const int *__r
         }
         s_part[part][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
-        if (tid < ns) x[fst + tid + (int64_t) q * ldx] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+        if (tid < ns) {
+            double a = s_part[0][tid];
+            if (NT == 1024) a = (a + s_part[1][tid]) + (s_part[NT == 1024 ? 2 : 0][tid] + s_part[NT == 1024 ? 3 : 0][tid]);
+            x[fst + tid + (int64_t) q * ldx] = a;
+        }
         __syncthreads();
     }
 }
@@ -960,25 +964,27 @@ __global__ __launch_bounds__(1024) void k_solve_diag(DevTables T, const int *__r
 //
 // lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414): workgroup = (supernode,
 // 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
-__global__ __launch_bounds__(1024) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                     int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs)
 {
+    constexpr int NP = NT / 64;     // column slices
     extern __shared__ double xk[];  // ns x nrhs
-    __shared__ double s_red[16][64 + 1];
+    __shared__ double s_red[NP][64 + 1];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int strip = blockIdx.x - prefix[ni];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += 1024) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
     const int r = tid & 63, part = tid >> 6;
     const int row = T.sn_ldiag[k] + strip * 64 + r;
     const bool rvalid = row < lda;
     const double *L = T.val + T.sn_lval[k] + row;
     const int grow = (rvalid && part == 0) ? T.lrow[T.sn_lrow[k] + row] : 0;   // flat map: no walk over the slot's block descriptors
-    const int cpp = (ns + 15) >> 4;               // columns per slice
+    const int cpp = (ns + NP - 1) / NP;           // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
     for (int q = 0; q < nrhs; ++q) {
         const double *xq = xk + q * ns;
@@ -999,7 +1005,7 @@ __global__ __launch_bounds__(1024) void k_fwd_update(DevTables T, const int *__r
         if (part == 0 && rvalid) {
             double a = 0.0;
 #pragma unroll
-            for (int p2 = 0; p2 < 16; ++p2) a += s_red[p2][r];
+            for (int p2 = 0; p2 < NP; ++p2) a += s_red[p2][r];
             atomic_sub_f64(x + grow + (int64_t) q * ldx, a);
         }
         __syncthreads();
@@ -1009,12 +1015,14 @@ __global__ __launch_bounds__(1024) void k_fwd_update(DevTables T, const int *__r
 // x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
 // lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
-__global__ __launch_bounds__(1024) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                     int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+template <int NT>   // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block)
+__global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs)
 {
+    constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = (NT == 1024) ? 4 : 1;
     __shared__ int s_cp[64], s_ld[64], s_gc[64];
     __shared__ double s_xc[64];
-    __shared__ double s_red[16][256];
+    __shared__ double s_red[NWV][64 * RB];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int chunk = blockIdx.x - prefix[ni];
@@ -1031,35 +1039,40 @@ __global__ __launch_bounds__(1024) void k_bwd_update(DevTables T, const int *__r
         if (tid < ncol) s_xc[tid] = x[s_gc[tid] + (int64_t) r * ldx];      // solved x of this chunk's columns: one gather
         __syncthreads();
         {
-            double a[4] = {0, 0, 0, 0};
-            double uv[4][4];
+            double a[RB];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = wave * 4 + cc;
-                const bool cok = c < ncol;
-                const int ld = cok ? s_ld[c] : ns;
-                const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
+            for (int q = 0; q < RB; ++q) a[q] = 0.0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = lane + 64 * q;
-                    uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+            for (int cb = 0; cb < CPW; cb += 4) {
+                double uv[4][RB];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = wave * CPW + cb + cc;
+                    const bool cok = c < ncol;
+                    const int ld = cok ? s_ld[c] : ns;
+                    const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        const int i = lane + 64 * q;
+                        uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = wave * CPW + cb + cc;
+                    const double xv = (c < ncol) ? s_xc[c] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) a[q] += uv[cc][q] * xv;
                 }
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = wave * 4 + cc;
-                const double xv = (c < ncol) ? s_xc[c] : 0.0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] += uv[cc][q] * xv;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s_red[wave][lane + 64 * q] = a[q];
+            for (int q = 0; q < RB; ++q) s_red[wave][lane + 64 * q] = a[q];
         }
         __syncthreads();
         if (tid < ns) {
             double sv = 0.0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) sv += s_red[w][tid];
+            for (int w = 0; w < NWV; ++w) sv += s_red[w][tid];
             if (sv != 0.0) atomic_sub_f64(x + fst + tid + (int64_t) r * ldx, sv);
         }
         __syncthreads();
@@ -1138,9 +1151,9 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_full_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     return 0;
 }
 
@@ -1190,18 +1203,27 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
 {
     if (nn <= 0) return;
     const size_t lds = (size_t) mx * nrhs * sizeof(double);
-    if (lower) hipLaunchKernelGGL(k_solve_diag<true>, dim3(nn), dim3(1024), lds, s, T, nodes, x, ldx, nrhs);
-    else hipLaunchKernelGGL(k_solve_diag<false>, dim3(nn), dim3(1024), lds, s, T, nodes, x, ldx, nrhs);
+    if (mx <= 64) {   // levels of narrow supernodes (the bottom of the elimination DAG: thousands of them): small workgroups
+        if (lower) hipLaunchKernelGGL((k_solve_diag<true, 256>), dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
+        else hipLaunchKernelGGL((k_solve_diag<false, 256>), dim3(nn), dim3(256), lds, s, T, nodes, x, ldx, nrhs);
+    } else {
+        if (lower) hipLaunchKernelGGL((k_solve_diag<true, 1024>), dim3(nn), dim3(1024), lds, s, T, nodes, x, ldx, nrhs);
+        else hipLaunchKernelGGL((k_solve_diag<false, 1024>), dim3(nn), dim3(1024), lds, s, T, nodes, x, ldx, nrhs);
+    }
 }
 
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_fwd_update, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
+    if (nwork <= 0) return;
+    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
+    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
 }
 
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs)
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_bwd_update, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
+    if (nwork <= 0) return;
+    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
+    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
 }
 
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)
