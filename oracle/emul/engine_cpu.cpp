@@ -28,8 +28,11 @@ static int find_node(const int *prefix, int nn, int id)
 
 int setup() { return 0; }
 
-void diag_lu(hipStream_t, const DevTables &T, const int *nodes, int nn, int, int replace_tiny, double thresh, int *info)
+static void inv_block(const DevTables &T, int k, int typ, int b);
+
+void diag_lu(hipStream_t, const DevTables &T, const int *nodes, int nn, int, int flags, double thresh, int *info)
 {
+    const int replace_tiny = flags & 1;
     for (int i = 0; i < nn; ++i) {
         const int k = nodes[i];
         if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
@@ -46,7 +49,33 @@ void diag_lu(hipStream_t, const DevTables &T, const int *nodes, int nn, int, int
                 for (int r = j + 1; r < ns; ++r) A[r + (size_t) c * lda] -= A[r + (size_t) j * lda] * u;
             }
         }
+        for (int typ = 0; typ < 2; ++typ) for (int b = 0; b < (ns + DB - 1) / DB; ++b) inv_block(T, k, typ, b);   // contract: dinv of the owned blocks
     }
+}
+
+static void inv_block(const DevTables &T, int k, int typ, int b)
+{
+    const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB, o = b * DB;
+    const int lda = T.sn_dlda[k];
+    const double *A = T.val + T.sn_dptr[k];
+    double Bs[DB][DB], X[DB][DB];
+    for (int i = 0; i < DB; ++i)
+        for (int c = 0; c < DB; ++c) {
+            double v = (i == c) ? 1.0 : 0.0;
+            if (o + i < ns && o + c < ns && i <= c) {
+                if (typ == 0) v = A[o + i + (size_t) (o + c) * lda];
+                else if (i < c) v = A[o + c + (size_t) (o + i) * lda];
+            }
+            Bs[i][c] = v;
+        }
+    for (int c = 0; c < DB; ++c)
+        for (int i = c; i >= 0; --i) {
+            double a = (i == c) ? 1.0 : 0.0;
+            for (int jj = i + 1; jj <= c; ++jj) a -= Bs[i][jj] * X[jj][c];
+            X[i][c] = a / Bs[i][i];
+        }
+    double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB;
+    for (int c = 0; c < DB; ++c) for (int i = 0; i < DB; ++i) dst[c * DB + i] = (i <= c) ? X[i][c] : 0.0;
 }
 
 void diag_inv(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask)
@@ -56,27 +85,8 @@ void diag_inv(hipStream_t, const DevTables &T, const int *nodes, const int *pref
         const int k = nodes[ni];
         if (!(T.sn_flags[k] & SNF_HAS_DIAG)) continue;
         const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB;
-        const int rem = task - prefix[ni], typ = rem / nblk, b = rem - typ * nblk, o = b * DB;
-        const int lda = T.sn_dlda[k];
-        const double *A = T.val + T.sn_dptr[k];
-        double Bs[DB][DB], X[DB][DB];
-        for (int i = 0; i < DB; ++i)
-            for (int c = 0; c < DB; ++c) {
-                double v = (i == c) ? 1.0 : 0.0;
-                if (o + i < ns && o + c < ns && i <= c) {
-                    if (typ == 0) v = A[o + i + (size_t) (o + c) * lda];
-                    else if (i < c) v = A[o + c + (size_t) (o + i) * lda];
-                }
-                Bs[i][c] = v;
-            }
-        for (int c = 0; c < DB; ++c)
-            for (int i = c; i >= 0; --i) {
-                double a = (i == c) ? 1.0 : 0.0;
-                for (int jj = i + 1; jj <= c; ++jj) a -= Bs[i][jj] * X[jj][c];
-                X[i][c] = a / Bs[i][i];
-            }
-        double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB;
-        for (int c = 0; c < DB; ++c) for (int i = 0; i < DB; ++i) dst[c * DB + i] = (i <= c) ? X[i][c] : 0.0;
+        const int rem = task - prefix[ni], typ = rem / nblk;
+        inv_block(T, k, typ, rem - typ * nblk);
     }
 }
 

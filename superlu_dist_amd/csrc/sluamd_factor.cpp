@@ -69,12 +69,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
-        eng::diag_lu(ps, T, nodes, nn, mx, H->opt.replace_tiny_pivot, thresh, H->d_info);                    // Local_Dgstrf2
+        eng::diag_lu(ps, T, nodes, nn, mx, (H->opt.replace_tiny_pivot ? 1 : 0) | (H->env.diag_v1 ? 2 : 0), thresh, H->d_info);   // Local_Dgstrf2 (+ dinv of the owned blocks)
         if (xy) {   // dDiagFactIBCast (dtrfCommWrapper.c:32-118): diagonal blocks down the process column and along the process row
             eng::pack_diag(ps, T, nodes, S.d_dg_prefix + po, S.d_dg_off + po, nn, S.dg_prefix[po + nn], H->d_val + S.dg_stage_off[l]);
             if (!rc_x) rc_x = exchange(H, S.x_diag_send[l], S.x_diag_recv[l], ps);
         }
-        eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);
+        if (xy) eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);   // column / row peers invert the diagonal blocks they received
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
         if (gemm_panels) {   // 1 x 1 layer: full inverses (also what the solve uses) + chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
             eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);

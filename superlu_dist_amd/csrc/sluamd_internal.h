@@ -194,7 +194,7 @@ struct Handle {
     int Pz = 1, myz = 0;
     // environment switches, read ONCE at creation (they may differ per handle)
     struct Env {
-        bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, trsm_panels = false;
+        bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, trsm_panels = false, diag_v1 = false;
         int fuse_min_pct = 75, fuse_max_prev = 1, lookahead_max_strips = 1 << 30, reserve_cus = 0;
     } env;
     // device arenas
@@ -244,7 +244,9 @@ struct Handle {
 // ------------------------------------------------------------------------------------------------
 namespace eng {
 int setup();   // one-time function attributes (dynamic LDS limits)
-void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
+// flags: bit 0 = ReplaceTinyPivot, bit 1 = round-1 right-looking kernel.  Also leaves the inverted 32 x 32 diagonal sub-blocks of the
+// owned blocks in T.dinv (what diag_inv computes for blocks received from another rank)
+void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int flags, double thresh, int *info);
 void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask);
 // L strips (work units [0, nl)) and U column strips ([nl, nl + nu)); strip height rs = 32 or 64
 void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu,

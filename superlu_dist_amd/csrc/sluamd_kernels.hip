@@ -218,6 +218,200 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
     }
 }
 
+// ---- diagonal block LU, Crout form ------------------------------------------------------------------------------------
+// Same arithmetic contract as k_diag_lu (Local_Dgstrf2, pdgstrf2.c:508-601: unpivoted, tiny-pivot replacement, zero-pivot
+// info), organised so that nothing on the critical path of the factorisation waits on read-modify-write round trips:
+// per 32-column step jb
+//   A  column panel  C = A[jb:, jb:jb+32] - L[jb:, 0:jb] U[0:jb, jb:jb+32]      left-looking, fp64 MFMA, result -> LDS
+//   B  32 x 32 head factored in registers by one wave (wave_lu32)
+//   C  Uinv11 = inv(U11), LinvT11 = inv(L11^T) by two other waves (also written to T.dinv: k_diag_inv's job for the owner)
+//   D  L21 = C21 Uinv11 (MFMA, in LDS), panel -> memory
+//   E  row panel     R = A[jb:jb+32, jb+32:] - L[jb:jb+32, 0:jb] U[0:jb, jb+32:]  (MFMA), U12 = Linv11 R (MFMA) -> memory
+// Every element of the block is written exactly once.  MFMA operand roles as in k_schur: D[i][j], i = column, j = row,
+// so that the 16 fast lanes run along rows (contiguous in the column-major block).
+template <int NSMAX>
+__global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__restrict__ nodes,
+                                                  int replace_tiny, double thresh, int *__restrict__ info)
+{
+    constexpr int ldp = NSMAX + 1;               // column panel in LDS: element (r, c) at Ps[c * ldp + r]
+    constexpr int UST = NSMAX + 2 - DB;          // k-fastest stage of the U block column: (kk, c) at Ush[c * UST + kk], UST == 2 mod 32
+    constexpr int USZ = (DB * UST > 64 * 34) ? DB * UST : 64 * 34;
+    extern __shared__ double dsm[];
+    double *Ps = dsm;                            // DB * ldp
+    double *Ush = Ps + DB * ldp;                 // USZ: phase A stage -- reused as Bs[2][32 * 33] in phase C and Rs[64 * 34] in phase E
+    double *Uis = Ush + USZ;                     // Uinv11: (kk, n) at Uis[n * 34 + kk]
+    double *Lis = Uis + DB * 34;                 // Linv11: (i, kk) at Lis[kk * 48 + i]
+    __shared__ double s_rinv[DB];
+    const int k = nodes[blockIdx.x];
+    if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_dlda[k];
+    double *A = T.val + T.sn_dptr[k];
+    const int nblk = (ns + DB - 1) / DB;
+    double *dinv = T.dinv + T.sn_dinv[k];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int jb = 0; jb < ns; jb += DB) {
+        const int nb = min(DB, ns - jb), m = ns - jb, nc = m - nb;
+        // ---- A: column panel, left-looking ----
+        if (jb > 0) {
+            for (int idx = tid; idx < jb * DB; idx += 256) {     // stage U[0:jb, jb:jb+32] (kk fastest: coalesced)
+                const int kk = idx % jb, c = idx / jb;
+                Ush[c * UST + kk] = (c < nb) ? A[kk + (size_t) (jb + c) * lda] : 0.0;
+            }
+        }
+        __syncthreads();
+        {
+            const int nrb = (m + 15) >> 4;
+            for (int rb0 = wave; rb0 < nrb; rb0 += 8) {          // up to two 16-row blocks per wave and pass
+                const int rb1 = rb0 + 4;
+                const bool has1 = rb1 < nrb;
+                d4 a00 = (d4){0.0, 0.0, 0.0, 0.0}, a01 = a00, a10 = a00, a11 = a00;
+                const int r0 = min(16 * rb0 + li, m - 1), r1 = min(16 * rb1 + li, m - 1);
+                const double *L0 = A + jb + r0, *L1 = A + jb + r1;
+#pragma unroll 4
+                for (int q = 0; q < jb / 4; ++q) {
+                    const int kk = 4 * q + lk;
+                    const double u0 = Ush[li * UST + kk], u1 = Ush[(16 + li) * UST + kk];
+                    const double l0 = L0[(size_t) kk * lda];
+                    const double l1 = has1 ? L1[(size_t) kk * lda] : 0.0;
+                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l0, a00, 0, 0, 0);
+                    a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l0, a01, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l1, a10, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l1, a11, 0, 0, 0);
+                }
+                auto put = [&](int rb, const d4 &h0, const d4 &h1) {
+                    const int row = 16 * rb + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = lk + 4 * r;
+                        if (row < m && c < nb) Ps[c * ldp + row] = A[jb + row + (size_t) (jb + c) * lda] - h0[r];
+                        if (row < m && 16 + c < nb) Ps[(16 + c) * ldp + row] = A[jb + row + (size_t) (jb + 16 + c) * lda] - h1[r];
+                    }
+                };
+                put(rb0, a00, a01);
+                if (has1) put(rb1, a10, a11);
+            }
+        }
+        __syncthreads();
+        // ---- B: head ----
+        if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info, s_rinv);
+        __syncthreads();
+        // ---- C: inverses of the head's triangles (identity-padded past nb), kept in LDS and written to T.dinv ----
+        if (wave == 1 || wave == 2) {
+            const int typ = wave - 1;            // 0: U11 ; 1: L11^T (unit)
+            const int c = lane & 31;
+            double *Bs = Ush + typ * DB * (DB + 1);              // the stage of phase A is free again: B(i, jj) at Bs[i * 33 + jj]
+            for (int e = lane; e < DB * DB; e += 64) {
+                const int i = e >> 5, jj = e & 31;
+                double v = (i == jj) ? 1.0 : 0.0;
+                if (i < nb && jj < nb && i <= jj) {
+                    if (typ == 0) v = Ps[jj * ldp + i];          // U(i, jj)
+                    else if (i < jj) v = Ps[i * ldp + jj];       // L(jj, i) = (L^T)(i, jj)
+                }
+                Bs[i * (DB + 1) + jj] = v;
+            }
+            // (same wave wrote and reads Bs: LDS operations of a wave complete in order)
+            if (lane < 32) {
+                double xi[DB];
+#pragma unroll
+                for (int i = 0; i < DB; ++i) xi[i] = 0.0;
+#pragma unroll
+                for (int i = DB - 1; i >= 0; --i) {
+                    double a = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int jj = i + 1; jj < DB; ++jj) a -= Bs[i * (DB + 1) + jj] * xi[jj];
+                    xi[i] = (i <= c) ? a / Bs[i * (DB + 1) + i] : 0.0;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                double *dst = dinv + (size_t) (typ * nblk + jb / DB) * DB * DB + c * DB;     // D(kk, cc) at [cc * 32 + kk]
+#pragma unroll
+                for (int i = 0; i < DB; ++i) {
+                    dst[i] = xi[i];
+                    if (typ == 0) Uis[c * 34 + i] = xi[i];       // Uinv(kk = i, n = c)
+                    else Lis[i * 48 + c] = xi[i];                // inv(L^T)(i, c) = Linv(c, i): Lis[kk = i][row = c]
+                }
+            }
+        }
+        __syncthreads();
+        // ---- D: L21 = C21 Uinv11 ----
+        if (nc > 0) {
+            const int nrb = (nc + 15) >> 4;
+            for (int rb = wave; rb < nrb; rb += 4) {
+                const int row = DB + 16 * rb + li;
+                double bfr[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bfr[q] = (row < m) ? Ps[(4 * q + lk) * ldp + row] : 0.0;
+                d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Uis[li * 34 + 4 * q + lk], bfr[q], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Uis[(16 + li) * 34 + 4 * q + lk], bfr[q], a1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row < m) { Ps[(lk + 4 * r) * ldp + row] = a0[r]; Ps[(16 + lk + 4 * r) * ldp + row] = a1[r]; }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int idx = tid; idx < m * nb; idx += 256) { const int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
+        // ---- E: row panel, 64 columns at a time: R = A12 - L_row U_above (MFMA), U12 = Linv11 R (MFMA) ----
+        double *Rs = Ush;                        // (row, col) at Rs[col * 34 + row]
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int cw = 16 * wave;            // this wave's 16 columns of the chunk
+            const int colg = jb + nb + c0 + cw;  // first global column (inside the block)
+            const bool wact = c0 + cw < nc;
+            d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+            if (wact) {
+                const int cl = min(colg + li, ns - 1);
+                const double *Uc = A + (size_t) cl * lda;          // U(kk, col li): 4 consecutive kk per lane group
+                const double *Lr0 = A + jb + li, *Lr1 = A + jb + min(16 + li, nb - 1);
+#pragma unroll 4
+                for (int q = 0; q < jb / 4; ++q) {
+                    const int kk = 4 * q + lk;
+                    const double u = Uc[kk];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, Lr0[(size_t) kk * lda], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, Lr1[(size_t) kk * lda], acc1, 0, 0, 0);
+                }
+                // R = A12 - acc -> Rs (this wave's 16 columns)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = lk + 4 * r;
+                    double v0 = 0.0, v1 = 0.0;
+                    if (colg + col < ns && li < nb) v0 = A[jb + li + (size_t) (colg + col) * lda] - acc0[r];
+                    if (colg + col < ns && 16 + li < nb) v1 = A[jb + 16 + li + (size_t) (colg + col) * lda] - acc1[r];
+                    Rs[(cw + col) * 34 + li] = v0;
+                    Rs[(cw + col) * 34 + 16 + li] = v1;
+                }
+            }
+            __syncthreads();
+            if (wact) {
+                // U12(i', col) = sum_k Linv(i', k) R(k, col): Aop(i = col, k) = R(k, col), Bop(k, j = i') = Linv(i', k)
+                d4 o0 = (d4){0.0, 0.0, 0.0, 0.0}, o1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double rf = Rs[(cw + li) * 34 + 4 * q + lk];
+                    o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + li], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + 16 + li], o1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = colg + lk + 4 * r;
+                    if (col < ns) {
+                        if (li < nb) A[jb + li + (size_t) col * lda] = o0[r];
+                        if (16 + li < nb) A[jb + 16 + li + (size_t) col * lda] = o1[r];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // Inverses of the 32x32 diagonal sub-blocks of U_kk (typ 0) and L_kk^T (typ 1, unit), identity-padded past
 // ns, written to T.dinv; 4 sub-blocks per 128-thread workgroup, one thread per column of an inverse
 // (back substitution with the block and the private solution column staged in LDS).
@@ -272,6 +466,49 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
         double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB + c * DB;
 #pragma unroll
         for (int i = 0; i < DB; ++i) dst[i] = xi[i];
+    }
+}
+
+// the same inverses for the OWNED diagonal blocks of a node list, one workgroup per supernode (companion of the
+// right-looking k_diag_lu; k_diag_lu2 writes them itself)
+__global__ __launch_bounds__(256) void k_diag_inv_all(DevTables T, const int *__restrict__ nodes)
+{
+    __shared__ double Bs[8][DB * (DB + 1)];
+    const int k = nodes[blockIdx.x];
+    if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;
+    const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB, lda = T.sn_dlda[k];
+    const double *A = T.val + T.sn_dptr[k];
+    const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
+    for (int t0 = 0; t0 < 2 * nblk; t0 += 8) {
+        const int task = t0 + g;
+        const bool valid = task < 2 * nblk;
+        const int typ = task / nblk, b = task - typ * nblk, o = b * DB;
+        if (valid)
+            for (int i = 0; i < DB; ++i) {
+                double v = (i == c) ? 1.0 : 0.0;
+                if (o + i < ns && o + c < ns && i <= c) {
+                    if (typ == 0) v = A[o + i + (size_t) (o + c) * lda];
+                    else if (i < c) v = A[o + c + (size_t) (o + i) * lda];
+                }
+                Bs[g][i * (DB + 1) + c] = v;
+            }
+        __syncthreads();
+        if (valid) {
+            double xi[DB];
+#pragma unroll
+            for (int i = 0; i < DB; ++i) xi[i] = 0.0;
+#pragma unroll
+            for (int i = DB - 1; i >= 0; --i) {
+                double a = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int jj = i + 1; jj < DB; ++jj) a -= Bs[g][i * (DB + 1) + jj] * xi[jj];
+                xi[i] = (i <= c) ? a / Bs[g][i * (DB + 1) + i] : 0.0;
+            }
+            double *dst = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk + b) * DB * DB + c * DB;
+#pragma unroll
+            for (int i = 0; i < DB; ++i) dst[i] = xi[i];
+        }
+        __syncthreads();
     }
 }
 
@@ -1150,6 +1387,8 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_full_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
@@ -1157,12 +1396,26 @@ int setup()
     return 0;
 }
 
+template <int NSMAX> static size_t diag_lu2_lds()
+{
+    const size_t usz = (size_t) DB * (NSMAX + 2 - DB) > 64 * 34 ? (size_t) DB * (NSMAX + 2 - DB) : 64 * 34;
+    return sizeof(double) * ((size_t) DB * (NSMAX + 1) + usz + DB * 34 + DB * 48);
+}
+
 void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx, int replace_tiny, double thresh, int *info)
 {
     if (nn <= 0) return;
+    if (replace_tiny >= 0 && !(replace_tiny & 2)) {   // bit 1 of the flag selects the round-1 right-looking kernel (SLUAMD_DIAG_V1)
+        if (mx <= 64) hipLaunchKernelGGL(k_diag_lu2<64>, dim3(nn), dim3(256), diag_lu2_lds<64>(), s, T, nodes, replace_tiny & 1, thresh, info);
+        else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu2<128>, dim3(nn), dim3(256), diag_lu2_lds<128>(), s, T, nodes, replace_tiny & 1, thresh, info);
+        else hipLaunchKernelGGL(k_diag_lu2<256>, dim3(nn), dim3(256), diag_lu2_lds<256>(), s, T, nodes, replace_tiny & 1, thresh, info);
+        return;
+    }
+    replace_tiny &= 1;
     if (mx <= 64) hipLaunchKernelGGL(k_diag_lu<64>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
     else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
     else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
+    hipLaunchKernelGGL(k_diag_inv_all, dim3(nn), dim3(256), 0, s, T, nodes);     // the contract: dinv of the owned blocks
 }
 
 void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask)
