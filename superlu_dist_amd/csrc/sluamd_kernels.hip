@@ -235,10 +235,10 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
 {
     constexpr int ldp = NSMAX + 1;               // column panel in LDS: element (r, c) at Ps[c * ldp + r]
     constexpr int UST = NSMAX + 2 - DB;          // k-fastest stage of the U block column: (kk, c) at Ush[c * UST + kk], UST == 2 mod 32
-    constexpr int USZ = (DB * UST > 64 * 34) ? DB * UST : 64 * 34;
+    constexpr int USZ = (DB * UST > 128 * 34) ? DB * UST : 128 * 34;
     extern __shared__ double dsm[];
     double *Ps = dsm;                            // DB * ldp
-    double *Ush = Ps + DB * ldp;                 // USZ: phase A stage -- reused as Bs[2][32 * 33] in phase C and Rs[64 * 34] in phase E
+    double *Ush = Ps + DB * ldp;                 // USZ: phase A stage -- reused as Bs[2][32 * 33] in phase C and Rs[128 * 34] in phase E
     double *Uis = Ush + USZ;                     // Uinv11: (kk, n) at Uis[n * 34 + kk]
     double *Lis = Uis + DB * 34;                 // Linv11: (i, kk) at Lis[kk * 48 + i]
     __shared__ double s_rinv[DB];
@@ -269,24 +269,45 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
                 d4 a00 = (d4){0.0, 0.0, 0.0, 0.0}, a01 = a00, a10 = a00, a11 = a00;
                 const int r0 = min(16 * rb0 + li, m - 1), r1 = min(16 * rb1 + li, m - 1);
                 const double *L0 = A + jb + r0, *L1 = A + jb + r1;
-#pragma unroll 4
-                for (int q = 0; q < jb / 4; ++q) {
-                    const int kk = 4 * q + lk;
-                    const double u0 = Ush[li * UST + kk], u1 = Ush[(16 + li) * UST + kk];
-                    const double l0 = L0[(size_t) kk * lda];
-                    const double l1 = has1 ? L1[(size_t) kk * lda] : 0.0;
-                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l0, a00, 0, 0, 0);
-                    a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l0, a01, 0, 0, 0);
-                    a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, l1, a10, 0, 0, 0);
-                    a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, l1, a11, 0, 0, 0);
+                const int nq = jb / 4;
+#pragma unroll
+                for (int hk = 0; hk < 2; ++hk) {                 // K in two halves: all L fragments of a half are loaded in ONE batch
+                    if (hk * 28 < nq) {
+                        double lf0[28], lf1[28];
+#pragma unroll
+                        for (int qq = 0; qq < 28; ++qq) {
+                            const int kk = 4 * (hk * 28 + qq) + lk;
+                            const bool ok = hk * 28 + qq < nq;
+                            lf0[qq] = ok ? L0[(size_t) kk * lda] : 0.0;
+                            lf1[qq] = (ok && has1) ? L1[(size_t) kk * lda] : 0.0;
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 28; ++qq) {
+                            if (hk * 28 + qq < nq) {
+                                const int kk = 4 * (hk * 28 + qq) + lk;
+                                const double u0 = Ush[li * UST + kk], u1 = Ush[(16 + li) * UST + kk];
+                                a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, lf0[qq], a00, 0, 0, 0);
+                                a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, lf0[qq], a01, 0, 0, 0);
+                                a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, lf1[qq], a10, 0, 0, 0);
+                                a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, lf1[qq], a11, 0, 0, 0);
+                            }
+                        }
+                    }
                 }
                 auto put = [&](int rb, const d4 &h0, const d4 &h1) {
                     const int row = 16 * rb + li;
+                    double av[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = lk + 4 * r;
-                        if (row < m && c < nb) Ps[c * ldp + row] = A[jb + row + (size_t) (jb + c) * lda] - h0[r];
-                        if (row < m && 16 + c < nb) Ps[(16 + c) * ldp + row] = A[jb + row + (size_t) (jb + 16 + c) * lda] - h1[r];
+                        av[r] = (row < m && c < nb) ? A[jb + row + (size_t) (jb + c) * lda] : 0.0;
+                        av[4 + r] = (row < m && 16 + c < nb) ? A[jb + row + (size_t) (jb + 16 + c) * lda] : 0.0;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = lk + 4 * r;
+                        if (row < m && c < nb) Ps[c * ldp + row] = av[r] - h0[r];
+                        if (row < m && 16 + c < nb) Ps[(16 + c) * ldp + row] = av[4 + r] - h1[r];
                     }
                 };
                 put(rb0, a00, a01);
@@ -357,55 +378,85 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
         __syncthreads();
 #pragma unroll 8
         for (int idx = tid; idx < m * nb; idx += 256) { const int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
-        // ---- E: row panel, 64 columns at a time: R = A12 - L_row U_above (MFMA), U12 = Linv11 R (MFMA) ----
-        double *Rs = Ush;                        // (row, col) at Rs[col * 34 + row]
-        for (int c0 = 0; c0 < nc; c0 += 64) {
-            const int cw = 16 * wave;            // this wave's 16 columns of the chunk
-            const int colg = jb + nb + c0 + cw;  // first global column (inside the block)
-            const bool wact = c0 + cw < nc;
-            d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-            if (wact) {
-                const int cl = min(colg + li, ns - 1);
-                const double *Uc = A + (size_t) cl * lda;          // U(kk, col li): 4 consecutive kk per lane group
-                const double *Lr0 = A + jb + li, *Lr1 = A + jb + min(16 + li, nb - 1);
-#pragma unroll 4
-                for (int q = 0; q < jb / 4; ++q) {
-                    const int kk = 4 * q + lk;
-                    const double u = Uc[kk];
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, Lr0[(size_t) kk * lda], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u, Lr1[(size_t) kk * lda], acc1, 0, 0, 0);
-                }
-                // R = A12 - acc -> Rs (this wave's 16 columns)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int col = lk + 4 * r;
-                    double v0 = 0.0, v1 = 0.0;
-                    if (colg + col < ns && li < nb) v0 = A[jb + li + (size_t) (colg + col) * lda] - acc0[r];
-                    if (colg + col < ns && 16 + li < nb) v1 = A[jb + 16 + li + (size_t) (colg + col) * lda] - acc1[r];
-                    Rs[(cw + col) * 34 + li] = v0;
-                    Rs[(cw + col) * 34 + 16 + li] = v1;
-                }
-            }
+        // ---- E: row panel, 128 columns per pass (two 16-column blocks per wave): R = A12 - L_row U_above (MFMA), U12 = Linv11 R ----
+        if (nc > 0) {
+            __syncthreads();                     // the panel has been stored: Ps is free
+            double *Lrs = Ps;                    // L[jb:jb+32, 0:jb] staged once per step: (row, kk) at Lrs[kk * 33 + row]
+            for (int idx = tid; idx < jb * DB; idx += 256) { const int row = idx & 31, kk = idx >> 5; Lrs[kk * 33 + row] = A[jb + row + (size_t) kk * lda]; }
             __syncthreads();
-            if (wact) {
-                // U12(i', col) = sum_k Linv(i', k) R(k, col): Aop(i = col, k) = R(k, col), Bop(k, j = i') = Linv(i', k)
-                d4 o0 = (d4){0.0, 0.0, 0.0, 0.0}, o1 = (d4){0.0, 0.0, 0.0, 0.0};
+            double *Rs = Ush;                    // (row, col) at Rs[col * 34 + row], 128 columns
+            const int nq = jb / 4;
+            for (int c0 = 0; c0 < nc; c0 += 128) {
+                const int cwA = 16 * wave, cwB = 64 + 16 * wave;          // this wave's two 16-column blocks of the pass
+                const int cgA = jb + nb + c0 + cwA, cgB = jb + nb + c0 + cwB;
+                const bool actA = c0 + cwA < nc, actB = c0 + cwB < nc;
+                d4 aA0 = (d4){0.0, 0.0, 0.0, 0.0}, aA1 = aA0, aB0 = aA0, aB1 = aA0;
+                if (actA) {
+                    const double *UcA = A + (size_t) min(cgA + li, ns - 1) * lda, *UcB = A + (size_t) min(cgB + li, ns - 1) * lda;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const double rf = Rs[(cw + li) * 34 + 4 * q + lk];
-                    o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + li], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + 16 + li], o1, 0, 0, 0);
-                }
+                    for (int hk = 0; hk < 2; ++hk) {
+                        if (hk * 28 < nq) {
+                            double ufA[28], ufB[28];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int col = colg + lk + 4 * r;
-                    if (col < ns) {
-                        if (li < nb) A[jb + li + (size_t) col * lda] = o0[r];
-                        if (16 + li < nb) A[jb + 16 + li + (size_t) col * lda] = o1[r];
+                            for (int qq = 0; qq < 28; ++qq) {
+                                const int kk = 4 * (hk * 28 + qq) + lk;
+                                const bool ok = hk * 28 + qq < nq;
+                                ufA[qq] = ok ? UcA[kk] : 0.0;
+                                ufB[qq] = (ok && actB) ? UcB[kk] : 0.0;
+                            }
+#pragma unroll
+                            for (int qq = 0; qq < 28; ++qq) {
+                                if (hk * 28 + qq < nq) {
+                                    const int kk = 4 * (hk * 28 + qq) + lk;
+                                    const double l0 = Lrs[kk * 33 + li], l1 = Lrs[kk * 33 + 16 + li];
+                                    aA0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufA[qq], l0, aA0, 0, 0, 0);
+                                    aA1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufA[qq], l1, aA1, 0, 0, 0);
+                                    aB0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufB[qq], l0, aB0, 0, 0, 0);
+                                    aB1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufB[qq], l1, aB1, 0, 0, 0);
+                                }
+                            }
+                        }
                     }
+                    auto putR = [&](int cw, int cg, const d4 &h0, const d4 &h1) {     // R = A12 - acc -> Rs
+                        double av[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = lk + 4 * r;
+                            av[r] = (cg + col < ns) ? A[jb + li + (size_t) (cg + col) * lda] : 0.0;
+                            av[4 + r] = (cg + col < ns) ? A[jb + 16 + li + (size_t) (cg + col) * lda] : 0.0;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = lk + 4 * r;
+                            Rs[(cw + col) * 34 + li] = (cg + col < ns) ? av[r] - h0[r] : 0.0;
+                            Rs[(cw + col) * 34 + 16 + li] = (cg + col < ns) ? av[4 + r] - h1[r] : 0.0;
+                        }
+                    };
+                    putR(cwA, cgA, aA0, aA1);
+                    if (actB) putR(cwB, cgB, aB0, aB1);
                 }
+                __syncthreads();
+                if (actA) {
+                    // U12(i', col) = sum_k Linv(i', k) R(k, col): Aop(i = col, k) = R(k, col), Bop(k, j = i') = Linv(i', k)
+                    auto solve = [&](int cw, int cg) {
+                        d4 o0 = (d4){0.0, 0.0, 0.0, 0.0}, o1 = o0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const double rf = Rs[(cw + li) * 34 + 4 * q + lk];
+                            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + li], o0, 0, 0, 0);
+                            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + 16 + li], o1, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int col = cg + lk + 4 * r;
+                            if (col < ns) { A[jb + li + (size_t) col * lda] = o0[r]; A[jb + 16 + li + (size_t) col * lda] = o1[r]; }
+                        }
+                    };
+                    solve(cwA, cgA);
+                    if (actB) solve(cwB, cgB);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         __threadfence_block();
         __syncthreads();
@@ -1389,6 +1440,7 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_full_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
@@ -1398,7 +1450,7 @@ int setup()
 
 template <int NSMAX> static size_t diag_lu2_lds()
 {
-    const size_t usz = (size_t) DB * (NSMAX + 2 - DB) > 64 * 34 ? (size_t) DB * (NSMAX + 2 - DB) : 64 * 34;
+    const size_t usz = (size_t) DB * (NSMAX + 2 - DB) > 128 * 34 ? (size_t) DB * (NSMAX + 2 - DB) : 128 * 34;
     return sizeof(double) * ((size_t) DB * (NSMAX + 1) + usz + DB * 34 + DB * 48);
 }
 
