@@ -442,6 +442,8 @@ void xseg_copy(hipStream_t, double *x, int64_t ldx, int nrhs, const int *runs, i
             }
 }
 
+int diag_profile(unsigned long long *out8, int) { for (int i = 0; i < 8; ++i) out8[i] = 0; return 0; }
+
 int mfma_selftest(const double *A, const double *B, double *D)
 {
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double a = 0; for (int k = 0; k < 4; ++k) a += A[i * 4 + k] * B[k * 16 + j]; D[i * 16 + j] = a; }

@@ -556,6 +556,9 @@ int sluamd_set_profile(sluamd_handle_t h, int on)
     return 0;
 }
 
+// debug hook (not in the public header): accumulated phase timers of k_diag_lu2 [A, B, C, D+store, E] in shader clock ticks
+int sluamd_debug_diag_profile(unsigned long long *out8, int reset) { return eng::diag_profile(out8, reset); }
+
 // test hook: MFMA fp64 fragment layout check
 int sluamd_mfma_selftest(const double *A, const double *B, double *D)
 {

@@ -274,6 +274,7 @@ void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *p
 void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs /*device: (row0, nrows, rows before) triples*/, int nruns, int64_t total,
                double *buf, int mode);
 int mfma_selftest(const double *A, const double *B, double *D);   // host pointers
+int diag_profile(unsigned long long *out8, int reset);            // debug: phase timers of k_diag_lu2
 // complex16 twins (1 x 1 x 1 grids)
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);

@@ -229,6 +229,10 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
 //   E  row panel     R = A[jb:jb+32, jb+32:] - L[jb:jb+32, 0:jb] U[0:jb, jb+32:]  (MFMA), U12 = Linv11 R (MFMA) -> memory
 // Every element of the block is written exactly once.  MFMA operand roles as in k_schur: D[i][j], i = column, j = row,
 // so that the 16 fast lanes run along rows (contiguous in the column-major block).
+// phase timers of k_diag_lu2 (shader clock ticks accumulated by thread 0 of every 256-wide block; read by sluamd_debug_diag_profile)
+__device__ unsigned long long g_diag_prof[8];
+#define DPROF(slot) do { if (NSMAX == 256 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_diag_prof[slot], t_ - tprev); tprev = t_; } } while (0)
+
 template <int NSMAX>
 __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__restrict__ nodes,
                                                   int replace_tiny, double thresh, int *__restrict__ info)
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
     double *dinv = T.dinv + T.sn_dinv[k];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
+    unsigned long long tprev = __builtin_readcyclecounter();
     for (int jb = 0; jb < ns; jb += DB) {
         const int nb = min(DB, ns - jb), m = ns - jb, nc = m - nb;
         // ---- A: column panel, left-looking ----
@@ -315,9 +320,11 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
             }
         }
         __syncthreads();
+        DPROF(0);
         // ---- B: head ----
         if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info, s_rinv);
         __syncthreads();
+        DPROF(1);
         // ---- C: inverses of the head's triangles (identity-padded past nb), kept in LDS and written to T.dinv ----
         if (wave == 1 || wave == 2) {
             const int typ = wave - 1;            // 0: U11 ; 1: L11^T (unit)
@@ -355,6 +362,7 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
             }
         }
         __syncthreads();
+        DPROF(2);
         // ---- D: L21 = C21 Uinv11 ----
         if (nc > 0) {
             const int nrb = (nc + 15) >> 4;
@@ -378,6 +386,7 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
         __syncthreads();
 #pragma unroll 8
         for (int idx = tid; idx < m * nb; idx += 256) { const int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
+        DPROF(3);
         // ---- E: row panel, 128 columns per pass (two 16-column blocks per wave): R = A12 - L_row U_above (MFMA), U12 = Linv11 R ----
         if (nc > 0) {
             __syncthreads();                     // the panel has been stored: Ps is free
@@ -460,6 +469,7 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
         }
         __threadfence_block();
         __syncthreads();
+        DPROF(4);
     }
 }
 
@@ -1564,6 +1574,13 @@ void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs,
     if (total <= 0 || nruns <= 0) return;
     const int64_t nb = (total * nrhs + 255) / 256;
     hipLaunchKernelGGL(k_xseg_copy, dim3((unsigned) (nb < 4096 ? nb : 4096)), dim3(256), 0, s, x, ldx, nrhs, runs, nruns, total, buf, mode);
+}
+
+int diag_profile(unsigned long long *out8, int reset)
+{
+    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag_prof), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_prof), z, sizeof(z))); }
+    return 0;
 }
 
 int mfma_selftest(const double *A, const double *B, double *D)
