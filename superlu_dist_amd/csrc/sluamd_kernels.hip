@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
 {
     constexpr int ldp = NSMAX + 1;               // column panel in LDS: element (r, c) at Ps[c * ldp + r]
     constexpr int UST = NSMAX + 2 - DB;          // k-fastest stage of the U block column: (kk, c) at Ush[c * UST + kk], UST == 2 mod 32
-    constexpr int USZ = (DB * UST > 128 * 34) ? DB * UST : 128 * 34;
+    constexpr int USZ = (DB * UST > 4800) ? DB * UST : 4800;       // >= Rs[128 * 34] and the phase-C scratch (4 x 32 x 33 + 2 x 16 x 17)
     extern __shared__ double dsm[];
     double *Ps = dsm;                            // DB * ldp
     double *Ush = Ps + DB * ldp;                 // USZ: phase A stage -- reused as Bs[2][32 * 33] in phase C and Rs[128 * 34] in phase E
@@ -328,8 +328,9 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
         // ---- C: inverses of the head's triangles (identity-padded past nb), kept in LDS and written to T.dinv ----
         if (wave == 1 || wave == 2) {
             const int typ = wave - 1;            // 0: U11 ; 1: L11^T (unit)
-            const int c = lane & 31;
             double *Bs = Ush + typ * DB * (DB + 1);              // the stage of phase A is free again: B(i, jj) at Bs[i * 33 + jj]
+            double *Xs = Ush + (2 + typ) * DB * (DB + 1);        // X = inv(B): X(i, jj) at Xs[i * 33 + jj]
+            double *Tm = Ush + 4 * DB * (DB + 1) + typ * 16 * 17;
             for (int e = lane; e < DB * DB; e += 64) {
                 const int i = e >> 5, jj = e & 31;
                 double v = (i == jj) ? 1.0 : 0.0;
@@ -338,27 +339,47 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
                     else if (i < jj) v = Ps[i * ldp + jj];       // L(jj, i) = (L^T)(i, jj)
                 }
                 Bs[i * (DB + 1) + jj] = v;
+                Xs[i * (DB + 1) + jj] = 0.0;
             }
-            // (same wave wrote and reads Bs: LDS operations of a wave complete in order)
+            // (one wave: its LDS operations complete in order)
+            // inv of the two 16 x 16 diagonal blocks: lane c < 32 solves column c % 16 of block c / 16 in registers
             if (lane < 32) {
-                double xi[DB];
+                const int o = lane & 16, cc = lane & 15;
+                double xi[16];
 #pragma unroll
-                for (int i = 0; i < DB; ++i) xi[i] = 0.0;
+                for (int i = 0; i < 16; ++i) xi[i] = 0.0;
 #pragma unroll
-                for (int i = DB - 1; i >= 0; --i) {
-                    double a = (i == c) ? 1.0 : 0.0;
+                for (int i = 15; i >= 0; --i) {
+                    double a = (i == cc) ? 1.0 : 0.0;
 #pragma unroll
-                    for (int jj = i + 1; jj < DB; ++jj) a -= Bs[i * (DB + 1) + jj] * xi[jj];
-                    xi[i] = (i <= c) ? a / Bs[i * (DB + 1) + i] : 0.0;
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int jj = i + 1; jj < 16; ++jj) a -= Bs[(o + i) * (DB + 1) + o + jj] * xi[jj];
+                    xi[i] = (i <= cc) ? a / Bs[(o + i) * (DB + 1) + o + i] : 0.0;
                 }
-                double *dst = dinv + (size_t) (typ * nblk + jb / DB) * DB * DB + c * DB;     // D(kk, cc) at [cc * 32 + kk]
 #pragma unroll
-                for (int i = 0; i < DB; ++i) {
-                    dst[i] = xi[i];
-                    if (typ == 0) Uis[c * 34 + i] = xi[i];       // Uinv(kk = i, n = c)
-                    else Lis[i * 48 + c] = xi[i];                // inv(L^T)(i, c) = Linv(c, i): Lis[kk = i][row = c]
-                }
+                for (int i = 0; i < 16; ++i) Xs[(o + i) * (DB + 1) + o + cc] = xi[i];
+            }
+            // X01 = -X00 (B01 X11): two 16 x 16 x 16 products on MFMA (whole wave)
+            {
+                d4 t = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)     // T(i, j) = sum_k B01(i, k) X11(k, j)
+                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(Bs[li * (DB + 1) + 16 + 4 * q + lk], Xs[(16 + 4 * q + lk) * (DB + 1) + 16 + li], t, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tm[(lk + 4 * r) * 17 + li] = t[r];
+                d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)     // X01(i, j) = -sum_k X00(i, k) T(k, j)
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[li * (DB + 1) + 4 * q + lk], Tm[(4 * q + lk) * 17 + li], x, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xs[(lk + 4 * r) * (DB + 1) + 16 + li] = -x[r];
+            }
+            // outputs: T.dinv block D(kk, cc) at [cc * 32 + kk]; Uis[n * 34 + kk] = Uinv(kk, n); Lis[kk * 48 + row] = Linv(row, kk)
+            double *dst = dinv + (size_t) (typ * nblk + jb / DB) * DB * DB;
+            for (int e = lane; e < DB * DB; e += 64) {
+                const int kk = e & 31, c2 = e >> 5;
+                const double v = Xs[kk * (DB + 1) + c2];
+                dst[c2 * DB + kk] = v;
+                if (typ == 0) Uis[c2 * 34 + kk] = v; else Lis[kk * 48 + c2] = v;
             }
         }
         __syncthreads();
@@ -1460,7 +1481,7 @@ int setup()
 
 template <int NSMAX> static size_t diag_lu2_lds()
 {
-    const size_t usz = (size_t) DB * (NSMAX + 2 - DB) > 128 * 34 ? (size_t) DB * (NSMAX + 2 - DB) : 128 * 34;
+    const size_t usz = (size_t) DB * (NSMAX + 2 - DB) > 4800 ? (size_t) DB * (NSMAX + 2 - DB) : 4800;
     return sizeof(double) * ((size_t) DB * (NSMAX + 1) + usz + DB * 34 + DB * 48);
 }
 
