@@ -64,7 +64,8 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
-    auto panel = [&](int l) {
+    // panel(l) in two parts: A needs only the diagonal blocks of level l to be up to date, B the whole panels
+    auto panelA = [&](int l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
@@ -73,22 +74,30 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         if (xy) {   // dDiagFactIBCast (dtrfCommWrapper.c:32-118): diagonal blocks down the process column and along the process row
             eng::pack_diag(ps, T, nodes, S.d_dg_prefix + po, S.d_dg_off + po, nn, S.dg_prefix[po + nn], H->d_val + S.dg_stage_off[l]);
             if (!rc_x) rc_x = exchange(H, S.x_diag_send[l], S.x_diag_recv[l], ps);
+            eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);   // column / row peers invert the diagonal blocks they received
         }
-        if (xy) eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);   // column / row peers invert the diagonal blocks they received
+        if (gemm_panels) eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);   // 1 x 1 layer: Linv / Uinv (the solve uses them too)
+        ev_end(H, H->ev_panel, H->ev_panel_used, ps);
+        H->st.num_launches += 1 + (gemm_panels ? 1 : 0) + (xy ? 2 : 0);
+    };
+    auto panelB = [&](int l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        const int *nodes = S.d_nodes + n0;
+        const int mx = S.max_nsupc[l];
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
-        if (gemm_panels) {   // 1 x 1 layer: full inverses (also what the solve uses) + chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
-            eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);
-            eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu);
-        } else eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);
+        ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
+        if (gemm_panels) eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu);   // chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
+        else eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);
         if (xy && !rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // dIBcastRecvLPanel / dIBcastRecvUPanel
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);
-        H->st.num_launches += 2 + (nl + nu > 0) + (gemm_panels ? 1 : 0);
+        H->st.num_launches += (nl + nu > 0);
     };
     if (lookahead && S.nlevels) {
         hipEvent_t e = next_event(H);    // the side stream must see everything queued so far on the main stream
         hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
     }
     bool panel_queued = false;           // panel(l) already queued on ps by the previous level's look-ahead
+    hipEvent_t pending_eu = nullptr;
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
         const int *nodes = S.d_nodes + n0;
@@ -97,7 +106,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                 hipEvent_t e = next_event(H);
                 hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
             }
-            panel(l);
+            panelA(l); panelB(l);
         }
         panel_queued = false;
         if (lookahead) {
@@ -114,16 +123,16 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         // K-fused pairs: a deferred supernode runs only its urgent tiles (everything the next level's panels need), so the
         // urgent pass is needed even without look-ahead; the rest of its update is accumulated by its partner's tiles
         const bool urgent_pass = split || (T.defer && S.lvl_defer[l]);
-        hipEvent_t eu = nullptr;
-        // pass 0: urgent tiles (explicit lists); pass 1: the rest (full grids, urgent tiles skipped)
-        for (int pass = urgent_pass ? 0 : 1; pass < 2; ++pass) {
+        // pass 0: urgent tiles whose destination is a diagonal block of level l+1; pass 1: the other urgent tiles (explicit
+        // lists); pass 2: the rest (full grids, urgent tiles skipped)
+        for (int pass = urgent_pass ? 0 : 2; pass < 3; ++pass) {
             for (int g = 0; g < 2; ++g) {
                 const int cnt = g == 0 ? nbig : nn - nbig;
                 if (!cnt) continue;
                 const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
                 const int *gn = nodes + (g == 0 ? 0 : nbig);
-                if (pass == 0) {
-                    const int u0 = S.u_off[2 * l + g], nu = S.u_off[2 * l + g + 1] - u0;
+                if (pass < 2) {
+                    const int u0 = S.u_off[(2 * l + g) * 2 + pass], nu = S.u_off[(2 * l + g) * 2 + pass + 1] - u0;
                     if (nu) schur(s, g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1);
                     continue;
                 }
@@ -144,14 +153,25 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                     }
                 }
             }
-            if (pass == 0 && split) { eu = next_event(H); hipEventRecord(eu, s); }
+            if (split && pass == 0) {
+                // the diagonal blocks of level l+1 are complete (and, by stream order, so is everything of level l-1):
+                // diag_lu(l+1) + its inverses run on the side stream while the other urgent tiles -- too few to fill the
+                // machine at the top of the tree -- are still in flight
+                hipEvent_t e0 = next_event(H);
+                hipEventRecord(e0, s); hipStreamWaitEvent(ps, e0, 0);
+                panelA(l + 1);
+            }
+            if (split && pass == 1) {
+                // all urgent tiles done: the panel solves of level l+1 may run; they overlap with the rest of level l as far as
+                // the machine has room (a host-staged exchange inside panelB blocks the host, not the GPU: queue the rest first)
+                hipEvent_t eu = next_event(H);
+                hipEventRecord(eu, s);
+                pending_eu = eu;
+            }
         }
         if (split) {
-            // panel(l+1) may start once the urgent tiles of level l (and, by stream order, the rest of level l-1) are
-            // complete; it then overlaps with the rest of level l, which is already queued on the main stream (a
-            // host-staged exchange inside panel() blocks the host, not the GPU)
-            hipStreamWaitEvent(ps, eu, 0);
-            panel(l + 1);
+            hipStreamWaitEvent(ps, pending_eu, 0);
+            panelB(l + 1);
             panel_queued = true;
         }
         if (rc_x) return rc_x;

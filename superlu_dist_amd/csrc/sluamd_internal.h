@@ -165,8 +165,8 @@ struct LevelSched {
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
-    std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level [big group | small group]
-    std::vector<int> u_off;         // [2*nlevels+1] offsets into ulist (2 groups per level)
+    std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level and tile-size group [diagonal-block destinations | other urgent tiles]
+    std::vector<int> u_off;         // [4*nlevels+1] offsets into ulist: index (2*level + group) * 2 + part
     // ---- XY block-cyclic exchange plan (empty on a 1 x 1 layer): per level, in ascending supernode order ----
     std::vector<int> dg_prefix;               // per node (lvl_poff layout): 1024-double chunks of the own diagonal blocks to pack
     std::vector<int64_t> dg_off;              // ... and their offsets inside the level's diagonal staging range

@@ -209,28 +209,38 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
 
 static void build_urgent_lists(const HostTables &t, const std::vector<int> &lvl, LevelSched &S)
 {
+    // urgent tiles of level l = the tiles that update a panel of level l + 1, in two parts per tile-size group:
+    //   part 0: destination is the DIAGONAL block of a level-(l+1) supernode  -> diag_lu(l+1) may start after these alone
+    //   part 1: the rest of the block row / block column of those supernodes  -> the panel solves of l+1 wait for these too
     S.sn_level = lvl;
-    S.u_off.assign(2 * S.nlevels + 1, 0);
+    S.u_off.assign(4 * S.nlevels + 1, 0);
     std::vector<uint8_t> rflag, cflag;
     for (int l = 0; l < S.nlevels; ++l) {
         const int nbig = S.n_big[l];
-        for (int g = 0; g < 2; ++g) {
-            const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
-            for (int i = b; i < e; ++i) {
-                const int k = S.nodes[i];
-                const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
-                if (!nrt || !nct) continue;
-                rflag.assign(nrt, 0); cflag.assign(nct, 0);
-                bool any = false;
-                for (int r = 0; r < nrt; ++r) { const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x]; rflag[r] = (lvl[ib] == l + 1); any |= rflag[r]; }
-                for (int c = 0; c < nct; ++c) { const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x]; cflag[c] = (lvl[jb] == l + 1); any |= cflag[c]; }
-                if (!any) continue;
-                for (int r = 0; r < nrt; ++r)
-                    for (int c = 0; c < nct; ++c)
-                        if (rflag[r] || cflag[c]) S.ulist.push_back(make_int4(k, r, c, 0));
+        for (int g = 0; g < 2; ++g)
+            for (int part = 0; part < 2; ++part) {
+                const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
+                for (int i = b; i < e; ++i) {
+                    const int k = S.nodes[i];
+                    const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
+                    if (!nrt || !nct) continue;
+                    rflag.assign(nrt, 0); cflag.assign(nct, 0);
+                    bool any = false;
+                    for (int r = 0; r < nrt; ++r) { const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x]; rflag[r] = (lvl[ib] == l + 1); any |= rflag[r]; }
+                    for (int c = 0; c < nct; ++c) { const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x]; cflag[c] = (lvl[jb] == l + 1); any |= cflag[c]; }
+                    if (!any) continue;
+                    for (int r = 0; r < nrt; ++r) {
+                        const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x];
+                        for (int c = 0; c < nct; ++c) {
+                            if (!(rflag[r] || cflag[c])) continue;
+                            const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x];
+                            const bool diag = (ib == jb);      // both flags set: the diagonal block of a level-(l+1) supernode
+                            if ((part == 0) == diag) S.ulist.push_back(make_int4(k, r, c, 0));
+                        }
+                    }
+                }
+                S.u_off[(2 * l + g) * 2 + part + 1] = (int) S.ulist.size();
             }
-            S.u_off[2 * l + g + 1] = (int) S.ulist.size();
-        }
     }
 }
 
