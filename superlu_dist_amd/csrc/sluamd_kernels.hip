@@ -924,17 +924,20 @@ __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__re
     }
 }
 
-// Linv / Uinv of the owned diagonal blocks of a node list: work unit = (supernode, typ, 64-row strip of the identity)
-__global__ __launch_bounds__(256) void k_full_inv(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn)
+// Linv / Uinv of the owned diagonal blocks of a node list: work unit = (supernode, typ, 16-row strip of the identity) = one
+// wave with 56 KB of LDS, so that the workgroups fit beside a resident Schur workgroup (a 64-row strip needs a whole CU and
+// would wait for the Schur kernel to drain)
+constexpr int FIS = 16;
+__global__ __launch_bounds__(FIS * 4) void k_full_inv(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn)
 {
     extern __shared__ double sm[];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int ns = T.xsup[k + 1] - T.xsup[k];
-    const int per = (ns + 63) / 64;
+    const int per = (ns + FIS - 1) / FIS;
     const int u = blockIdx.x - prefix[ni];
-    if (u < per) panel_trsm_body<2, 64>(T, k, u, sm);
-    else panel_trsm_body<3, 64>(T, k, u - per, sm);
+    if (u < per) panel_trsm_body<2, FIS>(T, k, u, sm);
+    else panel_trsm_body<3, FIS>(T, k, u - per, sm);
 }
 
 // ---- iterative refinement (pdgsrfs3d, SRC/double/pdgsrfs.c:345-510) --------------------------------
@@ -1532,7 +1535,7 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int mx)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_full_inv, dim3(nwork), dim3(256), trsm_lds_bytes(64, (mx + 31) & ~31), s, T, nodes, prefix, nn);
+    if (nwork > 0) hipLaunchKernelGGL(k_full_inv, dim3(nwork), dim3(FIS * 4), trsm_lds_bytes(FIS, (mx + 31) & ~31), s, T, nodes, prefix, nn);
 }
 
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int mx)

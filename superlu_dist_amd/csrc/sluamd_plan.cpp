@@ -293,7 +293,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 63) / 64;
             S.zfwd_prefix[po + 1] = S.zfwd_prefix[po] + (lrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
-            S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 63) / 64) : 0);
+            S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 15) / 16) : 0);    // FIS = 16-row identity strips
         }
     }
     build_urgent_lists(t, lvl, S);
