@@ -1,8 +1,18 @@
 #!/usr/bin/env python3
-"""Build profiles/rNN_pmc_schur.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite) of
+"""Build profiles/rNN_pmc_schur.json (bench.py reads profiles/r02_pmc_schur.json) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite) of
 `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` (3 factorisations per run).
 usage: make_pmc_json.py fetch.db write.db n_factorisations "source text" > profiles/r01_pmc_schur.json"""
-import json, re, sqlite3, sys
+import hashlib, json, os, re, sqlite3, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """the same hash bench.py checks: the traffic figure is only valid for the kernels it was measured on"""
+    h = hashlib.sha256()
+    for f in ("sluamd_kernels.hip", "sluamd_zkernels.inc"):
+        h.update(open(os.path.join(ROOT, "superlu_dist_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def total(path, counter):
@@ -20,6 +30,7 @@ nf = int(sys.argv[3])
 fetch_b, write_b = fetch_kb * 1024.0, write_kb * 1024.0
 out = {
     "source": sys.argv[4],
+    "kernel_source_sha16": kernel_source_hash(),
     "kernel": "k_schur<128,128,8> + k_schur<64,64,4> (all launches of a factorisation)",
     "factorisations_in_run": nf, "launches_in_run": nl,
     "fetch_bytes_per_factorisation_raw": fetch_b / nf, "write_bytes_per_factorisation_raw": write_b / nf,
