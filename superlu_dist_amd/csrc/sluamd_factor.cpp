@@ -260,9 +260,7 @@ static int reduce_ancestors(Handle *H, int zl)
                 if ((rc = ensure_xtmp(H, std::min(CH, r.second)))) return rc;
                 if ((rc = c->recv(H->d_xtmp, len * 8, peer))) return rc;
                 if ((rc = c->end(s))) return rc;
-                eng::axpy(s, len, 1.0, H->d_xtmp, H->d_val + r.first + o);
-                if (!c->stream_ordered()) continue;
-                HIPCHK(hipStreamSynchronize(s));   // the staging buffer is reused by the next chunk's receive
+                eng::axpy(s, len, 1.0, H->d_xtmp, H->d_val + r.first + o);   // the next chunk's receive into the staging buffer is ordered behind this on s
             } else {
                 if ((rc = c->send(H->d_val + r.first + o, len * 8, peer))) return rc;
                 if ((rc = c->end(s))) return rc;

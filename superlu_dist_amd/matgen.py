@@ -112,6 +112,37 @@ def random_unsym(n, density=0.02, seed=0, diag_scale=None):
     return n, np.cumsum(rowptr).astype(np.int32), cols.astype(np.int32), vals
 
 
+def stencil3d_unsym(N, drop=0.3, seed=0, reach=2):
+    """Irregular unsymmetric-PATTERN matrix on an N^3 grid (stand-in for unstructured FE matrices such as SuiteSparse
+    audikw_1, which is not available offline): every grid point couples to a random subset of the points within `reach`
+    grid steps along each axis (entries dropped independently with probability `drop`, so A(i,j) != 0 does not imply
+    A(j,i) != 0), uniform(-1, 1) values, diagonally dominant."""
+    rng = np.random.default_rng(seed)
+    n = N * N * N
+    idx = np.arange(n)
+    ii, jj, kk = idx // (N * N), (idx // N) % N, idx % N
+    rows, cols = [], []
+    for di in range(-reach, reach + 1):
+        for dj in range(-reach, reach + 1):
+            for dk in range(-reach, reach + 1):
+                if (di, dj, dk) == (0, 0, 0) or abs(di) + abs(dj) + abs(dk) > reach:
+                    continue
+                ok = (ii + di >= 0) & (ii + di < N) & (jj + dj >= 0) & (jj + dj < N) & (kk + dk >= 0) & (kk + dk < N)
+                ok &= rng.random(n) >= drop
+                rows.append(idx[ok]); cols.append(((ii + di) * N + (jj + dj)) * N + (kk + dk))
+                cols[-1] = cols[-1][ok]
+    r = np.concatenate(rows); c = np.concatenate(cols)
+    v = rng.uniform(-1.0, 1.0, r.size)
+    rowsum = np.zeros(n); np.add.at(rowsum, r, np.abs(v))
+    colsum = np.zeros(n); np.add.at(colsum, c, np.abs(v))
+    d = np.maximum(rowsum, colsum) + 1.0
+    rows = np.concatenate([r, idx]); cols = np.concatenate([c, idx]); vals = np.concatenate([v, d])
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64); np.add.at(rowptr, rows + 1, 1)
+    return n, np.cumsum(rowptr).astype(np.int32), cols.astype(np.int32), vals
+
+
 def write_triplet_dat(path, n, rowptr, colind, vals):
     """'.dat' triplet file the reference reads (SRC/double/dreadtriple.c:43-92, complex: SRC/complex16/zreadtriple.c):
     header 'm n nnz', 1-based, 'row col value' or 'row col re im'."""

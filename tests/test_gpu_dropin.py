@@ -87,6 +87,22 @@ def test_reference_pipeline_on_process_grids(grid, kind, tmp_path):
     assert abs(res_amd - res_ref) < 1e-10
 
 
+@pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF)), reason="prebuilt reference binaries not shipped")
+def test_irregular_unsymmetric_pattern_at_scale(tmp_path):
+    """Stand-in for BASELINE.json configs[3] (SuiteSparse audikw_1 is not available offline): an irregular, unsymmetric-PATTERN
+    3-D operator (n = 46 656, ~17 entries per row, random drops) through the reference's own MC64 + MMD(A'+A) + symbfact
+    (irregular supernodes up to 256 wide, ragged U skylines), with pdgstrf3d and every pdgstrs3d bound to the library;
+    residual parity with the untouched reference."""
+    n, rp, ci, v = matgen.stencil3d_unsym(36, drop=0.3, seed=1)
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    args = ["-r", "1", "-c", "1", "-d", "1", "-Q", "1", "-o", "none", str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(AMD, args, tmp_path, threads="8", extra_env={"SLUAMD_BIND_DEBUG": "1"})
+    res_ref, info_ref = _run(REF, args, tmp_path, threads="32")
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10
+
+
 @pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF)), reason="prebuilt reference binaries not shipped")
 @pytest.mark.parametrize("kind", ["zgrid_nd", "zunsym_defaults"])
 def test_reference_pipeline_with_our_pzgstrf3d(kind, tmp_path):
