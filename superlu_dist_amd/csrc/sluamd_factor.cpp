@@ -347,20 +347,18 @@ int ensure_inv(Handle *H)
     return 0;
 }
 
-struct XRuns { int *d = nullptr; int n = 0; int64_t total = 0; };
-
-// transient device image of a run list: (row0, nrows, rows before) triples; freed by the caller (to_free)
-static int make_runs(hipStream_t s, const std::vector<std::pair<int, int>> &runs, XRuns &o, std::vector<int *> &to_free)
+// device image of a run list: (row0, nrows, rows before) triples, uploaded once per list and kept with the handle
+static int runs_on_device(Handle *H, const LevelSched::XSeg &m, const int **d)
 {
-    std::vector<int> h;
-    int64_t tot = 0;
-    for (auto &r : runs) { h.push_back(r.first); h.push_back(r.second); h.push_back((int) tot); tot += r.second; }
-    o.n = (int) runs.size(); o.total = tot; o.d = nullptr;
-    if (h.empty()) return 0;
-    HIPCHK(hipMalloc((void **) &o.d, sizeof(int) * h.size()));
-    to_free.push_back(o.d);
-    HIPCHK(hipMemcpyAsync(o.d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // h goes out of scope
+    if (!m.d_runs) {
+        std::vector<int> h;
+        int64_t tot = 0;
+        for (auto &r : m.runs) { h.push_back(r.first); h.push_back(r.second); h.push_back((int) tot); tot += r.second; }
+        int *p = nullptr;
+        if (upload(H->d_misc, h, &p)) return SLUAMD_EHIP;
+        m.d_runs = p;
+    }
+    *d = m.d_runs;
     return 0;
 }
 
@@ -375,23 +373,27 @@ static int xseg_exchange(Handle *H, double *d_x, int64_t ldx, int nrhs, const st
     for (auto &m : rcv) need += m.total * nrhs;
     int rc = ensure_xtmp(H, need);
     if (rc) return rc;
-    std::vector<XRuns> rs(snd.size()), rr(rcv.size());
-    std::vector<int *> to_free;
-    auto mk = [&](const LevelSched::XSeg &m, XRuns &o) -> int { return make_runs(s, m.runs, o, to_free); };
     int64_t off = 0;
     Comm *c = H->comm;
-    for (size_t i = 0; i < snd.size(); ++i) { if ((rc = mk(snd[i], rs[i]))) return rc; }
-    for (size_t i = 0; i < rcv.size(); ++i) { if ((rc = mk(rcv[i], rr[i]))) return rc; }
     std::vector<int64_t> so(snd.size()), ro(rcv.size());
-    for (size_t i = 0; i < snd.size(); ++i) { so[i] = off; eng::xseg_copy(s, d_x, ldx, nrhs, rs[i].d, rs[i].n, rs[i].total, H->d_xtmp + off, pack_mode); off += snd[i].total * nrhs; }
+    for (size_t i = 0; i < snd.size(); ++i) {
+        const int *dr;
+        if ((rc = runs_on_device(H, snd[i], &dr))) return rc;
+        so[i] = off;
+        eng::xseg_copy(s, d_x, ldx, nrhs, dr, (int) snd[i].runs.size(), snd[i].total, H->d_xtmp + off, pack_mode);
+        off += snd[i].total * nrhs;
+    }
     for (size_t i = 0; i < rcv.size(); ++i) { ro[i] = off; off += rcv[i].total * nrhs; }
     if ((rc = c->begin())) return rc;
     for (size_t i = 0; i < snd.size(); ++i) if ((rc = c->send(H->d_xtmp + so[i], snd[i].total * nrhs * 8, snd[i].peer))) return rc;
     for (size_t i = 0; i < rcv.size(); ++i) if ((rc = c->recv(H->d_xtmp + ro[i], rcv[i].total * nrhs * 8, rcv[i].peer))) return rc;
     if ((rc = c->end(s))) return rc;
-    for (size_t i = 0; i < rcv.size(); ++i) eng::xseg_copy(s, d_x, ldx, nrhs, rr[i].d, rr[i].n, rr[i].total, H->d_xtmp + ro[i], unpack_mode);
-    HIPCHK(hipStreamSynchronize(s));   // the staging buffer and the run lists are reused by the next exchange
-    for (int *p : to_free) hipFree(p);
+    for (size_t i = 0; i < rcv.size(); ++i) {
+        const int *dr;
+        if ((rc = runs_on_device(H, rcv[i], &dr))) return rc;
+        eng::xseg_copy(s, d_x, ldx, nrhs, dr, (int) rcv[i].runs.size(), rcv[i].total, H->d_xtmp + ro[i], unpack_mode);
+    }
+    HIPCHK(hipStreamSynchronize(s));   // the staging buffer is reused by the next exchange
     return 0;
 }
 
@@ -456,7 +458,7 @@ int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
 // rows of the forests of Z levels [a0, a1) whose x entries this rank holds in role `role`:
 //   0 = lsum accumulators / b of the process row (k % Pr == myrow), 1 = solved x of the process column (k % Pc == mycol),
 //   2 = diagonal owner only
-static void forest_runs(const Handle *H, int a0, int a1, int role, LevelSched::XSeg &out)
+static void forest_runs_build(const Handle *H, int a0, int a1, int role, LevelSched::XSeg &out)
 {
     const HostStruct &hs = H->hs;
     const Grid &g = H->grid;
@@ -474,6 +476,32 @@ static void forest_runs(const Handle *H, int a0, int a1, int role, LevelSched::X
         else out.runs.emplace_back(row0, nr);
         out.total += nr;
     }
+}
+
+// cached: the forests of a handle never change.  role 3 = diagonal owner on the levels this layer factors (where b is
+// consumed and x is final)
+static const LevelSched::XSeg &forest_runs(Handle *H, int a0, int role)
+{
+    const int key = a0 * 8 + role;
+    auto it = H->xseg_cache.find(key);
+    if (it != H->xseg_cache.end()) return it->second;
+    LevelSched::XSeg seg;
+    const int nzl = (int) H->sched.size();
+    if (role == 3) {
+        const Grid &g = H->grid;
+        std::vector<int> ks;
+        for (int zl = 0; zl < nzl; ++zl) if (H->z_active[zl]) for (int k : H->forest_nodes[zl]) if (g.krow(k) == g.r && g.kcol(k) == g.c) ks.push_back(k);
+        std::sort(ks.begin(), ks.end());
+        for (int k : ks) {
+            const int row0 = H->hs.xsup[k], n1 = H->hs.xsup[k + 1] - row0;
+            if (!seg.runs.empty() && seg.runs.back().first + seg.runs.back().second == row0) seg.runs.back().second += n1; else seg.runs.emplace_back(row0, n1);
+            seg.total += n1;
+        }
+    } else forest_runs_build(H, a0, nzl, role, seg);
+    const LevelSched::XSeg &c = H->xseg_cache.emplace(key, std::move(seg)).first->second;
+    const int *dr;
+    runs_on_device(H, c, &dr);      // upload now: copies of the cached entry (with a peer filled in) share the device image
+    return c;
 }
 
 // pdgstrs3d on the grid: d_x holds the COMPLETE permuted right-hand side on entry (replicated) and the complete solution
@@ -497,24 +525,14 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
         // keep b only where it is consumed: at the diagonal owner, on the layer that factors the forest; everything else
         // starts as a zero accumulator (rows of other layers' forests are never touched)
         {
-            LevelSched::XSeg keep;
-            std::vector<int> ks;
-            for (int zl = 0; zl < nzl; ++zl) if (H->z_active[zl]) for (int k : H->forest_nodes[zl]) if (g.krow(k) == g.r && g.kcol(k) == g.c) ks.push_back(k);
-            std::sort(ks.begin(), ks.end());
-            for (int k : ks) {
-                const int row0 = H->hs.xsup[k], n1 = H->hs.xsup[k + 1] - row0;
-                if (!keep.runs.empty() && keep.runs.back().first + keep.runs.back().second == row0) keep.runs.back().second += n1; else keep.runs.emplace_back(row0, n1);
-                keep.total += n1;
-            }
+            const LevelSched::XSeg &keep = forest_runs(H, 0, 3);
             if ((rc = ensure_xtmp(H, std::max<int64_t>(keep.total * nr, 1)))) return rc;
-            XRuns kr;
-            std::vector<int *> to_free;
-            if ((rc = make_runs(s, keep.runs, kr, to_free))) return rc;
-            eng::xseg_copy(s, x, ldx, nr, kr.d, kr.n, kr.total, H->d_xtmp, 0);
+            const int *dr;
+            if ((rc = runs_on_device(H, keep, &dr))) return rc;
+            eng::xseg_copy(s, x, ldx, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 0);
             for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.n, s));
-            eng::xseg_copy(s, x, ldx, nr, kr.d, kr.n, kr.total, H->d_xtmp, 1);
+            eng::xseg_copy(s, x, ldx, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 1);
             HIPCHK(hipStreamSynchronize(s));
-            for (int *p : to_free) hipFree(p);
         }
         // ---- forward sweep, leaves to root ----
         for (int zl = 0; zl < nzl; ++zl) {
@@ -522,10 +540,9 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
             if (g.z % step) break;
             if (H->z_active[zl] && (rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
             if (zl + 1 < nzl) {
-                LevelSched::XSeg seg;
-                forest_runs(H, zl + 1, nzl, 0, seg);
                 const bool receiver = (g.z % (2 * step)) == 0;
                 if (receiver && g.z + step >= g.Pz) continue;
+                LevelSched::XSeg seg = forest_runs(H, zl + 1, 0);        // (copy shares the cached device image)
                 seg.peer = g.rank_of(g.r, g.c, receiver ? g.z + step : g.z - step);
                 std::vector<LevelSched::XSeg> one(1, seg), none;
                 if (seg.total && (rc = receiver ? xseg_exchange(H, x, ldx, nr, none, 0, one, 2, s) : xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s))) return rc;
@@ -536,10 +553,9 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
             const int step = 1 << zl;
             if (g.z % step) continue;
             if (zl + 1 < nzl) {
-                LevelSched::XSeg seg;
-                forest_runs(H, zl + 1, nzl, 1, seg);
                 const bool sender = (g.z % (2 * step)) == 0;
                 if (!(sender && g.z + step >= g.Pz)) {
+                    LevelSched::XSeg seg = forest_runs(H, zl + 1, 1);
                     seg.peer = g.rank_of(g.r, g.c, sender ? g.z + step : g.z - step);
                     std::vector<LevelSched::XSeg> one(1, seg), none;
                     if (seg.total && (rc = sender ? xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldx, nr, none, 0, one, 1, s))) return rc;
@@ -550,25 +566,14 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
         // ---- assemble: every x_k is final at its diagonal owner on the layer that factored its forest; gather on world
         //      rank 0, then hand the complete vector to everyone ----
         {
-            LevelSched::XSeg mine;
-            {
-                std::vector<int> ks;
-                for (int zl = 0; zl < nzl; ++zl) if (H->z_active[zl]) for (int k : H->forest_nodes[zl]) if (g.krow(k) == g.r && g.kcol(k) == g.c) ks.push_back(k);
-                std::sort(ks.begin(), ks.end());
-                for (int k : ks) {
-                    const int row0 = H->hs.xsup[k], n1 = H->hs.xsup[k + 1] - row0;
-                    if (!mine.runs.empty() && mine.runs.back().first + mine.runs.back().second == row0) mine.runs.back().second += n1; else mine.runs.emplace_back(row0, n1);
-                    mine.total += n1;
-                }
-            }
-            // every rank learns every rank's run list by recomputing it: ownership is a pure function of (k, grid, forests),
-            // but the forests of other layers are not known here -> ship the run lists (host) to rank 0 first
+            LevelSched::XSeg mine = forest_runs(H, 0, 3);
             Comm *c = H->comm;
             const int P = g.size(), me = g.rank();
-            std::vector<int> flat;
-            for (auto &r : mine.runs) { flat.push_back(r.first); flat.push_back(r.second); }
-            std::vector<std::vector<int>> all(P);
-            {
+            if (!H->gather_ready) {
+                // rank 0 learns every rank's owner rows once (the forests of the other layers are not known here)
+                std::vector<int> flat;
+                for (auto &r : mine.runs) { flat.push_back(r.first); flat.push_back(r.second); }
+                std::vector<std::vector<int>> all(P);
                 std::vector<int64_t> lens(P, 0);
                 int64_t mylen = (int64_t) flat.size();
                 if ((rc = c->hbegin())) return rc;
@@ -579,20 +584,20 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
                 if (me != 0) { if ((rc = c->hsend(flat.data(), mylen * 4, 0))) return rc; }
                 else for (int p = 1; p < P; ++p) { all[p].resize((size_t) lens[p]); if ((rc = c->hrecv(all[p].data(), lens[p] * 4, p))) return rc; }
                 if ((rc = c->hend())) return rc;
+                if (me == 0)
+                    for (int p = 1; p < P; ++p) {
+                        LevelSched::XSeg m; m.peer = p;
+                        for (size_t i = 0; i + 1 < all[p].size(); i += 2) { m.runs.emplace_back(all[p][i], all[p][i + 1]); m.total += all[p][i + 1]; }
+                        if (m.total) H->gather_cache.push_back(std::move(m));
+                    }
+                H->gather_ready = true;
             }
+            std::vector<LevelSched::XSeg> none;
             if (me != 0) {
                 mine.peer = 0;
-                std::vector<LevelSched::XSeg> one(1, mine), none;
+                std::vector<LevelSched::XSeg> one(1, mine);
                 if (mine.total && (rc = xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s))) return rc;
-            } else {
-                std::vector<LevelSched::XSeg> rcv, none;
-                for (int p = 1; p < P; ++p) {
-                    LevelSched::XSeg m; m.peer = p;
-                    for (size_t i = 0; i + 1 < all[p].size(); i += 2) { m.runs.emplace_back(all[p][i], all[p][i + 1]); m.total += all[p][i + 1]; }
-                    if (m.total) rcv.push_back(std::move(m));
-                }
-                if ((rc = xseg_exchange(H, x, ldx, nr, none, 0, rcv, 1, s))) return rc;
-            }
+            } else if ((rc = xseg_exchange(H, x, ldx, nr, none, 0, H->gather_cache, 1, s))) return rc;
             // complete vector from rank 0 to everyone
             if ((rc = c->begin())) return rc;
             for (int q = 0; q < nr; ++q) {

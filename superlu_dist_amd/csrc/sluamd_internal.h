@@ -8,6 +8,7 @@
 // no CPU path.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -174,7 +175,7 @@ struct LevelSched {
     std::vector<std::vector<XMsg>> x_panel_send, x_panel_recv;   // phase 2: L slots along the process row, U slots down the column
     std::vector<int64_t> dg_stage_off;        // [nlevels] arena offset of the level's packed own diagonal blocks
     // solve exchange plan: per level, x segments (as [first row, rows) runs) reduced to / broadcast from the diagonal owners
-    struct XSeg { int peer; std::vector<std::pair<int, int>> runs; int64_t total = 0; };
+    struct XSeg { int peer = -1; std::vector<std::pair<int, int>> runs; int64_t total = 0; mutable int *d_runs = nullptr; /* device image, uploaded on first use (owned by Handle::d_misc) */ };
     std::vector<std::vector<XSeg>> xs_red_send, xs_red_recv, xs_bc_send, xs_bc_recv;
     // device copies
     int *d_nodes = nullptr, *d_tile_prefix = nullptr, *d_ltr_prefix = nullptr, *d_utr_prefix = nullptr;
@@ -235,7 +236,9 @@ struct Handle {
     std::vector<int> h_fuse_prev, h_defer, h_pair_roff, h_pair_coff, h_pair_rowmap, h_pair_colinfo;
     int fused_pairs = 0;
     int max_nsupc = 0;
-    Comm *comm = nullptr;           // not owned; set by sluamd_dCreateLUHandleGrid / sluamd_attach_comm
+    Comm *comm = nullptr;           // not owned; set by sluamd_dCreateLUHandleGrid / ...FromSymbGrid
+    std::map<int, LevelSched::XSeg> xseg_cache;        // x-segment run lists of the grid solve (Z exchanges, owner rows), built once
+    std::vector<LevelSched::XSeg> gather_cache; bool gather_ready = false;   // rank 0: the other ranks' owner rows (final gather)
 };
 
 // ------------------------------------------------------------------------------------------------

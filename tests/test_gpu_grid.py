@@ -21,6 +21,12 @@ def test_own_pipeline_on_grids(N, grid, nrhs, unsym):
     grid_cases.check_own_pipeline(N, grid, nrhs=nrhs, unsym=unsym, leaf=27, relax=32, maxsup=128, refactor=(grid == (2, 2, 2)))
 
 
+@pytest.mark.parametrize("grid", [(1, 1, 1), (2, 2, 1)])
+def test_many_right_hand_sides_are_solved_in_chunks(grid):
+    """nrhs beyond what the LDS-staged solve kernels take at once (the reference accepts any nrhs): 70 columns, 256-wide supernodes."""
+    grid_cases.check_own_pipeline(12, grid, nrhs=70, leaf=64, relax=64, maxsup=256)
+
+
 def test_wide_supernodes_on_a_2x2x2_grid():
     """256-wide supernodes (128x128 Schur tiles, blocked diagonal LU, multi-block TRSMs) with panels received from peers."""
     grid_cases.check_own_pipeline(24, (2, 2, 2), nrhs=2, unsym=True, leaf=64, relax=64, maxsup=256)

@@ -36,6 +36,12 @@ def test_own_pipeline_on_grids(emul, N, grid, nrhs, unsym):
     grid_cases.check_own_pipeline(N, grid, nrhs=nrhs, unsym=unsym, refactor=(grid == (2, 2, 2)))
 
 
+@pytest.mark.parametrize("grid", [(1, 1, 1), (2, 2, 1)])
+def test_many_right_hand_sides_are_solved_in_chunks(emul, grid):
+    """nrhs beyond what the LDS-staged solve kernels take at once (the reference accepts any nrhs): 70 columns, 256-wide supernodes."""
+    grid_cases.check_own_pipeline(8, grid, nrhs=70, leaf=64, relax=64, maxsup=256)
+
+
 def test_grid_without_communicator_is_rejected(emul, golden):
     """A rank of a multi-rank grid cannot be factored alone: the old silent-wrong-factors path is an error now."""
     from superlu_dist_amd import driver
