@@ -223,9 +223,12 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     if (rc) ABORT(S.last_error());
     sluamd_stats_t st;
     S.stats(G.h, &st);
-    if (getenv("SLUAMD_BIND_DEBUG"))
-        fprintf(stderr, "[sluamd_bind] rank (%d,%d,%d) info %d nnzL %lld nnzU %lld factor_ms %.3f launches %d\n", myrow, mycol, myz,
-                *info, (long long) st.nnz_L, (long long) st.nnz_U, st.t_factor_ms, st.num_launches);
+    if (getenv("SLUAMD_BIND_DEBUG")) {
+        int wmax = 0;
+        for (int k = 0; k < v.nsupers; ++k) if (v.xsup[k + 1] - v.xsup[k] > wmax) wmax = v.xsup[k + 1] - v.xsup[k];
+        fprintf(stderr, "[sluamd_bind] rank (%d,%d,%d) info %d nnzL %lld nnzU %lld factor_ms %.3f launches %d widest_supernode %d\n", myrow,
+                mycol, myz, *info, (long long) st.nnz_L, (long long) st.nnz_U, st.t_factor_ms, st.num_launches, wmax);
+    }
     stat->ops[FACT] += (flops_t) (st.flops_schur_padded + st.flops_panel);   /* scuStatUpdate's tally     */
     stat->TinyPivots += st.tiny_pivots;
     free(nNodes); free(lists);

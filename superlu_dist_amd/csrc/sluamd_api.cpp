@@ -48,24 +48,39 @@ static int copy_values(Handle *H, const sluamd_dLUview_t *lu, int dir)
         pieces.clear(); fill = 0; dev_byte = -1;
         return 0;
     };
+    // one contiguous host range -> the next bytes of the arena, through the pinned buffer
+    auto stage = [&](char *hp, size_t total, int64_t dev_elem_off) -> int {
+        size_t done = 0;
+        while (done < total) {
+            const int64_t byte_off = dev_elem_off * (int64_t) esz + (int64_t) done;
+            if (fill && (dev_byte + (int64_t) fill != byte_off || fill == cap)) { int rc2 = flush(); if (rc2) return rc2; }
+            if (!fill) dev_byte = byte_off;
+            const size_t n = std::min(total - done, cap - fill);
+            pieces.push_back({hp + done, n});
+            fill += n; done += n;
+        }
+        return 0;
+    };
     for (int pass = 0; pass < 2; ++pass) {
         const std::vector<int> &order = pass == 0 ? H->own_l_order : H->own_u_order;
         for (int k : order) {
             const int64_t len = pass == 0 ? hs.lval_len[k] : hs.uval_len[k];
             if (!len) continue;
             const int64_t off = pass == 0 ? hs.lval_off[k] : hs.uval_off[k];
+            if (H->split.active) {   // refined wide supernodes: the slot's values are gathered from column pieces of the caller's panels
+                int64_t o = off;
+                for (const auto &pc : (pass == 0 ? H->split.lsrc[k] : H->split.usrc[k])) {
+                    char *base = reinterpret_cast<char *>(pc.arr == 0 ? (void *) lu->Lnzval_bc_ptr[pc.ok] : (void *) lu->Unzval_br_ptr[pc.ok]);
+                    if (!base) { set_error("value array missing for a stored panel"); return SLUAMD_ESTRUCT; }
+                    if ((rc = stage(base + (size_t) pc.hoff * esz, (size_t) pc.len * esz, o))) return rc;
+                    o += pc.len;
+                }
+                if (o - off != len) { set_error("internal: refined slot size mismatch"); return SLUAMD_ESTRUCT; }
+                continue;
+            }
             char *hp = reinterpret_cast<char *>(pass == 0 ? (void *) lu->Lnzval_bc_ptr[k / g.Pc] : (void *) lu->Unzval_br_ptr[k / g.Pr]);
             if (!hp) { set_error("value array missing for a stored panel"); return SLUAMD_ESTRUCT; }
-            size_t done = 0;
-            const size_t total = (size_t) len * esz;
-            while (done < total) {
-                const int64_t byte_off = off * (int64_t) esz + (int64_t) done;
-                if (fill && (dev_byte + (int64_t) fill != byte_off || fill == cap)) { if ((rc = flush())) return rc; }
-                if (!fill) dev_byte = byte_off;
-                const size_t n = std::min(total - done, cap - fill);
-                pieces.push_back({hp + done, n});
-                fill += n; done += n;
-            }
+            if ((rc = stage(hp, (size_t) len * esz, off))) return rc;
         }
         if ((rc = flush())) return rc;
     }

@@ -144,14 +144,146 @@ static int exchange_ints(Comm *comm, const std::vector<int> &peers_s, const std:
     return comm->hend();
 }
 
+// Wide supernodes (257..512 columns) of a 1 x 1 layer -> chains of <= 256-column pieces (SplitMap): rewrites the slot index
+// arrays, the block graph and the forest lists in the internal numbering and records where every internal slot's values live
+// inside the caller's arrays.
+static int split_wide_supernodes(Handle &H, SlotInput &in)
+{
+    HostStruct &hs = H.hs;
+    const int nso = hs.nsupers;
+    const std::vector<int> ox = hs.xsup;
+    int wmax = 0;
+    for (int k = 0; k < nso; ++k) wmax = std::max(wmax, ox[k + 1] - ox[k]);
+    if (wmax <= 256) return 0;
+    if (wmax > 512) { set_error("supernodes wider than 512 columns (MAX_SUPER_SIZE) are not supported"); return SLUAMD_EINVAL; }
+    if (H.grid.Pr * H.grid.Pc > 1) { set_error("supernodes wider than 256 columns are supported on 1 x 1 x Pz grids only (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
+    if (H.z) { set_error("complex16: supernodes wider than 256 columns are not supported"); return SLUAMD_EINVAL; }
+    SplitMap &M = H.split;
+    M.active = true; M.oxsup = ox; M.first.assign(nso + 1, 0);
+    std::vector<int> nx(1, 0);                 // internal xsup
+    for (int k = 0; k < nso; ++k) {
+        const int w = ox[k + 1] - ox[k];
+        M.first[k] = (int) nx.size() - 1;
+        const int np = (w + 255) / 256;
+        const int pw = (((w + np - 1) / np) + 31) & ~31;           // piece width: even split rounded up to the 32-column blocking
+        for (int c = 0; c < w; c += pw) nx.push_back(ox[k] + std::min(w, c + pw));
+    }
+    M.first[nso] = (int) nx.size() - 1;
+    const int ns = M.first[nso];
+    // piece of original supernode g holding global row `row`
+    auto piece_of = [&](int g, int row) { int q = M.first[g]; while (nx[q + 1] <= row) ++q; return q; };
+    std::vector<std::vector<int>> nl(ns), nu(ns), nsucc(ns);
+    std::vector<uint8_t> npresent(ns, 0);
+    M.lsrc.assign(ns, {}); M.usrc.assign(ns, {});
+    for (int ko = 0; ko < nso; ++ko) {
+        if (!hs.present[ko]) continue;
+        const std::vector<int> &li = in.lidx[ko], &ui = in.uidx[ko];
+        if (li.size() < (size_t) BC_HEADER) { set_error("L panel with the diagonal block missing"); return SLUAMD_ESTRUCT; }
+        const int x0 = ox[ko], w = ox[ko + 1] - x0, nsupr_o = li[1];
+        if (li[0] < 1 || li[BC_HEADER] != ko || li[BC_HEADER + 1] != w) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
+        const int f = M.first[ko], np = M.first[ko + 1] - f;
+        // original U row: column start offsets
+        std::vector<int64_t> ucol0;    // per (block, jj) flattened in walk order: value offset of the column's segment
+        for (int p = 0; p < np; ++p) {
+            const int id = f + p, c0 = nx[id] - x0, c1 = nx[id + 1] - x0, h = c1 - c0;
+            npresent[id] = 1;
+            // ---- L slot: rows of the original panel from diagonal row c0 on, columns [c0, c1) ----
+            std::vector<int> &o = nl[id];
+            o.assign(BC_HEADER, 0);
+            int nb = 0, nr = 0;
+            for (int q = p; q < np; ++q) {                       // the rest of the original diagonal block, piece by piece
+                const int r0 = nx[f + q], r1 = nx[f + q + 1];
+                o.push_back(f + q); o.push_back(r1 - r0);
+                for (int r = r0; r < r1; ++r) o.push_back(r);
+                ++nb; nr += r1 - r0;
+            }
+            int pp = BC_HEADER + LB_DESCRIPTOR + w;
+            for (int b = 1; b < li[0]; ++b) {                     // original off-diagonal blocks, split by the pieces of their supernode
+                const int g = li[pp], nbrow = li[pp + 1];
+                const int *rows = li.data() + pp + LB_DESCRIPTOR;
+                int i = 0, lastq = -1;
+                while (i < nbrow) {
+                    const int q = piece_of(g, rows[i]);
+                    if (q <= lastq) { set_error("L block rows are not grouped by ascending row: cannot refine a wide supernode"); return SLUAMD_ESTRUCT; }
+                    int j2 = i;
+                    while (j2 < nbrow && rows[j2] >= nx[q] && rows[j2] < nx[q + 1]) ++j2;
+                    o.push_back(q); o.push_back(j2 - i);
+                    o.insert(o.end(), rows + i, rows + j2);
+                    nsucc[id].push_back(q);
+                    ++nb; nr += j2 - i; i = j2; lastq = q;
+                }
+                pp += LB_DESCRIPTOR + nbrow;
+            }
+            o[0] = nb; o[1] = nr;
+            if (nr != nsupr_o - c0) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
+            for (int j = c0; j < c1; ++j) M.lsrc[id].push_back({0, ko, (int64_t) j * nsupr_o + c0, (int64_t) nr});
+            for (int q = p + 1; q < np; ++q) nsucc[id].push_back(f + q);
+            // ---- U slot: rows [x0 + c0, x0 + c1) ----
+            std::vector<int> &u = nu[id];
+            u.assign(BR_HEADER, 0);
+            int nub = 0; int64_t nnz = 0;
+            const int klst = x0 + c1, row0 = x0 + c0;
+            for (int q = p + 1; q < np; ++q) {                   // U(piece p, piece q): inside the original diagonal block, full segments
+                const int cq0 = nx[f + q] - x0, cq1 = nx[f + q + 1] - x0;
+                u.push_back(f + q); u.push_back(h * (cq1 - cq0));
+                for (int j = cq0; j < cq1; ++j) { u.push_back(row0); M.usrc[id].push_back({0, ko, (int64_t) j * nsupr_o + c0, (int64_t) h}); }
+                ++nub; nnz += (int64_t) h * (cq1 - cq0);
+            }
+            if (ui.size() >= (size_t) BR_HEADER) {
+                int iukp = BR_HEADER; int64_t rukp = 0;
+                for (int b = 0; b < ui[0]; ++b) {
+                    const int jbo = ui[iukp], wj = ox[jbo + 1] - ox[jbo];
+                    for (int q = M.first[jbo]; q < M.first[jbo + 1]; ++q) {
+                        const int cq0 = nx[q] - ox[jbo], cq1 = nx[q + 1] - ox[jbo];
+                        std::vector<int> fst(cq1 - cq0);
+                        std::vector<SplitMap::Piece> pcs;
+                        int bn = 0;
+                        int64_t off = rukp;
+                        for (int jj = 0; jj < cq0; ++jj) off += ox[ko + 1] - ui[iukp + UB_DESCRIPTOR + jj];
+                        for (int jj = cq0; jj < cq1; ++jj) {
+                            const int fo = ui[iukp + UB_DESCRIPTOR + jj], sego = ox[ko + 1] - fo;
+                            const int fn = std::max(fo, row0);
+                            const int seg = std::max(0, klst - fn);
+                            fst[jj - cq0] = seg ? fn : klst;
+                            if (seg) { pcs.push_back({1, ko, off + (fn - fo), (int64_t) seg}); bn += seg; }
+                            off += sego;
+                        }
+                        if (bn) {
+                            u.push_back(q); u.push_back(bn);
+                            u.insert(u.end(), fst.begin(), fst.end());
+                            M.usrc[id].insert(M.usrc[id].end(), pcs.begin(), pcs.end());
+                            nsucc[id].push_back(q);
+                            ++nub; nnz += bn;
+                        }
+                    }
+                    for (int jj = 0; jj < wj; ++jj) rukp += ox[ko + 1] - ui[iukp + UB_DESCRIPTOR + jj];
+                    iukp += UB_DESCRIPTOR + wj;
+                }
+            }
+            if (nnz > 0x7fffffff) { set_error("U block row too large"); return SLUAMD_ESTRUCT; }
+            u[0] = nub; u[1] = (int) nnz; u[2] = (int) u.size();
+            if (!nub) u.clear();
+        }
+    }
+    for (auto &v : nsucc) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+    for (auto &l : in.lists) {
+        std::vector<int> e;
+        for (int ko : l) for (int q = M.first[ko]; q < M.first[ko + 1]; ++q) e.push_back(q);
+        l.swap(e);
+    }
+    in.lidx.swap(nl); in.uidx.swap(nu); in.succ.swap(nsucc);
+    hs.nsupers = ns; hs.xsup = nx; hs.present = npresent;
+    return 0;
+}
+
 int slots_from_view(Handle &H, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests, Comm *comm, SlotInput &in)
 {
     if (!lu || !lu->xsup || lu->nsupers <= 0) { set_error("invalid LU view"); return SLUAMD_EINVAL; }
     Grid &g = H.grid;
     g = Grid{lu->nprow, lu->npcol, lu->npdep, lu->myrow, lu->mycol, lu->myzlayer};
     if (g.Pr < 1 || g.Pc < 1 || g.Pz < 1 || g.r < 0 || g.r >= g.Pr || g.c < 0 || g.c >= g.Pc || g.z < 0 || g.z >= g.Pz) { set_error("bad grid coordinates in the LU view"); return SLUAMD_EINVAL; }
-    if (g.size() > 1) {
-        if (!comm) { set_error("a process grid with more than one rank needs a communicator: use sluamd_dCreateLUHandleGrid"); return SLUAMD_EINVAL; }
+    if (g.size() > 1 && !comm) { set_error("a process grid with more than one rank needs a communicator: use sluamd_dCreateLUHandleGrid"); return SLUAMD_EINVAL; }
+    if (comm) {
         const Grid &cg = comm->grid;
         if (cg.Pr != g.Pr || cg.Pc != g.Pc || cg.Pz != g.Pz || cg.r != g.r || cg.c != g.c || cg.z != g.z) { set_error("communicator grid does not match the LU view's grid"); return SLUAMD_EINVAL; }
     }
@@ -225,7 +357,7 @@ int slots_from_view(Handle &H, const sluamd_dLUview_t *lu, const sluamd_forest_v
         }
     }
     finish_succ(in);
-    return 0;
+    return split_wide_supernodes(H, in);
 }
 
 // ================================================================================================

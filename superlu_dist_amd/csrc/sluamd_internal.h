@@ -187,6 +187,18 @@ struct LevelSched {
 
 struct Comm;   // sluamd_comm.h
 
+// Refinement of the caller's supernode partition: supernodes wider than 256 columns (the reference allows up to
+// MAX_SUPER_SIZE = 512, superlu_defs.h:154, sp_ienv.c:95-110) are handled as chains of <= 256-column pieces internally; the
+// caller's panels keep the reference layout, the value upload / download gathers / scatters by column.
+struct SplitMap {
+    bool active = false;
+    std::vector<int> oxsup;     // the caller's xsup [original nsupers + 1]
+    std::vector<int> first;     // [original nsupers + 1]: internal id of the first piece of each original supernode
+    struct Piece { int arr; int ok; int64_t hoff, len; };   // arr 0 / 1: Lnzval_bc_ptr[ok] / Unzval_br_ptr[ok]; element offset and count
+    std::vector<std::vector<Piece>> lsrc, usrc;             // per INTERNAL supernode, in slot (column-major) order
+};
+
+
 struct Handle {
     int device = 0;
     sluamd_options_t opt{};
@@ -209,6 +221,7 @@ struct Handle {
     std::vector<std::vector<int>> forest_nodes;   // ascending supernodes of the forest of every Z level on this layer's path (even when not factored here)
     std::vector<uint8_t> z_active;  // [Z levels] this layer factors that level's forest (!myZeroTrIdxs)
     std::vector<int> own_l_order, own_u_order;   // own L / U slots in value-arena order
+    SplitMap split;
     hipStream_t stream = nullptr;
     hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
     std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events

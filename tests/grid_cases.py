@@ -102,3 +102,73 @@ def check_own_pipeline(N, grid, nrhs=1, leaf=27, relax=16, maxsup=64, unsym=Fals
         assert res < 1e-10
         assert np.abs(x - x1).max() <= 1e-10 * np.abs(x1).max()
     symb.free()
+
+
+def forests_from_partition(tree, Pz, z):
+    """The dtrf3Dpartition_t view a 1 x 1 x Pz rank would hold, from the heap-ordered tree id of every supernode
+    (Symbolic.partition): forest Pz-1+z at level 0, then its ancestors; a rank idles at level l when z % 2^l != 0."""
+    ml = int(np.log2(Pz)) + 1
+    idx, t = [], Pz - 1 + z
+    for _ in range(ml):
+        idx.append(t); t = (t - 1) // 2
+    return dict(maxLvl=ml, myTreeIdxs=np.array(idx, dtype=np.int32),
+                myZeroTrIdxs=np.array([1 if z % (1 << l) else 0 for l in range(ml)], dtype=np.int32),
+                nodeLists=[np.flatnonzero(tree == f).astype(np.int32) if np.any(tree == f) else None
+                           for f in range(2 * Pz - 1)])
+
+
+def check_wide_supernodes(N, maxsup, Pz, orc):
+    """Reference-format panels with supernodes of 257..512 columns (sp_ienv(3) <= MAX_SUPER_SIZE = 512) through the view
+    path on a 1 x 1 x Pz grid: every L/U value against the CPU oracle's factorisation of the same store, then a solve.
+    Layer z > 0 starts with zeroed ancestor panels (pddistribute3d / zeroSetLU)."""
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(N)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=maxsup)
+    symb.distribute_host(v)
+    fs0 = symb.flat_store()
+    assert np.diff(fs0.xsup).max() > 256 or maxsup <= 256
+    o = orc.LUStore(fs0.n, fs0.xsup, fs0.Lrowind_off, fs0.Lrowind, fs0.Lnzval_off, fs0.Lnzval.copy(), fs0.Ufstnz_off,
+                    fs0.Ufstnz, fs0.Unzval_off, fs0.Unzval.copy())
+    orc.dfactor(o)
+    tree = symb.partition(Pz) if Pz > 1 else np.zeros(symb.nsupers, dtype=np.int32)
+    comms = grid3d.local_comms(1, 1, Pz)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 3)
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    scale = np.abs(v).max()
+
+    def rank_body(z):
+        fs = symb.flat_store()
+        fs.grid, fs.coords = (1, 1, Pz), (0, 0, z)
+        fs._build_view()
+        fr = forests_from_partition(tree, Pz, z) if Pz > 1 else None
+        mine = np.zeros(symb.nsupers, dtype=bool)
+        if Pz > 1:
+            for l, t in enumerate(fr["myTreeIdxs"]):
+                if not fr["myZeroTrIdxs"][l]:
+                    mine |= tree == t
+            for k in np.flatnonzero(tree < Pz - 1) if z else []:      # ancestors start at zero on layers z > 0
+                fs.Lnzval[fs.Lnzval_off[k]:fs.Lnzval_off[k + 1]] = 0.0
+                fs.Unzval[fs.Unzval_off[k]:fs.Unzval_off[k + 1]] = 0.0
+        else:
+            mine[:] = True
+        h = grid3d.GridHandle.from_store(fs, fr, comms[z])
+        assert h.pdgstrf3d(0.0) == 0
+        h.copy_to_host(fs)
+        for k in np.flatnonzero(mine):
+            a, e = fs.Lnzval_off[k], fs.Lnzval_off[k + 1]
+            assert np.abs(fs.Lnzval[a:e] - o.Lnzval[a:e]).max() <= 1e-12 * scale, ("L", z, k, np.abs(fs.Lnzval[a:e] - o.Lnzval[a:e]).max())
+            a, e = fs.Unzval_off[k], fs.Unzval_off[k + 1]
+            if e > a:
+                assert np.abs(fs.Unzval[a:e] - o.Unzval[a:e]).max() <= 1e-12 * scale, ("U", z, k)
+        y = h.pdgstrs3d(xp)
+        h.destroy()
+        return y
+
+    for y in grid3d.run_ranks(Pz, rank_body):
+        x = y[symb.perm_c, :]
+        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
+        assert np.abs(x - xt).max() <= 1e-8 * np.abs(xt).max()
+    symb.free()

@@ -18,6 +18,7 @@ ZREF = os.path.join(ROOT, "oracle", "_ref", "slu_ref_zdump")
 
 
 MPIEXEC = "/opt/conda/bin/mpiexec"
+_last = {}
 
 
 def _run(binary, args, tmp_path, threads="4", nproc=1, extra_env=None):
@@ -34,6 +35,7 @@ def _run(binary, args, tmp_path, threads="4", nproc=1, extra_env=None):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     m = re.search(r"RESIDUAL (\S+) INFO (\d+)", r.stdout)
     assert m, r.stdout[-2000:]
+    _last["stderr"] = r.stderr
     return float(m.group(1)), int(m.group(2))
 
 
@@ -98,6 +100,27 @@ def test_irregular_unsymmetric_pattern_at_scale(tmp_path):
     args = ["-r", "1", "-c", "1", "-d", "1", "-Q", "1", "-o", "none", str(tmp_path / "a.dat")]
     res_amd, info_amd = _run(AMD, args, tmp_path, threads="8", extra_env={"SLUAMD_BIND_DEBUG": "1"})
     res_ref, info_ref = _run(REF, args, tmp_path, threads="32")
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10
+
+
+@pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
+@pytest.mark.parametrize("npdep", [1, 2])
+def test_reference_supernodes_up_to_512_columns(npdep, tmp_path):
+    """SUPERLU_MAXSUP=512 (sp_ienv.c:95-110, MAX_SUPER_SIZE): the reference's symbfact builds supernodes of up to 512 columns;
+    the library refines them into <= 256-column pieces behind the same dLocalLU_t panels (1 x 1 x npdep grids)."""
+    N = 22
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    np.savetxt(tmp_path / "a.perm", perm, fmt="%d")
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    args = ["-r", "1", "-c", "1", "-d", str(npdep), "-Q", "1", "-o", "none", "-e", "0", "-p", "0", "-P", str(tmp_path / "a.perm"),
+            str(tmp_path / "a.dat")]
+    env = {"SUPERLU_MAXSUP": "512", "SUPERLU_RELAX": "64", "SLUAMD_BIND_DEBUG": "1"}
+    res_amd, info_amd = _run(AMD, args, tmp_path, threads="4", nproc=npdep, extra_env=env)
+    assert max(int(w) for w in re.findall(r"widest_supernode (\d+)", _last["stderr"])) > 256
+    res_ref, info_ref = _run(REF, args, tmp_path, threads="4", nproc=npdep, extra_env=env)
     assert info_amd == info_ref == 0
     assert res_amd < 1e-10 and res_ref < 1e-10
     assert abs(res_amd - res_ref) < 1e-10

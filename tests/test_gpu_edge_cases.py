@@ -75,9 +75,10 @@ def test_nrhs_zero_is_a_noop_and_negative_is_rejected():
     h.destroy()
 
 
-def test_supernodes_wider_than_256_are_rejected_with_a_message():
-    """SUPERLU_MAXSUP may go up to 512 in the reference (sp_ienv.c); this library states its limit instead of
-    silently mis-computing."""
+def test_supernodes_wider_than_256_from_own_symbolic_are_rejected_with_a_message():
+    """SUPERLU_MAXSUP may go up to 512 in the reference (sp_ienv.c).  Reference-format panels with such supernodes are
+    handled (test_gpu_grid.py::test_supernodes_257_to_512_columns); the library's OWN symbolic path states its limit
+    (ask it for maxsup <= 256) instead of silently mis-computing."""
     rng = np.random.default_rng(4)
     A = rng.standard_normal((300, 300)) * 0.1 + 300 * np.eye(300)
     n, rp, ci, v = _csr(A)
@@ -86,6 +87,26 @@ def test_supernodes_wider_than_256_are_rejected_with_a_message():
         pytest.skip("symbolic did not produce a wide supernode")
     with pytest.raises(RuntimeError, match="256"):
         driver.LUHandle.from_symbolic(symb, v)
+
+
+def test_dense_supernode_of_300_columns_through_the_view_path():
+    """One 300-column supernode (a dense matrix with relax = maxsup = 300): refined into two pieces internally, factors
+    returned in the caller's single 300 x 300 panel; against numpy's LU without pivoting (diagonally dominant)."""
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((300, 300)) * 0.1 + 300 * np.eye(300)
+    n, rp, ci, v = _csr(A)
+    symb = driver.Symbolic(n, rp, ci, None, relax=300, maxsup=300)
+    if np.diff(symb.xsup()).max() <= 256:
+        pytest.skip("symbolic did not produce a wide supernode")
+    symb.distribute_host(v)
+    fs = symb.flat_store()
+    h = driver.LUHandle.from_store(fs)
+    assert h.pdgstrf3d(0.0) == 0
+    b = rng.standard_normal((n, 2))
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    x = h.pdgstrs3d(xp)[symb.perm_c, :]
+    assert np.abs(A @ x - b).max() <= 1e-10 * np.abs(b).max()
+    h.destroy()
 
 
 def test_malformed_structure_is_rejected(golden):

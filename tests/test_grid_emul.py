@@ -62,3 +62,18 @@ def test_gloo_processes_through_the_callback_transport(world, grid, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "GRID_WORKER_OK" in r.stdout
+
+
+@pytest.mark.parametrize("N,maxsup,Pz", [(18, 512, 1), (20, 512, 1), (24, 384, 1), (18, 512, 2), (24, 512, 2)])
+def test_supernodes_257_to_512_columns(emul, N, maxsup, Pz):
+    import oracle as orc
+    grid_cases.check_wide_supernodes(N, maxsup, Pz, orc)
+
+
+def test_view_grid_must_match_the_communicator(emul, golden):
+    """A 1x1x1 LU view handed a 1x1x2 communicator is a caller error (it used to be accepted and the Z reduction skipped)."""
+    from superlu_dist_amd import driver, grid3d
+    st = driver.FlatStore.from_golden(golden("g20_1x1x1"), 0, "pre")
+    comms = grid3d.local_comms(1, 1, 2)
+    with pytest.raises(RuntimeError, match="does not match"):
+        grid3d.GridHandle.from_store(st, None, comms[0])
