@@ -197,7 +197,7 @@ void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lp
 }
 
 void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level)
+           const int4 *ulist, const int *sn_level, int skip_level, int skip_n)
 {
     (void) cfg;
     std::vector<double> acc, lrow;
@@ -216,7 +216,7 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
         const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
         const int nr = R.z, nc = C.z;
         const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
-        if (!ulist && skip_level >= 0 && (sn_level[ib] == skip_level || sn_level[jb] == skip_level)) continue;
+        if (!ulist && skip_level >= 0 && ((unsigned) (sn_level[ib] - skip_level) < (unsigned) skip_n || (unsigned) (sn_level[jb] - skip_level) < (unsigned) skip_n)) continue;
         if (!ulist && T.defer && T.defer[k]) continue;
         const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
         const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
@@ -442,7 +442,6 @@ void xseg_copy(hipStream_t, double *x, int64_t ldx, int nrhs, const int *runs, i
             }
 }
 
-int diag_profile(unsigned long long *out8, int) { for (int i = 0; i < 8; ++i) out8[i] = 0; return 0; }
 
 int mfma_selftest(const double *A, const double *B, double *D)
 {

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libsluamd.so")
+_SO = os.environ.get("SLUAMD_LIB") or os.path.join(_HERE, "libsluamd.so")   # SLUAMD_LIB: another build of the same library (A/B timing on one box)
 
 int_t = C.c_int32
 P_int = C.POINTER(C.c_int32)

@@ -496,6 +496,8 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     hipSetDevice(H->device);
     if (H->stream) hipStreamSynchronize(H->stream);
     if (H->pstream) hipStreamSynchronize(H->pstream);
+    if (H->ustream) hipStreamSynchronize(H->ustream);
+    if (H->u2stream) hipStreamSynchronize(H->u2stream);
     for (void *p : H->d_misc) hipFree(p);
     if (H->d_val) hipFree(H->d_val);
     if (H->d_info) hipFree(H->d_info);
@@ -511,6 +513,8 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->ev1) hipEventDestroy(H->ev1);
     for (auto e : H->ev_pool) hipEventDestroy(e);
     if (H->pstream) hipStreamDestroy(H->pstream);
+    if (H->ustream) hipStreamDestroy(H->ustream);
+    if (H->u2stream) hipStreamDestroy(H->u2stream);
     if (H->stream) hipStreamDestroy(H->stream);
     delete h;
 }
@@ -572,7 +576,6 @@ int sluamd_set_profile(sluamd_handle_t h, int on)
 }
 
 // debug hook (not in the public header): accumulated phase timers of k_diag_lu2 [A, B, C, D+store, E] in shader clock ticks
-int sluamd_debug_diag_profile(unsigned long long *out8, int reset) { return eng::diag_profile(out8, reset); }
 
 // test hook: MFMA fp64 fragment layout check
 int sluamd_mfma_selftest(const double *A, const double *B, double *D)

@@ -57,10 +57,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const bool gemm_panels = !xy && !H->env.trsm_panels;
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     int rc_x = 0;
+    int cur_level = 0, cur_pass = 0;
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
-                     const int4 *ulist, int skip_level) {
+                     const int4 *ulist, int skip_level, int skip_n) {
+        if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
-        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level);
+        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, skip_n);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -92,94 +94,96 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);
         H->st.num_launches += (nl + nu > 0);
     };
+    // Stream program.  Serial mode: everything in order on one stream.  Look-ahead mode, four streams:
+    //   s   (bulk)     : the bulk of Schur(l), level after level                                        -- never waits for a later panel
+    //   us  (urgent 1) : U1(l) [tiles that feed level-(l+1) panels: diagonal blocks first]
+    //   u2s (urgent 2) : U2(l) [tiles that feed level-(l+2) panels]
+    //   ps  (panels)   : panel(l+1) = diag LU / inverses after U1's diagonal part, panel solves after all of U1(l)
+    // panel(l+1) needs U1(l), U2(l-1) and the bulk of every level <= l-2: while the bulk of one level runs, the panels of the
+    // next TWO levels and the urgent tiles between them are factored beside it.
+    hipStream_t us = lookahead ? H->ustream : H->stream, u2s = lookahead ? H->u2stream : H->stream;
     if (lookahead && S.nlevels) {
-        hipEvent_t e = next_event(H);    // the side stream must see everything queued so far on the main stream
-        hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
+        hipEvent_t e = next_event(H);    // the side streams must see everything queued so far on the main stream
+        hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0); hipStreamWaitEvent(us, e, 0); hipStreamWaitEvent(u2s, e, 0);
     }
-    bool panel_queued = false;           // panel(l) already queued on ps by the previous level's look-ahead
-    hipEvent_t pending_eu = nullptr;
-    for (int l = 0; l < S.nlevels; ++l) {
+    auto group_launch = [&](hipStream_t st, int l, int part) {   // part 0..2: urgent lists; 3 / 4 / 5: full grids minus the tiles that feed levels l+1..l+2 / l+1 / none
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
         const int *nodes = S.d_nodes + n0;
-        if (!panel_queued) {
-            if (lookahead && l > 0) {   // no look-ahead was done for this level: its panels need ALL of Schur(l-1)
-                hipEvent_t e = next_event(H);
-                hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0);
-            }
-            panelA(l); panelB(l);
-        }
-        panel_queued = false;
-        if (lookahead) {
-            hipEvent_t e = next_event(H);
-            hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);     // Schur(l) needs panel(l)
-        }
         const int nbig = S.n_big[l];
-        // look-ahead split of this level's Schur update (SLUAMD_LOOKAHEAD_MAX_STRIPS bounds the panel work overlapped)
-        bool split = false;
-        if (lookahead && l + 1 < S.nlevels) {
-            const int po1 = S.lvl_poff[l + 1], nn1 = S.lvl_off[l + 2] - S.lvl_off[l + 1];
-            split = (S.ltr_prefix[po1 + nn1] + S.utr_prefix[po1 + nn1]) <= H->env.lookahead_max_strips;
-        }
-        // K-fused pairs: a deferred supernode runs only its urgent tiles (everything the next level's panels need), so the
-        // urgent pass is needed even without look-ahead; the rest of its update is accumulated by its partner's tiles
-        const bool urgent_pass = split || (T.defer && S.lvl_defer[l]);
-        // pass 0: urgent tiles whose destination is a diagonal block of level l+1; pass 1: the other urgent tiles (explicit
-        // lists); pass 2: the rest (full grids, urgent tiles skipped)
-        for (int pass = urgent_pass ? 0 : 2; pass < 3; ++pass) {
-            for (int g = 0; g < 2; ++g) {
-                const int cnt = g == 0 ? nbig : nn - nbig;
-                if (!cnt) continue;
-                const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
-                const int *gn = nodes + (g == 0 ? 0 : nbig);
-                if (pass < 2) {
-                    const int u0 = S.u_off[(2 * l + g) * 2 + pass], nu = S.u_off[(2 * l + g) * 2 + pass + 1] - u0;
-                    if (nu) schur(s, g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1);
-                    continue;
-                }
-                const int nt = S.tile_prefix[so + cnt];
-                if (!nt) continue;
-                if (T.defer && S.lvl_defer[l]) {   // nothing to launch when every supernode of the group is deferred
-                    bool all = true;
-                    const int i0 = n0 + (g == 0 ? 0 : nbig);
-                    for (int i = 0; i < cnt && all; ++i) all = H->h_defer[S.nodes[i0 + i]] != 0;
-                    if (all) continue;
-                }
-                if (!H->opt.deterministic) {
-                    schur(s, g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, urgent_pass ? l + 1 : -1);
-                } else {  // one supernode per launch: tiles of one k hit distinct destinations -> fixed summation order
-                    for (int i = 0; i < cnt; ++i) {
-                        const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
-                        if (c) schur(s, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1);
-                    }
-                }
+        const bool urgent = !H->opt.deterministic;
+        for (int g = 0; g < 2; ++g) {
+            const int cnt = g == 0 ? nbig : nn - nbig;
+            if (!cnt) continue;
+            const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
+            const int *gn = nodes + (g == 0 ? 0 : nbig);
+            if (part < 3) {
+                const int u0 = S.u_off[(2 * l + g) * 3 + part], nu = S.u_off[(2 * l + g) * 3 + part + 1] - u0;
+                if (nu) schur(st, g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1, 0);
+                continue;
             }
-            if (split && pass == 0) {
-                // the diagonal blocks of level l+1 are complete (and, by stream order, so is everything of level l-1):
-                // diag_lu(l+1) + its inverses run on the side stream while the other urgent tiles -- too few to fill the
-                // machine at the top of the tree -- are still in flight
-                hipEvent_t e0 = next_event(H);
-                hipEventRecord(e0, s); hipStreamWaitEvent(ps, e0, 0);
-                panelA(l + 1);
+            const int nt = S.tile_prefix[so + cnt];
+            if (!nt) continue;
+            if (T.defer && S.lvl_defer[l]) {   // nothing to launch when every supernode of the group is deferred
+                bool all = true;
+                const int i0 = n0 + (g == 0 ? 0 : nbig);
+                for (int i = 0; i < cnt && all; ++i) all = H->h_defer[S.nodes[i0 + i]] != 0;
+                if (all) continue;
             }
-            if (split && pass == 1) {
-                // all urgent tiles done: the panel solves of level l+1 may run; they overlap with the rest of level l as far as
-                // the machine has room (a host-staged exchange inside panelB blocks the host, not the GPU: queue the rest first)
-                hipEvent_t eu = next_event(H);
-                hipEventRecord(eu, s);
-                pending_eu = eu;
+            if (urgent) {
+                schur(st, g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, part == 5 ? -1 : l + 1, part == 4 ? 1 : 2);
+            } else {  // deterministic: one supernode per launch, tiles of one k hit distinct destinations -> fixed summation order
+                for (int i = 0; i < cnt; ++i) {
+                    const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
+                    if (c) schur(st, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1, 0);
+                }
             }
         }
-        if (split) {
-            hipStreamWaitEvent(ps, pending_eu, 0);
+    };
+    auto wait_on = [&](hipStream_t waiter, hipStream_t on) -> hipEvent_t {   // waiter continues after everything queued on `on`
+        hipEvent_t e = next_event(H);
+        hipEventRecord(e, on); hipStreamWaitEvent(waiter, e, 0);
+        return e;
+    };
+    hipEvent_t e_u2_prev = nullptr;      // U2(l-1) done
+    hipEvent_t e_bulk_prev = nullptr, e_bulk_prev2 = nullptr;   // bulk(l-1), bulk(l-2) done (stream order: and every earlier one)
+    if (S.nlevels) { panelA(0); panelB(0); }
+    for (int l = 0; l < S.nlevels; ++l) {
+        cur_level = l;
+        const bool more = l + 1 < S.nlevels;
+        if (!lookahead) {
+            // serial partition (also the measurement harness of the Schur kernel, as in rounds 1-2): one full-grid launch per
+            // level and tile-size group; only K-fused levels need their level-(l+1) urgent tiles launched apart
+            const bool urgent = !H->opt.deterministic && T.defer && S.lvl_defer[l];
+            if (urgent) { for (int part = 0; part < 2; ++part) { cur_pass = part; group_launch(s, l, part); } }
+            cur_pass = 3; group_launch(s, l, urgent ? 4 : 5);
+            if (more) { panelA(l + 1); panelB(l + 1); }
+            if (rc_x) return rc_x;
+            continue;
+        }
+        hipEvent_t e_p = next_event(H);  // panel(l) done
+        hipEventRecord(e_p, ps);
+        hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);
+        cur_pass = 0; group_launch(us, l, 0);
+        hipEvent_t e_u0 = next_event(H); hipEventRecord(e_u0, us);
+        cur_pass = 1; group_launch(us, l, 1);
+        hipEvent_t e_u1 = next_event(H); hipEventRecord(e_u1, us);
+        cur_pass = 2; group_launch(u2s, l, 2);
+        hipEvent_t e_u2 = next_event(H); hipEventRecord(e_u2, u2s);
+        cur_pass = 3; group_launch(s, l, 3);
+        hipEvent_t e_bulk = next_event(H); hipEventRecord(e_bulk, s);
+        if (more) {
+            hipStreamWaitEvent(ps, e_u0, 0);
+            if (e_u2_prev) hipStreamWaitEvent(ps, e_u2_prev, 0);
+            if (e_bulk_prev2) hipStreamWaitEvent(ps, e_bulk_prev2, 0);
+            if (xy && e_bulk_prev) hipStreamWaitEvent(ps, e_bulk_prev, 0);   // XY layer: the received panels of level l-1 share the scratch copy (level parity) that panel(l+1)'s exchange fills
+            panelA(l + 1);
+            hipStreamWaitEvent(ps, e_u1, 0);
             panelB(l + 1);
-            panel_queued = true;
         }
+        e_u2_prev = e_u2; e_bulk_prev2 = e_bulk_prev; e_bulk_prev = e_bulk;
         if (rc_x) return rc_x;
     }
-    if (lookahead && S.nlevels) {
-        hipEvent_t e = next_event(H);
-        hipEventRecord(e, ps); hipStreamWaitEvent(s, e, 0);
-    }
+    if (lookahead && S.nlevels) { wait_on(s, ps); wait_on(s, us); wait_on(s, u2s); }
     HIPCHK(hipGetLastError());
     return rc_x;
 }
@@ -279,6 +283,7 @@ int run_factor(Handle *H, double thresh, int *info)
     H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
     H->profile = H->opt.verbose >= 2 || H->env.profile;
     H->ev_schur_used = H->ev_panel_used = 0;
+    H->schur_rec.clear();
     H->ev_pool_used = 0;
     HIPCHK(hipEventRecord(H->ev0, H->stream));
     // Z levels in order (pdgstrf3d.c:333-385): factor my forest of the level, then the ancestor reduction
@@ -297,6 +302,12 @@ int run_factor(Handle *H, double thresh, int *info)
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
     H->dinv_ready = true; H->inv_ready = (g.Pr * g.Pc == 1) && !H->env.trsm_panels && !H->z;
+    if (H->profile && H->env.profile_dump && H->schur_rec.size() == H->ev_schur_used)
+        for (size_t i = 0; i < H->ev_schur_used; ++i) {
+            float ems = 0; hipEventElapsedTime(&ems, H->ev_schur[i].first, H->ev_schur[i].second);
+            const auto &r = H->schur_rec[i];
+            fprintf(stderr, "SCHUR level %d pass %d big %d tiles %d max_nsupc %d ms %.4f\n", r.level, r.pass, r.big, r.ntiles, r.mx, ems);
+        }
     H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
     H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
     H->st.tiny_pivots = res[1];

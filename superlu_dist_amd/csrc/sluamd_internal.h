@@ -166,8 +166,8 @@ struct LevelSched {
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
-    std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level and tile-size group [diagonal-block destinations | other urgent tiles]
-    std::vector<int> u_off;         // [4*nlevels+1] offsets into ulist: index (2*level + group) * 2 + part
+    std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level and tile-size group [diagonal blocks of level l+1 | rest of the level-(l+1) panels | level-(l+2) panels]
+    std::vector<int> u_off;         // [6*nlevels+1] offsets into ulist: index (2*level + group) * 3 + part
     // ---- XY block-cyclic exchange plan (empty on a 1 x 1 layer): per level, in ascending supernode order ----
     std::vector<int> dg_prefix;               // per node (lvl_poff layout): 1024-double chunks of the own diagonal blocks to pack
     std::vector<int64_t> dg_off;              // ... and their offsets inside the level's diagonal staging range
@@ -207,8 +207,8 @@ struct Handle {
     int Pz = 1, myz = 0;
     // environment switches, read ONCE at creation (they may differ per handle)
     struct Env {
-        bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, trsm_panels = false, diag_v1 = false;
-        int fuse_min_pct = 75, fuse_max_prev = 1, lookahead_max_strips = 1 << 30, reserve_cus = 0;
+        bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, profile_dump = false, trsm_panels = false, diag_v1 = false;
+        int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
     } env;
     // device arenas
     double *d_val = nullptr;
@@ -224,6 +224,8 @@ struct Handle {
     SplitMap split;
     hipStream_t stream = nullptr;
     hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
+    hipStream_t ustream = nullptr;          // high-priority stream for the Schur tiles that feed the next level's panels
+    hipStream_t u2stream = nullptr;         // ... and for those that feed the panels of the level after it
     std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events
     size_t ev_pool_used = 0;
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
@@ -240,6 +242,8 @@ struct Handle {
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
     size_t ev_schur_used = 0, ev_panel_used = 0;
+    struct SchurRec { int level, pass, big, ntiles, mx; };
+    std::vector<SchurRec> schur_rec;   // SLUAMD_PROFILE_DUMP: one record per profiled Schur launch (parallel to ev_schur)
     sluamd_stats_t st{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // host tables kept for stats / planning
@@ -271,7 +275,7 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level);
+           const int4 *ulist, const int *sn_level, int skip_level, int skip_n);
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
@@ -290,7 +294,6 @@ void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *p
 void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs /*device: (row0, nrows, rows before) triples*/, int nruns, int64_t total,
                double *buf, int mode);
 int mfma_selftest(const double *A, const double *B, double *D);   // host pointers
-int diag_profile(unsigned long long *out8, int reset);            // debug: phase timers of k_diag_lu2
 // complex16 twins (1 x 1 x 1 grids)
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);

@@ -220,30 +220,30 @@ __global__ __launch_bounds__(256) void k_diag_lu(DevTables T, const int *__restr
 
 // ---- diagonal block LU, Crout form ------------------------------------------------------------------------------------
 // Same arithmetic contract as k_diag_lu (Local_Dgstrf2, pdgstrf2.c:508-601: unpivoted, tiny-pivot replacement, zero-pivot
-// info), organised so that nothing on the critical path of the factorisation waits on read-modify-write round trips:
-// per 32-column step jb
-//   A  column panel  C = A[jb:, jb:jb+32] - L[jb:, 0:jb] U[0:jb, jb:jb+32]      left-looking, fp64 MFMA, result -> LDS
+// info), organised so that nothing on the critical path of the factorisation waits on read-modify-write round trips and so
+// that the workgroup (66 KB of LDS, <= 256 VGPRs, 4 waves) starts in the slot ONE retiring Schur workgroup frees: the panel
+// chain runs inside the previous level's Schur update instead of waiting for a CU to drain.  Per 32-column step jb
+//   A  column panel  C = A[jb:, jb:jb+32] - L[jb:, 0:jb] U[0:jb, jb:jb+32]   left-looking fp64 MFMA; U staged through LDS in
+//      K halves of 112, the L fragments loaded in register batches; C stays in the ACCUMULATORS (head rows -> LDS)
 //   B  32 x 32 head factored in registers by one wave (wave_lu32)
 //   C  Uinv11 = inv(U11), LinvT11 = inv(L11^T) by two other waves (also written to T.dinv: k_diag_inv's job for the owner)
-//   D  L21 = C21 Uinv11 (MFMA, in LDS), panel -> memory
-//   E  row panel     R = A[jb:jb+32, jb+32:] - L[jb:jb+32, 0:jb] U[0:jb, jb+32:]  (MFMA), U12 = Linv11 R (MFMA) -> memory
-// Every element of the block is written exactly once.  MFMA operand roles as in k_schur: D[i][j], i = column, j = row,
-// so that the 16 fast lanes run along rows (contiguous in the column-major block).
-// phase timers of k_diag_lu2 (shader clock ticks accumulated by thread 0 of every 256-wide block; read by sluamd_debug_diag_profile)
-__device__ unsigned long long g_diag_prof[8];
-#define DPROF(slot) do { if (NSMAX == 256 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_diag_prof[slot], t_ - tprev); tprev = t_; } } while (0)
+//   D  L21 = C21 Uinv11: the accumulator layout D[(l>>4)+4r][l&15] IS the B-operand layout, C21 never leaves registers
+//   E  row panel  R = A[jb:jb+32, jb+32:] - L[jb:jb+32, 0:jb] U[0:jb, jb+32:] with the operand roles swapped so that R lands in
+//      the A-operand layout of U12 = Linv11 R: no LDS round trip either
+// Every element of the block is written exactly once.
+constexpr int DKH = 112;                          // K half: 28 MFMA k-steps = one register batch of fragments
+constexpr int DST = DKH + 2;                      // stage stride (== 18 mod 32: conflict-free fragment reads)
+constexpr int DXS = 4 * DB * (DB + 1) + 2 * 16 * 17;   // staging buffer: >= 32 * DST and the phase-C scratch
+constexpr size_t DIAG_LU2_LDS = sizeof(double) * (DXS + DB * 33 + DB * 34 + DB * 48);
 
-template <int NSMAX>
-__global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__restrict__ nodes,
-                                                  int replace_tiny, double thresh, int *__restrict__ info)
+__global__ __launch_bounds__(256, 2) void k_diag_lu2(DevTables T, const int *__restrict__ nodes, int replace_tiny, double thresh,
+                                                     int *__restrict__ info)
 {
-    constexpr int ldp = NSMAX + 1;               // column panel in LDS: element (r, c) at Ps[c * ldp + r]
-    constexpr int UST = NSMAX + 2 - DB;          // k-fastest stage of the U block column: (kk, c) at Ush[c * UST + kk], UST == 2 mod 32
-    constexpr int USZ = (DB * UST > 4800) ? DB * UST : 4800;       // >= Rs[128 * 34] and the phase-C scratch (4 x 32 x 33 + 2 x 16 x 17)
+    __builtin_amdgcn_s_setprio(3);   // panel chain: its waves go first when they share a SIMD with Schur tiles
     extern __shared__ double dsm[];
-    double *Ps = dsm;                            // DB * ldp
-    double *Ush = Ps + DB * ldp;                 // USZ: phase A stage -- reused as Bs[2][32 * 33] in phase C and Rs[128 * 34] in phase E
-    double *Uis = Ush + USZ;                     // Uinv11: (kk, n) at Uis[n * 34 + kk]
+    double *X = dsm;                             // phase A: U(kk, c) at X[c * DST + kk]; phase E: L(row, kk) at X[row * DST + kk]; phase C scratch
+    double *Hs = X + DXS;                        // the 32 x 32 head: (r, c) at Hs[c * 33 + r]
+    double *Uis = Hs + DB * 33;                  // Uinv11: (kk, n) at Uis[n * 34 + kk]
     double *Lis = Uis + DB * 34;                 // Linv11: (i, kk) at Lis[kk * 48 + i]
     __shared__ double s_rinv[DB];
     const int k = nodes[blockIdx.x];
@@ -255,88 +255,89 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
     double *dinv = T.dinv + T.sn_dinv[k];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
-    unsigned long long tprev = __builtin_readcyclecounter();
     for (int jb = 0; jb < ns; jb += DB) {
         const int nb = min(DB, ns - jb), m = ns - jb, nc = m - nb;
-        // ---- A: column panel, left-looking ----
-        if (jb > 0) {
-            for (int idx = tid; idx < jb * DB; idx += 256) {     // stage U[0:jb, jb:jb+32] (kk fastest: coalesced)
-                const int kk = idx % jb, c = idx / jb;
-                Ush[c * UST + kk] = (c < nb) ? A[kk + (size_t) (jb + c) * lda] : 0.0;
+        const int nrbp = (m + 15) >> 4;          // 16-row blocks of the column panel (blocks 0 and 1 are the head)
+        // ---- A: column panel, left-looking; this wave owns blocks wave + 4 s (s = 0..3), columns 0-15 and 16-31 ----
+        d4 cp[4][2];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { cp[s4][0] = (d4){0.0, 0.0, 0.0, 0.0}; cp[s4][1] = cp[s4][0]; }
+        for (int k0 = 0; k0 < jb; k0 += DKH) {
+            const int kh = min(DKH, jb - k0), nq = kh >> 2;
+            __syncthreads();                     // X is free
+            for (int idx = tid; idx < kh * DB; idx += 256) {     // kk fastest: coalesced
+                const int kk = idx % kh, c = idx / kh;
+                X[c * DST + kk] = (c < nb) ? A[k0 + kk + (size_t) (jb + c) * lda] : 0.0;
             }
-        }
-        __syncthreads();
-        {
-            const int nrb = (m + 15) >> 4;
-            for (int rb0 = wave; rb0 < nrb; rb0 += 8) {          // up to two 16-row blocks per wave and pass
-                const int rb1 = rb0 + 4;
-                const bool has1 = rb1 < nrb;
-                d4 a00 = (d4){0.0, 0.0, 0.0, 0.0}, a01 = a00, a10 = a00, a11 = a00;
-                const int r0 = min(16 * rb0 + li, m - 1), r1 = min(16 * rb1 + li, m - 1);
-                const double *L0 = A + jb + r0, *L1 = A + jb + r1;
-                const int nq = jb / 4;
+            __syncthreads();
 #pragma unroll
-                for (int hk = 0; hk < 2; ++hk) {                 // K in two halves: all L fragments of a half are loaded in ONE batch
-                    if (hk * 28 < nq) {
-                        double lf0[28], lf1[28];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int b0 = wave + 8 * s2, b1 = b0 + 4;
+                if (b0 < nrbp) {
+                    const bool has1 = b1 < nrbp;
+                    const double *L0 = A + jb + min(16 * b0 + li, m - 1) + (size_t) k0 * lda;
+                    const double *L1 = A + jb + min(16 * b1 + li, m - 1) + (size_t) k0 * lda;
+                    double lf0[28], lf1[28];
 #pragma unroll
-                        for (int qq = 0; qq < 28; ++qq) {
-                            const int kk = 4 * (hk * 28 + qq) + lk;
-                            const bool ok = hk * 28 + qq < nq;
-                            lf0[qq] = ok ? L0[(size_t) kk * lda] : 0.0;
-                            lf1[qq] = (ok && has1) ? L1[(size_t) kk * lda] : 0.0;
-                        }
+                    for (int qq = 0; qq < 28; ++qq) {
+                        const int kk = 4 * qq + lk;
+                        lf0[qq] = (qq < nq) ? L0[(size_t) kk * lda] : 0.0;
+                        lf1[qq] = (qq < nq && has1) ? L1[(size_t) kk * lda] : 0.0;
+                    }
 #pragma unroll
-                        for (int qq = 0; qq < 28; ++qq) {
-                            if (hk * 28 + qq < nq) {
-                                const int kk = 4 * (hk * 28 + qq) + lk;
-                                const double u0 = Ush[li * UST + kk], u1 = Ush[(16 + li) * UST + kk];
-                                a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, lf0[qq], a00, 0, 0, 0);
-                                a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, lf0[qq], a01, 0, 0, 0);
-                                a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, lf1[qq], a10, 0, 0, 0);
-                                a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, lf1[qq], a11, 0, 0, 0);
-                            }
+                    for (int qq = 0; qq < 28; ++qq) {
+                        if (qq < nq) {
+                            const int kk = 4 * qq + lk;
+                            const double u0 = X[li * DST + kk], u1 = X[(16 + li) * DST + kk];
+                            cp[2 * s2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, lf0[qq], cp[2 * s2][0], 0, 0, 0);
+                            cp[2 * s2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, lf0[qq], cp[2 * s2][1], 0, 0, 0);
+                            cp[2 * s2 + 1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, lf1[qq], cp[2 * s2 + 1][0], 0, 0, 0);
+                            cp[2 * s2 + 1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, lf1[qq], cp[2 * s2 + 1][1], 0, 0, 0);
                         }
                     }
                 }
-                auto put = [&](int rb, const d4 &h0, const d4 &h1) {
-                    const int row = 16 * rb + li;
-                    double av[8];
+            }
+        }
+        // C = A - acc, in place in the accumulators (lane: row 16 b + li, columns lk + 4 r and 16 + lk + 4 r); head rows -> Hs
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = lk + 4 * r;
-                        av[r] = (row < m && c < nb) ? A[jb + row + (size_t) (jb + c) * lda] : 0.0;
-                        av[4 + r] = (row < m && 16 + c < nb) ? A[jb + row + (size_t) (jb + 16 + c) * lda] : 0.0;
-                    }
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int b = wave + 4 * s4, row = 16 * b + li;
+            if (b < nrbp) {
+                double av[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = lk + 4 * r;
-                        if (row < m && c < nb) Ps[c * ldp + row] = av[r] - h0[r];
-                        if (row < m && 16 + c < nb) Ps[(16 + c) * ldp + row] = av[4 + r] - h1[r];
-                    }
-                };
-                put(rb0, a00, a01);
-                if (has1) put(rb1, a10, a11);
+                for (int r = 0; r < 4; ++r) {
+                    const int c = lk + 4 * r;
+                    av[r] = (row < m && c < nb) ? A[jb + row + (size_t) (jb + c) * lda] : 0.0;
+                    av[4 + r] = (row < m && 16 + c < nb) ? A[jb + row + (size_t) (jb + 16 + c) * lda] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = lk + 4 * r;
+                    cp[s4][0][r] = (row < m && c < nb) ? av[r] - cp[s4][0][r] : 0.0;
+                    cp[s4][1][r] = (row < m && 16 + c < nb) ? av[4 + r] - cp[s4][1][r] : 0.0;
+                }
+                if (s4 == 0 && b < 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { Hs[(lk + 4 * r) * 33 + row] = cp[0][0][r]; Hs[(16 + lk + 4 * r) * 33 + row] = cp[0][1][r]; }
+                }
             }
         }
         __syncthreads();
-        DPROF(0);
         // ---- B: head ----
-        if (wave == 0) wave_lu32(Ps, ldp, nb, fst + jb + 1, replace_tiny, thresh, info, s_rinv);
+        if (wave == 0) wave_lu32(Hs, 33, nb, fst + jb + 1, replace_tiny, thresh, info, s_rinv);
         __syncthreads();
-        DPROF(1);
-        // ---- C: inverses of the head's triangles (identity-padded past nb), kept in LDS and written to T.dinv ----
+        // ---- C: inverses of the head's triangles (identity-padded past nb), kept in LDS and written to T.dinv; head -> memory ----
         if (wave == 1 || wave == 2) {
             const int typ = wave - 1;            // 0: U11 ; 1: L11^T (unit)
-            double *Bs = Ush + typ * DB * (DB + 1);              // the stage of phase A is free again: B(i, jj) at Bs[i * 33 + jj]
-            double *Xs = Ush + (2 + typ) * DB * (DB + 1);        // X = inv(B): X(i, jj) at Xs[i * 33 + jj]
-            double *Tm = Ush + 4 * DB * (DB + 1) + typ * 16 * 17;
+            double *Bs = X + typ * DB * (DB + 1);                // B(i, jj) at Bs[i * 33 + jj]
+            double *Xs = X + (2 + typ) * DB * (DB + 1);          // X = inv(B): X(i, jj) at Xs[i * 33 + jj]
+            double *Tm = X + 4 * DB * (DB + 1) + typ * 16 * 17;
             for (int e = lane; e < DB * DB; e += 64) {
                 const int i = e >> 5, jj = e & 31;
                 double v = (i == jj) ? 1.0 : 0.0;
                 if (i < nb && jj < nb && i <= jj) {
-                    if (typ == 0) v = Ps[jj * ldp + i];          // U(i, jj)
-                    else if (i < jj) v = Ps[i * ldp + jj];       // L(jj, i) = (L^T)(i, jj)
+                    if (typ == 0) v = Hs[jj * 33 + i];           // U(i, jj)
+                    else if (i < jj) v = Hs[i * 33 + jj];        // L(jj, i) = (L^T)(i, jj)
                 }
                 Bs[i * (DB + 1) + jj] = v;
                 Xs[i * (DB + 1) + jj] = 0.0;
@@ -381,116 +382,106 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
                 dst[c2 * DB + kk] = v;
                 if (typ == 0) Uis[c2 * 34 + kk] = v; else Lis[kk * 48 + c2] = v;
             }
-        }
-        __syncthreads();
-        DPROF(2);
-        // ---- D: L21 = C21 Uinv11 ----
-        if (nc > 0) {
-            const int nrb = (nc + 15) >> 4;
-            for (int rb = wave; rb < nrb; rb += 4) {
-                const int row = DB + 16 * rb + li;
-                double bfr[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) bfr[q] = (row < m) ? Ps[(4 * q + lk) * ldp + row] : 0.0;
-                d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Uis[li * 34 + 4 * q + lk], bfr[q], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Uis[(16 + li) * 34 + 4 * q + lk], bfr[q], a1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (row < m) { Ps[(lk + 4 * r) * ldp + row] = a0[r]; Ps[(16 + lk + 4 * r) * ldp + row] = a1[r]; }
-                }
+        } else {
+            // waves 0 and 3: the factored head L11 \ U11 -> memory
+            for (int e = lane + 64 * (wave == 3); e < DB * DB; e += 128) {
+                const int r = e & 31, c = e >> 5;
+                if (r < nb && c < nb) A[jb + r + (size_t) (jb + c) * lda] = Hs[c * 33 + r];
             }
         }
         __syncthreads();
-#pragma unroll 8
-        for (int idx = tid; idx < m * nb; idx += 256) { const int r = idx % m, c = idx / m; A[jb + r + (size_t) (jb + c) * lda] = Ps[c * ldp + r]; }
-        DPROF(3);
-        // ---- E: row panel, 128 columns per pass (two 16-column blocks per wave): R = A12 - L_row U_above (MFMA), U12 = Linv11 R ----
         if (nc > 0) {
-            __syncthreads();                     // the panel has been stored: Ps is free
-            double *Lrs = Ps;                    // L[jb:jb+32, 0:jb] staged once per step: (row, kk) at Lrs[kk * 33 + row]
-            for (int idx = tid; idx < jb * DB; idx += 256) { const int row = idx & 31, kk = idx >> 5; Lrs[kk * 33 + row] = A[jb + row + (size_t) kk * lda]; }
-            __syncthreads();
-            double *Rs = Ush;                    // (row, col) at Rs[col * 34 + row], 128 columns
-            const int nq = jb / 4;
-            for (int c0 = 0; c0 < nc; c0 += 128) {
-                const int cwA = 16 * wave, cwB = 64 + 16 * wave;          // this wave's two 16-column blocks of the pass
-                const int cgA = jb + nb + c0 + cwA, cgB = jb + nb + c0 + cwB;
-                const bool actA = c0 + cwA < nc, actB = c0 + cwB < nc;
-                d4 aA0 = (d4){0.0, 0.0, 0.0, 0.0}, aA1 = aA0, aB0 = aA0, aB1 = aA0;
-                if (actA) {
-                    const double *UcA = A + (size_t) min(cgA + li, ns - 1) * lda, *UcB = A + (size_t) min(cgB + li, ns - 1) * lda;
+            // ---- D: L21 = C21 Uinv11, straight from the accumulators to memory (nc > 0 implies nb == 32) ----
 #pragma unroll
-                    for (int hk = 0; hk < 2; ++hk) {
-                        if (hk * 28 < nq) {
-                            double ufA[28], ufB[28];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int b = wave + 4 * s4, row = 16 * b + li;
+                if (b >= 2 && b < nrbp) {
+                    d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                            for (int qq = 0; qq < 28; ++qq) {
-                                const int kk = 4 * (hk * 28 + qq) + lk;
-                                const bool ok = hk * 28 + qq < nq;
-                                ufA[qq] = ok ? UcA[kk] : 0.0;
-                                ufB[qq] = (ok && actB) ? UcB[kk] : 0.0;
-                            }
+                    for (int q = 0; q < 8; ++q) {
+                        const double bfr = cp[s4][q >> 2][q & 3];
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Uis[li * 34 + 4 * q + lk], bfr, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Uis[(16 + li) * 34 + 4 * q + lk], bfr, a1, 0, 0, 0);
+                    }
+                    if (row < m) {
 #pragma unroll
-                            for (int qq = 0; qq < 28; ++qq) {
-                                if (hk * 28 + qq < nq) {
-                                    const int kk = 4 * (hk * 28 + qq) + lk;
-                                    const double l0 = Lrs[kk * 33 + li], l1 = Lrs[kk * 33 + 16 + li];
-                                    aA0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufA[qq], l0, aA0, 0, 0, 0);
-                                    aA1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufA[qq], l1, aA1, 0, 0, 0);
-                                    aB0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufB[qq], l0, aB0, 0, 0, 0);
-                                    aB1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ufB[qq], l1, aB1, 0, 0, 0);
-                                }
+                        for (int r = 0; r < 4; ++r) {
+                            A[jb + row + (size_t) (jb + lk + 4 * r) * lda] = a0[r];
+                            A[jb + row + (size_t) (jb + 16 + lk + 4 * r) * lda] = a1[r];
+                        }
+                    }
+                }
+            }
+            // ---- E: row panel; pass p covers columns 128 p .. 128 p + 127, this wave's blocks 16 w and 64 + 16 w of the pass ----
+            d4 rr[2][2][2];                      // [pass][block A / B][row half]: lane (row lk + 4 r (+16), column li)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) { rr[p2][g][0] = (d4){0.0, 0.0, 0.0, 0.0}; rr[p2][g][1] = rr[p2][g][0]; }
+            for (int k0 = 0; k0 < jb; k0 += DKH) {
+                const int kh = min(DKH, jb - k0), nq = kh >> 2;
+                __syncthreads();                 // X is free (phase C scratch / previous half)
+                for (int idx = tid; idx < kh * DB; idx += 256) { const int row = idx & 31, kk = idx >> 5; X[row * DST + kk] = A[jb + row + (size_t) (k0 + kk) * lda]; }
+                __syncthreads();
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const int cA = 128 * p2 + 16 * wave, cB = cA + 64;
+                    if (cA < nc) {
+                        const bool actB = cB < nc;
+                        const double *UcA = A + k0 + (size_t) min(jb + nb + cA + li, ns - 1) * lda;
+                        const double *UcB = A + k0 + (size_t) min(jb + nb + cB + li, ns - 1) * lda;
+                        double ufA[28], ufB[28];
+#pragma unroll
+                        for (int qq = 0; qq < 28; ++qq) {
+                            const int kk = 4 * qq + lk;
+                            ufA[qq] = (qq < nq) ? UcA[kk] : 0.0;
+                            ufB[qq] = (qq < nq && actB) ? UcB[kk] : 0.0;
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 28; ++qq) {
+                            if (qq < nq) {
+                                const int kk = 4 * qq + lk;
+                                const double l0 = X[li * DST + kk], l1 = X[(16 + li) * DST + kk];
+                                rr[p2][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, ufA[qq], rr[p2][0][0], 0, 0, 0);
+                                rr[p2][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, ufA[qq], rr[p2][0][1], 0, 0, 0);
+                                rr[p2][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, ufB[qq], rr[p2][1][0], 0, 0, 0);
+                                rr[p2][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, ufB[qq], rr[p2][1][1], 0, 0, 0);
                             }
                         }
                     }
-                    auto putR = [&](int cw, int cg, const d4 &h0, const d4 &h1) {     // R = A12 - acc -> Rs
-                        double av[8];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int col = lk + 4 * r;
-                            av[r] = (cg + col < ns) ? A[jb + li + (size_t) (cg + col) * lda] : 0.0;
-                            av[4 + r] = (cg + col < ns) ? A[jb + 16 + li + (size_t) (cg + col) * lda] : 0.0;
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int col = lk + 4 * r;
-                            Rs[(cw + col) * 34 + li] = (cg + col < ns) ? av[r] - h0[r] : 0.0;
-                            Rs[(cw + col) * 34 + 16 + li] = (cg + col < ns) ? av[4 + r] - h1[r] : 0.0;
-                        }
-                    };
-                    putR(cwA, cgA, aA0, aA1);
-                    if (actB) putR(cwB, cgB, aB0, aB1);
                 }
-                __syncthreads();
-                if (actA) {
-                    // U12(i', col) = sum_k Linv(i', k) R(k, col): Aop(i = col, k) = R(k, col), Bop(k, j = i') = Linv(i', k)
-                    auto solve = [&](int cw, int cg) {
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int c0 = 128 * p2 + 64 * g + 16 * wave;
+                    if (c0 < nc) {
+                        const int cg = jb + nb + c0;
+                        // R = A12 - acc in the accumulator layout (row lk + 4 r (+16), column li) = the A-operand layout of U12 = Linv11 R
+                        const bool cok = cg + li < ns;
+                        const double *Ac = A + jb + (size_t) min(cg + li, ns - 1) * lda;
+                        double R[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { R[r] = cok ? Ac[lk + 4 * r] : 0.0; R[4 + r] = cok ? Ac[16 + lk + 4 * r] : 0.0; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { R[r] = cok ? R[r] - rr[p2][g][0][r] : 0.0; R[4 + r] = cok ? R[4 + r] - rr[p2][g][1][r] : 0.0; }
                         d4 o0 = (d4){0.0, 0.0, 0.0, 0.0}, o1 = o0;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const double rf = Rs[(cw + li) * 34 + 4 * q + lk];
-                            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + li], o0, 0, 0, 0);
-                            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Lis[(4 * q + lk) * 48 + 16 + li], o1, 0, 0, 0);
+                        for (int q = 0; q < 8; ++q) {   // U12(i', col) = sum_k Linv(i', k) R(k, col)
+                            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(R[q], Lis[(4 * q + lk) * 48 + li], o0, 0, 0, 0);
+                            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(R[q], Lis[(4 * q + lk) * 48 + 16 + li], o1, 0, 0, 0);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int col = cg + lk + 4 * r;
                             if (col < ns) { A[jb + li + (size_t) col * lda] = o0[r]; A[jb + 16 + li + (size_t) col * lda] = o1[r]; }
                         }
-                    };
-                    solve(cwA, cgA);
-                    if (actB) solve(cwB, cgB);
+                    }
                 }
-                __syncthreads();
-            }
         }
         __threadfence_block();
         __syncthreads();
-        DPROF(4);
     }
 }
 
@@ -500,6 +491,7 @@ __global__ __launch_bounds__(256) void k_diag_lu2(DevTables T, const int *__rest
 __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__restrict__ nodes,
                                                   const int *__restrict__ prefix, int nn)
 {
+    __builtin_amdgcn_s_setprio(3);   // panel chain: its waves go first when they share a SIMD with Schur tiles
     __shared__ double Bs[4][DB * (DB + 1)];     // 34 KB: the workgroup fits beside two Schur workgroups on a CU
     const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
     const int task = blockIdx.x * 4 + g;
@@ -913,6 +905,7 @@ __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int uni
 __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__restrict__ nodes, const int *__restrict__ lprefix,
                                                     const int *__restrict__ uprefix, int nn, int nl)
 {
+    __builtin_amdgcn_s_setprio(3);   // panel chain: its waves go first when they share a SIMD with Schur tiles
     __shared__ double Ts[PG_LDS];
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
@@ -930,6 +923,7 @@ __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__re
 constexpr int FIS = 16;
 __global__ __launch_bounds__(FIS * 4) void k_full_inv(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn)
 {
+    __builtin_amdgcn_s_setprio(3);   // panel chain: its waves go first when they share a SIMD with Schur tiles
     extern __shared__ double sm[];
     const int ni = find_node(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
@@ -995,12 +989,31 @@ __global__ __launch_bounds__(256) void k_rfs_update(int n, const int *__restrict
 // Two tile configurations: 128x128 (wide supernodes, big block pairs: 4x4 MFMA blocks per wave) and 64x64
 // (everything else).  Software pipeline: the next K chunk is fetched from HBM/L2 into registers while the
 // MFMAs of the current chunk run out of the other LDS buffer (one barrier per chunk).
+// the MFMAs of one K chunk for a wave that owns RA x CA 16 x 16 blocks
+template <int RA, int CA, int LDL, int LDU>
+__device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, int rm0, int cn0, int lane, d4 (&acc)[CA][RA])
+{
+#pragma unroll
+    for (int k4 = 0; k4 < KC; k4 += 4) {
+        const int kr = k4 + (lane >> 4);
+        double a[CA], b[RA];
+#pragma unroll
+        for (int c = 0; c < CA; ++c) a[c] = Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
+#pragma unroll
+        for (int r = 0; r < RA; ++r) b[r] = Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
+#pragma unroll
+        for (int c = 0; c < CA; ++c)
+#pragma unroll
+            for (int r = 0; r < RA; ++r) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[r], acc[c][r], 0, 0, 0);
+    }
+}
+
 template <int TMv, int TNv, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
-                                                                    int skip_level)
+                                                                    int skip_level, int skip_n)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -1033,25 +1046,31 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         if ((blockIdx.x >> 3) >= chunk || bid >= ntiles) return;
         bid += id_base;
     }
-    // look-ahead split: `ulist` != null -> explicit (k, row tile, col tile) list of the tiles that update the NEXT
-    // level's panels ("urgent"); otherwise the full tile grid, minus those tiles when skip_level >= 0
+    // look-ahead split: `ulist` != null -> explicit (k, row tile, col tile) list of the tiles that update the panels of the
+    // next one or two levels ("urgent"); otherwise the full tile grid, minus the tiles whose destination supernode sits on
+    // levels skip_level .. skip_level + skip_n - 1
     int k, rt, ct;
     if (ulist) {
+        __builtin_amdgcn_s_setprio(2);   // urgent tiles sit on the panel chain
         const int4 u = ulist[bid];
         k = u.x; rt = u.y; ct = u.z;
     } else {
         const int ni = find_node(prefix, nn, bid);
         k = nodes[ni];
         const int local = bid - prefix[ni];
-        const int nct = T.sn_nct[k];
-        rt = local / nct; ct = local - rt * nct;
+        // bands of 8 row tiles, column-major inside a band: the ~64 tiles an XCD runs at a time form an 8 x 8 block that
+        // shares 8 L row tiles and 8 U column tiles in that XCD's L2 (row-major order streamed one U tile per tile)
+        const int nct = T.sn_nct[k], nrt = T.sn_nrt[k];
+        const int band = local / (8 * nct), rem = local - band * 8 * nct;
+        const int bh = min(8, nrt - 8 * band);
+        ct = rem / bh; rt = 8 * band + (rem - ct * bh);
     }
     const int4 R = T.rtile[T.sn_rt_off[k] + rt];
     const int4 C = T.ctile[T.sn_ct_off[k] + ct];
     const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
-    const int nr = R.z, nc = C.z;
+    const int nr = __builtin_amdgcn_readfirstlane(R.z), nc = __builtin_amdgcn_readfirstlane(C.z);   // workgroup-uniform
     const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
-    if (!ulist && skip_level >= 0 && (sn_level[ib] == skip_level || sn_level[jb] == skip_level)) return;  // done by the urgent launch
+    if (!ulist && skip_level >= 0 && ((unsigned) (sn_level[ib] - skip_level) < (unsigned) skip_n || (unsigned) (sn_level[jb] - skip_level) < (unsigned) skip_n)) return;  // done by the urgent launches
     if (!ulist && T.defer && T.defer[k]) return;   // K-fused: the partner supernode's tiles apply this update
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int lda = T.sn_nsupr[k];
@@ -1107,8 +1126,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     }
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63;
-    const int rm0 = (wave % WR) * (TMv / WR), cn0 = (wave / WR) * (TNv / WC);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // a wave whose 32 x 64 (32 x 32) part lies entirely outside a ragged tile skips its MFMAs: the MFMA pipe is the resource
+    // the co-resident workgroups share.  The row part is rotated by the tile id so that the idle waves of short tiles fall on
+    // different SIMDs (wave w runs on SIMD w % 4).
+    const int rm0 = ((wave + bid) % WR) * (TMv / WR), cn0 = (wave / WR) * (TNv / WC);
+    const bool wave_on = rm0 < nr && cn0 < nc;
     d4 acc[NBC][NBR];
 #pragma unroll
     for (int a = 0; a < NBC; ++a)
@@ -1118,7 +1141,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     const int li = tid % TMv, lk = tid / TMv;           // L loader: row li, k = lk + LKS*q
     const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + UJS*q
     double pl[LQ], pu[UQ];
-    int ucp[UQ], uld[UQ];
+    const int *cpS = s_cptr, *ldS = s_lead;   // column maps of the current source (LDS): re-read per chunk, registers are scarce
     bool lrow_ok = li < nr;
     // per-source state of the K loop (source 0 = fused predecessor ka, source 1 = k itself)
     int ns_s = ns, lda_s = lda;
@@ -1132,7 +1155,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         }
         const int kg = k0 + uk;
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) pu[q] = (kg >= uld[q] && kg < ns_s) ? Uvs[ucp[q] + (kg - uld[q])] : 0.0;
+        for (int q = 0; q < UQ; ++q) {
+            const int ld = ldS[uj + UJS * q];
+            pu[q] = (kg >= ld && kg < ns_s) ? Uvs[cpS[uj + UJS * q] + (kg - ld)] : 0.0;
+        }
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -1157,13 +1183,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
             __syncthreads();
             ns_s = nss; lda_s = T.sn_nsupr[ks]; Lrow = T.val + T.sn_lval[ks] + max(ra, 0); Uvs = T.val + T.sn_uval[ks];
             kbeg = (nss - T.sn_ldu[ks]) & ~3; lrow_ok = ra >= 0;
-#pragma unroll
-            for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr2[uj + UJS * q]; uld[q] = s_lead2[uj + UJS * q]; }
+            cpS = s_cptr2; ldS = s_lead2;
         } else {
             ns_s = ns; lda_s = lda; Lrow = Lp + li; Uvs = Uv; lrow_ok = li < nr;
             kbeg = (ns - T.sn_ldu[k]) & ~3;              // U is zero above its tallest segment: skip those k
-#pragma unroll
-            for (int q = 0; q < UQ; ++q) { ucp[q] = s_cptr[uj + UJS * q]; uld[q] = s_lead[uj + UJS * q]; }
+            cpS = s_cptr; ldS = s_lead;
         }
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
         fetch(kbeg);
@@ -1173,19 +1197,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
             const bool more = k0 + KC < ns_s;
             if (more) fetch(k0 + KC);
             const double *Lb = Ls[buf], *Ub = Us[buf];
-#pragma unroll
-            for (int k4 = 0; k4 < KC; k4 += 4) {
-                const int kr = k4 + (lane >> 4);
-                double a[NBC], b[NBR];
-#pragma unroll
-                for (int c = 0; c < NBC; ++c) a[c] = Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
-#pragma unroll
-                for (int r = 0; r < NBR; ++r) b[r] = Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
-#pragma unroll
-                for (int c = 0; c < NBC; ++c)
-#pragma unroll
-                    for (int r = 0; r < NBR; ++r) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[r], acc[c][r], 0, 0, 0);
-            }
+            if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Lb, Ub, rm0, cn0, lane, acc);
             if (more) stash(buf ^ 1);
             __syncthreads();
             buf ^= 1;
@@ -1472,20 +1484,12 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_full_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) DIAG_LU2_LDS));
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     return 0;
-}
-
-template <int NSMAX> static size_t diag_lu2_lds()
-{
-    const size_t usz = (size_t) DB * (NSMAX + 2 - DB) > 4800 ? (size_t) DB * (NSMAX + 2 - DB) : 4800;
-    return sizeof(double) * ((size_t) DB * (NSMAX + 1) + usz + DB * 34 + DB * 48);
 }
 
 void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx, int replace_tiny, double thresh, int *info)
@@ -1495,8 +1499,7 @@ void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx
     // bottom of the tree, thousands of blocks per launch) are throughput-bound, not latency-bound: the right-looking kernel with
     // its smaller footprint is faster there (0.85 vs 2.2 ms per launch at 100^3)
     if (!(replace_tiny & 2) && mx > 64) {
-        if (mx <= 128) hipLaunchKernelGGL(k_diag_lu2<128>, dim3(nn), dim3(256), diag_lu2_lds<128>(), s, T, nodes, replace_tiny & 1, thresh, info);
-        else hipLaunchKernelGGL(k_diag_lu2<256>, dim3(nn), dim3(256), diag_lu2_lds<256>(), s, T, nodes, replace_tiny & 1, thresh, info);
+        hipLaunchKernelGGL(k_diag_lu2, dim3(nn), dim3(256), DIAG_LU2_LDS, s, T, nodes, replace_tiny & 1, thresh, info);
         return;
     }
     replace_tiny &= 1;
@@ -1521,13 +1524,13 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 }
 
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level)
+           const int4 *ulist, const int *sn_level, int skip_level, int skip_n)
 {
     if (ntiles <= 0) return;
     const int grid = ((ntiles + 7) / 8) * 8;
-    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
-    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
-    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level);
+    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n);
+    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n);
+    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n);
 }
 
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
@@ -1600,13 +1603,6 @@ void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs,
     if (total <= 0 || nruns <= 0) return;
     const int64_t nb = (total * nrhs + 255) / 256;
     hipLaunchKernelGGL(k_xseg_copy, dim3((unsigned) (nb < 4096 ? nb : 4096)), dim3(256), 0, s, x, ldx, nrhs, runs, nruns, total, buf, mode);
-}
-
-int diag_profile(unsigned long long *out8, int reset)
-{
-    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag_prof), 8 * sizeof(unsigned long long)));
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_prof), z, sizeof(z))); }
-    return 0;
 }
 
 int mfma_selftest(const double *A, const double *B, double *D)

@@ -207,39 +207,46 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
     return rows_a > 0 && cols_a > 0 && 100 * (int64_t) rows_a >= (int64_t) pct * rows_b && 100 * (int64_t) cols_a >= (int64_t) pct * ncolu_b;
 }
 
-static void build_urgent_lists(const HostTables &t, const std::vector<int> &lvl, LevelSched &S)
+static void build_urgent_lists(const HostTables &t, const std::vector<int> &lvl, const std::vector<int> &defer, LevelSched &S)
 {
-    // urgent tiles of level l = the tiles that update a panel of level l + 1, in two parts per tile-size group:
+    // urgent tiles of level l, per tile-size group, in three parts:
     //   part 0: destination is the DIAGONAL block of a level-(l+1) supernode  -> diag_lu(l+1) may start after these alone
     //   part 1: the rest of the block row / block column of those supernodes  -> the panel solves of l+1 wait for these too
+    //   part 2: destination in a panel of level l+2 (and not l+1)             -> with these done early the bulk of level l
+    //           may still be running while the panels of levels l+1 AND l+2 are factored (two-level look-ahead).
+    // A deferred (K-fused) supernode runs parts 0 and 1 only; its partner on the next level applies everything else.
     S.sn_level = lvl;
-    S.u_off.assign(4 * S.nlevels + 1, 0);
+    S.u_off.assign(6 * S.nlevels + 1, 0);
     std::vector<uint8_t> rflag, cflag;
     for (int l = 0; l < S.nlevels; ++l) {
         const int nbig = S.n_big[l];
         for (int g = 0; g < 2; ++g)
-            for (int part = 0; part < 2; ++part) {
+            for (int part = 0; part < 3; ++part) {
                 const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
                 for (int i = b; i < e; ++i) {
                     const int k = S.nodes[i];
                     const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
                     if (!nrt || !nct) continue;
-                    rflag.assign(nrt, 0); cflag.assign(nct, 0);
+                    if (part == 2 && !defer.empty() && defer[k]) continue;
+                    rflag.assign(nrt, 0); cflag.assign(nct, 0);   // 1: level l+1, 2: level l+2
                     bool any = false;
-                    for (int r = 0; r < nrt; ++r) { const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x]; rflag[r] = (lvl[ib] == l + 1); any |= rflag[r]; }
-                    for (int c = 0; c < nct; ++c) { const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x]; cflag[c] = (lvl[jb] == l + 1); any |= cflag[c]; }
+                    for (int r = 0; r < nrt; ++r) { const int d = lvl[t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x]] - l; rflag[r] = (d == 1 || d == 2) ? d : 0; any |= rflag[r] != 0; }
+                    for (int c = 0; c < nct; ++c) { const int d = lvl[t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x]] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; any |= cflag[c] != 0; }
                     if (!any) continue;
                     for (int r = 0; r < nrt; ++r) {
                         const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x];
                         for (int c = 0; c < nct; ++c) {
                             if (!(rflag[r] || cflag[c])) continue;
+                            const bool next = rflag[r] == 1 || cflag[c] == 1;          // feeds a level-(l+1) panel
+                            if (part == 2) { if (!next) S.ulist.push_back(make_int4(k, r, c, 0)); continue; }
+                            if (!next) continue;
                             const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x];
-                            const bool diag = (ib == jb);      // both flags set: the diagonal block of a level-(l+1) supernode
+                            const bool diag = (ib == jb);      // the diagonal block of a level-(l+1) supernode
                             if ((part == 0) == diag) S.ulist.push_back(make_int4(k, r, c, 0));
                         }
                     }
                 }
-                S.u_off[(2 * l + g) * 2 + part + 1] = (int) S.ulist.size();
+                S.u_off[(2 * l + g) * 3 + part + 1] = (int) S.ulist.size();
             }
     }
 }
@@ -296,7 +303,6 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 15) / 16) : 0);    // FIS = 16-row identity strips
         }
     }
-    build_urgent_lists(t, lvl, S);
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
     // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
     // (1 x 1 layers only: on an XY grid a deferred supernode's received panels would have to outlive two exchange phases.)
@@ -332,6 +338,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
                 H.fused_pairs += 1;
             }
     }
+    build_urgent_lists(t, lvl, H.h_defer, S);
 }
 
 static int upload_schedule(Handle &H, LevelSched &S)
@@ -601,6 +608,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIPCHK(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&H->ustream, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&H->u2stream, hipStreamNonBlocking, hi));
     }
     HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
     auto &K = H->d_misc;

@@ -149,10 +149,15 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
             // the separator into singleton supernodes.
             double zacc = 0;
             std::vector<int> extra;
-            // split long chains (separators) into equal pieces <= maxsup instead of maxsup + a small remainder:
-            // the GPU Schur tiles are 128 wide, a 250+250 split fills them, a 256+8 split does not
-            const int pieces = (chain[a] + maxsup - 1) / maxsup;
-            const int cap = (chain[a] + pieces - 1) / pieces;
+            // split long chains (separators) into pieces of exactly maxsup columns (full 128-wide Schur tiles and K chunks
+            // when maxsup is a multiple of 128); the tail of a chain is never a sliver: a remainder below maxsup / 2 is
+            // merged with the piece before it and that is halved (to a multiple of 16)
+            const int rem = chain[a];
+            int cap = maxsup;
+            static const bool equal_split = getenv("SLUAMD_SYMB_EQUAL_SPLIT") != nullptr;   // development: round-2 rule (equal pieces)
+            if (equal_split) { const int pieces = (rem + maxsup - 1) / maxsup; cap = (rem + pieces - 1) / pieces; } else
+            if (rem <= maxsup) cap = rem;
+            else if (rem < 2 * maxsup && rem - maxsup < maxsup / 2) cap = std::min(maxsup, ((rem + 1) / 2 + 15) & ~15);
             while (b + 1 < n && (b - a + 1) < cap && parent[b] == b + 1 && relax_end[b + 1] < 0) {
                 const int c = b + 1;
                 extra.clear();

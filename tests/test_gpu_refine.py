@@ -33,8 +33,12 @@ def test_refinement_matches_reference_fixture(golden, case):
     h.destroy()
 
 
-@pytest.mark.parametrize("N,scale", [(12, None), (0, 0.01)])
+@pytest.mark.parametrize("N,scale", [(12, None), (0, 0.02)])
 def test_refinement_against_oracle(N, scale):
+    """pdgsrfs3d on the device against the restated pdgsrfs3d of the oracle ON THE SAME FACTORS (copied back from the device),
+    same initial solve.  The weakly diagonal random case (element growth 1e8 without pivoting, initial residual 1e-6) needs
+    three refinement steps.  (At diag_scale 0.01 the growth is 1e11 and whether refinement converges at all depends on the
+    rounding of the factorisation -- the supernode partition, the summation order -- for the oracle and the device alike.)"""
     from superlu_dist_amd import driver, matgen
     if N:
         n, rp, ci, v = matgen.poisson3d(N)
@@ -45,18 +49,15 @@ def test_refinement_against_oracle(N, scale):
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
     x, info, st, h, symb = driver.pdgssvx3d(n, rp, ci, v, b, perm_c=perm, relax=8, maxsup=64, keep=True, refine=True)
     assert info == 0
-    # oracle: same factors (copied back from the device), same initial solve, then the restated pdgsrfs3d
-    symb.distribute_host(v)
-    fs = symb.flat_store()
+    fs = symb.flat_store(values=False)
+    h.copy_to_host(fs)
     ost = orc.LUStore(fs.n, fs.xsup, fs.Lrowind_off, fs.Lrowind, fs.Lnzval_off, fs.Lnzval, fs.Ufstnz_off, fs.Ufstnz,
                       fs.Unzval_off, fs.Unzval)
-    anorm = float(np.max(np.add.reduceat(np.abs(v), rp[:-1])))
-    orc.dfactor(ost, None, False, float(np.finfo(np.float32).eps) * anorm)
     pc = symb.perm_c
     xp = np.zeros_like(b, order="F"); xp[pc, :] = b
     X0 = np.asfortranarray(orc.dsolve(ost, xp)[pc, :])
     Xo, berr_o, steps_o = orc.dgsrfs(ost, rp, ci, v, pc, b, X0)
-    assert abs(st["refine_steps"] - steps_o) <= 3      # ~10 steps on the weakly diagonal case: the stopping test (berr halves) sits at rounding level
+    assert abs(st["refine_steps"] - steps_o) <= 1      # the stopping test (berr halves / reaches eps) sits at rounding level
     assert np.all(st["berr"] <= 4 * EPS) and np.all(berr_o <= 4 * EPS)
     assert np.abs(x - Xo).max() <= 1e-11 * max(1.0, np.abs(Xo).max())
     res = np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b)
