@@ -1125,6 +1125,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         }
     }
     __syncthreads();
+    // ---- destination maps (tile row / column -> offset inside the destination panel / U row), before the K loop: the first
+    // source fetch is in flight behind these index loads, and the lines can be touched ahead of the scatter ----
+    const bool has_dst = s_dinfo[3] != 0;
+    double *dst = T.val + s_dbase;
+    if (has_dst) {
+        if (ib >= jb) {
+            // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
+            const int *drows = T.lidx + T.sn_lidx[jb] + s_dinfo[1];
+            const int fnz = T.xsup[ib], dn = s_dinfo[2];
+            for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
+            __syncthreads();
+            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? s_dinfo[0] + s_ind[lsub[t] - fnz] : 0;
+            const int ldv = T.sn_nsupr[jb];
+            for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * ldv;
+        } else {
+            const int64_t d0 = T.sn_uidx[ib] + s_dinfo[0];
+            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
+            for (int t = tid; t < TNv; t += NT) {
+                int cm = 0;
+                if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
+                s_colmap[t] = cm;
+            }
+        }
+    }
+    __syncthreads();
+    double touch0 = 0.0, touch1 = 0.0;
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // a wave whose 32 x 64 (32 x 32) part lies entirely outside a ragged tile skips its MFMAs: the MFMA pipe is the resource
@@ -1189,6 +1215,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
             kbeg = (ns - T.sn_ldu[k]) & ~3;              // U is zero above its tallest segment: skip those k
             cpS = s_cptr; ldS = s_lead;
         }
+        // chunk at which the destination lines are touched: the one before the last chunk of the last source
+        const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((ns_s - 1 - kbeg) / KC - 1) * KC) : -1;
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
         fetch(kbeg);
         stash(buf);
@@ -1196,6 +1224,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         for (int k0 = kbeg; k0 < ns_s; k0 += KC) {
             const bool more = k0 + KC < ns_s;
             if (more) fetch(k0 + KC);
+            if (k0 == ktouch) {
+                // one chunk before the last: touch one element of every destination line (16 rows x 1 column of the tile) so
+                // that the fp64 atomics of the epilogue find their lines in L2 instead of each holding an L2 miss slot
+                constexpr int RG = TMv / 16;
+                const int id0 = tid, id1 = tid + NT;
+                const int c0 = id0 / RG, g0 = id0 % RG, c1 = id1 / RG, g1 = id1 % RG;
+                if (id0 < TNv * RG && c0 < nc && g0 * 16 < nr) touch0 = dst[s_colmap[c0] + s_rowmap[g0 * 16]];
+                if (id1 < TNv * RG && c1 < nc && g1 * 16 < nr) touch1 = dst[s_colmap[c1] + s_rowmap[g1 * 16]];
+            }
             const double *Lb = Ls[buf], *Ub = Us[buf];
             if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Lb, Ub, rm0, cn0, lane, acc);
             if (more) stash(buf ^ 1);
@@ -1205,27 +1242,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     }
 
     // ---- scatter (epilogue) ----------------------------------------------------------------------
-    if (!s_dinfo[3]) return;
-    double *dst = T.val + s_dbase;
-    if (ib >= jb) {
-        // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
-        const int *drows = T.lidx + T.sn_lidx[jb] + s_dinfo[1];
-        const int fnz = T.xsup[ib], dn = s_dinfo[2];
-        for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
-        __syncthreads();
-        for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? s_dinfo[0] + s_ind[lsub[t] - fnz] : 0;
-        const int ldv = T.sn_nsupr[jb];
-        for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * ldv;
-    } else {
-        const int64_t d0 = T.sn_uidx[ib] + s_dinfo[0];
-        for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
-        for (int t = tid; t < TNv; t += NT) {
-            int cm = 0;
-            if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
-            s_colmap[t] = cm;
-        }
-    }
-    __syncthreads();
+    if (!has_dst) return;
+    if (__builtin_expect(touch0 == 1.2345e-300 && touch1 == 1.2345e-300, 0)) atomicAdd(&info[3], 1);   // keeps the touch loads alive
 #pragma unroll
     for (int ci = 0; ci < NBC; ++ci)
 #pragma unroll
