@@ -170,8 +170,6 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
     }
     M.first[nso] = (int) nx.size() - 1;
     const int ns = M.first[nso];
-    // piece of original supernode g holding global row `row`
-    auto piece_of = [&](int g, int row) { int q = M.first[g]; while (nx[q + 1] <= row) ++q; return q; };
     std::vector<std::vector<int>> nl(ns), nu(ns), nsucc(ns);
     std::vector<uint8_t> npresent(ns, 0);
     M.lsrc.assign(ns, {}); M.usrc.assign(ns, {});
@@ -197,26 +195,35 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
                 for (int r = r0; r < r1; ++r) o.push_back(r);
                 ++nb; nr += r1 - r0;
             }
-            int pp = BC_HEADER + LB_DESCRIPTOR + w;
-            for (int b = 1; b < li[0]; ++b) {                     // original off-diagonal blocks, split by the pieces of their supernode
+            // host row (position inside the caller's panel) of every row of the internal slot: the rest of the diagonal block in
+            // place, then every off-diagonal block split by the pieces of its supernode (stable: the reference does not sort the
+            // rows inside a block, symbfact.c keeps discovery order)
+            std::vector<int> hostrow(nr);
+            for (int i = 0; i < nr; ++i) hostrow[i] = c0 + i;
+            int pp = BC_HEADER + LB_DESCRIPTOR + w, rowbase = w;
+            for (int b = 1; b < li[0]; ++b) {
                 const int g = li[pp], nbrow = li[pp + 1];
                 const int *rows = li.data() + pp + LB_DESCRIPTOR;
-                int i = 0, lastq = -1;
-                while (i < nbrow) {
-                    const int q = piece_of(g, rows[i]);
-                    if (q <= lastq) { set_error("L block rows are not grouped by ascending row: cannot refine a wide supernode"); return SLUAMD_ESTRUCT; }
-                    int j2 = i;
-                    while (j2 < nbrow && rows[j2] >= nx[q] && rows[j2] < nx[q + 1]) ++j2;
-                    o.push_back(q); o.push_back(j2 - i);
-                    o.insert(o.end(), rows + i, rows + j2);
+                for (int q = M.first[g]; q < M.first[g + 1]; ++q) {
+                    int cnt = 0;
+                    for (int i = 0; i < nbrow; ++i) cnt += rows[i] >= nx[q] && rows[i] < nx[q + 1];
+                    if (!cnt) continue;
+                    o.push_back(q); o.push_back(cnt);
+                    for (int i = 0; i < nbrow; ++i) if (rows[i] >= nx[q] && rows[i] < nx[q + 1]) { o.push_back(rows[i]); hostrow.push_back(rowbase + i); }
                     nsucc[id].push_back(q);
-                    ++nb; nr += j2 - i; i = j2; lastq = q;
+                    ++nb; nr += cnt;
                 }
-                pp += LB_DESCRIPTOR + nbrow;
+                pp += LB_DESCRIPTOR + nbrow; rowbase += nbrow;
             }
             o[0] = nb; o[1] = nr;
-            if (nr != nsupr_o - c0) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
-            for (int j = c0; j < c1; ++j) M.lsrc[id].push_back({0, ko, (int64_t) j * nsupr_o + c0, (int64_t) nr});
+            if (nr != nsupr_o - c0 || (int) hostrow.size() != nr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
+            for (int j = c0; j < c1; ++j)
+                for (int i = 0; i < nr;) {       // maximal runs of consecutive host rows
+                    int e = i + 1;
+                    while (e < nr && hostrow[e] == hostrow[e - 1] + 1) ++e;
+                    M.lsrc[id].push_back({0, ko, (int64_t) j * nsupr_o + hostrow[i], (int64_t) (e - i)});
+                    i = e;
+                }
             for (int q = p + 1; q < np; ++q) nsucc[id].push_back(f + q);
             // ---- U slot: rows [x0 + c0, x0 + c1) ----
             std::vector<int> &u = nu[id];

@@ -117,7 +117,30 @@ def forests_from_partition(tree, Pz, z):
                            for f in range(2 * Pz - 1)])
 
 
-def check_wide_supernodes(N, maxsup, Pz, orc):
+def shuffle_block_rows(fs, seed):
+    """Permute the rows INSIDE every off-diagonal L block (index entries and values alike): the reference's symbfact keeps the
+    row subscripts of a block in discovery order, not sorted."""
+    rng = np.random.default_rng(seed)
+    for k in range(fs.nsupers):
+        a, e = int(fs.Lrowind_off[k]), int(fs.Lrowind_off[k + 1])
+        if e - a < 2:
+            continue
+        li = fs.Lrowind[a:e]
+        nb, nsupr = int(li[0]), int(li[1])
+        w = int(fs.xsup[k + 1] - fs.xsup[k])
+        V = fs.Lnzval[int(fs.Lnzval_off[k]):int(fs.Lnzval_off[k + 1])].reshape((nsupr, w), order="F")
+        p, r0 = 2, 0
+        for b in range(nb):
+            g, nr = int(li[p]), int(li[p + 1])
+            if g != k and nr > 1:
+                perm = rng.permutation(nr)
+                li[p + 2:p + 2 + nr] = li[p + 2:p + 2 + nr][perm]
+                V[r0:r0 + nr, :] = V[r0:r0 + nr, :][perm, :]
+            p += 2 + nr; r0 += nr
+        fs.Lnzval[int(fs.Lnzval_off[k]):int(fs.Lnzval_off[k + 1])] = V.reshape(-1, order="F")
+
+
+def check_wide_supernodes(N, maxsup, Pz, orc, shuffle=False):
     """Reference-format panels with supernodes of 257..512 columns (sp_ienv(3) <= MAX_SUPER_SIZE = 512) through the view
     path on a 1 x 1 x Pz grid: every L/U value against the CPU oracle's factorisation of the same store, then a solve.
     Layer z > 0 starts with zeroed ancestor panels (pddistribute3d / zeroSetLU)."""
@@ -129,6 +152,8 @@ def check_wide_supernodes(N, maxsup, Pz, orc):
     symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=maxsup)
     symb.distribute_host(v)
     fs0 = symb.flat_store()
+    if shuffle:
+        shuffle_block_rows(fs0, N)
     assert np.diff(fs0.xsup).max() > 256 or maxsup <= 256
     o = orc.LUStore(fs0.n, fs0.xsup, fs0.Lrowind_off, fs0.Lrowind, fs0.Lnzval_off, fs0.Lnzval.copy(), fs0.Ufstnz_off,
                     fs0.Ufstnz, fs0.Unzval_off, fs0.Unzval.copy())
@@ -141,6 +166,8 @@ def check_wide_supernodes(N, maxsup, Pz, orc):
 
     def rank_body(z):
         fs = symb.flat_store()
+        if shuffle:
+            shuffle_block_rows(fs, N)
         fs.grid, fs.coords = (1, 1, Pz), (0, 0, z)
         fs._build_view()
         fr = forests_from_partition(tree, Pz, z) if Pz > 1 else None

@@ -61,9 +61,9 @@ def test_rccl_transport_two_ranks(tmp_path):
     assert "GRID_WORKER_OK" in r.stdout
 
 
-@pytest.mark.parametrize("N,maxsup,Pz", [(18, 512, 1), (24, 384, 1), (24, 512, 2), (32, 512, 2)])
-def test_supernodes_257_to_512_columns(N, maxsup, Pz):
+@pytest.mark.parametrize("N,maxsup,Pz,shuffle", [(18, 512, 1, True), (24, 384, 1, False), (24, 512, 2, True), (32, 512, 2, False)])
+def test_supernodes_257_to_512_columns(N, maxsup, Pz, shuffle):
     """Reference-format panels with supernodes of up to MAX_SUPER_SIZE = 512 columns (superlu_defs.h:154): refined into
     <= 256-column pieces at handle creation; every L/U value in the caller's layout against the CPU oracle."""
     import oracle as orc
-    grid_cases.check_wide_supernodes(N, maxsup, Pz, orc)
+    grid_cases.check_wide_supernodes(N, maxsup, Pz, orc, shuffle)

@@ -64,10 +64,10 @@ def test_gloo_processes_through_the_callback_transport(world, grid, tmp_path):
     assert "GRID_WORKER_OK" in r.stdout
 
 
-@pytest.mark.parametrize("N,maxsup,Pz", [(18, 512, 1), (20, 512, 1), (24, 384, 1), (18, 512, 2), (24, 512, 2)])
-def test_supernodes_257_to_512_columns(emul, N, maxsup, Pz):
+@pytest.mark.parametrize("N,maxsup,Pz,shuffle", [(18, 512, 1, False), (20, 512, 1, True), (24, 384, 1, False), (18, 512, 2, True), (24, 512, 2, False)])
+def test_supernodes_257_to_512_columns(emul, N, maxsup, Pz, shuffle):
     import oracle as orc
-    grid_cases.check_wide_supernodes(N, maxsup, Pz, orc)
+    grid_cases.check_wide_supernodes(N, maxsup, Pz, orc, shuffle)
 
 
 def test_view_grid_must_match_the_communicator(emul, golden):
