@@ -197,7 +197,7 @@ void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lp
 }
 
 void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level, int skip_n)
+           const int4 *ulist, const int *sn_level, int skip_level, int skip_n, int)
 {
     (void) cfg;
     std::vector<double> acc, lrow;
@@ -205,7 +205,7 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
     for (int bid0 = 0; bid0 < ntiles; ++bid0) {
         const int bid = bid0 + id_base;
         int k, rt, ct;
-        if (ulist) { k = ulist[bid].x; rt = ulist[bid].y; ct = ulist[bid].z; }
+        if (ulist) { k = ulist[bid].x; rt = ulist[bid].y - T.sn_rt_off[k]; ct = ulist[bid].z - T.sn_ct_off[k]; }
         else {
             const int ni = find_node(prefix, nn, bid);
             k = nodes[ni];
@@ -263,6 +263,14 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
         const int want = ldest ? ib : jb;
         int pos = -1;
         for (int q = 0; q < nb; ++q) if (dir[o + q] == want) { pos = q; break; }
+        if (ulist) {   // the host-resolved destination block and tile descriptors must agree with the tables
+            const int want_d = pos < 0 ? -1 : (ldest ? o + T.lbs_idx[o + pos] : o + pos);
+            const int2 ri = T.rt_info[ulist[bid].y];
+            const int4 ci = T.ct_info[ulist[bid].z];
+            if (ulist[bid].w != want_d || ri.x != ib || ci.x != jb || T.lidx + ri.y != lsub || ci.y != uix0 || ci.z != T.ub_stcol[ub] + C.y) {
+                std::fprintf(stderr, "engine_cpu: tile list entry disagrees with the block tables\n"); std::abort();
+            }
+        }
         if (pos < 0) { info[2] += 1; continue; }
         if (ldest) {
             const int d = o + T.lbs_idx[o + pos];

@@ -16,6 +16,8 @@ typedef struct emul_stream_s *hipStream_t;
 struct emul_event_s { std::chrono::steady_clock::time_point t; };
 typedef emul_event_s *hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+struct int2 { int x, y; };
+inline int2 make_int2(int x, int y) { int2 v = {x, y}; return v; }
 struct int4 { int x, y, z, w; };
 inline int4 make_int4(int x, int y, int z, int w) { int4 v = {x, y, z, w}; return v; }
 

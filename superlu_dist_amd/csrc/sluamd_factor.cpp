@@ -59,10 +59,10 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     int rc_x = 0;
     int cur_level = 0, cur_pass = 0;
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
-                     const int4 *ulist, int skip_level, int skip_n) {
+                     const int4 *ulist, int skip_level, int skip_n, int prio = 0) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
-        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, skip_n);
+        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, skip_n, prio);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -106,36 +106,32 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         hipEvent_t e = next_event(H);    // the side streams must see everything queued so far on the main stream
         hipEventRecord(e, s); hipStreamWaitEvent(ps, e, 0); hipStreamWaitEvent(us, e, 0); hipStreamWaitEvent(u2s, e, 0);
     }
-    auto group_launch = [&](hipStream_t st, int l, int part) {   // part 0..2: urgent lists; 3 / 4 / 5: full grids minus the tiles that feed levels l+1..l+2 / l+1 / none
+    // parts p0 .. p1 of level l's tile lists (0 / 1: feed level-(l+1) panels, diagonal blocks first; 2: feed level-(l+2) panels;
+    // 3: bulk) as ONE launch per tile-size group -- the parts are contiguous in the list
+    auto list_launch = [&](hipStream_t st, int l, int p0, int p1) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
+        const int nbig = S.n_big[l];
+        for (int g = 0; g < 2; ++g) {
+            const int cnt = g == 0 ? nbig : nn - nbig;
+            if (!cnt) continue;
+            const int u0 = S.u_off[(2 * l + g) * 4 + p0], nu = S.u_off[(2 * l + g) * 4 + p1 + 1] - u0;
+            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, -1, 0, (lookahead && p1 < 3) ? 1 : 0);
+        }
+    };
+    // deterministic mode: one supernode per launch over its full tile grid -- tiles of one k hit distinct destinations, the
+    // summation order is fixed
+    auto grid_launch = [&](hipStream_t st, int l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
         const int *nodes = S.d_nodes + n0;
         const int nbig = S.n_big[l];
-        const bool urgent = !H->opt.deterministic;
         for (int g = 0; g < 2; ++g) {
             const int cnt = g == 0 ? nbig : nn - nbig;
             if (!cnt) continue;
             const int so = S.lvl_soff[l] + (g == 0 ? 0 : nbig + 1);
             const int *gn = nodes + (g == 0 ? 0 : nbig);
-            if (part < 3) {
-                const int u0 = S.u_off[(2 * l + g) * 3 + part], nu = S.u_off[(2 * l + g) * 3 + part + 1] - u0;
-                if (nu) schur(st, g == 0, nu, gn, S.d_tile_prefix + so, cnt, 0, S.d_ulist + u0, -1, 0);
-                continue;
-            }
-            const int nt = S.tile_prefix[so + cnt];
-            if (!nt) continue;
-            if (T.defer && S.lvl_defer[l]) {   // nothing to launch when every supernode of the group is deferred
-                bool all = true;
-                const int i0 = n0 + (g == 0 ? 0 : nbig);
-                for (int i = 0; i < cnt && all; ++i) all = H->h_defer[S.nodes[i0 + i]] != 0;
-                if (all) continue;
-            }
-            if (urgent) {
-                schur(st, g == 0, nt, gn, S.d_tile_prefix + so, cnt, 0, nullptr, part == 5 ? -1 : l + 1, part == 4 ? 1 : 2);
-            } else {  // deterministic: one supernode per launch, tiles of one k hit distinct destinations -> fixed summation order
-                for (int i = 0; i < cnt; ++i) {
-                    const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
-                    if (c) schur(st, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1, 0);
-                }
+            for (int i = 0; i < cnt; ++i) {
+                const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
+                if (c) schur(st, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1, 0);
             }
         }
     };
@@ -151,11 +147,11 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         cur_level = l;
         const bool more = l + 1 < S.nlevels;
         if (!lookahead) {
-            // serial partition (also the measurement harness of the Schur kernel, as in rounds 1-2): one full-grid launch per
-            // level and tile-size group; only K-fused levels need their level-(l+1) urgent tiles launched apart
-            const bool urgent = !H->opt.deterministic && T.defer && S.lvl_defer[l];
-            if (urgent) { for (int part = 0; part < 2; ++part) { cur_pass = part; group_launch(s, l, part); } }
-            cur_pass = 3; group_launch(s, l, urgent ? 4 : 5);
+            // serial partition (also the measurement harness of the Schur kernel, as in rounds 1-2): one launch per level and
+            // tile-size group; only K-fused levels need their level-(l+1) urgent tiles launched apart
+            if (H->opt.deterministic) { cur_pass = 3; grid_launch(s, l); }
+            else if (T.defer && S.lvl_defer[l]) { cur_pass = 0; list_launch(s, l, 0, 0); cur_pass = 1; list_launch(s, l, 1, 1); cur_pass = 3; list_launch(s, l, 2, 3); }
+            else { cur_pass = 3; list_launch(s, l, 0, 3); }
             if (more) { panelA(l + 1); panelB(l + 1); }
             if (rc_x) return rc_x;
             continue;
@@ -163,13 +159,13 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         hipEvent_t e_p = next_event(H);  // panel(l) done
         hipEventRecord(e_p, ps);
         hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);
-        cur_pass = 0; group_launch(us, l, 0);
+        cur_pass = 0; list_launch(us, l, 0, 0);
         hipEvent_t e_u0 = next_event(H); hipEventRecord(e_u0, us);
-        cur_pass = 1; group_launch(us, l, 1);
+        cur_pass = 1; list_launch(us, l, 1, 1);
         hipEvent_t e_u1 = next_event(H); hipEventRecord(e_u1, us);
-        cur_pass = 2; group_launch(u2s, l, 2);
+        cur_pass = 2; list_launch(u2s, l, 2, 2);
         hipEvent_t e_u2 = next_event(H); hipEventRecord(e_u2, u2s);
-        cur_pass = 3; group_launch(s, l, 3);
+        cur_pass = 3; list_launch(s, l, 3, 3);
         hipEvent_t e_bulk = next_event(H); hipEventRecord(e_bulk, s);
         if (more) {
             hipStreamWaitEvent(ps, e_u0, 0);

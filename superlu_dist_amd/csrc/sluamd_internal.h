@@ -121,6 +121,8 @@ struct DevTables {
     const int *sn_ncolu;               // total non-empty U columns of block row k (this slot)
     const int *sn_lb_off, *sn_nlb;     // L block table range
     const int *sn_ub_off, *sn_nub;     // U block table range
+    const int2 *rt_info;               // per row tile / column tile: what the tile prologue would otherwise chase through four tables
+    const int4 *ct_info;
     const int *sn_rt_off, *sn_nrt;     // row-tile range
     const int *sn_ct_off, *sn_nct;     // col-tile range
     // flat maps that replace dependent index walks in the latency-bound kernels: global row id of every L slot row
@@ -166,8 +168,9 @@ struct LevelSched {
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
-    std::vector<int4> ulist;        // urgent tiles (k, rt, ct, 0): per level and tile-size group [diagonal blocks of level l+1 | rest of the level-(l+1) panels | level-(l+2) panels]
-    std::vector<int> u_off;         // [6*nlevels+1] offsets into ulist: index (2*level + group) * 3 + part
+    std::vector<int4> ulist;        // tile lists (k, absolute row tile, absolute column tile, destination block or -1): per level and tile-size group
+                                    // [diagonal blocks of level l+1 | rest of the level-(l+1) panels | level-(l+2) panels | bulk, 8 x 8 bands per supernode]
+    std::vector<int> u_off;         // [8*nlevels+1] offsets into ulist: index (2*level + group) * 4 + part
     // ---- XY block-cyclic exchange plan (empty on a 1 x 1 layer): per level, in ascending supernode order ----
     std::vector<int> dg_prefix;               // per node (lvl_poff layout): 1024-double chunks of the own diagonal blocks to pack
     std::vector<int64_t> dg_off;              // ... and their offsets inside the level's diagonal staging range
@@ -275,7 +278,7 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level, int skip_n);
+           const int4 *ulist, const int *sn_level, int skip_level, int skip_n, int prio);
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);

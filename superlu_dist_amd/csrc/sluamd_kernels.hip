@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
-                                                                    int skip_level, int skip_n)
+                                                                    int skip_level, int skip_n, int prio)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -1033,8 +1033,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     __shared__ int s_cptr2[TNv];  // the same two for the fused predecessor supernode (K-fused chain update)
     __shared__ int s_lead2[TNv];
     __shared__ int s_jj[TNv];     // column id inside supernode jb
-    __shared__ int64_t s_dbase;
-    __shared__ int s_dinfo[4];
+    __shared__ int s_dinfo[1];
 
     const int tid = threadIdx.x;
     // XCD-aware mapping: workgroup b runs on XCD b%8; give every XCD a contiguous range of tiles so that the
@@ -1046,36 +1045,40 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         if ((blockIdx.x >> 3) >= chunk || bid >= ntiles) return;
         bid += id_base;
     }
-    // look-ahead split: `ulist` != null -> explicit (k, row tile, col tile) list of the tiles that update the panels of the
-    // next one or two levels ("urgent"); otherwise the full tile grid, minus the tiles whose destination supernode sits on
-    // levels skip_level .. skip_level + skip_n - 1
-    int k, rt, ct;
+    // `ulist` != null (every schedule but the deterministic one): tile list entry (supernode, absolute row tile, absolute column
+    // tile, destination block) + per-tile descriptors -- the prologue is three dependent (scalar) loads deep.  Otherwise the full
+    // tile grid of the supernodes `nodes`, minus the tiles whose destination supernode sits on levels skip_level .. + skip_n - 1.
+    int k, ib, jb, dblk = -2, stc;
+    int4 R, C;
+    const int *lsub;            // global row ids of the tile rows
+    int64_t uix0;               // this U block inside the uidx arena
+    if (prio) __builtin_amdgcn_s_setprio(2);   // urgent tiles sit on the panel chain
     if (ulist) {
-        __builtin_amdgcn_s_setprio(2);   // urgent tiles sit on the panel chain
         const int4 u = ulist[bid];
-        k = u.x; rt = u.y; ct = u.z;
+        k = u.x; dblk = u.w;
+        R = T.rtile[u.y]; C = T.ctile[u.z];
+        const int2 ri = T.rt_info[u.y];
+        const int4 ci = T.ct_info[u.z];
+        ib = ri.x; jb = ci.x; lsub = T.lidx + ri.y; uix0 = ci.y; stc = ci.z;
     } else {
         const int ni = find_node(prefix, nn, bid);
         k = nodes[ni];
         const int local = bid - prefix[ni];
-        // bands of 8 row tiles, column-major inside a band: the ~64 tiles an XCD runs at a time form an 8 x 8 block that
-        // shares 8 L row tiles and 8 U column tiles in that XCD's L2 (row-major order streamed one U tile per tile)
-        const int nct = T.sn_nct[k], nrt = T.sn_nrt[k];
-        const int band = local / (8 * nct), rem = local - band * 8 * nct;
-        const int bh = min(8, nrt - 8 * band);
-        ct = rem / bh; rt = 8 * band + (rem - ct * bh);
+        const int nct = T.sn_nct[k];
+        const int rt = local / nct, ct = local - rt * nct;
+        R = T.rtile[T.sn_rt_off[k] + rt];
+        C = T.ctile[T.sn_ct_off[k] + ct];
+        const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
+        ib = T.lb_gid[lb]; jb = T.ub_gid[ub];
+        if (skip_level >= 0 && ((unsigned) (sn_level[ib] - skip_level) < (unsigned) skip_n || (unsigned) (sn_level[jb] - skip_level) < (unsigned) skip_n)) return;
+        if (T.defer && T.defer[k]) return;   // K-fused: the partner supernode's tiles apply this update
+        lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
+        uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
+        stc = T.ub_stcol[ub] + C.y;
     }
-    const int4 R = T.rtile[T.sn_rt_off[k] + rt];
-    const int4 C = T.ctile[T.sn_ct_off[k] + ct];
-    const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
     const int nr = __builtin_amdgcn_readfirstlane(R.z), nc = __builtin_amdgcn_readfirstlane(C.z);   // workgroup-uniform
-    const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
-    if (!ulist && skip_level >= 0 && ((unsigned) (sn_level[ib] - skip_level) < (unsigned) skip_n || (unsigned) (sn_level[jb] - skip_level) < (unsigned) skip_n)) return;  // done by the urgent launches
-    if (!ulist && T.defer && T.defer[k]) return;   // K-fused: the partner supernode's tiles apply this update
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int lda = T.sn_nsupr[k];
-    const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;  // global row ids of the tile rows
-    const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
     const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
     const double *Uv = T.val + T.sn_uval[k];
 
@@ -1094,8 +1097,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         }
         s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
     }
-    // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches -> binary search) ----
-    if ((tid >> 6) == NW - 1) {
+    // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches): host-resolved in list mode ----
+    if (dblk == -2 && (tid >> 6) == NW - 1) {
         // one wave scans the gid directory of the destination panel / row with ONE coalesced load per 64 blocks and a
         // ballot, instead of a binary search whose every step is a dependent L2 round trip
         const int ln = tid & 63;
@@ -1110,37 +1113,34 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
             const unsigned long long m = __ballot(g == want);
             if (m) pos = base + __ffsll((long long) m) - 1;
         }
-        if (ln == 0) {
-            if (pos >= 0) {
-                if (ldest) {
-                    const int d = o + T.lbs_idx[o + pos];
-                    s_dinfo[0] = T.lb_rowoff[d]; s_dinfo[1] = T.lb_lptr[d]; s_dinfo[2] = T.lb_nbrow[d];
-                    s_dbase = T.sn_lval[jb];
-                } else {
-                    s_dinfo[0] = T.ub_iukp[o + pos];
-                    s_dbase = T.sn_uval[ib];
-                }
-            } else atomicAdd(&info[2], 1);
-            s_dinfo[3] = pos >= 0;
-        }
+        if (ln == 0) s_dinfo[0] = pos < 0 ? -1 : (ldest ? o + T.lbs_idx[o + pos] : o + pos);
     }
     __syncthreads();
+    if (dblk == -2) dblk = s_dinfo[0];
+    const bool has_dst = dblk >= 0;
+    if (!has_dst && tid == 0) atomicAdd(&info[2], 1);
+    // destination block: (row offset inside the panel, its row ids, its row count) of L(ib, jb), or the index position of U(ib, jb)
+    int di0 = 0, di1 = 0, di2 = 0;
+    int64_t dbase = 0;
+    if (has_dst) {
+        if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = T.sn_lval[jb]; }
+        else { di0 = T.ub_iukp[dblk]; dbase = T.sn_uval[ib]; }
+    }
     // ---- destination maps (tile row / column -> offset inside the destination panel / U row), before the K loop: the first
     // source fetch is in flight behind these index loads, and the lines can be touched ahead of the scatter ----
-    const bool has_dst = s_dinfo[3] != 0;
-    double *dst = T.val + s_dbase;
+    double *dst = T.val + dbase;
     if (has_dst) {
         if (ib >= jb) {
             // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
-            const int *drows = T.lidx + T.sn_lidx[jb] + s_dinfo[1];
-            const int fnz = T.xsup[ib], dn = s_dinfo[2];
+            const int *drows = T.lidx + T.sn_lidx[jb] + di1;
+            const int fnz = T.xsup[ib], dn = di2;
             for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
             __syncthreads();
-            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? s_dinfo[0] + s_ind[lsub[t] - fnz] : 0;
+            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? di0 + s_ind[lsub[t] - fnz] : 0;
             const int ldv = T.sn_nsupr[jb];
             for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * ldv;
         } else {
-            const int64_t d0 = T.sn_uidx[ib] + s_dinfo[0];
+            const int64_t d0 = T.sn_uidx[ib] + di0;
             for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
             for (int t = tid; t < TNv; t += NT) {
                 int cm = 0;
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
             const int pj = 3 * k + (nprev - 1 - src);
             const int ks = T.fuse_prev[pj];
             const int nss = T.xsup[ks + 1] - T.xsup[ks];
-            const int *cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[pj] + T.ub_stcol[ub] + C.y);
+            const int *cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[pj] + stc);
             const int ra = (li < nr) ? T.pair_rowmap[T.pair_roff[pj] + R.w + li] : -1;
             for (int t = tid; t < TNv; t += NT) {
                 s_cptr2[t] = (t < nc) ? cinfo[2 * t] : 0;
@@ -1542,13 +1542,13 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 }
 
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level, int skip_n)
+           const int4 *ulist, const int *sn_level, int skip_level, int skip_n, int prio)
 {
     if (ntiles <= 0) return;
     const int grid = ((ntiles + 7) / 8) * 8;
-    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n);
-    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n);
-    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n);
+    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n, prio);
+    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n, prio);
+    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n, prio);
 }
 
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)

@@ -130,12 +130,22 @@ static int build_tables(Handle &H, HostTables &t)
             const int tm = big ? 128 : 64;
             for (int b = bfirst; b < nb; ++b) {
                 const int nbrow = t.lb_nbrow[lb0 + b], ro = t.lb_rowoff[lb0 + b];
-                for (int r0 = 0; r0 < nbrow; r0 += tm) t.rtile.push_back(make_int4(b, r0, std::min(tm, nbrow - r0), ro + r0));
+                for (int r0 = 0; r0 < nbrow; r0 += tm) {
+                    t.rtile.push_back(make_int4(b, r0, std::min(tm, nbrow - r0), ro + r0));
+                    const int64_t lo = t.sn_lidx[k] + t.lb_lptr[lb0 + b] + r0;
+                    if (lo > 0x7fffffff) { set_error("index arena too large for 32-bit tile descriptors"); return SLUAMD_ESTRUCT; }
+                    t.rt_info.push_back(make_int2(t.lb_gid[lb0 + b], (int) lo));
+                }
             }
             t.sn_nrt[k] = (int) t.rtile.size() - t.sn_rt_off[k];
             for (int b = 0; b < nub; ++b) {
                 const int nc = t.ub_ncols[ub0 + b];
-                for (int c0 = 0; c0 < nc; c0 += tm) t.ctile.push_back(make_int4(b, c0, std::min(tm, nc - c0), 0));
+                for (int c0 = 0; c0 < nc; c0 += tm) {
+                    t.ctile.push_back(make_int4(b, c0, std::min(tm, nc - c0), 0));
+                    const int64_t uo = t.sn_uidx[k] + t.ub_iukp[ub0 + b];
+                    if (uo > 0x7fffffff) { set_error("index arena too large for 32-bit tile descriptors"); return SLUAMD_ESTRUCT; }
+                    t.ct_info.push_back(make_int4(t.ub_gid[ub0 + b], (int) uo, t.ub_stcol[ub0 + b] + c0, 0));
+                }
             }
             t.sn_nct[k] = (int) t.ctile.size() - t.sn_ct_off[k];
         }
@@ -207,46 +217,79 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
     return rows_a > 0 && cols_a > 0 && 100 * (int64_t) rows_a >= (int64_t) pct * rows_b && 100 * (int64_t) cols_a >= (int64_t) pct * ncolu_b;
 }
 
-static void build_urgent_lists(const HostTables &t, const std::vector<int> &lvl, const std::vector<int> &defer, LevelSched &S)
+// destination block of the update L(ib, k) U(k, jb): index into the lb tables (block ib of panel jb, ib >= jb) or into the ub
+// tables (block jb of U row ib); -1 when this rank has no such block (structure not closed / not an own slot)
+static int dest_block(const HostTables &t, int ib, int jb)
 {
-    // urgent tiles of level l, per tile-size group, in three parts:
+    if (ib >= jb) {
+        const int o = t.sn_lb_off[jb], nb = t.sn_nlb[jb];
+        const int *g = t.lbs_gid.data() + o;
+        const int *p = std::lower_bound(g, g + nb, ib);
+        return (p != g + nb && *p == ib) ? o + t.lbs_idx[o + (int) (p - g)] : -1;
+    }
+    const int o = t.sn_ub_off[ib], nb = t.sn_nub[ib];
+    const int *g = t.ub_gid.data() + o;
+    const int *p = std::lower_bound(g, g + nb, jb);
+    return (p != g + nb && *p == jb) ? o + (int) (p - g) : -1;
+}
+
+static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, const std::vector<int> &defer, LevelSched &S)
+{
+    // every Schur tile of the schedule as (supernode, absolute row tile, absolute column tile, destination block): ONE load gives a
+    // workgroup what it otherwise chases through a prefix search and six tables.  Per level and tile-size group, four parts:
     //   part 0: destination is the DIAGONAL block of a level-(l+1) supernode  -> diag_lu(l+1) may start after these alone
     //   part 1: the rest of the block row / block column of those supernodes  -> the panel solves of l+1 wait for these too
     //   part 2: destination in a panel of level l+2 (and not l+1)             -> with these done early the bulk of level l
-    //           may still be running while the panels of levels l+1 AND l+2 are factored (two-level look-ahead).
+    //           may still be running while the panels of levels l+1 AND l+2 are factored (two-level look-ahead)
+    //   part 3: the bulk, supernode after supernode in bands of 8 row tiles, column-major inside a band: the ~64 tiles an XCD
+    //           runs at a time form an 8 x 8 block that shares 8 L row tiles and 8 U column tiles in that XCD's L2.
     // A deferred (K-fused) supernode runs parts 0 and 1 only; its partner on the next level applies everything else.
     S.sn_level = lvl;
-    S.u_off.assign(6 * S.nlevels + 1, 0);
-    std::vector<uint8_t> rflag, cflag;
+    S.u_off.assign(8 * S.nlevels + 1, 0);
+    std::vector<int8_t> rflag, cflag;
+    std::vector<int> dcache;
     for (int l = 0; l < S.nlevels; ++l) {
         const int nbig = S.n_big[l];
         for (int g = 0; g < 2; ++g)
-            for (int part = 0; part < 3; ++part) {
+            for (int part = 0; part < 4; ++part) {
                 const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
                 for (int i = b; i < e; ++i) {
                     const int k = S.nodes[i];
                     const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
                     if (!nrt || !nct) continue;
-                    if (part == 2 && !defer.empty() && defer[k]) continue;
+                    if (part >= 2 && !defer.empty() && defer[k]) continue;
+                    const int r0 = t.sn_rt_off[k], c0 = t.sn_ct_off[k], nub = t.sn_nub[k];
                     rflag.assign(nrt, 0); cflag.assign(nct, 0);   // 1: level l+1, 2: level l+2
                     bool any = false;
-                    for (int r = 0; r < nrt; ++r) { const int d = lvl[t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x]] - l; rflag[r] = (d == 1 || d == 2) ? d : 0; any |= rflag[r] != 0; }
-                    for (int c = 0; c < nct; ++c) { const int d = lvl[t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x]] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; any |= cflag[c] != 0; }
-                    if (!any) continue;
-                    for (int r = 0; r < nrt; ++r) {
-                        const int ib = t.lb_gid[t.sn_lb_off[k] + t.rtile[t.sn_rt_off[k] + r].x];
+                    for (int r = 0; r < nrt; ++r) { const int d = lvl[t.rt_info[r0 + r].x] - l; rflag[r] = (d == 1 || d == 2) ? d : 0; any |= rflag[r] != 0; }
+                    for (int c = 0; c < nct; ++c) { const int d = lvl[t.ct_info[c0 + c].x] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; any |= cflag[c] != 0; }
+                    if (part < 3 && !any) continue;
+                    dcache.assign((size_t) t.sn_nlb[k] * std::max(nub, 1), -2);
+                    auto emit = [&](int r, int c) {
+                        int &d = dcache[(size_t) t.rtile[r0 + r].x * nub + t.ctile[c0 + c].x];
+                        if (d == -2) d = dest_block(t, t.rt_info[r0 + r].x, t.ct_info[c0 + c].x);
+                        S.ulist.push_back(make_int4(k, r0 + r, c0 + c, d));
+                    };
+                    if (part == 3) {
+                        for (int band = 0; band < nrt; band += 8) {
+                            const int bh = std::min(8, nrt - band);
+                            for (int c = 0; c < nct; ++c)
+                                for (int r = band; r < band + bh; ++r)
+                                    if (!(rflag[r] || cflag[c])) emit(r, c);
+                        }
+                        continue;
+                    }
+                    for (int r = 0; r < nrt; ++r)
                         for (int c = 0; c < nct; ++c) {
                             if (!(rflag[r] || cflag[c])) continue;
                             const bool next = rflag[r] == 1 || cflag[c] == 1;          // feeds a level-(l+1) panel
-                            if (part == 2) { if (!next) S.ulist.push_back(make_int4(k, r, c, 0)); continue; }
+                            if (part == 2) { if (!next) emit(r, c); continue; }
                             if (!next) continue;
-                            const int jb = t.ub_gid[t.sn_ub_off[k] + t.ctile[t.sn_ct_off[k] + c].x];
-                            const bool diag = (ib == jb);      // the diagonal block of a level-(l+1) supernode
-                            if ((part == 0) == diag) S.ulist.push_back(make_int4(k, r, c, 0));
+                            const bool diag = t.rt_info[r0 + r].x == t.ct_info[c0 + c].x;      // the diagonal block of a level-(l+1) supernode
+                            if ((part == 0) == diag) emit(r, c);
                         }
-                    }
                 }
-                S.u_off[(2 * l + g) * 3 + part + 1] = (int) S.ulist.size();
+                S.u_off[(2 * l + g) * 4 + part + 1] = (int) S.ulist.size();
             }
     }
 }
@@ -338,7 +381,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
                 H.fused_pairs += 1;
             }
     }
-    build_urgent_lists(t, lvl, H.h_defer, S);
+    build_tile_lists(t, lvl, H.h_defer, S);
 }
 
 static int upload_schedule(Handle &H, LevelSched &S)
@@ -639,7 +682,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     UP(lb_gid, t.lb_gid, int) UP(lb_nbrow, t.lb_nbrow, int) UP(lb_rowoff, t.lb_rowoff, int) UP(lb_lptr, t.lb_lptr, int)
     UP(lbs_gid, t.lbs_gid, int) UP(lbs_idx, t.lbs_idx, int)
     UP(ub_gid, t.ub_gid, int) UP(ub_ncols, t.ub_ncols, int) UP(ub_iukp, t.ub_iukp, int) UP(ub_stcol, t.ub_stcol, int)
-    UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4)
+    UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4) UP(rt_info, t.rt_info, int2) UP(ct_info, t.ct_info, int4)
     UP(lrow, t.lrow, int) UP(sn_lrow, t.sn_lrow, int64_t) UP(ucol_cp, t.ucol_cp, int) UP(ucol_ld, t.ucol_ld, int) UP(ucol_gc, t.ucol_gc, int) UP(sn_ucol, t.sn_ucol, int64_t)
 #undef UP
     for (auto &S : H->sched) if (upload_schedule(*H, S)) return SLUAMD_EHIP;

@@ -26,6 +26,8 @@ struct HostTables {
     std::vector<int> lrow, ucol_cp, ucol_ld, ucol_gc;
     std::vector<int64_t> sn_lrow, sn_ucol;
     std::vector<int4> rtile, ctile;
+    std::vector<int2> rt_info;     // per row tile: (gid of its block row, offset of its row ids inside the lidx arena)
+    std::vector<int4> ct_info;     // per column tile: (gid of its block column, offset of its U block inside the uidx arena, rank of its first column among the non-empty columns of the U row, 0)
     std::vector<uint8_t> sn_big;   // 1: supernode uses the 128x128 Schur tile configuration
 };
 
