@@ -1051,7 +1051,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     int k, ib, jb, dblk = -2, stc;
     int4 R, C;
     const int *lsub;            // global row ids of the tile rows
-    int64_t uix0;               // this U block inside the uidx arena
     if (prio) __builtin_amdgcn_s_setprio(2);   // urgent tiles sit on the panel chain
     if (ulist) {
         const int4 u = ulist[bid];
@@ -1059,7 +1058,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         R = T.rtile[u.y]; C = T.ctile[u.z];
         const int2 ri = T.rt_info[u.y];
         const int4 ci = T.ct_info[u.z];
-        ib = ri.x; jb = ci.x; lsub = T.lidx + ri.y; uix0 = ci.y; stc = ci.z;
+        ib = ri.x; jb = ci.x; lsub = T.lidx + ri.y; stc = ci.z;
     } else {
         const int ni = find_node(prefix, nn, bid);
         k = nodes[ni];
@@ -1073,7 +1072,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         if (skip_level >= 0 && ((unsigned) (sn_level[ib] - skip_level) < (unsigned) skip_n || (unsigned) (sn_level[jb] - skip_level) < (unsigned) skip_n)) return;
         if (T.defer && T.defer[k]) return;   // K-fused: the partner supernode's tiles apply this update
         lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
-        uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
         stc = T.ub_stcol[ub] + C.y;
     }
     const int nr = __builtin_amdgcn_readfirstlane(R.z), nc = __builtin_amdgcn_readfirstlane(C.z);   // workgroup-uniform
@@ -1088,14 +1086,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     // column of k, where the same global row / column sits in its panel / U row (or that it is absent = zeros).
     int nprev = 0;
     if (T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
-    for (int t = tid; t < TNv; t += NT) {
-        int cp = 0, lead = ns, jj = 0;
-        if (t < nc) {
-            jj = T.unzcol[uix0 + C.y + t];
-            lead = ns - (klst - T.uidx[uix0 + jj]);
-            cp = T.ucolptr[uix0 + jj];
+    {   // per tile column: value offset inside U(k,:), leading zeros, column id inside supernode jb -- flat per-non-empty-column maps
+        const int64_t cb = T.sn_ucol[k] + stc;
+        const int fstj = T.xsup[jb];
+        for (int t = tid; t < TNv; t += NT) {
+            int cp = 0, lead = ns, jj = 0;
+            if (t < nc) { cp = T.ucol_cp[cb + t]; lead = T.ucol_ld[cb + t]; jj = T.ucol_gc[cb + t] - fstj; }
+            s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
         }
-        s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
     }
     // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches): host-resolved in list mode ----
     if (dblk == -2 && (tid >> 6) == NW - 1) {
