@@ -96,7 +96,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     };
     // Stream program.  Serial mode: everything in order on one stream.  Look-ahead mode, four streams:
     //   s   (bulk)     : the bulk of Schur(l), level after level                                        -- never waits for a later panel
-    //   us  (urgent 1) : U1(l) [tiles that feed level-(l+1) panels: diagonal blocks first]
+    //   us  (urgent 1) : U1(l) [tiles that feed level-(l+1) panels] minus its diagonal-block tiles, which run on ps in front of diag_lu(l+1)
     //   u2s (urgent 2) : U2(l) [tiles that feed level-(l+2) panels]
     //   ps  (panels)   : panel(l+1) = diag LU / inverses after U1's diagonal part, panel solves after all of U1(l)
     // panel(l+1) needs U1(l), U2(l-1) and the bulk of every level <= l-2: while the bulk of one level runs, the panels of the
@@ -159,8 +159,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         hipEvent_t e_p = next_event(H);  // panel(l) done
         hipEventRecord(e_p, ps);
         hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);
-        cur_pass = 0; list_launch(us, l, 0, 0);
-        hipEvent_t e_u0 = next_event(H); hipEventRecord(e_u0, us);
+        cur_pass = 0; list_launch(ps, l, 0, 0);   // on the panel stream itself: diag_lu(l+1) follows in stream order, no event hop
         cur_pass = 1; list_launch(us, l, 1, 1);
         hipEvent_t e_u1 = next_event(H); hipEventRecord(e_u1, us);
         cur_pass = 2; list_launch(u2s, l, 2, 2);
@@ -168,7 +167,6 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         cur_pass = 3; list_launch(s, l, 3, 3);
         hipEvent_t e_bulk = next_event(H); hipEventRecord(e_bulk, s);
         if (more) {
-            hipStreamWaitEvent(ps, e_u0, 0);
             if (e_u2_prev) hipStreamWaitEvent(ps, e_u2_prev, 0);
             if (e_bulk_prev2) hipStreamWaitEvent(ps, e_bulk_prev2, 0);
             if (xy && e_bulk_prev) hipStreamWaitEvent(ps, e_bulk_prev, 0);   // XY layer: the received panels of level l-1 share the scratch copy (level parity) that panel(l+1)'s exchange fills
