@@ -140,13 +140,15 @@ static int scatter_positions(const Handle &H, const Symb &sy, const HostTables &
     for (size_t zl = 0; zl < H.forest_nodes.size(); ++zl)
         if (g.z % (1 << zl) == 0) for (int k : H.forest_nodes[zl]) mine[k] = 1;
     pos.assign((size_t) rowptr[n], -1);
+    // supernode of a column in the handle's (possibly refined: H.split) partition
+    auto snode = [&](int col) { return H.split.active ? (int) (std::upper_bound(hs.xsup.begin(), hs.xsup.end(), col) - hs.xsup.begin()) - 1 : sy.supno[col]; };
     for (int64_t i = 0; i < n; ++i)
         for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
             const int pi = perm[i], pj = perm[colind[e]];
-            const int s = sy.supno[pj];
+            const int s = snode(pj);
             if (pi >= hs.xsup[s]) {       // L(:, s), row pi
                 if (!mine[s] || g.kcol(s) != g.c) continue;
-                const int ib = sy.supno[pi];
+                const int ib = snode(pi);
                 if (g.krow(ib) != g.r) continue;
                 const int o = t.sn_lb_off[s], nb = t.sn_nlb[s];
                 const int *dir = t.lbs_gid.data() + o;
@@ -158,7 +160,7 @@ static int scatter_positions(const Handle &H, const Symb &sy, const HostTables &
                 if (fr == rows + t.lb_nbrow[b] || *fr != pi) { fr = std::find(rows, rows + t.lb_nbrow[b], pi); if (fr == rows + t.lb_nbrow[b]) { set_error("A entry outside the symbolic structure of L"); return SLUAMD_ESTRUCT; } }
                 pos[e] = hs.lval_off[s] + t.lb_rowoff[b] + (fr - rows) + (int64_t) (pj - hs.xsup[s]) * t.sn_nsupr[s];
             } else {                       // U(r, s), r = supernode of row pi
-                const int r = sy.supno[pi];
+                const int r = snode(pi);
                 if (!mine[r] || g.krow(r) != g.r || g.kcol(s) != g.c) continue;
                 const int o = t.sn_ub_off[r], nb = t.sn_nub[r];
                 const int *dir = t.ub_gid.data() + o;

@@ -437,7 +437,7 @@ int slots_from_symb(Handle &H, const Symb &sy, const Grid &g, const int32_t *sn_
         }
     }
     finish_succ(in);
-    return 0;
+    return split_wide_supernodes(H, in);   // supernodes of 257..512 columns (maxsup up to MAX_SUPER_SIZE): refined like the view path
 }
 
 }  // namespace sluamd

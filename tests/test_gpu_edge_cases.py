@@ -75,18 +75,41 @@ def test_nrhs_zero_is_a_noop_and_negative_is_rejected():
     h.destroy()
 
 
-def test_supernodes_wider_than_256_from_own_symbolic_are_rejected_with_a_message():
-    """SUPERLU_MAXSUP may go up to 512 in the reference (sp_ienv.c).  Reference-format panels with such supernodes are
-    handled (test_gpu_grid.py::test_supernodes_257_to_512_columns); the library's OWN symbolic path states its limit
-    (ask it for maxsup <= 256) instead of silently mis-computing."""
+def test_dense_supernode_of_300_columns_through_the_own_symbolic_path():
+    """SUPERLU_MAXSUP may go up to 512 in the reference (sp_ienv.c).  One 300-column supernode (dense matrix, relax = maxsup = 300)
+    through sluamd_dCreateLUHandleFromSymb: refined into two pieces internally, A distributed on the device into the pieces."""
     rng = np.random.default_rng(4)
     A = rng.standard_normal((300, 300)) * 0.1 + 300 * np.eye(300)
     n, rp, ci, v = _csr(A)
     symb = driver.Symbolic(n, rp, ci, None, relax=300, maxsup=300)
     if np.diff(symb.xsup()).max() <= 256:
         pytest.skip("symbolic did not produce a wide supernode")
-    with pytest.raises(RuntimeError, match="256"):
-        driver.LUHandle.from_symbolic(symb, v)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    assert h.pdgstrf3d(0.0) == 0
+    b = rng.standard_normal((n, 2))
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    x = h.pdgstrs3d(xp)[symb.perm_c, :]
+    assert np.abs(A @ x - b).max() <= 1e-10 * np.abs(b).max()
+    h.destroy()
+
+
+def test_wide_supernodes_on_an_xy_layer_are_rejected_with_a_message():
+    """The refinement of 257..512-column supernodes is implemented for 1 x 1 x Pz grids; a 2 x 1 layer states the limit."""
+    from superlu_dist_amd import grid3d
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((300, 300)) * 0.1 + 300 * np.eye(300)
+    n, rp, ci, v = _csr(A)
+    symb = driver.Symbolic(n, rp, ci, None, relax=300, maxsup=300)
+    if np.diff(symb.xsup()).max() <= 256:
+        pytest.skip("symbolic did not produce a wide supernode")
+    comms = grid3d.local_comms(2, 1, 1)
+
+    def body(rank):
+        with pytest.raises(RuntimeError, match="256"):
+            grid3d.GridHandle.from_symbolic(symb, v, comms[rank], None)
+        return 0
+
+    grid3d.run_ranks(2, body)
 
 
 def test_dense_supernode_of_300_columns_through_the_view_path():

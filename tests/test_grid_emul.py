@@ -77,3 +77,10 @@ def test_view_grid_must_match_the_communicator(emul, golden):
     comms = grid3d.local_comms(1, 1, 2)
     with pytest.raises(RuntimeError, match="does not match"):
         grid3d.GridHandle.from_store(st, None, comms[0])
+
+
+@pytest.mark.parametrize("grid", [(1, 1, 1), (1, 1, 2)])
+def test_own_pipeline_with_supernodes_up_to_512_columns(emul, grid):
+    """maxsup = 512 through the library's own symbolic factorisation + device-side distribution: wide supernodes are refined
+    at handle creation, A's entries are scattered straight into the pieces."""
+    grid_cases.check_own_pipeline(18, grid, nrhs=2, leaf=64, relax=64, maxsup=512)
