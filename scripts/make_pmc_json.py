@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build profiles/rNN_pmc_schur.json (bench.py reads profiles/r02_pmc_schur.json) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite) of
-`python bench.py --steps 1 --warmup 1 --no-cpu-baseline` (3 factorisations per run).
+`python bench.py --steps 1 --warmup 2 --no-cpu-baseline` (4 factorisations per run: counted from the k_scatter_values launches).
 usage: make_pmc_json.py fetch.db write.db n_factorisations "source text" > profiles/r01_pmc_schur.json"""
 import hashlib, json, os, re, sqlite3, sys
 
@@ -24,9 +24,17 @@ def total(path, counter):
     return s, n
 
 
+def count_launches(path, counter, what):
+    cur = sqlite3.connect(path).cursor()
+    return sum(1 for name, cname in cur.execute("select name, counter_name from pmc_events") if cname == counter and what in name)
+
+
 fetch_kb, nl = total(sys.argv[1], "FETCH_SIZE")
 write_kb, nl2 = total(sys.argv[2], "WRITE_SIZE")
-nf = int(sys.argv[3])
+# factorisations in the run: every bench step (warm-up, timed, profiled) re-distributes A with one k_scatter_values launch, and the
+# handle creation launches one more; argv[3] is only the fallback
+nsc = count_launches(sys.argv[1], "FETCH_SIZE", "k_scatter_values")
+nf = nsc - 1 if nsc > 1 else int(sys.argv[3])
 fetch_b, write_b = fetch_kb * 1024.0, write_kb * 1024.0
 out = {
     "source": sys.argv[4],
