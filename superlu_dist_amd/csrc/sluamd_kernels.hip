@@ -99,6 +99,53 @@ __device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, i
     for (int c = 0; c < DB; ++c) if (lane < nb && c < nb) P[c * ld + lane] = a[c];
 }
 
+// Diagonal blocks of at most 64 columns -- the tens of thousands of leaf supernodes at the bottom of the elimination DAG: ONE WAVE per
+// block, the whole block in registers (lane r holds row r, 64 columns = 128 VGPRs), pivot rows broadcast with v_readlane: no LDS, no
+// barrier, one load and one store of the block.  (The workgroup-per-block kernel below spends ~150 us per block in barriers and L2
+// round trips: 1.5 - 2.4 ms per level for the four bottom levels of the 100^3 tree, exposed -- nothing else can run yet.)
+// Arithmetic as k_diag_lu / Local_Dgstrf2 (pdgstrf2.c:508-601): unpivoted right-looking elimination, tiny-pivot replacement, zero-pivot info.
+__global__ __launch_bounds__(256, 2) void k_diag_lu_wave(DevTables T, const int *__restrict__ nodes, int nn, int replace_tiny, double thresh,
+                                                         int *__restrict__ info)
+{
+    const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bi >= nn) return;
+    const int k = nodes[bi];
+    if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const int lda = T.sn_dlda[k];
+    double *A = T.val + T.sn_dptr[k];
+    const int lane = threadIdx.x & 63;
+    const bool rok = lane < ns;
+    double a[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) a[c] = (rok && c < ns) ? A[lane + (size_t) c * lda] : ((c == lane) ? 1.0 : 0.0);   // identity-padded
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (j < ns) {                                  // wave-uniform
+            double p = lane_bcast(a[j], j);
+            if (replace_tiny && fabs(p) < thresh) {
+                p = (p < 0) ? -thresh : thresh;
+                if (lane == j) a[j] = p;
+                if (lane == 0) atomicAdd(&info[1], 1);
+            }
+            if (p == 0.0 && lane == 0) atomicMin(&info[0], fst + j + 1);
+            const double rinv = (p != 0.0) ? 1.0 / p : 1.0;
+            const bool below = lane > j;
+            const double l = a[j] * rinv;
+            if (below) a[j] = l;
+#pragma unroll
+            for (int c = j + 1; c < 64; ++c) {
+                const double u = lane_bcast(a[c], j);
+                if (below) a[c] -= l * u;
+                if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the broadcast SGPRs
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) if (rok && c < ns) A[lane + (size_t) c * lda] = a[c];
+}
+
 // Blocked right-looking LU of the diagonal block in place in HBM/L2 (the block is re-read through L2 only):
 // per 32 columns: panel -> LDS, 32x32 head factored in registers by one wave, rows below solved one per thread
 // in registers, U12 one column per thread in registers, rank-32 trailing update on fp64 MFMA.
@@ -1519,7 +1566,7 @@ void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx
         return;
     }
     replace_tiny &= 1;
-    if (mx <= 64) hipLaunchKernelGGL(k_diag_lu<64>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
+    if (mx <= 64) hipLaunchKernelGGL(k_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
     else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
     hipLaunchKernelGGL(k_diag_inv_all, dim3(nn), dim3(256), 0, s, T, nodes);     // the contract: dinv of the owned blocks
