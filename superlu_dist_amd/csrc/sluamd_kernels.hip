@@ -592,15 +592,16 @@ __global__ __launch_bounds__(128) void k_diag_inv(DevTables T, const int *__rest
 
 // the same inverses for the OWNED diagonal blocks of a node list, one workgroup per supernode (companion of the
 // right-looking k_diag_lu; k_diag_lu2 writes them itself)
-__global__ __launch_bounds__(256) void k_diag_inv_all(DevTables T, const int *__restrict__ nodes)
+template <int NG>   // NG groups of 32 threads, one 32 x 32 inverse each: 8 (any width), or 4 for levels of <= 64-wide supernodes (at most 4 inverses)
+__global__ __launch_bounds__(NG * 32) void k_diag_inv_all(DevTables T, const int *__restrict__ nodes)
 {
-    __shared__ double Bs[8][DB * (DB + 1)];
+    __shared__ double Bs[NG][DB * (DB + 1)];
     const int k = nodes[blockIdx.x];
     if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;
     const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB, lda = T.sn_dlda[k];
     const double *A = T.val + T.sn_dptr[k];
     const int g = threadIdx.x >> 5, c = threadIdx.x & 31;
-    for (int t0 = 0; t0 < 2 * nblk; t0 += 8) {
+    for (int t0 = 0; t0 < 2 * nblk; t0 += NG) {
         const int task = t0 + g;
         const bool valid = task < 2 * nblk;
         const int typ = task / nblk, b = task - typ * nblk, o = b * DB;
@@ -1569,7 +1570,8 @@ void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx
     if (mx <= 64) hipLaunchKernelGGL(k_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
     else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
-    hipLaunchKernelGGL(k_diag_inv_all, dim3(nn), dim3(256), 0, s, T, nodes);     // the contract: dinv of the owned blocks
+    if (mx <= 64) hipLaunchKernelGGL(k_diag_inv_all<4>, dim3(nn), dim3(128), 0, s, T, nodes);     // the contract: dinv of the owned blocks
+    else hipLaunchKernelGGL(k_diag_inv_all<8>, dim3(nn), dim3(256), 0, s, T, nodes);
 }
 
 void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask)
