@@ -265,6 +265,10 @@ void sluamd_comm_destroy(sluamd_comm_t comm);
  * `comm` must outlive the handle. */
 int sluamd_dCreateLUHandleGrid(sluamd_handle_t *h, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
                                const sluamd_options_t *opt, sluamd_comm_t comm);
+/* complex16 on Z layers (1 x 1 x npdep grids; pzgstrf3d.c:333-392 ancestor reduction and the pzgstrs3d Z sweeps); collective like
+ * sluamd_dCreateLUHandleGrid */
+int sluamd_zCreateLUHandleGrid(sluamd_handle_t *h, const sluamd_zLUview_t *lu, const sluamd_forest_view_t *forests,
+                               const sluamd_options_t *opt, sluamd_comm_t comm);
 /* Same from the library's own symbolic factorisation (every rank holds the complete structure `s`; no structure exchange):
  * the store of this rank's grid position is built and A's values are distributed on the device (pddistribute3d +
  * dinit3DLUstructForest, pddistribute3d.c:1357, pd3dcomm.c:334-800).  sn_tree (sluamd_symb_partition) may be NULL when

@@ -48,7 +48,7 @@ EXPORTS = [
     "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",
     "sluamd_comm_rccl_unique_id", "sluamd_comm_create_rccl", "sluamd_comm_create_callbacks", "sluamd_comm_create_local",
     "sluamd_comm_rank", "sluamd_comm_size", "sluamd_comm_destroy", "sluamd_dCreateLUHandleGrid",
-    "sluamd_dCreateLUHandleFromSymbGrid",
+    "sluamd_dCreateLUHandleFromSymbGrid", "sluamd_zCreateLUHandleGrid",
 ]
 
 # sluamd_comm_callbacks_t
@@ -97,6 +97,7 @@ def bind(L):
     L.sluamd_mfma_selftest.argtypes = [P_dbl, P_dbl, P_dbl]
     L.sluamd_dResetValues.argtypes = [C.c_void_p]
     L.sluamd_zCreateLUHandle.argtypes = L.sluamd_dCreateLUHandle.argtypes     # zLUview is layout-identical to dLUview
+    L.sluamd_zCreateLUHandleGrid.argtypes = L.sluamd_dCreateLUHandleGrid.argtypes
     L.sluamd_zSetValues.argtypes = [C.c_void_p, C.POINTER(LUView)]
     L.sluamd_zCopyLU2Host.argtypes = [C.c_void_p, C.POINTER(LUView)]
     L.sluamd_pzgstrf3d.argtypes = [C.c_void_p, C.c_double, P_int]

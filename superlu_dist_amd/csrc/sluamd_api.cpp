@@ -261,6 +261,15 @@ int sluamd_zCreateLUHandle(sluamd_handle_t *out, const sluamd_zLUview_t *lu, con
     return create_from_view(out, reinterpret_cast<const sluamd_dLUview_t *>(lu), forests, opt, true, nullptr);
 }
 
+// complex16 on Z layers: 1 x 1 x npdep grids (the Z ancestor reduction and the distributed solve run on pairs of doubles)
+int sluamd_zCreateLUHandleGrid(sluamd_handle_t *out, const sluamd_zLUview_t *lu, const sluamd_forest_view_t *forests, const sluamd_options_t *opt,
+                               sluamd_comm_t comm)
+{
+    if (!comm) { set_error("null communicator"); return SLUAMD_EINVAL; }
+    if (lu && lu->nprow * lu->npcol > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
+    return create_from_view(out, reinterpret_cast<const sluamd_dLUview_t *>(lu), forests, opt, true, comm->c);
+}
+
 int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
 {
     if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
@@ -327,29 +336,11 @@ int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, in
         H->x_cap = need;
     }
     HIPCHK(hipMemcpy(H->d_x, x, sizeof(double) * need, hipMemcpyHostToDevice));
-    const int ch = std::max(1, (150 * 1024) / std::max(H->max_nsupc * 16, 1));
-    const DevTables &T = H->T;
     hipStream_t s = H->stream;
     HIPCHK(hipEventRecord(H->ev0, s));
-    for (int j0 = 0; j0 < nrhs; j0 += ch) {
-        const int nr = std::min(ch, nrhs - j0);
-        void *dx = H->d_x + (size_t) 2 * j0 * ldx;
-        for (size_t zl = 0; zl < H->sched.size(); ++zl) {
-            LevelSched &S = H->sched[zl];
-            for (int l = 0; l < S.nlevels; ++l) {
-                const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
-                eng::zsolve_diag(s, true, T, S.d_nodes + n0, nn, dx, ldx, nr, S.max_nsupc[l]);
-                eng::zfwd_update(s, T, S.d_nodes + n0, S.d_zfwd_prefix + po, nn, S.zfwd_prefix[po + nn], dx, ldx, nr, S.max_nsupc[l]);
-            }
-        }
-        for (int zl = (int) H->sched.size() - 1; zl >= 0; --zl) {
-            LevelSched &S = H->sched[zl];
-            for (int l = S.nlevels - 1; l >= 0; --l) {
-                const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
-                eng::zbwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], dx, ldx, nr);
-                eng::zsolve_diag(s, false, T, S.d_nodes + n0, nn, dx, ldx, nr, S.max_nsupc[l]);
-            }
-        }
+    {   // the same driver as the double path: level sweeps per Z level, Z exchanges / gather on grids (x seen as 2 n doubles there)
+        const int rc = run_solve_dev(H, H->d_x, ldx, nrhs);
+        if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(H->ev1, s));

@@ -246,7 +246,8 @@ static int reduce_ancestors(Handle *H, int zl)
     const bool receiver = (g.z % (2 * step)) == 0;
     const int peer = g.rank_of(g.r, g.c, receiver ? g.z + step : g.z - step);
     if (receiver && g.z + step >= g.Pz) return 0;
-    const int64_t CH = (int64_t) 1 << 25;   // 32 Mi doubles = 256 MiB per message
+    const int vs = H->z ? 2 : 1;            // doubles per value (complex16 panels are reduced as pairs of doubles)
+    const int64_t CH = (int64_t) 1 << 24;   // values per message: <= 256 MiB
     hipStream_t s = H->stream;
     Comm *c = H->comm;
     for (auto &r : rg)
@@ -255,12 +256,12 @@ static int reduce_ancestors(Handle *H, int zl)
             int rc = c->begin();
             if (rc) return rc;
             if (receiver) {
-                if ((rc = ensure_xtmp(H, std::min(CH, r.second)))) return rc;
-                if ((rc = c->recv(H->d_xtmp, len * 8, peer))) return rc;
+                if ((rc = ensure_xtmp(H, std::min(CH, r.second) * vs))) return rc;
+                if ((rc = c->recv(H->d_xtmp, len * 8 * vs, peer))) return rc;
                 if ((rc = c->end(s))) return rc;
-                eng::axpy(s, len, 1.0, H->d_xtmp, H->d_val + r.first + o);   // the next chunk's receive into the staging buffer is ordered behind this on s
+                eng::axpy(s, len * vs, 1.0, H->d_xtmp, H->d_val + (r.first + o) * vs);   // the next chunk's receive into the staging buffer is ordered behind this on s
             } else {
-                if ((rc = c->send(H->d_val + r.first + o, len * 8, peer))) return rc;
+                if ((rc = c->send(H->d_val + (r.first + o) * vs, len * 8 * vs, peer))) return rc;
                 if ((rc = c->end(s))) return rc;
             }
         }
@@ -415,6 +416,11 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
+        if (H->z) {   // complex16 (1 x 1 layers): d_x holds doublecomplex, ldx in complex values
+            eng::zsolve_diag(s, true, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
+            eng::zfwd_update(s, T, S.d_nodes + n0, S.d_zfwd_prefix + po, nn, S.zfwd_prefix[po + nn], d_x, ldx, nrhs, S.max_nsupc[l]);
+            continue;
+        }
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
         eng::solve_diag(s, true, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;
@@ -431,6 +437,11 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
+        if (H->z) {
+            eng::zbwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, ldx, nrhs);
+            eng::zsolve_diag(s, false, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
+            continue;
+        }
         eng::bwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, ldx, nrhs, S.max_nsupc[l]);
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
         eng::solve_diag(s, false, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
@@ -441,18 +452,19 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
 
 static int max_rhs_chunk(const Handle *H)
 {   // the diagonal solve stages (max_nsupc + 32) x nrhs doubles in LDS (<= 150 KiB of the 160 KiB per workgroup)
-    const int per = H->max_nsupc * 8;               // x_k staged in LDS by the diagonal solve / forward update
+    const int per = H->max_nsupc * (H->z ? 16 : 8);   // x_k staged in LDS by the diagonal solve / forward update
     return std::max(1, (128 * 1024) / std::max(per, 1));
 }
 
 int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
 {
-    int rc = ensure_inv(H);
+    int rc = H->z ? 0 : ensure_inv(H);
     if (rc) return rc;
     const int ch = max_rhs_chunk(H);
+    const int vs = H->z ? 2 : 1;
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
-        double *x = d_x + (size_t) j0 * ldx;
+        double *x = d_x + (size_t) j0 * ldx * vs;
         for (int z = 0; z < (int) H->sched.size(); ++z) if ((rc = solve_fwd_z(H, z, x, ldx, nr))) return rc;
         for (int z = (int) H->sched.size() - 1; z >= 0; --z) if ((rc = solve_bwd_z(H, z, x, ldx, nr))) return rc;
     }
@@ -475,8 +487,9 @@ static void forest_runs_build(const Handle *H, int a0, int a1, int role, LevelSc
         }
     std::sort(ks.begin(), ks.end());
     out.runs.clear(); out.total = 0;
+    const int vs = H->z ? 2 : 1;   // runs are in doubles of the right-hand side viewed as a real array (complex16: 2 per row)
     for (int k : ks) {
-        const int row0 = hs.xsup[k], nr = hs.xsup[k + 1] - hs.xsup[k];
+        const int row0 = hs.xsup[k] * vs, nr = (hs.xsup[k + 1] - hs.xsup[k]) * vs;
         if (!out.runs.empty() && out.runs.back().first + out.runs.back().second == row0) out.runs.back().second += nr;
         else out.runs.emplace_back(row0, nr);
         out.total += nr;
@@ -497,8 +510,9 @@ static const LevelSched::XSeg &forest_runs(Handle *H, int a0, int role)
         std::vector<int> ks;
         for (int zl = 0; zl < nzl; ++zl) if (H->z_active[zl]) for (int k : H->forest_nodes[zl]) if (g.krow(k) == g.r && g.kcol(k) == g.c) ks.push_back(k);
         std::sort(ks.begin(), ks.end());
+        const int vs = H->z ? 2 : 1;
         for (int k : ks) {
-            const int row0 = H->hs.xsup[k], n1 = H->hs.xsup[k + 1] - row0;
+            const int row0 = H->hs.xsup[k] * vs, n1 = (H->hs.xsup[k + 1] - H->hs.xsup[k]) * vs;
             if (!seg.runs.empty() && seg.runs.back().first + seg.runs.back().second == row0) seg.runs.back().second += n1; else seg.runs.emplace_back(row0, n1);
             seg.total += n1;
         }
@@ -523,10 +537,15 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
     hipStream_t s = H->stream;
     const int ch = max_rhs_chunk(H);
     int rc;
-    if ((rc = ensure_inv(H))) return rc;
+    if (!H->z && (rc = ensure_inv(H))) return rc;
+    if (H->z && g.Pr * g.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
+    // complex16: the exchanges see the right-hand sides as real arrays of 2 n rows (run lists in doubles, leading dimension ldxd);
+    // the sweeps get the complex view (ldx)
+    const int vs = H->z ? 2 : 1;
+    const int64_t ldxd = ldx * vs;
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
-        double *x = d_x + (size_t) j0 * ldx;
+        double *x = d_x + (size_t) j0 * ldxd;
         // keep b only where it is consumed: at the diagonal owner, on the layer that factors the forest; everything else
         // starts as a zero accumulator (rows of other layers' forests are never touched)
         {
@@ -534,9 +553,9 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
             if ((rc = ensure_xtmp(H, std::max<int64_t>(keep.total * nr, 1)))) return rc;
             const int *dr;
             if ((rc = runs_on_device(H, keep, &dr))) return rc;
-            eng::xseg_copy(s, x, ldx, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 0);
-            for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.n, s));
-            eng::xseg_copy(s, x, ldx, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 1);
+            eng::xseg_copy(s, x, ldxd, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 0);
+            for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldxd, 0, sizeof(double) * (size_t) H->hs.n * vs, s));
+            eng::xseg_copy(s, x, ldxd, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 1);
             HIPCHK(hipStreamSynchronize(s));
         }
         // ---- forward sweep, leaves to root ----
@@ -550,7 +569,7 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
                 LevelSched::XSeg seg = forest_runs(H, zl + 1, 0);        // (copy shares the cached device image)
                 seg.peer = g.rank_of(g.r, g.c, receiver ? g.z + step : g.z - step);
                 std::vector<LevelSched::XSeg> one(1, seg), none;
-                if (seg.total && (rc = receiver ? xseg_exchange(H, x, ldx, nr, none, 0, one, 2, s) : xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s))) return rc;
+                if (seg.total && (rc = receiver ? xseg_exchange(H, x, ldxd, nr, none, 0, one, 2, s) : xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s))) return rc;
             }
         }
         // ---- backward sweep, root to leaves ----
@@ -563,7 +582,7 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
                     LevelSched::XSeg seg = forest_runs(H, zl + 1, 1);
                     seg.peer = g.rank_of(g.r, g.c, sender ? g.z + step : g.z - step);
                     std::vector<LevelSched::XSeg> one(1, seg), none;
-                    if (seg.total && (rc = sender ? xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldx, nr, none, 0, one, 1, s))) return rc;
+                    if (seg.total && (rc = sender ? xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldxd, nr, none, 0, one, 1, s))) return rc;
                 }
             }
             if (H->z_active[zl] && (rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
@@ -601,13 +620,13 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
             if (me != 0) {
                 mine.peer = 0;
                 std::vector<LevelSched::XSeg> one(1, mine);
-                if (mine.total && (rc = xseg_exchange(H, x, ldx, nr, one, 0, none, 0, s))) return rc;
-            } else if ((rc = xseg_exchange(H, x, ldx, nr, none, 0, H->gather_cache, 1, s))) return rc;
+                if (mine.total && (rc = xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s))) return rc;
+            } else if ((rc = xseg_exchange(H, x, ldxd, nr, none, 0, H->gather_cache, 1, s))) return rc;
             // complete vector from rank 0 to everyone
             if ((rc = c->begin())) return rc;
             for (int q = 0; q < nr; ++q) {
-                if (me == 0) { for (int p = 1; p < P; ++p) if ((rc = c->send(x + (size_t) q * ldx, H->hs.n * 8, p))) return rc; }
-                else if ((rc = c->recv(x + (size_t) q * ldx, H->hs.n * 8, 0))) return rc;
+                if (me == 0) { for (int p = 1; p < P; ++p) if ((rc = c->send(x + (size_t) q * ldxd, H->hs.n * 8 * vs, p))) return rc; }
+                else if ((rc = c->recv(x + (size_t) q * ldxd, H->hs.n * 8 * vs, 0))) return rc;
             }
             if ((rc = c->end(s))) return rc;
         }

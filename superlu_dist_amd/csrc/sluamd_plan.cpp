@@ -416,7 +416,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     const Grid &g = H->grid;
     const int ns = hs.nsupers;
     const bool xy = g.Pr * g.Pc > 1;
-    if (H->z && g.size() > 1) { set_error("complex16 handles support 1 x 1 x 1 grids only"); return SLUAMD_EINVAL; }
+    if (H->z && g.Pr * g.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
     const int nz = (int) in.lists.size();
     H->Pz = g.Pz; H->myz = g.z;
     H->forest_nodes = in.lists;

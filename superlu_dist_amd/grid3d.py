@@ -117,8 +117,8 @@ def rccl_comm(dist, Pr, Pc, Pz, device):
 class GridHandle:
     """One rank's device-resident store on a process grid (sluamd_dCreateLUHandleGrid / ...FromSymbGrid)."""
 
-    def __init__(self, h, comm, n):
-        self._h, self.comm, self.n = h, comm, n
+    def __init__(self, h, comm, n, z=False):
+        self._h, self.comm, self.n, self.z = h, comm, n, z
 
     @classmethod
     def from_store(cls, store, forests, comm, **opts):
@@ -127,9 +127,9 @@ class GridHandle:
         o = LUHandle._opts(**opts)
         fv, keep = (None, None) if forests is None else _forest_view(forests)
         h = C.c_void_p()
-        _lib.check(L.sluamd_dCreateLUHandleGrid(C.byref(h), C.byref(store.view), None if fv is None else C.byref(fv), C.byref(o), comm),
-                   "sluamd_dCreateLUHandleGrid")
-        obj = cls(h, comm, store.n)
+        create = L.sluamd_zCreateLUHandleGrid if store.z else L.sluamd_dCreateLUHandleGrid   # complex16 store: 1 x 1 x npdep grids
+        _lib.check(create(C.byref(h), C.byref(store.view), None if fv is None else C.byref(fv), C.byref(o), comm), "sluamd_[dz]CreateLUHandleGrid")
+        obj = cls(h, comm, store.n, store.z)
         obj._keep = (keep, store)
         return obj
 
@@ -148,19 +148,25 @@ class GridHandle:
 
     def pdgstrf3d(self, thresh=0.0):
         info = C.c_int32(0)
-        _lib.check(_lib.load().sluamd_pdgstrf3d(self._h, float(thresh), C.byref(info)), "sluamd_pdgstrf3d")
+        L = _lib.load()
+        _lib.check((L.sluamd_pzgstrf3d if self.z else L.sluamd_pdgstrf3d)(self._h, float(thresh), C.byref(info)), "sluamd_p[dz]gstrf3d")
         return info.value
 
     def pdgstrs3d(self, xp):
         """xp: complete permuted right-hand side (n x nrhs), replicated; returns the complete solution."""
-        x = np.asfortranarray(np.array(xp, dtype=np.float64))
+        x = np.asfortranarray(np.array(xp, dtype=np.complex128 if self.z else np.float64))
         if x.ndim == 1:
             x = np.asfortranarray(x[:, None])
-        _lib.check(_lib.load().sluamd_pdgstrs3d(self._h, x.ctypes.data_as(_lib.P_dbl), x.shape[0], x.shape[1]), "sluamd_pdgstrs3d")
+        L = _lib.load()
+        if self.z:
+            _lib.check(L.sluamd_pzgstrs3d(self._h, x.ctypes.data_as(C.c_void_p), x.shape[0], x.shape[1]), "sluamd_pzgstrs3d")
+        else:
+            _lib.check(L.sluamd_pdgstrs3d(self._h, x.ctypes.data_as(_lib.P_dbl), x.shape[0], x.shape[1]), "sluamd_pdgstrs3d")
         return x
 
     def copy_to_host(self, store):
-        _lib.check(_lib.load().sluamd_dCopyLU2Host(self._h, C.byref(store.view)), "sluamd_dCopyLU2Host")
+        L = _lib.load()
+        _lib.check((L.sluamd_zCopyLU2Host if self.z else L.sluamd_dCopyLU2Host)(self._h, C.byref(store.view)), "sluamd_[dz]CopyLU2Host")
         return store
 
     def reset_values(self):

@@ -49,6 +49,9 @@ CASES = {
     "z_poisson8_nd": dict(matrix=("zpoisson", 8), grid=(1, 1, 1), nd=16, flags=["-e", "0", "-p", "0", "-i", "0"], z=True),
     "z_unsym200": dict(matrix=("zunsym", 200, 0.03, 9), grid=(1, 1, 1), flags=[], z=True),
     "z_grid24_nd": dict(matrix=("zgrid2d", 24), grid=(1, 1, 1), nd=16, flags=["-e", "0", "-p", "0", "-i", "0"], z=True),
+    # complex16 on Z layers (1 x 1 x 2): per-rank records of pzgstrf3d / pzgstrs3d
+    "z_cg20_1x1x2": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 2), flags=[], z=True),
+    "z_poisson8_nd_1x1x2": dict(matrix=("zpoisson", 8), grid=(1, 1, 2), nd=16, flags=["-e", "0", "-p", "0", "-i", "0"], z=True),
 }
 
 

@@ -5,6 +5,8 @@ import numpy as np
 from superlu_dist_amd import driver, grid3d, matgen
 
 GRID_FIXTURES = ["g20_1x1x2", "poisson8_nd_1x1x2", "g20_2x1x1", "g20_2x2x2"]
+ZGRID_FIXTURES = ["z_cg20_1x1x2", "z_poisson8_nd_1x1x2"]    # complex16 (pzgstrf3d / pzgstrs3d) on two Z layers: GPU only (the emulation
+                                                             # engine restates the double-precision kernels)
 
 
 def forests_of(g, rank):
@@ -41,11 +43,11 @@ def check_fixture_grid(g):
         si = 0
         while f"r0__solve{si}_B_in" in g:
             nrhs = int(g[f"r0__solve{si}_nrhs"][0])
-            B = np.zeros((n, nrhs), order="F")
+            B = np.zeros((n, nrhs), order="F", dtype=g[f"r0__solve{si}_B_in"].dtype)
             for q in range(Pr * Pc):     # layer 0 holds the 2-D row distribution of B
                 f0 = int(g[f"r{q}__solve{si}_fst_row"][0]); ml = int(g[f"r{q}__solve{si}_m_loc"][0])
                 B[f0:f0 + ml, :] = g[f"r{q}__solve{si}_B_in"].reshape((ml, nrhs), order="F")
-            xp = np.zeros((n, nrhs), order="F"); xp[pc_[pr_], :] = B
+            xp = np.zeros((n, nrhs), order="F", dtype=B.dtype); xp[pc_[pr_], :] = B
             y = h.pdgstrs3d(xp)
             if z == 0:
                 f0 = int(g[p + f"solve{si}_fst_row"][0]); ml = int(g[p + f"solve{si}_m_loc"][0])

@@ -74,3 +74,10 @@ def test_own_pipeline_with_supernodes_up_to_512_columns(grid):
     """maxsup = 512 through the library's own symbolic factorisation + device-side distribution: wide supernodes are refined
     at handle creation, A's entries are scattered straight into the pieces."""
     grid_cases.check_own_pipeline(18, grid, nrhs=2, leaf=64, relax=64, maxsup=512)
+
+
+@pytest.mark.parametrize("case", grid_cases.ZGRID_FIXTURES)
+def test_complex16_grid_fixture_per_rank_parity(golden, case):
+    """pzgstrf3d / pzgstrs3d on a 1 x 1 x 2 grid against the reference's per-rank records (the Z ancestor reduction and the Z
+    sweeps of the solve move complex16 values as pairs of doubles)."""
+    grid_cases.check_fixture_grid(golden(case))
