@@ -23,7 +23,7 @@
 #include <limits.h>
 #include <dlfcn.h>
 #include <unistd.h>
-#ifdef Z_PREC   /* complex16 twin: binds pzgstrf3d (SRC/complex16/pzgstrf3d.c) to the sluamd_z* entry points (1 x 1 x 1 grids) */
+#ifdef Z_PREC   /* complex16 twin: binds pzgstrf3d (SRC/complex16/pzgstrf3d.c) to the sluamd_z* entry points (1 x 1 x npdep grids) */
 #include "superlu_zdefs.h"
 #define xLUstruct_t zLUstruct_t
 #define xLocalLU_t zLocalLU_t
@@ -34,6 +34,7 @@
 #define LUVIEW_T sluamd_zLUview_t
 #define VALPP(p) ((sluamd_doublecomplex **) (p))
 #define SYM_CREATE "sluamd_zCreateLUHandle"
+#define SYM_CREATE_GRID "sluamd_zCreateLUHandleGrid"
 #define SYM_FACTOR "sluamd_pzgstrf3d"
 #define SYM_COPY "sluamd_zCopyLU2Host"
 #else
@@ -47,6 +48,7 @@
 #define LUVIEW_T sluamd_dLUview_t
 #define VALPP(p) (p)
 #define SYM_CREATE "sluamd_dCreateLUHandle"
+#define SYM_CREATE_GRID "sluamd_dCreateLUHandleGrid"
 #define SYM_FACTOR "sluamd_pdgstrf3d"
 #define SYM_COPY "sluamd_dCopyLU2Host"
 #endif
@@ -87,7 +89,7 @@ static void sluamd_load(void)
     if (!S.so) { fprintf(stderr, "dlopen(%s): %s\n", path, dlerror()); ABORT("cannot load libsluamd.so"); }
     S.default_options = (void (*)(sluamd_options_t *)) dlsym(S.so, "sluamd_default_options");
     S.create = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *)) dlsym(S.so, SYM_CREATE);
-    S.create_grid = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t)) dlsym(S.so, "sluamd_dCreateLUHandleGrid");
+    S.create_grid = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t)) dlsym(S.so, SYM_CREATE_GRID);
     S.factor = (int (*)(sluamd_handle_t, double, int *)) dlsym(S.so, SYM_FACTOR);
     S.copy2host = (int (*)(sluamd_handle_t, const LUVIEW_T *)) dlsym(S.so, SYM_COPY);
     S.solve = (int (*)(sluamd_handle_t, double *, int64_t, int32_t)) dlsym(S.so, "sluamd_pdgstrs3d");
@@ -195,8 +197,8 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     int rc;
     if (Pr * Pc * Pz > 1) {
 #ifdef Z_PREC
-        ABORT("complex16 binding: 1 x 1 x 1 grids only");
-#else
+        if (Pr * Pc > 1) ABORT("complex16 binding: 1 x 1 x npdep grids only");
+#endif
         /* library world rank of every MPI rank of grid3d->comm */
         int P; MPI_Comm_size(grid3d->comm, &P);
         int mine = (myz * Pr + myrow) * Pc + mycol;
@@ -210,7 +212,6 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
         rc = S.comm_create(&G.comm, &cb, Pr, Pc, Pz, myrow, mycol, myz);
         if (rc) ABORT(S.last_error());
         rc = S.create_grid(&G.h, &v, &fv, &o, G.comm);                       /* was dCreateLUgpuHandle    */
-#endif
     } else {
         rc = S.create(&G.h, &v, &fv, &o);
     }

@@ -149,3 +149,19 @@ def test_reference_pipeline_with_our_pzgstrf3d(kind, tmp_path):
     assert info_amd == info_ref == 0
     assert res_amd < 1e-10 and res_ref < 1e-10
     assert abs(res_amd - res_ref) < 1e-10
+
+
+@pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
+def test_reference_complex_pipeline_on_two_z_layers(tmp_path):
+    """mpiexec -n 2 slu_ref_zamd -d 2: pzgssvx3d on a 1 x 1 x 2 grid with pzgstrf3d bound to the library over the binding's MPI
+    transport (leaf forests on two ranks sharing the GPU, Z ancestor reduction of complex16 panels in the library); the
+    reference's own CPU pzgstrs3d then solves with the factors copied back; residual parity with the untouched reference."""
+    n, rp, ci, v = matgen.random_unsym(300, 0.03, seed=21)
+    v = matgen.complex_shift(v, rp, ci, seed=4)
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    args = ["-r", "1", "-c", "1", "-d", "2", "-Q", "1", "-o", "none", str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(ZAMD, args, tmp_path, threads="1", nproc=2)
+    res_ref, info_ref = _run(ZREF, args, tmp_path, threads="1", nproc=2)
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10
