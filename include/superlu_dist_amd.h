@@ -276,6 +276,10 @@ int sluamd_zCreateLUHandleGrid(sluamd_handle_t *h, const sluamd_zLUview_t *lu, c
 int sluamd_dCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
                                        const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
                                        const sluamd_options_t *opt, const int32_t *sn_tree, sluamd_comm_t comm);
+/* complex16 twin (1 x 1 x npdep grids) */
+int sluamd_zCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                                       const sluamd_doublecomplex *nzval, const sluamd_int_t *perm_c_final,
+                                       const sluamd_options_t *opt, const int32_t *sn_tree, sluamd_comm_t comm);
 /* Grid solve semantics (pdgstrs3d between pdReDistribute3d_B_to_X and pdReDistribute3d_X_to_B): every rank passes the
  * COMPLETE permuted right-hand side x = Pc*Pr*b (n x nrhs, replicated) and every rank receives the complete solution. */
 

@@ -48,7 +48,7 @@ EXPORTS = [
     "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",
     "sluamd_comm_rccl_unique_id", "sluamd_comm_create_rccl", "sluamd_comm_create_callbacks", "sluamd_comm_create_local",
     "sluamd_comm_rank", "sluamd_comm_size", "sluamd_comm_destroy", "sluamd_dCreateLUHandleGrid",
-    "sluamd_dCreateLUHandleFromSymbGrid", "sluamd_zCreateLUHandleGrid",
+    "sluamd_dCreateLUHandleFromSymbGrid", "sluamd_zCreateLUHandleGrid", "sluamd_zCreateLUHandleFromSymbGrid",
 ]
 
 # sluamd_comm_callbacks_t
@@ -85,6 +85,8 @@ def bind(L):
     L.sluamd_dCreateLUHandleGrid.argtypes = [C.POINTER(C.c_void_p), C.POINTER(LUView), C.POINTER(ForestView), C.POINTER(Options), C.c_void_p]
     L.sluamd_dCreateLUHandleFromSymb.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int, C.POINTER(Options)]
     L.sluamd_dCreateLUHandleFromSymbGrid.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, P_dbl, P_int, C.POINTER(Options),
+                                                     P_int, C.c_void_p]
+    L.sluamd_zCreateLUHandleFromSymbGrid.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, P_int, P_int, C.c_void_p, P_int, C.POINTER(Options),
                                                      P_int, C.c_void_p]
     L.sluamd_dSetValues.argtypes = [C.c_void_p, C.POINTER(LUView)]
     L.sluamd_pdgstrf3d.argtypes = [C.c_void_p, C.c_double, P_int]

@@ -540,6 +540,16 @@ int sluamd_dCreateLUHandleFromSymbGrid(sluamd_handle_t *out, sluamd_symb_t s, co
     return create_from_symb(out, s, rowptr, colind, nzval, perm_c_final, opt, comm->c->grid, sn_tree, comm->c, false);
 }
 
+// complex16 values on a 1 x 1 x npdep grid
+int sluamd_zCreateLUHandleFromSymbGrid(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                                       const sluamd_doublecomplex *nzval, const sluamd_int_t *perm_c_final, const sluamd_options_t *opt,
+                                       const int32_t *sn_tree, sluamd_comm_t comm)
+{
+    if (!comm) { set_error("null communicator"); return SLUAMD_EINVAL; }
+    if (comm->c->grid.Pr * comm->c->grid.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
+    return create_from_symb(out, s, rowptr, colind, reinterpret_cast<const double *>(nzval), perm_c_final, opt, comm->c->grid, sn_tree, comm->c, true);
+}
+
 // Device-side re-distribution of A's values into the resident store (handles made by sluamd_dCreateLUHandleFromSymb*):
 // zero-fill + scatter, asynchronous on the handle's stream.
 int sluamd_dResetValues(sluamd_handle_t h)

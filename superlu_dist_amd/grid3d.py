@@ -138,9 +138,15 @@ class GridHandle:
         from .driver import LUHandle, _pi, _pd
         L = _lib.load()
         o = LUHandle._opts(**opts)
-        nz = np.ascontiguousarray(nzval, dtype=np.float64)
         t = None if sn_tree is None else np.ascontiguousarray(sn_tree, dtype=np.int32)
         h = C.c_void_p()
+        if np.iscomplexobj(nzval):     # complex16: 1 x 1 x npdep grids
+            nz = np.ascontiguousarray(nzval, dtype=np.complex128)
+            _lib.check(L.sluamd_zCreateLUHandleFromSymbGrid(C.byref(h), symb._h, _pi(symb.rowptr), _pi(symb.colind), nz.ctypes.data_as(C.c_void_p),
+                                                            _pi(symb.perm_c), C.byref(o), None if t is None else t.ctypes.data_as(_lib.P_int), comm),
+                       "sluamd_zCreateLUHandleFromSymbGrid")
+            return cls(h, comm, symb.n, True)
+        nz = np.ascontiguousarray(nzval, dtype=np.float64)
         _lib.check(L.sluamd_dCreateLUHandleFromSymbGrid(C.byref(h), symb._h, _pi(symb.rowptr), _pi(symb.colind), _pd(nz), _pi(symb.perm_c),
                                                         C.byref(o), None if t is None else t.ctypes.data_as(_lib.P_int), comm),
                    "sluamd_dCreateLUHandleFromSymbGrid")
