@@ -197,7 +197,7 @@ void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lp
 }
 
 void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level, int skip_n, int)
+           const int4 *ulist, int)
 {
     (void) cfg;
     std::vector<double> acc, lrow;
@@ -216,8 +216,6 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
         const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
         const int nr = R.z, nc = C.z;
         const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
-        if (!ulist && skip_level >= 0 && ((unsigned) (sn_level[ib] - skip_level) < (unsigned) skip_n || (unsigned) (sn_level[jb] - skip_level) < (unsigned) skip_n)) continue;
-        if (!ulist && T.defer && T.defer[k]) continue;
         const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
         const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
         const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];

@@ -59,10 +59,10 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     int rc_x = 0;
     int cur_level = 0, cur_pass = 0;
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
-                     const int4 *ulist, int skip_level, int skip_n, int prio = 0) {
+                     const int4 *ulist, int prio = 0) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
-        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, S.d_sn_level, skip_level, skip_n, prio);
+        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -115,7 +115,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             const int cnt = g == 0 ? nbig : nn - nbig;
             if (!cnt) continue;
             const int u0 = S.u_off[(2 * l + g) * 4 + p0], nu = S.u_off[(2 * l + g) * 4 + p1 + 1] - u0;
-            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, -1, 0, (lookahead && p1 < 3) ? 1 : 0);
+            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, (lookahead && p1 < 3) ? 1 : 0);
         }
     };
     // deterministic mode: one supernode per launch over its full tile grid -- tiles of one k hit distinct destinations, the
@@ -131,7 +131,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             const int *gn = nodes + (g == 0 ? 0 : nbig);
             for (int i = 0; i < cnt; ++i) {
                 const int c = S.tile_prefix[so + i + 1] - S.tile_prefix[so + i];
-                if (c) schur(st, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr, -1, 0);
+                if (c) schur(st, g == 0, c, gn, S.d_tile_prefix + so, cnt, S.tile_prefix[so + i], nullptr);
             }
         }
     };

@@ -278,7 +278,7 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level, int skip_n, int prio);
+           const int4 *ulist, int prio);
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);

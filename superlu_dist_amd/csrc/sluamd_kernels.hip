@@ -1060,8 +1060,7 @@ template <int TMv, int TNv, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
-                                                                    const int4 *__restrict__ ulist, const int *__restrict__ sn_level,
-                                                                    int skip_level, int skip_n, int prio)
+                                                                    const int4 *__restrict__ ulist, int prio)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -1095,7 +1094,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     }
     // `ulist` != null (every schedule but the deterministic one): tile list entry (supernode, absolute row tile, absolute column
     // tile, destination block) + per-tile descriptors -- the prologue is three dependent (scalar) loads deep.  Otherwise the full
-    // tile grid of the supernodes `nodes`, minus the tiles whose destination supernode sits on levels skip_level .. + skip_n - 1.
+    // tile grid of the supernodes `nodes` (one supernode per launch: tiles of one k hit distinct destinations).
     int k, ib, jb, dblk = -2, stc;
     int4 R, C;
     const int *lsub;            // global row ids of the tile rows
@@ -1117,8 +1116,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
         C = T.ctile[T.sn_ct_off[k] + ct];
         const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
         ib = T.lb_gid[lb]; jb = T.ub_gid[ub];
-        if (skip_level >= 0 && ((unsigned) (sn_level[ib] - skip_level) < (unsigned) skip_n || (unsigned) (sn_level[jb] - skip_level) < (unsigned) skip_n)) return;
-        if (T.defer && T.defer[k]) return;   // K-fused: the partner supernode's tiles apply this update
         lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
         stc = T.ub_stcol[ub] + C.y;
     }
@@ -1589,13 +1586,13 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 }
 
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, const int *sn_level, int skip_level, int skip_n, int prio)
+           const int4 *ulist, int prio)
 {
     if (ntiles <= 0) return;
     const int grid = ((ntiles + 7) / 8) * 8;
-    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n, prio);
-    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n, prio);
-    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, sn_level, skip_level, skip_n, prio);
+    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
+    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
+    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
 }
 
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
