@@ -350,11 +350,13 @@ void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, i
     }
 }
 
-void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int)
+void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
+                const int2 *units)
 {
     for (int w = 0; w < nwork; ++w) {
-        const int ni = find_node(prefix, nn, w);
-        const int k = nodes[ni], strip = w - prefix[ni];
+        int k, strip;
+        if (units) { k = units[w].x; strip = units[w].y; }
+        else { const int ni = find_node(prefix, nn, w); k = nodes[ni]; strip = w - prefix[ni]; }
         const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
         const int *lsub = T.lidx + T.sn_lidx[k];
         for (int t = 0; t < 64; ++t) {
@@ -371,11 +373,13 @@ void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
     }
 }
 
-void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int)
+void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
+                const int2 *units)
 {
     for (int w = 0; w < nwork; ++w) {
-        const int ni = find_node(prefix, nn, w);
-        const int k = nodes[ni], chunk = w - prefix[ni];
+        int k, chunk;
+        if (units) { k = units[w].x; chunk = units[w].y; }
+        else { const int ni = find_node(prefix, nn, w); k = nodes[ni]; chunk = w - prefix[ni]; }
         const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
         const int ncol = std::min(64, T.sn_ncolu[k] - chunk * 64);
         const double *Uv = T.val + T.sn_uval[k];
@@ -389,6 +393,16 @@ void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
             }
         }
     }
+}
+
+// the far units FIRST, then the diagonal solves: on the device the diagonal workgroups are dispatched first -- a dependency
+// inside one launch that should not be there shows up under one of the two orders
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits,
+                double *x, int64_t ldx, int nrhs, int mx)
+{
+    if (lower) fwd_update(s, T, nullptr, nullptr, 0, nunits, x, ldx, nrhs, mx, units);
+    else bwd_update(s, T, nullptr, nullptr, 0, nunits, x, ldx, nrhs, mx, units);
+    if (nd > 0) solve_diag(s, lower, T, dnodes, nd, x, ldx, nrhs, mx);
 }
 
 void scatter_values(hipStream_t, double *val, const int64_t *pos, const double *a, int64_t nnz)

@@ -407,12 +407,57 @@ static int xseg_exchange(Handle *H, double *d_x, int64_t ldx, int nrhs, const st
 // XY layers: before the diagonal solves of a level the partial sums of x_k held by the process row k % Pr are reduced to
 // the diagonal owner (dlsum_fmod_inv's lsum reduction, pdgstrs_lsum.c:414-960 / dlsumReducePrK), afterwards x_k goes down
 // the process column k % Pc (dbCastXk2Pck, pdgstrs3d.c).  Non-owners use their entries of x as the lsum accumulators.
+// 1 x 1 layers, real: the update units of a level that feed the next level's diagonal blocks (LevelSched::fwd_units /
+// bwd_units, urgent part) run first; the others (levels >= l+2 only) share ONE launch with the next level's diagonal solves
+// (eng::sweep_step), so the diagonal solve of a chain supernode hides behind the far updates of its predecessor.  The
+// reference's solve gets this overlap from its message-driven fmod / bmod counters (pdgstrs_lsum.c:414-960); here it is static.
+// (Measured and rejected: the far units on side streams -- each event record / wait costs the chain ~6 us; the feeding units
+// run by the diagonal workgroup itself -- serial 64-row strips, 7.05 -> 8.1 ms.)
+static int solve_fwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    const int nl = S.nlevels;
+    if (nl == 0) return 0;
+    eng::sweep_step(s, true, T, S.d_nodes + S.lvl_off[0], S.lvl_off[1] - S.lvl_off[0], nullptr, 0, d_x, ldx, nrhs, S.max_nsupc[0]);
+    for (int l = 0; l < nl; ++l) {
+        const int u0 = S.fu_off[2 * l], u1 = S.fu_off[2 * l + 1], u2 = S.fu_off[2 * l + 2];
+        const int nd = (l + 1 < nl) ? S.lvl_off[l + 2] - S.lvl_off[l + 1] : 0;
+        const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
+        eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0);
+        eng::sweep_step(s, true, T, S.d_nodes + (nd ? S.lvl_off[l + 1] : 0), nd, S.d_fwd_units + u1, u2 - u1, d_x, ldx, nrhs, mx);
+    }
+    return 0;
+}
+
+static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    const int nl = S.nlevels;
+    if (nl == 0) return 0;
+    {   // far chunks of the top level (columns of ancestors in other forests, solved before this sweep)
+        const int u1 = S.bu_off[2 * (nl - 1) + 1], u2 = S.bu_off[2 * (nl - 1) + 2];
+        eng::sweep_step(s, false, T, nullptr, 0, S.d_bwd_units + u1, u2 - u1, d_x, ldx, nrhs, S.max_nsupc[nl - 1]);
+    }
+    for (int l = nl - 1; l >= 0; --l) {
+        const int u0 = S.bu_off[2 * l], u1 = S.bu_off[2 * l + 1];
+        const int nd = S.lvl_off[l + 1] - S.lvl_off[l];
+        const int b1 = l > 0 ? S.bu_off[2 * (l - 1) + 1] : 0, b2 = l > 0 ? S.bu_off[2 * (l - 1) + 2] : 0;   // far chunks of level l-1: x of levels >= l+1 only
+        const int mx = std::max(S.max_nsupc[l], l > 0 ? S.max_nsupc[l - 1] : 0);
+        eng::bwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, ldx, nrhs, S.max_nsupc[l], S.d_bwd_units + u0);
+        eng::sweep_step(s, false, T, S.d_nodes + S.lvl_off[l], nd, S.d_bwd_units + b1, b2 - b1, d_x, ldx, nrhs, mx);
+    }
+    return 0;
+}
+
 static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
     LevelSched &S = H->sched[z];
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
+    if (!xy && !H->z && !H->profile) return solve_fwd_links(H, S, d_x, ldx, nrhs);
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
@@ -434,6 +479,7 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     hipStream_t s = H->stream;
     LevelSched &S = H->sched[z];
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
+    if (!xy && !H->z && !H->profile) return solve_bwd_links(H, S, d_x, ldx, nrhs);
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
@@ -451,9 +497,10 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
 }
 
 static int max_rhs_chunk(const Handle *H)
-{   // the diagonal solve stages (max_nsupc + 32) x nrhs doubles in LDS (<= 150 KiB of the 160 KiB per workgroup)
-    const int per = H->max_nsupc * (H->z ? 16 : 8);   // x_k staged in LDS by the diagonal solve / forward update
-    return std::max(1, (128 * 1024) / std::max(per, 1));
+{   // x_k is staged in LDS by the diagonal solve / forward update: max_nsupc x nrhs values next to <= 50 KiB of static arrays
+    // (k_sweep), 160 KiB per workgroup
+    const int per = H->max_nsupc * (H->z ? 16 : 8);
+    return std::max(1, (96 * 1024) / std::max(per, 1));
 }
 
 int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)

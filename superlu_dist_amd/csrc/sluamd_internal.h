@@ -164,6 +164,11 @@ struct LevelSched {
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units: 64-row L strips / 64-column U chunks
     std::vector<int> zfwd_prefix;             // complex path: 256-row L strips
+    // the same units as explicit (supernode, strip / chunk) lists, per level [urgent | bulk]: urgent = touches a supernode of the
+    // adjacent level (l+1: rows the forward update writes / columns the backward update reads) = what the next diagonal solve of the
+    // chain waits for, bulk = levels >= l+2 only (launched together with that diagonal solve, eng::sweep_step)
+    std::vector<int2> fwd_units, bwd_units;
+    std::vector<int> fu_off, bu_off;          // [2*nlevels+1]: index 2*level + part
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
@@ -185,6 +190,7 @@ struct LevelSched {
     int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
     int *d_finv_prefix = nullptr, *d_zfwd_prefix = nullptr;
     int4 *d_ulist = nullptr;
+    int2 *d_fwd_units = nullptr, *d_bwd_units = nullptr;
     int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
 };
 
@@ -282,9 +288,15 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
+// units != null: the launch runs the host-built (supernode, strip / chunk) list `units[0 .. nwork)` instead of the level's prefix arrays
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs,
-                int max_nsupc);
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc);
+                int max_nsupc, const int2 *units = nullptr);
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc,
+                const int2 *units = nullptr);
+// one link of a sweep on a 1 x 1 layer: diagonal solves of `dnodes` + the update units `units` that do not feed them, one launch
+// (max_nsupc over everything in the launch)
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits,
+                double *x, int64_t ldx, int nrhs, int max_nsupc);
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz);
 void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
                   double *r_perm, unsigned long long *s_out, double safe1, double safe2);

@@ -1308,12 +1308,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
 // inverse (what the reference's DiagInv=YES solve does with Linv / Uinv, pdgstrs_lsum.c:414-520) -- no dependent chain
 // inside the block.  Used on XY layers, where the exchanges separate the diagonal solve from the updates.
 template <bool LOWER, int NT>   // NT = 1024, or 256 for levels whose supernodes are at most 64 wide (one column quarter)
-__global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
-                                                   int64_t ldx, int nrhs)
+__device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, double *__restrict__ x, int64_t ldx, int nrhs, double *xs /* ns x nrhs */)
 {
-    extern __shared__ double xs[];  // ns x nrhs
     __shared__ double s_part[NT / 256][256];
-    const int k = nodes[blockIdx.x];
     if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;           // x_k is solved by the owner of the diagonal block
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
@@ -1353,6 +1350,14 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
     }
 }
 
+template <bool LOWER, int NT>
+__global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__restrict__ nodes, double *__restrict__ x,
+                                                   int64_t ldx, int nrhs)
+{
+    extern __shared__ double xs[];  // ns x nrhs
+    solve_diag_body<LOWER, NT>(T, nodes[blockIdx.x], x, ldx, nrhs, xs);
+}
+
 // The sweeps are bound by load latency and per-CU bandwidth, not by HBM (one dependent launch per level of the elimination
 // DAG), so the update kernels are shaped for parallelism: small work units (64 panel rows / 64 skyline columns -> several
 // hundred workgroups for a top-level supernode) of 1024 threads, every thread issuing ONE batch of <= 16 independent loads.
@@ -1360,15 +1365,10 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
 // lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414): workgroup = (supernode,
 // 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+__device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, double *__restrict__ x, int64_t ldx, int nrhs, double *xk /* ns x nrhs */)
 {
     constexpr int NP = NT / 64;     // column slices
-    extern __shared__ double xk[];  // ns x nrhs
     __shared__ double s_red[NP][64 + 1];
-    const int ni = find_node(prefix, nn, blockIdx.x);
-    const int k = nodes[ni];
-    const int strip = blockIdx.x - prefix[ni];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     const int tid = threadIdx.x;
@@ -1407,20 +1407,27 @@ __global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__res
     }
 }
 
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs, const int2 *__restrict__ units)
+{
+    extern __shared__ double xk[];  // ns x nrhs
+    int k, strip;
+    if (units) { const int2 u = units[blockIdx.x]; k = u.x; strip = u.y; }   // host-built (supernode, strip) list of one launch
+    else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
+    fwd_update_body<NT>(T, k, strip, x, ldx, nrhs, xk);
+}
+
 // x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
 // lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
 template <int NT>   // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block)
-__global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+__device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int chunk, double *__restrict__ x, int64_t ldx, int nrhs)
 {
     constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = (NT == 1024) ? 4 : 1;
     __shared__ int s_cp[64], s_ld[64], s_gc[64];
     __shared__ double s_xc[64];
     __shared__ double s_red[NWV][64 * RB];
-    const int ni = find_node(prefix, nn, blockIdx.x);
-    const int k = nodes[ni];
-    const int chunk = blockIdx.x - prefix[ni];
     const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
     const int ncol = min(64, T.sn_ncolu[k] - chunk * 64);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1472,6 +1479,31 @@ __global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__res
         }
         __syncthreads();
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs, const int2 *__restrict__ units)
+{
+    int k, chunk;
+    if (units) { const int2 u = units[blockIdx.x]; k = u.x; chunk = u.y; }
+    else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
+    bwd_update_body<NT>(T, k, chunk, x, ldx, nrhs);
+}
+
+// One link of a sweep on a 1 x 1 layer in ONE launch: workgroups [0, nd) solve the diagonal blocks of `dnodes` (the next level
+// of the chain), the others run update units that do not feed those diagonal solves (LevelSched::fwd_units / bwd_units, bulk
+// part) -- the 10 us diagonal solve of a chain supernode hides behind the far updates of its predecessor.
+template <bool LOWER, int NT>
+__global__ __launch_bounds__(NT) void k_sweep(DevTables T, const int *__restrict__ dnodes, int nd, const int2 *__restrict__ units,
+                                              double *__restrict__ x, int64_t ldx, int nrhs)
+{
+    extern __shared__ double dyn[];  // max_nsupc x nrhs
+    const int bid = blockIdx.x;
+    if (bid < nd) { solve_diag_body<LOWER, NT>(T, dnodes[bid], x, ldx, nrhs, dyn); return; }
+    const int2 u = units[bid - nd];
+    if (LOWER) fwd_update_body<NT>(T, u.x, u.y, x, ldx, nrhs, dyn);
+    else bwd_update_body<NT>(T, u.x, u.y, x, ldx, nrhs);
 }
 
 // A's entries -> value arena (device-side pddistribute): val[pos[e]] = a[e]
@@ -1550,6 +1582,8 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     return 0;
 }
 
@@ -1618,18 +1652,34 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
     }
 }
 
-void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx)
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx,
+                const int2 *units)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
-    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs);
+    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs, units);
+    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs, units);
 }
 
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx)
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx,
+                const int2 *units)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
-    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, ldx, nrhs);
+    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, ldx, nrhs, units);
+    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, ldx, nrhs, units);
+}
+
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits,
+                double *x, int64_t ldx, int nrhs, int mx)
+{
+    if (nd + nunits <= 0) return;
+    const size_t lds = (size_t) mx * nrhs * sizeof(double);
+    if (mx <= 64) {
+        if (lower) hipLaunchKernelGGL((k_sweep<true, 256>), dim3(nd + nunits), dim3(256), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
+        else hipLaunchKernelGGL((k_sweep<false, 256>), dim3(nd + nunits), dim3(256), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
+    } else {
+        if (lower) hipLaunchKernelGGL((k_sweep<true, 1024>), dim3(nd + nunits), dim3(1024), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
+        else hipLaunchKernelGGL((k_sweep<false, 1024>), dim3(nd + nunits), dim3(1024), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
+    }
 }
 
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)

@@ -346,6 +346,40 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 15) / 16) : 0);    // FIS = 16-row identity strips
         }
     }
+    // solve units as explicit lists, per level [urgent | bulk]: a strip of L(:,k) is urgent when one of its rows belongs to a supernode
+    // of level l+1 (its diagonal solve is the next link of the chain), a chunk of U(k,:) when one of its columns does (solved just
+    // before level l in the backward sweep); the bulk units touch levels >= l+2 only and share a launch with the next diagonal solves
+    S.fu_off.assign(2 * S.nlevels + 1, 0); S.bu_off.assign(2 * S.nlevels + 1, 0);
+    {
+        std::vector<uint8_t> urg;
+        for (int l = 0; l < S.nlevels; ++l)
+            for (int part = 0; part < 2; ++part) {
+                for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+                    const int k = S.nodes[i], fl = t.sn_flags[k];
+                    const int ldiag = t.sn_ldiag[k];
+                    const int nstrip = (fl & SNF_L_OWN) ? (t.sn_nsupr[k] - ldiag + 63) / 64 : 0;
+                    urg.assign(nstrip, 0);
+                    for (int b = 0; b < t.sn_nlb[k] && nstrip; ++b) {
+                        const int bi = t.sn_lb_off[k] + b;
+                        if (t.lb_gid[bi] == k || lvl[t.lb_gid[bi]] != l + 1) continue;
+                        const int r0 = t.lb_rowoff[bi] - ldiag, r1 = r0 + t.lb_nbrow[bi] - 1;
+                        for (int sidx = r0 / 64; sidx <= r1 / 64; ++sidx) urg[sidx] = 1;
+                    }
+                    for (int sidx = 0; sidx < nstrip; ++sidx) if ((urg[sidx] != 0) == (part == 0)) S.fwd_units.push_back(make_int2(k, sidx));
+                    const int nchunk = (fl & SNF_U_OWN) ? (t.sn_ncolu[k] + 63) / 64 : 0;
+                    urg.assign(nchunk, 0);
+                    for (int b = 0; b < t.sn_nub[k] && nchunk; ++b) {
+                        const int bi = t.sn_ub_off[k] + b;
+                        if (!t.ub_ncols[bi] || lvl[t.ub_gid[bi]] != l + 1) continue;
+                        const int c0 = t.ub_stcol[bi], c1 = c0 + t.ub_ncols[bi] - 1;
+                        for (int c = c0 / 64; c <= c1 / 64; ++c) urg[c] = 1;
+                    }
+                    for (int c = 0; c < nchunk; ++c) if ((urg[c] != 0) == (part == 0)) S.bwd_units.push_back(make_int2(k, c));
+                }
+                S.fu_off[2 * l + part + 1] = (int) S.fwd_units.size();
+                S.bu_off[2 * l + part + 1] = (int) S.bwd_units.size();
+            }
+    }
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
     // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
     // (1 x 1 layers only: on an XY grid a deferred supernode's received panels would have to outlive two exchange phases.)
@@ -400,6 +434,8 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.zfwd_prefix, &S.d_zfwd_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.finv_prefix, &S.d_finv_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_off, &S.d_dg_off)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.fwd_units, &S.d_fwd_units)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.bwd_units, &S.d_bwd_units)) return SLUAMD_EHIP;
     return 0;
 }
 
