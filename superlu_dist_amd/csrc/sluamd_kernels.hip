@@ -1584,6 +1584,12 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+    // the 256-thread variants stage max_nsupc (<= 64) x nrhs values: above 64 KiB when a matrix of narrow supernodes is solved for many right-hand sides
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     return 0;
 }
 

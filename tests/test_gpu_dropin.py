@@ -106,6 +106,20 @@ def test_irregular_unsymmetric_pattern_at_scale(tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
+def test_irregular_unsymmetric_pattern_on_2x2x2_grid(tmp_path):
+    """BASELINE.json configs[3]'s grid shape with the stand-in operator (n = 13 824): mpiexec -n 8, 2 x 2 x 2 grid, the
+    reference's MC64 + MMD(A'+A) + symbfact and its 3D partition, factor and solves in the library (ranks share the GPU)."""
+    n, rp, ci, v = matgen.stencil3d_unsym(24, drop=0.3, seed=2)
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    args = ["-r", "2", "-c", "2", "-d", "2", "-Q", "1", "-o", "none", str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(AMD, args, tmp_path, threads="1", nproc=8)
+    res_ref, info_ref = _run(REF, args, tmp_path, threads="1", nproc=8)
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10
+
+
+@pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
 @pytest.mark.parametrize("npdep", [1, 2])
 def test_reference_supernodes_up_to_512_columns(npdep, tmp_path):
     """SUPERLU_MAXSUP=512 (sp_ienv.c:95-110, MAX_SUPER_SIZE): the reference's symbfact builds supernodes of up to 512 columns;

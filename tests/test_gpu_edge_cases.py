@@ -55,6 +55,16 @@ def test_supernode_width_exactly_256_and_multi_rhs():
     assert st["nnz_L"] > 0
 
 
+@pytest.mark.parametrize("maxsup,nrhs", [(32, 300), (256, 100)])
+def test_many_right_hand_sides(maxsup, nrhs):
+    """x_k is staged in LDS by the sweeps: narrow supernodes x 300 right-hand sides need more than the default 64 KiB of dynamic
+    LDS in the 256-thread kernels; 256-wide supernodes x 100 right-hand sides are solved in several column chunks."""
+    N = 12
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+    _solve_and_check(n, rp, ci, v, perm=perm, relax=16, maxsup=maxsup, nrhs=nrhs)
+
+
 def test_unsymmetric_values_wide_range_of_supernode_sizes():
     n, rp, ci, v = matgen.random_unsym(700, 0.01, seed=8)
     _solve_and_check(n, rp, ci, v, relax=8, maxsup=48, nrhs=3)
