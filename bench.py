@@ -163,7 +163,17 @@ def main():
         if dist_backend != "rccl":
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo")
+        # gloo reports its connections ("[Gloo] Rank 0 is connected to ...") on stdout: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from superlu_dist_amd import _lib, driver, matgen
     L = _lib.load()
