@@ -399,7 +399,9 @@ static int xseg_exchange(Handle *H, double *d_x, int64_t ldx, int nrhs, const st
         if ((rc = runs_on_device(H, rcv[i], &dr))) return rc;
         eng::xseg_copy(s, d_x, ldx, nrhs, dr, (int) rcv[i].runs.size(), rcv[i].total, H->d_xtmp + ro[i], unpack_mode);
     }
-    HIPCHK(hipStreamSynchronize(s));   // the staging buffer is reused by the next exchange
+    // the staging buffer is reused by the next exchange: a stream-ordered transport (RCCL) packs, moves and unpacks in the order of
+    // stream s already; the host-driven ones read and write the staging buffer from the host side
+    if (!c->stream_ordered()) HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
 
