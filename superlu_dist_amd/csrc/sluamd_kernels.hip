@@ -1056,8 +1056,11 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
     }
 }
 
+#ifndef SCHUR64_WGS
+#define SCHUR64_WGS 5   // workgroups per CU the 64 x 64 tile configuration is built for (<= 4: two LDS stages, as the 128 x 128 one)
+#endif
 template <int TMv, int TNv, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void k_schur(DevTables T, const int *__restrict__ nodes,
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_WGS))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, int prio)
@@ -1070,8 +1073,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
     constexpr int LQ = TMv * KC / NT, UQ = TNv * KC / NT;         // prefetch registers per thread
     constexpr int LKS = NT / TMv;                       // k stride of the L loader
     constexpr int UJS = NT / 16;                        // column stride of the U loader
-    __shared__ double Ls[2][KC * LDL];
-    __shared__ double Us[2][KC * LDU];
+    // 128 x 128 tiles: two LDS stages (one barrier per chunk).  64 x 64 tiles -- the bottom of the tree, short K loops, the tile's
+    // life is dependent index loads -- trade the second stage for occupancy: 24 KB instead of 44 KB per workgroup
+    constexpr int NBUF = (TMv == 64 && SCHUR64_WGS > 4) ? 1 : 2;
+    __shared__ double Ls[NBUF][KC * LDL];
+    __shared__ double Us[NBUF][KC * LDU];
     __shared__ int s_ind[256 + 8];
     __shared__ int s_rowmap[TMv];
     __shared__ int s_colmap[TNv];
@@ -1278,9 +1284,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : 4))) void
             }
             const double *Lb = Ls[buf], *Ub = Us[buf];
             if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Lb, Ub, rm0, cn0, lane, acc);
-            if (more) stash(buf ^ 1);
+            if (NBUF == 2) { if (more) stash(buf ^ 1); buf ^= 1; }
+            else if (more) { __syncthreads(); stash(0); }   // single stage: every wave is done reading before it is overwritten
             __syncthreads();
-            buf ^= 1;
         }
     }
 
