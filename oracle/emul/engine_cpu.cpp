@@ -156,7 +156,7 @@ void panel_trsm(hipStream_t, const DevTables &T, const int *nodes, const int *lp
     }
 }
 
-void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
+void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int)
 {
     std::vector<double> x, o;
     for (int w = 0; w < nl + nu; ++w) {

@@ -88,7 +88,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int mx = S.max_nsupc[l];
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
-        if (gemm_panels) eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu);   // chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
+        if (gemm_panels) eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, mx);   // chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
         else eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);
         if (xy && !rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // dIBcastRecvLPanel / dIBcastRecvUPanel
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);

@@ -281,7 +281,7 @@ void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *pr
 void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu,
                 int rs, int max_nsupc);
 // the same two panel solves as GEMMs with the full inverses T.inv (1 x 1 layers; 64-high work units)
-void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
            const int4 *ulist, int prio);

@@ -865,7 +865,8 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
 // (128-byte runs of an L column / contiguous pieces of a skyline segment).
 constexpr int PGK = 64;                        // K chunk of the inverse staged in LDS
 constexpr int PG_LDS = PGK * 48;               // doubles: [64][48] (c-fastest, MODE 1) or [32][66] (k-fastest, MODE 0)
-template <int MODE>
+template <int MODE, int NQ>   // NQ = fragment registers per lane = 64 (supernodes up to 256 columns), 32 (<= 128) or 16 (<= 64: the leaf levels,
+                              // where the register budget decides how many of the tens of thousands of small panels are in flight)
 __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int unit64, double *Ts)
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -873,7 +874,7 @@ __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int uni
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int nblk = (ns + DB - 1) / DB;
     const int li = lane & 15, lk = lane >> 4;
-    double a[64];
+    double a[NQ];
     // ---- load the wave's 16 rows: a[q] = X(row li, column 4 q + lk) ----
     const int lda = T.sn_nsupr[k];
     double *A = T.val + T.sn_lval[k];
@@ -889,7 +890,7 @@ __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int uni
         if (valid) { ld = T.ucol_ld[T.sn_ucol[k] + cr]; cp = T.ucol_cp[T.sn_ucol[k] + cr]; }
     }
 #pragma unroll
-    for (int q = 0; q < 64; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int c = 4 * q + lk;
         double v = 0.0;
         if (q < nblk * 8) {
@@ -903,7 +904,7 @@ __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int uni
     for (int jb = 0; jb < nblk; ++jb) {
         d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {          // K chunks of 64 strip columns: [0, 32 (jb + 1)) in all (Tinv is upper triangular)
+        for (int kc = 0; kc < NQ / 16; ++kc) {    // K chunks of 64 strip columns: [0, 32 (jb + 1)) in all (Tinv is upper triangular)
             if (kc * 2 <= jb) {
                 __syncthreads();                   // the previous chunk's fragment reads are done
                 const int k0 = kc * PGK;
@@ -950,6 +951,7 @@ __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int uni
 
 // L units (workgroups [0, nl)) and U units ([nl, nl + nu)) of one level in ONE launch; workgroup = 4 waves = 64 rows / columns
 // (the same 64-high work units as k_panel_trsm<64>)
+template <int NQ>
 __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__restrict__ nodes, const int *__restrict__ lprefix,
                                                     const int *__restrict__ uprefix, int nn, int nl)
 {
@@ -957,11 +959,11 @@ __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__re
     __shared__ double Ts[PG_LDS];
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
-        panel_gemm_wg<0>(T, nodes[ni], blockIdx.x - lprefix[ni], Ts);
+        panel_gemm_wg<0, NQ>(T, nodes[ni], blockIdx.x - lprefix[ni], Ts);
     } else {
         const int id = blockIdx.x - nl;
         const int ni = find_node(uprefix, nn, id);
-        panel_gemm_wg<1>(T, nodes[ni], id - uprefix[ni], Ts);
+        panel_gemm_wg<1, NQ>(T, nodes[ni], id - uprefix[ni], Ts);
     }
 }
 
@@ -1641,9 +1643,12 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
     else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
 }
 
-void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int mx)
 {
-    if (nl + nu > 0) hipLaunchKernelGGL(k_panel_gemm, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
+    if (nl + nu <= 0) return;
+    if (mx <= 64) hipLaunchKernelGGL(k_panel_gemm<16>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
+    else if (mx <= 128) hipLaunchKernelGGL(k_panel_gemm<32>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
+    else hipLaunchKernelGGL(k_panel_gemm<64>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int mx)
