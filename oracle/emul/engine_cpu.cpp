@@ -18,6 +18,8 @@
 
 namespace sluamd {
 namespace eng {
+// the restated kernels; the eng:: entry points at the end of the file hand them to the emulated streams (emul_rt.cpp)
+namespace impl {
 
 static int find_node(const int *prefix, int nn, int id)
 {
@@ -25,8 +27,6 @@ static int find_node(const int *prefix, int nn, int id)
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (prefix[mid] <= id) lo = mid; else hi = mid; }
     return lo;
 }
-
-int setup() { return 0; }
 
 static void inv_block(const DevTables &T, int k, int typ, int b);
 
@@ -462,6 +462,90 @@ void xseg_copy(hipStream_t, double *x, int64_t ldx, int nrhs, const int *runs, i
             }
 }
 
+
+}  // namespace impl
+
+int setup() { return 0; }
+
+void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int flags, double thresh, int *info)
+{
+    emul_enqueue(s, [=] { impl::diag_lu(s, T, nodes, nn, max_nsupc, flags, thresh, info); });
+}
+
+void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask)
+{
+    emul_enqueue(s, [=] { impl::diag_inv(s, T, nodes, prefix, nn, ntask); });
+}
+
+void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs, int max_nsupc)
+{
+    emul_enqueue(s, [=] { impl::panel_trsm(s, T, nodes, lprefix, uprefix, nn, nl, nu, rs, max_nsupc); });
+}
+
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc)
+{
+    emul_enqueue(s, [=] { impl::panel_gemm(s, T, nodes, lprefix, uprefix, nn, nl, nu, max_nsupc); });
+}
+
+void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int prio)
+{
+    emul_enqueue(s, [=] { impl::schur(s, cfg, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio); });
+}
+
+void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc)
+{
+    emul_enqueue(s, [=] { impl::full_inv(s, T, nodes, prefix, nn, nwork, max_nsupc); });
+}
+
+void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc)
+{
+    emul_enqueue(s, [=] { impl::solve_diag(s, lower, T, nodes, nn, x, ldx, nrhs, max_nsupc); });
+}
+
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
+{
+    emul_enqueue(s, [=] { impl::fwd_update(s, T, nodes, prefix, nn, nwork, x, ldx, nrhs, max_nsupc, units); });
+}
+
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
+{
+    emul_enqueue(s, [=] { impl::bwd_update(s, T, nodes, prefix, nn, nwork, x, ldx, nrhs, max_nsupc, units); });
+}
+
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits, double *x, int64_t ldx, int nrhs, int max_nsupc)
+{
+    emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dnodes, nd, units, nunits, x, ldx, nrhs, max_nsupc); });
+}
+
+void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)
+{
+    emul_enqueue(s, [=] { impl::scatter_values(s, val, pos, a, nnz); });
+}
+
+void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc, double *r_perm, unsigned long long *s_out, double safe1, double safe2)
+{
+    emul_enqueue(s, [=] { impl::rfs_residual(s, n, rp, ci, av, x, b, pc, r_perm, s_out, safe1, safe2); });
+}
+
+void rfs_update(hipStream_t s, int n, const int *pc, const double *dx_perm, double *x)
+{
+    emul_enqueue(s, [=] { impl::rfs_update(s, n, pc, dx_perm, x); });
+}
+
+void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y)
+{
+    emul_enqueue(s, [=] { impl::axpy(s, n, a, x, y); });
+}
+
+void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage)
+{
+    emul_enqueue(s, [=] { impl::pack_diag(s, T, nodes, prefix, off, nn, nwork, stage); });
+}
+
+void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs, int nruns, int64_t total, double *buf, int mode)
+{
+    emul_enqueue(s, [=] { impl::xseg_copy(s, x, ldx, nrhs, runs, nruns, total, buf, mode); });
+}
 
 int mfma_selftest(const double *A, const double *B, double *D)
 {

@@ -1,0 +1,88 @@
+"""Stream-order check of the drivers (CPU): the library's host code (look-ahead schedule of pdgstrf3d on four streams, XY panel
+exchanges, Z reduction, triangular sweeps) runs on the emulated HIP runtime with its ADVERSARIAL scheduler on
+(oracle/emul/emul_rt.cpp): stream work is queued and executed in a seeded order that honours only stream order, event waits and
+the synchronising calls.  A dependency the drivers forgot to express (a missing hipStreamWaitEvent, a host read before a
+synchronisation) gives a wrong factorisation here, whatever the timing on a real device happens to be."""
+import ctypes
+import numpy as np
+import pytest
+import grid_cases
+from superlu_dist_amd import driver, matgen
+
+
+def _sched(lib, mode, seed=1):
+    lib.sluamd_emul_sched(ctypes.c_int(mode), ctypes.c_uint(seed))
+
+
+def _stats(lib):
+    run, reord = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+    lib.sluamd_emul_sched_stats(ctypes.byref(run), ctypes.byref(reord))
+    return run.value, reord.value
+
+
+@pytest.fixture()
+def sched(emul):
+    yield emul
+    _sched(emul, 0)          # back to immediate execution for whatever test comes next
+
+
+def _factor_and_solve(n, rp, ci, v, perm, b, **kw):
+    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, **kw)
+    assert info == 0
+    return x
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_lookahead_schedule_single_rank(sched, mode, seed):
+    """Deep elimination DAG (narrow supernodes -> many levels, K-fused pairs, two-level look-ahead on four streams)."""
+    N = 10
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(5)
+    v = v * (1.0 + 0.2 * rng.random(v.size))
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=8)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    x_ref = _factor_and_solve(n, rp, ci, v, perm, b, relax=4, maxsup=16)       # immediate execution, issue order
+    _sched(sched, mode, seed)
+    x = _factor_and_solve(n, rp, ci, v, perm, b, relax=4, maxsup=16)
+    run, reordered = _stats(sched)
+    _sched(sched, 0)
+    assert run > 100 and reordered > 0          # the scheduler did reorder work across streams
+    assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
+    assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 2), (2, 1), (3, 1)])
+def test_wide_supernodes_big_tiles_and_fused_pairs(sched, mode, seed):
+    """256-wide supernodes: the 128 x 128 tile lists, K-fused chain pairs, Crout diagonal kernel + full inverses on the chain."""
+    N = 14
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
+    x_ref = _factor_and_solve(n, rp, ci, v, perm, b, relax=64, maxsup=256)
+    _sched(sched, mode, seed)
+    x = _factor_and_solve(n, rp, ci, v, perm, b, relax=64, maxsup=256)
+    _sched(sched, 0)
+    assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
+
+
+@pytest.mark.parametrize("grid", [(2, 2, 1), (1, 1, 2), (2, 2, 2)])
+@pytest.mark.parametrize("mode,seed", [(1, 1), (2, 1), (3, 2)])
+def test_grid_drivers(sched, grid, mode, seed):
+    """XY panel exchange (its own look-ahead rule: the received panels of a level share a scratch copy by level parity), Z ancestor
+    reduction and the distributed sweeps, ranks = threads over the in-process transport."""
+    _sched(sched, mode, seed)
+    grid_cases.check_own_pipeline(8, grid, nrhs=2, unsym=True, refactor=(grid == (2, 2, 2)))
+    _sched(sched, 0)
+
+
+@pytest.mark.parametrize("sched_env", ["1,11", "2,1", "3,4"])
+def test_reference_fixtures_under_the_scheduler(sched_env):
+    """The per-rank parity tests against the reference's recorded grids (1x1x2, 2x1x1, 2x2x2 golden fixtures, own pipeline on seven
+    grid shapes, wide supernodes) once more, the whole process under one adversarial schedule (SLUAMD_EMUL_SCHED=mode,seed)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SLUAMD_EMUL_SCHED=sched_env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_grid_emul.py"), "-q", "-x", "-k", "not gloo"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
