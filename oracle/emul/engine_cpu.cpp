@@ -11,6 +11,7 @@
 // (pdgstrs_lsum.c:414, :1362) -- with the kernels' blocking by 32 (inverted diagonal sub-blocks) kept.
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -196,11 +197,12 @@ void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lp
     }
 }
 
-void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, int)
+// V = double or std::complex<double>: the value arena is addressed in elements of V (offsets are type independent)
+template <class V>
+static void schur_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist)
 {
-    (void) cfg;
-    std::vector<double> acc, lrow;
+    V *val = reinterpret_cast<V *>(T.val);
+    std::vector<V> acc;
     std::vector<int> rowmap, colmap;
     for (int bid0 = 0; bid0 < ntiles; ++bid0) {
         const int bid = bid0 + id_base;
@@ -219,7 +221,7 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
         const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
         const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
         const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
-        acc.assign((size_t) nr * nc, 0.0);
+        acc.assign((size_t) nr * nc, V(0));
         int nprev = 0;
         if (T.fuse_prev) while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev;
         for (int src = 0; src <= nprev; ++src) {
@@ -228,25 +230,25 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
                 const int ks = T.fuse_prev[pj];
                 const int nss = T.xsup[ks + 1] - T.xsup[ks], ldas = T.sn_nsupr[ks];
                 const int *cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[pj] + T.ub_stcol[ub] + C.y);
-                const double *Ls = T.val + T.sn_lval[ks], *Us = T.val + T.sn_uval[ks];
+                const V *Ls = val + T.sn_lval[ks], *Us = val + T.sn_uval[ks];
                 for (int c = 0; c < nc; ++c) {
                     const int cp = cinfo[2 * c], lead = cinfo[2 * c + 1];
                     for (int r = 0; r < nr; ++r) {
                         const int ra = T.pair_rowmap[T.pair_roff[pj] + R.w + r];
                         if (ra < 0) continue;
-                        double a = 0;
+                        V a(0);
                         for (int kk = lead; kk < nss; ++kk) a += Ls[ra + (size_t) kk * ldas] * Us[cp + (kk - lead)];
                         acc[r + (size_t) c * nr] += a;
                     }
                 }
             } else {
                 const int lda = T.sn_nsupr[k];
-                const double *Lp = T.val + T.sn_lval[k] + R.w, *Uv = T.val + T.sn_uval[k];
+                const V *Lp = val + T.sn_lval[k] + R.w, *Uv = val + T.sn_uval[k];
                 for (int c = 0; c < nc; ++c) {
                     const int jj = T.unzcol[uix0 + C.y + c];
                     const int lead = ns - (klst - T.uidx[uix0 + jj]), cp = T.ucolptr[uix0 + jj];
                     for (int r = 0; r < nr; ++r) {
-                        double a = 0;
+                        V a(0);
                         for (int kk = lead; kk < ns; ++kk) a += Lp[r + (size_t) kk * lda] * Uv[cp + (kk - lead)];
                         acc[r + (size_t) c * nr] += a;
                     }
@@ -274,7 +276,7 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
             const int d = o + T.lbs_idx[o + pos];
             const int rowoff = T.lb_rowoff[d], dn = T.lb_nbrow[d];
             const int *drows = T.lidx + T.sn_lidx[jb] + T.lb_lptr[d];
-            double *dst = T.val + T.sn_lval[jb];
+            V *dst = val + T.sn_lval[jb];
             const int ldv = T.sn_nsupr[jb];
             for (int r = 0; r < nr; ++r) {
                 int di = -1;
@@ -287,7 +289,7 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
             }
         } else {
             const int64_t d0 = T.sn_uidx[ib] + T.ub_iukp[o + pos];
-            double *dst = T.val + T.sn_uval[ib];
+            V *dst = val + T.sn_uval[ib];
             for (int c = 0; c < nc; ++c) {
                 const int jj = T.unzcol[uix0 + C.y + c];
                 const int cm = T.ucolptr[d0 + jj] - T.uidx[d0 + jj];
@@ -295,6 +297,12 @@ void schur(hipStream_t, int cfg, const DevTables &T, const int *nodes, const int
             }
         }
     }
+}
+
+void schur(hipStream_t, int, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
+           const int4 *ulist, int)
+{
+    schur_t<double>(T, nodes, prefix, nn, id_base, ntiles, info, ulist);
 }
 
 void full_inv(hipStream_t, const DevTables &T, const int *nodes, const int *, int nn, int, int)
@@ -350,8 +358,8 @@ void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, i
     }
 }
 
-void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
-                const int2 *units)
+template <class V, int STRIP>
+static void fwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, V *x, int64_t ldx, int nrhs, const int2 *units)
 {
     for (int w = 0; w < nwork; ++w) {
         int k, strip;
@@ -359,13 +367,13 @@ void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
         else { const int ni = find_node(prefix, nn, w); k = nodes[ni]; strip = w - prefix[ni]; }
         const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
         const int *lsub = T.lidx + T.sn_lidx[k];
-        for (int t = 0; t < 64; ++t) {
-            const int row = T.sn_ldiag[k] + strip * 64 + t;
+        for (int t = 0; t < STRIP; ++t) {
+            const int row = T.sn_ldiag[k] + strip * STRIP + t;
             if (row >= lda) break;
             const int grow = T.lrow[T.sn_lrow[k] + row];
-            const double *L = T.val + T.sn_lval[k] + row;
+            const V *L = reinterpret_cast<const V *>(T.val) + T.sn_lval[k] + row;
             for (int r = 0; r < nrhs; ++r) {
-                double acc = 0;
+                V acc(0);
                 for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * x[fst + kk + (int64_t) r * ldx];
                 x[grow + (int64_t) r * ldx] -= acc;
             }
@@ -373,8 +381,8 @@ void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
     }
 }
 
-void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
-                const int2 *units)
+template <class V>
+static void bwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, V *x, int64_t ldx, int nrhs, const int2 *units)
 {
     for (int w = 0; w < nwork; ++w) {
         int k, chunk;
@@ -382,17 +390,29 @@ void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
         else { const int ni = find_node(prefix, nn, w); k = nodes[ni]; chunk = w - prefix[ni]; }
         const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
         const int ncol = std::min(64, T.sn_ncolu[k] - chunk * 64);
-        const double *Uv = T.val + T.sn_uval[k];
+        const V *Uv = reinterpret_cast<const V *>(T.val) + T.sn_uval[k];
         for (int t = 0; t < ncol; ++t) {
             const int c = chunk * 64 + t;
             const int64_t cidx = T.sn_ucol[k] + c;
             const int ld = T.ucol_ld[cidx], cp = T.ucol_cp[cidx], gc = T.ucol_gc[cidx];
             for (int r = 0; r < nrhs; ++r) {
-                const double xv = x[gc + (int64_t) r * ldx];
+                const V xv = x[gc + (int64_t) r * ldx];
                 for (int i = ld; i < ns; ++i) x[fst + i + (int64_t) r * ldx] -= Uv[cp + (i - ld)] * xv;
             }
         }
     }
+}
+
+void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
+                const int2 *units)
+{
+    fwd_update_t<double, 64>(T, nodes, prefix, nn, nwork, x, ldx, nrhs, units);
+}
+
+void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
+                const int2 *units)
+{
+    bwd_update_t<double>(T, nodes, prefix, nn, nwork, x, ldx, nrhs, units);
 }
 
 // the far units FIRST, then the diagonal solves: on the device the diagonal workgroups are dispatched first -- a dependency
@@ -553,15 +573,128 @@ int mfma_selftest(const double *A, const double *B, double *D)
     return 0;
 }
 
-// complex16: not restated here (the multi-rank paths this build exists for are double precision)
-static void no_z() { std::fprintf(stderr, "engine_cpu: complex16 kernels are not emulated\n"); std::abort(); }
-void zdiag_lu(hipStream_t, const DevTables &, const int *, int, int, int, double, int *) { no_z(); }
-void zpanel_trsm(hipStream_t, const DevTables &, const int *, const int *, const int *, int, int, int) { no_z(); }
-void zschur(hipStream_t, const DevTables &, const int *, const int *, int, int, int, int *) { no_z(); }
-void zsolve_diag(hipStream_t, bool, const DevTables &, const int *, int, void *, int64_t, int, int) { no_z(); }
-void zfwd_update(hipStream_t, const DevTables &, const int *, const int *, int, int, void *, int64_t, int, int) { no_z(); }
-void zbwd_update(hipStream_t, const DevTables &, const int *, const int *, int, int, void *, int64_t, int) { no_z(); }
-void zscatter_values(hipStream_t, void *, const int64_t *, const void *, int64_t) { no_z(); }
+// ---- complex16 twins (sluamd_zkernels.inc; 1 x 1 layers): the generic pieces above instantiated for std::complex<double>, the
+// panel kernels as plain substitutions on the factored diagonal block (the complex path has no inverted blocks) ----
+namespace impl {
+typedef std::complex<double> zc;
+static zc z_div(zc a, zc b)   // slud_z_div (Smith), SRC/complex16/dcomplex_dist.c:29-58 -- as the device kernels divide
+{
+    double ratio, den, cr, ci;
+    if (std::fabs(b.real()) <= std::fabs(b.imag())) {
+        ratio = b.real() / b.imag(); den = b.imag() * (1 + ratio * ratio);
+        cr = (a.real() * ratio + a.imag()) / den; ci = (a.imag() * ratio - a.real()) / den;
+    } else {
+        ratio = b.imag() / b.real(); den = b.real() * (1 + ratio * ratio);
+        cr = (a.real() + a.imag() * ratio) / den; ci = (a.imag() - a.real() * ratio) / den;
+    }
+    return zc(cr, ci);
+}
+
+// Local_Zgstrf2 (pzgstrf2.c): unpivoted right-looking LU of the diagonal block; |re|+|im| < thresh with both parts non-zero ->
+// (sign(re) thresh, 0); a zero pivot is reported in info[0] and leaves its column unscaled
+static void zdiag_lu(const DevTables &T, const int *nodes, int nn, int replace_tiny, double thresh, int *info)
+{
+    for (int q = 0; q < nn; ++q) {
+        const int k = nodes[q];
+        if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
+        zc *A = reinterpret_cast<zc *>(T.val) + T.sn_lval[k];
+        for (int j = 0; j < ns; ++j) {
+            zc p = A[j + (size_t) j * lda];
+            if (replace_tiny && (std::fabs(p.real()) + std::fabs(p.imag())) < thresh && p.real() != 0.0 && p.imag() != 0.0) {
+                p = zc(p.real() < 0 ? -thresh : thresh, 0.0);
+                A[j + (size_t) j * lda] = p; info[1] += 1;
+            }
+            const bool zero = p == zc(0.0, 0.0);
+            if (zero) info[0] = std::min(info[0], fst + j + 1);
+            const zc rinv = zero ? zc(1.0, 0.0) : z_div(zc(1.0, 0.0), p);
+            for (int i = j + 1; i < ns; ++i) {
+                zc l = A[i + (size_t) j * lda];
+                if (!zero) l *= rinv;
+                A[i + (size_t) j * lda] = l;
+                for (int c = j + 1; c < ns; ++c) A[i + (size_t) c * lda] -= l * A[j + (size_t) c * lda];
+            }
+        }
+    }
+}
+
+// zLPanelTrSolve / zUPanelTrSolve (ztrfCommWrapper.c): L(off-diagonal rows, :) <- L inv(U_kk), U(k, :) <- inv(L_kk) U(k, :) on the skyline
+static void zpanel_trsm(const DevTables &T, const int *nodes, int nn)
+{
+    for (int q = 0; q < nn; ++q) {
+        const int k = nodes[q];
+        const int ns = T.xsup[k + 1] - T.xsup[k], lda = T.sn_nsupr[k];
+        zc *A = reinterpret_cast<zc *>(T.val) + T.sn_lval[k];
+        if (T.sn_flags[k] & SNF_L_OWN)
+            for (int row = T.sn_ldiag[k]; row < lda; ++row)
+                for (int j = 0; j < ns; ++j) {
+                    zc acc = A[row + (size_t) j * lda];
+                    for (int kk = 0; kk < j; ++kk) acc -= A[row + (size_t) kk * lda] * A[kk + (size_t) j * lda];
+                    A[row + (size_t) j * lda] = z_div(acc, A[j + (size_t) j * lda]);
+                }
+        if (T.sn_flags[k] & SNF_U_OWN) {
+            zc *Uv = reinterpret_cast<zc *>(T.val) + T.sn_uval[k];
+            for (int c = 0; c < T.sn_ncolu[k]; ++c) {
+                const int64_t ci = T.sn_ucol[k] + c;
+                const int ld = T.ucol_ld[ci];
+                zc *col = Uv + T.ucol_cp[ci] - ld;       // col[i] = U(i, column), rows ld .. ns-1
+                for (int i = ld; i < ns; ++i) {
+                    zc acc = col[i];
+                    for (int kk = ld; kk < i; ++kk) acc -= A[i + (size_t) kk * lda] * col[kk];
+                    col[i] = acc;
+                }
+            }
+        }
+    }
+}
+
+static void zsolve_diag(bool lower, const DevTables &T, const int *nodes, int nn, zc *x, int64_t ldx, int nrhs)
+{
+    for (int q = 0; q < nn; ++q) {
+        const int k = nodes[q];
+        if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
+        const zc *A = reinterpret_cast<const zc *>(T.val) + T.sn_lval[k];
+        for (int r = 0; r < nrhs; ++r) {
+            zc *xk = x + fst + (int64_t) r * ldx;
+            if (lower) { for (int j = 0; j < ns; ++j) for (int i = j + 1; i < ns; ++i) xk[i] -= A[i + (size_t) j * lda] * xk[j]; }
+            else for (int j = ns - 1; j >= 0; --j) { xk[j] = z_div(xk[j], A[j + (size_t) j * lda]); for (int i = 0; i < j; ++i) xk[i] -= A[i + (size_t) j * lda] * xk[j]; }
+        }
+    }
+}
+}  // namespace impl
+
+void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int, int replace_tiny, double thresh, int *info)
+{
+    emul_enqueue(s, [=] { impl::zdiag_lu(T, nodes, nn, replace_tiny, thresh, info); });
+}
+void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *, const int *, int nn, int, int)
+{
+    emul_enqueue(s, [=] { impl::zpanel_trsm(T, nodes, nn); });
+}
+void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info)
+{
+    emul_enqueue(s, [=] { impl::schur_t<impl::zc>(T, nodes, prefix, nn, id_base, ntiles, info, nullptr); });
+}
+void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int)
+{
+    emul_enqueue(s, [=] { impl::zsolve_diag(lower, T, nodes, nn, static_cast<impl::zc *>(x), ldx, nrhs); });
+}
+void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs, int)
+{
+    emul_enqueue(s, [=] { impl::fwd_update_t<impl::zc, 256>(T, nodes, prefix, nn, nwork, static_cast<impl::zc *>(x), ldx, nrhs, nullptr); });
+}
+void zbwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs)
+{
+    emul_enqueue(s, [=] { impl::bwd_update_t<impl::zc>(T, nodes, prefix, nn, nwork, static_cast<impl::zc *>(x), ldx, nrhs, nullptr); });
+}
+void zscatter_values(hipStream_t s, void *val, const int64_t *pos, const void *a, int64_t nnz)
+{
+    emul_enqueue(s, [=] {
+        impl::zc *v = static_cast<impl::zc *>(val); const impl::zc *av = static_cast<const impl::zc *>(a);
+        for (int64_t e = 0; e < nnz; ++e) v[pos[e]] = av[e];
+    });
+}
 
 }  // namespace eng
 }  // namespace sluamd

@@ -87,36 +87,4 @@ def test_complex16_grid_fixture_per_rank_parity(golden, case):
 def test_own_pipeline_complex16_on_z_layers(Pz):
     """complex16 through the library's own symbolic factorisation + device-side distribution on a 1 x 1 x Pz grid: residual on the
     original system and agreement with the single-rank solution."""
-    import numpy as np
-    from superlu_dist_amd import driver, grid3d, matgen
-    N = 12
-    n, rp, ci, v = matgen.poisson3d(N)
-    v = matgen.complex_shift(v, rp, ci, seed=2)
-    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
-    rng = np.random.default_rng(3)
-    xt = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
-    b = np.zeros_like(xt)
-    for i in range(n):
-        b[i, :] = v[rp[i]:rp[i + 1]] @ xt[ci[rp[i]:rp[i + 1]], :]
-    symb = driver.Symbolic(n, rp, ci, perm, relax=16, maxsup=64)
-    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
-    h1 = driver.LUHandle.from_symbolic(symb, v)
-    assert h1.pzgstrf3d(0.0) == 0
-    x1 = h1.pzgstrs3d(xp)[symb.perm_c, :]
-    h1.destroy()
-    sn_tree = symb.partition(Pz)
-    comms = grid3d.local_comms(1, 1, Pz)
-
-    def rank_body(rank):
-        h = grid3d.GridHandle.from_symbolic(symb, v, comms[rank], sn_tree)
-        info = h.pdgstrf3d(0.0)
-        y = h.pdgstrs3d(xp)
-        h.destroy()
-        return info, y
-
-    for info, y in grid3d.run_ranks(Pz, rank_body):
-        assert info == 0
-        x = y[symb.perm_c, :]
-        assert np.abs(x - xt).max() <= 1e-10 * np.abs(xt).max()
-        assert np.abs(x - x1).max() <= 1e-10 * np.abs(x1).max()
-    symb.free()
+    grid_cases.check_own_pipeline_complex16(Pz)

@@ -15,7 +15,7 @@ def test_grid_fixture_per_rank_parity(emul, golden, case):
     grid_cases.check_fixture_grid(golden(case))
 
 
-@pytest.mark.parametrize("case", ["g20_1x1x1", "poisson10_nd", "unsym300", "unsym120_tiny"])
+@pytest.mark.parametrize("case", ["g20_1x1x1", "poisson10_nd", "unsym300", "unsym120_tiny", "z_cg20_1x1x1", "z_poisson8_nd", "z_unsym200", "z_grid24_nd"])
 def test_single_rank_fixture_parity(emul, golden, case):
     """1x1x1 through the same planner (slot model with one process row / column)."""
     from superlu_dist_amd import driver
@@ -28,6 +28,18 @@ def test_single_rank_fixture_parity(emul, golden, case):
     assert np.abs(st.Lnzval - g["r0__Lnzval_post"]).max() <= 1e-12 * scale
     assert np.abs(st.Unzval - g["r0__Unzval_post"]).max() <= 1e-12 * scale
     h.destroy()
+
+
+@pytest.mark.parametrize("case", grid_cases.ZGRID_FIXTURES)
+def test_complex16_grid_fixture_per_rank_parity(emul, golden, case):
+    """pzgstrf3d / pzgstrs3d on 1 x 1 x 2 against the reference's per-rank records: the host logic of the complex path (Z ancestor
+    reduction and Z sweeps on pairs of doubles) over the complex restatement of the kernels."""
+    grid_cases.check_fixture_grid(golden(case))
+
+
+@pytest.mark.parametrize("Pz", [2, 4])
+def test_own_pipeline_complex16_on_z_layers(emul, Pz):
+    grid_cases.check_own_pipeline_complex16(Pz)
 
 
 @pytest.mark.parametrize("N,grid,nrhs,unsym", [(8, (1, 1, 2), 1, False), (8, (2, 2, 1), 2, True), (10, (2, 2, 2), 1, True),
