@@ -23,3 +23,19 @@ def test_gpu_test_files_against_the_emulation_library(sched):
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert " passed" in r.stdout
+
+
+def test_reference_drop_in_against_the_emulation_library():
+    """test_gpu_dropin.py on CPU: the REAL reference pipeline (oracle/_ref/slu_ref_amd: pdgssvx3d / pzgssvx3d under mpiexec on 1x1x1 ...
+    2x2x2 grids, SUPERLU_MAXSUP=512, the irregular stand-in on 2x2x2) with pdgstrf3d and pdgstrs3d bound through
+    oracle/ref/sluamd_binding.c -- which loads the library named by SLUAMD_LIB -- to the emulation library.  Pins the binding, the
+    view path, the structure exchange and the MPI callback transport without a GPU (the n = 46 656 case is left to the GPU run)."""
+    so = os.path.join(ROOT, "oracle", "libsluamd_emul.so")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "slu_ref_amd")):
+        pytest.skip("prebuilt reference binaries not present (oracle/_ref is built where /root/reference exists)")
+    env = dict(os.environ, SLUAMD_LIB=so)
+    env.pop("SLUAMD_EMUL_SCHED", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "not at_scale", os.path.join(ROOT, "tests", "test_gpu_dropin.py")],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1]
