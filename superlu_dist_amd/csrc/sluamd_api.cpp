@@ -70,7 +70,7 @@ static int copy_values(Handle *H, const sluamd_dLUview_t *lu, int dir)
             if (H->split.active) {   // refined wide supernodes: the slot's values are gathered from column pieces of the caller's panels
                 int64_t o = off;
                 for (const auto &pc : (pass == 0 ? H->split.lsrc[k] : H->split.usrc[k])) {
-                    char *base = reinterpret_cast<char *>(pc.arr == 0 ? (void *) lu->Lnzval_bc_ptr[pc.ok] : (void *) lu->Unzval_br_ptr[pc.ok]);
+                    char *base = reinterpret_cast<char *>(pc.arr == 0 ? (void *) lu->Lnzval_bc_ptr[pc.ok / g.Pc] : (void *) lu->Unzval_br_ptr[pc.ok / g.Pr]);
                     if (!base) { set_error("value array missing for a stored panel"); return SLUAMD_ESTRUCT; }
                     if ((rc = stage(base + (size_t) pc.hoff * esz, (size_t) pc.len * esz, o))) return rc;
                     o += pc.len;

@@ -156,17 +156,20 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
     for (int k = 0; k < nso; ++k) wmax = std::max(wmax, ox[k + 1] - ox[k]);
     if (wmax <= 256) return 0;
     if (wmax > 512) { set_error("supernodes wider than 512 columns (MAX_SUPER_SIZE) are not supported"); return SLUAMD_EINVAL; }
-    if (H.grid.Pr * H.grid.Pc > 1) { set_error("supernodes wider than 256 columns are supported on 1 x 1 x Pz grids only (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
+    // XY layers: the pieces of a supernode stay with its owners (Grid::own) -- every rank refines the slots it works with (own and
+    // received index arrays alike) by the same rule, so senders and receivers of a panel agree on the refined layout
+    const bool xy = H.grid.Pr * H.grid.Pc > 1;
+    const Grid g0 = H.grid;                    // ownership of the caller's (unrefined) supernodes
     if (H.z) { set_error("complex16: supernodes wider than 256 columns are not supported"); return SLUAMD_EINVAL; }
     SplitMap &M = H.split;
-    M.active = true; M.oxsup = ox; M.first.assign(nso + 1, 0);
+    M.active = true; M.oxsup = ox; M.first.assign(nso + 1, 0); M.owner.clear();
     std::vector<int> nx(1, 0);                 // internal xsup
     for (int k = 0; k < nso; ++k) {
         const int w = ox[k + 1] - ox[k];
         M.first[k] = (int) nx.size() - 1;
         const int np = (w + 255) / 256;
         const int pw = (((w + np - 1) / np) + 31) & ~31;           // piece width: even split rounded up to the 32-column blocking
-        for (int c = 0; c < w; c += pw) nx.push_back(ox[k] + std::min(w, c + pw));
+        for (int c = 0; c < w; c += pw) { nx.push_back(ox[k] + std::min(w, c + pw)); M.owner.push_back(k); }
     }
     M.first[nso] = (int) nx.size() - 1;
     const int ns = M.first[nso];
@@ -176,9 +179,12 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
     for (int ko = 0; ko < nso; ++ko) {
         if (!hs.present[ko]) continue;
         const std::vector<int> &li = in.lidx[ko], &ui = in.uidx[ko];
-        if (li.size() < (size_t) BC_HEADER) { set_error("L panel with the diagonal block missing"); return SLUAMD_ESTRUCT; }
-        const int x0 = ox[ko], w = ox[ko + 1] - x0, nsupr_o = li[1];
-        if (li[0] < 1 || li[BC_HEADER] != ko || li[BC_HEADER + 1] != w) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
+        // this rank's part of the panel: the rows of its process row -- with the diagonal block on top on the process row of ko
+        const bool has_l = li.size() >= (size_t) BC_HEADER && li[0] > 0;
+        const bool has_diag = has_l && li[BC_HEADER] == ko;
+        const int x0 = ox[ko], w = ox[ko + 1] - x0, nsupr_o = has_l ? li[1] : 0;
+        if (g0.krow(ko) == g0.r && !has_diag) { set_error("L panel with the diagonal block missing"); return SLUAMD_ESTRUCT; }
+        if (has_diag && (g0.krow(ko) != g0.r || li[BC_HEADER + 1] != w)) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
         const int f = M.first[ko], np = M.first[ko + 1] - f;
         // original U row: column start offsets
         std::vector<int64_t> ucol0;    // per (block, jj) flattened in walk order: value offset of the column's segment
@@ -189,7 +195,7 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
             std::vector<int> &o = nl[id];
             o.assign(BC_HEADER, 0);
             int nb = 0, nr = 0;
-            for (int q = p; q < np; ++q) {                       // the rest of the original diagonal block, piece by piece
+            for (int q = p; q < np && has_diag; ++q) {           // the rest of the original diagonal block, piece by piece
                 const int r0 = nx[f + q], r1 = nx[f + q + 1];
                 o.push_back(f + q); o.push_back(r1 - r0);
                 for (int r = r0; r < r1; ++r) o.push_back(r);
@@ -200,8 +206,8 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
             // rows inside a block, symbfact.c keeps discovery order)
             std::vector<int> hostrow(nr);
             for (int i = 0; i < nr; ++i) hostrow[i] = c0 + i;
-            int pp = BC_HEADER + LB_DESCRIPTOR + w, rowbase = w;
-            for (int b = 1; b < li[0]; ++b) {
+            int pp = BC_HEADER + (has_diag ? LB_DESCRIPTOR + w : 0), rowbase = has_diag ? w : 0;
+            for (int b = has_diag ? 1 : 0; b < (has_l ? li[0] : 0); ++b) {
                 const int g = li[pp], nbrow = li[pp + 1];
                 const int *rows = li.data() + pp + LB_DESCRIPTOR;
                 for (int q = M.first[g]; q < M.first[g + 1]; ++q) {
@@ -216,7 +222,8 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
                 pp += LB_DESCRIPTOR + nbrow; rowbase += nbrow;
             }
             o[0] = nb; o[1] = nr;
-            if (nr != nsupr_o - c0 || (int) hostrow.size() != nr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
+            if (nr != (has_diag ? nsupr_o - c0 : nsupr_o) || (int) hostrow.size() != nr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
+            if (!nb) o.clear();
             for (int j = c0; j < c1; ++j)
                 for (int i = 0; i < nr;) {       // maximal runs of consecutive host rows
                     int e = i + 1;
@@ -230,7 +237,7 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
             u.assign(BR_HEADER, 0);
             int nub = 0; int64_t nnz = 0;
             const int klst = x0 + c1, row0 = x0 + c0;
-            for (int q = p + 1; q < np; ++q) {                   // U(piece p, piece q): inside the original diagonal block, full segments
+            for (int q = p + 1; q < np && g0.kcol(ko) == g0.c; ++q) {   // U(piece p, piece q): inside the original diagonal block, full segments (process column of ko)
                 const int cq0 = nx[f + q] - x0, cq1 = nx[f + q + 1] - x0;
                 u.push_back(f + q); u.push_back(h * (cq1 - cq0));
                 for (int j = cq0; j < cq1; ++j) { u.push_back(row0); M.usrc[id].push_back({0, ko, (int64_t) j * nsupr_o + c0, (int64_t) h}); }
@@ -272,6 +279,15 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
             if (!nub) u.clear();
         }
     }
+    if (xy)   // the block graph must be the same on every rank: all pieces of every successor (a superset of the true refined graph)
+        for (int ko = 0; ko < nso; ++ko) {
+            if (!hs.present[ko]) continue;
+            for (int id = M.first[ko]; id < M.first[ko + 1]; ++id) {
+                nsucc[id].clear();
+                for (int q = id + 1; q < M.first[ko + 1]; ++q) nsucc[id].push_back(q);
+                for (int gk : in.succ[ko]) for (int q = M.first[gk]; q < M.first[gk + 1]; ++q) nsucc[id].push_back(q);
+            }
+        }
     for (auto &v : nsucc) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
     for (auto &l : in.lists) {
         std::vector<int> e;
@@ -280,6 +296,7 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
     }
     in.lidx.swap(nl); in.uidx.swap(nu); in.succ.swap(nsucc);
     hs.nsupers = ns; hs.xsup = nx; hs.present = npresent;
+    H.grid.own = M.owner.data();
     return 0;
 }
 

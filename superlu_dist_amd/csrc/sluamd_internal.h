@@ -43,8 +43,9 @@ struct Grid {
     int size() const { return Pr * Pc * Pz; }
     int rank() const { return rank_of(r, c, z); }
     int rank_of(int rr, int cc, int zz) const { return (zz * Pr + rr) * Pc + cc; }
-    int krow(int k) const { return k % Pr; }   // PROW
-    int kcol(int k) const { return k % Pc; }   // PCOL
+    const int *own = nullptr;                  // refined wide supernodes (SplitMap): the caller's supernode an internal one is a piece of
+    int krow(int k) const { return (own ? own[k] : k) % Pr; }   // PROW
+    int kcol(int k) const { return (own ? own[k] : k) % Pc; }   // PCOL
 };
 
 // Host copy of the L/U *structure* this rank works with, indexed by GLOBAL supernode id.
@@ -203,6 +204,7 @@ struct SplitMap {
     bool active = false;
     std::vector<int> oxsup;     // the caller's xsup [original nsupers + 1]
     std::vector<int> first;     // [original nsupers + 1]: internal id of the first piece of each original supernode
+    std::vector<int> owner;     // [internal nsupers]: the original supernode of each piece (Grid::own)
     struct Piece { int arr; int ok; int64_t hoff, len; };   // arr 0 / 1: Lnzval_bc_ptr[ok] / Unzval_br_ptr[ok]; element offset and count
     std::vector<std::vector<Piece>> lsrc, usrc;             // per INTERNAL supernode, in slot (column-major) order
 };

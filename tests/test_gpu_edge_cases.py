@@ -103,8 +103,9 @@ def test_dense_supernode_of_300_columns_through_the_own_symbolic_path():
     h.destroy()
 
 
-def test_wide_supernodes_on_an_xy_layer_are_rejected_with_a_message():
-    """The refinement of 257..512-column supernodes is implemented for 1 x 1 x Pz grids; a 2 x 1 layer states the limit."""
+def test_one_wide_supernode_on_an_xy_layer():
+    """A dense 300-column matrix = one supernode of 300 columns on a 2 x 1 layer: both of its pieces live on its owners, the diagonal
+    block is split between them through the refined U slot."""
     from superlu_dist_amd import grid3d
     rng = np.random.default_rng(4)
     A = rng.standard_normal((300, 300)) * 0.1 + 300 * np.eye(300)
@@ -112,14 +113,21 @@ def test_wide_supernodes_on_an_xy_layer_are_rejected_with_a_message():
     symb = driver.Symbolic(n, rp, ci, None, relax=300, maxsup=300)
     if np.diff(symb.xsup()).max() <= 256:
         pytest.skip("symbolic did not produce a wide supernode")
+    b = rng.standard_normal((n, 2))
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
     comms = grid3d.local_comms(2, 1, 1)
 
     def body(rank):
-        with pytest.raises(RuntimeError, match="256"):
-            grid3d.GridHandle.from_symbolic(symb, v, comms[rank], None)
-        return 0
+        h = grid3d.GridHandle.from_symbolic(symb, v, comms[rank], None)
+        info = h.pdgstrf3d(0.0)
+        y = h.pdgstrs3d(xp)
+        h.destroy()
+        return info, y
 
-    grid3d.run_ranks(2, body)
+    for info, y in grid3d.run_ranks(2, body):
+        assert info == 0
+        x = y[symb.perm_c, :]
+        assert np.abs(A @ x - b).max() <= 1e-10 * np.abs(b).max()
 
 
 def test_dense_supernode_of_300_columns_through_the_view_path():

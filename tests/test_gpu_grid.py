@@ -69,10 +69,10 @@ def test_supernodes_257_to_512_columns(N, maxsup, Pz, shuffle):
     grid_cases.check_wide_supernodes(N, maxsup, Pz, orc, shuffle)
 
 
-@pytest.mark.parametrize("grid", [(1, 1, 1), (1, 1, 2)])
+@pytest.mark.parametrize("grid", [(1, 1, 1), (1, 1, 2), (2, 1, 1), (2, 2, 2)])
 def test_own_pipeline_with_supernodes_up_to_512_columns(grid):
     """maxsup = 512 through the library's own symbolic factorisation + device-side distribution: wide supernodes are refined
-    at handle creation, A's entries are scattered straight into the pieces."""
+    at handle creation (on XY layers the pieces stay with the owners of their supernode), A's entries are scattered straight into the pieces."""
     grid_cases.check_own_pipeline(18, grid, nrhs=2, leaf=64, relax=64, maxsup=512)
 
 
