@@ -12,7 +12,7 @@
 //     memory it completes at the call.
 // Everything else is free: mode 1 picks a random runnable stream at every step, mode 2 runs only what the synchronising call
 // transitively needs (other streams stay behind as long as possible), mode 3 runs every other runnable stream before the one
-// being waited for.  A missing event wait or a host read without synchronisation in the drivers (look-ahead schedule of
+// being waited for; the work units inside one launch (Schur tiles, update units) run in a shuffled order.  A missing event wait or a host read without synchronisation in the drivers (look-ahead schedule of
 // pdgstrf3d, panel exchanges, sweeps) becomes a wrong result under one of these orders -- tests/test_stream_order.py.
 #include <cstdio>
 #include <deque>
@@ -129,6 +129,12 @@ void emul_enqueue(hipStream_t s, std::function<void()> f)
     emul_op o; o.f = std::move(f); o.issue = ++g_issue;
     st->q.push_back(std::move(o)); ++st->issued;
     if (st == &g_null) flush(st, [&] { return st->q.empty(); });
+}
+
+unsigned emul_launch_seed()
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    return g_mode == 0 ? 0u : (unsigned) (g_rng() | 1u);
 }
 
 extern "C" void sluamd_emul_sched(int mode, unsigned seed)

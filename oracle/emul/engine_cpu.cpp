@@ -14,6 +14,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <random>
 #include <vector>
 #include "sluamd_internal.h"
 
@@ -204,7 +205,12 @@ static void schur_t(const DevTables &T, const int *nodes, const int *prefix, int
     V *val = reinterpret_cast<V *>(T.val);
     std::vector<V> acc;
     std::vector<int> rowmap, colmap;
-    for (int bid0 = 0; bid0 < ntiles; ++bid0) {
+    // workgroups of one launch run in no particular order on the device: under the adversarial scheduler, in a shuffled one here
+    std::vector<int> order(ntiles);
+    for (int i = 0; i < ntiles; ++i) order[i] = i;
+    if (unsigned sd = emul_launch_seed()) { std::mt19937 rng(sd); std::shuffle(order.begin(), order.end(), rng); }
+    for (int it = 0; it < ntiles; ++it) {
+        const int bid0 = order[it];
         const int bid = bid0 + id_base;
         int k, rt, ct;
         if (ulist) { k = ulist[bid].x; rt = ulist[bid].y - T.sn_rt_off[k]; ct = ulist[bid].z - T.sn_ct_off[k]; }
@@ -361,7 +367,11 @@ void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, i
 template <class V, int STRIP>
 static void fwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, V *x, int64_t ldx, int nrhs, const int2 *units)
 {
-    for (int w = 0; w < nwork; ++w) {
+    std::vector<int> order(std::max(nwork, 0));
+    for (int i = 0; i < nwork; ++i) order[i] = i;
+    if (unsigned sd = emul_launch_seed()) { std::mt19937 rng(sd); std::shuffle(order.begin(), order.end(), rng); }
+    for (int it = 0; it < nwork; ++it) {
+        const int w = order[it];
         int k, strip;
         if (units) { k = units[w].x; strip = units[w].y; }
         else { const int ni = find_node(prefix, nn, w); k = nodes[ni]; strip = w - prefix[ni]; }
@@ -384,7 +394,11 @@ static void fwd_update_t(const DevTables &T, const int *nodes, const int *prefix
 template <class V>
 static void bwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, V *x, int64_t ldx, int nrhs, const int2 *units)
 {
-    for (int w = 0; w < nwork; ++w) {
+    std::vector<int> order(std::max(nwork, 0));
+    for (int i = 0; i < nwork; ++i) order[i] = i;
+    if (unsigned sd = emul_launch_seed()) { std::mt19937 rng(sd); std::shuffle(order.begin(), order.end(), rng); }
+    for (int it = 0; it < nwork; ++it) {
+        const int w = order[it];
         int k, chunk;
         if (units) { k = units[w].x; chunk = units[w].y; }
         else { const int ni = find_node(prefix, nn, w); k = nodes[ni]; chunk = w - prefix[ni]; }
