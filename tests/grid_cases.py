@@ -67,14 +67,19 @@ def check_fixture_grid(g):
 def check_own_pipeline(N, grid, nrhs=1, leaf=27, relax=16, maxsup=64, unsym=False, refactor=False):
     """Library's own symbolic factorisation + device-side distribution on a Pr x Pc x Pz grid: residual on the original
     system < 1e-10 and the solution equal (1e-10) to the single-rank one."""
-    Pr, Pc, Pz = grid
-    P = Pr * Pc * Pz
     n, rp, ci, v = matgen.poisson3d(N)
     if unsym:
         rng = np.random.default_rng(N)
         v = v * (1.0 + 0.3 * rng.random(v.size))
         v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
     perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
+    check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=nrhs, relax=relax, maxsup=maxsup, refactor=refactor)
+
+
+def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False):
+    """Any CSR matrix (unpivoted LU must be stable for it) through the own pipeline on a Pr x Pc x Pz grid."""
+    Pr, Pc, Pz = grid
+    P = Pr * Pc * Pz
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, nrhs)
     x1, info1, _ = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=relax, maxsup=maxsup)
     assert info1 == 0

@@ -86,3 +86,31 @@ def test_reference_fixtures_under_the_scheduler(sched_env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_grid_emul.py"), "-q", "-x", "-k", "not gloo"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SLUAMD_FUZZ_CASES", "48"))))
+def test_random_structures_grids_and_schedules(sched, seed):
+    """Fuzz: random unsymmetric matrices (irregular supernodes, ragged skylines), random supernode limits, grid shapes, numbers of
+    right-hand sides and adversarial schedules -- the solution must agree with the single-rank one and solve the original system."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(60, 260))
+    n, rp, ci, v = matgen.random_unsym(n, float(rng.uniform(0.01, 0.06)), seed=seed)
+    grid = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 1, 2), (2, 1, 2), (1, 1, 4), (3, 1, 1), (2, 2, 2)][int(rng.integers(0, 9))]
+    relax = int(rng.choice([1, 4, 16, 64])); maxsup = int(rng.choice([4, 16, 48, 256]))
+    _sched(sched, int(rng.integers(1, 4)), int(rng.integers(1, 1000)))
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, None, grid, nrhs=int(rng.integers(1, 4)), relax=relax, maxsup=maxsup,
+                                    refactor=bool(rng.integers(0, 2)))
+    _sched(sched, 0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_wide_supernodes_grids_and_schedules(sched, seed):
+    """Fuzz of the 257..512-column refinement: nearly dense matrices (one or two supernodes of several hundred columns) on random
+    grids -- XY layers included -- under random schedules."""
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(270, 430))
+    n, rp, ci, v = matgen.random_unsym(n, float(rng.uniform(0.5, 0.95)), seed=100 + seed)
+    grid = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 1, 2), (2, 2, 2), (3, 2, 1)][int(rng.integers(0, 7))]
+    _sched(sched, int(rng.integers(1, 4)), int(rng.integers(1, 1000)))
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, None, grid, nrhs=2, relax=512, maxsup=512)
+    _sched(sched, 0)
