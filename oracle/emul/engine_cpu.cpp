@@ -311,11 +311,12 @@ void schur(hipStream_t, int, const DevTables &T, const int *nodes, const int *pr
     schur_t<double>(T, nodes, prefix, nn, id_base, ntiles, info, ulist);
 }
 
-void full_inv(hipStream_t, const DevTables &T, const int *nodes, const int *, int nn, int, int)
+void full_inv(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int, int)
 {
     for (int i0 = 0; i0 < nn; ++i0) {
         const int k = nodes[i0];
-        if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
+        if (prefix[i0 + 1] == prefix[i0]) continue;          // no work units: the block is not available here (or not wanted: XY peers in TRSM mode)
+        if (!(T.sn_flags[k] & SNF_HAS_DIAG)) { std::fprintf(stderr, "engine_cpu: full_inv unit without the diagonal block\n"); std::abort(); }
         const int ns = T.xsup[k + 1] - T.xsup[k], lda = T.sn_dlda[k], nblk = (ns + DB - 1) / DB;
         const double *A = T.val + T.sn_dptr[k];
         for (int typ = 0; typ < 2; ++typ) {

@@ -54,7 +54,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const DevTables &T = H->T;
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     const bool lookahead = !H->profile && !H->opt.deterministic && !H->env.no_lookahead;
-    const bool gemm_panels = !xy && !H->env.trsm_panels;
+    const bool gemm_panels = !H->env.trsm_panels;   // XY layers: the peers of a diagonal block invert the copy they receive (full_inv on SNF_HAS_DIAG)
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     int rc_x = 0;
     int cur_level = 0, cur_pass = 0;
@@ -78,7 +78,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             if (!rc_x) rc_x = exchange(H, S.x_diag_send[l], S.x_diag_recv[l], ps);
             eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);   // column / row peers invert the diagonal blocks they received
         }
-        if (gemm_panels) eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);   // 1 x 1 layer: Linv / Uinv (the solve uses them too)
+        if (gemm_panels) eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);   // Linv / Uinv (the solve uses the owner's too)
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);
         H->st.num_launches += 1 + (gemm_panels ? 1 : 0) + (xy ? 2 : 0);
     };
@@ -296,7 +296,7 @@ int run_factor(Handle *H, double thresh, int *info)
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
-    H->dinv_ready = true; H->inv_ready = (g.Pr * g.Pc == 1) && !H->env.trsm_panels && !H->z;
+    H->dinv_ready = true; H->inv_ready = !H->env.trsm_panels && !H->z;
     if (H->profile && H->env.profile_dump && H->schur_rec.size() == H->ev_schur_used)
         for (size_t i = 0; i < H->ev_schur_used; ++i) {
             float ems = 0; hipEventElapsedTime(&ems, H->ev_schur[i].first, H->ev_schur[i].second);

@@ -26,11 +26,16 @@ static void dag_levels(const SlotInput &in, const std::vector<int> &list, int ns
 }
 
 // ---- block tables, tile lists, flop tallies (host images of DevTables) ---------------------------------------------
+// XY layers run the panel solves in their GEMM form too: the row / column peers of a diagonal block compute its full inverses
+// from the block they receive (SLUAMD_TRSM_PANELS=1: the blocked substitution of round 1)
+static bool xy_gemm_panels(const Handle &H) { return H.grid.Pr * H.grid.Pc > 1 && !H.env.trsm_panels && !H.z; }
+
 static int build_tables(Handle &H, HostTables &t)
 {
     const HostStruct &hs = H.hs;
     const Grid &g = H.grid;
     const int ns = hs.nsupers;
+    const bool xy_gemm = xy_gemm_panels(H);
     t.sn_lval.resize(ns); t.sn_uval.resize(ns); t.sn_lidx.resize(ns); t.sn_uidx.resize(ns); t.sn_dinv.assign(ns, 0); t.sn_dptr.assign(ns, 0); t.sn_inv.assign(ns, 0);
     t.sn_nsupr.assign(ns, 0); t.sn_flags.assign(ns, 0); t.sn_ldiag.assign(ns, 0); t.sn_dlda.assign(ns, 1); t.sn_ldu.assign(ns, 0); t.sn_ncolu.assign(ns, 0);
     t.sn_lb_off.resize(ns); t.sn_nlb.assign(ns, 0); t.sn_ub_off.resize(ns); t.sn_nub.assign(ns, 0);
@@ -61,7 +66,8 @@ static int build_tables(Handle &H, HostTables &t)
         if (l_own || u_own) fl |= SNF_HAS_DIAG;
         t.sn_flags[k] = fl;
         if (fl & SNF_HAS_DIAG) t.dinv_total += (int64_t) 2 * ((nsupc + 31) / 32) * 32 * 32;
-        if (fl & SNF_OWN_DIAG) t.inv_total += (int64_t) 2 * nsupc * nsupc;
+        if (fl & (xy_gemm ? SNF_HAS_DIAG : SNF_OWN_DIAG)) t.inv_total += (int64_t) 2 * nsupc * nsupc;   // Linv / Uinv: the diagonal owner (solve, panel solves); on an XY
+                                                                                                  // layer also the row / column peers (GEMM-form panel solves with the block they receive)
         const int *li = hs.lidx.data() + hs.lidx_off[k];      // always >= BC_HEADER ints (empty slots carry {0, 0})
         const int nb = li[0], nsupr = li[1];
         t.sn_nsupr[k] = nsupr;
@@ -300,6 +306,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
 {
     const HostStruct &hs = H.hs;
     const int ns = hs.nsupers;
+    const bool xy_gemm = xy_gemm_panels(H);
     S.nlevels = nlevels;
     S.lvl_off.assign(S.nlevels + 1, 0);
     for (int k : list) S.lvl_off[lvl[k] + 1]++;
@@ -343,7 +350,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 63) / 64;
             S.zfwd_prefix[po + 1] = S.zfwd_prefix[po] + (lrows + 255) / 256;
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
-            S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & SNF_OWN_DIAG) ? 2 * ((nsupc + 15) / 16) : 0);    // FIS = 16-row identity strips
+            S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & (xy_gemm ? SNF_HAS_DIAG : SNF_OWN_DIAG)) ? 2 * ((nsupc + 15) / 16) : 0);    // FIS = 16-row identity strips
         }
     }
     // solve units as explicit lists, per level [urgent | bulk]: a strip of L(:,k) is urgent when one of its rows belongs to a supernode
