@@ -142,6 +142,9 @@ def test_reference_supernodes_up_to_512_columns(grid, tmp_path):
     assert info_amd == info_ref == 0
     assert res_amd < 1e-10 and res_ref < 1e-10
     assert abs(res_amd - res_ref) < 1e-10
+    if grid in ((2, 1, 1), (2, 2, 2)):   # the refined factors gathered back into the caller's 512-wide panels: the reference's own solves use them
+        res_fac, info_fac = _run(AMD, args, tmp_path, threads="1", nproc=nproc, extra_env=dict(env, SLUAMD_BIND_SOLVE="0"))
+        assert info_fac == 0 and res_fac < 1e-10 and abs(res_fac - res_ref) < 1e-10
 
 
 @pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF)), reason="prebuilt reference binaries not shipped")
