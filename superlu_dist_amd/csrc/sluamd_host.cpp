@@ -160,7 +160,7 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
     // received index arrays alike) by the same rule, so senders and receivers of a panel agree on the refined layout
     const bool xy = H.grid.Pr * H.grid.Pc > 1;
     const Grid g0 = H.grid;                    // ownership of the caller's (unrefined) supernodes
-    if (H.z) { set_error("complex16: supernodes wider than 256 columns are not supported"); return SLUAMD_EINVAL; }
+    // complex16: the pieces are ordinary supernodes to the complex kernels (values move as 16-byte elements)
     SplitMap &M = H.split;
     M.active = true; M.oxsup = ox; M.first.assign(nso + 1, 0); M.owner.clear();
     std::vector<int> nx(1, 0);                 // internal xsup

@@ -207,19 +207,18 @@ def check_wide_supernodes(N, maxsup, Pz, orc, shuffle=False):
     symb.free()
 
 
-def check_own_pipeline_complex16(Pz):
+def check_own_pipeline_complex16(Pz, N=12, leaf=27, relax=16, maxsup=64):
     """complex16 through the library's own symbolic factorisation + device-side distribution on a 1 x 1 x Pz grid: residual on the
     original system and agreement with the single-rank solution."""
-    N = 12
     n, rp, ci, v = matgen.poisson3d(N)
     v = matgen.complex_shift(v, rp, ci, seed=2)
-    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
     rng = np.random.default_rng(3)
     xt = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
     b = np.zeros_like(xt)
     for i in range(n):
         b[i, :] = v[rp[i]:rp[i + 1]] @ xt[ci[rp[i]:rp[i + 1]], :]
-    symb = driver.Symbolic(n, rp, ci, perm, relax=16, maxsup=64)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
     xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
     h1 = driver.LUHandle.from_symbolic(symb, v)
     assert h1.pzgstrf3d(0.0) == 0

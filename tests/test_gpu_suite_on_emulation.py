@@ -39,3 +39,35 @@ def test_reference_drop_in_against_the_emulation_library():
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1]
+
+
+@pytest.mark.parametrize("npdep", [1, 2])
+def test_complex16_reference_pipeline_with_512_column_supernodes_on_the_emulation(npdep, tmp_path):
+    """pzgssvx3d of the real reference with SUPERLU_MAXSUP=512 (widest supernode ~400 columns), pzgstrf3d bound to the emulation
+    library: residual parity with the untouched reference.  (CPU only: the complex refinement has not been run on the device yet.)"""
+    import re
+    import numpy as np
+    from superlu_dist_amd import matgen
+    zamd, zref = (os.path.join(ROOT, "oracle", "_ref", b) for b in ("slu_ref_zamd", "slu_ref_zdump"))
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(zamd) and os.path.exists(zref) and os.path.exists(mpiexec)):
+        pytest.skip("prebuilt reference binaries / mpiexec not present")
+    N = 20
+    n, rp, ci, v = matgen.poisson3d(N)
+    v = matgen.complex_shift(v, rp, ci, seed=4)
+    np.savetxt(tmp_path / "a.perm", matgen.nd_perm_grid3d(N, N, N, leaf=64), fmt="%d")
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    env = dict(os.environ, SLUAMD_LIB=os.path.join(ROOT, "oracle", "libsluamd_emul.so"), SUPERLU_MAXSUP="512", SUPERLU_RELAX="64",
+               OMP_NUM_THREADS="1", SLUAMD_BIND_DEBUG="1")
+    env.pop("LD_LIBRARY_PATH", None); env.pop("SLUAMD_EMUL_SCHED", None)
+    res = {}
+    for name, binary in (("amd", zamd), ("ref", zref)):
+        r = subprocess.run([mpiexec, "-n", str(npdep), binary, "-r", "1", "-c", "1", "-d", str(npdep), "-Q", "1", "-o", "none", "-e", "0", "-p", "0",
+                            "-P", str(tmp_path / "a.perm"), str(tmp_path / "a.dat")], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        m = re.search(r"RESIDUAL (\S+) INFO (\d+)", r.stdout)
+        assert m and int(m.group(2)) == 0, r.stdout[-1500:]
+        res[name] = float(m.group(1))
+        if name == "amd":
+            assert max(int(w) for w in re.findall(r"widest_supernode (\d+)", r.stderr)) > 256
+    assert res["amd"] < 1e-10 and abs(res["amd"] - res["ref"]) < 1e-10

@@ -42,6 +42,14 @@ def test_own_pipeline_complex16_on_z_layers(emul, Pz):
     grid_cases.check_own_pipeline_complex16(Pz)
 
 
+@pytest.mark.parametrize("Pz", [1, 2])
+def test_own_pipeline_complex16_with_supernodes_up_to_512_columns(emul, Pz):
+    """complex16 supernodes of 257..512 columns: refined like the double ones (the pieces are ordinary supernodes to the complex
+    kernels).  Checked on the emulation engine and, below the C ABI, through the reference's pzgssvx3d on CPU
+    (test_gpu_suite_on_emulation.py); no run on the device was made in round 2."""
+    grid_cases.check_own_pipeline_complex16(Pz, N=18, leaf=64, relax=64, maxsup=512)
+
+
 @pytest.mark.parametrize("N,grid,nrhs,unsym", [(8, (1, 1, 2), 1, False), (8, (2, 2, 1), 2, True), (10, (2, 2, 2), 1, True),
                                                 (8, (1, 2, 4), 1, False), (8, (3, 2, 1), 1, True), (8, (1, 1, 8), 3, False)])
 def test_own_pipeline_on_grids(emul, N, grid, nrhs, unsym):
