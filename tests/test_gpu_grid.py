@@ -88,3 +88,10 @@ def test_own_pipeline_complex16_on_z_layers(Pz):
     """complex16 through the library's own symbolic factorisation + device-side distribution on a 1 x 1 x Pz grid: residual on the
     original system and agreement with the single-rank solution."""
     grid_cases.check_own_pipeline_complex16(Pz)
+
+
+@pytest.mark.parametrize("Pz", [1, 2])
+def test_own_pipeline_complex16_with_supernodes_up_to_512_columns(Pz):
+    """complex16 supernodes of 257..512 columns (468 here): refined like the double ones; the pieces are ordinary supernodes to the
+    complex kernels."""
+    grid_cases.check_own_pipeline_complex16(Pz, N=18, leaf=64, relax=64, maxsup=512)

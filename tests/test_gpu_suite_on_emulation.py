@@ -44,7 +44,7 @@ def test_reference_drop_in_against_the_emulation_library():
 @pytest.mark.parametrize("npdep", [1, 2])
 def test_complex16_reference_pipeline_with_512_column_supernodes_on_the_emulation(npdep, tmp_path):
     """pzgssvx3d of the real reference with SUPERLU_MAXSUP=512 (widest supernode ~400 columns), pzgstrf3d bound to the emulation
-    library: residual parity with the untouched reference.  (CPU only: the complex refinement has not been run on the device yet.)"""
+    library: residual parity with the untouched reference.  (The device twin of the refinement itself: test_gpu_grid.py.)"""
     import re
     import numpy as np
     from superlu_dist_amd import matgen

@@ -45,8 +45,8 @@ def test_own_pipeline_complex16_on_z_layers(emul, Pz):
 @pytest.mark.parametrize("Pz", [1, 2])
 def test_own_pipeline_complex16_with_supernodes_up_to_512_columns(emul, Pz):
     """complex16 supernodes of 257..512 columns: refined like the double ones (the pieces are ordinary supernodes to the complex
-    kernels).  Checked on the emulation engine and, below the C ABI, through the reference's pzgssvx3d on CPU
-    (test_gpu_suite_on_emulation.py); no run on the device was made in round 2."""
+    kernels).  CPU twin of the test in test_gpu_grid.py; the reference's pzgssvx3d with SUPERLU_MAXSUP=512 runs against this engine in
+    test_gpu_suite_on_emulation.py."""
     grid_cases.check_own_pipeline_complex16(Pz, N=18, leaf=64, relax=64, maxsup=512)
 
 
