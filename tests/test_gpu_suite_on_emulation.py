@@ -71,3 +71,39 @@ def test_complex16_reference_pipeline_with_512_column_supernodes_on_the_emulatio
         if name == "amd":
             assert max(int(w) for w in re.findall(r"widest_supernode (\d+)", r.stderr)) > 256
     assert res["amd"] < 1e-10 and abs(res["amd"] - res["ref"]) < 1e-10
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLUAMD_FUZZ_CASES", "12"))))
+def test_reference_pipeline_fuzz_on_the_emulation(seed, tmp_path):
+    """Fuzz of the drop-in boundary on CPU: random irregular matrices through the REAL reference (defaults: equilibration, MC64, MMD,
+    its symbfact and 3D partition) on a random process grid with random SUPERLU_MAXSUP / SUPERLU_RELAX, pdgstrf3d + pdgstrs3d bound
+    to the emulation library over the binding's MPI transport; residual parity with the untouched reference."""
+    import re
+    import numpy as np
+    from superlu_dist_amd import matgen
+    amd, ref = (os.path.join(ROOT, "oracle", "_ref", b) for b in ("slu_ref_amd", "slu_ref_dump"))
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(amd) and os.path.exists(ref) and os.path.exists(mpiexec)):
+        pytest.skip("prebuilt reference binaries / mpiexec not present")
+    rng = np.random.default_rng(500 + seed)
+    if rng.integers(0, 2):
+        n, rp, ci, v = matgen.random_unsym(int(rng.integers(150, 700)), float(rng.uniform(0.008, 0.04)), seed=seed)
+    else:
+        n, rp, ci, v = matgen.stencil3d_unsym(int(rng.integers(7, 13)), drop=float(rng.uniform(0.1, 0.5)), seed=seed)
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    r, c, d = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 1, 2), (2, 2, 2), (1, 1, 4), (3, 1, 1)][int(rng.integers(0, 8))]
+    env = dict(os.environ, SLUAMD_LIB=os.path.join(ROOT, "oracle", "libsluamd_emul.so"), OMP_NUM_THREADS="1",
+               SUPERLU_MAXSUP=str(int(rng.choice([16, 64, 256, 512]))), SUPERLU_RELAX=str(int(rng.choice([4, 20, 60]))))
+    env.pop("LD_LIBRARY_PATH", None); env.pop("SLUAMD_EMUL_SCHED", None)
+    if rng.integers(0, 2):
+        env["SLUAMD_EMUL_SCHED"] = "%d,%d" % (int(rng.integers(1, 4)), int(rng.integers(1, 100)))
+    refine = ["-i", "0"] if rng.integers(0, 2) else []
+    res = {}
+    for name, binary in (("amd", amd), ("ref", ref)):
+        cmd = [mpiexec, "-n", str(r * c * d), binary, "-r", str(r), "-c", str(c), "-d", str(d), "-Q", "1", "-o", "none"] + refine + [str(tmp_path / "a.dat")]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+        assert out.returncode == 0, (cmd, out.stdout[-1500:] + out.stderr[-1500:])
+        m = re.search(r"RESIDUAL (\S+) INFO (\d+)", out.stdout)
+        assert m and int(m.group(2)) == 0, out.stdout[-1500:]
+        res[name] = float(m.group(1))
+    assert res["amd"] < 1e-10 and abs(res["amd"] - res["ref"]) < 1e-10, (res, (r, c, d), env["SUPERLU_MAXSUP"], env["SUPERLU_RELAX"])
