@@ -28,7 +28,9 @@ extern "C" {
 #endif
 
 /* reference int_t (superlu_defs.h:121-129): 32-bit in the default build, 64-bit with _LONGINT.
- * This library is built for the default 32-bit int_t; value offsets are 64-bit internally. */
+ * The ABI carries 32-bit indices (one rank's panels are far below 2^31 rows / columns); value offsets are 64-bit internally.
+ * An application built with 64-bit int_t passes narrowed copies of its index arrays -- oracle/ref/sluamd_binding.c does it under
+ * #if defined(_LONGINT), range-checked; the value arrays are used in place. */
 typedef int32_t sluamd_int_t;
 
 #define SLUAMD_OK 0

@@ -54,6 +54,30 @@
 #endif
 #include "superlu_dist_amd.h"
 
+/* The library's ABI carries 32-bit indices (sluamd_int_t).  An application built with 64-bit int_t (XSDK_INDEX_SIZE=64 / _LONGINT,
+ * superlu_defs.h:121-129) hands over narrowed copies of its index arrays -- the values are never copied -- and every index must fit
+ * (checked): one rank's panels are far below 2^31 rows and columns, what needs 64 bits in such builds are global counts. */
+#if defined(_LONGINT)
+static void *narrowed[1 << 16]; static int n_narrowed = 0;
+static sluamd_int_t *sluamd_narrow(const int_t *src, size_t n)
+{
+    if (!src) return NULL;
+    sluamd_int_t *d = (sluamd_int_t *) malloc(sizeof(sluamd_int_t) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) {
+        if (src[i] > INT_MAX || src[i] < INT_MIN) ABORT("sluamd binding: an index does not fit the library's 32-bit ABI");
+        d[i] = (sluamd_int_t) src[i];
+    }
+    if (n_narrowed == (int) (sizeof(narrowed) / sizeof(narrowed[0]))) ABORT("sluamd binding: too many index arrays");
+    narrowed[n_narrowed++] = d;
+    return d;
+}
+static void sluamd_narrow_release(void) { for (int i = 0; i < n_narrowed; ++i) free(narrowed[i]); n_narrowed = 0; }
+#define NARROW(p, n) sluamd_narrow((p), (size_t) (n))
+#else
+#define NARROW(p, n) (p)
+static void sluamd_narrow_release(void) {}
+#endif
+
 /* The library is C++/HIP; a C/MPI application binds it at run time (dlopen) so that the application's own
  * link line (here: conda's MPICH toolchain with an older libstdc++) does not have to resolve the HIP runtime.
  * A maintainer linking with the ROCm toolchain can call the sluamd_* functions directly instead. */
@@ -172,19 +196,35 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     const int myrow = MYROW(grid->iam, grid), mycol = MYCOL(grid->iam, grid), myz = grid3d->zscp.Iam;
 
     LUVIEW_T v;
-    v.n = n; v.nsupers = (int32_t) nsupers; v.xsup = Glu->xsup;
+    v.n = n; v.nsupers = (int32_t) nsupers; v.xsup = NARROW(Glu->xsup, nsupers + 1);
     v.nprow = Pr; v.npcol = Pc; v.npdep = Pz;
     v.myrow = myrow; v.mycol = mycol; v.myzlayer = myz;
-    v.Lrowind_bc_ptr = Llu->Lrowind_bc_ptr; v.Lnzval_bc_ptr = VALPP(Llu->Lnzval_bc_ptr);
-    v.Ufstnz_br_ptr = Llu->Ufstnz_br_ptr;   v.Unzval_br_ptr = VALPP(Llu->Unzval_br_ptr);
+    v.Lnzval_bc_ptr = VALPP(Llu->Lnzval_bc_ptr); v.Unzval_br_ptr = VALPP(Llu->Unzval_br_ptr);
+#if defined(_LONGINT)
+    {   /* index arrays of the local block columns / block rows: lengths from their headers (superlu_defs.h:156-198) */
+        const int_t nbc = CEILING(nsupers, Pc), nbr = CEILING(nsupers, Pr);
+        v.Lrowind_bc_ptr = (sluamd_int_t **) calloc(nbc ? nbc : 1, sizeof(sluamd_int_t *));
+        v.Ufstnz_br_ptr = (sluamd_int_t **) calloc(nbr ? nbr : 1, sizeof(sluamd_int_t *));
+        for (int_t lk = 0; lk < nbc; ++lk) {
+            const int_t *li = Llu->Lrowind_bc_ptr[lk];
+            if (li) v.Lrowind_bc_ptr[lk] = NARROW(li, BC_HEADER + li[0] * LB_DESCRIPTOR + li[1]);
+        }
+        for (int_t lb = 0; lb < nbr; ++lb) {
+            const int_t *ui = Llu->Ufstnz_br_ptr[lb];
+            if (ui) v.Ufstnz_br_ptr[lb] = NARROW(ui, ui[2]);
+        }
+    }
+#else
+    v.Lrowind_bc_ptr = Llu->Lrowind_bc_ptr; v.Ufstnz_br_ptr = Llu->Ufstnz_br_ptr;
+#endif
 
     /* elimination forests of this layer (dtrf3Dpartition_t, superlu_ddefs.h:317-337) */
     int maxLvl = log2i(grid3d->zscp.Np) + 1, nf = (1 << maxLvl) - 1;
     int32_t *nNodes = (int32_t *) calloc(nf, sizeof(int32_t));
     const sluamd_int_t **lists = (const sluamd_int_t **) calloc(nf, sizeof(*lists));
     for (int f = 0; f < nf; ++f)
-        if (trf3Dpartition->sForests[f]) { nNodes[f] = trf3Dpartition->sForests[f]->nNodes; lists[f] = trf3Dpartition->sForests[f]->nodeList; }
-    sluamd_forest_view_t fv = { maxLvl, trf3Dpartition->myTreeIdxs, trf3Dpartition->myZeroTrIdxs, nf, nNodes, lists };
+        if (trf3Dpartition->sForests[f]) { nNodes[f] = (int32_t) trf3Dpartition->sForests[f]->nNodes; lists[f] = NARROW(trf3Dpartition->sForests[f]->nodeList, nNodes[f]); }
+    sluamd_forest_view_t fv = { maxLvl, NARROW(trf3Dpartition->myTreeIdxs, maxLvl), NARROW(trf3Dpartition->myZeroTrIdxs, maxLvl), nf, nNodes, lists };
 
     sluamd_load();
     static int registered = 0;
@@ -233,6 +273,10 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     stat->ops[FACT] += (flops_t) (st.flops_schur_padded + st.flops_panel);   /* scuStatUpdate's tally     */
     stat->TinyPivots += st.tiny_pivots;
     free(nNodes); free(lists);
+#if defined(_LONGINT)
+    free(v.Lrowind_bc_ptr); free(v.Ufstnz_br_ptr);
+#endif
+    sluamd_narrow_release();
     (void) m; (void) SCT;
     return 0;
 }

@@ -186,3 +186,24 @@ def test_reference_complex_pipeline_on_two_z_layers(tmp_path):
     assert info_amd == info_ref == 0
     assert res_amd < 1e-10 and res_ref < 1e-10
     assert abs(res_amd - res_ref) < 1e-10
+
+
+AMD64 = os.path.join(ROOT, "oracle", "_ref64", "slu_ref_amd")
+REF64 = os.path.join(ROOT, "oracle", "_ref64", "slu_ref_dump")
+
+
+@pytest.mark.skipif(not (os.path.exists(AMD64) and os.path.exists(REF64) and os.path.exists(MPIEXEC)), reason="64-bit int_t reference binaries / mpiexec not available")
+@pytest.mark.parametrize("grid", [(1, 1, 1), (2, 1, 1), (2, 2, 2)])
+def test_reference_built_with_64bit_int_t(grid, tmp_path):
+    """The reference built with XSDK_INDEX_SIZE=64 (int_t = int64_t, superlu_defs.h:121-129): the binding hands the library narrowed
+    (32-bit, range-checked) copies of the index arrays, the value arrays are used in place; residual parity with the untouched 64-bit
+    reference on the same grid."""
+    n, rp, ci, v = matgen.stencil3d_unsym(16, drop=0.3, seed=3)
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    r, c, d = grid
+    args = ["-r", str(r), "-c", str(c), "-d", str(d), "-Q", "1", "-o", "none", str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(AMD64, args, tmp_path, threads="1", nproc=r * c * d)
+    res_ref, info_ref = _run(REF64, args, tmp_path, threads="1", nproc=r * c * d)
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10
