@@ -160,9 +160,11 @@ def main():
         # barrier.  Every exchange of the hot path is RCCL called directly by libsluamd.so (ncclSend / ncclRecv on its HIP
         # streams).  SLUAMD_DIST_BACKEND=gloo: debugging aid for boxes with fewer GPUs than ranks (ranks share devices, the
         # library's exchanges are staged through host memory over gloo); the measured configuration is always rccl.
+        ndev = torch.cuda.device_count()     # 0 only in the CPU test of this script (SLUAMD_LIB = the emulation library)
         if dist_backend != "rccl":
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
+            local_rank = local_rank % max(ndev, 1)
+        if ndev:
+            torch.cuda.set_device(local_rank)
         # gloo reports its connections ("[Gloo] Rank 0 is connected to ...") on stdout: keep stdout for the ONE JSON line
         sys.stdout.flush()
         saved_stdout = os.dup(1)

@@ -116,3 +116,23 @@ def test_reference_pipeline_fuzz_on_the_emulation(seed, tmp_path):
         assert m and int(m.group(2)) == 0, out.stdout[-1500:]
         res[name] = float(m.group(1))
     assert res["amd"] < 1e-10 and abs(res["amd"] - res["ref"]) < 1e-10, (res, (r, c, d), env["SUPERLU_MAXSUP"], env["SUPERLU_RELAX"])
+
+
+@pytest.mark.parametrize("ngpu", [1, 2, 8])
+def test_bench_script_flow_on_the_emulation(ngpu, tmp_path):
+    """bench.py end to end on CPU (emulation library; N > 1: torch.distributed.run, gloo-staged exchanges): ONE JSON line on stdout with
+    the contract's keys, the right grid for N ranks, a residual < 1e-10.  (No timing is asserted: nothing here measures the device.)"""
+    import json
+    env = dict(os.environ, SLUAMD_LIB=os.path.join(ROOT, "oracle", "libsluamd_emul.so"), SLUAMD_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("SLUAMD_EMUL_SCHED", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ngpu), "--grid-side", "12", "--steps", "2", "--warmup", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in j, key
+    assert j["n_gpus"] == ngpu and j["steps"] == 2 and j["value"] > 0 and j["residual"] < 1e-10
+    assert ("1x1x1" if ngpu == 1 else "1x1x2" if ngpu == 2 else "2x2x2") in j["config"]["workload"]
