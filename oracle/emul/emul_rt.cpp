@@ -14,12 +14,14 @@
 // transitively needs (other streams stay behind as long as possible), mode 3 runs every other runnable stream before the one
 // being waited for; the work units inside one launch (Schur tiles, update units) run in a shuffled order.  A missing event wait or a host read without synchronisation in the drivers (look-ahead schedule of
 // pdgstrf3d, panel exchanges, sweeps) becomes a wrong result under one of these orders -- tests/test_stream_order.py.
+#include <atomic>
 #include <cstdio>
 #include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <random>
+#include <thread>
 #include <vector>
 #include "sluamd_rt.h"
 
@@ -28,11 +30,13 @@ struct emul_op {
     emul_stream_s *wait_on = nullptr;
     unsigned long long wait_seq = 0;
     unsigned long long issue = 0;       // global issue index (statistics)
+    std::function<bool()> ready;        // optional: an EXTERNAL condition (a message of another rank's thread: comm_emul_stream.cpp)
 };
 struct emul_stream_s {
     std::deque<emul_op> q;
     unsigned long long issued = 0, done = 0;
     bool nonblocking = false;
+    int owner = 0;                      // the thread (= rank of an in-process grid) that created it: "the device" of that rank
 };
 struct emul_event_s {
     emul_stream_s *st = nullptr;        // stream of the last record (deferred modes)
@@ -42,8 +46,13 @@ struct emul_event_s {
 
 namespace {
 std::recursive_mutex g_mu;
-emul_stream_s g_null;
-std::vector<emul_stream_s *> g_streams{&g_null};   // streams are never freed: queued waits keep pointers to them
+std::vector<emul_stream_s *> g_streams;            // streams are never freed: queued waits keep pointers to them
+// Ranks of an in-process grid are threads; on a real node each rank has its own device, so "the device" a synchronising call waits
+// for (hipDeviceSynchronize, hipFree, the null stream) is the set of streams the CALLING thread created -- never another rank's
+std::atomic<int> g_next_tid{1};
+thread_local int t_tid = 0;
+thread_local emul_stream_s *t_null = nullptr;
+int my_tid() { if (!t_tid) t_tid = g_next_tid++; return t_tid; }
 std::map<const char *, size_t> g_pinned;
 int g_mode = 0;
 std::mt19937 g_rng(1);
@@ -60,7 +69,22 @@ struct EnvInit {
     }
 } g_env_init;
 
-bool runnable(const emul_op &o) { return !o.wait_on || o.wait_on->done >= o.wait_seq; }
+bool runnable(const emul_op &o) { return (!o.wait_on || o.wait_on->done >= o.wait_seq) && (!o.ready || o.ready()); }
+
+// every entry point holds g_mu through a Guard; a thread that has to wait for ANOTHER thread (a message, see `ready`) lets go of
+// all its recursion levels for a moment
+thread_local int t_depth = 0;
+struct Guard {
+    Guard() { g_mu.lock(); ++t_depth; }
+    ~Guard() { --t_depth; g_mu.unlock(); }
+};
+void yield_all()
+{
+    const int d = t_depth;
+    for (int i = 0; i < d; ++i) g_mu.unlock();
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+    for (int i = 0; i < d; ++i) g_mu.lock();
+}
 
 void step(emul_stream_s *st)
 {
@@ -78,14 +102,20 @@ void step(emul_stream_s *st)
 template <class Pred>
 void flush(emul_stream_s *target, Pred pred)
 {
+    long spins = 0;
     while (!pred()) {
         std::vector<emul_stream_s *> cand;
         bool pending = false;
         for (auto *st : g_streams)
             if (!st->q.empty()) { pending = true; if (runnable(st->q.front())) cand.push_back(st); }
         if (cand.empty()) {
-            if (pending) { std::fprintf(stderr, "emulated HIP runtime: streams wait for each other (deadlock)\n"); std::abort(); }
-            break;
+            if (!pending) break;
+            bool external = false;
+            for (auto *st : g_streams)
+                if (!st->q.empty() && st->q.front().ready && (!st->q.front().wait_on || st->q.front().wait_on->done >= st->q.front().wait_seq)) external = true;
+            if (!external || ++spins > 3000000) { std::fprintf(stderr, "emulated HIP runtime: streams wait for each other (deadlock)\n"); std::abort(); }
+            yield_all();      // another rank's thread has to publish / take a message first
+            continue;
         }
         emul_stream_s *pick = nullptr;
         if (g_mode == 2 && target) {          // only what the caller needs: follow the chain of unsatisfied waits
@@ -101,8 +131,9 @@ void flush(emul_stream_s *target, Pred pred)
         step(pick);
     }
 }
-bool all_empty() { for (auto *st : g_streams) if (!st->q.empty()) return false; return true; }
-bool blocking_empty() { for (auto *st : g_streams) if (!st->nonblocking && !st->q.empty()) return false; return true; }
+bool all_empty() { const int me = my_tid(); for (auto *st : g_streams) if (st->owner == me && !st->q.empty()) return false; return true; }
+bool everything_empty() { for (auto *st : g_streams) if (!st->q.empty()) return false; return true; }
+bool blocking_empty() { const int me = my_tid(); for (auto *st : g_streams) if (st->owner == me && !st->nonblocking && !st->q.empty()) return false; return true; }
 bool pinned(const void *p)
 {
     auto it = g_pinned.upper_bound((const char *) p);
@@ -112,42 +143,66 @@ bool pinned(const void *p)
 }
 hipStream_t new_stream(bool nonblocking)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     auto *s = new emul_stream_s();
     s->nonblocking = nonblocking;
+    s->owner = my_tid();
     g_streams.push_back(s);
     return s;
+}
+emul_stream_s *null_stream()      // the calling thread's legacy default stream (call with the lock held)
+{
+    if (!t_null) { t_null = new emul_stream_s(); t_null->owner = my_tid(); g_streams.push_back(t_null); }
+    return t_null;
 }
 }  // namespace
 
 void emul_enqueue(hipStream_t s, std::function<void()> f)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     if (g_mode == 0) { f(); return; }
-    emul_stream_s *st = s ? s : &g_null;
-    if (st == &g_null) flush(nullptr, blocking_empty);     // legacy null stream: after everything queued on the blocking streams
+    emul_stream_s *st = s ? s : null_stream();
+    if (st == t_null) flush(nullptr, blocking_empty);     // legacy null stream: after everything queued on the blocking streams
     emul_op o; o.f = std::move(f); o.issue = ++g_issue;
     st->q.push_back(std::move(o)); ++st->issued;
-    if (st == &g_null) flush(st, [&] { return st->q.empty(); });
+    if (st == t_null) flush(st, [&] { return st->q.empty(); });
 }
 
 unsigned emul_launch_seed()
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     return g_mode == 0 ? 0u : (unsigned) (g_rng() | 1u);
+}
+
+// an operation that may run only once ready() holds -- a condition another rank's thread establishes (message passing of the emulated
+// stream-ordered transport).  Immediate mode: the calling thread waits here, without the lock.
+void emul_enqueue_when(hipStream_t s, std::function<bool()> ready, std::function<void()> f)
+{
+    Guard lk;
+    if (g_mode == 0) {
+        long spins = 0;
+        while (!ready()) { if (++spins > 3000000) { std::fprintf(stderr, "emulated HIP runtime: message never arrived (deadlock)\n"); std::abort(); } yield_all(); }
+        f();
+        return;
+    }
+    emul_stream_s *st = s ? s : null_stream();
+    if (st == t_null) flush(nullptr, blocking_empty);
+    emul_op o; o.f = std::move(f); o.ready = std::move(ready); o.issue = ++g_issue;
+    st->q.push_back(std::move(o)); ++st->issued;
+    if (st == t_null) flush(st, [&] { return st->q.empty(); });
 }
 
 extern "C" void sluamd_emul_sched(int mode, unsigned seed)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    flush(nullptr, all_empty);
+    Guard lk;
+    flush(nullptr, everything_empty);
     g_mode = mode; g_rng.seed(seed ? seed : 1u);
     g_reordered = 0; g_run = 0; g_max_run = g_issue;
 }
 // operations run so far under the current schedule / how many of them ran after an operation issued later
 extern "C" void sluamd_emul_sched_stats(unsigned long long *run, unsigned long long *reordered)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     *run = g_run; *reordered = g_reordered;
 }
 
@@ -155,7 +210,7 @@ hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *
 hipError_t hipFree(void *p) { hipDeviceSynchronize(); std::free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     *p = std::malloc(n ? n : 1);
     if (!*p) return hipErrorOutOfMemory;
     g_pinned[(const char *) *p] = n ? n : 1;
@@ -164,28 +219,28 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned)
 hipError_t hipHostFree(void *p)
 {
     hipDeviceSynchronize();
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     g_pinned.erase((const char *) p);
     std::free(p);
     return hipSuccess;
 }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     flush(nullptr, blocking_empty);
     if (n) std::memmove(d, s, n);
     return hipSuccess;
 }
 hipError_t hipMemset(void *d, int v, size_t n)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     flush(nullptr, blocking_empty);
     if (n) std::memset(d, v, n);
     return hipSuccess;
 }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     if (g_mode == 0 || !n) { if (n) std::memmove(d, s, n); return hipSuccess; }
     if ((k == hipMemcpyHostToDevice && !pinned(s)) || k == hipMemcpyHostToHost) {
         if (k == hipMemcpyHostToHost) { hipStreamSynchronize(st); std::memmove(d, s, n); return hipSuccess; }
@@ -207,17 +262,17 @@ hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, unsigned, const unsigned
 hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int) { *s = new_stream((flags & hipStreamNonBlocking) != 0); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    emul_stream_s *st = s ? s : &g_null;
-    if (st == &g_null) flush(nullptr, blocking_empty);
+    Guard lk;
+    emul_stream_s *st = s ? s : null_stream();
+    if (st == t_null) flush(nullptr, blocking_empty);
     else flush(st, [&] { return st->q.empty(); });
     return hipSuccess;
 }
 hipError_t hipStreamDestroy(hipStream_t s) { return hipStreamSynchronize(s); }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    emul_stream_s *st = s ? s : &g_null;
+    Guard lk;
+    emul_stream_s *st = s ? s : null_stream();
     if (g_mode == 0 || !e->st || e->st == st || e->st->done >= e->seq) return hipSuccess;   // never recorded / same stream / already complete
     emul_op o; o.wait_on = e->st; o.wait_seq = e->seq;
     st->q.push_back(std::move(o)); ++st->issued;
@@ -226,17 +281,17 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new emul_event_s(); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     auto tp = e->t;
     if (g_mode == 0) { *tp = std::chrono::steady_clock::now(); e->st = nullptr; return hipSuccess; }
-    emul_stream_s *st = s ? s : &g_null;
+    emul_stream_s *st = s ? s : null_stream();
     emul_enqueue(st, [tp] { *tp = std::chrono::steady_clock::now(); });
     e->st = st; e->seq = st->issued;
     return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t e)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     if (e->st) flush(e->st, [&] { return e->st->done >= e->seq; });
     return hipSuccess;
 }
@@ -249,7 +304,7 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipDeviceSynchronize()
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    Guard lk;
     flush(nullptr, all_empty);
     return hipSuccess;
 }

@@ -28,6 +28,8 @@ inline int4 make_int4(int x, int y, int z, int w) { int4 v = {x, y, z, w}; retur
 
 // a "kernel launch" of the CPU engine: runs now (immediate mode) or when the scheduler gets to it
 void emul_enqueue(hipStream_t s, std::function<void()> f);
+// ... that may run only once ready() holds (a condition established by another rank's thread: the emulated stream-ordered transport)
+void emul_enqueue_when(hipStream_t s, std::function<bool()> ready, std::function<void()> f);
 // adversarial modes: a permutation seed for the work units INSIDE one launch (0 in immediate mode = issue order)
 unsigned emul_launch_seed();
 

@@ -64,7 +64,7 @@ def check_fixture_grid(g):
             assert np.array_equal(a, b)
 
 
-def check_own_pipeline(N, grid, nrhs=1, leaf=27, relax=16, maxsup=64, unsym=False, refactor=False):
+def check_own_pipeline(N, grid, nrhs=1, leaf=27, relax=16, maxsup=64, unsym=False, refactor=False, make_comms=None):
     """Library's own symbolic factorisation + device-side distribution on a Pr x Pc x Pz grid: residual on the original
     system < 1e-10 and the solution equal (1e-10) to the single-rank one."""
     n, rp, ci, v = matgen.poisson3d(N)
@@ -73,10 +73,28 @@ def check_own_pipeline(N, grid, nrhs=1, leaf=27, relax=16, maxsup=64, unsym=Fals
         v = v * (1.0 + 0.3 * rng.random(v.size))
         v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
     perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
-    check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=nrhs, relax=relax, maxsup=maxsup, refactor=refactor)
+    check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=nrhs, relax=relax, maxsup=maxsup, refactor=refactor, make_comms=make_comms)
 
 
-def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False):
+def stream_ordered_comms(Pr, Pc, Pz):
+    """Emulation library only: one communicator per rank of the in-process STREAM-ORDERED transport that stands behind
+    sluamd_comm_create_rccl in the CPU test build (oracle/emul/comm_norccl.cpp: RCCL's contract -- end(s) only queues -- for
+    ranks that are threads)."""
+    import ctypes as C
+    from superlu_dist_amd import _lib
+    L = _lib.load()
+    idbuf = (C.c_char * 128)()
+    _lib.check(L.sluamd_comm_rccl_unique_id(idbuf), "sluamd_comm_rccl_unique_id")
+    out = []
+    for rank in range(Pr * Pc * Pz):
+        r, c, z = grid3d.grid_coords(rank, Pr, Pc, Pz)
+        h = C.c_void_p()
+        _lib.check(L.sluamd_comm_create_rccl(C.byref(h), idbuf, Pr, Pc, Pz, r, c, z, -1), "sluamd_comm_create_rccl")
+        out.append(h)
+    return out
+
+
+def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False, make_comms=None):
     """Any CSR matrix (unpivoted LU must be stable for it) through the own pipeline on a Pr x Pc x Pz grid."""
     Pr, Pc, Pz = grid
     P = Pr * Pc * Pz
@@ -85,7 +103,7 @@ def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, 
     assert info1 == 0
     symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
     sn_tree = symb.partition(Pz) if Pz > 1 else None
-    comms = grid3d.local_comms(Pr, Pc, Pz)
+    comms = (make_comms or grid3d.local_comms)(Pr, Pc, Pz)
     xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
 
     def rank_body(rank):

@@ -88,6 +88,18 @@ def test_reference_fixtures_under_the_scheduler(sched_env):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
 
 
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 1, 2), (1, 1, 4), (2, 2, 2), (3, 2, 1)])
+@pytest.mark.parametrize("mode,seed", [(0, 1), (1, 3), (2, 1), (3, 8)])
+def test_grid_drivers_over_the_stream_ordered_transport(sched, grid, mode, seed):
+    """The drivers the way they run over RCCL: the transport behind sluamd_comm_create_rccl in the CPU build only QUEUES an exchange on
+    the stream and returns (oracle/emul/comm_norccl.cpp), so the host runs ahead of the device through the whole factorisation and solve
+    and nothing but stream order and events protects the exchange staging buffer, the scratch copies of received panels and the
+    ancestor reduction.  (LocalComm / the callbacks synchronise the stream at every exchange.)"""
+    _sched(sched, mode, seed)
+    grid_cases.check_own_pipeline(8, grid, nrhs=2, unsym=True, refactor=(grid == (2, 2, 2)), make_comms=grid_cases.stream_ordered_comms)
+    _sched(sched, 0)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SLUAMD_FUZZ_CASES", "48"))))
 def test_random_structures_grids_and_schedules(sched, seed):
     """Fuzz: random unsymmetric matrices (irregular supernodes, ragged skylines), random supernode limits, grid shapes, numbers of
@@ -99,7 +111,8 @@ def test_random_structures_grids_and_schedules(sched, seed):
     relax = int(rng.choice([1, 4, 16, 64])); maxsup = int(rng.choice([4, 16, 48, 256]))
     _sched(sched, int(rng.integers(1, 4)), int(rng.integers(1, 1000)))
     grid_cases.check_matrix_on_grid(n, rp, ci, v, None, grid, nrhs=int(rng.integers(1, 4)), relax=relax, maxsup=maxsup,
-                                    refactor=bool(rng.integers(0, 2)))
+                                    refactor=bool(rng.integers(0, 2)),
+                                    make_comms=grid_cases.stream_ordered_comms if rng.integers(0, 2) else None)
     _sched(sched, 0)
 
 
@@ -112,5 +125,6 @@ def test_random_wide_supernodes_grids_and_schedules(sched, seed):
     n, rp, ci, v = matgen.random_unsym(n, float(rng.uniform(0.5, 0.95)), seed=100 + seed)
     grid = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 1, 2), (2, 2, 2), (3, 2, 1)][int(rng.integers(0, 7))]
     _sched(sched, int(rng.integers(1, 4)), int(rng.integers(1, 1000)))
-    grid_cases.check_matrix_on_grid(n, rp, ci, v, None, grid, nrhs=2, relax=512, maxsup=512)
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, None, grid, nrhs=2, relax=512, maxsup=512,
+                                    make_comms=grid_cases.stream_ordered_comms if seed % 2 else None)
     _sched(sched, 0)
