@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unistd.h>
 #include "sluamd_comm.h"
 
 namespace sluamd {
@@ -87,6 +88,8 @@ int rccl_unique_id(void *id128)
     const unsigned id = g_next_id++;
     std::memcpy(id128, "emul-stream-world", 17);
     std::memcpy(static_cast<char *>(id128) + 32, &id, sizeof(id));
+    const long pid = (long) getpid();                  // the world lives in THIS process: ranks are its threads
+    std::memcpy(static_cast<char *>(id128) + 48, &pid, sizeof(pid));
     return 0;
 }
 
@@ -94,6 +97,9 @@ Comm *make_rccl_comm(const void *id128, const Grid &g, int)
 {
     const std::string key(static_cast<const char *>(id128), SLUAMD_UNIQUE_ID_BYTES);
     if (key.compare(0, 17, "emul-stream-world") != 0) { set_error("the CPU test build has no RCCL transport (unknown unique id)"); return nullptr; }
+    long pid = 0;
+    std::memcpy(&pid, static_cast<const char *>(id128) + 48, sizeof(pid));
+    if (pid != (long) getpid()) { set_error("the CPU test build has no RCCL transport: its stream-ordered stand-in connects threads of ONE process"); return nullptr; }
     auto *c = new EmulStreamComm();
     c->grid = g;
     c->me = g.rank();
