@@ -254,6 +254,10 @@ int sluamd_comm_create_callbacks(sluamd_comm_t *comm, const sluamd_comm_callback
 
 /* In-process world: comms[nprow*npcol*npdep] (indexed by world rank), one per thread; any number of ranks per device. */
 int sluamd_comm_create_local(sluamd_comm_t *comms, int nprow, int npcol, int npdep);
+/* Transport self-test (collective): ring exchange of `bytes` bytes as one stream-ordered group between device fills, the
+ * host-buffer group and the min-all-reduce -- every operation the drivers use of a transport; 0 when all data arrived intact.
+ * On a one-rank communicator every message goes to the rank itself. */
+int sluamd_comm_selftest(sluamd_comm_t comm, int64_t bytes);
 int sluamd_comm_rank(sluamd_comm_t comm);
 int sluamd_comm_size(sluamd_comm_t comm);
 void sluamd_comm_destroy(sluamd_comm_t comm);

@@ -22,7 +22,8 @@ struct SWorld {
     int size = 0;
     std::vector<std::deque<std::shared_ptr<SMsg>>> box;   // [src * size + dst]; touched only by stream operations (under the runtime's lock)
     std::mutex mu; std::condition_variable cv;            // min-all-reduce (host side)
-    int red_count = 0, red_gen = 0, red_val = 0, red_out = 0;
+    int red_count = 0, red_gen = 0;
+    std::vector<int> red_val, red_out;
 };
 std::mutex g_worlds_mu;
 std::map<std::string, std::shared_ptr<SWorld>> g_worlds;
@@ -68,15 +69,16 @@ struct EmulStreamComm : Comm {
         ops.clear();
         return 0;
     }
-    int allreduce_min(int *v) override
+    int allreduce_min(int *v, int n, hipStream_t s) override
     {
-        HIPCHK(hipStreamSynchronize(nullptr));
+        HIPCHK(hipStreamSynchronize(s));     // RcclComm: the collective runs on s and the host waits for s alone
         std::unique_lock<std::mutex> lk(w->mu);
         const int gen = w->red_gen;
-        if (w->red_count == 0) w->red_val = *v; else w->red_val = std::min(w->red_val, *v);
+        if (w->red_count == 0) w->red_val.assign(v, v + n);
+        else for (int i = 0; i < n; ++i) w->red_val[i] = std::min(w->red_val[i], v[i]);
         if (++w->red_count == w->size) { w->red_out = w->red_val; w->red_count = 0; ++w->red_gen; w->cv.notify_all(); }
         else w->cv.wait(lk, [&] { return w->red_gen != gen; });
-        *v = w->red_out;
+        for (int i = 0; i < n; ++i) v[i] = w->red_out[i];
         return 0;
     }
 };

@@ -47,7 +47,7 @@ EXPORTS = [
     "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
     "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",
     "sluamd_comm_rccl_unique_id", "sluamd_comm_create_rccl", "sluamd_comm_create_callbacks", "sluamd_comm_create_local",
-    "sluamd_comm_rank", "sluamd_comm_size", "sluamd_comm_destroy", "sluamd_dCreateLUHandleGrid",
+    "sluamd_comm_selftest", "sluamd_comm_rank", "sluamd_comm_size", "sluamd_comm_destroy", "sluamd_dCreateLUHandleGrid",
     "sluamd_dCreateLUHandleFromSymbGrid", "sluamd_zCreateLUHandleGrid", "sluamd_zCreateLUHandleFromSymbGrid",
 ]
 
@@ -114,6 +114,7 @@ def bind(L):
     L.sluamd_comm_create_rccl.argtypes = [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 7
     L.sluamd_comm_create_callbacks.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CommCallbacks)] + [C.c_int] * 6
     L.sluamd_comm_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+    L.sluamd_comm_selftest.argtypes = [C.c_void_p, C.c_int64]
     L.sluamd_comm_rank.argtypes = [C.c_void_p]
     L.sluamd_comm_size.argtypes = [C.c_void_p]
     L.sluamd_comm_destroy.argtypes = [C.c_void_p]

@@ -28,7 +28,12 @@ struct Comm {
     virtual int send(const void *dbuf, int64_t bytes, int dst) = 0;
     virtual int recv(void *dbuf, int64_t bytes, int src) = 0;
     virtual int end(hipStream_t s) = 0;
-    virtual int allreduce_min(int *v) = 0;           // over the whole grid, host value
+    // element-wise minimum of v[0..n) over the whole grid, host values in and out.  Ordered behind everything queued on
+    // stream s and complete on return (RcclComm runs the collective ON s: no null-stream work, no device-wide wait)
+    virtual int allreduce_min(int *v, int n, hipStream_t s) = 0;
+    // error on one rank: release the peers that wait for it (in-process transports), so that a failure surfaces as an error
+    // code everywhere instead of a hang
+    virtual void poison() {}
     virtual bool stream_ordered() const { return false; }
     // grouped point-to-point on HOST buffers (creation-time structure exchange); default: staged through device memory
     virtual int hbegin();
@@ -39,6 +44,7 @@ struct Comm {
 protected:
     struct HOp { void *h; void *d; int64_t bytes; bool is_recv; };
     std::vector<HOp> hops_;
+    void hfree_();   // release the device staging of a (possibly failed) host-buffer group
 };
 
 // ---- application-supplied transport ----
@@ -52,7 +58,7 @@ struct CallbackComm : Comm {
     int send(const void *dbuf, int64_t bytes, int dst) override;
     int recv(void *dbuf, int64_t bytes, int src) override;
     int end(hipStream_t s) override;
-    int allreduce_min(int *v) override;
+    int allreduce_min(int *v, int n, hipStream_t s) override;
     int hbegin() override { return 0; }
     int hsend(const void *buf, int64_t bytes, int dst) override;
     int hrecv(void *buf, int64_t bytes, int src) override;
@@ -67,7 +73,9 @@ struct LocalWorld {
     struct Msg { const void *ptr; int64_t bytes; bool host; bool taken = false; };
     std::vector<std::deque<std::shared_ptr<Msg>>> box;   // [src * size + dst]
     // min-all-reduce
-    int red_count = 0, red_gen = 0, red_val = 0, red_out = 0;
+    int red_count = 0, red_gen = 0;
+    std::vector<int> red_val, red_out;
+    bool poisoned = false;   // a rank failed inside an exchange: every waiter returns SLUAMD_EINVAL
 };
 struct LocalComm : Comm {
     std::shared_ptr<LocalWorld> w;
@@ -78,7 +86,8 @@ struct LocalComm : Comm {
     int send(const void *dbuf, int64_t bytes, int dst) override;
     int recv(void *dbuf, int64_t bytes, int src) override;
     int end(hipStream_t s) override;
-    int allreduce_min(int *v) override;
+    int allreduce_min(int *v, int n, hipStream_t s) override;
+    void poison() override;
     int hbegin() override { return 0; }
     int hsend(const void *buf, int64_t bytes, int dst) override;
     int hrecv(void *buf, int64_t bytes, int src) override;

@@ -20,12 +20,14 @@ namespace sluamd {
 struct RcclComm : Comm {
     ncclComm_t nc = nullptr;
     int device = 0;
-    int *d_red = nullptr;
+    static constexpr int RED_MAX = 16;
+    int *d_red = nullptr, *h_red = nullptr;   // device / pinned host image of the values of allreduce_min
     struct Op { void *d; int64_t bytes; int peer; bool is_recv; };
     std::vector<Op> ops;
     ~RcclComm() override
     {
         if (d_red) hipFree(d_red);
+        if (h_red) hipHostFree(h_red);
         if (nc) ncclCommDestroy(nc);
     }
     bool stream_ordered() const override { return true; }
@@ -34,26 +36,37 @@ struct RcclComm : Comm {
     int recv(void *dbuf, int64_t bytes, int src) override { ops.push_back({dbuf, bytes, src, true}); return 0; }
     int end(hipStream_t s) override
     {
+        struct Clear { std::vector<Op> &o; ~Clear() { o.clear(); } } clear_on_exit{ops};   // on every exit: no stale operations in the next group
         bool any = false;
         for (auto &o : ops) any |= o.bytes > 0;
-        if (!any) { ops.clear(); return 0; }
+        if (!any) return 0;
         NCCLCHK(ncclGroupStart());
+        // an error inside the group must still close it: a return between ncclGroupStart and ncclGroupEnd would leave this thread's
+        // group depth unbalanced and every later RCCL call silently deferred
+        ncclResult_t first = ncclSuccess;
+        const char *what = "";
         for (auto &o : ops) {
-            if (!o.bytes) continue;
+            if (!o.bytes || first != ncclSuccess) continue;
             // payloads are whole doubles except the creation-time index exchange: count in bytes
-            if (o.is_recv) NCCLCHK(ncclRecv(o.d, (size_t) o.bytes, ncclChar, o.peer, nc, s));
-            else NCCLCHK(ncclSend(o.d, (size_t) o.bytes, ncclChar, o.peer, nc, s));
+            first = o.is_recv ? ncclRecv(o.d, (size_t) o.bytes, ncclChar, o.peer, nc, s) : ncclSend(o.d, (size_t) o.bytes, ncclChar, o.peer, nc, s);
+            what = o.is_recv ? "ncclRecv" : "ncclSend";
         }
-        NCCLCHK(ncclGroupEnd());
-        ops.clear();
+        const ncclResult_t ge = ncclGroupEnd();
+        if (first != ncclSuccess) { set_error(std::string(what) + " failed: " + ncclGetErrorString(first)); return SLUAMD_EHIP; }
+        if (ge != ncclSuccess) { set_error(std::string("ncclGroupEnd failed: ") + ncclGetErrorString(ge)); return SLUAMD_EHIP; }
         return 0;
     }
-    int allreduce_min(int *v) override
+    int allreduce_min(int *v, int n, hipStream_t s) override
     {
-        HIPCHK(hipMemcpy(d_red, v, sizeof(int), hipMemcpyHostToDevice));
-        NCCLCHK(ncclAllReduce(d_red, d_red, 1, ncclInt32, ncclMin, nc, nullptr));
-        HIPCHK(hipStreamSynchronize(nullptr));
-        HIPCHK(hipMemcpy(v, d_red, sizeof(int), hipMemcpyDeviceToHost));
+        // on the caller's stream: ordered behind the factorisation's last kernels without a device-wide wait and without touching
+        // the null stream (which would serialise against the library's blocking streams)
+        if (n > RED_MAX) { set_error("allreduce_min: too many values"); return SLUAMD_EINVAL; }
+        std::memcpy(h_red, v, sizeof(int) * (size_t) n);
+        HIPCHK(hipMemcpyAsync(d_red, h_red, sizeof(int) * (size_t) n, hipMemcpyHostToDevice, s));
+        NCCLCHK(ncclAllReduce(d_red, d_red, (size_t) n, ncclInt32, ncclMin, nc, s));
+        HIPCHK(hipMemcpyAsync(h_red, d_red, sizeof(int) * (size_t) n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::memcpy(v, h_red, sizeof(int) * (size_t) n);
         return 0;
     }
 };
@@ -79,7 +92,8 @@ Comm *make_rccl_comm(const void *id128, const Grid &g, int device)
     std::memcpy(&id, id128, sizeof(id));
     ncclResult_t r = ncclCommInitRank(&c->nc, g.size(), id, g.rank());
     if (r != ncclSuccess) return fail(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
-    if (hipMalloc((void **) &c->d_red, sizeof(int)) != hipSuccess) return fail("hipMalloc failed");
+    if (hipMalloc((void **) &c->d_red, sizeof(int) * RcclComm::RED_MAX) != hipSuccess) return fail("hipMalloc failed");
+    if (hipHostMalloc((void **) &c->h_red, sizeof(int) * RcclComm::RED_MAX, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
     return c;
 }
 

@@ -309,12 +309,10 @@ int run_factor(Handle *H, double thresh, int *info)
     int linfo = (res[0] == 0x7fffffff) ? 0 : res[0];
     int missing = res[2];
     if (g.size() > 1) {   // info = first zero pivot over the whole grid (MPI_Allreduce MIN, pdgstrf3d.c:388-392)
-        int v = linfo ? linfo : 0x7fffffff;
-        if ((rc = H->comm->allreduce_min(&v))) return rc;
-        linfo = (v == 0x7fffffff) ? 0 : v;
-        int m = -missing;
-        if ((rc = H->comm->allreduce_min(&m))) return rc;
-        missing = -m;
+        int v[2] = {linfo ? linfo : 0x7fffffff, -missing};   // one collective for both, on the library's stream
+        if ((rc = H->comm->allreduce_min(v, 2, H->stream))) return rc;
+        linfo = (v[0] == 0x7fffffff) ? 0 : v[0];
+        missing = -v[1];
     }
     if (info) *info = linfo;
     if (missing) { set_error("Schur update found no destination block for " + std::to_string(missing) + " tiles (structure not closed)"); return SLUAMD_ESTRUCT; }

@@ -94,6 +94,44 @@ def stream_ordered_comms(Pr, Pc, Pz):
     return out
 
 
+def check_transport_selftest(comms, nbytes):
+    """sluamd_comm_selftest on every rank of a world (threads): ring exchange as one stream-ordered group, host-buffer group,
+    min-all-reduce.  A one-rank world sends to itself."""
+    from superlu_dist_amd import _lib
+    L = _lib.load()
+
+    def body(rank):
+        _lib.check(L.sluamd_comm_selftest(comms[rank], nbytes), "sluamd_comm_selftest")
+        return True
+
+    assert all(grid3d.run_ranks(len(comms), body))
+
+
+def check_fixture_on_one_rank_comm(g, comm):
+    """A 1 x 1 x 1 reference fixture through sluamd_dCreateLUHandleGrid over a one-rank communicator: factor and every recorded
+    solve against the reference's record (the grid entry points with a transport attached, no peer to talk to)."""
+    n = int(g["r0__n"][0])
+    st = driver.FlatStore.from_golden(g, 0, "pre")
+    h = grid3d.GridHandle.from_store(st, None, comm, replace_tiny=bool(g["r0__ReplaceTinyPivot"][0]))
+    assert h.pdgstrf3d(float(g["r0__thresh"][0])) == int(g["r0__info"][0])
+    h.copy_to_host(st)
+    scale = max(np.abs(g["r0__Lnzval_pre"]).max(), np.abs(g["r0__Unzval_pre"]).max())
+    assert np.abs(st.Lnzval - g["r0__Lnzval_post"]).max() <= 1e-12 * scale
+    assert np.abs(st.Unzval - g["r0__Unzval_post"]).max() <= 1e-12 * scale
+    pr_, pc_ = g["r0__perm_r"], g["r0__perm_c"]
+    si = 0
+    while f"r0__solve{si}_B_in" in g:
+        nrhs = int(g[f"r0__solve{si}_nrhs"][0])
+        B = g[f"r0__solve{si}_B_in"].reshape((n, nrhs), order="F")
+        xp = np.zeros((n, nrhs), order="F", dtype=B.dtype); xp[pc_[pr_], :] = B
+        y = h.pdgstrs3d(xp)
+        X = g[f"r0__solve{si}_B_out"].reshape((n, nrhs), order="F")
+        assert np.abs(y - X).max() <= 1e-10 * max(1.0, np.abs(X).max())
+        si += 1
+    assert si >= 1
+    h.destroy()
+
+
 def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False, make_comms=None):
     """Any CSR matrix (unpivoted LU must be stable for it) through the own pipeline on a Pr x Pc x Pz grid."""
     Pr, Pc, Pz = grid

@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--grid", type=int, nargs=3, default=[1, 1, 2])
     ap.add_argument("--side", dest="n", type=int, default=8)
     ap.add_argument("--transport", default="callbacks", choices=["callbacks", "rccl"])
+    ap.add_argument("--one-gpu-per-rank", action="store_true")
     a = ap.parse_args()
     import torch.distributed as dist
     from superlu_dist_amd import _lib, driver, grid3d, matgen
@@ -32,7 +33,9 @@ def main():
     symb = driver.Symbolic(n, rp, ci, perm, relax=16, maxsup=64)
     sn_tree = symb.partition(Pz) if Pz > 1 else None
     if a.transport == "rccl":
-        comm = grid3d.rccl_comm(dist, Pr, Pc, Pz, 0)
+        comm = grid3d.rccl_comm(dist, Pr, Pc, Pz, int(os.environ.get("LOCAL_RANK", "0")) if a.one_gpu_per_rank else 0)
+        print("RCCL_COMM_READY", flush=True)     # past ncclCommInitRank: from here on a failure is a transport bug, not "one GPU"
+        _lib.check(_lib.load().sluamd_comm_selftest(comm, 1 << 20), "sluamd_comm_selftest")
         tc = None
     else:
         tc = grid3d.TorchComm(dist, Pr, Pc, Pz)

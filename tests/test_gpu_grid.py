@@ -47,17 +47,56 @@ def test_processes_sharing_one_gpu_over_callbacks(world, grid, tmp_path):
     assert "GRID_WORKER_OK" in r.stdout
 
 
+def _rccl_comm_one_rank():
+    return grid_cases.stream_ordered_comms(1, 1, 1)[0]    # product library: sluamd_comm_rccl_unique_id + ncclCommInitRank(nranks = 1)
+
+
+@pytest.mark.parametrize("nbytes", [8, 1 << 20, (1 << 26) + 40])
+def test_rccl_transport_on_hardware_one_rank(nbytes):
+    """Every operation of the RCCL transport on the MI355X, no skip: a one-rank communicator (ncclCommInitRank with nranks = 1 is
+    legal on a one-GPU box) exchanging with itself -- ncclSend / ncclRecv inside one ncclGroup queued on a non-blocking stream
+    between device fills, an empty group, the device-staged host-buffer group, ncclAllReduce(min) on the stream."""
+    comm = _rccl_comm_one_rank()
+    grid_cases.check_transport_selftest([comm], nbytes)
+    from superlu_dist_amd import _lib
+    _lib.load().sluamd_comm_destroy(comm)
+
+
+def test_rccl_grid_handle_on_hardware_one_rank(golden):
+    """The grid entry points over the RCCL communicator: reference fixture through sluamd_dCreateLUHandleGrid (factor parity,
+    every recorded solve), then the library's own pipeline + refactor."""
+    comm = _rccl_comm_one_rank()
+    grid_cases.check_fixture_on_one_rank_comm(golden("poisson10_nd"), comm)
+    grid_cases.check_own_pipeline(10, (1, 1, 1), nrhs=2, refactor=True, make_comms=lambda *_: [comm])
+
+
+@pytest.mark.parametrize("grid", [(1, 1, 1), (1, 1, 2), (2, 2, 1)])
+def test_transport_selftest_in_process(grid):
+    from superlu_dist_amd import grid3d
+    grid_cases.check_transport_selftest(grid3d.local_comms(*grid), 1 << 16)
+
+
 def test_rccl_transport_two_ranks(tmp_path):
-    """Direct RCCL transport (ncclSend / ncclRecv from the library).  One GPU per rank is RCCL's normal contract; on a
-    single-GPU box this only runs when RCCL accepts two ranks on one device, otherwise it is skipped (the 8-GPU scaling run
-    of the driver exercises it for real)."""
+    """Direct RCCL transport with two ranks.  One GPU per rank is RCCL's contract: on a one-GPU box ncclCommInitRank refuses the
+    second rank ("Duplicate GPU detected") and ONLY that is a skip -- once the communicator exists, any failure or hang of the
+    exchanges is a failure of this test.  With two or more GPUs visible the test must pass."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    extra = ["--transport", "rccl"] + (["--one-gpu-per-rank"] if ngpu >= 2 else [])
     try:
-        r = _launch(2, (1, 1, 2), ["--transport", "rccl"], tmp_path, timeout=240)
-    except subprocess.TimeoutExpired:
-        pytest.skip("RCCL did not initialise with two ranks on one device")
-    if r.returncode != 0:
-        msg = [l for l in (r.stderr + r.stdout).splitlines() if "failed" in l or "NCCL" in l or "rror" in l]
-        pytest.skip("RCCL refused two ranks on one device: " + " | ".join(msg[-3:])[:600])
+        r = _launch(2, (1, 1, 2), extra, tmp_path, timeout=300)
+    except subprocess.TimeoutExpired as e:
+        out = ((e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")) + \
+              ((e.stderr or b"").decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or ""))
+        if ngpu < 2 and "RCCL_COMM_READY" not in out:
+            pytest.skip("ncclCommInitRank did not return with two ranks on one device")
+        raise AssertionError("RCCL exchange hung after the communicator was created:\n" + out[-2000:])
+    out = r.stdout + r.stderr
+    if r.returncode != 0 and ngpu < 2 and "RCCL_COMM_READY" not in out and ("ncclCommInitRank failed" in out or "Duplicate GPU" in out):
+        pytest.skip("RCCL refuses two ranks on one device (ncclCommInitRank): " + " | ".join(l for l in out.splitlines() if "ncclCommInitRank" in l or "Duplicate" in l)[:400])
+    if r.returncode != 0 and "the CPU test build has no RCCL transport" in out:
+        pytest.skip("emulation library (test_gpu_suite_on_emulation.py): its stream-ordered stand-in connects threads of one process")
+    assert r.returncode == 0, out[-3000:]
     assert "GRID_WORKER_OK" in r.stdout
 
 

@@ -104,3 +104,35 @@ def test_own_pipeline_with_supernodes_up_to_512_columns(emul, grid):
     """maxsup = 512 through the library's own symbolic factorisation + device-side distribution: wide supernodes are refined
     at handle creation (on XY layers the pieces stay with the owners of their supernode), A's entries are scattered straight into the pieces."""
     grid_cases.check_own_pipeline(18, grid, nrhs=2, leaf=64, relax=64, maxsup=512)
+
+
+@pytest.mark.parametrize("kind,grid", [("local", (1, 1, 1)), ("local", (1, 3, 1)), ("local", (2, 2, 2)), ("stream", (1, 1, 1)), ("stream", (1, 1, 2)), ("stream", (2, 2, 1))])
+@pytest.mark.parametrize("nbytes", [8, 4096 + 24])
+def test_transport_selftest(emul, kind, grid, nbytes):
+    """sluamd_comm_selftest over the in-process transports: a one-rank world exchanges with itself (the shape of the GPU box's
+    one-rank RCCL test), larger worlds run a ring."""
+    from superlu_dist_amd import grid3d
+    comms = grid3d.local_comms(*grid) if kind == "local" else grid_cases.stream_ordered_comms(*grid)
+    grid_cases.check_transport_selftest(comms, nbytes)
+
+
+@pytest.mark.parametrize("kind", ["local", "stream"])
+def test_fixture_through_the_grid_entry_points_on_a_one_rank_communicator(emul, golden, kind):
+    from superlu_dist_amd import grid3d
+    comm = (grid3d.local_comms(1, 1, 1) if kind == "local" else grid_cases.stream_ordered_comms(1, 1, 1))[0]
+    grid_cases.check_fixture_on_one_rank_comm(golden("poisson10_nd"), comm)
+
+
+def test_a_failing_rank_releases_its_peers(emul):
+    """A size mismatch inside an exchange used to leave the sender waiting for ever: now the failing rank poisons the
+    in-process world and every rank returns an error."""
+    import ctypes as C
+    from superlu_dist_amd import _lib, grid3d
+    L = _lib.load()
+    comms = grid3d.local_comms(1, 1, 2)
+
+    def body(rank):
+        return L.sluamd_comm_selftest(comms[rank], 64 if rank == 0 else 128)   # the two ranks disagree on the message size
+
+    rcs = grid3d.run_ranks(2, body)
+    assert all(rc != 0 for rc in rcs), rcs
