@@ -351,6 +351,18 @@ int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, in
     return 0;
 }
 
+// the dataflow sweeps (k_chain) raise a pinned host word when a dependency counter never reaches its value (bounded spins):
+// checked after the stream was synchronised
+static int chain_check(Handle *H)
+{
+    if (H->chain_abort && *H->chain_abort) {
+        *H->chain_abort = 0;
+        set_error("triangular solve: a dependency of the dataflow sweep never arrived (SLUAMD_CHAIN=0 selects the level-set form)");
+        return SLUAMD_EHIP;
+    }
+    return 0;
+}
+
 int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nrhs)
 {
     if (!h || !d_x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
@@ -365,7 +377,7 @@ int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nr
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_solve_ms = ms;
-    return 0;
+    return chain_check(H);
 }
 
 int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs)
@@ -458,7 +470,7 @@ int sluamd_pdgsrfs3d_dev(sluamd_handle_t h, const double *d_B, int64_t ldb, doub
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (steps) *steps = count;
-    return 0;
+    return chain_check(H);
 }
 
 int sluamd_pdgsrfs3d(sluamd_handle_t h, const double *B, int64_t ldb, double *X, int64_t ldx, int32_t nrhs, double *berr, int32_t *steps)
@@ -499,6 +511,7 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_apos) hipFree(H->d_apos);
     if (H->d_aval) hipFree(H->d_aval);
     if (H->h_pinned) hipHostFree(H->h_pinned);
+    if (H->chain_abort) hipHostFree(H->chain_abort);
     free_rfs(H);
     for (auto &e : H->ev_schur) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : H->ev_panel) { hipEventDestroy(e.first); hipEventDestroy(e.second); }

@@ -413,19 +413,29 @@ static int xseg_exchange(Handle *H, double *d_x, int64_t ldx, int nrhs, const st
 // reference's solve gets this overlap from its message-driven fmod / bmod counters (pdgstrs_lsum.c:414-960); here it is static.
 // (Measured and rejected: the far units on side streams -- each event record / wait costs the chain ~6 us; the feeding units
 // run by the diagonal workgroup itself -- serial 64-row strips, 7.05 -> 8.1 ms.)
+static bool use_chain(const Handle *H, const LevelSched &S) { return S.chain_l0 >= 0 && H->env.chain_mode && H->chain_abort; }
+
 static int solve_fwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
     const int nl = S.nlevels;
     if (nl == 0) return 0;
-    eng::sweep_step(s, true, T, S.d_nodes + S.lvl_off[0], S.lvl_off[1] - S.lvl_off[0], nullptr, 0, d_x, ldx, nrhs, S.max_nsupc[0]);
-    for (int l = 0; l < nl; ++l) {
+    // levels >= l0: the dataflow form (one persistent launch, LevelSched::cf_*); below it one launch pair per level
+    const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
+    if (l0 > 0) eng::sweep_step(s, true, T, S.d_nodes + S.lvl_off[0], S.lvl_off[1] - S.lvl_off[0], nullptr, 0, d_x, ldx, nrhs, S.max_nsupc[0]);
+    for (int l = 0; l < l0; ++l) {
         const int u0 = S.fu_off[2 * l], u1 = S.fu_off[2 * l + 1], u2 = S.fu_off[2 * l + 2];
-        const int nd = (l + 1 < nl) ? S.lvl_off[l + 2] - S.lvl_off[l + 1] : 0;
+        const int nd = (l + 1 < l0) ? S.lvl_off[l + 2] - S.lvl_off[l + 1] : 0;     // the diagonal solves of level l0 belong to the chain
         const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
         eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0);
         eng::sweep_step(s, true, T, S.d_nodes + (nd ? S.lvl_off[l + 1] : 0), nd, S.d_fwd_units + u1, u2 - u1, d_x, ldx, nrhs, mx);
+    }
+    if (l0 < nl) {
+        int mx = 0;
+        for (int l = l0; l < nl; ++l) mx = std::max(mx, S.max_nsupc[l]);
+        eng::chain_sweep(s, true, H->env.chain_mode, T, S.d_cf_units, (int) (S.cf_units.size() / 8), S.d_cf_waits, S.d_cf_sigs, S.d_chain_flags, S.chain_nflags,
+                         H->chain_abort, d_x, ldx, nrhs, mx);
     }
     return 0;
 }
@@ -436,11 +446,18 @@ static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
     hipStream_t s = H->stream;
     const int nl = S.nlevels;
     if (nl == 0) return 0;
-    {   // far chunks of the top level (columns of ancestors in other forests, solved before this sweep)
+    const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
+    if (l0 < nl) {
+        int mx = 0;
+        for (int l = l0; l < nl; ++l) mx = std::max(mx, S.max_nsupc[l]);
+        if (l0 > 0) mx = std::max(mx, S.max_nsupc[l0 - 1]);      // the far chunks of level l0 - 1 ride along (LevelSched: F(l - 1) after D(l))
+        eng::chain_sweep(s, false, H->env.chain_mode, T, S.d_cb_units, (int) (S.cb_units.size() / 8), S.d_cb_waits, S.d_cb_sigs, S.d_chain_flags, S.chain_nflags,
+                         H->chain_abort, d_x, ldx, nrhs, mx);
+    } else {   // far chunks of the top level (columns of ancestors in other forests, solved before this sweep)
         const int u1 = S.bu_off[2 * (nl - 1) + 1], u2 = S.bu_off[2 * (nl - 1) + 2];
         eng::sweep_step(s, false, T, nullptr, 0, S.d_bwd_units + u1, u2 - u1, d_x, ldx, nrhs, S.max_nsupc[nl - 1]);
     }
-    for (int l = nl - 1; l >= 0; --l) {
+    for (int l = l0 - 1; l >= 0; --l) {
         const int u0 = S.bu_off[2 * l], u1 = S.bu_off[2 * l + 1];
         const int nd = S.lvl_off[l + 1] - S.lvl_off[l];
         const int b1 = l > 0 ? S.bu_off[2 * (l - 1) + 1] : 0, b2 = l > 0 ? S.bu_off[2 * (l - 1) + 2] : 0;   // far chunks of level l-1: x of levels >= l+1 only

@@ -47,6 +47,8 @@ void read_env(Handle::Env &e)
     e.trsm_panels = getenv("SLUAMD_TRSM_PANELS") != nullptr;    // blocked-substitution panel kernels instead of the GEMM form (1 x 1 layers)
     if (const char *v = getenv("SLUAMD_FUSE_MIN_PCT")) e.fuse_min_pct = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_MAX_PREV")) e.fuse_max_prev = std::max(1, std::min(3, atoi(v)));
+    if (const char *v = getenv("SLUAMD_CHAIN")) e.chain_mode = std::max(0, std::min(2, atoi(v)));
+    if (const char *v = getenv("SLUAMD_CHAIN_MAX_NODES")) e.chain_max_nodes = std::max(1, atoi(v));
     if (const char *v = getenv("SLUAMD_RESERVE_CUS")) e.reserve_cus = std::max(0, atoi(v));
 }
 

@@ -170,6 +170,19 @@ struct LevelSched {
     // chain waits for, bulk = levels >= l+2 only (launched together with that diagonal solve, eng::sweep_step)
     std::vector<int2> fwd_units, bwd_units;
     std::vector<int> fu_off, bu_off;          // [2*nlevels+1]: index 2*level + part
+    // Dataflow ("chain") form of the two sweeps over the TOP of the schedule, levels >= chain_l0 (1 x 1 layers, real): few
+    // supernodes per level, one dependent launch pair per level in the level-set form -- launch latency, not bandwidth.  Here
+    // ONE persistent launch per sweep walks a topologically ordered unit list with device-side dependency counters, the
+    // reference's fmod / bmod counters (pdgstrs_lsum.c:414-960, the GPU solve's spin-wait kernels pdgstrs_lsum_cuda.cu:2197-2596)
+    // built on the host: unit = {type (0 diagonal solve, 1 update), supernode, strip / chunk, wait range, signal range, 0};
+    // wait = (flag, value to reach), signal = flag to increment.  flags: [0] ticket, [1] abort, [2 + 2 c] updates received by
+    // chain node c, [3 + 2 c] its diagonal solve done.
+    int chain_l0 = -1;              // -1: none
+    int chain_nflags = 0;
+    std::vector<int> cf_units, cf_sigs, cb_units, cb_sigs;   // 8 ints per unit
+    std::vector<int2> cf_waits, cb_waits;
+    int *d_cf_units = nullptr, *d_cf_sigs = nullptr, *d_cb_units = nullptr, *d_cb_sigs = nullptr, *d_chain_flags = nullptr;
+    int2 *d_cf_waits = nullptr, *d_cb_waits = nullptr;
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
@@ -220,6 +233,7 @@ struct Handle {
     struct Env {
         bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, profile_dump = false, trsm_panels = false, diag_v1 = false;
         int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
+        int chain_mode = 1, chain_max_nodes = 8;   // dataflow sweeps over the top levels (0 = off; 1 = agent-scope fences; 2 = write-through x, no fences)
     } env;
     // device arenas
     double *d_val = nullptr;
@@ -250,6 +264,7 @@ struct Handle {
     bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
     bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
     bool inv_ready = false;                                 // T.inv (Linv / Uinv) too
+    int *chain_abort = nullptr;                             // pinned host word written by k_chain when a dependency never arrives (checked after every solve)
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
     size_t ev_schur_used = 0, ev_panel_used = 0;
@@ -299,6 +314,9 @@ void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *
 // (max_nsupc over everything in the launch)
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits,
                 double *x, int64_t ldx, int nrhs, int max_nsupc);
+// dataflow sweep over a topologically ordered unit list (LevelSched::cf_* / cb_*): ONE persistent launch; `flags` zeroed on s first
+void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,
+                 int *flags, int nflags, int *host_abort /* pinned host word, set to 1 when a dependency never arrived */, double *x, int64_t ldx, int nrhs, int max_nsupc);
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz);
 void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
                   double *r_perm, unsigned long long *s_out, double safe1, double safe2);

@@ -1315,7 +1315,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
 // x_k <- Linv x_k (unit lower) or Uinv x_k: one workgroup per supernode of the level, ONE dense triangular GEMV with the full
 // inverse (what the reference's DiagInv=YES solve does with Linv / Uinv, pdgstrs_lsum.c:414-520) -- no dependent chain
 // inside the block.  Used on XY layers, where the exchanges separate the diagonal solve from the updates.
-template <bool LOWER, int NT>   // NT = 1024, or 256 for levels whose supernodes are at most 64 wide (one column quarter)
+// x accessors of the sweeps.  COH = true (the fence-free form of the dataflow sweeps, k_chain): every access to x is an 8-byte
+// agent-scope access -- loads served by L2 past the CU's L1, stores written through -- so that workgroups on other CUs / XCDs read
+// what was published without cache-maintenance fences (the fp64 atomics of the updates are agent-scope as well)
+template <bool COH> __device__ __forceinline__ double ld_x(const double *p)
+{
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ void st_x(double *p, double v)
+{
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool LOWER, int NT, bool COH = false>   // NT = 1024, or 256 for levels whose supernodes are at most 64 wide (one column quarter)
 __device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, double *__restrict__ x, int64_t ldx, int nrhs, double *xs /* ns x nrhs */)
 {
     __shared__ double s_part[NT / 256][256];
@@ -1323,7 +1337,7 @@ __device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, doubl
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xs[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xs[idx] = ld_x<COH>(x + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
     __syncthreads();
     // thread = (row i, quarter of the columns): <= 4 batches of 16 L2 loads; the inverse stores explicit zeros in the other
     // triangle, column blocks entirely outside the wave's rows are skipped
@@ -1352,7 +1366,7 @@ __device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, doubl
         if (tid < ns) {
             double a = s_part[0][tid];
             if (NT == 1024) a = (a + s_part[1][tid]) + (s_part[NT == 1024 ? 2 : 0][tid] + s_part[NT == 1024 ? 3 : 0][tid]);
-            x[fst + tid + (int64_t) q * ldx] = a;
+            st_x<COH>(x + fst + tid + (int64_t) q * ldx, a);
         }
         __syncthreads();
     }
@@ -1372,7 +1386,7 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
 //
 // lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414): workgroup = (supernode,
 // 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
-template <int NT>
+template <int NT, bool COH = false>
 __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, double *__restrict__ x, int64_t ldx, int nrhs, double *xk /* ns x nrhs */)
 {
     constexpr int NP = NT / 64;     // column slices
@@ -1380,7 +1394,7 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = x[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(x + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
     __syncthreads();
     const int r = tid & 63, part = tid >> 6;
     const int row = T.sn_ldiag[k] + strip * 64 + r;
@@ -1429,7 +1443,7 @@ __global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__res
 // x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
 // lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
-template <int NT>   // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block)
+template <int NT, bool COH = false>   // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block)
 __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int chunk, double *__restrict__ x, int64_t ldx, int nrhs)
 {
     constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = (NT == 1024) ? 4 : 1;
@@ -1446,7 +1460,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     __syncthreads();
     const double *Uv = T.val + T.sn_uval[k];
     for (int r = 0; r < nrhs; ++r) {
-        if (tid < ncol) s_xc[tid] = x[s_gc[tid] + (int64_t) r * ldx];      // solved x of this chunk's columns: one gather
+        if (tid < ncol) s_xc[tid] = ld_x<COH>(x + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
         __syncthreads();
         {
             double a[RB];
@@ -1514,6 +1528,74 @@ __global__ __launch_bounds__(NT) void k_sweep(DevTables T, const int *__restrict
     else bwd_update_body<NT>(T, u.x, u.y, x, ldx, nrhs);
 }
 
+// Dataflow sweeps over the top of the elimination DAG (LevelSched::chain_l0): ONE persistent launch walks a topologically
+// ordered unit list -- diagonal solves and 64-row / 64-column update units of the levels that hold only a few supernodes each --
+// instead of two dependent launches per level.  The reference's GPU solve does the same with spin-waits on its fmod / bmod
+// counters (dlsum_fmod_inv_gpu_mrhs / dlsum_bmod_inv_gpu_mrhs, pdgstrs_lsum_cuda.cu:2197-2596, :3038); here the dependency
+// structure is a host-built table of (flag, value) waits and flag increments per unit.
+//   * a workgroup takes the next unit by ticket (flags[0]): units are STARTED in list order and only wait for earlier units, so
+//     the unit with the smallest unfinished ticket can always run -- progress does not depend on how many workgroups are resident;
+//   * hand-off between workgroups (cdna_hip_programming.md section 6, Guideline 16): producer = every wave drains its memory
+//     operations, barrier, ONE lane releases at agent scope, then increments the flags with relaxed agent-scope atomics;
+//     consumer = the first wave polls its flags relaxed (one lane per flag, s_sleep between polls), ONE agent-scope acquire,
+//     barrier, plain loads.  MODE 2: every access to x is an agent-scope 8-byte access instead (updates are fp64 atomics, the
+//     diagonal solve writes x_k through) -- no cache-maintenance fence on either side;
+//   * spins are bounded: a dependency that never arrives raises flags[1] and every workgroup leaves (the host reports it).
+constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 22;     // x ~0.3 us per poll: about a second
+template <bool LOWER, int MODE>
+__global__ __launch_bounds__(1024) void k_chain(DevTables T, const int *__restrict__ units, int nunits, const int2 *__restrict__ waits,
+                                                const int *__restrict__ sigs, int *flags, int *host_abort, double *x, int64_t ldx, int nrhs)
+{
+    extern __shared__ double dyn[];  // max_nsupc x nrhs
+    __shared__ int s_u[2];
+    constexpr bool COH = MODE == 2;
+    const int tid = threadIdx.x;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            s_u[0] = __hip_atomic_fetch_add(&flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_u[1] = __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const int u = s_u[0];
+        if (u >= nunits || s_u[1]) return;
+        const int *rec = units + 8 * (size_t) u;
+        const int type = rec[0], k = rec[1], idx = rec[2], w_off = rec[3], w_n = rec[4], s_off = rec[5], s_n = rec[6];
+        // ---- consume: wait for the units this one depends on ----
+        if (tid < 64) {
+            bool fail = false;
+            if (tid < w_n) {
+                const int2 w = waits[w_off + tid];
+                unsigned spins = 0;
+                while (__hip_atomic_load(&flags[w.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < w.y) {
+                    if (++spins > CHAIN_SPIN_LIMIT || __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = true; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            if (__any(fail)) {
+                if (tid == 0) {
+                    __hip_atomic_store(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_u[1] = 1;
+                    __hip_atomic_store(host_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // pinned host word: the API reports the failure
+                }
+            }
+            else if (MODE == 1 && tid == 0 && w_n > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (s_u[1]) return;
+        // ---- the unit ----
+        if (type == 0) solve_diag_body<LOWER, 1024, COH>(T, k, x, ldx, nrhs, dyn);
+        else if (LOWER) fwd_update_body<1024, COH>(T, k, idx, x, ldx, nrhs, dyn);
+        else bwd_update_body<1024, COH>(T, k, idx, x, ldx, nrhs);
+        // ---- publish ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores / atomics have left the CU
+        __syncthreads();
+        if (tid == 0) {
+            if (MODE == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            for (int i = 0; i < s_n; ++i) __hip_atomic_fetch_add(&flags[sigs[s_off + i]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // A's entries -> value arena (device-side pddistribute): val[pos[e]] = a[e]
 __global__ void k_scatter_values(double *__restrict__ val, const int64_t *__restrict__ pos, const double *__restrict__ a, int64_t nnz)
 {
@@ -1579,6 +1661,7 @@ __global__ __launch_bounds__(256) void k_xseg_copy(double *__restrict__ x, int64
 // ================================================================================================
 namespace eng {
 
+static int g_num_cus = 256;
 int setup()
 {
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
@@ -1590,6 +1673,11 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_chain<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_chain<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_chain<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *) k_chain<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) g_num_cus = pr.multiProcessorCount; }
     HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     // the 256-thread variants stage max_nsupc (<= 64) x nrhs values: above 64 KiB when a matrix of narrow supernodes is solved for many right-hand sides
@@ -1696,6 +1784,22 @@ void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes
     } else {
         if (lower) hipLaunchKernelGGL((k_sweep<true, 1024>), dim3(nd + nunits), dim3(1024), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
         else hipLaunchKernelGGL((k_sweep<false, 1024>), dim3(nd + nunits), dim3(1024), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
+    }
+}
+
+void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,
+                 int *flags, int nflags, int *host_abort, double *x, int64_t ldx, int nrhs, int mx)
+{
+    if (nunits <= 0) return;
+    hipMemsetAsync(flags, 0, sizeof(int) * (size_t) nflags, s);      // tickets, abort flag, dependency counters: zeroed before every launch
+    const size_t lds = (size_t) mx * nrhs * sizeof(double);
+    const int grid = std::min(nunits, g_num_cus);                   // one 1024-thread workgroup per CU; fewer resident ones are fine (tickets)
+    if (mode == 2) {
+        if (lower) hipLaunchKernelGGL((k_chain<true, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
+        else hipLaunchKernelGGL((k_chain<false, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
+    } else {
+        if (lower) hipLaunchKernelGGL((k_chain<true, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
+        else hipLaunchKernelGGL((k_chain<false, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
     }
 }
 
