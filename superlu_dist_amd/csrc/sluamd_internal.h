@@ -233,7 +233,8 @@ struct Handle {
     struct Env {
         bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, profile_dump = false, trsm_panels = false, diag_v1 = false;
         int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
-        int chain_mode = 1, chain_max_nodes = 8;   // dataflow sweeps over the top levels (0 = off; 1 = agent-scope fences; 2 = write-through x, no fences)
+        int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
+                                                   // profiles/r03_ab_dataflow_sweeps.txt; 1 = agent-scope fences; 2 = write-through x, no fences)
     } env;
     // device arenas
     double *d_val = nullptr;
