@@ -1,21 +1,28 @@
 /*
- * sluamd_binding.c -- the reference-side binding of the MI355X hot path (this is the code INTEGRATION.md asks a
- * SuperLU_DIST maintainer to add next to SRC/double/pdgssvx3d.c:1013-1021).  It is OUR code; it includes the
- * reference's public headers only to unpack dLUstruct_t / gridinfo3d_t / dtrf3Dpartition_t into the plain-pointer
- * views of include/superlu_dist_amd.h.
+ * bindings/superlu_dist/sluamd_binding.c -- the reference-side binding of the MI355X hot path: the file a SuperLU_DIST
+ * maintainer adds next to SRC/double/pdgssvx3d.c:1013-1021.  It is OUR code; it includes the reference's
+ * public headers only to unpack dLUstruct_t / gridinfo3d_t / dtrf3Dpartition_t into the plain-pointer views of
+ * include/superlu_dist_amd.h.  Compiled once per precision (-DZ_PREC for complex16):
  *
  *   sluamd_bind_pdgstrf3d            replaces pdgstrf3d            (SRC/double/pdgstrf3d.c:121)
  *   sluamd_bind_pdgstrs3d[_newsolve] replace  pdgstrs3d[_newsolve] (SRC/double/pdgstrs3d.c:6604 / :6935)
+ *   sluamd_bind_pzgstrf3d, sluamd_bind_pzgstrs3d[_newsolve]        (SRC/complex16/pzgstrf3d.c, pzgstrs3d.c; 1 x 1 x npdep grids)
  *
  * on ANY nprow x npcol x npdep grid: the library runs the whole 3D algorithm (XY panel exchange, Z ancestor reduction,
- * distributed triangular solves) itself over a transport; here the transport is the application's MPI (grid3d->comm)
- * through the sluamd_comm_callbacks_t hooks, so several ranks may even share one GPU.  A node with one GPU per rank
- * passes an RCCL communicator instead (sluamd_comm_create_rccl) and nothing else changes.
+ * distributed triangular solves) itself over a transport, chosen at run time:
+ *   SLUAMD_BIND_TRANSPORT=mpi  (default) the application's MPI (grid3d->comm) through the sluamd_comm_callbacks_t hooks: host-staged,
+ *                              several ranks may share one GPU;
+ *   SLUAMD_BIND_TRANSPORT=rccl one rank per GPU: RCCL called directly by the library (ncclSend / ncclRecv on its HIP streams); the
+ *                              ncclUniqueId travels by MPI_Bcast, the device is the rank's index on its node.
+ * The right-hand side stays distributed at the solve boundary (sluamd_pdgstrs3d_dist: each rank hands over its m_loc rows of B,
+ * pdReDistribute3d_B_to_X / X_to_B run inside the library on the device).
  *
- * Built into oracle/_ref/slu_ref_amd (oracle/ref/Makefile) where `ld --wrap=pdgstrf3d --wrap=pdgstrs3d_newsolve
- * --wrap=pdgstrs3d` routes the reference's own pdgssvx3d to it: the reference's pre-processing, distribution and
- * refinement loop run unchanged around our factorisation and our solves.  Test infrastructure only.
+ * `make -C bindings/superlu_dist REF=<superlu_dist tree>` compiles it against a reference tree; oracle/ref/Makefile links it into
+ * oracle/_ref/slu_ref_amd / slu_ref_zamd, where `ld --wrap=pdgstrf3d --wrap=pdgstrs3d_newsolve --wrap=pdgstrs3d` routes the
+ * reference's own pdgssvx3d to it: the reference's pre-processing, distribution and refinement loop run unchanged around our
+ * factorisation and our solves (tests/test_gpu_dropin.py).
  */
+#define _GNU_SOURCE   /* readlink, dladdr-free path lookup */
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -58,20 +65,25 @@
  * superlu_defs.h:121-129) hands over narrowed copies of its index arrays -- the values are never copied -- and every index must fit
  * (checked): one rank's panels are far below 2^31 rows and columns, what needs 64 bits in such builds are global counts. */
 #if defined(_LONGINT)
-static void *narrowed[1 << 16]; static int n_narrowed = 0;
+static void **narrowed = NULL; static size_t n_narrowed = 0, cap_narrowed = 0;     /* one entry per local block column / block row / forest list: grows */
 static sluamd_int_t *sluamd_narrow(const int_t *src, size_t n)
 {
     if (!src) return NULL;
     sluamd_int_t *d = (sluamd_int_t *) malloc(sizeof(sluamd_int_t) * (n ? n : 1));
+    if (!d) ABORT("sluamd binding: out of memory (narrowed index array)");
     for (size_t i = 0; i < n; ++i) {
         if (src[i] > INT_MAX || src[i] < INT_MIN) ABORT("sluamd binding: an index does not fit the library's 32-bit ABI");
         d[i] = (sluamd_int_t) src[i];
     }
-    if (n_narrowed == (int) (sizeof(narrowed) / sizeof(narrowed[0]))) ABORT("sluamd binding: too many index arrays");
+    if (n_narrowed == cap_narrowed) {
+        cap_narrowed = cap_narrowed ? 2 * cap_narrowed : 4096;
+        narrowed = (void **) realloc(narrowed, sizeof(void *) * cap_narrowed);
+        if (!narrowed) ABORT("sluamd binding: out of memory (narrowed index table)");
+    }
     narrowed[n_narrowed++] = d;
     return d;
 }
-static void sluamd_narrow_release(void) { for (int i = 0; i < n_narrowed; ++i) free(narrowed[i]); n_narrowed = 0; }
+static void sluamd_narrow_release(void) { for (size_t i = 0; i < n_narrowed; ++i) free(narrowed[i]); n_narrowed = 0; }
 #define NARROW(p, n) sluamd_narrow((p), (size_t) (n))
 #else
 #define NARROW(p, n) (p)
@@ -88,8 +100,11 @@ static struct {
     int (*create_grid)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t);
     int (*factor)(sluamd_handle_t, double, int *);
     int (*copy2host)(sluamd_handle_t, const LUVIEW_T *);
-    int (*solve)(sluamd_handle_t, double *, int64_t, int32_t);
+    int (*solve_dist)(sluamd_handle_t, double *, int64_t, int32_t, int64_t, int64_t, const sluamd_int_t *, const sluamd_int_t *);
+    int (*zsolve)(sluamd_handle_t, sluamd_doublecomplex *, int64_t, int32_t);
     int (*stats)(sluamd_handle_t, sluamd_stats_t *);
+    int (*rccl_id)(void *);
+    int (*comm_create_rccl)(sluamd_comm_t *, const void *, int, int, int, int, int, int, int);
     void (*destroy)(sluamd_handle_t);
     int (*comm_create)(sluamd_comm_t *, const sluamd_comm_callbacks_t *, int, int, int, int, int, int);
     void (*comm_destroy)(sluamd_comm_t);
@@ -102,7 +117,7 @@ static void sluamd_load(void)
     char path[4096];
     const char *env = getenv("SLUAMD_LIB");
     if (env) snprintf(path, sizeof path, "%s", env);
-    else {   /* <repo>/oracle/_ref/<exe>  ->  <repo>/superlu_dist_amd/libsluamd.so */
+    else {   /* this repository's test binaries: <repo>/oracle/_ref/<exe>  ->  <repo>/superlu_dist_amd/libsluamd.so */
         ssize_t k = readlink("/proc/self/exe", path, sizeof path - 64);
         if (k < 0) ABORT("readlink(/proc/self/exe) failed");
         path[k] = 0;
@@ -116,13 +131,17 @@ static void sluamd_load(void)
     S.create_grid = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t)) dlsym(S.so, SYM_CREATE_GRID);
     S.factor = (int (*)(sluamd_handle_t, double, int *)) dlsym(S.so, SYM_FACTOR);
     S.copy2host = (int (*)(sluamd_handle_t, const LUVIEW_T *)) dlsym(S.so, SYM_COPY);
-    S.solve = (int (*)(sluamd_handle_t, double *, int64_t, int32_t)) dlsym(S.so, "sluamd_pdgstrs3d");
+    S.solve_dist = (int (*)(sluamd_handle_t, double *, int64_t, int32_t, int64_t, int64_t, const sluamd_int_t *, const sluamd_int_t *)) dlsym(S.so, "sluamd_pdgstrs3d_dist");
+    S.zsolve = (int (*)(sluamd_handle_t, sluamd_doublecomplex *, int64_t, int32_t)) dlsym(S.so, "sluamd_pzgstrs3d");
+    S.rccl_id = (int (*)(void *)) dlsym(S.so, "sluamd_comm_rccl_unique_id");
+    S.comm_create_rccl = (int (*)(sluamd_comm_t *, const void *, int, int, int, int, int, int, int)) dlsym(S.so, "sluamd_comm_create_rccl");
     S.stats = (int (*)(sluamd_handle_t, sluamd_stats_t *)) dlsym(S.so, "sluamd_get_stats");
     S.destroy = (void (*)(sluamd_handle_t)) dlsym(S.so, "sluamd_dDestroyLUHandle");
     S.comm_create = (int (*)(sluamd_comm_t *, const sluamd_comm_callbacks_t *, int, int, int, int, int, int)) dlsym(S.so, "sluamd_comm_create_callbacks");
     S.comm_destroy = (void (*)(sluamd_comm_t)) dlsym(S.so, "sluamd_comm_destroy");
     S.last_error = (const char *(*)(void)) dlsym(S.so, "sluamd_last_error");
-    if (!S.create || !S.create_grid || !S.factor || !S.copy2host || !S.solve || !S.destroy || !S.comm_create) ABORT("libsluamd.so lacks a required symbol");
+    if (!S.create || !S.create_grid || !S.factor || !S.copy2host || !S.solve_dist || !S.zsolve || !S.destroy || !S.comm_create || !S.rccl_id || !S.comm_create_rccl)
+        ABORT("libsluamd.so lacks a required symbol");
 }
 
 /* ---- MPI transport for sluamd_comm_callbacks_t (host buffers; the library stages device ranges) ---- */
@@ -174,10 +193,32 @@ static int m_allmin(void *ctx, int32_t *v)
     return 0;
 }
 
+/* the communicator the library runs its exchanges over: MPI callbacks (host-staged) or RCCL (one rank per GPU; the unique id
+ * is shipped with MPI_Bcast like any NCCL application does, the device is the rank's index among the ranks of its node) */
+static struct { sluamd_handle_t h; sluamd_comm_t comm; int n; } G;
+static int bind_comm_create(MPI_Comm comm, int Pr, int Pc, int Pz, int myrow, int mycol, int myz, int use_rccl)
+{
+    if (use_rccl) {
+        int rank; MPI_Comm_rank(comm, &rank);
+        int mine = (myz * Pr + myrow) * Pc + mycol, root_is_me = (mine == 0), root = 0, cand = root_is_me ? rank : 0;
+        MPI_Allreduce(&cand, &root, 1, MPI_INT, MPI_MAX, comm);          /* the MPI rank that is library world rank 0 creates the id */
+        char id[SLUAMD_UNIQUE_ID_BYTES];
+        memset(id, 0, sizeof id);
+        if (root_is_me && S.rccl_id(id)) return 1;
+        MPI_Bcast(id, SLUAMD_UNIQUE_ID_BYTES, MPI_BYTE, root, comm);
+        MPI_Comm node; int local = 0;
+        MPI_Comm_split_type(comm, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node);
+        MPI_Comm_rank(node, &local);
+        MPI_Comm_free(&node);
+        const char *dv = getenv("SLUAMD_BIND_DEVICE");                  /* override, e.g. a launcher that already set HIP_VISIBLE_DEVICES per rank */
+        return S.comm_create_rccl(&G.comm, id, Pr, Pc, Pz, myrow, mycol, myz, dv ? atoi(dv) : local);
+    }
+    sluamd_comm_callbacks_t cb = { NULL, m_isend, m_irecv, m_waitall, m_allmin };
+    return S.comm_create(&G.comm, &cb, Pr, Pc, Pz, myrow, mycol, myz);
+}
+
 /* the device-resident factors stay alive between pdgstrf3d and the solves (pdgssvx3d calls pdgstrs3d once, pdgsrfs3d
  * once per refinement step); released when the next factorisation starts or at exit */
-static struct { sluamd_handle_t h; sluamd_comm_t comm; int n; } G;
-
 static void sluamd_bind_release(void)
 {
     if (G.h) { S.destroy(G.h); G.h = NULL; }
@@ -235,7 +276,10 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     o.replace_tiny_pivot = (options->ReplaceTinyPivot == YES);
 
     int rc;
-    if (Pr * Pc * Pz > 1) {
+    const char *tr = getenv("SLUAMD_BIND_TRANSPORT");
+    const int use_rccl = tr && !strcmp(tr, "rccl");
+    const double t_start = SuperLU_timer_();
+    if (Pr * Pc * Pz > 1 || use_rccl) {
 #ifdef Z_PREC
         if (Pr * Pc > 1) ABORT("complex16 binding: 1 x 1 x npdep grids only");
 #endif
@@ -248,8 +292,7 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
         M.mpi_rank_of = (int *) realloc(M.mpi_rank_of, sizeof(int) * P);
         for (int q = 0; q < P; ++q) M.mpi_rank_of[all[q]] = q;
         free(all);
-        sluamd_comm_callbacks_t cb = { NULL, m_isend, m_irecv, m_waitall, m_allmin };
-        rc = S.comm_create(&G.comm, &cb, Pr, Pc, Pz, myrow, mycol, myz);
+        rc = bind_comm_create(grid3d->comm, Pr, Pc, Pz, myrow, mycol, myz, use_rccl);
         if (rc) ABORT(S.last_error());
         rc = S.create_grid(&G.h, &v, &fv, &o, G.comm);                       /* was dCreateLUgpuHandle    */
     } else {
@@ -272,21 +315,25 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     }
     stat->ops[FACT] += (flops_t) (st.flops_schur_padded + st.flops_panel);   /* scuStatUpdate's tally     */
     stat->TinyPivots += st.tiny_pivots;
+    /* the reference brackets its level loop with SCT->pdgstrfTimer (pdgstrf3d.c:331, :395) and pdgssvx3d reports stat->utime[FACT]
+     * around the call: the numeric phase on the device (HIP events, upload and download of the panels excluded) and the whole call */
+    if (SCT) SCT->pdgstrfTimer = 1e-3 * st.t_factor_ms;
+    stat->utime[FACT] = SuperLU_timer_() - t_start;
     free(nNodes); free(lists);
 #if defined(_LONGINT)
     free(v.Lrowind_bc_ptr); free(v.Ufstnz_br_ptr);
 #endif
     sluamd_narrow_release();
-    (void) m; (void) SCT;
+    (void) m;
     return 0;
 }
 
+/* pdgstrs3d / pdgstrs3d_newsolve (pdgstrs3d.c:6604 / :6935): B holds this rank's m_loc rows (from fst_row) of the right-hand side
+ * in the ORIGINAL row order on the layer-0 grid (the other layers' copies are not read: refinement-step right-hand sides exist on
+ * layer 0 only, pdgsrfs3d); on return the same rows of the solution of the PERMUTED system (pdgssvx3d applies Pc^T itself). */
 #ifndef Z_PREC
-/* pdgstrs3d / pdgstrs3d_newsolve (pdgstrs3d.c:6604 / :6935): B holds this rank's m_loc rows (from fst_row) of the
- * right-hand side in the ORIGINAL row order, replicated on every Z layer; on return the same rows of the solution of the
- * permuted system.  The reference redistributes B -> x blocks (pdReDistribute3d_B_to_X, :6265), solves, and redistributes
- * back (:6404); here: gather the complete permuted right-hand side (row i of B goes to row perm_c[perm_r[i]]), one
- * collective library solve on the device-resident factors, keep the local rows. */
+/* double: B stays distributed -- row i of B goes to row perm_c[perm_r[i]] of the factored system inside the library
+ * (pdReDistribute3d_B_to_X, :6265), the solution rows come back the same way (pdReDistribute3d_X_to_B, :6404) */
 static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, double *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
                        SuperLUStat_t *stat, int *info)
 {
@@ -295,41 +342,56 @@ static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, do
     if (nrhs < 0) { *info = -9; return; }
     if (!G.h || G.n != n) ABORT("sluamd binding: pdgstrs3d called without a factorisation on the device");
     if (nrhs == 0) return;
-    gridinfo_t *grid = &grid3d->grid2d;
-    int P2; MPI_Comm_size(grid->comm, &P2);
-    int *cnt = (int *) malloc(sizeof(int) * 2 * P2), *dsp = cnt + P2;
-    int mine = (int) m_loc;
-    MPI_Allgather(&mine, 1, MPI_INT, cnt, 1, MPI_INT, grid->comm);
-    int tot = 0;
-    for (int q = 0; q < P2; ++q) { dsp[q] = tot; tot += cnt[q]; }
-    if (tot != n || dsp[grid->iam] != fst_row) ABORT("sluamd binding: unexpected row distribution of B");
-    double *col = (double *) malloc(sizeof(double) * (size_t) n), *xp = (double *) malloc(sizeof(double) * (size_t) n * nrhs);
+    static sluamd_int_t *perm = NULL; static int_t perm_n = -1;
+    if (perm_n != n) { free(perm); perm = (sluamd_int_t *) malloc(sizeof(sluamd_int_t) * (size_t) (n ? n : 1)); perm_n = n; }
+    for (int_t i = 0; i < n; ++i) perm[i] = (sluamd_int_t) SP->perm_c[SP->perm_r[i]];
+    const int layer0 = grid3d->zscp.Iam == 0;
     double t0 = SuperLU_timer_();
-    for (int j = 0; j < nrhs; ++j) {
-        MPI_Allgatherv(B + (size_t) j * ldb, (int) m_loc, MPI_DOUBLE, col, cnt, dsp, MPI_DOUBLE, grid->comm);
-        for (int_t i = 0; i < n; ++i) xp[SP->perm_c[SP->perm_r[i]] + (size_t) j * n] = col[i];
-    }
-    /* refinement-step right-hand sides are only valid on layer 0 (pdgsrfs3d works on the layer-0 2-D grid): take layer 0's */
-    if (grid3d->npdep > 1) MPI_Bcast(xp, (int) ((size_t) n * nrhs), MPI_DOUBLE, 0, grid3d->zscp.comm);
-    if (S.solve(G.h, xp, n, nrhs)) ABORT(S.last_error());
-    for (int j = 0; j < nrhs; ++j)
-        for (int_t i = 0; i < m_loc; ++i) B[i + (size_t) j * ldb] = xp[fst_row + i + (size_t) j * n];
+    if (S.solve_dist(G.h, B, ldb, nrhs, layer0 ? (int64_t) m_loc : 0, layer0 ? (int64_t) fst_row : 0, perm, NULL)) ABORT(S.last_error());
     stat->utime[SOLVE] = SuperLU_timer_() - t0;
-    free(col); free(xp); free(cnt);
 }
-
-void sluamd_bind_pdgstrs3d_newsolve(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct, xScalePermstruct_t *SP,
-                                    xtrf3Dpartition_t *part, gridinfo3d_t *grid3d, double *B, int_t m_loc, int_t fst_row, int_t ldb,
-                                    int nrhs, xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
+#define BIND_SOLVE_NEW sluamd_bind_pdgstrs3d_newsolve
+#define BIND_SOLVE_OLD sluamd_bind_pdgstrs3d
+typedef double bind_scalar_t;
+#else
+/* complex16 (1 x 1 x npdep grids): the library's complex solve takes the complete permuted right-hand side */
+static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, doublecomplex *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
+                       SuperLUStat_t *stat, int *info)
 {
-    (void) options; (void) LUstruct; (void) part; (void) SOLVEstruct;
-    bind_solve(n, SP, grid3d, B, m_loc, fst_row, ldb, nrhs, stat, info);
+    *info = 0;
+    if (n < 0) { *info = -1; return; }
+    if (nrhs < 0) { *info = -9; return; }
+    if (!G.h || G.n != n) ABORT("sluamd binding: pzgstrs3d called without a factorisation on the device");
+    if (nrhs == 0) return;
+    if (m_loc != n || fst_row != 0) ABORT("sluamd binding: complex16 solves run on 1 x 1 x npdep grids (every layer-0 rank holds all rows)");
+    sluamd_doublecomplex *xp = (sluamd_doublecomplex *) malloc(sizeof(sluamd_doublecomplex) * (size_t) n * nrhs);
+    if (!xp) ABORT("sluamd binding: out of memory");
+    double t0 = SuperLU_timer_();
+    for (int j = 0; j < nrhs; ++j)
+        for (int_t i = 0; i < n; ++i) { const doublecomplex b = B[i + (size_t) j * ldb]; sluamd_doublecomplex *d = &xp[SP->perm_c[SP->perm_r[i]] + (size_t) j * n]; d->r = b.r; d->i = b.i; }
+    if (grid3d->npdep > 1) MPI_Bcast(xp, (int) (2 * (size_t) n * nrhs), MPI_DOUBLE, 0, grid3d->zscp.comm);   /* layer 0's right-hand side */
+    if (S.zsolve(G.h, xp, n, nrhs)) ABORT(S.last_error());
+    for (int j = 0; j < nrhs; ++j)
+        for (int_t i = 0; i < n; ++i) { B[i + (size_t) j * ldb].r = xp[i + (size_t) j * n].r; B[i + (size_t) j * ldb].i = xp[i + (size_t) j * n].i; }
+    stat->utime[SOLVE] = SuperLU_timer_() - t0;
+    free(xp);
 }
-void sluamd_bind_pdgstrs3d(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct, xScalePermstruct_t *SP,
-                           xtrf3Dpartition_t *part, gridinfo3d_t *grid3d, double *B, int_t m_loc, int_t fst_row, int_t ldb,
-                           int nrhs, xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
-{
-    (void) options; (void) LUstruct; (void) part; (void) SOLVEstruct;
-    bind_solve(n, SP, grid3d, B, m_loc, fst_row, ldb, nrhs, stat, info);
-}
+#define BIND_SOLVE_NEW sluamd_bind_pzgstrs3d_newsolve
+#define BIND_SOLVE_OLD sluamd_bind_pzgstrs3d
+typedef doublecomplex bind_scalar_t;
 #endif
+
+void BIND_SOLVE_NEW(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct, xScalePermstruct_t *SP,
+                    xtrf3Dpartition_t *part, gridinfo3d_t *grid3d, bind_scalar_t *B, int_t m_loc, int_t fst_row, int_t ldb,
+                    int nrhs, xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
+{
+    (void) options; (void) LUstruct; (void) part; (void) SOLVEstruct;
+    bind_solve(n, SP, grid3d, B, m_loc, fst_row, ldb, nrhs, stat, info);
+}
+void BIND_SOLVE_OLD(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct, xScalePermstruct_t *SP,
+                    xtrf3Dpartition_t *part, gridinfo3d_t *grid3d, bind_scalar_t *B, int_t m_loc, int_t fst_row, int_t ldb,
+                    int nrhs, xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
+{
+    (void) options; (void) LUstruct; (void) part; (void) SOLVEstruct;
+    bind_solve(n, SP, grid3d, B, m_loc, fst_row, ldb, nrhs, stat, info);
+}

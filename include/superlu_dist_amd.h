@@ -291,8 +291,20 @@ int sluamd_dCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, cons
 int sluamd_zCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
                                        const sluamd_doublecomplex *nzval, const sluamd_int_t *perm_c_final,
                                        const sluamd_options_t *opt, const int32_t *sn_tree, sluamd_comm_t comm);
-/* Grid solve semantics (pdgstrs3d between pdReDistribute3d_B_to_X and pdReDistribute3d_X_to_B): every rank passes the
- * COMPLETE permuted right-hand side x = Pc*Pr*b (n x nrhs, replicated) and every rank receives the complete solution. */
+/* Grid solve, replicated form (sluamd_pdgstrs3d[_dev] on a grid handle): every rank passes the COMPLETE permuted right-hand side
+ * x = Pc*Pr*b (n x nrhs) and every rank receives the complete solution (direct all-gather of the owners' rows).
+ *
+ * Grid solve, distributed form = the boundary of the reference's pdgstrs3d[_newsolve] (pdgstrs3d.c:6604, :6935) including
+ * pdReDistribute3d_B_to_X (:6265) and pdReDistribute3d_X_to_B (:6404): B is distributed by block rows over the processes of
+ * layer 0 -- this rank holds rows [fst_row, fst_row + m_loc) of the ORIGINAL right-hand side, column-major with leading dimension
+ * ldb (NRformat_loc); ranks of the other layers pass m_loc = 0 -- and is overwritten by rows of the solved vector y (L U y = x).
+ * perm_in[i]  = row of the factored system that row i of B goes to: x[perm_in[i]] = B[i], i.e. ScalePermstruct->perm_c[perm_r[i]];
+ * perm_out[i] = row of y returned in row i: B[i] = y[perm_out[i]].  The reference returns the rows of the PERMUTED solution
+ *               (perm_out = identity; pdgssvx3d applies Pc^T itself); perm_out = perm_c gives x in the original order.
+ * Both are replicated on every rank; NULL = identity.  Every row travels once to the rank that consumes it and every row of the
+ * solution once back; nothing is replicated.  Collective on grid handles; works on single-rank handles too (m_loc = n). */
+int sluamd_pdgstrs3d_dist(sluamd_handle_t h, double *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row,
+                          const sluamd_int_t *perm_in, const sluamd_int_t *perm_out);
 
 #ifdef __cplusplus
 }

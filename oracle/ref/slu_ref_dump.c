@@ -196,7 +196,7 @@ int_t WRAP(gstrf3d)(superlu_dist_options_t *options, int m, int n, double anorm,
         put_intt(nm, sf->topoInfo.numLvl + 1, sf->topoInfo.eTreeTopLims);
     }
     if (g_out) dump_lu("pre", LUstruct, grid, 0);
-#ifdef USE_SLUAMD   /* slu_ref_amd: the reference pipeline with OUR numeric factorisation (oracle/ref/sluamd_binding.c) */
+#ifdef USE_SLUAMD   /* slu_ref_amd: the reference pipeline with OUR numeric factorisation (bindings/superlu_dist/sluamd_binding.c) */
 #ifdef Z_PREC
 #define BIND_NAME sluamd_bind_pzgstrf3d
 #else
@@ -247,11 +247,18 @@ void WRAP(gstrs3d_newsolve)(superlu_dist_options_t *options, int_t n, xLUstruct_
                                xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
 {
     dump_solve("newsolve", n, SP, B, m_loc, fst_row, ldb, nrhs, 0);
-#if defined(USE_SLUAMD) && !defined(Z_PREC)   /* slu_ref_amd: OUR triangular solves on the device-resident factors (SLUAMD_BIND_SOLVE=0: the reference's) */
-    extern void sluamd_bind_pdgstrs3d_newsolve(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *, xtrf3Dpartition_t *,
-                                               gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int, xSOLVEstruct_t *, SuperLUStat_t *, int *);
+#if defined(USE_SLUAMD)   /* slu_ref_amd / slu_ref_zamd: OUR triangular solves on the device-resident factors (SLUAMD_BIND_SOLVE=0: the reference's) */
+#ifdef Z_PREC
+#define BIND_SOLVE_NEW sluamd_bind_pzgstrs3d_newsolve
+#define BIND_SOLVE_OLD sluamd_bind_pzgstrs3d
+#else
+#define BIND_SOLVE_NEW sluamd_bind_pdgstrs3d_newsolve
+#define BIND_SOLVE_OLD sluamd_bind_pdgstrs3d
+#endif
+    extern void BIND_SOLVE_NEW(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *, xtrf3Dpartition_t *,
+                               gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int, xSOLVEstruct_t *, SuperLUStat_t *, int *);
     if (!getenv("SLUAMD_BIND_SOLVE") || atoi(getenv("SLUAMD_BIND_SOLVE")))
-        sluamd_bind_pdgstrs3d_newsolve(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs, SOLVEstruct, stat, info);
+        BIND_SOLVE_NEW(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs, SOLVEstruct, stat, info);
     else
 #endif
     REAL(gstrs3d_newsolve)(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,
@@ -268,11 +275,11 @@ void WRAP(gstrs3d)(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstru
                       xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
 {
     dump_solve("legacy", n, SP, B, m_loc, fst_row, ldb, nrhs, 0);
-#if defined(USE_SLUAMD) && !defined(Z_PREC)
-    extern void sluamd_bind_pdgstrs3d(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *, xtrf3Dpartition_t *,
-                                      gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int, xSOLVEstruct_t *, SuperLUStat_t *, int *);
+#if defined(USE_SLUAMD)
+    extern void BIND_SOLVE_OLD(superlu_dist_options_t *, int_t, xLUstruct_t *, xScalePermstruct_t *, xtrf3Dpartition_t *,
+                               gridinfo3d_t *, scalar_t *, int_t, int_t, int_t, int, xSOLVEstruct_t *, SuperLUStat_t *, int *);
     if (!getenv("SLUAMD_BIND_SOLVE") || atoi(getenv("SLUAMD_BIND_SOLVE")))
-        sluamd_bind_pdgstrs3d(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs, SOLVEstruct, stat, info);
+        BIND_SOLVE_OLD(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs, SOLVEstruct, stat, info);
     else
 #endif
     REAL(gstrs3d)(options, n, LUstruct, SP, part, grid3d, B, m_loc, fst_row, ldb, nrhs,

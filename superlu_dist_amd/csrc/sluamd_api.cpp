@@ -380,6 +380,35 @@ int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nr
     return chain_check(H);
 }
 
+int sluamd_pdgstrs3d_dist(sluamd_handle_t h, double *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row, const sluamd_int_t *perm_in,
+                          const sluamd_int_t *perm_out)
+{
+    if (!h || nrhs < 0 || m_loc < 0 || fst_row < 0 || fst_row + m_loc > h->H.hs.n || (m_loc > 0 && (!B || ldb < m_loc))) { set_error("bad distributed-solve arguments"); return SLUAMD_EINVAL; }
+    if (h->H.z) { set_error("complex16 handle: call sluamd_pzgstrs3d"); return SLUAMD_EINVAL; }
+    if (nrhs == 0) return 0;
+    Handle *H = &h->H;
+    HIPCHK(hipSetDevice(H->device));
+    const int64_t need = std::max<int64_t>(m_loc, 1) * nrhs;
+    if (need > H->bloc_cap) {
+        if (H->d_bloc) hipFree(H->d_bloc);
+        H->d_bloc = nullptr; H->bloc_cap = 0;
+        HIPCHK(hipMalloc((void **) &H->d_bloc, sizeof(double) * (size_t) need));
+        H->bloc_cap = need;
+    }
+    const int64_t ldd = std::max<int64_t>(m_loc, 1);
+    for (int q = 0; q < nrhs && m_loc; ++q) HIPCHK(hipMemcpy(H->d_bloc + (size_t) q * ldd, B + (size_t) q * ldb, sizeof(double) * (size_t) m_loc, hipMemcpyHostToDevice));
+    HIPCHK(hipEventRecord(H->ev0, H->stream));
+    int rc = run_solve_dist(H, H->d_bloc, ldd, nrhs, m_loc, fst_row, perm_in, perm_out);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(H->ev1, H->stream));
+    HIPCHK(hipStreamSynchronize(H->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
+    H->st.t_solve_ms = ms;
+    if ((rc = chain_check(H))) return rc;
+    for (int q = 0; q < nrhs && m_loc; ++q) HIPCHK(hipMemcpy(B + (size_t) q * ldb, H->d_bloc + (size_t) q * ldd, sizeof(double) * (size_t) m_loc, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs)
 {
     if (!h || !x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
@@ -512,6 +541,8 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_aval) hipFree(H->d_aval);
     if (H->h_pinned) hipHostFree(H->h_pinned);
     if (H->chain_abort) hipHostFree(H->chain_abort);
+    if (H->d_bloc) hipFree(H->d_bloc);
+    for (void *q : H->dist.bufs) hipFree(q);
     free_rfs(H);
     for (auto &e : H->ev_schur) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : H->ev_panel) { hipEventDestroy(e.first); hipEventDestroy(e.second); }

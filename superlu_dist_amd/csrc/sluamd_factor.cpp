@@ -587,22 +587,150 @@ static const LevelSched::XSeg &forest_runs(Handle *H, int a0, int role)
     return c;
 }
 
-// pdgstrs3d on the grid: d_x holds the COMPLETE permuted right-hand side on entry (replicated) and the complete solution
-// on return.  Z sweeps as pdgsTrForwardSolve3d / pdgsTrBackSolve3d (pdgstrs3d.c:7312, :7564): forward reduction of the
-// ancestor rows to the partner layer (dfsolveReduceLsum3d :1646), backward hand-down of the solved ancestors
-// (dp2pSolvedX3d :1596).
+// every rank's owner rows -- the rows whose x is final on that rank after the sweeps (diagonal owner, on the layer that factors
+// the forest) -- learnt once per handle: all-to-all of the run lists over the host-buffer channel
+static int ensure_owner_runs(Handle *H)
+{
+    if (H->owner_ready) return 0;
+    const Grid &g = H->grid;
+    const int P = g.size(), me = g.rank();
+    LevelSched::XSeg mine = forest_runs(H, 0, 3);
+    H->owner_runs.assign(P, LevelSched::XSeg());
+    mine.peer = me;
+    H->owner_runs[me] = mine;
+    if (P > 1) {
+        Comm *c = H->comm;
+        int rc;
+        std::vector<int> flat;
+        for (auto &r : mine.runs) { flat.push_back(r.first); flat.push_back(r.second); }
+        std::vector<int64_t> lens(P, 0);
+        int64_t mylen = (int64_t) flat.size();
+        if ((rc = c->hbegin())) return rc;
+        for (int p = 0; p < P; ++p) if (p != me) { if ((rc = c->hsend(&mylen, 8, p))) return rc; if ((rc = c->hrecv(&lens[p], 8, p))) return rc; }
+        if ((rc = c->hend())) return rc;
+        std::vector<std::vector<int>> all(P);
+        if ((rc = c->hbegin())) return rc;
+        for (int p = 0; p < P; ++p) {
+            if (p == me) continue;
+            all[p].resize((size_t) lens[p]);
+            if (mylen && (rc = c->hsend(flat.data(), mylen * 4, p))) return rc;
+            if (lens[p] && (rc = c->hrecv(all[p].data(), lens[p] * 4, p))) return rc;
+        }
+        if ((rc = c->hend())) return rc;
+        for (int p = 0; p < P; ++p) {
+            if (p == me) continue;
+            LevelSched::XSeg &m = H->owner_runs[p];
+            m.peer = p;
+            for (size_t i = 0; i + 1 < all[p].size(); i += 2) { m.runs.emplace_back(all[p][i], all[p][i + 1]); m.total += all[p][i + 1]; }
+        }
+    }
+    H->owner_ready = true;
+    return 0;
+}
+
+// all-gather of the solution: every rank packs its owner rows ONCE and sends them to every other rank directly, one grouped
+// exchange (xGMI is a full mesh: P - 1 concurrent links per GPU) -- not a gather on rank 0 followed by P - 1 full-vector sends
+static int allgather_solution(Handle *H, double *x, int64_t ldxd, int nr, hipStream_t s)
+{
+    int rc = ensure_owner_runs(H);
+    if (rc) return rc;
+    const Grid &g = H->grid;
+    const int P = g.size(), me = g.rank();
+    Comm *c = H->comm;
+    const LevelSched::XSeg &mine = H->owner_runs[me];
+    int64_t need = mine.total * nr;
+    for (int p = 0; p < P; ++p) if (p != me) need += H->owner_runs[p].total * nr;
+    if ((rc = ensure_xtmp(H, std::max<int64_t>(need, 1)))) return rc;
+    const int *dr;
+    if (mine.total) {
+        if ((rc = runs_on_device(H, mine, &dr))) return rc;
+        eng::xseg_copy(s, x, ldxd, nr, dr, (int) mine.runs.size(), mine.total, H->d_xtmp, 0);
+    }
+    std::vector<int64_t> ro(P, 0);
+    int64_t off = mine.total * nr;
+    if ((rc = c->begin())) return rc;
+    for (int p = 0; p < P; ++p) {
+        if (p == me) continue;
+        if (mine.total && (rc = c->send(H->d_xtmp, mine.total * nr * 8, p))) return rc;
+        const int64_t t = H->owner_runs[p].total * nr;
+        ro[p] = off;
+        if (t && (rc = c->recv(H->d_xtmp + off, t * 8, p))) return rc;
+        off += t;
+    }
+    if ((rc = c->end(s))) return rc;
+    for (int p = 0; p < P; ++p) {
+        const LevelSched::XSeg &m = H->owner_runs[p];
+        if (p == me || !m.total) continue;
+        if ((rc = runs_on_device(H, m, &dr))) return rc;
+        eng::xseg_copy(s, x, ldxd, nr, dr, (int) m.runs.size(), m.total, H->d_xtmp + ro[p], 1);
+    }
+    if (!c->stream_ordered()) HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// forward and backward sweeps of one right-hand-side chunk on the grid.  On entry x holds b at the rows this rank consumes (diagonal
+// owner on the factoring layer) and zeros elsewhere; on return x_k is final at those rows.  Z sweeps as pdgsTrForwardSolve3d /
+// pdgsTrBackSolve3d (pdgstrs3d.c:7312, :7564): forward reduction of the ancestor rows to the partner layer (dfsolveReduceLsum3d
+// :1646), backward hand-down of the solved ancestors (dp2pSolvedX3d :1596).
+static int grid_sweeps(Handle *H, double *x, int64_t ldx, int nr)
+{
+    const Grid &g = H->grid;
+    const int nzl = (int) H->sched.size();
+    hipStream_t s = H->stream;
+    const int vs = H->z ? 2 : 1;
+    const int64_t ldxd = ldx * vs;
+    int rc;
+    // ---- forward sweep, leaves to root ----
+    for (int zl = 0; zl < nzl; ++zl) {
+        const int step = 1 << zl;
+        if (g.z % step) break;
+        if (H->z_active[zl] && (rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
+        if (zl + 1 < nzl) {
+            const bool receiver = (g.z % (2 * step)) == 0;
+            if (receiver && g.z + step >= g.Pz) continue;
+            LevelSched::XSeg seg = forest_runs(H, zl + 1, 0);        // (copy shares the cached device image)
+            seg.peer = g.rank_of(g.r, g.c, receiver ? g.z + step : g.z - step);
+            std::vector<LevelSched::XSeg> one(1, seg), none;
+            if (seg.total && (rc = receiver ? xseg_exchange(H, x, ldxd, nr, none, 0, one, 2, s) : xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s))) return rc;
+        }
+    }
+    // ---- backward sweep, root to leaves ----
+    for (int zl = nzl - 1; zl >= 0; --zl) {
+        const int step = 1 << zl;
+        if (g.z % step) continue;
+        if (zl + 1 < nzl) {
+            const bool sender = (g.z % (2 * step)) == 0;
+            if (!(sender && g.z + step >= g.Pz)) {
+                LevelSched::XSeg seg = forest_runs(H, zl + 1, 1);
+                seg.peer = g.rank_of(g.r, g.c, sender ? g.z + step : g.z - step);
+                std::vector<LevelSched::XSeg> one(1, seg), none;
+                if (seg.total && (rc = sender ? xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldxd, nr, none, 0, one, 1, s))) return rc;
+            }
+        }
+        if (H->z_active[zl] && (rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
+    }
+    return 0;
+}
+
+static int grid_solve_checks(Handle *H)
+{
+    const Grid &g = H->grid;
+    if (!H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
+    if (!H->dinv_ready) { set_error("grid solve needs the factorisation to have run on this handle"); return SLUAMD_EINVAL; }
+    if (H->z && g.Pr * g.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
+    return H->z ? 0 : ensure_inv(H);
+}
+
+// pdgstrs3d on the grid, replicated form: d_x holds the COMPLETE permuted right-hand side on entry (on every rank) and the
+// complete solution on return.  (sluamd_pdgstrs3d_dist keeps B distributed like the reference.)
 int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
 {
     const Grid &g = H->grid;
     if (g.size() == 1) return run_solve_local(H, d_x, ldx, nrhs);
-    if (!H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
-    if (!H->dinv_ready) { set_error("grid solve needs the factorisation to have run on this handle"); return SLUAMD_EINVAL; }
-    const int nzl = (int) H->sched.size();
+    int rc = grid_solve_checks(H);
+    if (rc) return rc;
     hipStream_t s = H->stream;
     const int ch = max_rhs_chunk(H);
-    int rc;
-    if (!H->z && (rc = ensure_inv(H))) return rc;
-    if (H->z && g.Pr * g.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
     // complex16: the exchanges see the right-hand sides as real arrays of 2 n rows (run lists in doubles, leading dimension ldxd);
     // the sweeps get the complex view (ldx)
     const int vs = H->z ? 2 : 1;
@@ -620,80 +748,181 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
             eng::xseg_copy(s, x, ldxd, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 0);
             for (int q = 0; q < nr; ++q) HIPCHK(hipMemsetAsync(x + (size_t) q * ldxd, 0, sizeof(double) * (size_t) H->hs.n * vs, s));
             eng::xseg_copy(s, x, ldxd, nr, dr, (int) keep.runs.size(), keep.total, H->d_xtmp, 1);
-            HIPCHK(hipStreamSynchronize(s));
+            if (!H->comm->stream_ordered()) HIPCHK(hipStreamSynchronize(s));
         }
-        // ---- forward sweep, leaves to root ----
-        for (int zl = 0; zl < nzl; ++zl) {
-            const int step = 1 << zl;
-            if (g.z % step) break;
-            if (H->z_active[zl] && (rc = solve_fwd_z(H, zl, x, ldx, nr))) return rc;
-            if (zl + 1 < nzl) {
-                const bool receiver = (g.z % (2 * step)) == 0;
-                if (receiver && g.z + step >= g.Pz) continue;
-                LevelSched::XSeg seg = forest_runs(H, zl + 1, 0);        // (copy shares the cached device image)
-                seg.peer = g.rank_of(g.r, g.c, receiver ? g.z + step : g.z - step);
-                std::vector<LevelSched::XSeg> one(1, seg), none;
-                if (seg.total && (rc = receiver ? xseg_exchange(H, x, ldxd, nr, none, 0, one, 2, s) : xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s))) return rc;
-            }
+        if ((rc = grid_sweeps(H, x, ldx, nr))) return rc;
+        // every x_k is final at its diagonal owner on the layer that factored its forest: all-gather
+        if ((rc = allgather_solution(H, x, ldxd, nr, s))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ================================================================================================
+//        distributed right-hand side at the solve boundary: pdReDistribute3d_B_to_X / X_to_B
+// ================================================================================================
+static uint64_t hash_perm(const int *perm, int64_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    if (perm) for (int64_t i = 0; i < n; ++i) { h ^= (uint32_t) perm[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+static void free_dist_plan(Handle *H)
+{
+    for (void *p : H->dist.bufs) hipFree(p);
+    H->dist = Handle::DistPlan();
+}
+
+// Routing of the caller's rows of B (row-block distribution over the ranks of layer 0: m_loc rows from fst_row, NRformat_loc) to
+// the ranks that consume them in the sweeps (through perm_in) and of the solution back (through perm_out).  Both sides of a pair
+// derive matching lists from replicated data (the permutation, every rank's range and owner rows): the rows between one pair of
+// ranks travel in ascending order of the row of x.
+static int build_route(Handle *H, const std::vector<int> &src_rank, const std::vector<int> &owner, int64_t m_loc, int64_t fst_row,
+                       const int *perm, Handle::DistRoute &R, std::vector<void *> &bufs)
+{
+    const Grid &g = H->grid;
+    const int P = g.size(), me = g.rank();
+    const int64_t n = H->hs.n;
+    std::vector<int> iperm(n, -1);
+    for (int64_t i = 0; i < n; ++i) {
+        const int q = perm ? perm[i] : (int) i;
+        if (q < 0 || q >= n || iperm[q] >= 0) { set_error("sluamd_pdgstrs3d_dist: perm is not a permutation"); return SLUAMD_EINVAL; }
+        iperm[q] = (int) i;
+    }
+    std::vector<std::vector<std::pair<int, int>>> bs(P);     // my rows of B: (row of x, local row), bucketed by the owner of the row of x
+    for (int64_t i = 0; i < m_loc; ++i) {
+        const int q = perm ? perm[fst_row + i] : (int) (fst_row + i);
+        if (owner[q] < 0) { set_error("sluamd_pdgstrs3d_dist: a row of the system has no owner in this grid"); return SLUAMD_ESTRUCT; }
+        bs[owner[q]].emplace_back(q, (int) i);
+    }
+    std::vector<std::vector<int>> xs(P);                     // my owner rows of x (ascending), bucketed by the rank that holds the paired row of B
+    for (auto &r : H->owner_runs[me].runs) for (int q = r.first; q < r.first + r.second; ++q) xs[src_rank[iperm[q]]].push_back(q);
+    R.cnt_b.assign(P, 0); R.cnt_x.assign(P, 0); R.d_bidx.assign(P, nullptr); R.d_xidx.assign(P, nullptr);
+    for (int p = 0; p < P; ++p) {
+        std::sort(bs[p].begin(), bs[p].end());
+        std::vector<int> bi(bs[p].size());
+        for (size_t j = 0; j < bi.size(); ++j) bi[j] = bs[p][j].second;
+        R.cnt_b[p] = (int64_t) bi.size(); R.cnt_x[p] = (int64_t) xs[p].size();
+        if (!bi.empty() && upload(bufs, bi, &R.d_bidx[p])) return SLUAMD_EHIP;
+        if (!xs[p].empty() && upload(bufs, xs[p], &R.d_xidx[p])) return SLUAMD_EHIP;
+    }
+    if (R.cnt_b[me] != R.cnt_x[me]) { set_error("sluamd_pdgstrs3d_dist: inconsistent routing tables"); return SLUAMD_ESTRUCT; }
+    return 0;
+}
+
+static int build_dist_plan(Handle *H, int64_t m_loc, int64_t fst_row, const int *perm_in, const int *perm_out)
+{
+    const Grid &g = H->grid;
+    const int P = g.size(), me = g.rank();
+    const int64_t n = H->hs.n;
+    int rc = ensure_owner_runs(H);
+    if (rc) return rc;
+    free_dist_plan(H);
+    Handle::DistPlan &D = H->dist;
+    // every rank's range
+    std::vector<int64_t> rng(2 * (size_t) P, 0);
+    rng[2 * me] = fst_row; rng[2 * me + 1] = m_loc;
+    if (P > 1) {
+        Comm *c = H->comm;
+        if ((rc = c->hbegin())) return rc;
+        for (int p = 0; p < P; ++p) if (p != me) { if ((rc = c->hsend(&rng[2 * me], 16, p))) return rc; if ((rc = c->hrecv(&rng[2 * p], 16, p))) return rc; }
+        if ((rc = c->hend())) return rc;
+    }
+    std::vector<int> src_rank(n, -1);       // original row -> the rank that holds it in B
+    int64_t covered = 0;
+    for (int p = 0; p < P; ++p) {
+        const int64_t f = rng[2 * p], m = rng[2 * p + 1];
+        if (m < 0 || f < 0 || f + m > n) { set_error("sluamd_pdgstrs3d_dist: a rank's row range lies outside the matrix"); return SLUAMD_EINVAL; }
+        for (int64_t i = f; i < f + m; ++i) { if (src_rank[i] >= 0) { set_error("sluamd_pdgstrs3d_dist: the row ranges of two ranks overlap"); return SLUAMD_EINVAL; } src_rank[i] = p; }
+        covered += m;
+    }
+    if (covered != n) { set_error("sluamd_pdgstrs3d_dist: the ranks' row ranges do not cover the matrix"); return SLUAMD_EINVAL; }
+    std::vector<int> owner(n, -1);          // row of x -> the rank where it is consumed / final
+    for (int p = 0; p < P; ++p)
+        for (auto &r : H->owner_runs[p].runs) for (int i = r.first; i < r.first + r.second; ++i) owner[i] = p;
+    D.hash_in = hash_perm(perm_in, n); D.hash_out = hash_perm(perm_out, n);
+    D.same = D.hash_in == D.hash_out && (!perm_in) == (!perm_out);
+    if ((rc = build_route(H, src_rank, owner, m_loc, fst_row, perm_in, D.in, D.bufs))) return rc;
+    if (!D.same && (rc = build_route(H, src_rank, owner, m_loc, fst_row, perm_out, D.out, D.bufs))) return rc;
+    D.m_loc = m_loc; D.fst_row = fst_row; D.ready = true;
+    return 0;
+}
+
+// one direction of the redistribution for one chunk of right-hand sides: b2x = rows of d_b (local, ld ldb) -> rows of x; else back
+static int redistribute(Handle *H, bool b2x, double *d_b, int64_t ldb, double *x, int64_t ldx, int nr, hipStream_t s)
+{
+    const Grid &g = H->grid;
+    const int P = g.size(), me = g.rank();
+    const Handle::DistRoute &R = (b2x || H->dist.same) ? H->dist.in : H->dist.out;
+    const std::vector<int64_t> &cs = b2x ? R.cnt_b : R.cnt_x, &cr = b2x ? R.cnt_x : R.cnt_b;
+    int64_t need = 0;
+    for (int p = 0; p < P; ++p) need += (cs[p] + (p == me ? 0 : cr[p])) * nr;
+    int rc = ensure_xtmp(H, std::max<int64_t>(need, 1));
+    if (rc) return rc;
+    std::vector<int64_t> so(P), ro(P);
+    int64_t off = 0;
+    for (int p = 0; p < P; ++p) {     // pack
+        so[p] = off; off += cs[p] * nr;
+        if (b2x) eng::rows_copy(s, d_b, ldb, nr, R.d_bidx[p], cs[p], H->d_xtmp + so[p], 0);
+        else eng::rows_copy(s, x, ldx, nr, R.d_xidx[p], cs[p], H->d_xtmp + so[p], 0);
+    }
+    for (int p = 0; p < P; ++p) { ro[p] = (p == me) ? so[p] : off; if (p != me) off += cr[p] * nr; }     // my own rows need no transport
+    if (P > 1) {
+        Comm *c = H->comm;
+        if ((rc = c->begin())) return rc;
+        for (int p = 0; p < P; ++p) {
+            if (p == me) continue;
+            if (cs[p] && (rc = c->send(H->d_xtmp + so[p], cs[p] * nr * 8, p))) return rc;
+            if (cr[p] && (rc = c->recv(H->d_xtmp + ro[p], cr[p] * nr * 8, p))) return rc;
         }
-        // ---- backward sweep, root to leaves ----
-        for (int zl = nzl - 1; zl >= 0; --zl) {
-            const int step = 1 << zl;
-            if (g.z % step) continue;
-            if (zl + 1 < nzl) {
-                const bool sender = (g.z % (2 * step)) == 0;
-                if (!(sender && g.z + step >= g.Pz)) {
-                    LevelSched::XSeg seg = forest_runs(H, zl + 1, 1);
-                    seg.peer = g.rank_of(g.r, g.c, sender ? g.z + step : g.z - step);
-                    std::vector<LevelSched::XSeg> one(1, seg), none;
-                    if (seg.total && (rc = sender ? xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s) : xseg_exchange(H, x, ldxd, nr, none, 0, one, 1, s))) return rc;
-                }
-            }
-            if (H->z_active[zl] && (rc = solve_bwd_z(H, zl, x, ldx, nr))) return rc;
+        if ((rc = c->end(s))) return rc;
+    }
+    for (int p = 0; p < P; ++p) {     // unpack
+        if (b2x) eng::rows_copy(s, x, ldx, nr, R.d_xidx[p], cr[p], H->d_xtmp + ro[p], 1);
+        else eng::rows_copy(s, d_b, ldb, nr, R.d_bidx[p], cr[p], H->d_xtmp + ro[p], 1);
+    }
+    if (P > 1 && !H->comm->stream_ordered()) HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// pdgstrs3d with B distributed as in the reference (pdgstrs3d.c:6604-6933): the ranks of layer 0 hold m_loc consecutive rows of B
+// from fst_row (ORIGINAL row order), the other layers none; perm[i] = row of the factored system that row i of B belongs to
+// (perm_c[perm_r[i]], pdReDistribute3d_B_to_X :6265).  d_b: the local rows on the device (ld ldb), overwritten by the local rows
+// of the solution: row i = row perm_out[i] of the solved vector (pdReDistribute3d_X_to_B :6404 returns the rows of the solution of
+// the PERMUTED system, perm_out = identity; pdgssvx3d applies Pc^T afterwards).  Collective.
+int run_solve_dist(Handle *H, double *d_b, int64_t ldb, int nrhs, int64_t m_loc, int64_t fst_row, const int *perm, const int *perm_out)
+{
+    const Grid &g = H->grid;
+    int rc;
+    if (g.size() > 1) { if ((rc = grid_solve_checks(H))) return rc; }
+    else if (!H->z && (rc = ensure_inv(H))) return rc;
+    if (H->z) { set_error("sluamd_pdgstrs3d_dist: double precision handles only"); return SLUAMD_EINVAL; }
+    if (!H->dist.ready || H->dist.m_loc != m_loc || H->dist.fst_row != fst_row || H->dist.hash_in != hash_perm(perm, H->hs.n) ||
+        H->dist.hash_out != hash_perm(perm_out, H->hs.n))
+        if ((rc = build_dist_plan(H, m_loc, fst_row, perm, perm_out))) return rc;
+    hipStream_t s = H->stream;
+    const int64_t n = H->hs.n;
+    const int ch = max_rhs_chunk(H);
+    const int64_t need = n * std::min(ch, nrhs);
+    if (need > H->x_cap) {
+        if (H->d_x) hipFree(H->d_x);
+        H->d_x = nullptr; H->x_cap = 0;
+        HIPCHK(hipMalloc((void **) &H->d_x, sizeof(double) * (size_t) need));
+        H->x_cap = need;
+    }
+    for (int j0 = 0; j0 < nrhs; j0 += ch) {
+        const int nr = std::min(ch, nrhs - j0);
+        double *b = d_b + (size_t) j0 * ldb;
+        HIPCHK(hipMemsetAsync(H->d_x, 0, sizeof(double) * (size_t) n * nr, s));       // zero accumulators everywhere but the consumed rows
+        if ((rc = redistribute(H, true, b, ldb, H->d_x, n, nr, s))) return rc;
+        if (g.size() > 1) { if ((rc = grid_sweeps(H, H->d_x, n, nr))) return rc; }
+        else {
+            for (int z = 0; z < (int) H->sched.size(); ++z) if ((rc = solve_fwd_z(H, z, H->d_x, n, nr))) return rc;
+            for (int z = (int) H->sched.size() - 1; z >= 0; --z) if ((rc = solve_bwd_z(H, z, H->d_x, n, nr))) return rc;
         }
-        // ---- assemble: every x_k is final at its diagonal owner on the layer that factored its forest; gather on world
-        //      rank 0, then hand the complete vector to everyone ----
-        {
-            LevelSched::XSeg mine = forest_runs(H, 0, 3);
-            Comm *c = H->comm;
-            const int P = g.size(), me = g.rank();
-            if (!H->gather_ready) {
-                // rank 0 learns every rank's owner rows once (the forests of the other layers are not known here)
-                std::vector<int> flat;
-                for (auto &r : mine.runs) { flat.push_back(r.first); flat.push_back(r.second); }
-                std::vector<std::vector<int>> all(P);
-                std::vector<int64_t> lens(P, 0);
-                int64_t mylen = (int64_t) flat.size();
-                if ((rc = c->hbegin())) return rc;
-                if (me != 0) { if ((rc = c->hsend(&mylen, 8, 0))) return rc; }
-                else for (int p = 1; p < P; ++p) if ((rc = c->hrecv(&lens[p], 8, p))) return rc;
-                if ((rc = c->hend())) return rc;
-                if ((rc = c->hbegin())) return rc;
-                if (me != 0) { if ((rc = c->hsend(flat.data(), mylen * 4, 0))) return rc; }
-                else for (int p = 1; p < P; ++p) { all[p].resize((size_t) lens[p]); if ((rc = c->hrecv(all[p].data(), lens[p] * 4, p))) return rc; }
-                if ((rc = c->hend())) return rc;
-                if (me == 0)
-                    for (int p = 1; p < P; ++p) {
-                        LevelSched::XSeg m; m.peer = p;
-                        for (size_t i = 0; i + 1 < all[p].size(); i += 2) { m.runs.emplace_back(all[p][i], all[p][i + 1]); m.total += all[p][i + 1]; }
-                        if (m.total) H->gather_cache.push_back(std::move(m));
-                    }
-                H->gather_ready = true;
-            }
-            std::vector<LevelSched::XSeg> none;
-            if (me != 0) {
-                mine.peer = 0;
-                std::vector<LevelSched::XSeg> one(1, mine);
-                if (mine.total && (rc = xseg_exchange(H, x, ldxd, nr, one, 0, none, 0, s))) return rc;
-            } else if ((rc = xseg_exchange(H, x, ldxd, nr, none, 0, H->gather_cache, 1, s))) return rc;
-            // complete vector from rank 0 to everyone
-            if ((rc = c->begin())) return rc;
-            for (int q = 0; q < nr; ++q) {
-                if (me == 0) { for (int p = 1; p < P; ++p) if ((rc = c->send(x + (size_t) q * ldxd, H->hs.n * 8 * vs, p))) return rc; }
-                else if ((rc = c->recv(x + (size_t) q * ldxd, H->hs.n * 8 * vs, 0))) return rc;
-            }
-            if ((rc = c->end(s))) return rc;
-        }
+        if ((rc = redistribute(H, false, b, ldb, H->d_x, n, nr, s))) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());

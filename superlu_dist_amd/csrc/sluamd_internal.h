@@ -282,7 +282,20 @@ struct Handle {
     int max_nsupc = 0;
     Comm *comm = nullptr;           // not owned; set by sluamd_dCreateLUHandleGrid / ...FromSymbGrid
     std::map<int, LevelSched::XSeg> xseg_cache;        // x-segment run lists of the grid solve (Z exchanges, owner rows), built once
-    std::vector<LevelSched::XSeg> gather_cache; bool gather_ready = false;   // rank 0: the other ranks' owner rows (final gather)
+    std::vector<LevelSched::XSeg> owner_runs; bool owner_ready = false;      // every rank's owner rows (where x is final after the sweeps), indexed by world rank; exchanged once
+    // distributed right-hand side at the solve boundary (sluamd_pdgstrs3d_dist): routing of the caller's local rows of B to the ranks
+    // that consume them and back, built once per (m_loc, fst_row, perm)
+    struct DistRoute {                              // rows of B (original order, local index) <-> rows of x (factored order) for one permutation
+        std::vector<int64_t> cnt_b, cnt_x;          // per world rank: my rows of B paired with it / my owner rows of x paired with it
+        std::vector<int *> d_bidx, d_xidx;          // device: local row of B per pair (ordered by the row of x); row of x per pair (ascending)
+    };
+    struct DistPlan {
+        bool ready = false, same = false;           // same: perm_out == perm_in (route_out unused)
+        int64_t m_loc = -1, fst_row = -1; uint64_t hash_in = 0, hash_out = 0;
+        DistRoute in, out;                          // B -> x through perm_in, x -> B through perm_out
+        std::vector<void *> bufs;                   // device allocations of this plan
+    } dist;
+    double *d_bloc = nullptr; int64_t bloc_cap = 0;   // the caller's local rows of B on the device
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -329,6 +342,8 @@ void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *p
 // x segments <-> contiguous buffer; mode 0: buf = x, 1: x = buf, 2: x += buf, 3: buf = x then x = 0
 void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs /*device: (row0, nrows, rows before) triples*/, int nruns, int64_t total,
                double *buf, int mode);
+// indexed rows <-> contiguous cnt x nrhs buffer; mode 0: buf[j] = v[idx[j]], 1: v[idx[j]] = buf[j]  (pdReDistribute3d_B_to_X / X_to_B)
+void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode);
 int mfma_selftest(const double *A, const double *B, double *D);   // host pointers
 // complex16 twins (1 x 1 x 1 grids)
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);

@@ -55,6 +55,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t);
 // drivers (sluamd_factor.cpp)
 int run_factor(Handle *H, double thresh, int *info);
 int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs);
+int run_solve_dist(Handle *H, double *d_b, int64_t ldb, int nrhs, int64_t m_loc, int64_t fst_row, const int *perm_in, const int *perm_out);   // B distributed by rows (pdReDistribute3d_B_to_X / X_to_B inside)
 int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs);   // single-rank sweep over every schedule (refinement)
 int ensure_dinv(Handle *H);
 int ensure_inv(Handle *H);

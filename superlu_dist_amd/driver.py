@@ -223,6 +223,16 @@ class LUHandle:
 
     pzgstrs3d = pdgstrs3d
 
+    def pdgstrs3d_dist(self, B, perm=None, fst_row=0):
+        """sluamd_pdgstrs3d_dist on a single-rank handle: B in the ORIGINAL row order (all n rows), perm[i] = row of the factored system."""
+        B = np.asfortranarray(np.array(B, dtype=np.float64))
+        if B.ndim == 1:
+            B = np.asfortranarray(B[:, None])
+        pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        _lib.check(_lib.load().sluamd_pdgstrs3d_dist(self._h, B.ctypes.data_as(C.c_void_p), max(B.shape[0], 1), B.shape[1], B.shape[0], int(fst_row),
+                                                     None if pm is None else _pi(pm), None if pm is None else _pi(pm)), "sluamd_pdgstrs3d_dist")
+        return B
+
     def pdgstrs3d_dev(self, ptr, ldx, nrhs):
         _lib.check(_lib.load().sluamd_pdgstrs3d_dev(self._h, C.c_void_p(ptr), ldx, nrhs), "sluamd_pdgstrs3d_dev")
 

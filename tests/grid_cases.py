@@ -144,10 +144,26 @@ def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, 
     comms = (make_comms or grid3d.local_comms)(Pr, Pc, Pz)
     xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
 
+    # the reference's boundary: B distributed by block rows over layer 0 (uneven blocks, one of them empty when the layer has >= 3 ranks)
+    nl0 = Pr * Pc
+    cuts = np.linspace(0, n, nl0 + 1).astype(np.int64)
+    if nl0 >= 3:
+        cuts[1] = cuts[0]
+    cuts[1:-1] += np.arange(1, nl0) % 3
+
     def rank_body(rank):
         h = grid3d.GridHandle.from_symbolic(symb, v, comms[rank], sn_tree)
         info = h.pdgstrf3d(0.0)
         y = h.pdgstrs3d(xp)
+        # distributed form (sluamd_pdgstrs3d_dist: pdReDistribute3d_B_to_X / X_to_B inside): my rows of b in, my rows of x out
+        f0, f1 = (int(cuts[rank]), int(cuts[rank + 1])) if rank < nl0 else (0, 0)
+        xl = h.pdgstrs3d_dist(b[f0:f1, :], f0, symb.perm_c)
+        assert xl.shape == (f1 - f0, b.shape[1])
+        if f1 > f0:
+            assert np.abs(xl - y[symb.perm_c, :][f0:f1, :]).max() <= 1e-12 * np.abs(y).max()
+        xr = h.pdgstrs3d_dist(b[f0:f1, :], f0, symb.perm_c, perm_out=None)      # the reference's convention: rows of the PERMUTED solution
+        if f1 > f0:
+            assert np.abs(xr - y[f0:f1, :]).max() <= 1e-12 * np.abs(y).max()
         if refactor:                    # device-side re-distribution + second factorisation reproduce the solution
             h.reset_values()
             assert h.pdgstrf3d(0.0) == 0

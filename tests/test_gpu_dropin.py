@@ -1,6 +1,6 @@
 """Drop-in test: the REAL reference pipeline (pdgssvx3d: equilibration, MC64, MMD ordering, symbolic factorisation,
 pddistribute3d, pdgstrs3d, refinement -- prebuilt from /root/reference into oracle/_ref/) with its pdgstrf3d call routed
-into libsluamd.so by the binding of INTEGRATION.md (oracle/ref/sluamd_binding.c).  The triangular solve that follows
+into libsluamd.so by the binding of INTEGRATION.md (bindings/superlu_dist/sluamd_binding.c).  The triangular solve that follows
 and every refinement-step solve (pdgstrs3d / pdgstrs3d_newsolve) run in libsluamd.so on the device-resident factors
 (SLUAMD_BIND_SOLVE=0 keeps the reference's CPU solves on the factors copied back in the reference's formats), on 1x1x1 and,
 through mpiexec with the binding's MPI transport, on 1x1x2 / 2x1x1 / 2x2x2 grids whose ranks share the box's GPU."""
@@ -36,6 +36,7 @@ def _run(binary, args, tmp_path, threads="4", nproc=1, extra_env=None):
     m = re.search(r"RESIDUAL (\S+) INFO (\d+)", r.stdout)
     assert m, r.stdout[-2000:]
     _last["stderr"] = r.stderr
+    _last["stdout"] = r.stdout
     return float(m.group(1)), int(m.group(2))
 
 
@@ -57,6 +58,8 @@ def test_reference_pipeline_with_our_pdgstrf3d(kind, tmp_path):
     matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
     args = ["-r", "1", "-c", "1", "-d", "1", "-Q", "1", "-o", "none"] + flags + [str(tmp_path / "a.dat")]
     res_amd, info_amd = _run(AMD, args, tmp_path)                                    # our factor + our solves
+    t = re.search(r"REFTIMES n \d+ FACT (\S+) s SOLVE (\S+) s", _last["stdout"])           # the binding fills stat->utime[FACT] / [SOLVE] like the reference
+    assert t and float(t.group(1)) > 0.0 and float(t.group(2)) > 0.0
     res_fac, info_fac = _run(AMD, args, tmp_path, extra_env={"SLUAMD_BIND_SOLVE": "0"})   # our factor, reference solves
     res_ref, info_ref = _run(REF, args, tmp_path)
     assert info_amd == info_fac == info_ref == 0
@@ -87,6 +90,26 @@ def test_reference_pipeline_on_process_grids(grid, kind, tmp_path):
     assert info_amd == info_ref == 0
     assert res_amd < 1e-10 and res_ref < 1e-10
     assert abs(res_amd - res_ref) < 1e-10
+
+
+@pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF)), reason="prebuilt reference binaries not shipped")
+@pytest.mark.parametrize("kind", ["poisson_defaults", "unsym_norefine"])
+def test_binding_over_the_rccl_transport(kind, tmp_path):
+    """SLUAMD_BIND_TRANSPORT=rccl: the one-rank-per-GPU variant of the binding -- the ncclUniqueId made by the library, shipped with
+    MPI_Bcast, sluamd_comm_create_rccl on the rank's node-local device, a GRID handle over that communicator, B handed over
+    distributed (sluamd_pdgstrs3d_dist).  One rank here (one GPU per box); the same code path a 2 x 2 x 2 run takes on an 8-GPU node."""
+    if kind == "poisson_defaults":
+        n, rp, ci, v = matgen.poisson3d(12)
+        flags = []
+    else:
+        n, rp, ci, v = matgen.random_unsym(400, 0.02, seed=11)
+        flags = ["-i", "0"]
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    args = ["-r", "1", "-c", "1", "-d", "1", "-Q", "1", "-o", "none"] + flags + [str(tmp_path / "a.dat")]
+    res_amd, info_amd = _run(AMD, args, tmp_path, extra_env={"SLUAMD_BIND_TRANSPORT": "rccl"})
+    res_ref, info_ref = _run(REF, args, tmp_path)
+    assert info_amd == info_ref == 0
+    assert res_amd < 1e-10 and res_ref < 1e-10 and abs(res_amd - res_ref) < 1e-10
 
 
 @pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF)), reason="prebuilt reference binaries not shipped")
@@ -150,7 +173,8 @@ def test_reference_supernodes_up_to_512_columns(grid, tmp_path):
 @pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF)), reason="prebuilt reference binaries not shipped")
 @pytest.mark.parametrize("kind", ["zgrid_nd", "zunsym_defaults"])
 def test_reference_pipeline_with_our_pzgstrf3d(kind, tmp_path):
-    """complex16 twin: pzgssvx3d (reference) with pzgstrf3d routed into sluamd_pzgstrf3d."""
+    """complex16 twin: pzgssvx3d (reference) with pzgstrf3d AND pzgstrs3d[_newsolve] routed into sluamd_pzgstrf3d / sluamd_pzgstrs3d
+    (SLUAMD_BIND_SOLVE=0: the reference's CPU solves on the factors copied back)."""
     if kind == "zgrid_nd":
         n, rp, ci, v = matgen.poisson3d(0, 24, 24, 1)
         perm = matgen.nd_perm_grid3d(24, 24, 1, leaf=16)
@@ -166,17 +190,18 @@ def test_reference_pipeline_with_our_pzgstrf3d(kind, tmp_path):
     # "z_div.c: division by zero" on the zgrid_nd input as soon as it runs with >= 2 OpenMP threads (verified in the build
     # container, 3/3 runs at 2, 4 and 8 threads, 0/3 at 1 thread) -- an upstream race, independent of this library
     res_amd, info_amd = _run(ZAMD, args, tmp_path, threads="1")
+    res_fac, info_fac = _run(ZAMD, args, tmp_path, threads="1", extra_env={"SLUAMD_BIND_SOLVE": "0"})
     res_ref, info_ref = _run(ZREF, args, tmp_path, threads="1")
-    assert info_amd == info_ref == 0
-    assert res_amd < 1e-10 and res_ref < 1e-10
-    assert abs(res_amd - res_ref) < 1e-10
+    assert info_amd == info_fac == info_ref == 0
+    assert res_amd < 1e-10 and res_fac < 1e-10 and res_ref < 1e-10
+    assert abs(res_amd - res_ref) < 1e-10 and abs(res_fac - res_ref) < 1e-10
 
 
 @pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
 def test_reference_complex_pipeline_on_two_z_layers(tmp_path):
     """mpiexec -n 2 slu_ref_zamd -d 2: pzgssvx3d on a 1 x 1 x 2 grid with pzgstrf3d bound to the library over the binding's MPI
-    transport (leaf forests on two ranks sharing the GPU, Z ancestor reduction of complex16 panels in the library); the
-    reference's own CPU pzgstrs3d then solves with the factors copied back; residual parity with the untouched reference."""
+    transport (leaf forests on two ranks sharing the GPU, Z ancestor reduction of complex16 panels in the library) and pzgstrs3d bound
+    to the library's complex solve (Z sweeps of the solve on pairs of doubles); residual parity with the untouched reference."""
     n, rp, ci, v = matgen.random_unsym(300, 0.03, seed=21)
     v = matgen.complex_shift(v, rp, ci, seed=4)
     matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)

@@ -207,3 +207,24 @@ def test_own_pipeline_complex16(shape, leaf, relax, maxsup):
     res = np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b)
     assert res < 1e-10
     assert np.abs(x - xt).max() < 1e-9 * np.abs(xt).max()
+
+
+@pytest.mark.parametrize("nrhs", [1, 3, 60])
+def test_distributed_boundary_on_a_single_rank(nrhs):
+    """sluamd_pdgstrs3d_dist (pdgstrs3d's own boundary: original row order in, pdReDistribute3d_B_to_X / X_to_B inside) on a single-rank
+    handle gives what the permuted-vector entry point gives; a wrong row range is an error, not a wrong answer."""
+    N = 10
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, nrhs)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=16, maxsup=64)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    assert h.pdgstrf3d(0.0) == 0
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    x1 = h.pdgstrs3d(xp)[symb.perm_c, :]
+    x2 = h.pdgstrs3d_dist(b, symb.perm_c)
+    assert np.abs(x2 - x1).max() <= 1e-13 * np.abs(x1).max()
+    assert np.abs(x2 - xt).max() <= 1e-9
+    with pytest.raises(RuntimeError, match="row range"):
+        h.pdgstrs3d_dist(b[:-3, :], symb.perm_c)
+    h.destroy(); symb.free()
