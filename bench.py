@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--leaf", type=int, default=64)
     ap.add_argument("--relax", type=int, default=64)
     ap.add_argument("--maxsup", type=int, default=256)
+    ap.add_argument("--scale-n", type=int, default=150,
+                    help="grid side of the SCALING POINT reported beside the headline configuration at every N (150^3: 1.5e14 flop, "
+                         "90 GB of factors -- seconds of work per step, so that exchange latency does not dominate the N > 1 runs); 0 = skip")
+    ap.add_argument("--no-scaling-point", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d"],
@@ -193,80 +197,98 @@ def main():
     if L.sluamd_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
 
-    t_setup = time.perf_counter()
-    n, rp, ci, v, perm, xt, b = build_problem(args.n, args.leaf, args.workload)
-    zwork = args.workload == "zgrid2d"
-    if zwork and world > 1:
-        raise SystemExit("bench.py: the complex16 workload is single-GPU")
-    symb = driver.Symbolic(n, rp, ci, perm, relax=args.relax, maxsup=args.maxsup)
-    grid = (1, 1, 1)
-    if world == 1:
-        h = driver.LUHandle.from_symbolic(symb, v, device=local_rank)
-    else:   # Pr x Pc x Pz process grid, one rank per GPU (8 -> 2 x 2 x 2 = BASELINE.json's grid); SLUAMD_GRID="r,c,z" overrides
-        from superlu_dist_amd import grid3d
-        grid = tuple(int(t) for t in os.environ["SLUAMD_GRID"].split(",")) if os.environ.get("SLUAMD_GRID") else grid3d.default_grid(world)
-        assert grid[0] * grid[1] * grid[2] == world
-        sn_tree = symb.partition(grid[2]) if grid[2] > 1 else None
-        if dist_backend == "rccl":
-            comm = grid3d.rccl_comm(dist, *grid, local_rank)
+    def measure(N, steps, warm, workload):
+        """Build the N-sided problem, factor + solve `steps` times after `warm` warm-up steps; returns the measurements and keeps the
+        handle alive for the caller's extra passes (profile, refinement)."""
+        t_setup = time.perf_counter()
+        n, rp, ci, v, perm, xt, b = build_problem(N, args.leaf, workload)
+        symb = driver.Symbolic(n, rp, ci, perm, relax=args.relax, maxsup=args.maxsup)
+        grid = (1, 1, 1)
+        if world == 1:
+            h = driver.LUHandle.from_symbolic(symb, v, device=local_rank)
+        else:   # Pr x Pc x Pz process grid, one rank per GPU (8 -> 2 x 2 x 2 = BASELINE.json's grid); SLUAMD_GRID="r,c,z" overrides
+            from superlu_dist_amd import grid3d
+            grid = tuple(int(t) for t in os.environ["SLUAMD_GRID"].split(",")) if os.environ.get("SLUAMD_GRID") else grid3d.default_grid(world)
+            assert grid[0] * grid[1] * grid[2] == world
+            sn_tree = symb.partition(grid[2]) if grid[2] > 1 else None
+            if dist_backend == "rccl":
+                if "comm" not in comm_cache:
+                    comm_cache["comm"] = grid3d.rccl_comm(dist, *grid, local_rank)
+            elif "comm" not in comm_cache:
+                comm_cache["tcomm"] = grid3d.TorchComm(dist, *grid)
+                comm_cache["comm"] = comm_cache["tcomm"].handle
+            h = grid3d.GridHandle.from_symbolic(symb, v, comm_cache["comm"], sn_tree, device=local_rank)
+        t_setup = time.perf_counter() - t_setup
+        thresh = driver.pivot_thresh(n, rp, ci, np.abs(v))
+        xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+        # N > 1: the reference's solve boundary -- B distributed by block rows over layer 0 (sluamd_pdgstrs3d_dist)
+        nl0 = grid[0] * grid[1]
+        cuts = np.linspace(0, n, nl0 + 1).astype(np.int64)
+        f0, f1 = (int(cuts[rank]), int(cuts[rank + 1])) if rank < nl0 else (0, 0)
+
+        def step():
+            h.reset_values()                    # device-side re-distribution of A (zero fill + scatter): part of every step
+            info = h.pdgstrf3d(thresh)          # N > 1: collective -- Z-level loop, XY panel exchange, ancestor reduction, info all-reduce
+            if world == 1:
+                y = h.pdgstrs3d(xp)
+            else:
+                y = h.pdgstrs3d_dist(b[f0:f1, :], f0, symb.perm_c)     # collective: B_to_X, distributed sweeps, X_to_B; my rows of x back
+            st = h.stats()
+            return info, y, st["t_factor_ms"], st["t_solve_ms"]          # HIP-event times of the two phases
+
+        for _ in range(warm):
+            info, y, _, _ = step()
+        sync()
+        t0 = time.perf_counter()
+        fact_ms, solve_ms = [], []
+        for _ in range(steps):
+            ts = time.perf_counter()
+            info, y, fm, sm = step()
+            fact_ms.append(fm); solve_ms.append(sm)
+            if os.environ.get("SLUAMD_BENCH_TRACE"):
+                print("step wall %.2f ms (factor %.2f solve %.2f)" % (1e3 * (time.perf_counter() - ts), fm, sm), file=sys.stderr)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([elapsed, float(np.mean(fact_ms)), float(np.mean(solve_ms))], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt[0].item())
+            fact_ms, solve_ms = [float(tt[1].item())], [float(tt[2].item())]
+            parts = [None] * world                     # the solution's rows from the layer-0 ranks (outside the timed region)
+            dist.all_gather_object(parts, (f0, np.asarray(y)))
+            x = np.zeros_like(b, order="F")
+            for q0, yq in parts:
+                if yq.shape[0]:
+                    x[q0:q0 + yq.shape[0], :] = yq
         else:
-            tcomm = grid3d.TorchComm(dist, *grid)
-            comm = tcomm.handle
-        h = grid3d.GridHandle.from_symbolic(symb, v, comm, sn_tree, device=local_rank)
-    t_setup = time.perf_counter() - t_setup
-    thresh = driver.pivot_thresh(n, rp, ci, np.abs(v))
-    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+            x = y[symb.perm_c, :]
+        res = float(np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b))
+        err = float(np.abs(x - xt).max())
+        return dict(n=n, rp=rp, ci=ci, v=v, xt=xt, b=b, symb=symb, h=h, grid=grid, thresh=thresh, t_setup=t_setup, info=info, x=x,
+                    fact_ms=fact_ms, solve_ms=solve_ms, elapsed=elapsed, res=res, err=err, steps=steps)
 
     def sync():
         L.sluamd_device_synchronize()
         if dist is not None:
             dist.barrier()
 
-    def step():
-        h.reset_values()                    # device-side re-distribution of A (zero fill + scatter): part of every step
-        if world == 1:
-            info = h.pdgstrf3d(thresh)
-            y = h.pdgstrs3d(xp)
-            st = h.stats()
-            return info, y, st["t_factor_ms"], st["t_solve_ms"]          # HIP-event times of the two phases
-        info = h.pdgstrf3d(thresh)          # collective: Z-level loop, XY panel exchange, ancestor reduction, info all-reduce
-        y = h.pdgstrs3d(xp)                 # collective: distributed forward / backward sweeps
-        st = h.stats()
-        return info, y, st["t_factor_ms"], st["t_solve_ms"]
-
+    comm_cache = {}
+    zwork = args.workload == "zgrid2d"
+    if zwork and world > 1:
+        raise SystemExit("bench.py: the complex16 workload is single-GPU")
     # untimed warm-up: W complete steps, each exactly what a timed step is, and never fewer than two -- the HIP runtime spreads its
     # one-time costs over the first TWO steps of a process (first step: code objects, the pinned / staging buffers of the host
     # copies; second step: another 15-25 ms inside the first host-to-device copy of the solve, SLUAMD_BENCH_TRACE=1 shows the per-step
     # wall times); "warmup" in the JSON line is the number actually run
     n_warm = max(2, args.warmup)
-    for _ in range(n_warm):
-        info, y, _, _ = step()
-    sync()
-    t0 = time.perf_counter()
-    fact_ms, solve_ms = [], []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        info, y, fm, sm = step()
-        fact_ms.append(fm); solve_ms.append(sm)
-        if os.environ.get("SLUAMD_BENCH_TRACE"):
-            print("step wall %.2f ms (factor %.2f solve %.2f)" % (1e3 * (time.perf_counter() - ts), fm, sm), file=sys.stderr)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed, float(np.mean(fact_ms)), float(np.mean(solve_ms))], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0].item())
-        fact_ms, solve_ms = [float(tt[1].item())], [float(tt[2].item())]
-
-    # correctness of the last step
-    x = y[symb.perm_c, :]
-    res = float(np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b))
-    err = float(np.abs(x - xt).max())
+    M = measure(args.n, args.steps, n_warm, args.workload)
+    n, rp, ci, v, xt, b, symb, h, grid, thresh = (M[k] for k in ("n", "rp", "ci", "v", "xt", "b", "symb", "h", "grid", "thresh"))
+    t_setup, info, x, fact_ms, solve_ms, elapsed, res, err = (M[k] for k in ("t_setup", "info", "x", "fact_ms", "solve_ms", "elapsed", "res", "err"))
 
     # one extra profiled step: per-kernel-family HIP-event times on the compute stream
-    if world == 1 and not zwork:
-        h.set_profile(True)
+    if not zwork:
+        h.set_profile(True)                  # N > 1: collective like every factorisation (serial schedule on every rank)
         h.reset_values(); h.pdgstrf3d(thresh)
         stp = h.stats()
         h.set_profile(False)
@@ -343,10 +365,45 @@ def main():
                                  "achieved": solve_gbs, "peak": 8000.0, "unit": "GB/s", "frac": solve_gbs / 8000.0,
                                  "algorithmic_bytes_per_solve": solve_bytes,
                                  "note": "%d levels x 4 launches per solve; 3-4.7 TB/s on the levels that hold the data, launch latency on the single-supernode levels of the top separator" % st["num_levels"]}
-    if world > 1:   # the dominant kernel is profiled in the N=1 run of this same command (HIP-event profiling is per handle)
-        out["roofline"].update(achieved=None, frac=None, avg_launch_ms=None, schur_ms=None, panel_ms=None,
-                               profiled_factor_ms=None, launches=None, flops_per_launch=None, algorithmic_bytes_per_launch=None,
-                               note="per-kernel roofline is measured by the N=1 run (bench.py --gpus 1); N>1 lines report whole-job throughput")
+    if world > 1:   # the dominant kernel is profiled in the N=1 run of this same command (here: this rank's share under the serial schedule)
+        out["roofline"].update(achieved=None, frac=None, avg_launch_ms=None, flops_per_launch=None, algorithmic_bytes_per_launch=None,
+                               note="per-kernel roofline is measured by the N=1 run (bench.py --gpus 1); N>1 lines report whole-job throughput; "
+                                    "schur_ms / panel_ms / launches are rank 0's, from its extra profiled (serial-schedule) factorisation")
+        # per-phase times of the profiled factorisation, MAX over ranks: where an N > 1 run spends its time beside the kernels
+        import torch
+        ph = torch.tensor([stp["t_exchange_ms"], stp["t_reduce_ms"], stp["t_schur_ms"], stp["t_panel_ms"], stp["t_factor_ms"]], dtype=torch.float64)
+        dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        out["phases"] = {"exchange_ms": float(ph[0]), "reduce_ms": float(ph[1]), "schur_ms": float(ph[2]), "panel_ms": float(ph[3]),
+                         "profiled_factor_ms": float(ph[4]),
+                         "note": "one extra factorisation under the serial (profiling) schedule, HIP events, max over ranks: exchange = the XY "
+                                 "panel-exchange phases (dDiagFactIBCast + L / U panel broadcasts; part of panel_ms), reduce = the Z ancestor "
+                                 "reduction (dreduceAllAncestors3d); the timed steps overlap the exchanges with the Schur tiles of the previous level"}
+    # ---- scaling point: the same job one size up, reported beside the headline configuration at EVERY N (100^3 is a
+    # 0.3 s job -- its N > 1 runs are exchange-latency-bound; 150^3 is 3 s of work and fits one GPU at 90 GB).  `value` stays the
+    # headline configuration so that the driver's efficiency figure compares equal jobs; this block lets it be recomputed on 150^3.
+    if not zwork and not args.no_scaling_point and args.scale_n and args.scale_n != args.n:
+        h.destroy(); symb.free()
+        try:
+            S2 = measure(args.scale_n, max(1, min(args.steps, 2)), 1, args.workload)
+            st2 = S2["h"].stats()
+            F2 = S2["symb"].flops
+            out["scaling_point"] = {"workload": f"{args.scale_n}^3 7-point Poisson (double), {S2['grid'][0]}x{S2['grid'][1]}x{S2['grid'][2]} grid, same ordering / supernode parameters",
+                                    "n": S2["n"], "flops_per_step": F2, "steps": S2["steps"], "warmup": 1,
+                                    "value": F2 * S2["steps"] / S2["elapsed"] / 1e9, "unit": "GFLOP/s", "ms_per_step": 1e3 * S2["elapsed"] / S2["steps"],
+                                    "factor_ms": float(np.mean(S2["fact_ms"])), "solve_ms": float(np.mean(S2["solve_ms"])),
+                                    "factor_gflops_kernel_only": F2 / (np.mean(S2["fact_ms"]) * 1e-3) / 1e9,
+                                    "residual": S2["res"], "nnz_LU_this_rank": int(st2["nnz_L"] + st2["nnz_U"]),
+                                    "bytes_device_this_rank": int(st2["bytes_device"]), "setup_s": S2["t_setup"]}
+            if world == 1:
+                out["scaling_point"]["solve_hbm_frac"] = 8.0 * float(st2["nnz_L"] + st2["nnz_U"]) / (np.mean(S2["solve_ms"]) * 1e-3) / 1e9 / PEAK_HBM_GBS
+            if S2["res"] > 1e-10:
+                raise SystemExit(f"bench.py: scaling-point residual {S2['res']:.3e} exceeds 1e-10")
+            h, symb = S2["h"], S2["symb"]
+        except SystemExit:
+            raise
+        except Exception as e:      # e.g. not enough HBM on this rank: reported, the headline line stands
+            out["scaling_point"] = {"error": str(e)[:300]}
+            h, symb = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not zwork:
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.leaf, args.relax, args.maxsup)
@@ -354,7 +411,8 @@ def main():
             out["cpu_baseline"] = {"error": str(e)[:300]}
     if rank == 0:
         print(json.dumps(out))
-    h.destroy(); symb.free()
+    if h is not None:
+        h.destroy(); symb.free()
     if dist is not None:
         dist.destroy_process_group()
     if res > 1e-10:

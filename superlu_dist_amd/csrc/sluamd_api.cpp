@@ -546,6 +546,8 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     free_rfs(H);
     for (auto &e : H->ev_schur) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : H->ev_panel) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : H->ev_xchg) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : H->ev_red) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (H->ev0) hipEventDestroy(H->ev0);
     if (H->ev1) hipEventDestroy(H->ev1);
     for (auto e : H->ev_pool) hipEventDestroy(e);

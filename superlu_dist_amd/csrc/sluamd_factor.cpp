@@ -75,7 +75,9 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         eng::diag_lu(ps, T, nodes, nn, mx, (H->opt.replace_tiny_pivot ? 1 : 0) | (H->env.diag_v1 ? 2 : 0), thresh, H->d_info);   // Local_Dgstrf2 (+ dinv of the owned blocks)
         if (xy) {   // dDiagFactIBCast (dtrfCommWrapper.c:32-118): diagonal blocks down the process column and along the process row
             eng::pack_diag(ps, T, nodes, S.d_dg_prefix + po, S.d_dg_off + po, nn, S.dg_prefix[po + nn], H->d_val + S.dg_stage_off[l]);
+            ev_begin(H, H->ev_xchg, H->ev_xchg_used, ps);
             if (!rc_x) rc_x = exchange(H, S.x_diag_send[l], S.x_diag_recv[l], ps);
+            ev_end(H, H->ev_xchg, H->ev_xchg_used, ps);
             eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);   // column / row peers invert the diagonal blocks they received
         }
         if (gemm_panels) eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);   // Linv / Uinv (the solve uses the owner's too)
@@ -90,7 +92,11 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
         if (gemm_panels) eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, mx);   // chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
         else eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);
-        if (xy && !rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // dIBcastRecvLPanel / dIBcastRecvUPanel
+        if (xy) {
+            ev_begin(H, H->ev_xchg, H->ev_xchg_used, ps);
+            if (!rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // dIBcastRecvLPanel / dIBcastRecvUPanel
+            ev_end(H, H->ev_xchg, H->ev_xchg_used, ps);
+        }
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);
         H->st.num_launches += (nl + nu > 0);
     };
@@ -277,7 +283,7 @@ int run_factor(Handle *H, double thresh, int *info)
     HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
     H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
     H->profile = H->opt.verbose >= 2 || H->env.profile;
-    H->ev_schur_used = H->ev_panel_used = 0;
+    H->ev_schur_used = H->ev_panel_used = H->ev_xchg_used = H->ev_red_used = 0;
     H->schur_rec.clear();
     H->ev_pool_used = 0;
     HIPCHK(hipEventRecord(H->ev0, H->stream));
@@ -288,7 +294,12 @@ int run_factor(Handle *H, double thresh, int *info)
             rc = H->z ? run_factor_z(H, H->sched[zl], thresh) : run_factor_sched(H, H->sched[zl], thresh);
             if (rc) return rc;
         }
-        if (g.Pz > 1 && (rc = reduce_ancestors(H, (int) zl))) return rc;
+        if (g.Pz > 1) {
+            ev_begin(H, H->ev_red, H->ev_red_used, H->stream);
+            rc = reduce_ancestors(H, (int) zl);
+            ev_end(H, H->ev_red, H->ev_red_used, H->stream);
+            if (rc) return rc;
+        }
     }
     HIPCHK(hipEventRecord(H->ev1, H->stream));
     int res[4];
@@ -305,6 +316,8 @@ int run_factor(Handle *H, double thresh, int *info)
         }
     H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
     H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
+    H->st.t_exchange_ms = H->profile ? ev_sum(H->ev_xchg, H->ev_xchg_used) : 0.0;     // XY panel-exchange phases (inside t_panel_ms)
+    H->st.t_reduce_ms = H->profile ? ev_sum(H->ev_red, H->ev_red_used) : 0.0;         // Z ancestor reduction
     H->st.tiny_pivots = res[1];
     int linfo = (res[0] == 0x7fffffff) ? 0 : res[0];
     int missing = res[2];

@@ -267,8 +267,8 @@ struct Handle {
     bool inv_ready = false;                                 // T.inv (Linv / Uinv) too
     int *chain_abort = nullptr;                             // pinned host word written by k_chain when a dependency never arrives (checked after every solve)
     bool profile = false;                                   // per-kernel-family HIP-event timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel;
-    size_t ev_schur_used = 0, ev_panel_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel, ev_xchg, ev_red;
+    size_t ev_schur_used = 0, ev_panel_used = 0, ev_xchg_used = 0, ev_red_used = 0;
     struct SchurRec { int level, pass, big, ntiles, mx; };
     std::vector<SchurRec> schur_rec;   // SLUAMD_PROFILE_DUMP: one record per profiled Schur launch (parallel to ev_schur)
     sluamd_stats_t st{};

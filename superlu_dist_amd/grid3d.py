@@ -193,6 +193,10 @@ class GridHandle:
     def reset_values(self):
         _lib.check(_lib.load().sluamd_dResetValues(self._h), "sluamd_dResetValues")
 
+    def set_profile(self, on=True):
+        """per-phase HIP-event timing (serial schedule): Schur / panel kernels, XY exchange phases, Z ancestor reduction"""
+        _lib.load().sluamd_set_profile(self._h, int(on))
+
     def stats(self):
         s = _lib.Stats()
         _lib.load().sluamd_get_stats(self._h, C.byref(s))
