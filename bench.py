@@ -22,6 +22,7 @@ import numpy as np  # noqa: E402
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
+HBM_BYTES = 288e9              # per MI355X
 
 
 def kernel_source_hash():
@@ -44,6 +45,21 @@ def build_problem(N, leaf, workload="poisson3d"):
         xt = np.where((np.arange(n) % 2) == 1, 1.0, -1.0)[:, None].astype(np.complex128)
         b = matgen.csr_matvec(n, rp, ci, v, xt)
         return n, rp, ci, v, perm, np.asfortranarray(xt), b
+    if workload == "audikw_like":
+        # BASELINE.json configs[3] stand-in (SuiteSparse audikw_1 is not available offline): SPD 3-D mesh operator with 3 unknowns per
+        # node, 27-point node coupling, randomly renumbered -- N = 68: n = 943 296 (audikw_1: 943 695), ~75 entries per row (82);
+        # ordered WITHOUT geometry by the library's own nested dissection (sluamd_order_nd).  --matrix file.mtx reads the real one.
+        from superlu_dist_amd import driver
+        n, rp, ci, v = matgen.elasticity3d_like(N, drop=0.05, seed=1)
+        perm = driver.order_nd(n, rp, ci, leaf=leaf)
+        xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
+        return n, rp, ci, v, perm, xt, b
+    if workload.endswith(".mtx"):
+        from superlu_dist_amd import driver
+        n, rp, ci, v = matgen.read_matrix_market(workload)
+        perm = driver.order_nd(n, rp, ci, leaf=leaf)
+        xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
+        return n, rp, ci, v, perm, xt, b
     n, rp, ci, v = matgen.poisson3d(N)
     perm = matgen.nd_perm_grid3d(N, N, N, leaf=leaf)
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
@@ -151,9 +167,10 @@ def main():
     ap.add_argument("--no-scaling-point", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d"],
+    ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d", "audikw_like"],
                     help="poisson3d = BASELINE configs[1] (default, the metric's config); zgrid2d = configs[4] family "
-                         "(complex16 2-D grid operator, use --n 1000)")
+                         "(complex16 2-D grid operator, use --n 1000); audikw_like = configs[3] stand-in (use --n 68)")
+    ap.add_argument("--matrix", default=None, help="MatrixMarket file instead of a generated workload (e.g. SuiteSparse audikw_1.mtx), ordered by sluamd_order_nd")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -205,12 +222,22 @@ def main():
         symb = driver.Symbolic(n, rp, ci, perm, relax=args.relax, maxsup=args.maxsup)
         grid = (1, 1, 1)
         if world == 1:
+            if (symb.nnzL + symb.nnzU) * (16 if workload == "zgrid2d" else 8) * 1.06 > HBM_BYTES:
+                raise SystemExit(f"bench.py: {N}^3 does not fit one {HBM_BYTES / 1e9:.0f} GB GPU: nnz(L+U) = {symb.nnzL + symb.nnzU} = "
+                                 f"{(symb.nnzL + symb.nnzU) * 8 / 1e9:.0f} GB of factor values (run it on a process grid: --gpus 8)")
             h = driver.LUHandle.from_symbolic(symb, v, device=local_rank)
         else:   # Pr x Pc x Pz process grid, one rank per GPU (8 -> 2 x 2 x 2 = BASELINE.json's grid); SLUAMD_GRID="r,c,z" overrides
             from superlu_dist_amd import grid3d
             grid = tuple(int(t) for t in os.environ["SLUAMD_GRID"].split(",")) if os.environ.get("SLUAMD_GRID") else grid3d.default_grid(world)
             assert grid[0] * grid[1] * grid[2] == world
             sn_tree = symb.partition(grid[2]) if grid[2] > 1 else None
+            # pre-flight: the factors must fit the ranks' HBM -- fail loudly with the byte count, before any allocation
+            vals, rep, _idx = symb.grid_footprint(*grid, sn_tree)
+            need = float(vals.max()) * 8 * 1.12          # + ~12 % for the exchange scratch, index images and inverse blocks (measured: profiles/r03_grid_footprint.txt)
+            if need > HBM_BYTES:
+                raise SystemExit(f"bench.py: {N}^3 does not fit a {grid[0]}x{grid[1]}x{grid[2]} grid of {HBM_BYTES / 1e9:.0f} GB GPUs: the fullest rank stores "
+                                 f"{vals.max() * 8 / 1e9:.1f} GB of factor values ({rep.max() * 8 / 1e9:.1f} GB of them ancestor panels replicated along Z), "
+                                 f"~{need / 1e9:.0f} GB with scratch and tables; nnz(L+U) = {(symb.nnzL + symb.nnzU) * 8 / 1e9:.0f} GB in total")
             if dist_backend == "rccl":
                 if "comm" not in comm_cache:
                     comm_cache["comm"] = grid3d.rccl_comm(dist, *grid, local_rank)
@@ -282,6 +309,8 @@ def main():
     # copies; second step: another 15-25 ms inside the first host-to-device copy of the solve, SLUAMD_BENCH_TRACE=1 shows the per-step
     # wall times); "warmup" in the JSON line is the number actually run
     n_warm = max(2, args.warmup)
+    if args.matrix:
+        args.workload = args.matrix
     M = measure(args.n, args.steps, n_warm, args.workload)
     n, rp, ci, v, xt, b, symb, h, grid, thresh = (M[k] for k in ("n", "rp", "ci", "v", "xt", "b", "symb", "h", "grid", "thresh"))
     t_setup, info, x, fact_ms, solve_ms, elapsed, res, err = (M[k] for k in ("t_setup", "info", "x", "fact_ms", "solve_ms", "elapsed", "res", "err"))
@@ -336,7 +365,12 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "c128" if zwork else "f64", "data": "synthetic",
         "config": {"workload": (f"pzdrive3d-equivalent on a {args.n}x{args.n} 5-point complex16 grid operator (cg20 family), 1x1x1 grid, "
-                                if zwork else f"pddrive3d-equivalent on {args.n}^3 7-point Poisson (double), {grid[0]}x{grid[1]}x{grid[2]} grid, ")
+                                if zwork else
+                                f"pddrive3d-equivalent on the audikw_1 stand-in ({args.n}^3 nodes x 3 unknowns, 27-point node coupling, SPD, random numbering), {grid[0]}x{grid[1]}x{grid[2]} grid, graph "
+                                if args.workload == "audikw_like" else
+                                f"pddrive3d-equivalent on {os.path.basename(args.workload)} (MatrixMarket), {grid[0]}x{grid[1]}x{grid[2]} grid, graph "
+                                if args.workload.endswith(".mtx") else
+                                f"pddrive3d-equivalent on {args.n}^3 7-point Poisson (double), {grid[0]}x{grid[1]}x{grid[2]} grid, ")
                                + f"ND perm_c (leaf {args.leaf}), relax {args.relax}, maxsup {args.maxsup}, nrhs 1",
                    "n": n, "nnz_A": int(len(v)), "nnz_LU": int(st["nnz_L"] + st["nnz_U"]), "nsupers": symb.nsupers,
                    "parallelism": "single GPU" if world == 1 else
@@ -381,7 +415,7 @@ def main():
     # ---- scaling point: the same job one size up, reported beside the headline configuration at EVERY N (100^3 is a
     # 0.3 s job -- its N > 1 runs are exchange-latency-bound; 150^3 is 3 s of work and fits one GPU at 90 GB).  `value` stays the
     # headline configuration so that the driver's efficiency figure compares equal jobs; this block lets it be recomputed on 150^3.
-    if not zwork and not args.no_scaling_point and args.scale_n and args.scale_n != args.n:
+    if args.workload == "poisson3d" and not args.no_scaling_point and args.scale_n and args.scale_n != args.n:
         h.destroy(); symb.free()
         try:
             S2 = measure(args.scale_n, max(1, min(args.steps, 2)), 1, args.workload)
@@ -404,7 +438,7 @@ def main():
         except Exception as e:      # e.g. not enough HBM on this rank: reported, the headline line stands
             out["scaling_point"] = {"error": str(e)[:300]}
             h, symb = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not zwork:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "poisson3d":
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.leaf, args.relax, args.maxsup)
         except Exception as e:

@@ -5,6 +5,11 @@
  *
  *   pddrive3d_amd N            7-point Poisson on an N^3 grid (what EXAMPLE/pddrive3d reads as a generated .dat), natural order
  *   pddrive3d_amd file.dat     triplet file, the format dreadtriple.c reads: "m n nnz" then "row col value", 0- or 1-based
+ *   pddrive3d_amd file.mtx     MatrixMarket coordinate file (real / integer / pattern; general / symmetric / skew-symmetric), what
+ *                              dreadMM.c reads (SRC/double/dreadMM.c: symmetric storage is expanded to the full pattern) -- e.g.
+ *                              SuiteSparse audikw_1.mtx (BASELINE.json configs[3]; not shipped: no network)
+ * Files are ordered with sluamd_order_nd (nested dissection of the pattern of A + A^T; the generated grid keeps its natural order
+ * unless -nd is given).
  *
  * Pipeline: symbolic factorisation (sluamd_dsymbfact) -> device-resident distribution + handle
  * (sluamd_dCreateLUHandleFromSymb) -> sluamd_pdgstrf3d -> sluamd_pdgstrs3d -> sluamd_pdgsrfs3d (IterRefine = SLU_DOUBLE),
@@ -81,15 +86,66 @@ static int read_triplets(const char *path, int64_t *n_out, int **rp_out, int **c
     return 0;
 }
 
+/* MatrixMarket coordinate format (what dreadMM_dist reads, SRC/double/dreadMM.c:40-230): banner "%%MatrixMarket matrix coordinate
+ * <real|integer|pattern> <general|symmetric|skew-symmetric>", comment lines, "m n nnz", then 1-based "row col [value]" lines;
+ * symmetric / skew-symmetric files store one triangle and are expanded; pattern files get value 1 (diagonal: row degree + 1, so
+ * that the unpivoted factorisation is defined).  Duplicates are summed. */
+static int read_matrix_market(const char *path, int64_t *n_out, int **rp_out, int **ci_out, double **v_out)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return 1;
+    char line[1024], obj[64], fmt[64], field[64], sym[64];
+    if (!fgets(line, sizeof line, f) || sscanf(line, "%%%%MatrixMarket %63s %63s %63s %63s", obj, fmt, field, sym) != 4) { fclose(f); return 1; }
+    for (char *c = field; *c; ++c) if (*c >= 'A' && *c <= 'Z') *c += 32;
+    for (char *c = sym; *c; ++c) if (*c >= 'A' && *c <= 'Z') *c += 32;
+    if (strcmp(fmt, "coordinate") || (strcmp(field, "real") && strcmp(field, "integer") && strcmp(field, "pattern"))) { fclose(f); return 1; }
+    const int pattern = !strcmp(field, "pattern");
+    const int symm = !strcmp(sym, "symmetric"), skew = !strcmp(sym, "skew-symmetric");
+    if (!symm && !skew && strcmp(sym, "general")) { fclose(f); return 1; }
+    do { if (!fgets(line, sizeof line, f)) { fclose(f); return 1; } } while (line[0] == '%');
+    long m, n, nz;
+    if (sscanf(line, "%ld %ld %ld", &m, &n, &nz) != 3 || m != n) { fclose(f); return 1; }
+    trip_t *t = (trip_t *) malloc(sizeof(trip_t) * (size_t) (2 * nz + 1));
+    if (!t) { fclose(f); return 1; }
+    long k = 0;
+    for (long e = 0; e < nz; ++e) {
+        int r, c; double val = 1.0;
+        if (pattern ? fscanf(f, "%d %d", &r, &c) != 2 : fscanf(f, "%d %d %lf", &r, &c, &val) != 3) { fclose(f); free(t); return 1; }
+        if (r < 1 || r > n || c < 1 || c > n) { fclose(f); free(t); return 1; }
+        t[k].r = r - 1; t[k].c = c - 1; t[k].v = val; ++k;
+        if ((symm || skew) && r != c) { t[k].r = c - 1; t[k].c = r - 1; t[k].v = skew ? -val : val; ++k; }
+    }
+    fclose(f);
+    qsort(t, (size_t) k, sizeof(trip_t), cmp_trip);
+    long u = 0;                                          /* sum duplicates */
+    for (long e = 0; e < k; ++e) { if (u && t[u - 1].r == t[e].r && t[u - 1].c == t[e].c) t[u - 1].v += t[e].v; else t[u++] = t[e]; }
+    int *rp = (int *) calloc((size_t) n + 1, sizeof(int)), *ci = (int *) malloc(sizeof(int) * (size_t) (u ? u : 1));
+    double *v = (double *) malloc(sizeof(double) * (size_t) (u ? u : 1));
+    for (long e = 0; e < u; ++e) { rp[t[e].r + 1]++; ci[e] = t[e].c; v[e] = t[e].v; }
+    for (long i = 0; i < n; ++i) rp[i + 1] += rp[i];
+    if (pattern) for (long i = 0; i < n; ++i) for (int e = rp[i]; e < rp[i + 1]; ++e) if (ci[e] == i) v[e] = (double) (rp[i + 1] - rp[i]) + 1.0;
+    free(t);
+    *n_out = n; *rp_out = rp; *ci_out = ci; *v_out = v;
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: %s N | file.dat\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s N [-nd] | file.dat | file.mtx\n", argv[0]); return 2; }
     if (sluamd_device_count() < 1) { fprintf(stderr, "no HIP device: this library has no CPU fallback\n"); return 3; }
     int64_t n; int *rp, *ci; double *v;
     char *end;
     const long N = strtol(argv[1], &end, 10);
+    int use_nd = argc > 2 && !strcmp(argv[2], "-nd");
+    const size_t len = strlen(argv[1]);
     if (*end == '\0' && N > 0) { if (poisson3d((int) N, &n, &rp, &ci, &v)) return 2; }
-    else if (read_triplets(argv[1], &n, &rp, &ci, &v)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+    else if (len > 4 && !strcmp(argv[1] + len - 4, ".mtx")) {
+        if (read_matrix_market(argv[1], &n, &rp, &ci, &v)) { fprintf(stderr, "cannot read MatrixMarket file %s\n", argv[1]); return 2; }
+        use_nd = 1;
+    } else {
+        if (read_triplets(argv[1], &n, &rp, &ci, &v)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+        use_nd = 1;
+    }
 
     /* xtrue, b = A xtrue, anorm (infinity norm, what pdgssvx3d passes to pdgstrf3d) */
     double *xt = (double *) malloc(sizeof(double) * n), *b = (double *) malloc(sizeof(double) * n), anorm = 0.0;
@@ -100,9 +156,11 @@ int main(int argc, char **argv)
         b[i] = s; if (rs > anorm) anorm = rs;
     }
 
-    /* symbolic factorisation: ColPerm = NATURAL (identity perm_c in; the etree postorder comes back in perm_c) */
+    /* ColPerm: NATURAL (generated grid) or our nested dissection (files), MY_PERMC in the reference's terms; the etree postorder of
+     * the symbolic factorisation is composed into perm_c */
     int *perm_c = (int *) malloc(sizeof(int) * n), *perm_c_in = (int *) malloc(sizeof(int) * n);
-    for (int64_t i = 0; i < n; ++i) perm_c_in[i] = (int) i;
+    if (use_nd) CHECK(sluamd_order_nd(n, rp, ci, 64, perm_c_in));
+    else for (int64_t i = 0; i < n; ++i) perm_c_in[i] = (int) i;
     sluamd_symb_t symb;
     CHECK(sluamd_dsymbfact(&symb, n, rp, ci, perm_c_in, 32, 256, perm_c));
     int32_t nsupers; int64_t nnzL, nnzU; double flops;
@@ -117,11 +175,11 @@ int main(int argc, char **argv)
     CHECK(sluamd_pdgstrf3d(h, thresh, &info));
     if (info) { printf("INFO = %d returned from pdgstrf3d (zero pivot)\n", info); return 1; }
 
-    /* solve: y = Pc b ; L U z = y ; x = Pc^T z */
-    double *y = (double *) malloc(sizeof(double) * n), *x = (double *) malloc(sizeof(double) * n);
-    for (int64_t i = 0; i < n; ++i) y[perm_c[i]] = b[i];
-    CHECK(sluamd_pdgstrs3d(h, y, n, 1));
-    for (int64_t i = 0; i < n; ++i) x[i] = y[perm_c[i]];
+    /* solve through pdgstrs3d's own boundary: b in the ORIGINAL row order in, x in the original order out (B_to_X / X_to_B with
+     * perm_c run inside the library; a single rank holds all n rows) */
+    double *x = (double *) malloc(sizeof(double) * n);
+    memcpy(x, b, sizeof(double) * n);
+    CHECK(sluamd_pdgstrs3d_dist(h, x, n, 1, n, 0, perm_c, perm_c));
 
     /* IterRefine = SLU_DOUBLE */
     double berr = 0.0; int32_t steps = 0;

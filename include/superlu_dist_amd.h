@@ -174,6 +174,10 @@ typedef struct sluamd_symb_s *sluamd_symb_t;
  * roles of sp_ienv_dist(2) / sp_ienv_dist(3) (sp_ienv.c:95-110). */
 int sluamd_dsymbfact(sluamd_symb_t *s, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
                      const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out);
+/* Fill-reducing ordering for matrices without geometry (the role of get_perm_c / METIS in the reference,
+ * SRC/prec-independent/get_perm_c.c): nested dissection of the pattern of A + A^T by BFS level structures; perm_c[old] = new,
+ * to be passed to sluamd_dsymbfact.  leaf = component size below which no further separator is sought (<= 0: 64). */
+int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind, int32_t leaf, sluamd_int_t *perm_c);
 int sluamd_symb_info(sluamd_symb_t s, int32_t *nsupers, int64_t *nnzL, int64_t *nnzU, int64_t *lidx_len,
                      int64_t *uidx_len, double *flops);
 /* borrow the store in the reference's formats (valid until sluamd_symb_free) */
@@ -197,6 +201,12 @@ void sluamd_symb_free(sluamd_symb_t s);
 /* elimination-forest partition for npdep Z layers (getForests' job, supernodalForest.c; tree ids in heap order like
  * getGridTrees, supernodal_etree.c:840-851): sn_tree[k] = forest of supernode k (see sluamd_dCreateLUHandleFromSymbGrid) */
 int sluamd_symb_partition(sluamd_symb_t s, int32_t npdep, int32_t *sn_tree);
+/* Capacity planning: stored factor values per world rank of an nprow x npcol x npdep grid (own slots, including the ancestor
+ * panels every layer below a forest replicates -- dinit3DLUstructForest, pd3dcomm.c:334-800), the part of them that is such a
+ * replica, and the index entries, from the symbolic structure alone.  Arrays of nprow*npcol*npdep entries; `replicated` /
+ * `index_entries` may be NULL; sn_tree as for sluamd_dCreateLUHandleFromSymbGrid (NULL when npdep == 1). */
+int sluamd_symb_grid_footprint(sluamd_symb_t s, int32_t nprow, int32_t npcol, int32_t npdep, const int32_t *sn_tree,
+                               int64_t *values, int64_t *replicated, int64_t *index_entries);
 /* re-run the device-side distribution (zero-fill + scatter of A) on such a handle: refactor loops */
 int sluamd_dResetValues(sluamd_handle_t h);
 

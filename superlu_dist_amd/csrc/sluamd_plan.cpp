@@ -2,6 +2,7 @@
 // (own slots ordered by Z level, DAG level, supernode so that every exchange moves ONE contiguous range), device block
 // tables / tile lists (dSchurComplementSetup's job, dtrfAux.c:102-491, done once), XY panel-exchange plans.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 #include "sluamd_comm.h"
@@ -786,7 +787,17 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
 
     // ---- 7. device allocations + uploads ----
     const size_t esz = H->z ? 16 : 8;
-    if (hipMalloc((void **) &H->d_val, esz * (size_t) std::max<int64_t>(H->arena_len, 1)) != hipSuccess) { set_error("hipMalloc of the value arena failed"); return SLUAMD_ENOMEM; }
+    if (hipMalloc((void **) &H->d_val, esz * (size_t) std::max<int64_t>(H->arena_len, 1)) != hipSuccess) {
+        size_t fr = 0, tot = 0;
+        hipMemGetInfo(&fr, &tot);
+        char msg[512];
+        snprintf(msg, sizeof msg, "hipMalloc of the value arena failed: rank (%d,%d,%d) of the %d x %d x %d grid needs %.1f GB (own L/U slots %.1f GB + exchange scratch %.1f GB) "
+                 "and %.1f GB of %.1f GB are free on device %d -- use a larger process grid (scripts/capacity.py prints the per-rank storage of a grid)",
+                 H->grid.r, H->grid.c, H->grid.z, H->grid.Pr, H->grid.Pc, H->grid.Pz, esz * (double) H->arena_len / 1e9, esz * (double) H->own_len / 1e9,
+                 esz * (double) (H->arena_len - H->own_len) / 1e9, fr / 1e9, tot / 1e9, H->device);
+        set_error(msg);
+        return SLUAMD_ENOMEM;
+    }
     HIPCHK(hipMemset(H->d_val, 0, esz * (size_t) H->arena_len));
     if (H->env.reserve_cus > 0) {
         // keep `reserve_cus` compute units out of the main (Schur tile) stream: the panel kernels of the look-ahead stream then

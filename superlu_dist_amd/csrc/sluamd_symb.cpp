@@ -414,3 +414,160 @@ extern "C" int sluamd_symb_partition(sluamd_symb_t s, int32_t npdep, int32_t *sn
     std::copy(t.begin(), t.end(), sn_tree);
     return 0;
 }
+
+// Storage of the factors per rank of an nprow x npcol x npdep grid, from the symbolic structure alone (what
+// sluamd_dCreateLUHandleFromSymbGrid will allocate for the own slots): L blocks live at (block row % nprow, k % npcol), U blocks at
+// (k % nprow, block column % npcol); a supernode of a forest at depth d of the forest tree is stored by every layer below that
+// forest -- factored on the first, zero-initialised replicas on the others (dinit3DLUstructForest, pd3dcomm.c:334-800) -- which is
+// what the Z ancestor reduction sums (pd3dcomm.c:1046-1081).
+extern "C" int sluamd_symb_grid_footprint(sluamd_symb_t sp, int32_t nprow, int32_t npcol, int32_t npdep, const int32_t *sn_tree,
+                                          int64_t *values, int64_t *replicated, int64_t *index_entries)
+{
+    using namespace sluamd;
+    if (!sp || nprow < 1 || npcol < 1 || npdep < 1 || (npdep & (npdep - 1)) || (npdep > 1 && !sn_tree) || !values) { set_error("bad footprint arguments"); return SLUAMD_EINVAL; }
+    const Symb &sy = *reinterpret_cast<Symb *>(sp);
+    const HostStruct &hs = sy.hs;
+    const int P = nprow * npcol * npdep;
+    int L = 1;
+    while ((1 << (L - 1)) < npdep) ++L;
+    std::fill(values, values + P, 0);
+    if (replicated) std::fill(replicated, replicated + P, 0);
+    if (index_entries) std::fill(index_entries, index_entries + P, 0);
+    for (int k = 0; k < hs.nsupers; ++k) {
+        const int f = npdep > 1 ? sn_tree[k] : 0;
+        int d = 0;
+        while ((1 << (d + 1)) - 1 <= f) ++d;                       // depth of forest f in the heap-ordered forest tree
+        if (d >= L) { set_error("sn_tree holds a forest id outside the tree of this npdep"); return SLUAMD_EINVAL; }
+        const int span = 1 << (L - 1 - d), z0 = (f - ((1 << d) - 1)) * span;     // layers z0 .. z0 + span - 1; z0 factors it
+        const int ns = hs.xsup[k + 1] - hs.xsup[k];
+        const int *li = hs.lidx.data() + hs.lidx_off[k];
+        if (hs.lidx_off[k + 1] - hs.lidx_off[k] >= BC_HEADER) {
+            int p = BC_HEADER;
+            for (int b = 0; b < li[0]; ++b) {
+                const int gid = li[p], nbrow = li[p + 1];
+                for (int z = z0; z < z0 + span && z < npdep; ++z) {
+                    const int w = (z * nprow + gid % nprow) * npcol + k % npcol;
+                    values[w] += (int64_t) nbrow * ns;
+                    if (replicated && z != z0) replicated[w] += (int64_t) nbrow * ns;
+                    if (index_entries) index_entries[w] += LB_DESCRIPTOR + nbrow;
+                }
+                p += LB_DESCRIPTOR + nbrow;
+            }
+        }
+        if (hs.uidx_off[k + 1] - hs.uidx_off[k] >= BR_HEADER) {
+            const int *ui = hs.uidx.data() + hs.uidx_off[k];
+            int p = BR_HEADER;
+            for (int b = 0; b < ui[0]; ++b) {
+                const int jb = ui[p], nnzb = ui[p + 1], nsj = hs.xsup[jb + 1] - hs.xsup[jb];
+                for (int z = z0; z < z0 + span && z < npdep; ++z) {
+                    const int w = (z * nprow + k % nprow) * npcol + jb % npcol;
+                    values[w] += nnzb;
+                    if (replicated && z != z0) replicated[w] += nnzb;
+                    if (index_entries) index_entries[w] += UB_DESCRIPTOR + nsj;
+                }
+                p += UB_DESCRIPTOR + nsj;
+            }
+        }
+    }
+    return 0;
+}
+
+// ---- fill-reducing ordering for matrices without geometry (what get_perm_c / METIS do for the reference,
+// SRC/prec-independent/get_perm_c.c, get_perm_c_parmetis.c).  Nested dissection of the pattern of A + A^T by BFS level structures
+// (George): connected component -> pseudo-peripheral root (repeated BFS) -> the level that halves the component, thinned to the
+// vertices that really touch the far side, is the separator (numbered last) -> recurse on both sides; components of at most `leaf`
+// vertices are numbered as they are.  Our own algorithm, O(nnz log n); the elimination-tree postorder of sluamd_dsymbfact then
+// makes the supernodes.
+extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind, int32_t leaf, sluamd_int_t *perm_c)
+{
+    using namespace sluamd;
+    if (n <= 0 || !rowptr || !colind || !perm_c) { set_error("bad ordering arguments"); return SLUAMD_EINVAL; }
+    if (leaf < 1) leaf = 64;
+    // symmetric adjacency without the diagonal
+    std::vector<int64_t> off(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i)
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const int j = colind[e];
+            if (j < 0 || j >= n) { set_error("column index out of range"); return SLUAMD_EINVAL; }
+            if (j != i) { off[i + 1]++; off[j + 1]++; }
+        }
+    for (int64_t i = 0; i < n; ++i) off[i + 1] += off[i];
+    std::vector<int> adj((size_t) off[n]);
+    {
+        std::vector<int64_t> pos(off.begin(), off.end() - 1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) { const int j = colind[e]; if (j != i) { adj[pos[i]++] = j; adj[pos[j]++] = (int) i; } }
+    }   // (duplicate edges of a symmetric input are harmless to BFS)
+    std::vector<int> part(n, 0);            // id of the vertex set a vertex currently belongs to; -1 = numbered
+    std::vector<int> level(n, -1), queue; queue.reserve(1024);
+    struct Job { std::vector<int> verts; };
+    std::vector<Job> stack;
+    { Job all; all.verts.resize(n); std::iota(all.verts.begin(), all.verts.end(), 0); stack.push_back(std::move(all)); }
+    int64_t next = n;                        // labels are handed out from the end: separators last
+    int next_part = 1;
+    auto number = [&](const std::vector<int> &vs) { for (auto it = vs.rbegin(); it != vs.rend(); ++it) { perm_c[*it] = (int) --next; part[*it] = -1; } };
+    // BFS inside the set `id` from `root`; fills queue (visit order) and level[]; returns the number of levels
+    auto bfs = [&](int root, int id) {
+        queue.clear(); queue.push_back(root); level[root] = 0;
+        int nl = 1;
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const int v = queue[h];
+            for (int64_t e = off[v]; e < off[v + 1]; ++e) {
+                const int w = adj[e];
+                if (part[w] == id && level[w] < 0) { level[w] = level[v] + 1; nl = level[w] + 1; queue.push_back(w); }
+            }
+        }
+        return nl;
+    };
+    while (!stack.empty()) {
+        Job job = std::move(stack.back()); stack.pop_back();
+        std::vector<int> &V = job.verts;
+        if (V.empty()) continue;
+        const int id = next_part++;
+        for (int v : V) part[v] = id;
+        if ((int) V.size() <= leaf) { number(V); continue; }
+        // first connected component (the others go back on the stack as they are)
+        int nl = bfs(V[0], id);
+        if (queue.size() < V.size()) {
+            Job rest, comp;
+            comp.verts = queue;
+            for (int v : V) if (level[v] < 0) rest.verts.push_back(v);
+            for (int v : queue) level[v] = -1;
+            stack.push_back(std::move(rest)); stack.push_back(std::move(comp));
+            continue;
+        }
+        // pseudo-peripheral root: restart from a vertex of the last level while the level structure gets deeper
+        for (int it = 0; it < 4; ++it) {
+            int far = queue.back(), best = (int) (off[far + 1] - off[far]);
+            for (size_t q = queue.size(); q-- > 0 && level[queue[q]] == nl - 1;) { const int v = queue[q], dg = (int) (off[v + 1] - off[v]); if (dg < best) { best = dg; far = v; } }
+            for (int v : queue) level[v] = -1;
+            const int nl2 = bfs(far, id);
+            if (nl2 <= nl) { nl = nl2; break; }
+            nl = nl2;
+        }
+        if (nl < 3) { for (int v : queue) level[v] = -1; number(V); continue; }     // (near-)clique: nothing to dissect
+        // the level that halves the component; among the levels around it the smallest one
+        std::vector<int64_t> cnt(nl, 0);
+        for (int v : queue) cnt[level[v]]++;
+        int64_t run = 0; int mid = 1;
+        for (int l = 0; l < nl; ++l) { run += cnt[l]; if (2 * run >= (int64_t) V.size()) { mid = l; break; } }
+        mid = std::max(1, std::min(nl - 2, mid));
+        int m = mid;
+        for (int l = std::max(1, mid - 1); l <= std::min(nl - 2, mid + 1); ++l) if (cnt[l] < cnt[m]) m = l;
+        Job lo, hi; std::vector<int> sep;
+        for (int v : queue) {
+            if (level[v] < m) lo.verts.push_back(v);
+            else if (level[v] > m) hi.verts.push_back(v);
+            else {   // thinning: a separator-level vertex without a neighbour in level m + 1 belongs to the near side
+                bool touches = false;
+                for (int64_t e = off[v]; e < off[v + 1] && !touches; ++e) touches = part[adj[e]] == id && level[adj[e]] == m + 1;
+                if (touches) sep.push_back(v); else lo.verts.push_back(v);
+            }
+        }
+        for (int v : queue) level[v] = -1;
+        number(sep);
+        stack.push_back(std::move(lo)); stack.push_back(std::move(hi));
+    }
+    if (next != 0) { set_error("ordering did not number every vertex"); return SLUAMD_ESTRUCT; }
+    return 0;
+}

@@ -76,6 +76,14 @@ class FlatStore:
         self.view = v
 
 
+def order_nd(n, rowptr, colind, leaf=64):
+    """perm_c[old] = new: nested dissection of the pattern of A + A^T without geometry (sluamd_order_nd)"""
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32); ci = np.ascontiguousarray(colind, dtype=np.int32)
+    perm = np.zeros(n, dtype=np.int32)
+    _lib.check(_lib.load().sluamd_order_nd(int(n), _pi(rp), _pi(ci), int(leaf), _pi(perm)), "sluamd_order_nd")
+    return perm
+
+
 class Symbolic:
     """sluamd_dsymbfact result (our symbfact_dist + pddistribute3d stand-in for a 1x1 layer)."""
 
@@ -104,6 +112,16 @@ class Symbolic:
         xs = np.empty(self.nsupers + 1, dtype=np.int32)
         _lib.check(_lib.load().sluamd_symb_export(self._h, _pi(xs), None, None, None, None, None, None, None, None), "sluamd_symb_export")
         return xs
+
+    def grid_footprint(self, Pr, Pc, Pz, sn_tree=None):
+        """stored factor values / replicated values / index entries per world rank of a Pr x Pc x Pz grid (sluamd_symb_grid_footprint)"""
+        P = Pr * Pc * Pz
+        vals, rep, idx = (np.zeros(P, dtype=np.int64) for _ in range(3))
+        t = None if sn_tree is None else np.ascontiguousarray(sn_tree, dtype=np.int32)
+        p64 = C.POINTER(C.c_int64)
+        _lib.check(_lib.load().sluamd_symb_grid_footprint(self._h, Pr, Pc, Pz, None if t is None else _pi(t), vals.ctypes.data_as(p64),
+                                                          rep.ctypes.data_as(p64), idx.ctypes.data_as(p64)), "sluamd_symb_grid_footprint")
+        return vals, rep, idx
 
     def partition(self, npdep):
         """Tree id (heap order) of every supernode for a 1 x 1 x npdep grid."""

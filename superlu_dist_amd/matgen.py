@@ -143,6 +143,51 @@ def stencil3d_unsym(N, drop=0.3, seed=0, reach=2):
     return n, np.cumsum(rowptr).astype(np.int32), cols.astype(np.int32), vals
 
 
+def elasticity3d_like(N, dof=3, drop=0.1, seed=0, shuffle=True):
+    """Stand-in for BASELINE.json configs[3] (SuiteSparse audikw_1: symmetric positive definite, 3-D structural mesh with 3 unknowns
+    per node, n = 943 695, ~82 entries per row -- not available offline): N^3 nodes x `dof` unknowns, every node coupled to its
+    27-point neighbourhood through dense dof x dof blocks (81 entries per row inside the mesh), a fraction `drop` of the node pairs
+    removed at random (irregular row lengths and separators), symmetric values, strictly diagonally dominant (SPD: unpivoted LU is
+    stable); the nodes are renumbered at random so that nothing but the graph tells an ordering where the separators are.
+    N = 68, dof = 3 gives n = 943 296."""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(N ** 3).reshape(N, N, N)
+    pairs_a, pairs_b = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if (dx, dy, dz) <= (0, 0, 0):
+                    continue                         # each undirected node pair once
+                sa = idx[max(0, -dx):N - max(0, dx), max(0, -dy):N - max(0, dy), max(0, -dz):N - max(0, dz)]
+                sb = idx[max(0, dx):N + min(0, dx), max(0, dy):N + min(0, dy), max(0, dz):N + min(0, dz)]
+                pairs_a.append(sa.ravel()); pairs_b.append(sb.ravel())
+    a = np.concatenate(pairs_a); b = np.concatenate(pairs_b)
+    keep = rng.random(a.size) >= drop
+    a, b = a[keep], b[keep]
+    if shuffle:
+        ren = rng.permutation(N ** 3)
+        a, b = ren[a], ren[b]
+    nn = N ** 3
+    # block entries: pair (a, b) -> dof x dof block W and its transpose at (b, a)
+    W = -rng.random((a.size, dof, dof))
+    ii = (a[:, None, None] * dof + np.arange(dof)[None, :, None]) + np.zeros((1, 1, dof), dtype=np.int64)
+    jj = (b[:, None, None] * dof + np.arange(dof)[None, None, :]) + np.zeros((1, dof, 1), dtype=np.int64)
+    rows = np.concatenate([ii.ravel(), jj.ravel()]); cols = np.concatenate([jj.ravel(), ii.ravel()]); vals = np.concatenate([W.ravel(), W.ravel()])
+    # diagonal blocks: symmetric coupling of the node's own unknowns, diagonal = 1 + sum of the row's magnitudes
+    D = -rng.random((nn, dof, dof)); D = 0.5 * (D + D.transpose(0, 2, 1))
+    di = (np.arange(nn)[:, None, None] * dof + np.arange(dof)[None, :, None]) + np.zeros((1, 1, dof), dtype=np.int64)
+    dj = (np.arange(nn)[:, None, None] * dof + np.arange(dof)[None, None, :]) + np.zeros((1, dof, 1), dtype=np.int64)
+    off = di.ravel() != dj.ravel()
+    rows = np.concatenate([rows, di.ravel()[off]]); cols = np.concatenate([cols, dj.ravel()[off]]); vals = np.concatenate([vals, D.ravel()[off]])
+    import scipy.sparse as sp
+    n = nn * dof
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    rowsum = np.asarray(abs(A).sum(axis=1)).ravel()
+    A = (A + sp.diags(1.0 + rowsum)).tocsr()
+    A.sort_indices()
+    return n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
 def write_triplet_dat(path, n, rowptr, colind, vals):
     """'.dat' triplet file the reference reads (SRC/double/dreadtriple.c:43-92, complex: SRC/complex16/zreadtriple.c):
     header 'm n nnz', 1-based, 'row col value' or 'row col re im'."""
@@ -167,3 +212,53 @@ def complex_shift(vals, rowptr, colind, seed=0):
     d = rows == colind
     out[d] = vals[d] * (1.0 + 0.0j) + (1.0 + 0.5j)
     return out
+
+
+def read_matrix_market(path):
+    """MatrixMarket coordinate file -> CSR (n, rowptr, colind, values) with symmetric / skew-symmetric storage expanded to the full
+    pattern and duplicates summed: what dreadMM_dist does for the reference (SRC/double/dreadMM.c).  real / integer / pattern / complex."""
+    with open(path) as f:
+        banner = f.readline().split()
+        if len(banner) != 5 or banner[0] != "%%MatrixMarket" or banner[2].lower() != "coordinate":
+            raise ValueError("not a MatrixMarket coordinate file: " + path)
+        field, sym = banner[3].lower(), banner[4].lower()
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        m, n, nz = (int(t) for t in line.split())
+        if m != n:
+            raise ValueError("matrix is not square")
+        data = np.loadtxt(f, ndmin=2) if nz else np.zeros((0, 3))
+    r = data[:, 0].astype(np.int64) - 1; c = data[:, 1].astype(np.int64) - 1
+    if field == "pattern":
+        val = np.ones(len(r))
+    elif field == "complex":
+        val = data[:, 2] + 1j * data[:, 3]
+    else:
+        val = data[:, 2].astype(np.float64)
+    if sym in ("symmetric", "skew-symmetric", "hermitian"):
+        off = r != c
+        r2, c2 = c[off], r[off]
+        v2 = -val[off] if sym == "skew-symmetric" else (np.conj(val[off]) if sym == "hermitian" else val[off])
+        r, c, val = np.concatenate([r, r2]), np.concatenate([c, c2]), np.concatenate([val, v2])
+    elif sym != "general":
+        raise ValueError("unsupported MatrixMarket symmetry " + sym)
+    import scipy.sparse as sp
+    A = sp.coo_matrix((val, (r, c)), shape=(n, n)).tocsr()      # sums duplicates
+    A.sort_indices()
+    v = A.data.copy()
+    if field == "pattern":      # a value that makes the unpivoted factorisation well defined: unit off-diagonals, dominant diagonal
+        deg = np.diff(A.indptr)
+        rows = np.repeat(np.arange(n), deg)
+        v[A.indices == rows] = (deg + 1.0)[rows[A.indices == rows]]
+    return n, A.indptr.astype(np.int32), A.indices.astype(np.int32), v
+
+
+def write_matrix_market(path, n, rowptr, colind, values, symmetric=False):
+    """CSR -> MatrixMarket coordinate real (symmetric=True stores the lower triangle only, like the SuiteSparse files)."""
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    keep = rows >= colind if symmetric else np.ones(len(colind), dtype=bool)
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real " + ("symmetric" if symmetric else "general") + "\n% written by superlu_dist_amd.matgen\n")
+        f.write(f"{n} {n} {int(keep.sum())}\n")
+        np.savetxt(f, np.column_stack([rows[keep] + 1, colind[keep] + 1, values[keep]]), fmt="%d %d %.17g")

@@ -63,3 +63,48 @@ def test_flops_match_oracle_tally():
     # symmetric pattern -> full U segments -> padded Schur flops == 2*nsupc*r*r summed
     total = flops[0] + flops[1]
     assert abs(total - symb.flops) / symb.flops < 0.05
+
+
+def test_matrix_market_reader_expands_symmetric_storage(tmp_path):
+    """dreadMM.c's job: symmetric / skew-symmetric coordinate files store one triangle; general files everything; duplicates are summed."""
+    import numpy as np
+    from superlu_dist_amd import matgen
+    n, rp, ci, v = matgen.elasticity3d_like(5, drop=0.2, seed=4)
+    matgen.write_matrix_market(str(tmp_path / "s.mtx"), n, rp, ci, v, symmetric=True)
+    matgen.write_matrix_market(str(tmp_path / "g.mtx"), n, rp, ci, v, symmetric=False)
+    for name in ("s.mtx", "g.mtx"):
+        n2, rp2, ci2, v2 = matgen.read_matrix_market(str(tmp_path / name))
+        assert n2 == n and np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.allclose(v2, v, rtol=0, atol=1e-15)
+    (tmp_path / "p.mtx").write_text("%%MatrixMarket matrix coordinate pattern symmetric\n% c\n3 3 4\n1 1\n2 1\n3 2\n3 3\n")
+    n3, rp3, ci3, v3 = matgen.read_matrix_market(str(tmp_path / "p.mtx"))
+    assert n3 == 3 and list(rp3) == [0, 2, 4, 6] and list(ci3) == [0, 1, 0, 2, 1, 2]
+    (tmp_path / "k.mtx").write_text("%%MatrixMarket matrix coordinate real skew-symmetric\n2 2 1\n2 1 3.5\n")
+    n4, rp4, ci4, v4 = matgen.read_matrix_market(str(tmp_path / "k.mtx"))
+    assert list(ci4) == [1, 0] and list(v4) == [-3.5, 3.5]
+
+
+def test_graph_nested_dissection_ordering(emul):
+    """sluamd_order_nd: a permutation, without geometry; far less fill than the natural order on a randomly renumbered mesh operator and on an
+    unsymmetric-pattern matrix; disconnected components and tiny inputs are handled; the factorisation with it solves the system."""
+    import numpy as np
+    from superlu_dist_amd import driver, matgen
+    n, rp, ci, v = matgen.elasticity3d_like(9, drop=0.1, seed=5)
+    p = driver.order_nd(n, rp, ci, leaf=32)
+    assert sorted(p.tolist()) == list(range(n))
+    s_nd = driver.Symbolic(n, rp, ci, p, relax=16, maxsup=128)
+    s_nat = driver.Symbolic(n, rp, ci, np.arange(n, dtype=np.int32), relax=16, maxsup=128)
+    assert s_nd.nnzL + s_nd.nnzU < 0.5 * (s_nat.nnzL + s_nat.nnzU)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, p, relax=16, maxsup=128)
+    assert info == 0 and np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
+    s_nd.free(); s_nat.free()
+    # two disconnected copies + isolated vertices
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    B = sp.block_diag([A, A, sp.identity(3)]).tocsr(); B.sort_indices()
+    pb = driver.order_nd(B.shape[0], B.indptr.astype(np.int32), B.indices.astype(np.int32), leaf=32)
+    assert sorted(pb.tolist()) == list(range(B.shape[0]))
+    n2, rp2, ci2, v2 = matgen.stencil3d_unsym(10, drop=0.3, seed=6)
+    p2 = driver.order_nd(n2, rp2, ci2)
+    assert sorted(p2.tolist()) == list(range(n2))
+    assert sorted(driver.order_nd(1, np.array([0, 1], dtype=np.int32), np.array([0], dtype=np.int32)).tolist()) == [0]
