@@ -233,7 +233,9 @@ def main():
             sn_tree = symb.partition(grid[2]) if grid[2] > 1 else None
             # pre-flight: the factors must fit the ranks' HBM -- fail loudly with the byte count, before any allocation
             vals, rep, _idx = symb.grid_footprint(*grid, sn_tree)
-            need = float(vals.max()) * 8 * 1.12          # + ~12 % for the exchange scratch, index images and inverse blocks (measured: profiles/r03_grid_footprint.txt)
+            # + index images / inverse blocks (~5 %) + on XY layers the double-buffered scratch for the panels received per DAG level, which
+            # grows with n, not with nnz (measured on 2 x 2 x 2 at 100^3: 1.5 kB per row, profiles/r03_grid_footprint.txt)
+            need = float(vals.max()) * 8 * 1.05 + (1500.0 * n if grid[0] * grid[1] > 1 else 0.0)
             if need > HBM_BYTES:
                 raise SystemExit(f"bench.py: {N}^3 does not fit a {grid[0]}x{grid[1]}x{grid[2]} grid of {HBM_BYTES / 1e9:.0f} GB GPUs: the fullest rank stores "
                                  f"{vals.max() * 8 / 1e9:.1f} GB of factor values ({rep.max() * 8 / 1e9:.1f} GB of them ancestor panels replicated along Z), "

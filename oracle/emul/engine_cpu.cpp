@@ -366,7 +366,7 @@ void solve_diag(hipStream_t, bool lower, const DevTables &T, const int *nodes, i
 }
 
 template <class V, int STRIP>
-static void fwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, V *x, int64_t ldx, int nrhs, const int2 *units)
+static void fwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const V *xsrc, V *x, int64_t ldx, int nrhs, const int2 *units)
 {
     std::vector<int> order(std::max(nwork, 0));
     for (int i = 0; i < nwork; ++i) order[i] = i;
@@ -385,7 +385,7 @@ static void fwd_update_t(const DevTables &T, const int *nodes, const int *prefix
             const V *L = reinterpret_cast<const V *>(T.val) + T.sn_lval[k] + row;
             for (int r = 0; r < nrhs; ++r) {
                 V acc(0);
-                for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * x[fst + kk + (int64_t) r * ldx];
+                for (int kk = 0; kk < ns; ++kk) acc += L[(size_t) kk * lda] * xsrc[fst + kk + (int64_t) r * ldx];
                 x[grow + (int64_t) r * ldx] -= acc;
             }
         }
@@ -393,7 +393,7 @@ static void fwd_update_t(const DevTables &T, const int *nodes, const int *prefix
 }
 
 template <class V>
-static void bwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, V *x, int64_t ldx, int nrhs, const int2 *units)
+static void bwd_update_t(const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const V *xcols, V *x, int64_t ldx, int nrhs, const int2 *units)
 {
     std::vector<int> order(std::max(nwork, 0));
     for (int i = 0; i < nwork; ++i) order[i] = i;
@@ -411,33 +411,57 @@ static void bwd_update_t(const DevTables &T, const int *nodes, const int *prefix
             const int64_t cidx = T.sn_ucol[k] + c;
             const int ld = T.ucol_ld[cidx], cp = T.ucol_cp[cidx], gc = T.ucol_gc[cidx];
             for (int r = 0; r < nrhs; ++r) {
-                const V xv = x[gc + (int64_t) r * ldx];
+                const V xv = xcols[gc + (int64_t) r * ldx];
                 for (int i = ld; i < ns; ++i) x[fst + i + (int64_t) r * ldx] -= Uv[cp + (i - ld)] * xv;
             }
         }
     }
 }
 
-void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
+void fwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int,
                 const int2 *units)
 {
-    fwd_update_t<double, 64>(T, nodes, prefix, nn, nwork, x, ldx, nrhs, units);
+    fwd_update_t<double, 64>(T, nodes, prefix, nn, nwork, xsrc, x, ldx, nrhs, units);
 }
 
-void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int,
+void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int,
                 const int2 *units)
 {
-    bwd_update_t<double>(T, nodes, prefix, nn, nwork, x, ldx, nrhs, units);
+    bwd_update_t<double>(T, nodes, prefix, nn, nwork, xcols, x, ldx, nrhs, units);
 }
 
-// the far units FIRST, then the diagonal solves: on the device the diagonal workgroups are dispatched first -- a dependency
-// inside one launch that should not be there shows up under one of the two orders
-void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits,
-                double *x, int64_t ldx, int nrhs, int mx)
+// out-of-place diagonal-solve strips (diag_strip_body): xout_k[64-row strip] = inverse[strip rows, :] xin_k, in a shuffled order under the
+// adversarial modes -- the strips of one supernode are independent only because xin != xout
+static void diag_strips(bool lower, const DevTables &T, const int2 *dunits, int ndu, const double *xin, double *xout, int64_t ldx, int nrhs)
 {
-    if (lower) fwd_update(s, T, nullptr, nullptr, 0, nunits, x, ldx, nrhs, mx, units);
-    else bwd_update(s, T, nullptr, nullptr, 0, nunits, x, ldx, nrhs, mx, units);
-    if (nd > 0) solve_diag(s, lower, T, dnodes, nd, x, ldx, nrhs, mx);
+    std::vector<int> order(std::max(ndu, 0));
+    for (int i = 0; i < ndu; ++i) order[i] = i;
+    if (unsigned sd = emul_launch_seed()) { std::mt19937 rng(sd + 17); std::shuffle(order.begin(), order.end(), rng); }
+    for (int it = 0; it < ndu; ++it) {
+        const int k = dunits[order[it]].x, strip = dunits[order[it]].y;
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+        const double *Ti = T.inv + T.sn_inv[k] + (lower ? 0 : (size_t) ns * ns);
+        for (int q = 0; q < nrhs; ++q)
+            for (int i = strip * 64; i < std::min(ns, strip * 64 + 64); ++i) {
+                double a = 0.0;
+                const int j0 = lower ? 0 : i, j1 = lower ? i + 1 : ns;
+                for (int j = j0; j < j1; ++j) a += Ti[i + (size_t) j * ns] * xin[fst + j + (int64_t) q * ldx];
+                xout[fst + i + (int64_t) q * ldx] = a;
+            }
+    }
+}
+
+// the far units and the diagonal strips of one launch in either order (seed parity): a dependency inside one launch that should
+// not be there shows up under one of the two orders
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
+                double *xa, double *xb, int64_t ldx, int nrhs, int mx)
+{
+    const bool diag_first = emul_launch_seed() & 1;
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((pass == 0) == diag_first) { if (ndu > 0) diag_strips(lower, T, dunits, ndu, lower ? xa : xb, lower ? xb : xa, ldx, nrhs); }
+        else if (lower) fwd_update(s, T, nullptr, nullptr, 0, nunits, xb, xa, ldx, nrhs, mx, units);
+        else bwd_update(s, T, nullptr, nullptr, 0, nunits, xa, xb, ldx, nrhs, mx, units);
+    }
 }
 
 // Dataflow sweep (k_chain): the device runs a unit as soon as the flags it waits for have reached their values -- in ANY order
@@ -445,7 +469,7 @@ void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes
 // so a wait missing from the host-built table changes the result on CPU.  A unit list that cannot complete (a signal nobody sends)
 // raises the abort word exactly like the bounded spin of the kernel.
 void chain_sweep(hipStream_t s, bool lower, int, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs, int *flags, int nflags,
-                 int *host_abort, double *x, int64_t ldx, int nrhs, int mx)
+                 int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs, int mx)
 {
     std::fill(flags, flags + nflags, 0);
     std::vector<char> done(std::max(nunits, 0), 0);
@@ -466,9 +490,13 @@ void chain_sweep(hipStream_t s, bool lower, int, const DevTables &T, const int *
         const int *rec = units + 8 * (size_t) u;
         const int k = rec[1];
         const int2 one = make_int2(k, rec[2]);
-        if (rec[0] == 0) solve_diag(s, lower, T, &k, 1, x, ldx, nrhs, mx);
-        else if (lower) fwd_update(s, T, nullptr, nullptr, 0, 1, x, ldx, nrhs, mx, &one);
-        else bwd_update(s, T, nullptr, nullptr, 0, 1, x, ldx, nrhs, mx, &one);
+        if (rec[0] == 0) {    // whole-node diagonal solve, lower xa -> xb, upper xb -> xa
+            const int nst = (T.xsup[k + 1] - T.xsup[k] + 63) / 64;
+            std::vector<int2> du(nst);
+            for (int st = 0; st < nst; ++st) du[st] = make_int2(k, st);
+            diag_strips(lower, T, du.data(), nst, lower ? xa : xb, lower ? xb : xa, ldx, nrhs);
+        } else if (lower) fwd_update(s, T, nullptr, nullptr, 0, 1, xb, xa, ldx, nrhs, mx, &one);
+        else bwd_update(s, T, nullptr, nullptr, 0, 1, xa, xb, ldx, nrhs, mx, &one);
         for (int i = 0; i < rec[6]; ++i) flags[sigs[rec[5] + i]]++;
         done[u] = 1;
     }
@@ -579,26 +607,27 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
     emul_enqueue(s, [=] { impl::solve_diag(s, lower, T, nodes, nn, x, ldx, nrhs, max_nsupc); });
 }
 
-void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
 {
-    emul_enqueue(s, [=] { impl::fwd_update(s, T, nodes, prefix, nn, nwork, x, ldx, nrhs, max_nsupc, units); });
+    emul_enqueue(s, [=] { impl::fwd_update(s, T, nodes, prefix, nn, nwork, xsrc, x, ldx, nrhs, max_nsupc, units); });
 }
 
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
 {
-    emul_enqueue(s, [=] { impl::bwd_update(s, T, nodes, prefix, nn, nwork, x, ldx, nrhs, max_nsupc, units); });
+    emul_enqueue(s, [=] { impl::bwd_update(s, T, nodes, prefix, nn, nwork, xcols, x, ldx, nrhs, max_nsupc, units); });
 }
 
-void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits, double *x, int64_t ldx, int nrhs, int max_nsupc)
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits, double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc)
 {
-    emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dnodes, nd, units, nunits, x, ldx, nrhs, max_nsupc); });
+    if (ndu + nunits <= 0) return;
+    emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, max_nsupc); });
 }
 
 void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs, int *flags, int nflags,
-                 int *host_abort, double *x, int64_t ldx, int nrhs, int max_nsupc)
+                 int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc)
 {
     if (nunits <= 0) return;
-    emul_enqueue(s, [=] { impl::chain_sweep(s, lower, mode, T, units, nunits, waits, sigs, flags, nflags, host_abort, x, ldx, nrhs, max_nsupc); });
+    emul_enqueue(s, [=] { impl::chain_sweep(s, lower, mode, T, units, nunits, waits, sigs, flags, nflags, host_abort, xa, xb, ldx, nrhs, max_nsupc); });
 }
 
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)
@@ -752,11 +781,11 @@ void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes
 }
 void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs, int)
 {
-    emul_enqueue(s, [=] { impl::fwd_update_t<impl::zc, 256>(T, nodes, prefix, nn, nwork, static_cast<impl::zc *>(x), ldx, nrhs, nullptr); });
+    emul_enqueue(s, [=] { impl::fwd_update_t<impl::zc, 256>(T, nodes, prefix, nn, nwork, static_cast<const impl::zc *>(x), static_cast<impl::zc *>(x), ldx, nrhs, nullptr); });
 }
 void zbwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs)
 {
-    emul_enqueue(s, [=] { impl::bwd_update_t<impl::zc>(T, nodes, prefix, nn, nwork, static_cast<impl::zc *>(x), ldx, nrhs, nullptr); });
+    emul_enqueue(s, [=] { impl::bwd_update_t<impl::zc>(T, nodes, prefix, nn, nwork, static_cast<const impl::zc *>(x), static_cast<impl::zc *>(x), ldx, nrhs, nullptr); });
 }
 void zscatter_values(hipStream_t s, void *val, const int64_t *pos, const void *a, int64_t nnz)
 {

@@ -537,6 +537,7 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_info) hipFree(H->d_info);
     if (H->d_x) hipFree(H->d_x);
     if (H->d_xtmp) hipFree(H->d_xtmp);
+    if (H->d_w) hipFree(H->d_w);
     if (H->d_apos) hipFree(H->d_apos);
     if (H->d_aval) hipFree(H->d_aval);
     if (H->h_pinned) hipHostFree(H->h_pinned);

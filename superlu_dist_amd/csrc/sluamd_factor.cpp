@@ -428,55 +428,77 @@ static int xseg_exchange(Handle *H, double *d_x, int64_t ldx, int nrhs, const st
 // run by the diagonal workgroup itself -- serial 64-row strips, 7.05 -> 8.1 ms.)
 static bool use_chain(const Handle *H, const LevelSched &S) { return S.chain_l0 >= 0 && H->env.chain_mode && H->chain_abort; }
 
+static int max_rhs_chunk(const Handle *H);
+// second vector of the sweeps below: the diagonal solves are out of place (strips of one supernode = independent workgroups)
+static int ensure_w(Handle *H, int64_t doubles)
+{
+    if (doubles <= H->w_cap) return 0;
+    if (H->d_w) hipFree(H->d_w);
+    H->d_w = nullptr; H->w_cap = 0;
+    if (hipMalloc((void **) &H->d_w, sizeof(double) * (size_t) doubles) != hipSuccess) { set_error("hipMalloc of the solve work vector failed"); return SLUAMD_ENOMEM; }
+    H->w_cap = doubles;
+    return 0;
+}
+
+// Forward links.  x (= d_x) holds the right-hand side minus the updates applied so far; w receives the solved blocks y_k = Linv (x_k)
+// and is what the updates read.  After the forward sweeps of all Z levels w holds y for every supernode solved on this rank.
 static int solve_fwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
     const int nl = S.nlevels;
     if (nl == 0) return 0;
+    double *w = H->d_w;
     // levels >= l0: the dataflow form (one persistent launch, LevelSched::cf_*); below it one launch pair per level
     const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
-    if (l0 > 0) eng::sweep_step(s, true, T, S.d_nodes + S.lvl_off[0], S.lvl_off[1] - S.lvl_off[0], nullptr, 0, d_x, ldx, nrhs, S.max_nsupc[0]);
+    if (l0 > 0) eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[0], S.du_off[1] - S.du_off[0], nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0]);
     for (int l = 0; l < l0; ++l) {
         const int u0 = S.fu_off[2 * l], u1 = S.fu_off[2 * l + 1], u2 = S.fu_off[2 * l + 2];
-        const int nd = (l + 1 < l0) ? S.lvl_off[l + 2] - S.lvl_off[l + 1] : 0;     // the diagonal solves of level l0 belong to the chain
+        const int nd = (l + 1 < l0) ? S.du_off[l + 2] - S.du_off[l + 1] : 0;     // the diagonal solves of level l0 belong to the chain
         const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
-        eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0);
-        eng::sweep_step(s, true, T, S.d_nodes + (nd ? S.lvl_off[l + 1] : 0), nd, S.d_fwd_units + u1, u2 - u1, d_x, ldx, nrhs, mx);
+        eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, w, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0);
+        eng::sweep_step(s, true, T, S.d_diag_units + (nd ? S.du_off[l + 1] : 0), nd, S.d_fwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, mx);
+        H->st.solve_launches += 2;
     }
     if (l0 < nl) {
         int mx = 0;
         for (int l = l0; l < nl; ++l) mx = std::max(mx, S.max_nsupc[l]);
         eng::chain_sweep(s, true, H->env.chain_mode, T, S.d_cf_units, (int) (S.cf_units.size() / 8), S.d_cf_waits, S.d_cf_sigs, S.d_chain_flags, S.chain_nflags,
-                         H->chain_abort, d_x, ldx, nrhs, mx);
+                         H->chain_abort, d_x, w, ldx, nrhs, mx);
+        H->st.solve_launches += 1;
     }
     return 0;
 }
 
+// Backward links: w_k (the forward solution) minus the updates U(k, :) x accumulates in w; the final x_k = Uinv w_k goes to d_x.
 static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
     hipStream_t s = H->stream;
     const int nl = S.nlevels;
     if (nl == 0) return 0;
+    double *w = H->d_w;
     const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
     if (l0 < nl) {
         int mx = 0;
         for (int l = l0; l < nl; ++l) mx = std::max(mx, S.max_nsupc[l]);
         if (l0 > 0) mx = std::max(mx, S.max_nsupc[l0 - 1]);      // the far chunks of level l0 - 1 ride along (LevelSched: F(l - 1) after D(l))
         eng::chain_sweep(s, false, H->env.chain_mode, T, S.d_cb_units, (int) (S.cb_units.size() / 8), S.d_cb_waits, S.d_cb_sigs, S.d_chain_flags, S.chain_nflags,
-                         H->chain_abort, d_x, ldx, nrhs, mx);
+                         H->chain_abort, d_x, w, ldx, nrhs, mx);
+        H->st.solve_launches += 1;
     } else {   // far chunks of the top level (columns of ancestors in other forests, solved before this sweep)
         const int u1 = S.bu_off[2 * (nl - 1) + 1], u2 = S.bu_off[2 * (nl - 1) + 2];
-        eng::sweep_step(s, false, T, nullptr, 0, S.d_bwd_units + u1, u2 - u1, d_x, ldx, nrhs, S.max_nsupc[nl - 1]);
+        eng::sweep_step(s, false, T, nullptr, 0, S.d_bwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, S.max_nsupc[nl - 1]);
+        H->st.solve_launches += 1;
     }
     for (int l = l0 - 1; l >= 0; --l) {
         const int u0 = S.bu_off[2 * l], u1 = S.bu_off[2 * l + 1];
-        const int nd = S.lvl_off[l + 1] - S.lvl_off[l];
+        const int nd = S.du_off[l + 1] - S.du_off[l];
         const int b1 = l > 0 ? S.bu_off[2 * (l - 1) + 1] : 0, b2 = l > 0 ? S.bu_off[2 * (l - 1) + 2] : 0;   // far chunks of level l-1: x of levels >= l+1 only
         const int mx = std::max(S.max_nsupc[l], l > 0 ? S.max_nsupc[l - 1] : 0);
-        eng::bwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, ldx, nrhs, S.max_nsupc[l], S.d_bwd_units + u0);
-        eng::sweep_step(s, false, T, S.d_nodes + S.lvl_off[l], nd, S.d_bwd_units + b1, b2 - b1, d_x, ldx, nrhs, mx);
+        eng::bwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, w, ldx, nrhs, S.max_nsupc[l], S.d_bwd_units + u0);
+        eng::sweep_step(s, false, T, S.d_diag_units + S.du_off[l], nd, S.d_bwd_units + b1, b2 - b1, d_x, w, ldx, nrhs, mx);
+        H->st.solve_launches += 2;
     }
     return 0;
 }
@@ -487,7 +509,10 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     hipStream_t s = H->stream;
     LevelSched &S = H->sched[z];
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
-    if (!xy && !H->z && !H->profile) return solve_fwd_links(H, S, d_x, ldx, nrhs);
+    if (!xy && !H->z && !H->profile) {
+        int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));
+        return rc ? rc : solve_fwd_links(H, S, d_x, ldx, nrhs);
+    }
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
@@ -499,7 +524,7 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
         eng::solve_diag(s, true, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;
-        eng::fwd_update(s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, S.fwd_prefix[po + nn], d_x, ldx, nrhs, S.max_nsupc[l]);
+        eng::fwd_update(s, T, S.d_nodes + n0, S.d_fwd_prefix + po, nn, S.fwd_prefix[po + nn], d_x, d_x, ldx, nrhs, S.max_nsupc[l]);
     }
     return 0;
 }
@@ -509,7 +534,10 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     hipStream_t s = H->stream;
     LevelSched &S = H->sched[z];
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
-    if (!xy && !H->z && !H->profile) return solve_bwd_links(H, S, d_x, ldx, nrhs);
+    if (!xy && !H->z && !H->profile) {
+        int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));      // (already there: the forward sweep ran first)
+        return rc ? rc : solve_bwd_links(H, S, d_x, ldx, nrhs);
+    }
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
@@ -518,7 +546,7 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
             eng::zsolve_diag(s, false, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
             continue;
         }
-        eng::bwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, ldx, nrhs, S.max_nsupc[l]);
+        eng::bwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, d_x, ldx, nrhs, S.max_nsupc[l]);
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
         eng::solve_diag(s, false, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
         if (xy && (rc = xseg_exchange(H, d_x, ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;
@@ -537,6 +565,7 @@ int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
 {
     int rc = H->z ? 0 : ensure_inv(H);
     if (rc) return rc;
+    H->st.solve_launches = 0;
     const int ch = max_rhs_chunk(H);
     const int vs = H->z ? 2 : 1;
     for (int j0 = 0; j0 < nrhs; j0 += ch) {

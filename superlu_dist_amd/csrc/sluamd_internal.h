@@ -170,6 +170,8 @@ struct LevelSched {
     // chain waits for, bulk = levels >= l+2 only (launched together with that diagonal solve, eng::sweep_step)
     std::vector<int2> fwd_units, bwd_units;
     std::vector<int> fu_off, bu_off;          // [2*nlevels+1]: index 2*level + part
+    std::vector<int2> diag_units;             // (supernode, 64-row strip) of every owned diagonal block, level by level: the out-of-place diagonal solves of the sweeps
+    std::vector<int> du_off;                  // [nlevels+1]
     // Dataflow ("chain") form of the two sweeps over the TOP of the schedule, levels >= chain_l0 (1 x 1 layers, real): few
     // supernodes per level, one dependent launch pair per level in the level-set form -- launch latency, not bandwidth.  Here
     // ONE persistent launch per sweep walks a topologically ordered unit list with device-side dependency counters, the
@@ -204,7 +206,7 @@ struct LevelSched {
     int *d_fwd_prefix = nullptr, *d_bwd_prefix = nullptr, *d_inv_prefix = nullptr, *d_sn_level = nullptr, *d_zltr_prefix = nullptr;
     int *d_finv_prefix = nullptr, *d_zfwd_prefix = nullptr;
     int4 *d_ulist = nullptr;
-    int2 *d_fwd_units = nullptr, *d_bwd_units = nullptr;
+    int2 *d_fwd_units = nullptr, *d_bwd_units = nullptr, *d_diag_units = nullptr;
     int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
 };
 
@@ -257,6 +259,7 @@ struct Handle {
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
     double *d_x = nullptr; int64_t x_cap = 0;
     double *d_xtmp = nullptr; int64_t xtmp_cap = 0;   // exchange staging of the distributed solve / ancestor reduction
+    double *d_w = nullptr; int64_t w_cap = 0;         // second vector of the 1 x 1-layer sweeps (out-of-place diagonal solves: forward solution, backward accumulators)
     int64_t *d_apos = nullptr; double *d_aval = nullptr; int64_t a_nnz = 0;  // A's entries for device-side (re)distribution
     // iterative refinement (sluamd_dAttachMatrix): the ORIGINAL matrix in CSR + perm_c, and work vectors
     int *d_rfs_rp = nullptr, *d_rfs_ci = nullptr, *d_rfs_pc = nullptr; double *d_rfs_av = nullptr;
@@ -319,18 +322,22 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
-// units != null: the launch runs the host-built (supernode, strip / chunk) list `units[0 .. nwork)` instead of the level's prefix arrays
-void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs,
+// units != null: the launch runs the host-built (supernode, strip / chunk) list `units[0 .. nwork)` instead of the level's prefix arrays.
+// Two vectors (they may be the same one: XY layers, profiling): the update reads solved blocks from xsrc / xcols and subtracts from x
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs,
                 int max_nsupc, const int2 *units = nullptr);
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int max_nsupc,
-                const int2 *units = nullptr);
-// one link of a sweep on a 1 x 1 layer: diagonal solves of `dnodes` + the update units `units` that do not feed them, one launch
-// (max_nsupc over everything in the launch)
-void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits,
-                double *x, int64_t ldx, int nrhs, int max_nsupc);
-// dataflow sweep over a topologically ordered unit list (LevelSched::cf_* / cb_*): ONE persistent launch; `flags` zeroed on s first
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs,
+                int max_nsupc, const int2 *units = nullptr);
+// one link of a sweep on a 1 x 1 layer: the diagonal-solve strips `dunits` (supernode, 64-row strip; OUT OF PLACE: lower xa -> xb, upper
+// xb -> xa) + the update units `units` that do not feed them (lower: read xb, subtract from xa; upper: read xa, subtract from xb), one
+// launch (max_nsupc over everything in the launch)
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
+                double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc);
+// dataflow sweep over a topologically ordered unit list (LevelSched::cf_* / cb_*): ONE persistent launch; `flags` zeroed on s first;
+// the same two vectors as sweep_step
 void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,
-                 int *flags, int nflags, int *host_abort /* pinned host word, set to 1 when a dependency never arrived */, double *x, int64_t ldx, int nrhs, int max_nsupc);
+                 int *flags, int nflags, int *host_abort /* pinned host word, set to 1 when a dependency never arrived */, double *xa, double *xb, int64_t ldx, int nrhs,
+                 int max_nsupc);
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz);
 void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
                   double *r_perm, unsigned long long *s_out, double safe1, double safe2);

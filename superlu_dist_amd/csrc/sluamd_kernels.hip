@@ -1330,14 +1330,14 @@ template <bool COH> __device__ __forceinline__ void st_x(double *p, double v)
 }
 
 template <bool LOWER, int NT, bool COH = false>   // NT = 1024, or 256 for levels whose supernodes are at most 64 wide (one column quarter)
-__device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, double *__restrict__ x, int64_t ldx, int nrhs, double *xs /* ns x nrhs */)
+__device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, const double *xin, double *xout, int64_t ldx, int nrhs, double *xs /* ns x nrhs */)
 {
     __shared__ double s_part[NT / 256][256];
     if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;           // x_k is solved by the owner of the diagonal block
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xs[idx] = ld_x<COH>(x + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xs[idx] = ld_x<COH>(xin + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
     __syncthreads();
     // thread = (row i, quarter of the columns): <= 4 batches of 16 L2 loads; the inverse stores explicit zeros in the other
     // triangle, column blocks entirely outside the wave's rows are skipped
@@ -1366,7 +1366,7 @@ __device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, doubl
         if (tid < ns) {
             double a = s_part[0][tid];
             if (NT == 1024) a = (a + s_part[1][tid]) + (s_part[NT == 1024 ? 2 : 0][tid] + s_part[NT == 1024 ? 3 : 0][tid]);
-            st_x<COH>(x + fst + tid + (int64_t) q * ldx, a);
+            st_x<COH>(xout + fst + tid + (int64_t) q * ldx, a);
         }
         __syncthreads();
     }
@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
                                                    int64_t ldx, int nrhs)
 {
     extern __shared__ double xs[];  // ns x nrhs
-    solve_diag_body<LOWER, NT>(T, nodes[blockIdx.x], x, ldx, nrhs, xs);
+    solve_diag_body<LOWER, NT>(T, nodes[blockIdx.x], x, x, ldx, nrhs, xs);
 }
 
 // The sweeps are bound by load latency and per-CU bandwidth, not by HBM (one dependent launch per level of the elimination
@@ -1387,14 +1387,15 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
 // lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414): workgroup = (supernode,
 // 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
 template <int NT, bool COH = false>
-__device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, double *__restrict__ x, int64_t ldx, int nrhs, double *xk /* ns x nrhs */)
+__device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, const double *xsrc /* solved x_k */, double *xdst /* lsum accumulators */,
+                                                int64_t ldx, int nrhs, double *xk /* ns x nrhs */)
 {
     constexpr int NP = NT / 64;     // column slices
     __shared__ double s_red[NP][64 + 1];
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(x + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(xsrc + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
     __syncthreads();
     const int r = tid & 63, part = tid >> 6;
     const int row = T.sn_ldiag[k] + strip * 64 + r;
@@ -1423,7 +1424,7 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
             double a = 0.0;
 #pragma unroll
             for (int p2 = 0; p2 < NP; ++p2) a += s_red[p2][r];
-            atomic_sub_f64(x + grow + (int64_t) q * ldx, a);
+            atomic_sub_f64(xdst + grow + (int64_t) q * ldx, a);
         }
         __syncthreads();
     }
@@ -1431,20 +1432,21 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs, const int2 *__restrict__ units)
+                                                   int nn, const double *xsrc, double *xdst, int64_t ldx, int nrhs, const int2 *__restrict__ units)
 {
     extern __shared__ double xk[];  // ns x nrhs
     int k, strip;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; strip = u.y; }   // host-built (supernode, strip) list of one launch
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
-    fwd_update_body<NT>(T, k, strip, x, ldx, nrhs, xk);
+    fwd_update_body<NT>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
 }
 
 // x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
 // lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
 template <int NT, bool COH = false>   // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block)
-__device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int chunk, double *__restrict__ x, int64_t ldx, int nrhs)
+__device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int chunk, const double *xcols /* solved x of the chunk's columns */,
+                                                double *xrows /* accumulators of x_k */, int64_t ldx, int nrhs)
 {
     constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = (NT == 1024) ? 4 : 1;
     __shared__ int s_cp[64], s_ld[64], s_gc[64];
@@ -1460,7 +1462,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     __syncthreads();
     const double *Uv = T.val + T.sn_uval[k];
     for (int r = 0; r < nrhs; ++r) {
-        if (tid < ncol) s_xc[tid] = ld_x<COH>(x + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
+        if (tid < ncol) s_xc[tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
         __syncthreads();
         {
             double a[RB];
@@ -1497,7 +1499,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
             double sv = 0.0;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) sv += s_red[w][tid];
-            if (sv != 0.0) atomic_sub_f64(x + fst + tid + (int64_t) r * ldx, sv);
+            if (sv != 0.0) atomic_sub_f64(xrows + fst + tid + (int64_t) r * ldx, sv);
         }
         __syncthreads();
     }
@@ -1505,27 +1507,83 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                   int nn, double *__restrict__ x, int64_t ldx, int nrhs, const int2 *__restrict__ units)
+                                                   int nn, const double *xcols, double *xrows, int64_t ldx, int nrhs, const int2 *__restrict__ units)
 {
     int k, chunk;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; chunk = u.y; }
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
-    bwd_update_body<NT>(T, k, chunk, x, ldx, nrhs);
+    bwd_update_body<NT>(T, k, chunk, xcols, xrows, ldx, nrhs);
 }
 
-// One link of a sweep on a 1 x 1 layer in ONE launch: workgroups [0, nd) solve the diagonal blocks of `dnodes` (the next level
-// of the chain), the others run update units that do not feed those diagonal solves (LevelSched::fwd_units / bwd_units, bulk
-// part) -- the 10 us diagonal solve of a chain supernode hides behind the far updates of its predecessor.
+// One 64-row strip of a diagonal solve, OUT OF PLACE: xout_k[strip rows] = (Linv or Uinv)[strip rows, :] xin_k.  The diagonal solve of a
+// chain supernode sits on the critical path of the sweeps (one dependent launch per level): as ONE workgroup it streams the 512 KB
+// inverse through one CU (~10 us); as ns / 64 independent strips of the same GEMV shape as the panel update it takes what a launch
+// takes.  Independent only because input and output are different vectors (LevelSched sweeps ping-pong between x and a work vector).
 template <bool LOWER, int NT>
-__global__ __launch_bounds__(NT) void k_sweep(DevTables T, const int *__restrict__ dnodes, int nd, const int2 *__restrict__ units,
-                                              double *__restrict__ x, int64_t ldx, int nrhs)
+__device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int strip, const double *xin, double *xout, int64_t ldx, int nrhs,
+                                                double *xk /* ns x nrhs */)
+{
+    constexpr int NP = NT / 64;     // column slices
+    __shared__ double s_dred[NP][64 + 1];
+    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+    const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = xin[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    __syncthreads();
+    const int r = tid & 63, part = tid >> 6;
+    const int row = strip * 64 + r;
+    const bool rvalid = row < ns;
+    // the inverse stores explicit zeros in the other triangle: only the column blocks up to (from) the strip's own are read
+    const int c0 = LOWER ? 0 : strip * 64, c1 = LOWER ? min(ns, strip * 64 + 64) : ns;
+    const int cpp = (c1 - c0 + NP - 1) / NP;
+    const int ka = min(c1, c0 + part * cpp), kb = min(c1, ka + cpp);
+    const double *Tr = Ti + row;
+    for (int q = 0; q < nrhs; ++q) {
+        const double *xq = xk + q * ns;
+        double acc[4] = {0, 0, 0, 0};
+        if (rvalid) {
+            int kk = ka;
+            for (; kk + 16 <= kb; kk += 16) {
+                double tv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tv[u] = Tr[(size_t) (kk + u) * ns];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u & 3] += tv[u] * xq[kk + u];
+            }
+            for (; kk < kb; ++kk) acc[0] += Tr[(size_t) kk * ns] * xq[kk];
+        }
+        s_dred[part][r] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();
+        if (part == 0 && rvalid) {
+            double a = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < NP; ++p2) a += s_dred[p2][r];
+            xout[fst + row + (int64_t) q * ldx] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// One link of a sweep on a 1 x 1 layer in ONE launch: workgroups [0, ndu) run the diagonal-solve strips `dunits` of the next level of
+// the chain, the others run update units that do not feed those diagonal solves (LevelSched::fwd_units / bwd_units, bulk part) -- the
+// diagonal solve of a chain supernode hides behind the far updates of its predecessor.  Two vectors: forward, the accumulated
+// right-hand side lives in xa and the solved blocks go to xb (updates read xb, subtract from xa); backward, the accumulators are
+// xb (= the forward solution minus the updates) and the final x_k goes to xa (updates read xa, subtract from xb).
+template <bool LOWER, int NT>
+__global__ __launch_bounds__(NT) void k_sweep(DevTables T, const int2 *__restrict__ dunits, int ndu, const int2 *__restrict__ units,
+                                              double *xa, double *xb, int64_t ldx, int nrhs)
 {
     extern __shared__ double dyn[];  // max_nsupc x nrhs
     const int bid = blockIdx.x;
-    if (bid < nd) { solve_diag_body<LOWER, NT>(T, dnodes[bid], x, ldx, nrhs, dyn); return; }
-    const int2 u = units[bid - nd];
-    if (LOWER) fwd_update_body<NT>(T, u.x, u.y, x, ldx, nrhs, dyn);
-    else bwd_update_body<NT>(T, u.x, u.y, x, ldx, nrhs);
+    if (bid < ndu) {
+        const int2 d = dunits[bid];
+        if (LOWER) diag_strip_body<true, NT>(T, d.x, d.y, xa, xb, ldx, nrhs, dyn);
+        else diag_strip_body<false, NT>(T, d.x, d.y, xb, xa, ldx, nrhs, dyn);
+        return;
+    }
+    const int2 u = units[bid - ndu];
+    if (LOWER) fwd_update_body<NT>(T, u.x, u.y, xb, xa, ldx, nrhs, dyn);
+    else bwd_update_body<NT>(T, u.x, u.y, xa, xb, ldx, nrhs);
 }
 
 // Dataflow sweeps over the top of the elimination DAG (LevelSched::chain_l0): ONE persistent launch walks a topologically
@@ -1544,7 +1602,7 @@ __global__ __launch_bounds__(NT) void k_sweep(DevTables T, const int *__restrict
 constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 22;     // x ~0.3 us per poll: about a second
 template <bool LOWER, int MODE>
 __global__ __launch_bounds__(1024) void k_chain(DevTables T, const int *__restrict__ units, int nunits, const int2 *__restrict__ waits,
-                                                const int *__restrict__ sigs, int *flags, int *host_abort, double *x, int64_t ldx, int nrhs)
+                                                const int *__restrict__ sigs, int *flags, int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs)
 {
     extern __shared__ double dyn[];  // max_nsupc x nrhs
     __shared__ int s_u[2];
@@ -1583,9 +1641,10 @@ __global__ __launch_bounds__(1024) void k_chain(DevTables T, const int *__restri
         __syncthreads();
         if (s_u[1]) return;
         // ---- the unit ----
-        if (type == 0) solve_diag_body<LOWER, 1024, COH>(T, k, x, ldx, nrhs, dyn);
-        else if (LOWER) fwd_update_body<1024, COH>(T, k, idx, x, ldx, nrhs, dyn);
-        else bwd_update_body<1024, COH>(T, k, idx, x, ldx, nrhs);
+        // the same two vectors as k_sweep: forward xa -> xb at the diagonal solves, backward xb -> xa
+        if (type == 0) { if (LOWER) solve_diag_body<true, 1024, COH>(T, k, xa, xb, ldx, nrhs, dyn); else solve_diag_body<false, 1024, COH>(T, k, xb, xa, ldx, nrhs, dyn); }
+        else if (LOWER) fwd_update_body<1024, COH>(T, k, idx, xb, xa, ldx, nrhs, dyn);
+        else bwd_update_body<1024, COH>(T, k, idx, xa, xb, ldx, nrhs);
         // ---- publish ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores / atomics have left the CU
         __syncthreads();
@@ -1769,49 +1828,49 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
     }
 }
 
-void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx,
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int mx,
                 const int2 *units)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs, units);
-    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, x, ldx, nrhs, units);
+    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units);
+    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units);
 }
 
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, double *x, int64_t ldx, int nrhs, int mx,
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int mx,
                 const int2 *units)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, x, ldx, nrhs, units);
-    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, x, ldx, nrhs, units);
+    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units);
+    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units);
 }
 
-void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int *dnodes, int nd, const int2 *units, int nunits,
-                double *x, int64_t ldx, int nrhs, int mx)
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
+                double *xa, double *xb, int64_t ldx, int nrhs, int mx)
 {
-    if (nd + nunits <= 0) return;
+    if (ndu + nunits <= 0) return;
     const size_t lds = (size_t) mx * nrhs * sizeof(double);
     if (mx <= 64) {
-        if (lower) hipLaunchKernelGGL((k_sweep<true, 256>), dim3(nd + nunits), dim3(256), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
-        else hipLaunchKernelGGL((k_sweep<false, 256>), dim3(nd + nunits), dim3(256), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
+        if (lower) hipLaunchKernelGGL((k_sweep<true, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
+        else hipLaunchKernelGGL((k_sweep<false, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
     } else {
-        if (lower) hipLaunchKernelGGL((k_sweep<true, 1024>), dim3(nd + nunits), dim3(1024), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
-        else hipLaunchKernelGGL((k_sweep<false, 1024>), dim3(nd + nunits), dim3(1024), lds, s, T, dnodes, nd, units, x, ldx, nrhs);
+        if (lower) hipLaunchKernelGGL((k_sweep<true, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
+        else hipLaunchKernelGGL((k_sweep<false, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
     }
 }
 
 void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,
-                 int *flags, int nflags, int *host_abort, double *x, int64_t ldx, int nrhs, int mx)
+                 int *flags, int nflags, int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs, int mx)
 {
     if (nunits <= 0) return;
     hipMemsetAsync(flags, 0, sizeof(int) * (size_t) nflags, s);      // tickets, abort flag, dependency counters: zeroed before every launch
     const size_t lds = (size_t) mx * nrhs * sizeof(double);
     const int grid = std::min(nunits, g_num_cus);                   // one 1024-thread workgroup per CU; fewer resident ones are fine (tickets)
     if (mode == 2) {
-        if (lower) hipLaunchKernelGGL((k_chain<true, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
-        else hipLaunchKernelGGL((k_chain<false, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
+        if (lower) hipLaunchKernelGGL((k_chain<true, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
+        else hipLaunchKernelGGL((k_chain<false, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
     } else {
-        if (lower) hipLaunchKernelGGL((k_chain<true, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
-        else hipLaunchKernelGGL((k_chain<false, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, x, ldx, nrhs);
+        if (lower) hipLaunchKernelGGL((k_chain<true, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
+        else hipLaunchKernelGGL((k_chain<false, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
     }
 }
 

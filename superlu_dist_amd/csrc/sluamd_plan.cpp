@@ -486,6 +486,15 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
                 S.bu_off[2 * l + part + 1] = (int) S.bwd_units.size();
             }
     }
+    S.diag_units.clear(); S.du_off.assign(S.nlevels + 1, 0);
+    for (int l = 0; l < S.nlevels; ++l) {
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+            const int k = S.nodes[i];
+            if (!(t.sn_flags[k] & SNF_OWN_DIAG)) continue;
+            for (int st = 0; st < (nsupc_of(hs, k) + 63) / 64; ++st) S.diag_units.push_back(make_int2(k, st));
+        }
+        S.du_off[l + 1] = (int) S.diag_units.size();
+    }
     build_chain(H, t, lvl, S);
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
     // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
@@ -543,6 +552,7 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.dg_off, &S.d_dg_off)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.fwd_units, &S.d_fwd_units)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.bwd_units, &S.d_bwd_units)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.diag_units, &S.d_diag_units)) return SLUAMD_EHIP;
     if (S.chain_l0 >= 0) {
         if (upload(H.d_misc, S.cf_units, &S.d_cf_units) || upload(H.d_misc, S.cf_waits, &S.d_cf_waits) || upload(H.d_misc, S.cf_sigs, &S.d_cf_sigs)) return SLUAMD_EHIP;
         if (upload(H.d_misc, S.cb_units, &S.d_cb_units) || upload(H.d_misc, S.cb_waits, &S.d_cb_waits) || upload(H.d_misc, S.cb_sigs, &S.d_cb_sigs)) return SLUAMD_EHIP;
