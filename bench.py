@@ -318,13 +318,10 @@ def main():
     t_setup, info, x, fact_ms, solve_ms, elapsed, res, err = (M[k] for k in ("t_setup", "info", "x", "fact_ms", "solve_ms", "elapsed", "res", "err"))
 
     # one extra profiled step: per-kernel-family HIP-event times on the compute stream
-    if not zwork:
-        h.set_profile(True)                  # N > 1: collective like every factorisation (serial schedule on every rank)
-        h.reset_values(); h.pdgstrf3d(thresh)
-        stp = h.stats()
-        h.set_profile(False)
-    else:
-        stp = dict(h.stats(), t_schur_ms=0.0, t_panel_ms=0.0)
+    h.set_profile(True)                  # N > 1: collective like every factorisation (serial schedule on every rank)
+    h.reset_values(); h.pdgstrf3d(thresh)
+    stp = h.stats()
+    h.set_profile(False)
 
     # accuracy row: one untimed pass of IterRefine=SLU_DOUBLE (pdgsrfs3d on the device) on the last solution
     accuracy = None
@@ -383,7 +380,8 @@ def main():
         "factor_gflops_kernel_only": F / (np.mean(fact_ms) * 1e-3) / 1e9,
         "residual": res, "max_abs_err_vs_xtrue": err, "info": int(info), "accuracy": accuracy,
         "levels": st["num_levels"], "fused_level_pairs": st["reserved_i"], "launches_per_factor": st["num_launches"], "setup_s": t_setup,
-        "roofline": {"bound": "mfma", "kernel": "k_schur (fused gather + fp64 MFMA GEMM + scatter)",
+        "roofline": {"bound": "mfma", "kernel": "kz_schur (fused gather + complex GEMM on fp64 MFMA, split planes + complex scatter; 8 real flop per complex multiply-add)" if zwork else
+                     "k_schur (fused gather + fp64 MFMA GEMM + scatter)",
                      "achieved": schur_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": schur_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                      "traffic_source": traffic_src, "traffic_stale": traffic_stale, "algorithmic_bytes_per_launch": alg_bytes_per_launch,

@@ -771,9 +771,10 @@ void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int 
 {
     emul_enqueue(s, [=] { impl::zpanel_trsm(T, nodes, nn); });
 }
-void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info)
+void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist)
 {
-    emul_enqueue(s, [=] { impl::schur_t<impl::zc>(T, nodes, prefix, nn, id_base, ntiles, info, nullptr); });
+    if (ntiles <= 0) return;
+    emul_enqueue(s, [=] { impl::schur_t<impl::zc>(T, nodes, prefix, nn, id_base, ntiles, info, ulist); });
 }
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int)
 {

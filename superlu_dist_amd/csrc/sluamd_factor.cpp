@@ -54,7 +54,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const DevTables &T = H->T;
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     const bool lookahead = !H->profile && !H->opt.deterministic && !H->env.no_lookahead;
-    const bool gemm_panels = !H->env.trsm_panels;   // XY layers: the peers of a diagonal block invert the copy they receive (full_inv on SNF_HAS_DIAG)
+    const bool gemm_panels = !H->env.trsm_panels && !H->z;   // XY layers: the peers of a diagonal block invert the copy they receive (full_inv on SNF_HAS_DIAG)
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     int rc_x = 0;
     int cur_level = 0, cur_pass = 0;
@@ -62,7 +62,8 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                      const int4 *ulist, int prio = 0) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
-        eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio);
+        if (H->z) eng::zschur(st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist);     // complex16: 64 x 64 tiles on split planes (sluamd_zkernels.inc)
+        else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -72,6 +73,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
+        if (H->z) {   // Local_Zgstrf2 (pzgstrf2.c); the complex panel solves substitute on the factored block: no inverses
+            eng::zdiag_lu(ps, T, nodes, nn, mx, H->opt.replace_tiny_pivot, thresh, H->d_info);
+            ev_end(H, H->ev_panel, H->ev_panel_used, ps);
+            H->st.num_launches += 1;
+            return;
+        }
         eng::diag_lu(ps, T, nodes, nn, mx, (H->opt.replace_tiny_pivot ? 1 : 0) | (H->env.diag_v1 ? 2 : 0), thresh, H->d_info);   // Local_Dgstrf2 (+ dinv of the owned blocks)
         if (xy) {   // dDiagFactIBCast (dtrfCommWrapper.c:32-118): diagonal blocks down the process column and along the process row
             eng::pack_diag(ps, T, nodes, S.d_dg_prefix + po, S.d_dg_off + po, nn, S.dg_prefix[po + nn], H->d_val + S.dg_stage_off[l]);
@@ -90,6 +97,13 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         const int mx = S.max_nsupc[l];
         const int nl = S.ltr_prefix[po + nn], nu = S.utr_prefix[po + nn];
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
+        if (H->z) {   // zLPanelTrSolve / zUPanelTrSolve (ztrfCommWrapper.c): 64-row strips / 64-column chunks
+            const int znl = S.zltr_prefix[po + nn], znu = S.bwd_prefix[po + nn];
+            eng::zpanel_trsm(ps, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, znl, znu);
+            ev_end(H, H->ev_panel, H->ev_panel_used, ps);
+            H->st.num_launches += (znl + znu > 0);
+            return;
+        }
         if (gemm_panels) eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, mx);   // chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
         else eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);
         if (xy) {
@@ -188,30 +202,6 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     return rc_x;
 }
 
-// complex16 (serial level loop; see sluamd_zkernels.inc)
-static int run_factor_z(Handle *H, LevelSched &S, double thresh)
-{
-    const DevTables &T = H->T;
-    hipStream_t s = H->stream;
-    for (int l = 0; l < S.nlevels; ++l) {
-        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
-        const int *nodes = S.d_nodes + n0;
-        eng::zdiag_lu(s, T, nodes, nn, S.max_nsupc[l], H->opt.replace_tiny_pivot, thresh, H->d_info);
-        const int po = S.lvl_poff[l];
-        const int nl = S.zltr_prefix[po + nn], nu = S.bwd_prefix[po + nn];   // 64-row strips / 64-column chunks
-        eng::zpanel_trsm(s, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, nl, nu);
-        H->st.num_launches += 1 + (nl + nu > 0);
-        const int so = S.lvl_soff[l] + S.n_big[l] + 1;     // complex handles have no 128-tile group
-        const int nt = S.tile_prefix[so + nn];
-        if (nt) {
-            eng::zschur(s, T, nodes, S.d_tile_prefix + so, nn, 0, nt, H->d_info);
-            H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += nt;
-        }
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
 static int ensure_xtmp(Handle *H, int64_t doubles)
 {
     if (doubles <= H->xtmp_cap) return 0;
@@ -291,7 +281,7 @@ int run_factor(Handle *H, double thresh, int *info)
     int rc = 0;
     for (size_t zl = 0; zl < H->sched.size(); ++zl) {
         if (H->z_active[zl]) {
-            rc = H->z ? run_factor_z(H, H->sched[zl], thresh) : run_factor_sched(H, H->sched[zl], thresh);
+            rc = run_factor_sched(H, H->sched[zl], thresh);     // double and complex16 alike: the look-ahead schedule is type-independent
             if (rc) return rc;
         }
         if (g.Pz > 1) {

@@ -1930,15 +1930,18 @@ int mfma_selftest(const double *A, const double *B, double *D)
 // ---- complex16 ----
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx, int replace_tiny, double thresh, int *info)
 {
-    if (nn > 0) hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), zdiag_lds_bytes(mx), s, T, nodes, replace_tiny, thresh, info, mx | 1);
+    if (nn <= 0) return;
+    // levels of narrow supernodes (the leaves and the small separators: tens of thousands of blocks): one wave per block in registers
+    if (mx <= 64) hipLaunchKernelGGL(kz_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
+    else hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), zdiag_lds_bytes(mx), s, T, nodes, replace_tiny, thresh, info, mx | 1);
 }
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
 {
     if (nl + nu > 0) hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
-void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info)
+void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(kz_schur, dim3(((ntiles + 7) / 8) * 8), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info);
+    if (ntiles > 0) hipLaunchKernelGGL(kz_schur, dim3(((ntiles + 7) / 8) * 8), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist);
 }
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int mx)
 {

@@ -94,6 +94,39 @@ def test_wide_supernodes_big_tiles_and_fused_pairs(sched, mode, seed):
     assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
 
 
+@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 4), (2, 2), (3, 3)])
+def test_complex16_through_the_lookahead_schedule(sched, mode, seed):
+    """pzgstrf3d runs the same four-stream look-ahead schedule as pdgstrf3d (urgent tile lists, panels of the next two levels beside
+    the bulk): a deep complex16 elimination DAG under the adversarial stream scheduler against immediate execution."""
+    N = 10
+    n, rp, ci, v = matgen.poisson3d(N)
+    v = matgen.complex_shift(v, rp, ci, seed=9)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=8)
+    rng = np.random.default_rng(2)
+    xt = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
+    b = matgen.csr_matvec(n, rp, ci, v, xt)
+
+    def run():
+        symb = driver.Symbolic(n, rp, ci, perm, relax=4, maxsup=16)
+        h = driver.LUHandle.from_symbolic(symb, v)
+        assert h.pzgstrf3d(0.0) == 0
+        xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+        x = h.pzgstrs3d(xp)[symb.perm_c, :]
+        st = h.stats()
+        h.destroy(); symb.free()
+        return x, st
+
+    x_ref, st = run()
+    assert st["num_levels"] > 8
+    _sched(sched, mode, seed)
+    x, _ = run()
+    run_count, reordered = _stats(sched)
+    _sched(sched, 0)
+    assert reordered > 0
+    assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
+    assert np.abs(x - xt).max() <= 1e-9 * np.abs(xt).max()
+
+
 @pytest.mark.parametrize("grid", [(2, 2, 1), (1, 1, 2), (2, 2, 2)])
 @pytest.mark.parametrize("mode,seed", [(1, 1), (2, 1), (3, 2)])
 def test_grid_drivers(sched, grid, mode, seed):
