@@ -4,7 +4,7 @@ tag=${1:-arg}; shift
 mkdir -p gpurun_out
 run() {
   local name=$1; shift
-  timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline $* > gpurun_out/${tag}_$name.json 2> gpurun_out/${tag}_$name.err
+  timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-scaling-point $* > gpurun_out/${tag}_$name.json 2> gpurun_out/${tag}_$name.err
   python - <<PY
 import json
 try:
