@@ -6,7 +6,7 @@
  *
  *   sluamd_bind_pdgstrf3d            replaces pdgstrf3d            (SRC/double/pdgstrf3d.c:121)
  *   sluamd_bind_pdgstrs3d[_newsolve] replace  pdgstrs3d[_newsolve] (SRC/double/pdgstrs3d.c:6604 / :6935)
- *   sluamd_bind_pzgstrf3d, sluamd_bind_pzgstrs3d[_newsolve]        (SRC/complex16/pzgstrf3d.c, pzgstrs3d.c; 1 x 1 x npdep grids)
+ *   sluamd_bind_pzgstrf3d, sluamd_bind_pzgstrs3d[_newsolve]        (SRC/complex16/pzgstrf3d.c, pzgstrs3d.c)
  *
  * on ANY nprow x npcol x npdep grid: the library runs the whole 3D algorithm (XY panel exchange, Z ancestor reduction,
  * distributed triangular solves) itself over a transport, chosen at run time:
@@ -280,9 +280,6 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     const int use_rccl = tr && !strcmp(tr, "rccl");
     const double t_start = SuperLU_timer_();
     if (Pr * Pc * Pz > 1 || use_rccl) {
-#ifdef Z_PREC
-        if (Pr * Pc > 1) ABORT("complex16 binding: 1 x 1 x npdep grids only");
-#endif
         /* library world rank of every MPI rank of grid3d->comm */
         int P; MPI_Comm_size(grid3d->comm, &P);
         int mine = (myz * Pr + myrow) * Pc + mycol;
@@ -354,7 +351,8 @@ static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, do
 #define BIND_SOLVE_OLD sluamd_bind_pdgstrs3d
 typedef double bind_scalar_t;
 #else
-/* complex16 (1 x 1 x npdep grids): the library's complex solve takes the complete permuted right-hand side */
+/* complex16: the library's complex solve takes the complete permuted right-hand side (replicated form): the layer's rows of B are
+ * gathered (MPI_Allgatherv on the 2-D grid), layer 0's copy goes to the other layers, every rank keeps its rows of the solution */
 static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, doublecomplex *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
                        SuperLUStat_t *stat, int *info)
 {
@@ -363,18 +361,28 @@ static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, do
     if (nrhs < 0) { *info = -9; return; }
     if (!G.h || G.n != n) ABORT("sluamd binding: pzgstrs3d called without a factorisation on the device");
     if (nrhs == 0) return;
-    if (m_loc != n || fst_row != 0) ABORT("sluamd binding: complex16 solves run on 1 x 1 x npdep grids (every layer-0 rank holds all rows)");
+    gridinfo_t *grid = &grid3d->grid2d;
+    int P2; MPI_Comm_size(grid->comm, &P2);
+    int *cnt = (int *) malloc(sizeof(int) * 2 * P2), *dsp = cnt + P2;
+    int mine = 2 * (int) m_loc;                          /* in doubles */
+    MPI_Allgather(&mine, 1, MPI_INT, cnt, 1, MPI_INT, grid->comm);
+    int tot = 0;
+    for (int q = 0; q < P2; ++q) { dsp[q] = tot; tot += cnt[q]; }
+    if (tot != 2 * n || dsp[grid->iam] != 2 * fst_row) ABORT("sluamd binding: unexpected row distribution of B");
+    sluamd_doublecomplex *col = (sluamd_doublecomplex *) malloc(sizeof(sluamd_doublecomplex) * (size_t) n);
     sluamd_doublecomplex *xp = (sluamd_doublecomplex *) malloc(sizeof(sluamd_doublecomplex) * (size_t) n * nrhs);
-    if (!xp) ABORT("sluamd binding: out of memory");
+    if (!col || !xp || !cnt) ABORT("sluamd binding: out of memory");
     double t0 = SuperLU_timer_();
-    for (int j = 0; j < nrhs; ++j)
-        for (int_t i = 0; i < n; ++i) { const doublecomplex b = B[i + (size_t) j * ldb]; sluamd_doublecomplex *d = &xp[SP->perm_c[SP->perm_r[i]] + (size_t) j * n]; d->r = b.r; d->i = b.i; }
+    for (int j = 0; j < nrhs; ++j) {
+        MPI_Allgatherv(B + (size_t) j * ldb, mine, MPI_DOUBLE, col, cnt, dsp, MPI_DOUBLE, grid->comm);
+        for (int_t i = 0; i < n; ++i) xp[SP->perm_c[SP->perm_r[i]] + (size_t) j * n] = col[i];
+    }
     if (grid3d->npdep > 1) MPI_Bcast(xp, (int) (2 * (size_t) n * nrhs), MPI_DOUBLE, 0, grid3d->zscp.comm);   /* layer 0's right-hand side */
     if (S.zsolve(G.h, xp, n, nrhs)) ABORT(S.last_error());
     for (int j = 0; j < nrhs; ++j)
-        for (int_t i = 0; i < n; ++i) { B[i + (size_t) j * ldb].r = xp[i + (size_t) j * n].r; B[i + (size_t) j * ldb].i = xp[i + (size_t) j * n].i; }
+        for (int_t i = 0; i < m_loc; ++i) { B[i + (size_t) j * ldb].r = xp[fst_row + i + (size_t) j * n].r; B[i + (size_t) j * ldb].i = xp[fst_row + i + (size_t) j * n].i; }
     stat->utime[SOLVE] = SuperLU_timer_() - t0;
-    free(xp);
+    free(col); free(xp); free(cnt);
 }
 #define BIND_SOLVE_NEW sluamd_bind_pzgstrs3d_newsolve
 #define BIND_SOLVE_OLD sluamd_bind_pzgstrs3d

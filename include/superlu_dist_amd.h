@@ -286,7 +286,8 @@ void sluamd_comm_destroy(sluamd_comm_t comm);
  * `comm` must outlive the handle. */
 int sluamd_dCreateLUHandleGrid(sluamd_handle_t *h, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests,
                                const sluamd_options_t *opt, sluamd_comm_t comm);
-/* complex16 on Z layers (1 x 1 x npdep grids; pzgstrf3d.c:333-392 ancestor reduction and the pzgstrs3d Z sweeps); collective like
+/* complex16 on any nprow x npcol x npdep grid (pzgstrf3d.c: XY panel exchange -- ztrfCommWrapper.c, zcommunication_aux.c --, the 333-392 ancestor
+ * reduction; the distributed pzgstrs3d): complex16 values travel as pairs of doubles through the double path's exchange plans; collective like
  * sluamd_dCreateLUHandleGrid */
 int sluamd_zCreateLUHandleGrid(sluamd_handle_t *h, const sluamd_zLUview_t *lu, const sluamd_forest_view_t *forests,
                                const sluamd_options_t *opt, sluamd_comm_t comm);
@@ -297,7 +298,7 @@ int sluamd_zCreateLUHandleGrid(sluamd_handle_t *h, const sluamd_zLUview_t *lu, c
 int sluamd_dCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr,
                                        const sluamd_int_t *colind, const double *nzval, const sluamd_int_t *perm_c_final,
                                        const sluamd_options_t *opt, const int32_t *sn_tree, sluamd_comm_t comm);
-/* complex16 twin (1 x 1 x npdep grids) */
+/* complex16 twin */
 int sluamd_zCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
                                        const sluamd_doublecomplex *nzval, const sluamd_int_t *perm_c_final,
                                        const sluamd_options_t *opt, const int32_t *sn_tree, sluamd_comm_t comm);

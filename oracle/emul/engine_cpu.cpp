@@ -535,16 +535,16 @@ void axpy(hipStream_t, int64_t n, double a, const double *x, double *y)
     for (int64_t i = 0; i < n; ++i) y[i] += a * x[i];
 }
 
-void pack_diag(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage)
+void pack_diag(hipStream_t, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage, int vs)
 {
     for (int w = 0; w < nwork; ++w) {
         const int ni = find_node(prefix, nn, w);
         const int k = nodes[ni], ns = T.xsup[k + 1] - T.xsup[k];
         const int e0 = (w - prefix[ni]) * 1024, e1 = std::min(e0 + 1024, ns * ns);
-        const double *A = T.val + T.sn_dptr[k];
+        const double *A = T.val + T.sn_dptr[k] * vs;
         const int lda = T.sn_dlda[k];
-        double *S = stage + off[ni];
-        for (int e = e0; e < e1; ++e) S[e] = A[(e % ns) + (size_t) (e / ns) * lda];
+        double *S = stage + off[ni] * vs;
+        for (int e = e0; e < e1; ++e) for (int v = 0; v < vs; ++v) S[(size_t) e * vs + v] = A[((e % ns) + (size_t) (e / ns) * lda) * vs + v];
     }
 }
 
@@ -650,9 +650,9 @@ void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y)
     emul_enqueue(s, [=] { impl::axpy(s, n, a, x, y); });
 }
 
-void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage)
+void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage, int vs)
 {
-    emul_enqueue(s, [=] { impl::pack_diag(s, T, nodes, prefix, off, nn, nwork, stage); });
+    emul_enqueue(s, [=] { impl::pack_diag(s, T, nodes, prefix, off, nn, nwork, stage, vs); });
 }
 
 void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs, int nruns, int64_t total, double *buf, int mode)
@@ -696,8 +696,8 @@ static void zdiag_lu(const DevTables &T, const int *nodes, int nn, int replace_t
     for (int q = 0; q < nn; ++q) {
         const int k = nodes[q];
         if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
-        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
-        zc *A = reinterpret_cast<zc *>(T.val) + T.sn_lval[k];
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_dlda[k];
+        zc *A = reinterpret_cast<zc *>(T.val) + T.sn_dptr[k];
         for (int j = 0; j < ns; ++j) {
             zc p = A[j + (size_t) j * lda];
             if (replace_tiny && (std::fabs(p.real()) + std::fabs(p.imag())) < thresh && p.real() != 0.0 && p.imag() != 0.0) {
@@ -724,12 +724,14 @@ static void zpanel_trsm(const DevTables &T, const int *nodes, int nn)
         const int k = nodes[q];
         const int ns = T.xsup[k + 1] - T.xsup[k], lda = T.sn_nsupr[k];
         zc *A = reinterpret_cast<zc *>(T.val) + T.sn_lval[k];
+        const zc *D = reinterpret_cast<const zc *>(T.val) + T.sn_dptr[k];      // factored diagonal block: own slot or the received image
+        const int ldd = T.sn_dlda[k];
         if (T.sn_flags[k] & SNF_L_OWN)
             for (int row = T.sn_ldiag[k]; row < lda; ++row)
                 for (int j = 0; j < ns; ++j) {
                     zc acc = A[row + (size_t) j * lda];
-                    for (int kk = 0; kk < j; ++kk) acc -= A[row + (size_t) kk * lda] * A[kk + (size_t) j * lda];
-                    A[row + (size_t) j * lda] = z_div(acc, A[j + (size_t) j * lda]);
+                    for (int kk = 0; kk < j; ++kk) acc -= A[row + (size_t) kk * lda] * D[kk + (size_t) j * ldd];
+                    A[row + (size_t) j * lda] = z_div(acc, D[j + (size_t) j * ldd]);
                 }
         if (T.sn_flags[k] & SNF_U_OWN) {
             zc *Uv = reinterpret_cast<zc *>(T.val) + T.sn_uval[k];
@@ -739,7 +741,7 @@ static void zpanel_trsm(const DevTables &T, const int *nodes, int nn)
                 zc *col = Uv + T.ucol_cp[ci] - ld;       // col[i] = U(i, column), rows ld .. ns-1
                 for (int i = ld; i < ns; ++i) {
                     zc acc = col[i];
-                    for (int kk = ld; kk < i; ++kk) acc -= A[i + (size_t) kk * lda] * col[kk];
+                    for (int kk = ld; kk < i; ++kk) acc -= D[i + (size_t) kk * ldd] * col[kk];
                     col[i] = acc;
                 }
             }
@@ -752,8 +754,8 @@ static void zsolve_diag(bool lower, const DevTables &T, const int *nodes, int nn
     for (int q = 0; q < nn; ++q) {
         const int k = nodes[q];
         if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
-        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_nsupr[k];
-        const zc *A = reinterpret_cast<const zc *>(T.val) + T.sn_lval[k];
+        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst, lda = T.sn_dlda[k];
+        const zc *A = reinterpret_cast<const zc *>(T.val) + T.sn_dptr[k];
         for (int r = 0; r < nrhs; ++r) {
             zc *xk = x + fst + (int64_t) r * ldx;
             if (lower) { for (int j = 0; j < ns; ++j) for (int i = j + 1; i < ns; ++i) xk[i] -= A[i + (size_t) j * lda] * xk[j]; }

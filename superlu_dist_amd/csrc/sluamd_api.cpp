@@ -266,7 +266,7 @@ int sluamd_zCreateLUHandleGrid(sluamd_handle_t *out, const sluamd_zLUview_t *lu,
                                sluamd_comm_t comm)
 {
     if (!comm) { set_error("null communicator"); return SLUAMD_EINVAL; }
-    if (lu && lu->nprow * lu->npcol > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
+
     return create_from_view(out, reinterpret_cast<const sluamd_dLUview_t *>(lu), forests, opt, true, comm->c);
 }
 
@@ -593,7 +593,7 @@ int sluamd_zCreateLUHandleFromSymbGrid(sluamd_handle_t *out, sluamd_symb_t s, co
                                        const int32_t *sn_tree, sluamd_comm_t comm)
 {
     if (!comm) { set_error("null communicator"); return SLUAMD_EINVAL; }
-    if (comm->c->grid.Pr * comm->c->grid.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
+
     return create_from_symb(out, s, rowptr, colind, reinterpret_cast<const double *>(nzval), perm_c_final, opt, comm->c->grid, sn_tree, comm->c, true);
 }
 

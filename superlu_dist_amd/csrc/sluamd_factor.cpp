@@ -39,8 +39,9 @@ static int exchange(Handle *H, const std::vector<XMsg> &sends, const std::vector
     Comm *c = H->comm;
     int rc = c->begin();
     if (rc) return rc;
-    for (auto &m : sends) if ((rc = c->send(H->d_val + m.off, m.len * 8, m.peer))) return rc;
-    for (auto &m : recvs) if ((rc = c->recv(H->d_val + m.off, m.len * 8, m.peer))) return rc;
+    const int vs = H->z ? 2 : 1;     // doubles per value (arena offsets / lengths are in values)
+    for (auto &m : sends) if ((rc = c->send(H->d_val + m.off * vs, m.len * 8 * vs, m.peer))) return rc;
+    for (auto &m : recvs) if ((rc = c->recv(H->d_val + m.off * vs, m.len * 8 * vs, m.peer))) return rc;
     return c->end(s);
 }
 
@@ -75,8 +76,14 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
         if (H->z) {   // Local_Zgstrf2 (pzgstrf2.c); the complex panel solves substitute on the factored block: no inverses
             eng::zdiag_lu(ps, T, nodes, nn, mx, H->opt.replace_tiny_pivot, thresh, H->d_info);
+            if (xy) {   // zDiagFactIBCast (ztrfCommWrapper.c): packed diagonal blocks down the process column and along the process row
+                eng::pack_diag(ps, T, nodes, S.d_dg_prefix + po, S.d_dg_off + po, nn, S.dg_prefix[po + nn], H->d_val + 2 * S.dg_stage_off[l], 2);
+                ev_begin(H, H->ev_xchg, H->ev_xchg_used, ps);
+                if (!rc_x) rc_x = exchange(H, S.x_diag_send[l], S.x_diag_recv[l], ps);
+                ev_end(H, H->ev_xchg, H->ev_xchg_used, ps);
+            }
             ev_end(H, H->ev_panel, H->ev_panel_used, ps);
-            H->st.num_launches += 1;
+            H->st.num_launches += 1 + (xy ? 1 : 0);
             return;
         }
         eng::diag_lu(ps, T, nodes, nn, mx, (H->opt.replace_tiny_pivot ? 1 : 0) | (H->env.diag_v1 ? 2 : 0), thresh, H->d_info);   // Local_Dgstrf2 (+ dinv of the owned blocks)
@@ -100,6 +107,11 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         if (H->z) {   // zLPanelTrSolve / zUPanelTrSolve (ztrfCommWrapper.c): 64-row strips / 64-column chunks
             const int znl = S.zltr_prefix[po + nn], znu = S.bwd_prefix[po + nn];
             eng::zpanel_trsm(ps, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, znl, znu);
+            if (xy) {
+                ev_begin(H, H->ev_xchg, H->ev_xchg_used, ps);
+                if (!rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // zIBcastRecvLPanel / zIBcastRecvUPanel
+                ev_end(H, H->ev_xchg, H->ev_xchg_used, ps);
+            }
             ev_end(H, H->ev_panel, H->ev_panel_used, ps);
             H->st.num_launches += (znl + znu > 0);
             return;
@@ -506,8 +518,10 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     for (int l = 0; l < S.nlevels; ++l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         int rc;
-        if (H->z) {   // complex16 (1 x 1 layers): d_x holds doublecomplex, ldx in complex values
+        if (H->z) {   // complex16: d_x holds doublecomplex, ldx in complex values; the exchanges see 2 ldx doubles (run lists in doubles)
+            if (xy && (rc = xseg_exchange(H, d_x, 2 * ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
             eng::zsolve_diag(s, true, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
+            if (xy && (rc = xseg_exchange(H, d_x, 2 * ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;
             eng::zfwd_update(s, T, S.d_nodes + n0, S.d_zfwd_prefix + po, nn, S.zfwd_prefix[po + nn], d_x, ldx, nrhs, S.max_nsupc[l]);
             continue;
         }
@@ -533,7 +547,9 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
         int rc;
         if (H->z) {
             eng::zbwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, ldx, nrhs);
+            if (xy && (rc = xseg_exchange(H, d_x, 2 * ldx, nrhs, S.xs_red_send[l], 3, S.xs_red_recv[l], 2, s))) return rc;
             eng::zsolve_diag(s, false, T, S.d_nodes + n0, nn, d_x, ldx, nrhs, S.max_nsupc[l]);
+            if (xy && (rc = xseg_exchange(H, d_x, 2 * ldx, nrhs, S.xs_bc_send[l], 0, S.xs_bc_recv[l], 1, s))) return rc;
             continue;
         }
         eng::bwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], d_x, d_x, ldx, nrhs, S.max_nsupc[l]);
@@ -749,7 +765,6 @@ static int grid_solve_checks(Handle *H)
     const Grid &g = H->grid;
     if (!H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
     if (!H->dinv_ready) { set_error("grid solve needs the factorisation to have run on this handle"); return SLUAMD_EINVAL; }
-    if (H->z && g.Pr * g.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
     return H->z ? 0 : ensure_inv(H);
 }
 

@@ -345,14 +345,15 @@ void rfs_update(hipStream_t s, int n, const int *pc, const double *dx_perm, doub
 // y[i] += a * x[i]  (ancestor reduction: dzRecvLPanel / dzRecvUPanel's daxpy, pd3dcomm.c:189-331)
 void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y);
 // XY exchange helpers: own diagonal blocks of a level -> contiguous staging range (ns x ns, lda = ns each)
-void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage);
+void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage /* already offset */,
+               int vs = 1 /* doubles per value: 2 = complex16 */);
 // x segments <-> contiguous buffer; mode 0: buf = x, 1: x = buf, 2: x += buf, 3: buf = x then x = 0
 void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs /*device: (row0, nrows, rows before) triples*/, int nruns, int64_t total,
                double *buf, int mode);
 // indexed rows <-> contiguous cnt x nrhs buffer; mode 0: buf[j] = v[idx[j]], 1: v[idx[j]] = buf[j]  (pdReDistribute3d_B_to_X / X_to_B)
 void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode);
 int mfma_selftest(const double *A, const double *B, double *D);   // host pointers
-// complex16 twins (1 x 1 x 1 grids)
+// complex16 twins (any grid: the diagonal-block operand comes from sn_dptr / sn_dlda like the double kernels')
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
 void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist = nullptr);

@@ -1683,6 +1683,7 @@ __global__ __launch_bounds__(256) void k_axpy(int64_t n, double a, const double 
 // Own diagonal blocks of one level -> contiguous staging range (ns x ns, lda = ns each): the payload of dDiagFactIBCast
 // (dtrfCommWrapper.c:32-118).  One workgroup per 1024-element chunk.
 constexpr int DGC = 1024;
+template <int VS>    // VS doubles per value: 1 (double), 2 (complex16)
 __global__ __launch_bounds__(256) void k_pack_diag(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
                                                    const int64_t *__restrict__ off, int nn, double *__restrict__ stage)
 {
@@ -1690,10 +1691,14 @@ __global__ __launch_bounds__(256) void k_pack_diag(DevTables T, const int *__res
     const int k = nodes[ni];
     const int ns = T.xsup[k + 1] - T.xsup[k];
     const int e0 = (blockIdx.x - prefix[ni]) * DGC, e1 = min(e0 + DGC, ns * ns);
-    const double *A = T.val + T.sn_dptr[k];
+    const double *A = T.val + T.sn_dptr[k] * VS;
     const int lda = T.sn_dlda[k];
-    double *S = stage + off[ni];
-    for (int e = e0 + threadIdx.x; e < e1; e += 256) S[e] = A[(e % ns) + (size_t) (e / ns) * lda];
+    double *S = stage + off[ni] * VS;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        const size_t a = ((e % ns) + (size_t) (e / ns) * lda) * VS;
+#pragma unroll
+        for (int v = 0; v < VS; ++v) S[(size_t) e * VS + v] = A[a + v];
+    }
 }
 
 // x segments (runs of rows, all nrhs columns) <-> one contiguous total x nrhs column-major buffer (runs concatenated).
@@ -1897,9 +1902,11 @@ void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y)
     hipLaunchKernelGGL(k_axpy, dim3((unsigned) (nb < 8192 ? nb : 8192)), dim3(256), 0, s, n, a, x, y);
 }
 
-void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage)
+void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage, int vs)
 {
-    if (nwork > 0) hipLaunchKernelGGL(k_pack_diag, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, off, nn, stage);
+    if (nwork <= 0) return;
+    if (vs == 2) hipLaunchKernelGGL(k_pack_diag<2>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, off, nn, stage);
+    else hipLaunchKernelGGL(k_pack_diag<1>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, off, nn, stage);
 }
 
 void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs, int nruns, int64_t total, double *buf, int mode)

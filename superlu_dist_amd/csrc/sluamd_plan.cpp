@@ -576,7 +576,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     const Grid &g = H->grid;
     const int ns = hs.nsupers;
     const bool xy = g.Pr * g.Pc > 1;
-    if (H->z && g.Pr * g.Pc > 1) { set_error("complex16 handles run on 1 x 1 x npdep grids"); return SLUAMD_EINVAL; }
+
     const int nz = (int) in.lists.size();
     H->Pz = g.Pz; H->myz = g.z;
     H->forest_nodes = in.lists;
@@ -714,13 +714,15 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
                 roff += len;
             }
             // -- solve: lsum of x_k reduced along process row k % Pr to the diagonal owner; x_k broadcast down column k % Pc
+            // (run lists in DOUBLES of the right-hand side seen as a real array: complex16 rows count twice)
+            const int xvs = H->z ? 2 : 1;
             for (int c2 = 0; c2 < g.Pc; ++c2) {
                 if (c2 == g.c) continue;
                 LevelSched::XSeg snd, rcv; snd.peer = rcv.peer = g.rank_of(g.r, c2, g.z);
                 for (int k : nodes) {
                     if (g.krow(k) != g.r) continue;
-                    if (g.kcol(k) == c2) add_runs(snd.runs, snd.total, hs.xsup[k], nsupc_of(hs, k));
-                    if (g.kcol(k) == g.c) add_runs(rcv.runs, rcv.total, hs.xsup[k], nsupc_of(hs, k));
+                    if (g.kcol(k) == c2) add_runs(snd.runs, snd.total, hs.xsup[k] * xvs, nsupc_of(hs, k) * xvs);
+                    if (g.kcol(k) == g.c) add_runs(rcv.runs, rcv.total, hs.xsup[k] * xvs, nsupc_of(hs, k) * xvs);
                 }
                 if (snd.total) X.rs.push_back(std::move(snd));
                 if (rcv.total) X.rr.push_back(std::move(rcv));
@@ -730,8 +732,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
                 LevelSched::XSeg snd, rcv; snd.peer = rcv.peer = g.rank_of(r2, g.c, g.z);
                 for (int k : nodes) {
                     if (g.kcol(k) != g.c) continue;
-                    if (g.krow(k) == g.r) add_runs(snd.runs, snd.total, hs.xsup[k], nsupc_of(hs, k));
-                    if (g.krow(k) == r2) add_runs(rcv.runs, rcv.total, hs.xsup[k], nsupc_of(hs, k));
+                    if (g.krow(k) == g.r) add_runs(snd.runs, snd.total, hs.xsup[k] * xvs, nsupc_of(hs, k) * xvs);
+                    if (g.krow(k) == r2) add_runs(rcv.runs, rcv.total, hs.xsup[k] * xvs, nsupc_of(hs, k) * xvs);
                 }
                 if (snd.total) X.bs.push_back(std::move(snd));
                 if (rcv.total) X.br.push_back(std::move(rcv));

@@ -127,7 +127,7 @@ class GridHandle:
         o = LUHandle._opts(**opts)
         fv, keep = (None, None) if forests is None else _forest_view(forests)
         h = C.c_void_p()
-        create = L.sluamd_zCreateLUHandleGrid if store.z else L.sluamd_dCreateLUHandleGrid   # complex16 store: 1 x 1 x npdep grids
+        create = L.sluamd_zCreateLUHandleGrid if store.z else L.sluamd_dCreateLUHandleGrid   
         _lib.check(create(C.byref(h), C.byref(store.view), None if fv is None else C.byref(fv), C.byref(o), comm), "sluamd_[dz]CreateLUHandleGrid")
         obj = cls(h, comm, store.n, store.z)
         obj._keep = (keep, store)
@@ -140,7 +140,7 @@ class GridHandle:
         o = LUHandle._opts(**opts)
         t = None if sn_tree is None else np.ascontiguousarray(sn_tree, dtype=np.int32)
         h = C.c_void_p()
-        if np.iscomplexobj(nzval):     # complex16: 1 x 1 x npdep grids
+        if np.iscomplexobj(nzval):
             nz = np.ascontiguousarray(nzval, dtype=np.complex128)
             _lib.check(L.sluamd_zCreateLUHandleFromSymbGrid(C.byref(h), symb._h, _pi(symb.rowptr), _pi(symb.colind), nz.ctypes.data_as(C.c_void_p),
                                                             _pi(symb.perm_c), C.byref(o), None if t is None else t.ctypes.data_as(_lib.P_int), comm),

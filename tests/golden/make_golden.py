@@ -52,6 +52,10 @@ CASES = {
     # complex16 on Z layers (1 x 1 x 2): per-rank records of pzgstrf3d / pzgstrs3d
     "z_cg20_1x1x2": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 2), flags=[], z=True),
     "z_poisson8_nd_1x1x2": dict(matrix=("zpoisson", 8), grid=(1, 1, 2), nd=16, flags=["-e", "0", "-p", "0", "-i", "0"], z=True),
+    # complex16 on XY layers (round 3): per-rank records on 2 x 1 x 1, 1 x 2 x 1 and 2 x 2 x 2 grids
+    "z_cg20_2x1x1": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(2, 1, 1), flags=[], z=True),
+    "z_cg20_1x2x1": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 2, 1), flags=[], z=True),
+    "z_cg20_2x2x2": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(2, 2, 2), flags=[], z=True),
 }
 
 

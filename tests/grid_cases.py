@@ -5,7 +5,8 @@ import numpy as np
 from superlu_dist_amd import driver, grid3d, matgen
 
 GRID_FIXTURES = ["g20_1x1x2", "poisson8_nd_1x1x2", "g20_2x1x1", "g20_2x2x2"]
-ZGRID_FIXTURES = ["z_cg20_1x1x2", "z_poisson8_nd_1x1x2"]    # complex16 (pzgstrf3d / pzgstrs3d) on two Z layers
+ZGRID_FIXTURES = ["z_cg20_1x1x2", "z_poisson8_nd_1x1x2",     # complex16 (pzgstrf3d / pzgstrs3d) on two Z layers
+                  "z_cg20_2x1x1", "z_cg20_1x2x1", "z_cg20_2x2x2"]   # ... and on XY block-cyclic layers (round 3)
 
 
 def forests_of(g, rank):
@@ -279,8 +280,8 @@ def check_wide_supernodes(N, maxsup, Pz, orc, shuffle=False):
     symb.free()
 
 
-def check_own_pipeline_complex16(Pz, N=12, leaf=27, relax=16, maxsup=64):
-    """complex16 through the library's own symbolic factorisation + device-side distribution on a 1 x 1 x Pz grid: residual on the
+def check_own_pipeline_complex16(Pz, N=12, leaf=27, relax=16, maxsup=64, Pr=1, Pc=1, make_comms=None):
+    """complex16 through the library's own symbolic factorisation + device-side distribution on a Pr x Pc x Pz grid: residual on the
     original system and agreement with the single-rank solution."""
     n, rp, ci, v = matgen.poisson3d(N)
     v = matgen.complex_shift(v, rp, ci, seed=2)
@@ -296,8 +297,8 @@ def check_own_pipeline_complex16(Pz, N=12, leaf=27, relax=16, maxsup=64):
     assert h1.pzgstrf3d(0.0) == 0
     x1 = h1.pzgstrs3d(xp)[symb.perm_c, :]
     h1.destroy()
-    sn_tree = symb.partition(Pz)
-    comms = grid3d.local_comms(1, 1, Pz)
+    sn_tree = symb.partition(Pz) if Pz > 1 else None
+    comms = (make_comms or grid3d.local_comms)(Pr, Pc, Pz)
 
     def rank_body(rank):
         h = grid3d.GridHandle.from_symbolic(symb, v, comms[rank], sn_tree)
@@ -306,7 +307,7 @@ def check_own_pipeline_complex16(Pz, N=12, leaf=27, relax=16, maxsup=64):
         h.destroy()
         return info, y
 
-    for info, y in grid3d.run_ranks(Pz, rank_body):
+    for info, y in grid3d.run_ranks(Pr * Pc * Pz, rank_body):
         assert info == 0
         x = y[symb.perm_c, :]
         assert np.abs(x - xt).max() <= 1e-10 * np.abs(xt).max()

@@ -117,8 +117,9 @@ def test_own_pipeline_with_supernodes_up_to_512_columns(grid):
 
 @pytest.mark.parametrize("case", grid_cases.ZGRID_FIXTURES)
 def test_complex16_grid_fixture_per_rank_parity(golden, case):
-    """pzgstrf3d / pzgstrs3d on a 1 x 1 x 2 grid against the reference's per-rank records (the Z ancestor reduction and the Z
-    sweeps of the solve move complex16 values as pairs of doubles)."""
+    """pzgstrf3d / pzgstrs3d against the reference's per-rank records on 1 x 1 x 2 (the Z ancestor reduction and the Z sweeps of the
+    solve move complex16 values as pairs of doubles) and on 2 x 1 x 1 / 1 x 2 x 1 / 2 x 2 x 2 (XY panel exchange of complex16 panels,
+    distributed complex solves)."""
     grid_cases.check_fixture_grid(golden(case))
 
 
@@ -134,3 +135,16 @@ def test_own_pipeline_complex16_with_supernodes_up_to_512_columns(Pz):
     """complex16 supernodes of 257..512 columns (468 here): refined like the double ones; the pieces are ordinary supernodes to the
     complex kernels."""
     grid_cases.check_own_pipeline_complex16(Pz, N=18, leaf=64, relax=64, maxsup=512)
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (2, 2, 2), (3, 2, 1)])
+def test_own_pipeline_complex16_on_xy_layers(grid):
+    """complex16 on XY block-cyclic layers (round 3; pzgstrf3d's panel exchange -- ztrfCommWrapper.c, zcommunication_aux.c -- and the
+    distributed pzgstrs3d): own symbolic factorisation + device-side distribution, residual and agreement with the single-rank solution."""
+    grid_cases.check_own_pipeline_complex16(grid[2], Pr=grid[0], Pc=grid[1])
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 2)])
+def test_own_pipeline_complex16_with_wide_supernodes_on_xy_layers(grid):
+    """... with supernodes of 257..512 columns refined into pieces that stay with the owners of their supernode."""
+    grid_cases.check_own_pipeline_complex16(grid[2], N=18, leaf=64, relax=64, maxsup=512, Pr=grid[0], Pc=grid[1])

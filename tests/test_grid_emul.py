@@ -32,8 +32,8 @@ def test_single_rank_fixture_parity(emul, golden, case):
 
 @pytest.mark.parametrize("case", grid_cases.ZGRID_FIXTURES)
 def test_complex16_grid_fixture_per_rank_parity(emul, golden, case):
-    """pzgstrf3d / pzgstrs3d on 1 x 1 x 2 against the reference's per-rank records: the host logic of the complex path (Z ancestor
-    reduction and Z sweeps on pairs of doubles) over the complex restatement of the kernels."""
+    """pzgstrf3d / pzgstrs3d against the reference's per-rank records on 1 x 1 x 2 (Z ancestor reduction and Z sweeps on pairs of doubles)
+    and on 2 x 1 x 1 / 1 x 2 x 1 / 2 x 2 x 2 (XY panel exchange of complex16 panels, distributed complex solves)."""
     grid_cases.check_fixture_grid(golden(case))
 
 
@@ -136,3 +136,16 @@ def test_a_failing_rank_releases_its_peers(emul):
 
     rcs = grid3d.run_ranks(2, body)
     assert all(rc != 0 for rc in rcs), rcs
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (2, 2, 2), (3, 2, 1)])
+def test_own_pipeline_complex16_on_xy_layers(emul, grid):
+    """complex16 on XY block-cyclic layers (round 3; pzgstrf3d's panel exchange -- ztrfCommWrapper.c, zcommunication_aux.c -- and the
+    distributed pzgstrs3d): own symbolic factorisation + device-side distribution, residual and agreement with the single-rank solution."""
+    grid_cases.check_own_pipeline_complex16(grid[2], Pr=grid[0], Pc=grid[1])
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 2)])
+def test_own_pipeline_complex16_with_wide_supernodes_on_xy_layers(emul, grid):
+    """... with supernodes of 257..512 columns refined into pieces that stay with the owners of their supernode."""
+    grid_cases.check_own_pipeline_complex16(grid[2], N=18, leaf=64, relax=64, maxsup=512, Pr=grid[0], Pc=grid[1])

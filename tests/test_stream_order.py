@@ -149,6 +149,16 @@ def test_reference_fixtures_under_the_scheduler(sched_env):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
 
 
+@pytest.mark.parametrize("grid", [(2, 2, 1), (2, 2, 2)])
+@pytest.mark.parametrize("mode,seed", [(1, 2), (2, 5), (3, 1)])
+@pytest.mark.parametrize("stream_ordered", [False, True])
+def test_complex16_grid_drivers(sched, grid, mode, seed, stream_ordered):
+    """complex16 on XY layers under the adversarial scheduler, over the host-staged transport and over the queue-only (RCCL-like) one."""
+    _sched(sched, mode, seed)
+    grid_cases.check_own_pipeline_complex16(grid[2], Pr=grid[0], Pc=grid[1], make_comms=grid_cases.stream_ordered_comms if stream_ordered else None)
+    _sched(sched, 0)
+
+
 @pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1), (2, 2, 1), (1, 1, 2), (1, 1, 4), (2, 2, 2), (3, 2, 1)])
 @pytest.mark.parametrize("mode,seed", [(0, 1), (1, 3), (2, 1), (3, 8)])
 def test_grid_drivers_over_the_stream_ordered_transport(sched, grid, mode, seed):
