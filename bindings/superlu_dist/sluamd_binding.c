@@ -44,6 +44,7 @@
 #define SYM_CREATE_GRID "sluamd_zCreateLUHandleGrid"
 #define SYM_FACTOR "sluamd_pzgstrf3d"
 #define SYM_COPY "sluamd_zCopyLU2Host"
+#define SYM_SOLVE_DIST "sluamd_pzgstrs3d_dist"
 #else
 #include "superlu_ddefs.h"
 #define xLUstruct_t dLUstruct_t
@@ -58,6 +59,7 @@
 #define SYM_CREATE_GRID "sluamd_dCreateLUHandleGrid"
 #define SYM_FACTOR "sluamd_pdgstrf3d"
 #define SYM_COPY "sluamd_dCopyLU2Host"
+#define SYM_SOLVE_DIST "sluamd_pdgstrs3d_dist"
 #endif
 #include "superlu_dist_amd.h"
 
@@ -100,8 +102,7 @@ static struct {
     int (*create_grid)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t);
     int (*factor)(sluamd_handle_t, double, int *);
     int (*copy2host)(sluamd_handle_t, const LUVIEW_T *);
-    int (*solve_dist)(sluamd_handle_t, double *, int64_t, int32_t, int64_t, int64_t, const sluamd_int_t *, const sluamd_int_t *);
-    int (*zsolve)(sluamd_handle_t, sluamd_doublecomplex *, int64_t, int32_t);
+    int (*solve_dist)(sluamd_handle_t, void *, int64_t, int32_t, int64_t, int64_t, const sluamd_int_t *, const sluamd_int_t *);   /* double or doublecomplex rows */
     int (*stats)(sluamd_handle_t, sluamd_stats_t *);
     int (*rccl_id)(void *);
     int (*comm_create_rccl)(sluamd_comm_t *, const void *, int, int, int, int, int, int, int);
@@ -131,8 +132,7 @@ static void sluamd_load(void)
     S.create_grid = (int (*)(sluamd_handle_t *, const LUVIEW_T *, const sluamd_forest_view_t *, const sluamd_options_t *, sluamd_comm_t)) dlsym(S.so, SYM_CREATE_GRID);
     S.factor = (int (*)(sluamd_handle_t, double, int *)) dlsym(S.so, SYM_FACTOR);
     S.copy2host = (int (*)(sluamd_handle_t, const LUVIEW_T *)) dlsym(S.so, SYM_COPY);
-    S.solve_dist = (int (*)(sluamd_handle_t, double *, int64_t, int32_t, int64_t, int64_t, const sluamd_int_t *, const sluamd_int_t *)) dlsym(S.so, "sluamd_pdgstrs3d_dist");
-    S.zsolve = (int (*)(sluamd_handle_t, sluamd_doublecomplex *, int64_t, int32_t)) dlsym(S.so, "sluamd_pzgstrs3d");
+    S.solve_dist = (int (*)(sluamd_handle_t, void *, int64_t, int32_t, int64_t, int64_t, const sluamd_int_t *, const sluamd_int_t *)) dlsym(S.so, SYM_SOLVE_DIST);
     S.rccl_id = (int (*)(void *)) dlsym(S.so, "sluamd_comm_rccl_unique_id");
     S.comm_create_rccl = (int (*)(sluamd_comm_t *, const void *, int, int, int, int, int, int, int)) dlsym(S.so, "sluamd_comm_create_rccl");
     S.stats = (int (*)(sluamd_handle_t, sluamd_stats_t *)) dlsym(S.so, "sluamd_get_stats");
@@ -140,7 +140,7 @@ static void sluamd_load(void)
     S.comm_create = (int (*)(sluamd_comm_t *, const sluamd_comm_callbacks_t *, int, int, int, int, int, int)) dlsym(S.so, "sluamd_comm_create_callbacks");
     S.comm_destroy = (void (*)(sluamd_comm_t)) dlsym(S.so, "sluamd_comm_destroy");
     S.last_error = (const char *(*)(void)) dlsym(S.so, "sluamd_last_error");
-    if (!S.create || !S.create_grid || !S.factor || !S.copy2host || !S.solve_dist || !S.zsolve || !S.destroy || !S.comm_create || !S.rccl_id || !S.comm_create_rccl)
+    if (!S.create || !S.create_grid || !S.factor || !S.copy2host || !S.solve_dist || !S.destroy || !S.comm_create || !S.rccl_id || !S.comm_create_rccl)
         ABORT("libsluamd.so lacks a required symbol");
 }
 
@@ -328,66 +328,34 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
 /* pdgstrs3d / pdgstrs3d_newsolve (pdgstrs3d.c:6604 / :6935): B holds this rank's m_loc rows (from fst_row) of the right-hand side
  * in the ORIGINAL row order on the layer-0 grid (the other layers' copies are not read: refinement-step right-hand sides exist on
  * layer 0 only, pdgsrfs3d); on return the same rows of the solution of the PERMUTED system (pdgssvx3d applies Pc^T itself). */
-#ifndef Z_PREC
-/* double: B stays distributed -- row i of B goes to row perm_c[perm_r[i]] of the factored system inside the library
+/* B stays distributed -- row i of B goes to row perm_c[perm_r[i]] of the factored system inside the library
  * (pdReDistribute3d_B_to_X, :6265), the solution rows come back the same way (pdReDistribute3d_X_to_B, :6404) */
-static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, double *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
+#ifndef Z_PREC
+typedef double bind_scalar_t;
+#define BIND_SOLVE_NEW sluamd_bind_pdgstrs3d_newsolve
+#define BIND_SOLVE_OLD sluamd_bind_pdgstrs3d
+#else
+typedef doublecomplex bind_scalar_t;
+#define BIND_SOLVE_NEW sluamd_bind_pzgstrs3d_newsolve
+#define BIND_SOLVE_OLD sluamd_bind_pzgstrs3d
+#endif
+static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, bind_scalar_t *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
                        SuperLUStat_t *stat, int *info)
 {
     *info = 0;
     if (n < 0) { *info = -1; return; }
     if (nrhs < 0) { *info = -9; return; }
-    if (!G.h || G.n != n) ABORT("sluamd binding: pdgstrs3d called without a factorisation on the device");
+    if (!G.h || G.n != n) ABORT("sluamd binding: the triangular solve was called without a factorisation on the device");
     if (nrhs == 0) return;
     static sluamd_int_t *perm = NULL; static int_t perm_n = -1;
     if (perm_n != n) { free(perm); perm = (sluamd_int_t *) malloc(sizeof(sluamd_int_t) * (size_t) (n ? n : 1)); perm_n = n; }
+    if (!perm) ABORT("sluamd binding: out of memory");
     for (int_t i = 0; i < n; ++i) perm[i] = (sluamd_int_t) SP->perm_c[SP->perm_r[i]];
     const int layer0 = grid3d->zscp.Iam == 0;
     double t0 = SuperLU_timer_();
-    if (S.solve_dist(G.h, B, ldb, nrhs, layer0 ? (int64_t) m_loc : 0, layer0 ? (int64_t) fst_row : 0, perm, NULL)) ABORT(S.last_error());
+    if (S.solve_dist(G.h, (void *) B, ldb, nrhs, layer0 ? (int64_t) m_loc : 0, layer0 ? (int64_t) fst_row : 0, perm, NULL)) ABORT(S.last_error());
     stat->utime[SOLVE] = SuperLU_timer_() - t0;
 }
-#define BIND_SOLVE_NEW sluamd_bind_pdgstrs3d_newsolve
-#define BIND_SOLVE_OLD sluamd_bind_pdgstrs3d
-typedef double bind_scalar_t;
-#else
-/* complex16: the library's complex solve takes the complete permuted right-hand side (replicated form): the layer's rows of B are
- * gathered (MPI_Allgatherv on the 2-D grid), layer 0's copy goes to the other layers, every rank keeps its rows of the solution */
-static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, doublecomplex *B, int_t m_loc, int_t fst_row, int_t ldb, int nrhs,
-                       SuperLUStat_t *stat, int *info)
-{
-    *info = 0;
-    if (n < 0) { *info = -1; return; }
-    if (nrhs < 0) { *info = -9; return; }
-    if (!G.h || G.n != n) ABORT("sluamd binding: pzgstrs3d called without a factorisation on the device");
-    if (nrhs == 0) return;
-    gridinfo_t *grid = &grid3d->grid2d;
-    int P2; MPI_Comm_size(grid->comm, &P2);
-    int *cnt = (int *) malloc(sizeof(int) * 2 * P2), *dsp = cnt + P2;
-    int mine = 2 * (int) m_loc;                          /* in doubles */
-    MPI_Allgather(&mine, 1, MPI_INT, cnt, 1, MPI_INT, grid->comm);
-    int tot = 0;
-    for (int q = 0; q < P2; ++q) { dsp[q] = tot; tot += cnt[q]; }
-    if (tot != 2 * n || dsp[grid->iam] != 2 * fst_row) ABORT("sluamd binding: unexpected row distribution of B");
-    sluamd_doublecomplex *col = (sluamd_doublecomplex *) malloc(sizeof(sluamd_doublecomplex) * (size_t) n);
-    sluamd_doublecomplex *xp = (sluamd_doublecomplex *) malloc(sizeof(sluamd_doublecomplex) * (size_t) n * nrhs);
-    if (!col || !xp || !cnt) ABORT("sluamd binding: out of memory");
-    double t0 = SuperLU_timer_();
-    for (int j = 0; j < nrhs; ++j) {
-        MPI_Allgatherv(B + (size_t) j * ldb, mine, MPI_DOUBLE, col, cnt, dsp, MPI_DOUBLE, grid->comm);
-        for (int_t i = 0; i < n; ++i) xp[SP->perm_c[SP->perm_r[i]] + (size_t) j * n] = col[i];
-    }
-    if (grid3d->npdep > 1) MPI_Bcast(xp, (int) (2 * (size_t) n * nrhs), MPI_DOUBLE, 0, grid3d->zscp.comm);   /* layer 0's right-hand side */
-    if (S.zsolve(G.h, xp, n, nrhs)) ABORT(S.last_error());
-    for (int j = 0; j < nrhs; ++j)
-        for (int_t i = 0; i < m_loc; ++i) { B[i + (size_t) j * ldb].r = xp[fst_row + i + (size_t) j * n].r; B[i + (size_t) j * ldb].i = xp[fst_row + i + (size_t) j * n].i; }
-    stat->utime[SOLVE] = SuperLU_timer_() - t0;
-    free(col); free(xp); free(cnt);
-}
-#define BIND_SOLVE_NEW sluamd_bind_pzgstrs3d_newsolve
-#define BIND_SOLVE_OLD sluamd_bind_pzgstrs3d
-typedef doublecomplex bind_scalar_t;
-#endif
 
 void BIND_SOLVE_NEW(superlu_dist_options_t *options, int_t n, xLUstruct_t *LUstruct, xScalePermstruct_t *SP,
                     xtrf3Dpartition_t *part, gridinfo3d_t *grid3d, bind_scalar_t *B, int_t m_loc, int_t fst_row, int_t ldb,

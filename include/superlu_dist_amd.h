@@ -316,6 +316,9 @@ int sluamd_zCreateLUHandleFromSymbGrid(sluamd_handle_t *h, sluamd_symb_t s, cons
  * solution once back; nothing is replicated.  Collective on grid handles; works on single-rank handles too (m_loc = n). */
 int sluamd_pdgstrs3d_dist(sluamd_handle_t h, double *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row,
                           const sluamd_int_t *perm_in, const sluamd_int_t *perm_out);
+/* complex16 twin: the boundary of pzgstrs3d[_newsolve] (SRC/complex16/pzgstrs3d.c) */
+int sluamd_pzgstrs3d_dist(sluamd_handle_t h, sluamd_doublecomplex *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row,
+                          const sluamd_int_t *perm_in, const sluamd_int_t *perm_out);
 
 #ifdef __cplusplus
 }

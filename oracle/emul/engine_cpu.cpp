@@ -559,13 +559,14 @@ void xseg_copy(hipStream_t, double *x, int64_t ldx, int nrhs, const int *runs, i
             }
 }
 
-void rows_copy(hipStream_t, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode)
+void rows_copy(hipStream_t, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode, int vs)
 {
     for (int q = 0; q < nrhs; ++q)
-        for (int64_t j = 0; j < cnt; ++j) {
-            double *vp = v + idx[j] + (int64_t) q * ldv;
-            if (mode == 0) buf[j + q * cnt] = *vp; else *vp = buf[j + q * cnt];
-        }
+        for (int64_t j = 0; j < cnt; ++j)
+            for (int t = 0; t < vs; ++t) {
+                double *vp = v + (idx[j] + (int64_t) q * ldv) * vs + t;
+                if (mode == 0) buf[(j + q * cnt) * vs + t] = *vp; else *vp = buf[(j + q * cnt) * vs + t];
+            }
 }
 
 }  // namespace impl
@@ -660,10 +661,10 @@ void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs,
     emul_enqueue(s, [=] { impl::xseg_copy(s, x, ldx, nrhs, runs, nruns, total, buf, mode); });
 }
 
-void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode)
+void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode, int vs)
 {
     if (cnt <= 0) return;
-    emul_enqueue(s, [=] { impl::rows_copy(s, v, ldv, nrhs, idx, cnt, buf, mode); });
+    emul_enqueue(s, [=] { impl::rows_copy(s, v, ldv, nrhs, idx, cnt, buf, mode, vs); });
 }
 
 int mfma_selftest(const double *A, const double *B, double *D)

@@ -42,7 +42,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "sluamd_default_options", "sluamd_dCreateLUHandle", "sluamd_dSetValues", "sluamd_pdgstrf3d",
-    "sluamd_dCopyLU2Host", "sluamd_pdgstrs3d", "sluamd_pdgstrs3d_dev", "sluamd_pdgstrs3d_dist", "sluamd_dDestroyLUHandle",
+    "sluamd_dCopyLU2Host", "sluamd_pdgstrs3d", "sluamd_pdgstrs3d_dev", "sluamd_pdgstrs3d_dist", "sluamd_pzgstrs3d_dist", "sluamd_dDestroyLUHandle",
     "sluamd_get_stats", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_order_nd", "sluamd_symb_info",
     "sluamd_symb_view", "sluamd_symb_grid_footprint", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
     "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
@@ -97,6 +97,7 @@ def bind(L):
     L.sluamd_pdgstrs3d.argtypes = [C.c_void_p, P_dbl, C.c_int64, C.c_int32]
     L.sluamd_pdgstrs3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.sluamd_pdgstrs3d_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, P_int, P_int]
+    L.sluamd_pzgstrs3d_dist.argtypes = L.sluamd_pdgstrs3d_dist.argtypes
     L.sluamd_dDestroyLUHandle.argtypes = [C.c_void_p]
     L.sluamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.sluamd_mfma_selftest.argtypes = [P_dbl, P_dbl, P_dbl]

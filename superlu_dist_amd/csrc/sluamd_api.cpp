@@ -380,23 +380,25 @@ int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nr
     return chain_check(H);
 }
 
-int sluamd_pdgstrs3d_dist(sluamd_handle_t h, double *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row, const sluamd_int_t *perm_in,
-                          const sluamd_int_t *perm_out)
+// B: host, this rank's m_loc rows (vs doubles per value), leading dimension ldb in values
+static int solve_dist_host(sluamd_handle_t h, double *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row, const sluamd_int_t *perm_in,
+                           const sluamd_int_t *perm_out, bool z)
 {
     if (!h || nrhs < 0 || m_loc < 0 || fst_row < 0 || fst_row + m_loc > h->H.hs.n || (m_loc > 0 && (!B || ldb < m_loc))) { set_error("bad distributed-solve arguments"); return SLUAMD_EINVAL; }
-    if (h->H.z) { set_error("complex16 handle: call sluamd_pzgstrs3d"); return SLUAMD_EINVAL; }
+    if (h->H.z != z) { set_error(z ? "double handle: call sluamd_pdgstrs3d_dist" : "complex16 handle: call sluamd_pzgstrs3d_dist"); return SLUAMD_EINVAL; }
     if (nrhs == 0) return 0;
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
-    const int64_t need = std::max<int64_t>(m_loc, 1) * nrhs;
+    const int vs = z ? 2 : 1;
+    const int64_t ldd = std::max<int64_t>(m_loc, 1);
+    const int64_t need = ldd * nrhs * vs;
     if (need > H->bloc_cap) {
         if (H->d_bloc) hipFree(H->d_bloc);
         H->d_bloc = nullptr; H->bloc_cap = 0;
         HIPCHK(hipMalloc((void **) &H->d_bloc, sizeof(double) * (size_t) need));
         H->bloc_cap = need;
     }
-    const int64_t ldd = std::max<int64_t>(m_loc, 1);
-    for (int q = 0; q < nrhs && m_loc; ++q) HIPCHK(hipMemcpy(H->d_bloc + (size_t) q * ldd, B + (size_t) q * ldb, sizeof(double) * (size_t) m_loc, hipMemcpyHostToDevice));
+    for (int q = 0; q < nrhs && m_loc; ++q) HIPCHK(hipMemcpy(H->d_bloc + (size_t) q * ldd * vs, B + (size_t) q * ldb * vs, sizeof(double) * (size_t) m_loc * vs, hipMemcpyHostToDevice));
     HIPCHK(hipEventRecord(H->ev0, H->stream));
     int rc = run_solve_dist(H, H->d_bloc, ldd, nrhs, m_loc, fst_row, perm_in, perm_out);
     if (rc) return rc;
@@ -405,8 +407,20 @@ int sluamd_pdgstrs3d_dist(sluamd_handle_t h, double *B, int64_t ldb, int32_t nrh
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_solve_ms = ms;
     if ((rc = chain_check(H))) return rc;
-    for (int q = 0; q < nrhs && m_loc; ++q) HIPCHK(hipMemcpy(B + (size_t) q * ldb, H->d_bloc + (size_t) q * ldd, sizeof(double) * (size_t) m_loc, hipMemcpyDeviceToHost));
+    for (int q = 0; q < nrhs && m_loc; ++q) HIPCHK(hipMemcpy(B + (size_t) q * ldb * vs, H->d_bloc + (size_t) q * ldd * vs, sizeof(double) * (size_t) m_loc * vs, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int sluamd_pdgstrs3d_dist(sluamd_handle_t h, double *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row, const sluamd_int_t *perm_in,
+                          const sluamd_int_t *perm_out)
+{
+    return solve_dist_host(h, B, ldb, nrhs, m_loc, fst_row, perm_in, perm_out, false);
+}
+
+int sluamd_pzgstrs3d_dist(sluamd_handle_t h, sluamd_doublecomplex *B, int64_t ldb, int32_t nrhs, int64_t m_loc, int64_t fst_row,
+                          const sluamd_int_t *perm_in, const sluamd_int_t *perm_out)
+{
+    return solve_dist_host(h, reinterpret_cast<double *>(B), ldb, nrhs, m_loc, fst_row, perm_in, perm_out, true);
 }
 
 int sluamd_pdgstrs3d(sluamd_handle_t h, double *x, int64_t ldx, int32_t nrhs)

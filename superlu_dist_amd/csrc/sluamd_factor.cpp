@@ -845,7 +845,8 @@ static int build_route(Handle *H, const std::vector<int> &src_rank, const std::v
         bs[owner[q]].emplace_back(q, (int) i);
     }
     std::vector<std::vector<int>> xs(P);                     // my owner rows of x (ascending), bucketed by the rank that holds the paired row of B
-    for (auto &r : H->owner_runs[me].runs) for (int q = r.first; q < r.first + r.second; ++q) xs[src_rank[iperm[q]]].push_back(q);
+    const int ovs = H->z ? 2 : 1;                            // (owner runs are in doubles of the right-hand side seen as a real array)
+    for (auto &r : H->owner_runs[me].runs) for (int q = r.first / ovs; q < (r.first + r.second) / ovs; ++q) xs[src_rank[iperm[q]]].push_back(q);
     R.cnt_b.assign(P, 0); R.cnt_x.assign(P, 0); R.d_bidx.assign(P, nullptr); R.d_xidx.assign(P, nullptr);
     for (int p = 0; p < P; ++p) {
         std::sort(bs[p].begin(), bs[p].end());
@@ -887,8 +888,9 @@ static int build_dist_plan(Handle *H, int64_t m_loc, int64_t fst_row, const int 
     }
     if (covered != n) { set_error("sluamd_pdgstrs3d_dist: the ranks' row ranges do not cover the matrix"); return SLUAMD_EINVAL; }
     std::vector<int> owner(n, -1);          // row of x -> the rank where it is consumed / final
+    const int ovs = H->z ? 2 : 1;
     for (int p = 0; p < P; ++p)
-        for (auto &r : H->owner_runs[p].runs) for (int i = r.first; i < r.first + r.second; ++i) owner[i] = p;
+        for (auto &r : H->owner_runs[p].runs) for (int i = r.first / ovs; i < (r.first + r.second) / ovs; ++i) owner[i] = p;
     D.hash_in = hash_perm(perm_in, n); D.hash_out = hash_perm(perm_out, n);
     D.same = D.hash_in == D.hash_out && (!perm_in) == (!perm_out);
     if ((rc = build_route(H, src_rank, owner, m_loc, fst_row, perm_in, D.in, D.bufs))) return rc;
@@ -904,31 +906,32 @@ static int redistribute(Handle *H, bool b2x, double *d_b, int64_t ldb, double *x
     const int P = g.size(), me = g.rank();
     const Handle::DistRoute &R = (b2x || H->dist.same) ? H->dist.in : H->dist.out;
     const std::vector<int64_t> &cs = b2x ? R.cnt_b : R.cnt_x, &cr = b2x ? R.cnt_x : R.cnt_b;
+    const int vs = H->z ? 2 : 1;      // doubles per value: the staging offsets below are in doubles, ldb / ldx in values
     int64_t need = 0;
-    for (int p = 0; p < P; ++p) need += (cs[p] + (p == me ? 0 : cr[p])) * nr;
+    for (int p = 0; p < P; ++p) need += (cs[p] + (p == me ? 0 : cr[p])) * nr * vs;
     int rc = ensure_xtmp(H, std::max<int64_t>(need, 1));
     if (rc) return rc;
     std::vector<int64_t> so(P), ro(P);
     int64_t off = 0;
     for (int p = 0; p < P; ++p) {     // pack
-        so[p] = off; off += cs[p] * nr;
-        if (b2x) eng::rows_copy(s, d_b, ldb, nr, R.d_bidx[p], cs[p], H->d_xtmp + so[p], 0);
-        else eng::rows_copy(s, x, ldx, nr, R.d_xidx[p], cs[p], H->d_xtmp + so[p], 0);
+        so[p] = off; off += cs[p] * nr * vs;
+        if (b2x) eng::rows_copy(s, d_b, ldb, nr, R.d_bidx[p], cs[p], H->d_xtmp + so[p], 0, vs);
+        else eng::rows_copy(s, x, ldx, nr, R.d_xidx[p], cs[p], H->d_xtmp + so[p], 0, vs);
     }
-    for (int p = 0; p < P; ++p) { ro[p] = (p == me) ? so[p] : off; if (p != me) off += cr[p] * nr; }     // my own rows need no transport
+    for (int p = 0; p < P; ++p) { ro[p] = (p == me) ? so[p] : off; if (p != me) off += cr[p] * nr * vs; }     // my own rows need no transport
     if (P > 1) {
         Comm *c = H->comm;
         if ((rc = c->begin())) return rc;
         for (int p = 0; p < P; ++p) {
             if (p == me) continue;
-            if (cs[p] && (rc = c->send(H->d_xtmp + so[p], cs[p] * nr * 8, p))) return rc;
-            if (cr[p] && (rc = c->recv(H->d_xtmp + ro[p], cr[p] * nr * 8, p))) return rc;
+            if (cs[p] && (rc = c->send(H->d_xtmp + so[p], cs[p] * nr * 8 * vs, p))) return rc;
+            if (cr[p] && (rc = c->recv(H->d_xtmp + ro[p], cr[p] * nr * 8 * vs, p))) return rc;
         }
         if ((rc = c->end(s))) return rc;
     }
     for (int p = 0; p < P; ++p) {     // unpack
-        if (b2x) eng::rows_copy(s, x, ldx, nr, R.d_xidx[p], cr[p], H->d_xtmp + ro[p], 1);
-        else eng::rows_copy(s, d_b, ldb, nr, R.d_bidx[p], cr[p], H->d_xtmp + ro[p], 1);
+        if (b2x) eng::rows_copy(s, x, ldx, nr, R.d_xidx[p], cr[p], H->d_xtmp + ro[p], 1, vs);
+        else eng::rows_copy(s, d_b, ldb, nr, R.d_bidx[p], cr[p], H->d_xtmp + ro[p], 1, vs);
     }
     if (P > 1 && !H->comm->stream_ordered()) HIPCHK(hipStreamSynchronize(s));
     return 0;
@@ -945,14 +948,14 @@ int run_solve_dist(Handle *H, double *d_b, int64_t ldb, int nrhs, int64_t m_loc,
     int rc;
     if (g.size() > 1) { if ((rc = grid_solve_checks(H))) return rc; }
     else if (!H->z && (rc = ensure_inv(H))) return rc;
-    if (H->z) { set_error("sluamd_pdgstrs3d_dist: double precision handles only"); return SLUAMD_EINVAL; }
+    const int vs = H->z ? 2 : 1;      // d_b, H->d_x: values of vs doubles; ldb in values
     if (!H->dist.ready || H->dist.m_loc != m_loc || H->dist.fst_row != fst_row || H->dist.hash_in != hash_perm(perm, H->hs.n) ||
         H->dist.hash_out != hash_perm(perm_out, H->hs.n))
         if ((rc = build_dist_plan(H, m_loc, fst_row, perm, perm_out))) return rc;
     hipStream_t s = H->stream;
     const int64_t n = H->hs.n;
     const int ch = max_rhs_chunk(H);
-    const int64_t need = n * std::min(ch, nrhs);
+    const int64_t need = n * std::min(ch, nrhs) * vs;
     if (need > H->x_cap) {
         if (H->d_x) hipFree(H->d_x);
         H->d_x = nullptr; H->x_cap = 0;
@@ -961,8 +964,8 @@ int run_solve_dist(Handle *H, double *d_b, int64_t ldb, int nrhs, int64_t m_loc,
     }
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
-        double *b = d_b + (size_t) j0 * ldb;
-        HIPCHK(hipMemsetAsync(H->d_x, 0, sizeof(double) * (size_t) n * nr, s));       // zero accumulators everywhere but the consumed rows
+        double *b = d_b + (size_t) j0 * ldb * vs;
+        HIPCHK(hipMemsetAsync(H->d_x, 0, sizeof(double) * (size_t) n * nr * vs, s));       // zero accumulators everywhere but the consumed rows
         if ((rc = redistribute(H, true, b, ldb, H->d_x, n, nr, s))) return rc;
         if (g.size() > 1) { if ((rc = grid_sweeps(H, H->d_x, n, nr))) return rc; }
         else {

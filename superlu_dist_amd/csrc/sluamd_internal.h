@@ -351,7 +351,7 @@ void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *p
 void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs /*device: (row0, nrows, rows before) triples*/, int nruns, int64_t total,
                double *buf, int mode);
 // indexed rows <-> contiguous cnt x nrhs buffer; mode 0: buf[j] = v[idx[j]], 1: v[idx[j]] = buf[j]  (pdReDistribute3d_B_to_X / X_to_B)
-void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode);
+void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode, int vs = 1 /* doubles per value; ldv in values */);
 int mfma_selftest(const double *A, const double *B, double *D);   // host pointers
 // complex16 twins (any grid: the diagonal-block operand comes from sn_dptr / sn_dlda like the double kernels')
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);

@@ -1722,13 +1722,15 @@ __global__ __launch_bounds__(256) void k_xseg_copy(double *__restrict__ x, int64
 
 // indexed rows (all nrhs columns) <-> contiguous cnt x nrhs buffer: the device side of pdReDistribute3d_B_to_X / X_to_B
 // (pdgstrs3d.c:6265, :6404).  mode 0: buf = v[idx], 1: v[idx] = buf
+template <int VS>    // doubles per value: 1 (double), 2 (complex16); ldv in values
 __global__ __launch_bounds__(256) void k_rows_copy(double *__restrict__ v, int64_t ldv, int nrhs, const int *__restrict__ idx, int64_t cnt,
                                                    double *__restrict__ buf, int mode)
 {
     for (int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x; e < cnt * nrhs; e += (int64_t) gridDim.x * 256) {
         const int64_t j = e % cnt; const int q = (int) (e / cnt);
-        double *vp = v + idx[j] + (int64_t) q * ldv;
-        if (mode == 0) buf[e] = *vp; else *vp = buf[e];
+        double *vp = v + (idx[j] + (int64_t) q * ldv) * VS;
+#pragma unroll
+        for (int t = 0; t < VS; ++t) { if (mode == 0) buf[e * VS + t] = vp[t]; else vp[t] = buf[e * VS + t]; }
     }
 }
 
@@ -1916,11 +1918,12 @@ void xseg_copy(hipStream_t s, double *x, int64_t ldx, int nrhs, const int *runs,
     hipLaunchKernelGGL(k_xseg_copy, dim3((unsigned) (nb < 4096 ? nb : 4096)), dim3(256), 0, s, x, ldx, nrhs, runs, nruns, total, buf, mode);
 }
 
-void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode)
+void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, int64_t cnt, double *buf, int mode, int vs)
 {
     if (cnt <= 0) return;
     const int64_t nb = (cnt * nrhs + 255) / 256;
-    hipLaunchKernelGGL(k_rows_copy, dim3((unsigned) (nb < 4096 ? nb : 4096)), dim3(256), 0, s, v, ldv, nrhs, idx, cnt, buf, mode);
+    if (vs == 2) hipLaunchKernelGGL(k_rows_copy<2>, dim3((unsigned) (nb < 4096 ? nb : 4096)), dim3(256), 0, s, v, ldv, nrhs, idx, cnt, buf, mode);
+    else hipLaunchKernelGGL(k_rows_copy<1>, dim3((unsigned) (nb < 4096 ? nb : 4096)), dim3(256), 0, s, v, ldv, nrhs, idx, cnt, buf, mode);
 }
 
 int mfma_selftest(const double *A, const double *B, double *D)

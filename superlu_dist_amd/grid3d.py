@@ -174,15 +174,16 @@ class GridHandle:
         """Distributed boundary (sluamd_pdgstrs3d_dist): B_loc = this rank's rows [fst_row, fst_row + m_loc) of the ORIGINAL right-hand
         side (m_loc = 0 on layers z > 0), perm[i] = row of the factored system of original row i; returns rows perm_out[i] of the solved
         vector (default: the same permutation = x in the original order; None = the reference's convention, rows of the permuted solution)."""
-        B = np.asfortranarray(np.array(B_loc, dtype=np.float64))
+        B = np.asfortranarray(np.array(B_loc, dtype=np.complex128 if self.z else np.float64))
         if B.ndim == 1:
             B = np.asfortranarray(B[:, None])
         m_loc, nrhs = B.shape
         pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
         po = pm if isinstance(perm_out, str) else (None if perm_out is None else np.ascontiguousarray(perm_out, dtype=np.int32))
-        _lib.check(_lib.load().sluamd_pdgstrs3d_dist(self._h, B.ctypes.data_as(C.c_void_p), max(m_loc, 1), nrhs, m_loc, int(fst_row),
-                                                     None if pm is None else pm.ctypes.data_as(_lib.P_int),
-                                                     None if po is None else po.ctypes.data_as(_lib.P_int)), "sluamd_pdgstrs3d_dist")
+        fn = _lib.load().sluamd_pzgstrs3d_dist if self.z else _lib.load().sluamd_pdgstrs3d_dist
+        _lib.check(fn(self._h, B.ctypes.data_as(C.c_void_p), max(m_loc, 1), nrhs, m_loc, int(fst_row),
+                      None if pm is None else pm.ctypes.data_as(_lib.P_int),
+                      None if po is None else po.ctypes.data_as(_lib.P_int)), "sluamd_p[dz]gstrs3d_dist")
         return B
 
     def copy_to_host(self, store):

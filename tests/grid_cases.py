@@ -300,10 +300,17 @@ def check_own_pipeline_complex16(Pz, N=12, leaf=27, relax=16, maxsup=64, Pr=1, P
     sn_tree = symb.partition(Pz) if Pz > 1 else None
     comms = (make_comms or grid3d.local_comms)(Pr, Pc, Pz)
 
+    nl0 = Pr * Pc
+    cuts = np.linspace(0, n, nl0 + 1).astype(np.int64)
+
     def rank_body(rank):
         h = grid3d.GridHandle.from_symbolic(symb, v, comms[rank], sn_tree)
         info = h.pdgstrf3d(0.0)
         y = h.pdgstrs3d(xp)
+        f0, f1 = (int(cuts[rank]), int(cuts[rank + 1])) if rank < nl0 else (0, 0)      # pzgstrs3d's own boundary: B distributed over layer 0
+        xl = h.pdgstrs3d_dist(b[f0:f1, :], f0, symb.perm_c)
+        if f1 > f0:
+            assert np.abs(xl - y[symb.perm_c, :][f0:f1, :]).max() <= 1e-12 * np.abs(y).max()
         h.destroy()
         return info, y
 
