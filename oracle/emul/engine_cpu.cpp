@@ -530,6 +530,11 @@ void rfs_update(hipStream_t, int n, const int *pc, const double *dx_perm, double
     for (int i = 0; i < n; ++i) x[i] += dx_perm[pc[i]];
 }
 
+void add_atomic(hipStream_t, int64_t n, const double *x, double *y)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] += x[i];
+}
+
 void axpy(hipStream_t, int64_t n, double a, const double *x, double *y)
 {
     for (int64_t i = 0; i < n; ++i) y[i] += a * x[i];
@@ -649,6 +654,12 @@ void rfs_update(hipStream_t s, int n, const int *pc, const double *dx_perm, doub
 void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y)
 {
     emul_enqueue(s, [=] { impl::axpy(s, n, a, x, y); });
+}
+
+void add_atomic(hipStream_t s, int64_t n, const double *x, double *y)
+{
+    if (n <= 0) return;
+    emul_enqueue(s, [=] { impl::add_atomic(s, n, x, y); });
 }
 
 void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage, int vs)

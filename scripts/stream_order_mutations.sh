@@ -16,6 +16,7 @@ muts=(
   'if (e_bulk_prev2) hipStreamWaitEvent(ps, e_bulk_prev2, 0);'
   'if (e_u2_prev) hipStreamWaitEvent(ps, e_u2_prev, 0);'
   'if (xy && e_bulk_prev) hipStreamWaitEvent(ps, e_bulk_prev, 0);'
+  'if (e) hipStreamWaitEvent(ps, e, 0);'
 )
 # dependency table of the dataflow sweeps: forward update waits for its supernode's diagonal solve; diagonal solve waits for the
 # updates it receives (forward / backward); backward update waits for the supernodes whose x it reads

@@ -546,6 +546,7 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->pstream) hipStreamSynchronize(H->pstream);
     if (H->ustream) hipStreamSynchronize(H->ustream);
     if (H->u2stream) hipStreamSynchronize(H->u2stream);
+    if (H->rstream) hipStreamSynchronize(H->rstream);
     for (void *p : H->d_misc) hipFree(p);
     if (H->d_val) hipFree(H->d_val);
     if (H->d_info) hipFree(H->d_info);
@@ -569,6 +570,9 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->pstream) hipStreamDestroy(H->pstream);
     if (H->ustream) hipStreamDestroy(H->ustream);
     if (H->u2stream) hipStreamDestroy(H->u2stream);
+    if (H->rstream) hipStreamDestroy(H->rstream);
+    for (auto e : H->red_pool) hipEventDestroy(e);
+    if (H->red_all) hipEventDestroy(H->red_all);
     if (H->stream) hipStreamDestroy(H->stream);
     delete h;
 }

@@ -50,6 +50,8 @@ static int exchange(Handle *H, const std::vector<XMsg> &sends, const std::vector
 // ("urgent", explicit list) and the rest; the panel kernels of level l+1 -- and on an XY layer their two exchange
 // phases -- run on a high-priority stream as soon as the urgent tiles are done and overlap with the rest: the GPU form of
 // the reference's look-ahead pipeline (dsparseTreeFactor_ASYNC, dtreeFactorization.c:381-706, num_lookaheads).
+static hipEvent_t red_wait_event(const Handle *H, int64_t lend, int64_t uend);     // pipelined Z reduction, below
+
 static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
 {
     const DevTables &T = H->T;
@@ -69,10 +71,29 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
     // panel(l) in two parts: A needs only the diagonal blocks of level l to be up to date, B the whole panels
+    // pipelined Z reduction: the own L / U slots of DAG level l end at these arena offsets (own slots are laid out level by level)
+    std::vector<int64_t> lv_lend, lv_uend;
+    if (!H->red_events.empty()) {
+        lv_lend.assign(S.nlevels, -1); lv_uend.assign(S.nlevels, -1);
+        int64_t le = -1, ue = -1;
+        for (int l = 0; l < S.nlevels; ++l) {
+            for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+                const int k = S.nodes[i];
+                if ((H->h_flags[k] & SNF_L_OWN) && H->hs.lval_len[k]) le = std::max(le, H->hs.lval_off[k] + H->hs.lval_len[k]);
+                if ((H->h_flags[k] & SNF_U_OWN) && H->hs.uval_len[k]) ue = std::max(ue, H->hs.uval_off[k] + H->hs.uval_len[k]);
+            }
+            lv_lend[l] = le; lv_uend[l] = ue;
+        }
+    }
+    else if (H->red_all) hipStreamWaitEvent(s, H->red_all, 0);     // nothing chunk-wise pending: whatever an earlier reduction still adds must be in
     auto panelA = [&](int l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         const int *nodes = S.d_nodes + n0;
         const int mx = S.max_nsupc[l];
+        if (!lv_lend.empty()) {   // the panels of this level must hold the partner layer's contributions before they are factored
+            hipEvent_t e = red_wait_event(H, lv_lend[l], lv_uend[l]);
+            if (e) hipStreamWaitEvent(ps, e, 0);
+        }
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
         if (H->z) {   // Local_Zgstrf2 (pzgstrf2.c); the complex panel solves substitute on the factored block: no inverses
             eng::zdiag_lu(ps, T, nodes, nn, mx, H->opt.replace_tiny_pivot, thresh, H->d_info);
@@ -242,12 +263,24 @@ static void ancestor_ranges(const Handle *H, int zl, std::vector<std::pair<int64
 }
 
 // dreduceAllAncestors3d (pd3dcomm.c:1046-1081) after Z level zl: the layer myz + 2^zl sends its copies of every ancestor
-// forest to layer myz (myz % 2^(zl+1) == 0), which adds them (dzRecvLPanel / dzRecvUPanel: daxpy) -- as whole arena ranges,
-// in bounded chunks through one staging buffer.
+// forest to layer myz (myz % 2^(zl+1) == 0), which adds them (dzRecvLPanel / dzRecvUPanel: daxpy) -- whole arena ranges in
+// bounded chunks through one staging buffer.
+// PIPELINED with the factorisation of the next forest (the reference overlaps the same way through its look-ahead / Isend,
+// pdgstrf3d.c:333-385): receives and additions run on a stream of their own (rstream), L and U chunks alternate in arena order
+// (= Z level, DAG level, supernode), every chunk records an event; a DAG level of the next forest waits only for the chunks that
+// cover ITS own L and U slots (run_factor_sched).  The additions are fp64 atomics: the Schur tiles of the levels already running
+// scatter into panels of later levels whose chunks are still to come -- sums commute, the two kinds of update must only not tear.
+static hipEvent_t red_event(Handle *H)
+{
+    if (H->red_pool_used == H->red_pool.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); H->red_pool.push_back(e); }
+    return H->red_pool[H->red_pool_used++];
+}
+
 static int reduce_ancestors(Handle *H, int zl)
 {
     const Grid &g = H->grid;
     const int step = 1 << zl;
+    H->red_events.clear();
     if (zl + 1 >= (int) H->forest_nodes.size() || (g.z % step) != 0) return 0;
     std::vector<std::pair<int64_t, int64_t>> rg;
     ancestor_ranges(H, zl, rg);
@@ -256,24 +289,70 @@ static int reduce_ancestors(Handle *H, int zl)
     if (receiver && g.z + step >= g.Pz) return 0;
     const int vs = H->z ? 2 : 1;            // doubles per value (complex16 panels are reduced as pairs of doubles)
     const int64_t CH = (int64_t) 1 << 24;   // values per message: <= 256 MiB
-    hipStream_t s = H->stream;
     Comm *c = H->comm;
-    for (auto &r : rg)
-        for (int64_t o = 0; o < r.second; o += CH) {
-            const int64_t len = std::min(CH, r.second - o);
-            int rc = c->begin();
-            if (rc) return rc;
-            if (receiver) {
-                if ((rc = ensure_xtmp(H, std::min(CH, r.second) * vs))) return rc;
-                if ((rc = c->recv(H->d_xtmp, len * 8 * vs, peer))) return rc;
-                if ((rc = c->end(s))) return rc;
-                eng::axpy(s, len * vs, 1.0, H->d_xtmp, H->d_val + (r.first + o) * vs);   // the next chunk's receive into the staging buffer is ordered behind this on s
-            } else {
-                if ((rc = c->send(H->d_val + (r.first + o) * vs, len * 8 * vs, peer))) return rc;
-                if ((rc = c->end(s))) return rc;
-            }
+    // serial (profiling / deterministic / SLUAMD_NO_LOOKAHEAD) runs keep the reduction on the main stream: t_reduce_ms then measures it
+    const bool pipelined = H->rstream && !H->profile && !H->opt.deterministic && !H->env.no_lookahead;
+    hipStream_t s = H->stream, rs = pipelined ? H->rstream : H->stream;
+    // what is sent / added to must be complete: everything the factorisation queued so far (all look-ahead streams were joined
+    // into s), and on the sender also the additions of an earlier reduction that are still running on rstream
+    {
+        hipEvent_t e = red_event(H);
+        HIPCHK(hipEventRecord(e, s)); HIPCHK(hipStreamWaitEvent(rs, e, 0));
+    }
+    // chunk sequence: L and U alternate, so that the first DAG levels of the next forest are complete early in BOTH ranges
+    struct Ch { int r; int64_t o, len; };
+    std::vector<Ch> seq;
+    {
+        std::vector<int64_t> pos(rg.size(), 0);
+        for (bool any = true; any;) {
+            any = false;
+            for (size_t r = 0; r < rg.size(); ++r)
+                if (pos[r] < rg[r].second) { const int64_t len = std::min(CH, rg[r].second - pos[r]); seq.push_back({(int) r, pos[r], len}); pos[r] += len; any = true; }
         }
+    }
+    int rc;
+    if (receiver) {
+        int64_t mx = 0;
+        for (auto &q : seq) mx = std::max(mx, q.len);
+        if ((rc = ensure_xtmp(H, std::max<int64_t>(mx * vs, 1)))) return rc;
+    }
+    int64_t done[2] = {-1, -1};            // arena offset covered so far in the L range (rg[0]) and the U range (rg[1]); -1: nothing to wait for
+    // ancestor_ranges() returns [L range][U range] (either may be missing: then its kind is complete from the start)
+    bool has_l = false, has_u = false;
+    {
+        // tell the kinds apart by the arena layout: own L slots come first, own U slots after hs.nnzL
+        for (size_t r = 0; r < rg.size(); ++r) { if (rg[r].first < H->hs.nnzL) has_l = true; else has_u = true; }
+    }
+    for (auto &q : seq) {
+        const auto &r = rg[q.r];
+        if ((rc = c->begin())) return rc;
+        if (receiver) {
+            if ((rc = c->recv(H->d_xtmp, q.len * 8 * vs, peer))) return rc;
+            if ((rc = c->end(rs))) return rc;
+            eng::add_atomic(rs, q.len * vs, H->d_xtmp, H->d_val + (r.first + q.o) * vs);   // the next chunk's receive into the staging buffer is ordered behind this on rs
+            const bool is_l = r.first < H->hs.nnzL;
+            done[is_l ? 0 : 1] = r.first + q.o + q.len;
+            hipEvent_t e = red_event(H);
+            HIPCHK(hipEventRecord(e, rs));
+            H->red_events.push_back({has_l ? done[0] : INT64_MAX, has_u ? done[1] : INT64_MAX, e});
+        } else {
+            if ((rc = c->send(H->d_val + (r.first + q.o) * vs, q.len * 8 * vs, peer))) return rc;
+            if ((rc = c->end(rs))) return rc;
+        }
+    }
+    if (!pipelined) { H->red_events.clear(); return 0; }      // everything is on s already
+    HIPCHK(hipEventRecord(H->red_all, rs));
+    if (!receiver) HIPCHK(hipStreamWaitEvent(s, H->red_all, 0));    // a sender's later work (the solve) follows its sends
     return 0;
+}
+
+// the chunk event a DAG level of the forest being factored has to wait for: the first one whose coverage reaches the end of the
+// level's own L and U slots (nullptr: nothing pending)
+static hipEvent_t red_wait_event(const Handle *H, int64_t lend, int64_t uend)
+{
+    for (auto &e : H->red_events)
+        if ((lend < 0 || e.lend >= lend) && (uend < 0 || e.uend >= uend)) return e.ev;
+    return H->red_events.empty() ? nullptr : H->red_events.back().ev;
 }
 
 int run_factor(Handle *H, double thresh, int *info)
@@ -288,6 +367,7 @@ int run_factor(Handle *H, double thresh, int *info)
     H->ev_schur_used = H->ev_panel_used = H->ev_xchg_used = H->ev_red_used = 0;
     H->schur_rec.clear();
     H->ev_pool_used = 0;
+    H->red_pool_used = 0; H->red_events.clear();
     HIPCHK(hipEventRecord(H->ev0, H->stream));
     // Z levels in order (pdgstrf3d.c:333-385): factor my forest of the level, then the ancestor reduction
     int rc = 0;
@@ -303,6 +383,7 @@ int run_factor(Handle *H, double thresh, int *info)
             if (rc) return rc;
         }
     }
+    if (H->red_all) { HIPCHK(hipStreamWaitEvent(H->stream, H->red_all, 0)); H->red_events.clear(); }   // the last reduction's additions belong to the factorisation
     HIPCHK(hipEventRecord(H->ev1, H->stream));
     int res[4];
     HIPCHK(hipMemcpyAsync(res, H->d_info, sizeof(res), hipMemcpyDeviceToHost, H->stream));

@@ -254,6 +254,13 @@ struct Handle {
     hipStream_t pstream = nullptr;          // high-priority stream for the panel kernels (look-ahead)
     hipStream_t ustream = nullptr;          // high-priority stream for the Schur tiles that feed the next level's panels
     hipStream_t u2stream = nullptr;         // ... and for those that feed the panels of the level after it
+    hipStream_t rstream = nullptr;          // Z ancestor reduction: receives + adds run here, beside the factorisation of the ancestor forest
+    // pipelined ancestor reduction (reduce_ancestors): chunk events of the reduction that follows the last factored Z level; a DAG level
+    // of the next forest may start once the chunks covering its own L and U slots have been added
+    struct RedEv { int64_t lend, uend; hipEvent_t ev; };      // own-slot arena offsets (values) covered so far in the L / U range
+    std::vector<RedEv> red_events;
+    std::vector<hipEvent_t> red_pool; size_t red_pool_used = 0;
+    hipEvent_t red_all = nullptr;            // everything queued on rstream so far
     std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events
     size_t ev_pool_used = 0;
     int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
@@ -344,6 +351,8 @@ void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const doub
 void rfs_update(hipStream_t s, int n, const int *pc, const double *dx_perm, double *x);
 // y[i] += a * x[i]  (ancestor reduction: dzRecvLPanel / dzRecvUPanel's daxpy, pd3dcomm.c:189-331)
 void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y);
+// y[i] += x[i] with fp64 atomics (safe beside the atomic scatter of Schur tiles into the same panels)
+void add_atomic(hipStream_t s, int64_t n, const double *x, double *y);
 // XY exchange helpers: own diagonal blocks of a level -> contiguous staging range (ns x ns, lda = ns each)
 void pack_diag(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, const int64_t *off, int nn, int nwork, double *stage /* already offset */,
                int vs = 1 /* doubles per value: 2 = complex16 */);

@@ -1680,6 +1680,13 @@ __global__ __launch_bounds__(256) void k_axpy(int64_t n, double a, const double 
     for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) y[i] += a * x[i];
 }
 
+// ... the same with fp64 atomics: the pipelined ancestor reduction adds the partner layer's partial sums while the Schur tiles of the
+// ancestor forest's first levels already scatter (atomically) into the same panels
+__global__ __launch_bounds__(256) void k_axpy_atomic(int64_t n, const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) { const double v = x[i]; if (v != 0.0) unsafeAtomicAdd(y + i, v); }
+}
+
 // Own diagonal blocks of one level -> contiguous staging range (ns x ns, lda = ns each): the payload of dDiagFactIBCast
 // (dtrfCommWrapper.c:32-118).  One workgroup per 1024-element chunk.
 constexpr int DGC = 1024;
@@ -1895,6 +1902,13 @@ void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const doub
 void rfs_update(hipStream_t s, int n, const int *pc, const double *dx_perm, double *x)
 {
     hipLaunchKernelGGL(k_rfs_update, dim3((n + 255) / 256), dim3(256), 0, s, n, pc, dx_perm, x);
+}
+
+void add_atomic(hipStream_t s, int64_t n, const double *x, double *y)
+{
+    if (n <= 0) return;
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_axpy_atomic, dim3((unsigned) (nb < 8192 ? nb : 8192)), dim3(256), 0, s, n, x, y);
 }
 
 void axpy(hipStream_t s, int64_t n, double a, const double *x, double *y)

@@ -827,6 +827,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         HIPCHK(hipStreamCreateWithPriority(&H->pstream, hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&H->ustream, hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&H->u2stream, hipStreamNonBlocking, hi));
+        if (H->grid.Pz > 1) { HIPCHK(hipStreamCreateWithPriority(&H->rstream, hipStreamNonBlocking, lo)); HIPCHK(hipEventCreateWithFlags(&H->red_all, hipEventDisableTiming)); }
     }
     HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
     auto &K = H->d_misc;
