@@ -1,0 +1,39 @@
+"""BASELINE.json configs[1] -- the configuration bench.py's headline number is quoted on -- as a `-m gpu` parity test.  (Kept out of the files
+test_gpu_suite_on_emulation.py replays on CPU: 1.3e13 flop.)"""
+import numpy as np
+import pytest
+from superlu_dist_amd import driver, matgen
+
+pytestmark = pytest.mark.gpu
+
+
+def test_benched_configuration_100_cubed():
+    """BASELINE.json configs[1] itself (100^3 7-point Poisson, geometric ND, relax 64, maxsup 256, nrhs 1) as a parity test, not only as
+    bench.py's residual: the oracle cannot run 1.3e13 flop, so the checks are the size-independent ones -- residual on the original
+    system < 1e-10, x against xtrue, one step of iterative refinement (pdgsrfs3d) leaves berr at roundoff, a second factorisation after
+    the device-side re-distribution reproduces the solution to summation-order accuracy."""
+    N = 100
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=256)
+    assert abs(symb.flops - 1.2735e13) < 1e10 and symb.nnzL + symb.nnzU == 2124596738
+    h = driver.LUHandle.from_symbolic(symb, v)
+    thresh = driver.pivot_thresh(n, rp, ci, np.abs(v))
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    xs = []
+    for rep in range(2):
+        if rep:
+            h.reset_values()
+        assert h.pdgstrf3d(thresh) == 0
+        x = h.pdgstrs3d(xp)[symb.perm_c, :]
+        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
+        assert np.abs(x - xt).max() < 1e-9
+        xs.append(x)
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-11
+    h.attach_matrix(n, rp, ci, v, symb.perm_c)
+    xr, berr, steps = h.pdgsrfs3d(b, xs[1])
+    assert berr.max() < 1e-14 and np.abs(xr - xt).max() < 1e-9
+    st = h.stats()
+    assert st["tiny_pivots"] == 0
+    h.destroy(); symb.free()

@@ -228,3 +228,33 @@ def test_distributed_boundary_on_a_single_rank(nrhs):
     with pytest.raises(RuntimeError, match="row range"):
         h.pdgstrs3d_dist(b[:-3, :], symb.perm_c)
     h.destroy(); symb.free()
+
+
+def test_several_exact_zero_pivots_report_the_first_column():
+    """A structurally non-singular matrix whose unpivoted elimination meets several exact zero pivots, in different supernodes and
+    levels of the elimination DAG: `info` is the smallest 1-based column with a zero pivot -- what the reference's documentation of
+    `info` says (pdgstrf2.c:493-497; its code keeps the one met LAST in execution order, :568-571: DESIGN section 2) -- the same on
+    every run, whatever order the workgroups reach them in."""
+    n = 96
+    rows, cols, vals = [], [], []
+    for i in range(n):                     # block-diagonal 2 x 2 blocks [[0, 1], [1, 0]] at three places, identity-like elsewhere
+        rows.append(i); cols.append(i); vals.append(2.0)
+    rp = np.arange(n + 1, dtype=np.int32); ci = np.arange(n, dtype=np.int32); v = np.array(vals)
+    import scipy.sparse as sp
+    A = sp.lil_matrix((n, n)); A.setdiag(2.0)
+    for i in range(n - 1):
+        A[i, i + 1] = -0.5; A[i + 1, i] = -0.5
+    for z in (10, 41, 77):                 # exact zero pivots: a_zz = 0 and nothing earlier updates it
+        A[z, z] = 0.0
+        if z > 0:
+            A[z, z - 1] = 0.0; A[z - 1, z] = 0.0
+    A = A.tocsr(); A.sort_indices()
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    perm = np.arange(n, dtype=np.int32)
+    for rep in range(3):
+        symb = driver.Symbolic(n, rp, ci, perm, relax=4, maxsup=8)
+        h = driver.LUHandle.from_symbolic(symb, v)
+        info = h.pdgstrf3d(0.0)
+        expected = min(int(symb.perm_c[z]) for z in (10, 41, 77)) + 1
+        assert info == expected, (info, expected)
+        h.destroy(); symb.free()
