@@ -785,7 +785,7 @@ void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int 
 {
     emul_enqueue(s, [=] { impl::zpanel_trsm(T, nodes, nn); });
 }
-void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist)
+void zschur(hipStream_t s, int, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int)
 {
     if (ntiles <= 0) return;
     emul_enqueue(s, [=] { impl::schur_t<impl::zc>(T, nodes, prefix, nn, id_base, ntiles, info, ulist); });

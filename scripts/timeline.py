@@ -11,12 +11,12 @@ qcol = next((c for c in cols if c in ("queue_id", "queue", "stream_id", "stream"
 rows = cur.execute(f"select {name_col}, start, end" + (f", {qcol}" if qcol else ", 0") + " from kernels order by start").fetchall()
 rows = [(re.sub(r"\(.*", "", n).replace("void sluamd::", "").replace("sluamd::", ""), s, e, q) for n, s, e, q in rows]
 # factorisations are delimited by k_scatter_values (device-side re-distribution) launches
-marks = [i for i, r in enumerate(rows) if r[0].startswith("k_scatter_values")]
+marks = [i for i, r in enumerate(rows) if r[0].startswith(("k_scatter_values", "kz_scatter_values"))]
 if len(marks) > which:
     lo, hi = marks[which], marks[which + 1] if which + 1 < len(marks) else len(rows)
 else:
     lo, hi = 0, len(rows)
-seg = [r for r in rows[lo:hi] if not r[0].startswith(("k_fwd", "k_bwd", "k_solve", "k_sweep", "k_full_inv", "k_rfs", "__amd"))]
+seg = [r for r in rows[lo:hi] if not r[0].startswith(("k_fwd", "k_bwd", "k_solve", "k_sweep", "k_full_inv", "k_rfs", "kz_fwd", "kz_bwd", "kz_solve", "__amd"))]
 t0 = seg[0][1]
 print("# columns in kernels table:", cols)
 print("# launches of one factorisation: idx start_ms dur_us queue kernel")

@@ -65,7 +65,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
                      const int4 *ulist, int prio = 0) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
-        if (H->z) eng::zschur(st, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist);     // complex16: 64 x 64 tiles on split planes (sluamd_zkernels.inc)
+        if (H->z) eng::zschur(st, big ? 0 : 1, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio);     // complex16: k_schur on the real embedding
         else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;

@@ -365,7 +365,8 @@ int mfma_selftest(const double *A, const double *B, double *D);   // host pointe
 // complex16 twins (any grid: the diagonal-block operand comes from sn_dptr / sn_dlda like the double kernels')
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
-void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist = nullptr);
+void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
+            const int4 *ulist = nullptr, int prio = 0);   // cfg 0: tiles of 64 panel rows x 128 columns, else 64 x 64
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int max_nsupc);
 void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs,
                  int max_nsupc);

@@ -1061,7 +1061,13 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 #ifndef SCHUR64_WGS
 #define SCHUR64_WGS 5   // workgroups per CU the 64 x 64 tile configuration is built for (<= 4: two LDS stages, as the 128 x 128 one)
 #endif
-template <int TMv, int TNv, int NW>
+// Z = true: the complex16 update through its REAL embedding -- C (m x n complex) -= L U is the real GEMM
+//   Creal (2m x n, rows = re / im interleaved: the native complex column-major layout) -= Lexp (2m x 2K) Ureal (2K x n),
+//   Lexp[2i + a][2p + b] = (a == b) ? Re L(i,p) : (a ? Im L(i,p) : -Im L(i,p)),   Ureal[2p + b][j] = (b ? Im : Re) U(p,j)
+// so that U and the destination are read / written where they lie and only the L loader differs (it picks the part a ^ b with
+// a per-thread constant sign): the same tile machinery, every MFMA a useful one (2 (2m)(2K) n = 8 m K n flop).  A tile of
+// TMv real rows is TMv / 2 rows of the complex panel.
+template <int TMv, int TNv, int NW, bool Z = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_WGS))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
@@ -1075,6 +1081,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
     constexpr int LQ = TMv * KC / NT, UQ = TNv * KC / NT;         // prefetch registers per thread
     constexpr int LKS = NT / TMv;                       // k stride of the L loader
     constexpr int UJS = NT / 16;                        // column stride of the U loader
+    constexpr int ZS = Z ? 2 : 1;                       // doubles per value: arena offsets and tile rows of the tables are in values
+    static_assert(!Z || (LKS % 2 == 0 && KC % 2 == 0), "complex L loader: the parity of a thread's k must be constant");
     // 128 x 128 tiles: two LDS stages (one barrier per chunk).  64 x 64 tiles -- the bottom of the tree, short K loops, the tile's
     // life is dependent index loads -- trade the second stage for occupancy: 24 KB instead of 44 KB per workgroup
     constexpr int NBUF = (TMv == 64 && SCHUR64_WGS > 4) ? 1 : 2;
@@ -1127,18 +1135,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
         lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
         stc = T.ub_stcol[ub] + C.y;
     }
-    const int nr = __builtin_amdgcn_readfirstlane(R.z), nc = __builtin_amdgcn_readfirstlane(C.z);   // workgroup-uniform
+    const int nr = __builtin_amdgcn_readfirstlane(R.z) * ZS, nc = __builtin_amdgcn_readfirstlane(C.z);   // workgroup-uniform
     const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
     const int lda = T.sn_nsupr[k];
-    const double *Lp = T.val + T.sn_lval[k] + R.w;                   // first tile row, column 0 of the panel
-    const double *Uv = T.val + T.sn_uval[k];
+    const double *Lp = T.val + ZS * (T.sn_lval[k] + R.w);            // first tile row, column 0 of the panel
+    const double *Uv = T.val + ZS * T.sn_uval[k];
 
     // K-fused update: the deferred updates of up to three predecessors of k in its chain (k = parent(k-1) = ..., consecutive
     // levels) are accumulated here in the same registers -> ONE prologue and ONE scatter for K = sum of their widths.  A
     // predecessor's block structure beyond k is a subset of k's: host-built maps give, per panel row / non-empty U
     // column of k, where the same global row / column sits in its panel / U row (or that it is absent = zeros).
     int nprev = 0;
-    if (T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
+    if (!Z && T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
     {   // per tile column: value offset inside U(k,:), leading zeros, column id inside supernode jb -- flat per-non-empty-column maps
         const int64_t cb = T.sn_ucol[k] + stc;
         const int fstj = T.xsup[jb];
@@ -1174,8 +1182,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
     int di0 = 0, di1 = 0, di2 = 0;
     int64_t dbase = 0;
     if (has_dst) {
-        if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = T.sn_lval[jb]; }
-        else { di0 = T.ub_iukp[dblk]; dbase = T.sn_uval[ib]; }
+        if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = ZS * T.sn_lval[jb]; }
+        else { di0 = T.ub_iukp[dblk]; dbase = ZS * T.sn_uval[ib]; }
     }
     // ---- destination maps (tile row / column -> offset inside the destination panel / U row), before the K loop: the first
     // source fetch is in flight behind these index loads, and the lines can be touched ahead of the scatter ----
@@ -1187,16 +1195,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
             const int fnz = T.xsup[ib], dn = di2;
             for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
             __syncthreads();
-            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? di0 + s_ind[lsub[t] - fnz] : 0;
+            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? ZS * (di0 + s_ind[lsub[t / ZS] - fnz]) + t % ZS : 0;
             const int ldv = T.sn_nsupr[jb];
-            for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * ldv;
+            for (int t = tid; t < TNv; t += NT) s_colmap[t] = ZS * s_jj[t] * ldv;
         } else {
             const int64_t d0 = T.sn_uidx[ib] + di0;
-            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
+            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? ZS * lsub[t / ZS] + t % ZS : 0;
             for (int t = tid; t < TNv; t += NT) {
                 int cm = 0;
                 if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
-                s_colmap[t] = cm;
+                s_colmap[t] = ZS * cm;
             }
         }
     }
@@ -1220,21 +1228,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
     double pl[LQ], pu[UQ];
     const int *cpS = s_cptr, *ldS = s_lead;   // column maps of the current source (LDS): re-read per chunk, registers are scarce
     bool lrow_ok = li < nr;
-    // per-source state of the K loop (source 0 = fused predecessor ka, source 1 = k itself)
-    int ns_s = ns, lda_s = lda;
-    const double *Lrow = Lp + li, *Uvs = Uv;
+    // complex L loader: real row li = (panel row li / 2, part a), the thread's k all have parity b = lk & 1: it reads part a ^ b,
+    // negated for (a, b) = (0, 1)
+    const int zoff = Z ? ((li ^ lk) & 1) : 0;
+    const double zsgn = (Z && !(li & 1) && (lk & 1)) ? -1.0 : 1.0;
+    const int lrow0 = Z ? (li & ~1) + zoff : li;
+    // per-source state of the K loop (source 0 = fused predecessor ka, source 1 = k itself); ns_s counts REAL k (2 per complex one)
+    int ns_s = ZS * ns, lda_s = lda;
+    const double *Lrow = Lp + lrow0, *Uvs = Uv;
 
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < LQ; ++q) {
             const int kg = k0 + lk + LKS * q;
-            pl[q] = (lrow_ok && kg < ns_s) ? Lrow[(size_t) kg * lda_s] : 0.0;
+            if (Z) pl[q] = (lrow_ok && kg < ns_s) ? zsgn * Lrow[(size_t) (kg >> 1) * 2 * lda_s] : 0.0;
+            else pl[q] = (lrow_ok && kg < ns_s) ? Lrow[(size_t) kg * lda_s] : 0.0;
         }
         const int kg = k0 + uk;
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
             const int ld = ldS[uj + UJS * q];
-            pu[q] = (kg >= ld && kg < ns_s) ? Uvs[cpS[uj + UJS * q] + (kg - ld)] : 0.0;
+            if (Z) pu[q] = ((kg >> 1) >= ld && kg < ns_s) ? Uvs[2 * (cpS[uj + UJS * q] + ((kg >> 1) - ld)) + (kg & 1)] : 0.0;
+            else pu[q] = (kg >= ld && kg < ns_s) ? Uvs[cpS[uj + UJS * q] + (kg - ld)] : 0.0;
         }
     };
     auto stash = [&](int buf) {
@@ -1262,8 +1277,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
             kbeg = (nss - T.sn_ldu[ks]) & ~3; lrow_ok = ra >= 0;
             cpS = s_cptr2; ldS = s_lead2;
         } else {
-            ns_s = ns; lda_s = lda; Lrow = Lp + li; Uvs = Uv; lrow_ok = li < nr;
-            kbeg = (ns - T.sn_ldu[k]) & ~3;              // U is zero above its tallest segment: skip those k
+            ns_s = ZS * ns; lda_s = lda; Lrow = Lp + lrow0; Uvs = Uv; lrow_ok = li < nr;
+            kbeg = ZS * ((ns - T.sn_ldu[k]) & ~3);       // U is zero above its tallest segment: skip those k
             cpS = s_cptr; ldS = s_lead;
         }
         // chunk at which the destination lines are touched: the one before the last chunk of the last source
@@ -1963,9 +1978,14 @@ void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int 
 {
     if (nl + nu > 0) hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
-void zschur(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist)
+void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
+            const int4 *ulist, int prio)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(kz_schur, dim3(((ntiles + 7) / 8) * 8), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist);
+    // the real kernel on the real embedding: tiles of 64 panel rows x 128 columns (cfg 0) / 32 x 64
+    if (ntiles <= 0) return;
+    const int grid = ((ntiles + 7) / 8) * 8;
+    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8, true>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
+    else hipLaunchKernelGGL((k_schur<64, 64, 4, true>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
 }
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int mx)
 {

@@ -128,17 +128,19 @@ static int build_tables(Handle &H, HostTables &t)
             const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k];
             const int bfirst = ldiag ? 1 : 0;
             long t128r = 0, t128c = 0;
-            for (int b = bfirst; b < nb; ++b) t128r += (t.lb_nbrow[lb0 + b] + 127) / 128;
+            const int tmr_big = H.z ? 64 : 128;   // complex16: a tile is 64 / 32 panel rows (128 / 64 real rows of the embedding) x 128 / 64 columns
+            for (int b = bfirst; b < nb; ++b) t128r += (t.lb_nbrow[lb0 + b] + tmr_big - 1) / tmr_big;
             for (int b = 0; b < nub; ++b) t128c += (t.ub_ncols[ub0 + b] + 127) / 128;
             const double cells = (double) (nsupr - ldiag) * ncol_tot;
-            const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * 128.0 * 128.0) : 0.0;
-            const bool big = !H.z && nsupc >= 96 && util128 >= 0.5 && !H.env.no_big_tiles;
+            const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * tmr_big * 128.0) : 0.0;
+            const bool big = nsupc >= (H.z ? 48 : 96) && util128 >= 0.5 && !H.env.no_big_tiles;
             t.sn_big[k] = big;
             const int tm = big ? 128 : 64;
+            const int tmr = H.z ? tm / 2 : tm;    // complex16: 64 (32) panel rows = 128 (64) real rows of the embedding
             for (int b = bfirst; b < nb; ++b) {
                 const int nbrow = t.lb_nbrow[lb0 + b], ro = t.lb_rowoff[lb0 + b];
-                for (int r0 = 0; r0 < nbrow; r0 += tm) {
-                    t.rtile.push_back(make_int4(b, r0, std::min(tm, nbrow - r0), ro + r0));
+                for (int r0 = 0; r0 < nbrow; r0 += tmr) {
+                    t.rtile.push_back(make_int4(b, r0, std::min(tmr, nbrow - r0), ro + r0));
                     const int64_t lo = t.sn_lidx[k] + t.lb_lptr[lb0 + b] + r0;
                     if (lo > 0x7fffffff) { set_error("index arena too large for 32-bit tile descriptors"); return SLUAMD_ESTRUCT; }
                     t.rt_info.push_back(make_int2(t.lb_gid[lb0 + b], (int) lo));
