@@ -160,7 +160,10 @@ def main():
     ap.add_argument("--n", "--grid-side", dest="n", type=int, default=100, help="grid side of the N^3 Poisson problem")
     ap.add_argument("--leaf", type=int, default=64)
     ap.add_argument("--relax", type=int, default=64)
-    ap.add_argument("--maxsup", type=int, default=256)
+    ap.add_argument("--maxsup", type=int, default=None,
+                    help="supernode width cap (the reference's SUPERLU_MAXSUP / sp_ienv_dist(3)); default 256, and 64 for the complex16 "
+                         "workload, whose diagonal-block kernel is one workgroup per supernode (measured on zgrid2d 1000: 64 -> 25.7 ms, "
+                         "128 -> 30.0 ms, 256 -> 39.1 ms)")
     ap.add_argument("--scale-n", type=int, default=150,
                     help="grid side of the SCALING POINT reported beside the headline configuration at every N (150^3: 1.5e14 flop, "
                          "90 GB of factors -- seconds of work per step, so that exchange latency does not dominate the N > 1 runs); 0 = skip")
@@ -172,6 +175,7 @@ def main():
                          "(complex16 2-D grid operator, use --n 1000); audikw_like = configs[3] stand-in (use --n 68)")
     ap.add_argument("--matrix", default=None, help="MatrixMarket file instead of a generated workload (e.g. SuiteSparse audikw_1.mtx), ordered by sluamd_order_nd")
     args = ap.parse_args()
+    if args.maxsup is None: args.maxsup = 64 if args.workload == "zgrid2d" else 256
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started as a plain `python bench.py --gpus N`: re-launch under torch.distributed.run, one rank per GPU

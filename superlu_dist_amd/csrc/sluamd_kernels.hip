@@ -1971,7 +1971,10 @@ void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int m
 {
     if (nn <= 0) return;
     // levels of narrow supernodes (the leaves and the small separators: tens of thousands of blocks): one wave per block in registers
-    if (mx <= 64) hipLaunchKernelGGL(kz_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
+    if (mx <= 8) hipLaunchKernelGGL(kz_diag_lu_wave_small<8>, dim3(nn), dim3(64), 0, s, T, nodes, nn, replace_tiny, thresh, info);
+    else if (mx <= 16) hipLaunchKernelGGL(kz_diag_lu_wave_small<16>, dim3(nn), dim3(64), 0, s, T, nodes, nn, replace_tiny, thresh, info);
+    else if (mx <= 32) hipLaunchKernelGGL(kz_diag_lu_wave_small<32>, dim3(nn), dim3(64), 0, s, T, nodes, nn, replace_tiny, thresh, info);
+    else if (mx <= 64) hipLaunchKernelGGL(kz_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), zdiag_lds_bytes(mx), s, T, nodes, replace_tiny, thresh, info, mx | 1);
 }
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
