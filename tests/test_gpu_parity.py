@@ -209,6 +209,40 @@ def test_own_pipeline_complex16(shape, leaf, relax, maxsup):
     assert np.abs(x - xt).max() < 1e-9 * np.abs(xt).max()
 
 
+@pytest.mark.parametrize("shape,leaf,relax,maxsup,nrhs", [((30, 30, 1), 8, 4, 6, 1), ((30, 30, 1), 16, 12, 12, 3), ((40, 40, 1), 16, 24, 24, 7),
+                                                          ((40, 40, 1), 16, 48, 48, 5), ((12, 12, 12), 27, 32, 100, 9), ((14, 14, 14), 27, 64, 200, 2)])
+def test_complex16_values_match_oracle(shape, leaf, relax, maxsup, nrhs):
+    """Every complex16 kernel variant against the CPU oracle, value by value: supernode widths of at most 6 / 12 / 24 / 48 columns (the one-wave
+    diagonal LU with 8 / 16 / 32 / 2 x 32 columns in registers), 100 and 200 (workgroup LU; Schur tiles of 32 x 64 and 64 x 128 on the real
+    embedding), and the blocked diagonal solves with 1..9 right-hand sides (one wave per right-hand side, four at a time)."""
+    nx, ny, nz = shape
+    n, rp, ci, v = matgen.poisson3d(0, nx, ny, nz)
+    v = matgen.complex_shift(v, rp, ci, seed=5)
+    perm = matgen.nd_perm_grid3d(nx, ny, nz, leaf=leaf)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+    symb.distribute_host(v.real); fr = symb.flat_store()      # the distribution is linear in the values: real and imaginary parts apart
+    symb.distribute_host(v.imag); fi = symb.flat_store()
+    assert np.diff(fr.xsup).max() <= maxsup
+    Lz = fr.Lnzval + 1j * fi.Lnzval; Uz = fr.Unzval + 1j * fi.Unzval
+    o = orc.LUStore(fr.n, fr.xsup, fr.Lrowind_off, fr.Lrowind, fr.Lnzval_off, Lz, fr.Ufstnz_off, fr.Ufstnz, fr.Unzval_off, Uz)
+    fs = driver.FlatStore(fr.n, fr.xsup, fr.Lrowind_off, fr.Lrowind, fr.Lnzval_off, Lz, fr.Ufstnz_off, fr.Ufstnz, fr.Unzval_off, Uz)
+    h = driver.LUHandle.from_store(fs)
+    assert h.z
+    assert h.pdgstrf3d(0.0) == 0
+    h.copy_to_host()
+    info, _, _ = orc.dfactor(o)
+    assert info == 0
+    scale = np.abs(v).max()
+    assert np.abs(fs.Lnzval - o.Lnzval).max() <= 1e-12 * scale
+    assert np.abs(fs.Unzval - o.Unzval).max() <= 1e-12 * scale
+    rng = np.random.default_rng(nrhs)
+    xp = np.asfortranarray(rng.standard_normal((n, nrhs)) + 1j * rng.standard_normal((n, nrhs)))
+    x = h.pdgstrs3d(xp)
+    xo = orc.dsolve(o, xp)
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    h.destroy(); symb.free()
+
+
 @pytest.mark.parametrize("nrhs", [1, 3, 60])
 def test_distributed_boundary_on_a_single_rank(nrhs):
     """sluamd_pdgstrs3d_dist (pdgstrs3d's own boundary: original row order in, pdReDistribute3d_B_to_X / X_to_B inside) on a single-rank
