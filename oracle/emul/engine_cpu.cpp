@@ -598,8 +598,10 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
     emul_enqueue(s, [=] { impl::panel_gemm(s, T, nodes, lprefix, uprefix, nn, nl, nu, max_nsupc); });
 }
 
-void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int prio)
+void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int prio,
+           const int *, int mmode)
 {
+    if (mmode == 1) return;     // build pass of the per-tile records: the restatement reads the tables every time
     emul_enqueue(s, [=] { impl::schur(s, cfg, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio); });
 }
 
@@ -785,9 +787,10 @@ void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int 
 {
     emul_enqueue(s, [=] { impl::zpanel_trsm(T, nodes, nn); });
 }
-void zschur(hipStream_t s, int, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int)
+void zschur(hipStream_t s, int, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int,
+            const int *, int mmode)
 {
-    if (ntiles <= 0) return;
+    if (ntiles <= 0 || mmode == 1) return;
     emul_enqueue(s, [=] { impl::schur_t<impl::zc>(T, nodes, prefix, nn, id_base, ntiles, info, ulist); });
 }
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int)

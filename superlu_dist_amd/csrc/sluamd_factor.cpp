@@ -61,12 +61,40 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     int rc_x = 0;
     int cur_level = 0, cur_pass = 0;
+    // per-tile records of the list schedules (k_schur mmode 1 / 2): built once per schedule, on its first factorisation
+    if (S.maps_state == 0) {
+        S.maps_state = -1;
+        if (!H->env.no_tile_maps && !H->opt.deterministic && !S.ulist.empty()) {
+            S.m_off.assign(2 * S.nlevels + 1, 0);
+            for (int l = 0; l < S.nlevels; ++l)
+                for (int g = 0; g < 2; ++g) {
+                    const int64_t cnt = S.u_off[(2 * l + g) * 4 + 4] - S.u_off[(2 * l + g) * 4];
+                    S.m_off[2 * l + g + 1] = S.m_off[2 * l + g] + cnt * eng::schur_rec_ints(g == 0 ? 0 : 2, H->z);
+                }
+            const size_t bytes = sizeof(int) * (size_t) S.m_off[2 * S.nlevels];
+            size_t fr = 0, tot = 0;
+            hipMemGetInfo(&fr, &tot);
+            // the records are an accelerator, not a requirement: leave a tenth of the device free
+            if (bytes > 0 && bytes + tot / 10 < fr && hipMalloc((void **) &S.d_tmaps, bytes) == hipSuccess) {
+                H->d_misc.push_back(S.d_tmaps);
+                for (int l = 0; l < S.nlevels; ++l)
+                    for (int g = 0; g < 2; ++g) {
+                        const int u0 = S.u_off[(2 * l + g) * 4], nu = S.u_off[(2 * l + g) * 4 + 4] - u0;
+                        if (!nu) continue;
+                        if (H->z) eng::zschur(s, g == 0 ? 0 : 1, T, nullptr, nullptr, 0, 0, nu, H->d_info, S.d_ulist + u0, 0, S.d_tmaps + S.m_off[2 * l + g], 1);
+                        else eng::schur(s, g == 0 ? (H->env.schur_4waves ? 1 : 0) : 2, T, nullptr, nullptr, 0, 0, nu, H->d_info, S.d_ulist + u0, 0, S.d_tmaps + S.m_off[2 * l + g], 1);
+                    }
+                S.maps_state = 1;
+                H->st.bytes_device += (int64_t) bytes;
+            } else (void) hipGetLastError();
+        }
+    }
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
-                     const int4 *ulist, int prio = 0) {
+                     const int4 *ulist, int prio = 0, const int *tmaps = nullptr) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
-        if (H->z) eng::zschur(st, big ? 0 : 1, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio);     // complex16: k_schur on the real embedding
-        else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio);
+        if (H->z) eng::zschur(st, big ? 0 : 1, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0);     // complex16: k_schur on the real embedding
+        else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -168,7 +196,8 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             const int cnt = g == 0 ? nbig : nn - nbig;
             if (!cnt) continue;
             const int u0 = S.u_off[(2 * l + g) * 4 + p0], nu = S.u_off[(2 * l + g) * 4 + p1 + 1] - u0;
-            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, (lookahead && p1 < 3) ? 1 : 0);
+            const int *tm = S.maps_state == 1 ? S.d_tmaps + S.m_off[2 * l + g] + (int64_t) (u0 - S.u_off[(2 * l + g) * 4]) * eng::schur_rec_ints(g == 0 ? 0 : 2, H->z) : nullptr;
+            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, (lookahead && p1 < 3) ? 1 : 0, tm);
         }
     };
     // deterministic mode: one supernode per launch over its full tile grid -- tiles of one k hit distinct destinations, the

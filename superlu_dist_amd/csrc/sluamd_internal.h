@@ -192,6 +192,9 @@ struct LevelSched {
     std::vector<int4> ulist;        // tile lists (k, absolute row tile, absolute column tile, destination block or -1): per level and tile-size group
                                     // [diagonal blocks of level l+1 | rest of the level-(l+1) panels | level-(l+2) panels | bulk, 8 x 8 bands per supernode]
     std::vector<int> u_off;         // [8*nlevels+1] offsets into ulist: index (2*level + group) * 4 + part
+    std::vector<int64_t> m_off;     // [2*nlevels+1] first int of the tile records of (level, group) in d_tmaps (record of tile u of the group: + (u - u_off[group start]) * rec)
+    int *d_tmaps = nullptr;         // per-tile records of k_schur, built on the first factorisation (owned by Handle::d_misc)
+    int maps_state = 0;             // 0: not built yet, 1: built, -1: unavailable (memory / switched off)
     // ---- XY block-cyclic exchange plan (empty on a 1 x 1 layer): per level, in ascending supernode order ----
     std::vector<int> dg_prefix;               // per node (lvl_poff layout): 1024-double chunks of the own diagonal blocks to pack
     std::vector<int64_t> dg_off;              // ... and their offsets inside the level's diagonal staging range
@@ -235,6 +238,7 @@ struct Handle {
     struct Env {
         bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, profile_dump = false, trsm_panels = false, diag_v1 = false;
         int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
+        bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
                                                    // profiles/r03_ab_dataflow_sweeps.txt; 1 = agent-scope fences; 2 = write-through x, no fences)
     } env;
@@ -325,7 +329,10 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, int prio);
+           const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0);
+// per-tile records of the list schedules (k_schur): mmode 1 = build pass (writes the records of the launch's tiles at tmaps, no update),
+// mmode 2 = the tiles read their records; ints per record for a tile configuration
+inline int schur_rec_ints(int cfg, bool z) { return (cfg <= 1) ? 16 + 128 + 3 * 128 : 16 + 64 + 3 * 64; (void) z; }
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
@@ -366,7 +373,7 @@ int mfma_selftest(const double *A, const double *B, double *D);   // host pointe
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
 void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-            const int4 *ulist = nullptr, int prio = 0);   // cfg 0: tiles of 64 panel rows x 128 columns, else 64 x 64
+            const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0);   // cfg 0: tiles of 64 panel rows x 128 columns, else 32 x 64
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int max_nsupc);
 void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs,
                  int max_nsupc);

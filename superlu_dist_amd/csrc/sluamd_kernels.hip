@@ -1067,11 +1067,12 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 // so that U and the destination are read / written where they lie and only the L loader differs (it picks the part a ^ b with
 // a per-thread constant sign): the same tile machinery, every MFMA a useful one (2 (2m)(2K) n = 8 m K n flop).  A tile of
 // TMv real rows is TMv / 2 rows of the complex panel.
-template <int TMv, int TNv, int NW, bool Z = false>
+template <int TMv, int TNv, int NW, bool Z = false, int MM = 0>   // MM 0: the tiles chase the tables; 1: and write their per-tile records instead of updating (plan-time build pass); 2: they read the records
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_WGS))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
-                                                                    const int4 *__restrict__ ulist, int prio)
+                                                                    const int4 *__restrict__ ulist, int prio,
+                                                                    const int *__restrict__ tmaps)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -1097,6 +1098,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
     __shared__ int s_lead2[TNv];
     __shared__ int s_jj[TNv];     // column id inside supernode jb
     __shared__ int s_dinfo[1];
+    __shared__ int s_hdr[16];
+    constexpr int REC = 16 + TMv + 3 * TNv;          // ints per tile record (mmode 1 / 2)
 
     const int tid = threadIdx.x;
     // XCD-aware mapping: workgroup b runs on XCD b%8; give every XCD a contiguous range of tiles so that the
@@ -1108,107 +1111,157 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
         if ((blockIdx.x >> 3) >= chunk || bid >= ntiles) return;
         bid += id_base;
     }
-    // `ulist` != null (every schedule but the deterministic one): tile list entry (supernode, absolute row tile, absolute column
-    // tile, destination block) + per-tile descriptors -- the prologue is three dependent (scalar) loads deep.  Otherwise the full
-    // tile grid of the supernodes `nodes` (one supernode per launch: tiles of one k hit distinct destinations).
-    int k, ib, jb, dblk = -2, stc;
-    int4 R, C;
-    const int *lsub;            // global row ids of the tile rows
+    // Per-tile state of the K loop and the scatter.  mmode 2 (every schedule but the deterministic one, after the plan's build pass):
+    // ONE contiguous record per tile -- header + the four maps -- written once per plan by this kernel itself (mmode 1), instead
+    // of the chain of dependent table lookups below (tile list -> tile descriptors -> supernode tables -> column maps ->
+    // destination block -> its row list -> inverse row map): the record's address depends on the tile id alone.
+    int k, nr, nc, ns, lda, stc, Rw, kbeg_own;
+    bool has_dst;
+    const double *Lp, *Uv;
+    double *dst;
     if (prio) __builtin_amdgcn_s_setprio(2);   // urgent tiles sit on the panel chain
-    if (ulist) {
-        const int4 u = ulist[bid];
-        k = u.x; dblk = u.w;
-        R = T.rtile[u.y]; C = T.ctile[u.z];
-        const int2 ri = T.rt_info[u.y];
-        const int4 ci = T.ct_info[u.z];
-        ib = ri.x; jb = ci.x; lsub = T.lidx + ri.y; stc = ci.z;
+    if (MM == 2) {
+        const int *rec = tmaps + (size_t) (bid - id_base) * REC;
+        for (int t = tid; t < REC; t += NT) {
+            const int v = rec[t];
+            if (t < 16) s_hdr[t] = v;
+            else if (t < 16 + TMv) s_rowmap[t - 16] = v;
+            else if (t < 16 + TMv + TNv) s_colmap[t - 16 - TMv] = v;
+            else if (t < 16 + TMv + 2 * TNv) s_cptr[t - 16 - TMv - TNv] = v;
+            else s_lead[t - 16 - TMv - 2 * TNv] = v;
+        }
+        __syncthreads();
+        k = s_hdr[0];
+        nr = __builtin_amdgcn_readfirstlane(s_hdr[1]); nc = __builtin_amdgcn_readfirstlane(s_hdr[2]);
+        ns = s_hdr[3]; lda = s_hdr[4]; kbeg_own = s_hdr[5];
+        Lp = T.val + (((int64_t) s_hdr[7] << 32) | (uint32_t) s_hdr[6]);
+        Uv = T.val + (((int64_t) s_hdr[9] << 32) | (uint32_t) s_hdr[8]);
+        const int64_t dbase = ((int64_t) s_hdr[11] << 32) | (uint32_t) s_hdr[10];
+        has_dst = dbase >= 0;
+        dst = T.val + (has_dst ? dbase : 0);
+        stc = s_hdr[12]; Rw = s_hdr[13];
+        if (!has_dst && tid == 0) atomicAdd(&info[2], 1);
     } else {
-        const int ni = find_node(prefix, nn, bid);
-        k = nodes[ni];
-        const int local = bid - prefix[ni];
-        const int nct = T.sn_nct[k];
-        const int rt = local / nct, ct = local - rt * nct;
-        R = T.rtile[T.sn_rt_off[k] + rt];
-        C = T.ctile[T.sn_ct_off[k] + ct];
-        const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
-        ib = T.lb_gid[lb]; jb = T.ub_gid[ub];
-        lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
-        stc = T.ub_stcol[ub] + C.y;
-    }
-    const int nr = __builtin_amdgcn_readfirstlane(R.z) * ZS, nc = __builtin_amdgcn_readfirstlane(C.z);   // workgroup-uniform
-    const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
-    const int lda = T.sn_nsupr[k];
-    const double *Lp = T.val + ZS * (T.sn_lval[k] + R.w);            // first tile row, column 0 of the panel
-    const double *Uv = T.val + ZS * T.sn_uval[k];
+        // `ulist` != null (every schedule but the deterministic one): tile list entry (supernode, absolute row tile, absolute column
+        // tile, destination block) + per-tile descriptors -- the prologue is three dependent (scalar) loads deep.  Otherwise the full
+        // tile grid of the supernodes `nodes` (one supernode per launch: tiles of one k hit distinct destinations).
+        int ib, jb, dblk = -2;
+        int4 R, C;
+        const int *lsub;            // global row ids of the tile rows
+        if (ulist) {
+            const int4 u = ulist[bid];
+            k = u.x; dblk = u.w;
+            R = T.rtile[u.y]; C = T.ctile[u.z];
+            const int2 ri = T.rt_info[u.y];
+            const int4 ci = T.ct_info[u.z];
+            ib = ri.x; jb = ci.x; lsub = T.lidx + ri.y; stc = ci.z;
+        } else {
+            const int ni = find_node(prefix, nn, bid);
+            k = nodes[ni];
+            const int local = bid - prefix[ni];
+            const int nct = T.sn_nct[k];
+            const int rt = local / nct, ct = local - rt * nct;
+            R = T.rtile[T.sn_rt_off[k] + rt];
+            C = T.ctile[T.sn_ct_off[k] + ct];
+            const int lb = T.sn_lb_off[k] + R.x, ub = T.sn_ub_off[k] + C.x;
+            ib = T.lb_gid[lb]; jb = T.ub_gid[ub];
+            lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
+            stc = T.ub_stcol[ub] + C.y;
+        }
+        nr = __builtin_amdgcn_readfirstlane(R.z) * ZS; nc = __builtin_amdgcn_readfirstlane(C.z);   // workgroup-uniform
+        ns = T.xsup[k + 1] - T.xsup[k];
+        lda = T.sn_nsupr[k];
+        Rw = R.w;
+        kbeg_own = ZS * ((ns - T.sn_ldu[k]) & ~3);       // U is zero above its tallest segment: skip those k
+        Lp = T.val + ZS * (T.sn_lval[k] + R.w);            // first tile row, column 0 of the panel
+        Uv = T.val + ZS * T.sn_uval[k];
 
+        {   // per tile column: value offset inside U(k,:), leading zeros, column id inside supernode jb -- flat per-non-empty-column maps
+            const int64_t cb = T.sn_ucol[k] + stc;
+            const int fstj = T.xsup[jb];
+            for (int t = tid; t < TNv; t += NT) {
+                int cp = 0, lead = ns, jj = 0;
+                if (t < nc) { cp = T.ucol_cp[cb + t]; lead = T.ucol_ld[cb + t]; jj = T.ucol_gc[cb + t] - fstj; }
+                s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
+            }
+        }
+        // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches): host-resolved in list mode ----
+        if (dblk == -2 && (tid >> 6) == NW - 1) {
+            // one wave scans the gid directory of the destination panel / row with ONE coalesced load per 64 blocks and a
+            // ballot, instead of a binary search whose every step is a dependent L2 round trip
+            const int ln = tid & 63;
+            const bool ldest = ib >= jb;
+            const int o = ldest ? T.sn_lb_off[jb] : T.sn_ub_off[ib];
+            const int nb = ldest ? T.sn_nlb[jb] : T.sn_nub[ib];
+            const int *dir = ldest ? T.lbs_gid : T.ub_gid;
+            const int want = ldest ? ib : jb;
+            int pos = -1;
+            for (int base = 0; base < nb && pos < 0; base += 64) {
+                const int g = (base + ln < nb) ? dir[o + base + ln] : -1;
+                const unsigned long long m = __ballot(g == want);
+                if (m) pos = base + __ffsll((long long) m) - 1;
+            }
+            if (ln == 0) s_dinfo[0] = pos < 0 ? -1 : (ldest ? o + T.lbs_idx[o + pos] : o + pos);
+        }
+        __syncthreads();
+        if (dblk == -2) dblk = s_dinfo[0];
+        has_dst = dblk >= 0;
+        if (!has_dst && tid == 0) atomicAdd(&info[2], 1);
+        // destination block: (row offset inside the panel, its row ids, its row count) of L(ib, jb), or the index position of U(ib, jb)
+        int di0 = 0, di1 = 0, di2 = 0;
+        int64_t dbase = 0;
+        if (has_dst) {
+            if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = ZS * T.sn_lval[jb]; }
+            else { di0 = T.ub_iukp[dblk]; dbase = ZS * T.sn_uval[ib]; }
+        }
+        // ---- destination maps (tile row / column -> offset inside the destination panel / U row), before the K loop: the first
+        // source fetch is in flight behind these index loads, and the lines can be touched ahead of the scatter ----
+        dst = T.val + dbase;
+        if (has_dst) {
+            if (ib >= jb) {
+                // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
+                const int *drows = T.lidx + T.sn_lidx[jb] + di1;
+                const int fnz = T.xsup[ib], dn = di2;
+                for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
+                __syncthreads();
+                for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? ZS * (di0 + s_ind[lsub[t / ZS] - fnz]) + t % ZS : 0;
+                const int ldv = T.sn_nsupr[jb];
+                for (int t = tid; t < TNv; t += NT) s_colmap[t] = ZS * s_jj[t] * ldv;
+            } else {
+                const int64_t d0 = T.sn_uidx[ib] + di0;
+                for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? ZS * lsub[t / ZS] + t % ZS : 0;
+                for (int t = tid; t < TNv; t += NT) {
+                    int cm = 0;
+                    if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
+                    s_colmap[t] = ZS * cm;
+                }
+            }
+        }
+        __syncthreads();
+        if (MM == 1) {
+            // plan-time build pass: the record this tile reads from now on
+            int *rec = const_cast<int *>(tmaps) + (size_t) (bid - id_base) * REC;
+            if (tid == 0) {
+                const int64_t lo = Lp - T.val, uo = Uv - T.val, db = has_dst ? (int64_t) (dst - T.val) : -1;
+                rec[0] = k; rec[1] = nr; rec[2] = nc; rec[3] = ns; rec[4] = lda; rec[5] = kbeg_own;
+                rec[6] = (int) (uint32_t) lo; rec[7] = (int) (lo >> 32); rec[8] = (int) (uint32_t) uo; rec[9] = (int) (uo >> 32);
+                rec[10] = (int) (uint32_t) db; rec[11] = (int) (db >> 32); rec[12] = stc; rec[13] = Rw; rec[14] = 0; rec[15] = 0;
+            }
+            for (int t = tid; t < TMv; t += NT) rec[16 + t] = has_dst ? s_rowmap[t] : 0;
+            for (int t = tid; t < TNv; t += NT) {
+                rec[16 + TMv + t] = has_dst ? s_colmap[t] : 0;
+                rec[16 + TMv + TNv + t] = s_cptr[t];
+                rec[16 + TMv + 2 * TNv + t] = s_lead[t];
+            }
+            return;
+        }
+    }
     // K-fused update: the deferred updates of up to three predecessors of k in its chain (k = parent(k-1) = ..., consecutive
     // levels) are accumulated here in the same registers -> ONE prologue and ONE scatter for K = sum of their widths.  A
     // predecessor's block structure beyond k is a subset of k's: host-built maps give, per panel row / non-empty U
     // column of k, where the same global row / column sits in its panel / U row (or that it is absent = zeros).
     int nprev = 0;
     if (!Z && T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
-    {   // per tile column: value offset inside U(k,:), leading zeros, column id inside supernode jb -- flat per-non-empty-column maps
-        const int64_t cb = T.sn_ucol[k] + stc;
-        const int fstj = T.xsup[jb];
-        for (int t = tid; t < TNv; t += NT) {
-            int cp = 0, lead = ns, jj = 0;
-            if (t < nc) { cp = T.ucol_cp[cb + t]; lead = T.ucol_ld[cb + t]; jj = T.ucol_gc[cb + t] - fstj; }
-            s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
-        }
-    }
-    // ---- destination lookup (dscatter_l :138-147 / scatter_u :593-602 linear searches): host-resolved in list mode ----
-    if (dblk == -2 && (tid >> 6) == NW - 1) {
-        // one wave scans the gid directory of the destination panel / row with ONE coalesced load per 64 blocks and a
-        // ballot, instead of a binary search whose every step is a dependent L2 round trip
-        const int ln = tid & 63;
-        const bool ldest = ib >= jb;
-        const int o = ldest ? T.sn_lb_off[jb] : T.sn_ub_off[ib];
-        const int nb = ldest ? T.sn_nlb[jb] : T.sn_nub[ib];
-        const int *dir = ldest ? T.lbs_gid : T.ub_gid;
-        const int want = ldest ? ib : jb;
-        int pos = -1;
-        for (int base = 0; base < nb && pos < 0; base += 64) {
-            const int g = (base + ln < nb) ? dir[o + base + ln] : -1;
-            const unsigned long long m = __ballot(g == want);
-            if (m) pos = base + __ffsll((long long) m) - 1;
-        }
-        if (ln == 0) s_dinfo[0] = pos < 0 ? -1 : (ldest ? o + T.lbs_idx[o + pos] : o + pos);
-    }
-    __syncthreads();
-    if (dblk == -2) dblk = s_dinfo[0];
-    const bool has_dst = dblk >= 0;
-    if (!has_dst && tid == 0) atomicAdd(&info[2], 1);
-    // destination block: (row offset inside the panel, its row ids, its row count) of L(ib, jb), or the index position of U(ib, jb)
-    int di0 = 0, di1 = 0, di2 = 0;
-    int64_t dbase = 0;
-    if (has_dst) {
-        if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = ZS * T.sn_lval[jb]; }
-        else { di0 = T.ub_iukp[dblk]; dbase = ZS * T.sn_uval[ib]; }
-    }
-    // ---- destination maps (tile row / column -> offset inside the destination panel / U row), before the K loop: the first
-    // source fetch is in flight behind these index loads, and the lines can be touched ahead of the scatter ----
-    double *dst = T.val + dbase;
-    if (has_dst) {
-        if (ib >= jb) {
-            // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
-            const int *drows = T.lidx + T.sn_lidx[jb] + di1;
-            const int fnz = T.xsup[ib], dn = di2;
-            for (int i = tid; i < dn; i += NT) s_ind[drows[i] - fnz] = i;
-            __syncthreads();
-            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? ZS * (di0 + s_ind[lsub[t / ZS] - fnz]) + t % ZS : 0;
-            const int ldv = T.sn_nsupr[jb];
-            for (int t = tid; t < TNv; t += NT) s_colmap[t] = ZS * s_jj[t] * ldv;
-        } else {
-            const int64_t d0 = T.sn_uidx[ib] + di0;
-            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? ZS * lsub[t / ZS] + t % ZS : 0;
-            for (int t = tid; t < TNv; t += NT) {
-                int cm = 0;
-                if (t < nc) cm = T.ucolptr[d0 + s_jj[t]] - T.uidx[d0 + s_jj[t]];  // colptr - fstnz
-                s_colmap[t] = ZS * cm;
-            }
-        }
-    }
-    __syncthreads();
     double touch0 = 0.0, touch1 = 0.0;
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1267,7 +1320,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
             const int ks = T.fuse_prev[pj];
             const int nss = T.xsup[ks + 1] - T.xsup[ks];
             const int *cinfo = T.pair_colinfo + 2 * (size_t) (T.pair_coff[pj] + stc);
-            const int ra = (li < nr) ? T.pair_rowmap[T.pair_roff[pj] + R.w + li] : -1;
+            const int ra = (li < nr) ? T.pair_rowmap[T.pair_roff[pj] + Rw + li] : -1;
             for (int t = tid; t < TNv; t += NT) {
                 s_cptr2[t] = (t < nc) ? cinfo[2 * t] : 0;
                 s_lead2[t] = (t < nc) ? cinfo[2 * t + 1] : nss;
@@ -1278,7 +1331,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_W
             cpS = s_cptr2; ldS = s_lead2;
         } else {
             ns_s = ZS * ns; lda_s = lda; Lrow = Lp + lrow0; Uvs = Uv; lrow_ok = li < nr;
-            kbeg = ZS * ((ns - T.sn_ldu[k]) & ~3);       // U is zero above its tallest segment: skip those k
+            kbeg = kbeg_own;
             cpS = s_cptr; ldS = s_lead;
         }
         // chunk at which the destination lines are touched: the one before the last chunk of the last source
@@ -1821,14 +1874,20 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
     else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nl + nu), dim3(256), lds, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 
+#define SCHUR_LAUNCH(TM, TN, NWV, ZV, THREADS) \
+    do { \
+        if (mmode == 2) hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 2>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps); \
+        else if (mmode == 1) hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 1>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps); \
+        else hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 0>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps); \
+    } while (0)
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, int prio)
+           const int4 *ulist, int prio, const int *tmaps, int mmode)
 {
     if (ntiles <= 0) return;
     const int grid = ((ntiles + 7) / 8) * 8;
-    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
-    else if (cfg == 1) hipLaunchKernelGGL((k_schur<128, 128, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
-    else hipLaunchKernelGGL((k_schur<64, 64, 4>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
+    if (cfg == 0) SCHUR_LAUNCH(128, 128, 8, false, 512);
+    else if (cfg == 1) SCHUR_LAUNCH(128, 128, 4, false, 256);
+    else SCHUR_LAUNCH(64, 64, 4, false, 256);
 }
 
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int mx)
@@ -1982,13 +2041,13 @@ void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int 
     if (nl + nu > 0) hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-            const int4 *ulist, int prio)
+            const int4 *ulist, int prio, const int *tmaps, int mmode)
 {
     // the real kernel on the real embedding: tiles of 64 panel rows x 128 columns (cfg 0) / 32 x 64
     if (ntiles <= 0) return;
     const int grid = ((ntiles + 7) / 8) * 8;
-    if (cfg == 0) hipLaunchKernelGGL((k_schur<128, 128, 8, true>), dim3(grid), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
-    else hipLaunchKernelGGL((k_schur<64, 64, 4, true>), dim3(grid), dim3(256), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio);
+    if (cfg == 0) SCHUR_LAUNCH(128, 128, 8, true, 512);
+    else SCHUR_LAUNCH(64, 64, 4, true, 256);
 }
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int mx)
 {
