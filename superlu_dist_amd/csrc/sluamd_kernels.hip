@@ -1059,7 +1059,8 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 }
 
 #ifndef SCHUR64_WGS
-#define SCHUR64_WGS 5   // workgroups per CU the 64 x 64 tile configuration is built for (<= 4: two LDS stages, as the 128 x 128 one)
+#define SCHUR64_WGS 5   // workgroups per CU the 64 x 64 tile configuration is built for (<= 4: two LDS stages, as the 128 x 128 one); the complex
+                        // variant fits six without spills (76 VGPRs) and is built for six: zgrid2d 1000 24.8 -> 23.9 ms; the double one spills at 80: +1.6 ms
 #endif
 // Z = true: the complex16 update through its REAL embedding -- C (m x n complex) -= L U is the real GEMM
 //   Creal (2m x n, rows = re / im interleaved: the native complex column-major layout) -= Lexp (2m x 2K) Ureal (2K x n),
@@ -1068,7 +1069,7 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 // a per-thread constant sign): the same tile machinery, every MFMA a useful one (2 (2m)(2K) n = 8 m K n flop).  A tile of
 // TMv real rows is TMv / 2 rows of the complex panel.
 template <int TMv, int TNv, int NW, bool Z = false, int MM = 0>   // MM 0: the tiles chase the tables; 1: and write their per-tile records instead of updating (plan-time build pass); 2: they read the records
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : SCHUR64_WGS))) void k_schur(DevTables T, const int *__restrict__ nodes,
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : SCHUR64_WGS)))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, int prio,
