@@ -384,6 +384,7 @@ def main():
         "factor_gflops_kernel_only": F / (np.mean(fact_ms) * 1e-3) / 1e9,
         "residual": res, "max_abs_err_vs_xtrue": err, "info": int(info), "accuracy": accuracy,
         "levels": st["num_levels"], "fused_level_pairs": st["reserved_i"], "launches_per_factor": st["num_launches"], "setup_s": t_setup,
+        "bytes_device_this_rank": int(st["bytes_device"]),
         "roofline": {"bound": "mfma", "kernel": "k_schur<Z> (the double kernel on the real embedding of the complex update: fused gather + fp64 MFMA + scatter; 8 real flop per complex multiply-add)" if zwork else
                      "k_schur (fused gather + fp64 MFMA GEMM + scatter)",
                      "achieved": schur_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
