@@ -87,10 +87,11 @@ __device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, i
         const bool below = lane > j;
         const double l = a[j] * rinv;
         if (below) a[j] = l;
+        const double lm = below ? l : 0.0;      // rows at and above the pivot take a zero multiplier: one FMA per column, no select
 #pragma unroll
         for (int c = j + 1; c < DB; ++c) {
             const double u = lane_bcast(a[c], j);
-            if (below) a[c] -= l * u;
+            a[c] -= lm * u;
             if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the broadcast SGPRs
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -133,10 +134,11 @@ __global__ __launch_bounds__(256, 2) void k_diag_lu_wave(DevTables T, const int 
             const bool below = lane > j;
             const double l = a[j] * rinv;
             if (below) a[j] = l;
+            const double lm = below ? l : 0.0;
 #pragma unroll
             for (int c = j + 1; c < 64; ++c) {
                 const double u = lane_bcast(a[c], j);
-                if (below) a[c] -= l * u;
+                a[c] -= lm * u;
                 if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the broadcast SGPRs
             }
         }
