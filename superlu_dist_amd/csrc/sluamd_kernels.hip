@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_diag_lu2(DevTables T, const int *__r
                     double a = (i == cc) ? 1.0 : 0.0;
 #pragma unroll
                     for (int jj = i + 1; jj < 16; ++jj) a -= Bs[(o + i) * (DB + 1) + o + jj] * xi[jj];
-                    xi[i] = (i <= cc) ? a / Bs[(o + i) * (DB + 1) + o + i] : 0.0;
+                    xi[i] = (i <= cc) ? a * ((typ == 0) ? s_rinv[o + i] : 1.0) : 0.0;    // 1 / U(i,i) from the head's factorisation; L is unit
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Xs[(o + i) * (DB + 1) + o + cc] = xi[i];
