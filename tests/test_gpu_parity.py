@@ -209,6 +209,45 @@ def test_own_pipeline_complex16(shape, leaf, relax, maxsup):
     assert np.abs(x - xt).max() < 1e-9 * np.abs(xt).max()
 
 
+@pytest.mark.parametrize("complex16", [False, True])
+def test_tile_records_match_table_lookups(complex16, monkeypatch):
+    """The per-tile records of the Schur tiles (written by a plan-time pass of the kernel, read by every later factorisation) against the
+    same factorisation with the tiles chasing the tables (SLUAMD_NO_TILE_MAPS): same factors to summation-order accuracy, both tile
+    configurations in use, a second factorisation on the same handle (records reused) included."""
+    N = 24
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(3)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    if complex16:
+        v = matgen.complex_shift(v, rp, ci, seed=4)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=32, maxsup=160)
+    out = []
+    xt = rng.standard_normal((n, 2)) + (1j * rng.standard_normal((n, 2)) if complex16 else 0.0)
+    b = matgen.csr_matvec(n, rp, ci, v, xt)
+    for no_maps in (False, True):
+        if no_maps:
+            monkeypatch.setenv("SLUAMD_NO_TILE_MAPS", "1")
+        h = driver.LUHandle.from_symbolic(symb, v)
+        assert h.pdgstrf3d(0.0) == 0
+        by0 = h.stats()["bytes_device"]
+        if not no_maps:
+            h.reset_values()
+            assert h.pdgstrf3d(0.0) == 0          # the records were built by the first factorisation
+            assert h.stats()["bytes_device"] == by0
+        xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+        x = h.pdgstrs3d(xp)[symb.perm_c, :]
+        assert np.abs(x - xt).max() < 1e-9 * np.abs(xt).max()
+        out.append((x, by0))
+        h.destroy()
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-11 * np.abs(out[1][0]).max()
+    if "emul" in os.environ.get("SLUAMD_LIB", ""):
+        assert out[0][1] >= out[1][1]             # CPU test build: no records (its Schur restatement reads the tables every time)
+    else:
+        assert out[0][1] > out[1][1]              # the records are device memory the statistics report
+    symb.free()
+
+
 @pytest.mark.parametrize("shape,leaf,relax,maxsup,nrhs", [((30, 30, 1), 8, 4, 6, 1), ((30, 30, 1), 16, 12, 12, 3), ((40, 40, 1), 16, 24, 24, 7),
                                                           ((40, 40, 1), 16, 48, 48, 5), ((12, 12, 12), 27, 32, 100, 9), ((14, 14, 14), 27, 64, 200, 2)])
 def test_complex16_values_match_oracle(shape, leaf, relax, maxsup, nrhs):
