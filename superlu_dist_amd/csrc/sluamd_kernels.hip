@@ -1101,8 +1101,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     __shared__ int s_lead2[TNv];
     __shared__ int s_jj[TNv];     // column id inside supernode jb
     __shared__ int s_dinfo[1];
-    __shared__ int s_hdr[16];
-    constexpr int REC = 16 + TMv + 3 * TNv;          // ints per tile record (mmode 1 / 2)
+    constexpr int HDR = 32;                          // header ints of a tile record: [0,16) the tile itself, [16,32) its K-fused predecessor
+    __shared__ int s_hdr[HDR];
+    constexpr int REC = HDR + TMv + 3 * TNv;         // ints per tile record (MM 1 / 2)
 
     const int tid = threadIdx.x;
     // XCD-aware mapping: workgroup b runs on XCD b%8; give every XCD a contiguous range of tiles so that the
@@ -1127,11 +1128,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         const int *rec = tmaps + (size_t) (bid - id_base) * REC;
         for (int t = tid; t < REC; t += NT) {
             const int v = rec[t];
-            if (t < 16) s_hdr[t] = v;
-            else if (t < 16 + TMv) s_rowmap[t - 16] = v;
-            else if (t < 16 + TMv + TNv) s_colmap[t - 16 - TMv] = v;
-            else if (t < 16 + TMv + 2 * TNv) s_cptr[t - 16 - TMv - TNv] = v;
-            else s_lead[t - 16 - TMv - 2 * TNv] = v;
+            if (t < HDR) s_hdr[t] = v;
+            else if (t < HDR + TMv) s_rowmap[t - HDR] = v;
+            else if (t < HDR + TMv + TNv) s_colmap[t - HDR - TMv] = v;
+            else if (t < HDR + TMv + 2 * TNv) s_cptr[t - HDR - TMv - TNv] = v;
+            else s_lead[t - HDR - TMv - 2 * TNv] = v;
         }
         __syncthreads();
         k = s_hdr[0];
@@ -1250,11 +1251,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
                 rec[6] = (int) (uint32_t) lo; rec[7] = (int) (lo >> 32); rec[8] = (int) (uint32_t) uo; rec[9] = (int) (uo >> 32);
                 rec[10] = (int) (uint32_t) db; rec[11] = (int) (db >> 32); rec[12] = stc; rec[13] = Rw; rec[14] = 0; rec[15] = 0;
             }
-            for (int t = tid; t < TMv; t += NT) rec[16 + t] = has_dst ? s_rowmap[t] : 0;
+            if (tid == 64) {
+                // the K-fused predecessor (at most one by default: fuse_max_prev): everything its source pass needs but the two maps
+                int np = 0;
+                if (!Z && T.fuse_prev) { while (np < 3 && T.fuse_prev[3 * k + np] >= 0) ++np; }
+                rec[16] = np;
+                for (int q = 17; q < HDR; ++q) rec[q] = 0;
+                if (np == 1) {
+                    const int pj = 3 * k, ks = T.fuse_prev[pj];
+                    const int nss = T.xsup[ks + 1] - T.xsup[ks];
+                    const int64_t lo = T.sn_lval[ks], uo = T.sn_uval[ks];
+                    const int64_t co = 2 * (int64_t) (T.pair_coff[pj] + stc), ro = (int64_t) T.pair_roff[pj] + Rw;
+                    rec[17] = nss; rec[18] = T.sn_nsupr[ks]; rec[19] = (nss - T.sn_ldu[ks]) & ~3;
+                    rec[20] = (int) (uint32_t) lo; rec[21] = (int) (lo >> 32); rec[22] = (int) (uint32_t) uo; rec[23] = (int) (uo >> 32);
+                    rec[24] = (int) (uint32_t) co; rec[25] = (int) (co >> 32); rec[26] = (int) (uint32_t) ro; rec[27] = (int) (ro >> 32);
+                }
+            }
+            for (int t = tid; t < TMv; t += NT) rec[HDR + t] = has_dst ? s_rowmap[t] : 0;
             for (int t = tid; t < TNv; t += NT) {
-                rec[16 + TMv + t] = has_dst ? s_colmap[t] : 0;
-                rec[16 + TMv + TNv + t] = s_cptr[t];
-                rec[16 + TMv + 2 * TNv + t] = s_lead[t];
+                rec[HDR + TMv + t] = has_dst ? s_colmap[t] : 0;
+                rec[HDR + TMv + TNv + t] = s_cptr[t];
+                rec[HDR + TMv + 2 * TNv + t] = s_lead[t];
             }
             return;
         }
@@ -1264,7 +1281,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     // predecessor's block structure beyond k is a subset of k's: host-built maps give, per panel row / non-empty U
     // column of k, where the same global row / column sits in its panel / U row (or that it is absent = zeros).
     int nprev = 0;
-    if (!Z && T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
+    if (MM == 2) nprev = Z ? 0 : s_hdr[16];
+    else if (!Z && T.fuse_prev) { while (nprev < 3 && T.fuse_prev[3 * k + nprev] >= 0) ++nprev; }
     double touch0 = 0.0, touch1 = 0.0;
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1318,7 +1336,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     int buf = 0;
     for (int src = 0; src <= nprev; ++src) {       // farthest predecessor first, k itself last
         int kbeg;
-        if (src < nprev) {
+        if (MM == 2 && src < nprev && nprev == 1) {
+            // the predecessor's scalars come with the record: its two maps are the only loads before its first fetch
+            const int nss = s_hdr[17];
+            const int64_t co = ((int64_t) s_hdr[25] << 32) | (uint32_t) s_hdr[24], ro = ((int64_t) s_hdr[27] << 32) | (uint32_t) s_hdr[26];
+            const int *cinfo = T.pair_colinfo + co;
+            const int ra = (li < nr) ? T.pair_rowmap[ro + li] : -1;
+            for (int t = tid; t < TNv; t += NT) {
+                s_cptr2[t] = (t < nc) ? cinfo[2 * t] : 0;
+                s_lead2[t] = (t < nc) ? cinfo[2 * t + 1] : nss;
+            }
+            __syncthreads();
+            ns_s = nss; lda_s = s_hdr[18];
+            Lrow = T.val + (((int64_t) s_hdr[21] << 32) | (uint32_t) s_hdr[20]) + max(ra, 0);
+            Uvs = T.val + (((int64_t) s_hdr[23] << 32) | (uint32_t) s_hdr[22]);
+            kbeg = s_hdr[19]; lrow_ok = ra >= 0;
+            cpS = s_cptr2; ldS = s_lead2;
+        } else if (src < nprev) {
             const int pj = 3 * k + (nprev - 1 - src);
             const int ks = T.fuse_prev[pj];
             const int nss = T.xsup[ks + 1] - T.xsup[ks];
