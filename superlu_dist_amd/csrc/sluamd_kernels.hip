@@ -1500,8 +1500,6 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const int lda = T.sn_nsupr[k];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(xsrc + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
-    __syncthreads();
     const int r = tid & 63, part = tid >> 6;
     const int row = T.sn_ldiag[k] + strip * 64 + r;
     const bool rvalid = row < lda;
@@ -1509,11 +1507,20 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     const int grow = (rvalid && part == 0) ? T.lrow[T.sn_lrow[k] + row] : 0;   // flat map: no walk over the slot's block descriptors
     const int cpp = (ns + NP - 1) / NP;           // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
+    // the thread's first batch of L (all of it for supernodes of <= 16 NP columns) goes in flight BEFORE x_k is staged: it does not depend
+    // on x, and on the levels where a workgroup's life is a chain of round trips this removes one of them
+    double lv0[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) lv0[u] = (rvalid && ka + u < kb) ? __builtin_nontemporal_load(L + (size_t) (ka + u) * lda) : 0.0;
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(xsrc + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
+    __syncthreads();
     for (int q = 0; q < nrhs; ++q) {
         const double *xq = xk + q * ns;
         double acc[4] = {0, 0, 0, 0};
         if (rvalid) {
-            int kk = ka;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 3] += lv0[u] * xq[min(ka + u, ns - 1)];     // lv0 is zero past kb
+            int kk = ka + 16;
             for (; kk + 16 <= kb; kk += 16) {
                 double lv[16];
 #pragma unroll
@@ -1566,6 +1573,21 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     }
     __syncthreads();
     const double *Uv = T.val + T.sn_uval[k];
+    // the wave's first four columns go in flight BEFORE the gather of x (they depend on the column maps only): one round trip less in the
+    // life of a workgroup on the levels where that is what a workgroup's life consists of
+    double uv0[4][RB];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+        const int c = wave * CPW + cc;
+        const bool cok = c < ncol;
+        const int ld = cok ? s_ld[c] : ns;
+        const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int i = lane + 64 * q;
+            uv0[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+        }
+    }
     for (int r = 0; r < nrhs; ++r) {
         if (tid < ncol) s_xc[tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
         __syncthreads();
@@ -1585,7 +1607,8 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
                         const int i = lane + 64 * q;
-                        uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+                        if (cb == 0) uv[cc][q] = uv0[cc][q];
+                        else uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
                     }
                 }
 #pragma unroll
@@ -1633,8 +1656,6 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = xin[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
-    __syncthreads();
     const int r = tid & 63, part = tid >> 6;
     const int row = strip * 64 + r;
     const bool rvalid = row < ns;
@@ -1643,11 +1664,18 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
     const int cpp = (c1 - c0 + NP - 1) / NP;
     const int ka = min(c1, c0 + part * cpp), kb = min(c1, ka + cpp);
     const double *Tr = Ti + row;
+    double tv0[16];                               // first batch of the inverse in flight before x_k is staged (as fwd_update_body)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tv0[u] = (rvalid && ka + u < kb) ? Tr[(size_t) (ka + u) * ns] : 0.0;
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = xin[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
+    __syncthreads();
     for (int q = 0; q < nrhs; ++q) {
         const double *xq = xk + q * ns;
         double acc[4] = {0, 0, 0, 0};
         if (rvalid) {
-            int kk = ka;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 3] += tv0[u] * xq[min(ka + u, ns - 1)];
+            int kk = ka + 16;
             for (; kk + 16 <= kb; kk += 16) {
                 double tv[16];
 #pragma unroll
