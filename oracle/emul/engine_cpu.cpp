@@ -615,17 +615,20 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
     emul_enqueue(s, [=] { impl::solve_diag(s, lower, T, nodes, nn, x, ldx, nrhs, max_nsupc); });
 }
 
-void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
+void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units,
+                const int4 *)      // unit records: the restatement reads the tables
 {
     emul_enqueue(s, [=] { impl::fwd_update(s, T, nodes, prefix, nn, nwork, xsrc, x, ldx, nrhs, max_nsupc, units); });
 }
 
-void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units)
+void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units,
+                const int4 *)
 {
     emul_enqueue(s, [=] { impl::bwd_update(s, T, nodes, prefix, nn, nwork, xcols, x, ldx, nrhs, max_nsupc, units); });
 }
 
-void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits, double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc)
+void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits, double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc,
+                const int4 *, const int4 *)
 {
     if (ndu + nunits <= 0) return;
     emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, max_nsupc); });

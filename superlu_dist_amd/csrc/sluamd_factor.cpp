@@ -563,13 +563,15 @@ static int solve_fwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
     double *w = H->d_w;
     // levels >= l0: the dataflow form (one persistent launch, LevelSched::cf_*); below it one launch pair per level
     const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
-    if (l0 > 0) eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[0], S.du_off[1] - S.du_off[0], nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0]);
+    const int4 *fr = S.d_fwd_recs, *dr = S.d_diag_recs;     // unit records (null on complex handles)
+    if (l0 > 0) eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[0], S.du_off[1] - S.du_off[0], nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0], dr ? dr + 2 * (size_t) S.du_off[0] : nullptr, nullptr);
     for (int l = 0; l < l0; ++l) {
         const int u0 = S.fu_off[2 * l], u1 = S.fu_off[2 * l + 1], u2 = S.fu_off[2 * l + 2];
         const int nd = (l + 1 < l0) ? S.du_off[l + 2] - S.du_off[l + 1] : 0;     // the diagonal solves of level l0 belong to the chain
         const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
-        eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, w, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0);
-        eng::sweep_step(s, true, T, S.d_diag_units + (nd ? S.du_off[l + 1] : 0), nd, S.d_fwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, mx);
+        eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, w, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0, fr ? fr + 2 * (size_t) u0 : nullptr);
+        eng::sweep_step(s, true, T, S.d_diag_units + (nd ? S.du_off[l + 1] : 0), nd, S.d_fwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, mx,
+                        dr ? dr + 2 * (size_t) (nd ? S.du_off[l + 1] : 0) : nullptr, fr ? fr + 2 * (size_t) u1 : nullptr);
         H->st.solve_launches += 2;
     }
     if (l0 < nl) {
@@ -590,6 +592,7 @@ static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
     const int nl = S.nlevels;
     if (nl == 0) return 0;
     double *w = H->d_w;
+    const int4 *br = S.d_bwd_recs, *dr = S.d_diag_recs;
     const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
     if (l0 < nl) {
         int mx = 0;
@@ -600,7 +603,7 @@ static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
         H->st.solve_launches += 1;
     } else {   // far chunks of the top level (columns of ancestors in other forests, solved before this sweep)
         const int u1 = S.bu_off[2 * (nl - 1) + 1], u2 = S.bu_off[2 * (nl - 1) + 2];
-        eng::sweep_step(s, false, T, nullptr, 0, S.d_bwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, S.max_nsupc[nl - 1]);
+        eng::sweep_step(s, false, T, nullptr, 0, S.d_bwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, S.max_nsupc[nl - 1], nullptr, br ? br + 2 * (size_t) u1 : nullptr);
         H->st.solve_launches += 1;
     }
     for (int l = l0 - 1; l >= 0; --l) {
@@ -608,8 +611,9 @@ static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
         const int nd = S.du_off[l + 1] - S.du_off[l];
         const int b1 = l > 0 ? S.bu_off[2 * (l - 1) + 1] : 0, b2 = l > 0 ? S.bu_off[2 * (l - 1) + 2] : 0;   // far chunks of level l-1: x of levels >= l+1 only
         const int mx = std::max(S.max_nsupc[l], l > 0 ? S.max_nsupc[l - 1] : 0);
-        eng::bwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, w, ldx, nrhs, S.max_nsupc[l], S.d_bwd_units + u0);
-        eng::sweep_step(s, false, T, S.d_diag_units + S.du_off[l], nd, S.d_bwd_units + b1, b2 - b1, d_x, w, ldx, nrhs, mx);
+        eng::bwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, w, ldx, nrhs, S.max_nsupc[l], S.d_bwd_units + u0, br ? br + 2 * (size_t) u0 : nullptr);
+        eng::sweep_step(s, false, T, S.d_diag_units + S.du_off[l], nd, S.d_bwd_units + b1, b2 - b1, d_x, w, ldx, nrhs, mx,
+                        dr ? dr + 2 * (size_t) S.du_off[l] : nullptr, br ? br + 2 * (size_t) b1 : nullptr);
         H->st.solve_launches += 2;
     }
     return 0;

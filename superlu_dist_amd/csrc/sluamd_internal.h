@@ -210,6 +210,10 @@ struct LevelSched {
     int *d_finv_prefix = nullptr, *d_zfwd_prefix = nullptr;
     int4 *d_ulist = nullptr;
     int2 *d_fwd_units = nullptr, *d_bwd_units = nullptr, *d_diag_units = nullptr;
+    // unit records of the 1 x 1 layer sweeps, two int4 per unit in the order of the unit lists: what a unit otherwise looks up in six tables
+    // behind its list entry (fwd / bwd_update_body, diag_strip_body)
+    std::vector<int4> fwd_recs, bwd_recs, diag_recs;
+    int4 *d_fwd_recs = nullptr, *d_bwd_recs = nullptr, *d_diag_recs = nullptr;
     int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
 };
 
@@ -339,14 +343,14 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
 // units != null: the launch runs the host-built (supernode, strip / chunk) list `units[0 .. nwork)` instead of the level's prefix arrays.
 // Two vectors (they may be the same one: XY layers, profiling): the update reads solved blocks from xsrc / xcols and subtracts from x
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs,
-                int max_nsupc, const int2 *units = nullptr);
+                int max_nsupc, const int2 *units = nullptr, const int4 *recs = nullptr);   // recs: unit records of the same list (LevelSched::fwd_recs)
 void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs,
-                int max_nsupc, const int2 *units = nullptr);
+                int max_nsupc, const int2 *units = nullptr, const int4 *recs = nullptr);
 // one link of a sweep on a 1 x 1 layer: the diagonal-solve strips `dunits` (supernode, 64-row strip; OUT OF PLACE: lower xa -> xb, upper
 // xb -> xa) + the update units `units` that do not feed them (lower: read xb, subtract from xa; upper: read xa, subtract from xb), one
 // launch (max_nsupc over everything in the launch)
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
-                double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc);
+                double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc, const int4 *drecs = nullptr, const int4 *urecs = nullptr);
 // dataflow sweep over a topologically ordered unit list (LevelSched::cf_* / cb_*): ONE persistent launch; `flags` zeroed on s first;
 // the same two vectors as sweep_step
 void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,

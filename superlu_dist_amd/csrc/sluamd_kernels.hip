@@ -1493,18 +1493,29 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
 // 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
 template <int NT, bool COH = false>
 __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, const double *xsrc /* solved x_k */, double *xdst /* lsum accumulators */,
-                                                int64_t ldx, int nrhs, double *xk /* ns x nrhs */)
+                                                int64_t ldx, int nrhs, double *xk /* ns x nrhs */, const int4 *rec = nullptr)
 {
     constexpr int NP = NT / 64;     // column slices
     __shared__ double s_red[NP][64 + 1];
-    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
-    const int lda = T.sn_nsupr[k];
+    // `rec` (1 x 1 layer sweeps): the unit's scalars in one 32-byte record written at plan time -- (first column, width, panel height, first
+    // row of the strip) + (offset of the strip's first L value, offset of its first entry in the flat row map) -- instead of six table
+    // lookups behind the unit list entry: the values and x_k go in flight one round trip earlier
+    int fst, ns, lda, row0;
+    int64_t loff, roff;
+    if (rec) {
+        const int4 a = rec[0], b = rec[1];
+        fst = a.x; ns = a.y; lda = a.z; row0 = a.w;
+        loff = ((int64_t) b.y << 32) | (uint32_t) b.x; roff = ((int64_t) b.w << 32) | (uint32_t) b.z;
+    } else {
+        fst = T.xsup[k]; ns = T.xsup[k + 1] - fst; lda = T.sn_nsupr[k]; row0 = T.sn_ldiag[k] + strip * 64;
+        loff = T.sn_lval[k] + row0; roff = T.sn_lrow[k] + row0;
+    }
     const int tid = threadIdx.x;
     const int r = tid & 63, part = tid >> 6;
-    const int row = T.sn_ldiag[k] + strip * 64 + r;
+    const int row = row0 + r;
     const bool rvalid = row < lda;
-    const double *L = T.val + T.sn_lval[k] + row;
-    const int grow = (rvalid && part == 0) ? T.lrow[T.sn_lrow[k] + row] : 0;   // flat map: no walk over the slot's block descriptors
+    const double *L = T.val + loff + r;
+    const int grow = (rvalid && part == 0) ? T.lrow[roff + r] : 0;   // flat map: no walk over the slot's block descriptors
     const int cpp = (ns + NP - 1) / NP;           // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
     // the thread's first batch of L (all of it for supernodes of <= 16 NP columns) goes in flight BEFORE x_k is staged: it does not depend
@@ -1544,9 +1555,11 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                   int nn, const double *xsrc, double *xdst, int64_t ldx, int nrhs, const int2 *__restrict__ units)
+                                                   int nn, const double *xsrc, double *xdst, int64_t ldx, int nrhs, const int2 *__restrict__ units,
+                                                   const int4 *__restrict__ recs)
 {
     extern __shared__ double xk[];  // ns x nrhs
+    if (recs) { fwd_update_body<NT>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
     int k, strip;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; strip = u.y; }   // host-built (supernode, strip) list of one launch
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
@@ -1558,21 +1571,29 @@ __global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__res
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
 template <int NT, bool COH = false>   // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block)
 __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int chunk, const double *xcols /* solved x of the chunk's columns */,
-                                                double *xrows /* accumulators of x_k */, int64_t ldx, int nrhs)
+                                                double *xrows /* accumulators of x_k */, int64_t ldx, int nrhs, const int4 *rec = nullptr)
 {
     constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = (NT == 1024) ? 4 : 1;
     __shared__ int s_cp[64], s_ld[64], s_gc[64];
     __shared__ double s_xc[64];
     __shared__ double s_red[NWV][64 * RB];
-    const int fst = T.xsup[k], klst = T.xsup[k + 1], ns = klst - fst;
-    const int ncol = min(64, T.sn_ncolu[k] - chunk * 64);
+    int fst, ns, ncol;          // `rec`: (first column, width, columns of this chunk) + (first entry in the flat column maps, offset of U(k,:)) as in fwd_update_body
+    int64_t ci0, uoff;
+    if (rec) {
+        const int4 a = rec[0], b = rec[1];
+        fst = a.x; ns = a.y; ncol = a.z;
+        ci0 = ((int64_t) b.y << 32) | (uint32_t) b.x; uoff = ((int64_t) b.w << 32) | (uint32_t) b.z;
+    } else {
+        fst = T.xsup[k]; ns = T.xsup[k + 1] - fst; ncol = min(64, T.sn_ncolu[k] - chunk * 64);
+        ci0 = T.sn_ucol[k] + chunk * 64; uoff = T.sn_uval[k];
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < ncol) {
-        const int64_t ci = T.sn_ucol[k] + chunk * 64 + tid;
+        const int64_t ci = ci0 + tid;
         s_ld[tid] = T.ucol_ld[ci]; s_cp[tid] = T.ucol_cp[ci]; s_gc[tid] = T.ucol_gc[ci];
     }
     __syncthreads();
-    const double *Uv = T.val + T.sn_uval[k];
+    const double *Uv = T.val + uoff;
     // the wave's first four columns go in flight BEFORE the gather of x (they depend on the column maps only): one round trip less in the
     // life of a workgroup on the levels where that is what a workgroup's life consists of
     double uv0[4][RB];
@@ -1635,8 +1656,10 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
-                                                   int nn, const double *xcols, double *xrows, int64_t ldx, int nrhs, const int2 *__restrict__ units)
+                                                   int nn, const double *xcols, double *xrows, int64_t ldx, int nrhs, const int2 *__restrict__ units,
+                                                   const int4 *__restrict__ recs)
 {
+    if (recs) { bwd_update_body<NT>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
     int k, chunk;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; chunk = u.y; }
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
@@ -1649,12 +1672,21 @@ __global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__res
 // takes.  Independent only because input and output are different vectors (LevelSched sweeps ping-pong between x and a work vector).
 template <bool LOWER, int NT>
 __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int strip, const double *xin, double *xout, int64_t ldx, int nrhs,
-                                                double *xk /* ns x nrhs */)
+                                                double *xk /* ns x nrhs */, const int4 *rec = nullptr)
 {
     constexpr int NP = NT / 64;     // column slices
     __shared__ double s_dred[NP][64 + 1];
-    const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
-    const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
+    int fst, ns;                // `rec`: (first column, width, strip) + (offset of Linv, offset of Uinv)
+    int64_t ioff;
+    if (rec) {
+        const int4 a = rec[0], b = rec[1];
+        fst = a.x; ns = a.y; strip = a.z;
+        ioff = LOWER ? (((int64_t) b.y << 32) | (uint32_t) b.x) : (((int64_t) b.w << 32) | (uint32_t) b.z);
+    } else {
+        fst = T.xsup[k]; ns = T.xsup[k + 1] - fst;
+        ioff = T.sn_inv[k] + (LOWER ? 0 : (int64_t) ns * ns);
+    }
+    const double *Ti = T.inv + ioff;
     const int tid = threadIdx.x;
     const int r = tid & 63, part = tid >> 6;
     const int row = strip * 64 + r;
@@ -1704,14 +1736,24 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
 // xb (= the forward solution minus the updates) and the final x_k goes to xa (updates read xa, subtract from xb).
 template <bool LOWER, int NT>
 __global__ __launch_bounds__(NT) void k_sweep(DevTables T, const int2 *__restrict__ dunits, int ndu, const int2 *__restrict__ units,
-                                              double *xa, double *xb, int64_t ldx, int nrhs)
+                                              double *xa, double *xb, int64_t ldx, int nrhs, const int4 *__restrict__ drecs, const int4 *__restrict__ urecs)
 {
     extern __shared__ double dyn[];  // max_nsupc x nrhs
     const int bid = blockIdx.x;
     if (bid < ndu) {
+        if (drecs) {     // unit records (same order as dunits)
+            if (LOWER) diag_strip_body<true, NT>(T, 0, 0, xa, xb, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
+            else diag_strip_body<false, NT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
+            return;
+        }
         const int2 d = dunits[bid];
         if (LOWER) diag_strip_body<true, NT>(T, d.x, d.y, xa, xb, ldx, nrhs, dyn);
         else diag_strip_body<false, NT>(T, d.x, d.y, xb, xa, ldx, nrhs, dyn);
+        return;
+    }
+    if (urecs) {
+        if (LOWER) fwd_update_body<NT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - ndu));
+        else bwd_update_body<NT>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - ndu));
         return;
     }
     const int2 u = units[bid - ndu];
@@ -1982,32 +2024,32 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
 }
 
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int mx,
-                const int2 *units)
+                const int2 *units, const int4 *recs)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units);
-    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units);
+    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs);
+    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs);
 }
 
 void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int mx,
-                const int2 *units)
+                const int2 *units, const int4 *recs)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units);
-    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units);
+    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs);
+    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs);
 }
 
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
-                double *xa, double *xb, int64_t ldx, int nrhs, int mx)
+                double *xa, double *xb, int64_t ldx, int nrhs, int mx, const int4 *drecs, const int4 *urecs)
 {
     if (ndu + nunits <= 0) return;
     const size_t lds = (size_t) mx * nrhs * sizeof(double);
     if (mx <= 64) {
-        if (lower) hipLaunchKernelGGL((k_sweep<true, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
-        else hipLaunchKernelGGL((k_sweep<false, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
+        if (lower) hipLaunchKernelGGL((k_sweep<true, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
+        else hipLaunchKernelGGL((k_sweep<false, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
     } else {
-        if (lower) hipLaunchKernelGGL((k_sweep<true, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
-        else hipLaunchKernelGGL((k_sweep<false, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs);
+        if (lower) hipLaunchKernelGGL((k_sweep<true, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
+        else hipLaunchKernelGGL((k_sweep<false, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
     }
 }
 

@@ -536,7 +536,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     build_tile_lists(t, lvl, H.h_defer, S);
 }
 
-static int upload_schedule(Handle &H, LevelSched &S)
+static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
 {
     if (upload(H.d_misc, S.nodes, &S.d_nodes)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.tile_prefix, &S.d_tile_prefix)) return SLUAMD_EHIP;
@@ -555,6 +555,32 @@ static int upload_schedule(Handle &H, LevelSched &S)
     if (upload(H.d_misc, S.fwd_units, &S.d_fwd_units)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.bwd_units, &S.d_bwd_units)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.diag_units, &S.d_diag_units)) return SLUAMD_EHIP;
+    if (!H.z) {
+        // unit records (k_sweep / k_fwd_update / k_bwd_update): the scalars of every unit in the order of the unit lists
+        const HostStruct &hs = H.hs;
+        auto lohi = [](int64_t v, int &lo, int &hi) { lo = (int) (uint32_t) v; hi = (int) (v >> 32); };
+        S.fwd_recs.resize(2 * S.fwd_units.size()); S.bwd_recs.resize(2 * S.bwd_units.size()); S.diag_recs.resize(2 * S.diag_units.size());
+        for (size_t u = 0; u < S.fwd_units.size(); ++u) {
+            const int k = S.fwd_units[u].x, strip = S.fwd_units[u].y;
+            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst, row0 = t.sn_ldiag[k] + strip * 64;
+            int4 b; lohi(t.sn_lval[k] + row0, b.x, b.y); lohi(t.sn_lrow[k] + row0, b.z, b.w);
+            S.fwd_recs[2 * u] = make_int4(fst, ns, t.sn_nsupr[k], row0); S.fwd_recs[2 * u + 1] = b;
+        }
+        for (size_t u = 0; u < S.bwd_units.size(); ++u) {
+            const int k = S.bwd_units[u].x, chunk = S.bwd_units[u].y;
+            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst;
+            int4 b; lohi(t.sn_ucol[k] + (int64_t) chunk * 64, b.x, b.y); lohi(t.sn_uval[k], b.z, b.w);
+            S.bwd_recs[2 * u] = make_int4(fst, ns, std::min(64, t.sn_ncolu[k] - chunk * 64), 0); S.bwd_recs[2 * u + 1] = b;
+        }
+        for (size_t u = 0; u < S.diag_units.size(); ++u) {
+            const int k = S.diag_units[u].x, strip = S.diag_units[u].y;
+            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst;
+            int4 b; lohi(t.sn_inv[k], b.x, b.y); lohi(t.sn_inv[k] + (int64_t) ns * ns, b.z, b.w);
+            S.diag_recs[2 * u] = make_int4(fst, ns, strip, 0); S.diag_recs[2 * u + 1] = b;
+        }
+        if (upload(H.d_misc, S.fwd_recs, &S.d_fwd_recs) || upload(H.d_misc, S.bwd_recs, &S.d_bwd_recs) || upload(H.d_misc, S.diag_recs, &S.d_diag_recs)) return SLUAMD_EHIP;
+        std::vector<int4>().swap(S.fwd_recs); std::vector<int4>().swap(S.bwd_recs); std::vector<int4>().swap(S.diag_recs);
+    }
     if (S.chain_l0 >= 0) {
         if (upload(H.d_misc, S.cf_units, &S.d_cf_units) || upload(H.d_misc, S.cf_waits, &S.d_cf_waits) || upload(H.d_misc, S.cf_sigs, &S.d_cf_sigs)) return SLUAMD_EHIP;
         if (upload(H.d_misc, S.cb_units, &S.d_cb_units) || upload(H.d_misc, S.cb_waits, &S.d_cb_waits) || upload(H.d_misc, S.cb_sigs, &S.d_cb_sigs)) return SLUAMD_EHIP;
@@ -862,7 +888,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4) UP(rt_info, t.rt_info, int2) UP(ct_info, t.ct_info, int4)
     UP(lrow, t.lrow, int) UP(sn_lrow, t.sn_lrow, int64_t) UP(ucol_cp, t.ucol_cp, int) UP(ucol_ld, t.ucol_ld, int) UP(ucol_gc, t.ucol_gc, int) UP(sn_ucol, t.sn_ucol, int64_t)
 #undef UP
-    for (auto &S : H->sched) if (upload_schedule(*H, S)) return SLUAMD_EHIP;
+    for (auto &S : H->sched) if (upload_schedule(*H, S, t)) return SLUAMD_EHIP;
     if (H->fused_pairs) {
         int *p0, *p1, *p2, *p3, *p4, *p5;
         if (upload(K, H->h_fuse_prev, &p0) || upload(K, H->h_defer, &p1) || upload(K, H->h_pair_roff, &p2) ||
