@@ -2160,6 +2160,11 @@ void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes
 {
     if (nn <= 0) return;
     const size_t lds = (size_t) mx * nrhs * 16;
+    if (mx <= 64) {     // one wave per supernode in registers
+        if (lower) hipLaunchKernelGGL(kz_solve_diag_wave<true>, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, reinterpret_cast<zc *>(x), ldx, nrhs);
+        else hipLaunchKernelGGL(kz_solve_diag_wave<false>, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, reinterpret_cast<zc *>(x), ldx, nrhs);
+        return;
+    }
     if (lower) hipLaunchKernelGGL(kz_solve_diag<true>, dim3(nn), dim3(256), lds, s, T, nodes, reinterpret_cast<zc *>(x), ldx, nrhs);
     else hipLaunchKernelGGL(kz_solve_diag<false>, dim3(nn), dim3(256), lds, s, T, nodes, reinterpret_cast<zc *>(x), ldx, nrhs);
 }
