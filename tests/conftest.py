@@ -34,8 +34,11 @@ def emul():
     import ctypes, subprocess
     from superlu_dist_amd import _lib
     so = os.path.join(ROOT, "oracle", "libsluamd_emul.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsluamd_emul.so"])
+    if not getattr(emul, "_made", False):
+        # once per session, and not only when the file is missing: a stale CPU test build would test yesterday's host sources (make is a
+        # no-op when the library is newer than every source it is built from)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libsluamd_emul.so"])
+        emul._made = True
     saved = _lib._lib
     _lib._lib = _lib.bind(ctypes.CDLL(so))
     yield _lib._lib

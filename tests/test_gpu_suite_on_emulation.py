@@ -22,8 +22,7 @@ def _mpirun(cmd, env, cwd):
 @pytest.mark.parametrize("sched", ["", "1,7"])
 def test_gpu_test_files_against_the_emulation_library(sched):
     so = os.path.join(ROOT, "oracle", "libsluamd_emul.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libsluamd_emul.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libsluamd_emul.so"])      # no-op when up to date; never a stale build
     env = dict(os.environ, SLUAMD_LIB=so)
     env.pop("SLUAMD_EMUL_SCHED", None)
     if sched:
