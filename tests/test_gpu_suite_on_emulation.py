@@ -7,7 +7,7 @@ import os, subprocess, sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["test_gpu_parity.py", "test_gpu_edge_cases.py", "test_gpu_refine.py", "test_gpu_grid.py"]
+FILES = ["test_gpu_parity.py", "test_gpu_edge_cases.py", "test_gpu_refine.py", "test_gpu_grid.py", "test_gpu_fuzz.py"]
 
 
 def _mpirun(cmd, env, cwd):
