@@ -66,7 +66,60 @@ def build_problem(N, leaf, workload="poisson3d"):
     return n, rp, ci, v, perm, xt, b
 
 
-def cpu_baseline(N, leaf, relax, maxsup, want_reference=True):
+def cpu_baseline_grid(N, leaf, relax, maxsup, ref_bin, host_cores):
+    """SURVEY 8(d)'s second CPU leg: the real reference on a 2 x 2 x 2 process grid, 8 MPI ranks x host_cores/8 OpenMP threads (capped at 16:
+    the reference stops scaling past ~8 threads per rank, see the 1-rank sweep), every rank pinned to its own contiguous core range.
+    RowPerm stays at the reference's default (LargeDiag_MC64: the identity on this diagonally dominant matrix; v9.2.1's pdgssvx3d fails in
+    symbfact with NOROWPERM on a 2 x 2 x 2 grid), everything else as the 1-rank leg.  Timer = stat.utime[FACT] of rank 0 (pdgstrf3d.c:331,395)."""
+    import shutil
+    from superlu_dist_amd import driver, matgen
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        return {"error": "mpiexec not available"}
+    n, rp, ci, v, perm, xt, b = build_problem(N, leaf)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+    flops = symb.flops
+    symb.free()
+    th = max(1, min(16, host_cores // 8))
+    with tempfile.TemporaryDirectory() as tmp:
+        mpath = os.path.join(tmp, "a.dat"); ppath = os.path.join(tmp, "a.perm")
+        matgen.write_triplet_dat(mpath, n, rp, ci, v)
+        np.savetxt(ppath, perm, fmt="%d")
+        env = dict(os.environ, OMP_NUM_THREADS=str(th), SUPERLU_MAXSUP=str(maxsup), SUPERLU_RELAX=str(relax))
+        env.pop("LD_LIBRARY_PATH", None)
+        args = f"{ref_bin} -r 2 -c 2 -d 2 -e 0 -p 1 -i 0 -Q 1 -P {ppath} -o none {mpath}"
+        allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(host_cores))
+        pinned = bool(shutil.which("taskset")) and len(allowed) >= 8 * th
+        if pinned:   # rank q -> the q-th run of `th` CPUs this process may use: OpenMP's close / cores placement then stays inside the rank's own range
+            env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
+            wrap = os.path.join(tmp, "rank.sh")
+            with open(wrap, "w") as f:
+                f.write("#!/bin/sh\ncase $PMI_RANK in\n")
+                for q in range(8):
+                    f.write(f"{q}) exec taskset -c {','.join(str(c) for c in allowed[q * th:(q + 1) * th])} {args};;\n")
+                f.write(f"*) exec {args};;\nesac\n")
+            os.chmod(wrap, 0o755)
+            cmd = [mpiexec, "-n", "8", wrap]
+        else:
+            cmd = [mpiexec, "-n", "8"] + args.split()
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+        except subprocess.TimeoutExpired:
+            return {"error": "timeout 150 s", "sample": f"{N}^3", "ranks": 8, "threads_per_rank": th}
+        wall = time.perf_counter() - t0
+    line = [l for l in r.stdout.splitlines() if l.startswith("REFTIMES")]
+    if r.returncode != 0 or not line:
+        return {"error": ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-200:]}
+    tok = line[0].split()
+    res = [l for l in r.stdout.splitlines() if l.startswith("RESIDUAL")]
+    return {"kind": "reference", "grid": "2x2x2", "ranks": 8, "threads_per_rank": th, "cores": 8 * th, "pinned": pinned,
+            "sample": f"{N}^3 7-pt Poisson, same ND perm_c/relax/maxsup, 2x2x2 grid (mpiexec -n 8), nrhs=1", "flops": flops,
+            "factor_s": float(tok[4]), "solve_s": float(tok[7]), "value": flops / float(tok[4]) / 1e9, "unit": "GFLOP/s",
+            "reference_ops_FACT": float(tok[10]), "residual": float(res[0].split()[1]) if res else None, "wall_s": wall}
+
+
+def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0):
     """Time the CPU leg on a bounded sample (N^3 Poisson, same ordering / supernode parameters).
     kind = "reference": the real reference's pdgstrf3d (oracle/_ref/slu_ref_dump, OpenMP, internal CBLAS)
     kind = "port":      oracle/slu_oracle.c (our CPU restatement, OpenMP over (L block, U block) pairs)."""
@@ -149,6 +202,11 @@ def cpu_baseline(N, leaf, relax, maxsup, want_reference=True):
                                         "hours at this rate); supernodes are wider there, so its GFLOP/s would be somewhat higher"})
         except Exception as e:  # the reference leg is best-effort; the port leg above stands
             out["reference_error"] = str(e)[:200]
+        if grid_n:
+            try:
+                out["grid_2x2x2"] = cpu_baseline_grid(grid_n, leaf, relax, maxsup, ref_bin, host_cores)
+            except Exception as e:
+                out["grid_2x2x2"] = {"error": str(e)[:200]}
     return out
 
 
@@ -170,6 +228,10 @@ def main():
     ap.add_argument("--no-scaling-point", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs4", action="store_true",
+                    help="skip the `configs4` block of the default line (BASELINE.json configs[4]: complex16 1000 x 1000 grid operator, 5 steps)")
+    ap.add_argument("--cpu-grid-n", type=int, default=60,
+                    help="grid side of the 2x2x2 leg of the CPU baseline (8 MPI ranks x host_cores/8 threads of the real reference); 0 = skip")
     ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d", "audikw_like"],
                     help="poisson3d = BASELINE configs[1] (default, the metric's config); zgrid2d = configs[4] family "
                          "(complex16 2-D grid operator, use --n 1000); audikw_like = configs[3] stand-in (use --n 68)")
@@ -218,12 +280,12 @@ def main():
     if L.sluamd_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
 
-    def measure(N, steps, warm, workload):
+    def measure(N, steps, warm, workload, maxsup=None):
         """Build the N-sided problem, factor + solve `steps` times after `warm` warm-up steps; returns the measurements and keeps the
         handle alive for the caller's extra passes (profile, refinement)."""
         t_setup = time.perf_counter()
         n, rp, ci, v, perm, xt, b = build_problem(N, args.leaf, workload)
-        symb = driver.Symbolic(n, rp, ci, perm, relax=args.relax, maxsup=args.maxsup)
+        symb = driver.Symbolic(n, rp, ci, perm, relax=args.relax, maxsup=maxsup or args.maxsup)
         grid = (1, 1, 1)
         if world == 1:
             if (symb.nnzL + symb.nnzU) * (16 if workload == "zgrid2d" else 8) * 1.06 > HBM_BYTES:
@@ -443,9 +505,43 @@ def main():
         except Exception as e:      # e.g. not enough HBM on this rank: reported, the headline line stands
             out["scaling_point"] = {"error": str(e)[:300]}
             h, symb = None, None
+    # ---- configs4: BASELINE.json configs[4] (pzdrive3d complex16, cg20 family scaled 50x per grid side = 1000 x 1000 5-point complex grid
+    # operator, 1 GPU) measured by the SAME default command, so that the driver's record carries it:
+    # 5 timed steps after 2 warm-up steps, MFMA fraction of k_schur<Z> from one extra profiled factorisation, HBM fraction of the solve
+    if world == 1 and args.workload == "poisson3d" and not args.no_configs4:
+        if h is not None:
+            h.destroy(); symb.free(); h, symb = None, None
+        try:
+            Z4 = measure(1000, 5, 2, "zgrid2d", maxsup=64)
+            hz = Z4["h"]
+            hz.set_profile(True); hz.reset_values(); hz.pdgstrf3d(Z4["thresh"]); stpz = hz.stats(); hz.set_profile(False)
+            stz = hz.stats()
+            Fz = stz["flops_schur_exact"] + stz["flops_panel"]
+            z_tf = stz["flops_schur_exact"] / (stpz["t_schur_ms"] * 1e-3) / 1e12 if stpz["t_schur_ms"] > 0 else 0.0
+            z_gbs = 16.0 * float(stz["nnz_L"] + stz["nnz_U"]) / (np.mean(Z4["solve_ms"]) * 1e-3) / 1e9
+            out["configs4"] = {"workload": "pzdrive3d-equivalent on a 1000x1000 5-point complex16 grid operator (cg20 family, grid side x 50), 1x1x1 grid, "
+                                           f"ND perm_c (leaf {args.leaf}), relax {args.relax}, maxsup 64, nrhs 1",
+                               "dtype": "c128", "n": Z4["n"], "nnz_LU": int(stz["nnz_L"] + stz["nnz_U"]), "flops_per_step": Fz, "steps": Z4["steps"], "warmup": 2,
+                               "value": Fz * Z4["steps"] / Z4["elapsed"] / 1e9, "unit": "GFLOP/s", "ms_per_step": 1e3 * Z4["elapsed"] / Z4["steps"],
+                               "factor_ms": float(np.mean(Z4["fact_ms"])), "solve_ms": float(np.mean(Z4["solve_ms"])),
+                               "factor_gflops_kernel_only": Fz / (np.mean(Z4["fact_ms"]) * 1e-3) / 1e9,
+                               "residual": Z4["res"], "max_abs_err_vs_xtrue": Z4["err"], "info": int(Z4["info"]),
+                               "launches_per_factor": stz["num_launches"], "levels": stz["num_levels"],
+                               "roofline": {"bound": "mfma", "kernel": "k_schur<Z> (real embedding of the complex update on the fp64 MFMA kernel)",
+                                            "achieved": z_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": z_tf / PEAK_FP64_MFMA_TFLOPS,
+                                            "schur_ms": stpz["t_schur_ms"], "panel_ms": stpz["t_panel_ms"], "launches": int(stpz["schur_launches"])},
+                               "roofline_solve": {"bound": "hbm", "achieved": z_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": z_gbs / PEAK_HBM_GBS,
+                                                  "algorithmic_bytes_per_solve": 16.0 * float(stz["nnz_L"] + stz["nnz_U"])}}
+            hz.destroy(); Z4["symb"].free()
+            if Z4["res"] > 1e-10:
+                raise SystemExit(f"bench.py: configs4 residual {Z4['res']:.3e} exceeds 1e-10")
+        except SystemExit:
+            raise
+        except Exception as e:
+            out["configs4"] = {"error": str(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "poisson3d":
         try:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.leaf, args.relax, args.maxsup)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.leaf, args.relax, args.maxsup, grid_n=args.cpu_grid_n)
         except Exception as e:
             out["cpu_baseline"] = {"error": str(e)[:300]}
     if rank == 0:

@@ -892,6 +892,7 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
     if (rc) return rc;
     hipStream_t s = H->stream;
     const int ch = max_rhs_chunk(H);
+    H->st.solve_launches = 0;     // launches of THIS solve (the grid sweeps only ever add)
     // complex16: the exchanges see the right-hand sides as real arrays of 2 n rows (run lists in doubles, leading dimension ldxd);
     // the sweeps get the complex view (ldx)
     const int vs = H->z ? 2 : 1;
@@ -923,11 +924,13 @@ int run_solve_dev(Handle *H, double *d_x, int64_t ldx, int nrhs)
 // ================================================================================================
 //        distributed right-hand side at the solve boundary: pdReDistribute3d_B_to_X / X_to_B
 // ================================================================================================
-static uint64_t hash_perm(const int *perm, int64_t n)
+// the plan is keyed by the permutations THEMSELVES (kept with the plan and compared element by element: a hash could collide and
+// silently reuse the wrong route)
+static bool same_perm(const std::vector<int> &kept, bool kept_null, const int *perm, int64_t n)
 {
-    uint64_t h = 1469598103934665603ull;
-    if (perm) for (int64_t i = 0; i < n; ++i) { h ^= (uint32_t) perm[i]; h *= 1099511628211ull; }
-    return h;
+    if (kept_null != (perm == nullptr)) return false;
+    if (!perm) return true;
+    return (int64_t) kept.size() == n && std::memcmp(kept.data(), perm, sizeof(int) * (size_t) n) == 0;
 }
 
 static void free_dist_plan(Handle *H)
@@ -1005,8 +1008,10 @@ static int build_dist_plan(Handle *H, int64_t m_loc, int64_t fst_row, const int 
     const int ovs = H->z ? 2 : 1;
     for (int p = 0; p < P; ++p)
         for (auto &r : H->owner_runs[p].runs) for (int i = r.first / ovs; i < (r.first + r.second) / ovs; ++i) owner[i] = p;
-    D.hash_in = hash_perm(perm_in, n); D.hash_out = hash_perm(perm_out, n);
-    D.same = D.hash_in == D.hash_out && (!perm_in) == (!perm_out);
+    D.null_in = !perm_in; D.null_out = !perm_out;
+    if (perm_in) D.perm_in.assign(perm_in, perm_in + n);
+    if (perm_out) D.perm_out.assign(perm_out, perm_out + n);
+    D.same = same_perm(D.perm_in, D.null_in, perm_out, n);
     if ((rc = build_route(H, src_rank, owner, m_loc, fst_row, perm_in, D.in, D.bufs))) return rc;
     if (!D.same && (rc = build_route(H, src_rank, owner, m_loc, fst_row, perm_out, D.out, D.bufs))) return rc;
     D.m_loc = m_loc; D.fst_row = fst_row; D.ready = true;
@@ -1063,10 +1068,16 @@ int run_solve_dist(Handle *H, double *d_b, int64_t ldb, int nrhs, int64_t m_loc,
     if (g.size() > 1) { if ((rc = grid_solve_checks(H))) return rc; }
     else if (!H->z && (rc = ensure_inv(H))) return rc;
     const int vs = H->z ? 2 : 1;      // d_b, H->d_x: values of vs doubles; ldb in values
-    if (!H->dist.ready || H->dist.m_loc != m_loc || H->dist.fst_row != fst_row || H->dist.hash_in != hash_perm(perm, H->hs.n) ||
-        H->dist.hash_out != hash_perm(perm_out, H->hs.n))
-        if ((rc = build_dist_plan(H, m_loc, fst_row, perm, perm_out))) return rc;
     hipStream_t s = H->stream;
+    {
+        // build_dist_plan is COLLECTIVE (it exchanges every rank's row range): the decision to rebuild must be too -- a rank whose own
+        // range and permutations are unchanged still has to take part when a peer's partition of B changed
+        int keep[1] = {(H->dist.ready && H->dist.m_loc == m_loc && H->dist.fst_row == fst_row && same_perm(H->dist.perm_in, H->dist.null_in, perm, H->hs.n) &&
+                        same_perm(H->dist.perm_out, H->dist.null_out, perm_out, H->hs.n)) ? 1 : 0};
+        if (g.size() > 1 && (rc = H->comm->allreduce_min(keep, 1, s))) return rc;
+        if (!keep[0] && (rc = build_dist_plan(H, m_loc, fst_row, perm, perm_out))) return rc;
+    }
+    H->st.solve_launches = 0;
     const int64_t n = H->hs.n;
     const int ch = max_rhs_chunk(H);
     const int64_t need = n * std::min(ch, nrhs) * vs;

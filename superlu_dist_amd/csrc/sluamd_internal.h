@@ -309,7 +309,8 @@ struct Handle {
     };
     struct DistPlan {
         bool ready = false, same = false;           // same: perm_out == perm_in (route_out unused)
-        int64_t m_loc = -1, fst_row = -1; uint64_t hash_in = 0, hash_out = 0;
+        int64_t m_loc = -1, fst_row = -1;
+        std::vector<int> perm_in, perm_out; bool null_in = true, null_out = true;   // the permutations the routes were built for (compared element by element)
         DistRoute in, out;                          // B -> x through perm_in, x -> B through perm_out
         std::vector<void *> bufs;                   // device allocations of this plan
     } dist;

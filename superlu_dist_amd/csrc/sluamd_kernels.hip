@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         __syncthreads();
         if (dblk == -2) dblk = s_dinfo[0];
         has_dst = dblk >= 0;
-        if (!has_dst && tid == 0) atomicAdd(&info[2], 1);
+        if (MM != 1 && !has_dst && tid == 0) atomicAdd(&info[2], 1);     // (the plan-time build pass only writes records: the factorisation's pass counts)
         // destination block: (row offset inside the panel, its row ids, its row count) of L(ib, jb), or the index position of U(ib, jb)
         int di0 = 0, di1 = 0, di2 = 0;
         int64_t dbase = 0;

@@ -561,14 +561,16 @@ extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const slua
         const int id = next_part++;
         for (int v : V) part[v] = id;
         if ((int) V.size() <= leaf) { number(V); continue; }
-        // first connected component (the others go back on the stack as they are)
+        // disconnected set: label ALL its connected components in one sweep (one BFS each, every vertex visited once -- peeling one
+        // component per iteration and rescanning the rest costs O(|V| * #components) on block-diagonal inputs) and push them
+        // in reverse discovery order, so that they are dissected in discovery order as before
         int nl = bfs(V[0], id);
         if (queue.size() < V.size()) {
-            Job rest, comp;
-            comp.verts = queue;
-            for (int v : V) if (level[v] < 0) rest.verts.push_back(v);
-            for (int v : queue) level[v] = -1;
-            stack.push_back(std::move(rest)); stack.push_back(std::move(comp));
+            std::vector<Job> comps;
+            { Job c; c.verts = queue; comps.push_back(std::move(c)); }
+            for (int v : V) if (level[v] < 0) { bfs(v, id); Job c; c.verts = queue; comps.push_back(std::move(c)); }
+            for (int v : V) level[v] = -1;
+            for (size_t q = comps.size(); q-- > 0;) stack.push_back(std::move(comps[q]));
             continue;
         }
         // pseudo-peripheral root: restart from a vertex of the last level while the level structure gets deeper

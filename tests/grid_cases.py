@@ -165,6 +165,15 @@ def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, 
         xr = h.pdgstrs3d_dist(b[f0:f1, :], f0, symb.perm_c, perm_out=None)      # the reference's convention: rows of the PERMUTED solution
         if f1 > f0:
             assert np.abs(xr - y[f0:f1, :]).max() <= 1e-12 * np.abs(y).max()
+        if nl0 >= 2:
+            # B re-partitioned between two solves on the same handle: only the boundary between ranks 0 and 1 moves, so every other rank
+            # (the rest of layer 0, all of the layers above) sees an unchanged (m_loc, fst_row, perm) -- the decision to rebuild the routing
+            # plan must be collective all the same (a rank that skipped the rebuild left its peers waiting in the exchange)
+            cuts2 = cuts.copy(); cuts2[1] = min(cuts2[1] + 5, cuts2[2])
+            g0, g1 = (int(cuts2[rank]), int(cuts2[rank + 1])) if rank < nl0 else (0, 0)
+            xl2 = h.pdgstrs3d_dist(b[g0:g1, :], g0, symb.perm_c)
+            if g1 > g0:
+                assert np.abs(xl2 - y[symb.perm_c, :][g0:g1, :]).max() <= 1e-12 * np.abs(y).max()
         if refactor:                    # device-side re-distribution + second factorisation reproduce the solution
             h.reset_values()
             assert h.pdgstrf3d(0.0) == 0

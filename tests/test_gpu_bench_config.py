@@ -37,3 +37,34 @@ def test_benched_configuration_100_cubed():
     st = h.stats()
     assert st["tiny_pivots"] == 0
     h.destroy(); symb.free()
+
+
+def test_configs4_complex16_1000_squared():
+    """BASELINE.json configs[4] at its stated size (pzdrive3d complex16, the cg20 grid operator with the grid side scaled 50x = 1000 x 1000
+    5-point complex operator, n = 10^6, maxsup 64 as bench.py's `configs4` block runs it; reference path SRC/complex16/pzgstrf3d.c,
+    pzgstrs3d.c): the oracle cannot run it in seconds, so the size-independent properties -- residual on the original system < 1e-10,
+    x against xtrue, a second factorisation after the device-side re-distribution reproduces the solution to summation-order accuracy,
+    info == 0 and no tiny pivots."""
+    N = 1000
+    n, rp, ci, v = matgen.poisson3d(0, N, N, 1)
+    v = matgen.complex_shift(v, rp, ci, seed=20)
+    perm = matgen.nd_perm_grid3d(N, N, 1, leaf=64)
+    xt = np.where((np.arange(n) % 2) == 1, 1.0, -1.0)[:, None].astype(np.complex128)
+    b = matgen.csr_matvec(n, rp, ci, v, xt)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=64)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    assert h.z
+    thresh = driver.pivot_thresh(n, rp, ci, np.abs(v))
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    xs = []
+    for rep in range(2):
+        if rep:
+            h.reset_values()
+        assert h.pdgstrf3d(thresh) == 0
+        x = h.pdgstrs3d(xp)[symb.perm_c, :]
+        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
+        assert np.abs(x - xt).max() < 1e-9
+        xs.append(x)
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-11
+    assert h.stats()["tiny_pivots"] == 0
+    h.destroy(); symb.free()

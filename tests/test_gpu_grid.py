@@ -80,8 +80,8 @@ def test_rccl_transport_two_ranks(tmp_path):
     """Direct RCCL transport with two ranks.  One GPU per rank is RCCL's contract: on a one-GPU box ncclCommInitRank refuses the
     second rank ("Duplicate GPU detected") and ONLY that is a skip -- once the communicator exists, any failure or hang of the
     exchanges is a failure of this test.  With two or more GPUs visible the test must pass."""
-    import torch
-    ngpu = torch.cuda.device_count()
+    from superlu_dist_amd import _lib
+    ngpu = _lib.load().sluamd_device_count()     # the library's own count: no torch needed to decide (ADVICE r3)
     extra = ["--transport", "rccl"] + (["--one-gpu-per-rank"] if ngpu >= 2 else [])
     try:
         r = _launch(2, (1, 1, 2), extra, tmp_path, timeout=300)
