@@ -195,7 +195,11 @@ static int m_allmin(void *ctx, int32_t *v)
 
 /* the communicator the library runs its exchanges over: MPI callbacks (host-staged) or RCCL (one rank per GPU; the unique id
  * is shipped with MPI_Bcast like any NCCL application does, the device is the rank's index among the ranks of its node) */
-static struct { sluamd_handle_t h; sluamd_comm_t comm; int n; } G;
+static struct {
+    sluamd_handle_t h; sluamd_comm_t comm; int n;
+    /* lazy copy-back: the factors of the last factorisation live on the device only until a host consumer asks for them */
+    int host_stale; xLUstruct_t *LUstruct; gridinfo3d_t *grid3d;
+} G;
 static int bind_comm_create(MPI_Comm comm, int Pr, int Pc, int Pz, int myrow, int mycol, int myz, int use_rccl)
 {
     if (use_rccl) {
@@ -222,7 +226,85 @@ static int bind_comm_create(MPI_Comm comm, int Pr, int Pc, int Pz, int myrow, in
 static void sluamd_bind_release(void)
 {
     if (G.h) { S.destroy(G.h); G.h = NULL; }
+    G.host_stale = 0;
     if (G.comm) { S.comm_destroy(G.comm); G.comm = NULL; }
+}
+
+/* the reference's dLocalLU_t of this rank as the library's view (pointer arrays as they are; a _LONGINT build hands over narrowed
+ * copies of the index arrays) */
+static void bind_view_build(LUVIEW_T *v, int n, xLUstruct_t *LUstruct, gridinfo3d_t *grid3d)
+{
+    gridinfo_t *grid = &grid3d->grid2d;
+    Glu_persist_t *Glu = LUstruct->Glu_persist;
+    xLocalLU_t *Llu = LUstruct->Llu;
+    int_t nsupers = Glu->supno[n - 1] + 1;
+    const int Pr = grid->nprow, Pc = grid->npcol, Pz = grid3d->npdep;
+    v->n = n; v->nsupers = (int32_t) nsupers; v->xsup = NARROW(Glu->xsup, nsupers + 1);
+    v->nprow = Pr; v->npcol = Pc; v->npdep = Pz;
+    v->myrow = MYROW(grid->iam, grid); v->mycol = MYCOL(grid->iam, grid); v->myzlayer = grid3d->zscp.Iam;
+    v->Lnzval_bc_ptr = VALPP(Llu->Lnzval_bc_ptr); v->Unzval_br_ptr = VALPP(Llu->Unzval_br_ptr);
+#if defined(_LONGINT)
+    {   /* index arrays of the local block columns / block rows: lengths from their headers (superlu_defs.h:156-198) */
+        const int_t nbc = CEILING(nsupers, Pc), nbr = CEILING(nsupers, Pr);
+        v->Lrowind_bc_ptr = (sluamd_int_t **) calloc(nbc ? nbc : 1, sizeof(sluamd_int_t *));
+        v->Ufstnz_br_ptr = (sluamd_int_t **) calloc(nbr ? nbr : 1, sizeof(sluamd_int_t *));
+        for (int_t lk = 0; lk < nbc; ++lk) {
+            const int_t *li = Llu->Lrowind_bc_ptr[lk];
+            if (li) v->Lrowind_bc_ptr[lk] = NARROW(li, BC_HEADER + li[0] * LB_DESCRIPTOR + li[1]);
+        }
+        for (int_t lb = 0; lb < nbr; ++lb) {
+            const int_t *ui = Llu->Ufstnz_br_ptr[lb];
+            if (ui) v->Ufstnz_br_ptr[lb] = NARROW(ui, ui[2]);
+        }
+    }
+#else
+    v->Lrowind_bc_ptr = Llu->Lrowind_bc_ptr; v->Ufstnz_br_ptr = Llu->Ufstnz_br_ptr;
+#endif
+}
+static void bind_view_free(LUVIEW_T *v)
+{
+#if defined(_LONGINT)
+    free(v->Lrowind_bc_ptr); free(v->Ufstnz_br_ptr);
+#endif
+    (void) v;
+    sluamd_narrow_release();
+}
+
+/* Copy-back policy.  The reference's GPU path copies the factors to the host after every factorisation
+ * (dCopyLUGPU2Host, pdgssvx3d.c:1013-1021): 17 GB at 100^3, longer than the factorisation itself -- and nothing reads them when both
+ * triangular solves are bound to the library, which keeps the factors on the device.
+ *   SLUAMD_BIND_COPYBACK=eager  copy after every factorisation (the reference's behaviour)
+ *   SLUAMD_BIND_COPYBACK=lazy   leave them on the device; BIND_SYNC_HOST() copies on the first host consumer -- call it before anything
+ *                               reads LUstruct->Llu's values on the host (the CPU solves pdgstrs3d[_newsolve] when they are NOT bound,
+ *                               pdCompute_Diag_Inv, dgatherAllFactoredLU, dwriteLUtoDisk / dDumpLblocks3D); dbroadcastAncestor3d after
+ *                               the factorisation only feeds the CPU solve and may run on the stale host values; dDestroy_LU needs none
+ *   unset                       lazy when the solves are bound (SLUAMD_BIND_SOLVE unset or non-zero), eager with SLUAMD_BIND_SOLVE=0:
+ *                               tests/test_gpu_dropin.py::test_factor_only_binding shows the CPU solves need the copy */
+static int bind_copyback_lazy(void)
+{
+    const char *cb = getenv("SLUAMD_BIND_COPYBACK");
+    if (cb) return !strcmp(cb, "lazy");
+    const char *bs = getenv("SLUAMD_BIND_SOLVE");
+    return !bs || atoi(bs) != 0;
+}
+#ifndef Z_PREC
+#define BIND_SYNC_HOST sluamd_bind_dsync_host
+#else
+#define BIND_SYNC_HOST sluamd_bind_zsync_host
+#endif
+/* the factors of the last factorisation -> LUstruct's host arrays, if they are not there yet; returns 1 when a copy was made */
+int BIND_SYNC_HOST(void)
+{
+    if (!G.h || !G.host_stale) return 0;
+    LUVIEW_T v;
+    bind_view_build(&v, G.n, G.LUstruct, G.grid3d);
+    const double t0 = SuperLU_timer_();
+    int rc = S.copy2host(G.h, &v);                                           /* was dCopyLUGPU2Host       */
+    bind_view_free(&v);
+    if (rc) ABORT(S.last_error());
+    G.host_stale = 0;
+    if (getenv("SLUAMD_BIND_DEBUG")) fprintf(stderr, "[sluamd_bind] copyback on demand %.3f ms\n", 1e3 * (SuperLU_timer_() - t0));
+    return 1;
 }
 
 int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
@@ -230,34 +312,11 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
                             gridinfo3d_t *grid3d, SuperLUStat_t *stat, int *info)
 {
     gridinfo_t *grid = &grid3d->grid2d;
-    Glu_persist_t *Glu = LUstruct->Glu_persist;
-    xLocalLU_t *Llu = LUstruct->Llu;
-    int_t nsupers = Glu->supno[n - 1] + 1;
     const int Pr = grid->nprow, Pc = grid->npcol, Pz = grid3d->npdep;
     const int myrow = MYROW(grid->iam, grid), mycol = MYCOL(grid->iam, grid), myz = grid3d->zscp.Iam;
 
     LUVIEW_T v;
-    v.n = n; v.nsupers = (int32_t) nsupers; v.xsup = NARROW(Glu->xsup, nsupers + 1);
-    v.nprow = Pr; v.npcol = Pc; v.npdep = Pz;
-    v.myrow = myrow; v.mycol = mycol; v.myzlayer = myz;
-    v.Lnzval_bc_ptr = VALPP(Llu->Lnzval_bc_ptr); v.Unzval_br_ptr = VALPP(Llu->Unzval_br_ptr);
-#if defined(_LONGINT)
-    {   /* index arrays of the local block columns / block rows: lengths from their headers (superlu_defs.h:156-198) */
-        const int_t nbc = CEILING(nsupers, Pc), nbr = CEILING(nsupers, Pr);
-        v.Lrowind_bc_ptr = (sluamd_int_t **) calloc(nbc ? nbc : 1, sizeof(sluamd_int_t *));
-        v.Ufstnz_br_ptr = (sluamd_int_t **) calloc(nbr ? nbr : 1, sizeof(sluamd_int_t *));
-        for (int_t lk = 0; lk < nbc; ++lk) {
-            const int_t *li = Llu->Lrowind_bc_ptr[lk];
-            if (li) v.Lrowind_bc_ptr[lk] = NARROW(li, BC_HEADER + li[0] * LB_DESCRIPTOR + li[1]);
-        }
-        for (int_t lb = 0; lb < nbr; ++lb) {
-            const int_t *ui = Llu->Ufstnz_br_ptr[lb];
-            if (ui) v.Ufstnz_br_ptr[lb] = NARROW(ui, ui[2]);
-        }
-    }
-#else
-    v.Lrowind_bc_ptr = Llu->Lrowind_bc_ptr; v.Ufstnz_br_ptr = Llu->Ufstnz_br_ptr;
-#endif
+    bind_view_build(&v, n, LUstruct, grid3d);
 
     /* elimination forests of this layer (dtrf3Dpartition_t, superlu_ddefs.h:317-337) */
     int maxLvl = log2i(grid3d->zscp.Np) + 1, nf = (1 << maxLvl) - 1;
@@ -300,8 +359,14 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     double thresh = smach_dist("Epsilon") * anorm;                           /* pdgstrf3d.c:132-133       */
     rc = S.factor(G.h, thresh, info);                                        /* was pdgstrf3d_LUv1: collective, info already MIN over the grid */
     if (rc) ABORT(S.last_error());
-    rc = S.copy2host(G.h, &v);                                               /* was dCopyLUGPU2Host       */
-    if (rc) ABORT(S.last_error());
+    G.LUstruct = LUstruct; G.grid3d = grid3d; G.host_stale = 1;
+    if (!bind_copyback_lazy()) {
+        const double t0 = SuperLU_timer_();
+        rc = S.copy2host(G.h, &v);                                           /* was dCopyLUGPU2Host       */
+        if (rc) ABORT(S.last_error());
+        G.host_stale = 0;
+        if (getenv("SLUAMD_BIND_DEBUG")) fprintf(stderr, "[sluamd_bind] copyback eager %.3f ms\n", 1e3 * (SuperLU_timer_() - t0));
+    } else if (getenv("SLUAMD_BIND_DEBUG")) fprintf(stderr, "[sluamd_bind] copyback deferred (factors stay on the device)\n");
     sluamd_stats_t st;
     S.stats(G.h, &st);
     if (getenv("SLUAMD_BIND_DEBUG")) {
@@ -317,10 +382,7 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     if (SCT) SCT->pdgstrfTimer = 1e-3 * st.t_factor_ms;
     stat->utime[FACT] = SuperLU_timer_() - t_start;
     free(nNodes); free(lists);
-#if defined(_LONGINT)
-    free(v.Lrowind_bc_ptr); free(v.Ufstnz_br_ptr);
-#endif
-    sluamd_narrow_release();
+    bind_view_free(&v);
     (void) m;
     return 0;
 }

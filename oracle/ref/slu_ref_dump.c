@@ -205,6 +205,15 @@ int_t WRAP(gstrf3d)(superlu_dist_options_t *options, int m, int n, double anorm,
     extern int_t BIND_NAME(superlu_dist_options_t *, int, int, double, xtrf3Dpartition_t *, SCT_t *,
                            xLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
     int_t r = BIND_NAME(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
+#ifdef Z_PREC
+#define BIND_SYNC_HOST sluamd_bind_zsync_host
+#else
+#define BIND_SYNC_HOST sluamd_bind_dsync_host
+#endif
+    extern int BIND_SYNC_HOST(void);
+    /* lazy copy-back (SLUAMD_BIND_COPYBACK): this driver is a host consumer of the factors when it records them, and when the CPU
+     * solves of a Z-replicated grid follow (dbroadcastAncestor3d reads the host panels right after this call) */
+    if (g_out || (getenv("SLUAMD_BIND_SOLVE") && !atoi(getenv("SLUAMD_BIND_SOLVE")))) BIND_SYNC_HOST();
 #else
     int_t r = REAL(gstrf3d)(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
 #endif

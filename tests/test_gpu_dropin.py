@@ -30,8 +30,7 @@ def _run(binary, args, tmp_path, threads="4", nproc=1, extra_env=None):
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
         if r.returncode == 0:
             break
-        if "MPI" in r.stderr and "nit" in r.stderr and attempt == 2:
-            pytest.skip("MPICH could not initialise on this box: " + r.stderr[-300:])
+    # (a start-up failure of MPICH after three attempts is a FAILURE, not a skip: a bad box must not make this file vanish silently)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     m = re.search(r"RESIDUAL (\S+) INFO (\d+)", r.stdout)
     assert m, r.stdout[-2000:]
@@ -195,6 +194,36 @@ def test_reference_pipeline_with_our_pzgstrf3d(kind, tmp_path):
     assert info_amd == info_fac == info_ref == 0
     assert res_amd < 1e-10 and res_fac < 1e-10 and res_ref < 1e-10
     assert abs(res_amd - res_ref) < 1e-10 and abs(res_fac - res_ref) < 1e-10
+
+
+@pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
+@pytest.mark.parametrize("grid", [(1, 1, 1), (2, 2, 2)])
+def test_copyback_policy_of_the_binding(grid, tmp_path):
+    """SLUAMD_BIND_COPYBACK (replaces the unconditional dCopyLUGPU2Host of pdgssvx3d.c:1013-1021): with both solves bound the
+    factors stay on the device (default = lazy: no device-to-host copy at all, same residual as the eager run); eager copies after the
+    factorisation; lazy with the CPU solves (SLUAMD_BIND_SOLVE=0) copies on the first host consumer through sluamd_bind_dsync_host and the
+    reference's own solves then give the reference's residual."""
+    N = 14
+    n, rp, ci, v = matgen.poisson3d(N)
+    matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
+    r, c, d = grid
+    P = r * c * d
+    args = ["-r", str(r), "-c", str(c), "-d", str(d), "-Q", "1", "-o", "none", "-i", "0", str(tmp_path / "a.dat")]
+    dbg = {"SLUAMD_BIND_DEBUG": "1"}
+    res_lazy, info_lazy = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dbg)
+    assert "copyback deferred" in _last["stderr"] and "copyback eager" not in _last["stderr"] and "copyback on demand" not in _last["stderr"]
+    res_eager, info_eager = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dict(dbg, SLUAMD_BIND_COPYBACK="eager"))
+    assert "copyback eager" in _last["stderr"] and "copyback deferred" not in _last["stderr"]
+    # CPU solves: the default turns eager by itself; an explicit lazy is served by the sync call of the first host consumer
+    res_cpu, info_cpu = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dict(dbg, SLUAMD_BIND_SOLVE="0"))
+    assert "copyback eager" in _last["stderr"]
+    res_cpu_lazy, info_cpu_lazy = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dict(dbg, SLUAMD_BIND_SOLVE="0", SLUAMD_BIND_COPYBACK="lazy"))
+    assert "copyback on demand" in _last["stderr"]
+    res_ref, info_ref = _run(REF, args, tmp_path, threads="1", nproc=P)
+    assert info_lazy == info_eager == info_cpu == info_cpu_lazy == info_ref == 0
+    for res in (res_lazy, res_eager, res_cpu, res_cpu_lazy):
+        assert res < 1e-10 and abs(res - res_ref) < 1e-10
+    assert res_lazy == res_eager            # the same device-resident factors and solves: the copy is not on the path
 
 
 @pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
