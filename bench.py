@@ -67,7 +67,7 @@ def build_problem(N, leaf, workload="poisson3d"):
 
 
 def cpu_baseline_grid(N, leaf, relax, maxsup, ref_bin, host_cores):
-    """SURVEY 8(d)'s second CPU leg: the real reference on a 2 x 2 x 2 process grid, 8 MPI ranks x host_cores/8 OpenMP threads (capped at 16:
+    """SURVEY 8(d)'s second CPU leg: the real reference on a 2 x 2 x 2 process grid, 8 MPI ranks x host_cores/8 OpenMP threads (capped at 8:
     the reference stops scaling past ~8 threads per rank, see the 1-rank sweep), every rank pinned to its own contiguous core range.
     RowPerm stays at the reference's default (LargeDiag_MC64: the identity on this diagonally dominant matrix; v9.2.1's pdgssvx3d fails in
     symbfact with NOROWPERM on a 2 x 2 x 2 grid), everything else as the 1-rank leg.  Timer = stat.utime[FACT] of rank 0 (pdgstrf3d.c:331,395)."""
@@ -80,7 +80,7 @@ def cpu_baseline_grid(N, leaf, relax, maxsup, ref_bin, host_cores):
     symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
     flops = symb.flops
     symb.free()
-    th = max(1, min(16, host_cores // 8))
+    th = max(1, min(8, host_cores // 8))     # 8 threads per rank: the best point of the 1-rank sweep (16: 69 s at 60^3 on the round-4 box, slower than 8)
     with tempfile.TemporaryDirectory() as tmp:
         mpath = os.path.join(tmp, "a.dat"); ppath = os.path.join(tmp, "a.perm")
         matgen.write_triplet_dat(mpath, n, rp, ci, v)
@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs4", action="store_true",
                     help="skip the `configs4` block of the default line (BASELINE.json configs[4]: complex16 1000 x 1000 grid operator, 5 steps)")
-    ap.add_argument("--cpu-grid-n", type=int, default=60,
+    ap.add_argument("--cpu-grid-n", type=int, default=50,
                     help="grid side of the 2x2x2 leg of the CPU baseline (8 MPI ranks x host_cores/8 threads of the real reference); 0 = skip")
     ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d", "audikw_like"],
                     help="poisson3d = BASELINE configs[1] (default, the metric's config); zgrid2d = configs[4] family "

@@ -4,7 +4,7 @@ tag=${1:-env}; shift
 mkdir -p gpurun_out
 run() {
   local name=$1; shift
-  env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point > gpurun_out/${tag}_$name.json 2> gpurun_out/${tag}_$name.err
+  env "$@" timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point --no-configs4 > gpurun_out/${tag}_$name.json 2> gpurun_out/${tag}_$name.err
   python - <<PY
 import json
 try:

@@ -6,14 +6,14 @@ R=$GRAFT_REPO_ROOT
 bash scripts/collect_pmc.sh $tag > gpurun_out/${tag}_collect_pmc.log 2>&1
 cp gpurun_out/${tag}_pmc_schur.json profiles/r03_pmc_schur.json    # bench.py reads this one (same box, same kernels)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks
-rocprofv3 --kernel-trace --stats -d /tmp/ks -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point > /tmp/ks.json 2> /tmp/ks.err
+rocprofv3 --kernel-trace --stats -d /tmp/ks -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point --no-configs4 > /tmp/ks.json 2> /tmp/ks.err
 cd $R
 db=$(find /tmp/ks -name "*.db" | head -1)
 python scripts/rocpd_stats.py $db > gpurun_out/${tag}_kernel_stats_lookahead_final.txt 2>&1
 python scripts/timeline.py $db 3 > gpurun_out/${tag}_timeline_final.txt 2>&1
 python scripts/solve_timeline.py $db 2 > gpurun_out/${tag}_solve_timeline_final.txt 2>&1
 cd /tmp && rm -rf /tmp/ks2
-SLUAMD_NO_LOOKAHEAD=1 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point > /tmp/ks2.json 2> /tmp/ks2.err
+SLUAMD_NO_LOOKAHEAD=1 rocprofv3 --kernel-trace --stats -d /tmp/ks2 -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point --no-configs4 > /tmp/ks2.json 2> /tmp/ks2.err
 cd $R
 db2=$(find /tmp/ks2 -name "*.db" | head -1)
 python scripts/rocpd_stats.py $db2 > gpurun_out/${tag}_kernel_stats_serial_final.txt 2>&1

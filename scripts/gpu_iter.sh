@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 (timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_refine.py tests/test_gpu_edge_cases.py tests/test_gpu_grid.py -q --timeout=300 -x > gpurun_out/${tag}_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/${tag}_pytest.log)
 grep -E "passed|failed|FAILED|rc " gpurun_out/${tag}_pytest.log | tail -8
 for r in "$@"; do
-  SLUAMD_RESERVE_CUS=$r timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point > gpurun_out/${tag}_bench_r$r.json 2> gpurun_out/${tag}_bench_r$r.err
+  SLUAMD_RESERVE_CUS=$r timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point --no-configs4 > gpurun_out/${tag}_bench_r$r.json 2> gpurun_out/${tag}_bench_r$r.err
   python - <<PY
 import json
 try:

@@ -60,6 +60,17 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     const bool gemm_panels = !H->env.trsm_panels && !H->z;   // XY layers: the peers of a diagonal block invert the copy they receive (full_inv on SNF_HAS_DIAG)
     hipStream_t s = H->stream, ps = lookahead ? H->pstream : H->stream;
     int rc_x = 0;
+    // Tail of the panel chain (1 x 1 layers): on the last `trsm_tail` single-supernode levels -- the top separator, where the trailing
+    // update is shorter than the chain diag LU -> Linv / Uinv -> panel GEMM -> urgent tiles -- the panel solves run as blocked
+    // substitutions on the 32 x 32 inverses the diagonal kernel leaves behind (k_panel_trsm), so that the full inverses (which the
+    // triangular solves still want) leave the chain: they are computed beside it on the bulk stream
+    const int trsm_tail = (gemm_panels && !xy) ? H->env.trsm_tail : 0;
+    auto tail_level = [&](int l) { return trsm_tail > 0 && l >= S.nlevels - trsm_tail && S.lvl_off[l + 1] - S.lvl_off[l] == 1; };
+    auto deferred_inv = [&](hipStream_t st, int l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+        eng::full_inv(st, T, S.d_nodes + n0, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], S.max_nsupc[l]);
+        H->st.num_launches++;
+    };
     int cur_level = 0, cur_pass = 0;
     // per-tile records of the list schedules (k_schur mmode 1 / 2): built once per schedule, on its first factorisation
     if (S.maps_state == 0) {
@@ -135,7 +146,9 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             H->st.num_launches += 1 + (xy ? 1 : 0);
             return;
         }
-        eng::diag_lu(ps, T, nodes, nn, mx, (H->opt.replace_tiny_pivot ? 1 : 0) | (H->env.diag_v1 ? 2 : 0), thresh, H->d_info);   // Local_Dgstrf2 (+ dinv of the owned blocks)
+        // bit 2: the single-supernode levels at the top of the tree get the diagonal kernel built for the whole register file (no scratch)
+        const int big_regs = (H->env.diag_tail > 0 && nn == 1 && l >= S.nlevels - H->env.diag_tail) ? 4 : 0;
+        eng::diag_lu(ps, T, nodes, nn, mx, (H->opt.replace_tiny_pivot ? 1 : 0) | (H->env.diag_v1 ? 2 : 0) | big_regs, thresh, H->d_info);   // Local_Dgstrf2 (+ dinv of the owned blocks)
         if (xy) {   // dDiagFactIBCast (dtrfCommWrapper.c:32-118): diagonal blocks down the process column and along the process row
             eng::pack_diag(ps, T, nodes, S.d_dg_prefix + po, S.d_dg_off + po, nn, S.dg_prefix[po + nn], H->d_val + S.dg_stage_off[l]);
             ev_begin(H, H->ev_xchg, H->ev_xchg_used, ps);
@@ -143,9 +156,10 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             ev_end(H, H->ev_xchg, H->ev_xchg_used, ps);
             eng::diag_inv(ps, T, nodes, S.d_inv_prefix + po, nn, S.inv_prefix[po + nn]);   // column / row peers invert the diagonal blocks they received
         }
-        if (gemm_panels) eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);   // Linv / Uinv (the solve uses the owner's too)
+        const bool inv_here = gemm_panels && !tail_level(l);
+        if (inv_here) eng::full_inv(ps, T, nodes, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], mx);   // Linv / Uinv (the solve uses the owner's too)
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);
-        H->st.num_launches += 1 + (gemm_panels ? 1 : 0) + (xy ? 2 : 0);
+        H->st.num_launches += 1 + (inv_here ? 1 : 0) + (xy ? 2 : 0);
     };
     auto panelB = [&](int l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
@@ -165,7 +179,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             H->st.num_launches += (znl + znu > 0);
             return;
         }
-        if (gemm_panels) eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, mx);   // chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
+        if (gemm_panels && !tail_level(l)) eng::panel_gemm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, mx);   // chain-free GEMM form of dLPanelTrSolve / dUPanelTrSolve
         else eng::panel_trsm(ps, T, nodes, S.d_ltr_prefix + po, S.d_utr_prefix + po, nn, nl, nu, trsm_rs(*H, (mx + 31) & ~31), mx);
         if (xy) {
             ev_begin(H, H->ev_xchg, H->ev_xchg_used, ps);
@@ -224,7 +238,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     };
     hipEvent_t e_u2_prev = nullptr;      // U2(l-1) done
     hipEvent_t e_bulk_prev = nullptr, e_bulk_prev2 = nullptr;   // bulk(l-1), bulk(l-2) done (stream order: and every earlier one)
-    if (S.nlevels) { panelA(0); panelB(0); }
+    if (S.nlevels) { panelA(0); panelB(0); if (!lookahead && tail_level(0)) deferred_inv(s, 0); }
     for (int l = 0; l < S.nlevels; ++l) {
         cur_level = l;
         const bool more = l + 1 < S.nlevels;
@@ -234,13 +248,14 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             if (H->opt.deterministic) { cur_pass = 3; grid_launch(s, l); }
             else if (T.defer && S.lvl_defer[l]) { cur_pass = 0; list_launch(s, l, 0, 0); cur_pass = 1; list_launch(s, l, 1, 1); cur_pass = 3; list_launch(s, l, 2, 3); }
             else { cur_pass = 3; list_launch(s, l, 0, 3); }
-            if (more) { panelA(l + 1); panelB(l + 1); }
+            if (more) { panelA(l + 1); panelB(l + 1); if (tail_level(l + 1)) deferred_inv(s, l + 1); }
             if (rc_x) return rc_x;
             continue;
         }
         hipEvent_t e_p = next_event(H);  // panel(l) done
         hipEventRecord(e_p, ps);
         hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);
+        if (tail_level(l)) deferred_inv(s, l);        // off the chain: the bulk stream waits for panel(l) anyway
         cur_pass = 0; list_launch(ps, l, 0, 0);   // on the panel stream itself: diag_lu(l+1) follows in stream order, no event hop
         cur_pass = 1; list_launch(us, l, 1, 1);
         hipEvent_t e_u1 = next_event(H); hipEventRecord(e_u1, us);

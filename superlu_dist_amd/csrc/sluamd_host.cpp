@@ -46,6 +46,8 @@ void read_env(Handle::Env &e)
     e.profile_dump = getenv("SLUAMD_PROFILE_DUMP") != nullptr;   // per-launch Schur table on stderr after a profiled factorisation
     e.diag_v1 = getenv("SLUAMD_DIAG_V1") != nullptr;             // round-1 right-looking diagonal LU kernel
     e.trsm_panels = getenv("SLUAMD_TRSM_PANELS") != nullptr;    // blocked-substitution panel kernels instead of the GEMM form (1 x 1 layers)
+    if (const char *v = getenv("SLUAMD_TRSM_TAIL")) e.trsm_tail = atoi(v);
+    if (const char *v = getenv("SLUAMD_DIAG_TAIL")) e.diag_tail = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_MIN_PCT")) e.fuse_min_pct = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_MAX_PREV")) e.fuse_max_prev = std::max(1, std::min(3, atoi(v)));
     if (const char *v = getenv("SLUAMD_CHAIN")) e.chain_mode = std::max(0, std::min(2, atoi(v)));

@@ -242,6 +242,8 @@ struct Handle {
     struct Env {
         bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, profile_dump = false, trsm_panels = false, diag_v1 = false;
         int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
+        int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
+        int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
                                                    // profiles/r03_ab_dataflow_sweeps.txt; 1 = agent-scope fences; 2 = write-through x, no fences)
@@ -323,7 +325,7 @@ struct Handle {
 // ------------------------------------------------------------------------------------------------
 namespace eng {
 int setup();   // one-time function attributes (dynamic LDS limits)
-// flags: bit 0 = ReplaceTinyPivot, bit 1 = round-1 right-looking kernel.  Also leaves the inverted 32 x 32 diagonal sub-blocks of the
+// flags: bit 0 = ReplaceTinyPivot, bit 1 = round-1 right-looking kernel, bit 2 = k_diag_lu2 built for the whole register file (tail levels).  Also leaves the inverted 32 x 32 diagonal sub-blocks of the
 // owned blocks in T.dinv (what diag_inv computes for blocks received from another rank)
 void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int flags, double thresh, int *info);
 void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask);

@@ -61,6 +61,32 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
+// Reciprocal of a pivot off the IEEE division sequence: v_rcp_f64 + two Newton steps (5 dependent instructions instead of ~12;
+// relative error < 2^-52 for normal pivots -- tiny pivots were replaced, zero pivots never get here).  The pivot chain of the one-wave
+// LU kernels is latency: 32 (64) dependent reciprocals per block.
+__device__ __forceinline__ double pivot_recip(double p)
+{
+    double r = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-p, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// pivot of column j as the one-wave kernels see it: broadcast, tiny-pivot replacement (pdgstrf2.c:544-560), zero-pivot info (:568-571);
+// returns 1 / pivot (1 for a zero pivot, which leaves the column unscaled like pdgstrf2.c:566-575)
+__device__ __forceinline__ double wave_pivot(double &acol, int j, int lane, int col1based, int replace_tiny, double thresh, int *info)
+{
+    double p = lane_bcast(acol, j);
+    if (replace_tiny && fabs(p) < thresh) {
+        p = (p < 0) ? -thresh : thresh;
+        if (lane == j) acol = p;
+        if (lane == 0) atomicAdd(&info[1], 1);
+    }
+    if (p == 0.0 && lane == 0) atomicMin(&info[0], col1based);
+    return (p != 0.0) ? pivot_recip(p) : 1.0;
+}
+
 // Unpivoted LU of the nb x nb (nb <= 32) block at P (LDS, column-major, ld), executed by ONE wave entirely in
 // registers: lane r holds row r (identity-padded to 32), pivot rows are broadcast with v_readlane.
 // s_rinv[j] receives 1/U(j,j) (1 for a zero pivot, which leaves the column unscaled like pdgstrf2.c:566-575).
@@ -71,30 +97,30 @@ __device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, i
     double a[DB];
 #pragma unroll
     for (int c = 0; c < DB; ++c) a[c] = (lane < nb && c < nb) ? P[c * ld + lane] : ((c == lane) ? 1.0 : 0.0);
+    // software pipeline of the pivot chain: step j updates column j + 1 FIRST and starts the reciprocal of pivot j + 1 at once, so that
+    // its latency hides behind the updates of the columns j + 2 .. 31 instead of heading the next step
+    double rinv = wave_pivot(a[0], 0, lane, col1, replace_tiny && 0 < nb, thresh, info);
 #pragma unroll
     for (int j = 0; j < DB; ++j) {
-        double p = lane_bcast(a[j], j);
-        if (j < nb) {
-            if (replace_tiny && fabs(p) < thresh) {
-                p = (p < 0) ? -thresh : thresh;
-                if (lane == j) a[j] = p;
-                if (lane == 0) atomicAdd(&info[1], 1);
-            }
-            if (p == 0.0 && lane == 0) atomicMin(&info[0], col1 + j);
-        }
-        const double rinv = (p != 0.0) ? 1.0 / p : 1.0;
         if (lane == 0) s_rinv[j] = rinv;
         const bool below = lane > j;
         const double l = a[j] * rinv;
         if (below) a[j] = l;
         const double lm = below ? l : 0.0;      // rows at and above the pivot take a zero multiplier: one FMA per column, no select
+        double rnext = 1.0;
+        if (j + 1 < DB) {
+            const double u = lane_bcast(a[j + 1], j);
+            a[j + 1] -= lm * u;
+            rnext = (j + 1 < nb) ? wave_pivot(a[j + 1], j + 1, lane, col1 + j + 1, replace_tiny, thresh, info) : 1.0;   // identity padding past nb
+        }
 #pragma unroll
-        for (int c = j + 1; c < DB; ++c) {
+        for (int c = j + 2; c < DB; ++c) {
             const double u = lane_bcast(a[c], j);
             a[c] -= lm * u;
             if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the broadcast SGPRs
         }
         __builtin_amdgcn_sched_barrier(0);
+        rinv = rnext;
     }
 #pragma unroll
     for (int c = 0; c < DB; ++c) if (lane < nb && c < nb) P[c * ld + lane] = a[c];
@@ -120,27 +146,28 @@ __global__ __launch_bounds__(256, 2) void k_diag_lu_wave(DevTables T, const int 
     double a[64];
 #pragma unroll
     for (int c = 0; c < 64; ++c) a[c] = (rok && c < ns) ? A[lane + (size_t) c * lda] : ((c == lane) ? 1.0 : 0.0);   // identity-padded
+    // pivot chain pipelined as in wave_lu32: column j + 1 first, its reciprocal in flight behind the other columns' updates
+    double rinv = wave_pivot(a[0], 0, lane, fst + 1, replace_tiny, thresh, info);
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
         if (j < ns) {                                  // wave-uniform
-            double p = lane_bcast(a[j], j);
-            if (replace_tiny && fabs(p) < thresh) {
-                p = (p < 0) ? -thresh : thresh;
-                if (lane == j) a[j] = p;
-                if (lane == 0) atomicAdd(&info[1], 1);
-            }
-            if (p == 0.0 && lane == 0) atomicMin(&info[0], fst + j + 1);
-            const double rinv = (p != 0.0) ? 1.0 / p : 1.0;
             const bool below = lane > j;
             const double l = a[j] * rinv;
             if (below) a[j] = l;
             const double lm = below ? l : 0.0;
+            double rnext = 1.0;
+            if (j + 1 < 64) {
+                const double u = lane_bcast(a[j + 1], j);
+                a[j + 1] -= lm * u;
+                if (j + 1 < ns) rnext = wave_pivot(a[j + 1], j + 1, lane, fst + j + 2, replace_tiny, thresh, info);
+            }
 #pragma unroll
-            for (int c = j + 1; c < 64; ++c) {
+            for (int c = j + 2; c < 64; ++c) {
                 const double u = lane_bcast(a[c], j);
                 a[c] -= lm * u;
                 if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the live range of the broadcast SGPRs
             }
+            rinv = rnext;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -285,8 +312,13 @@ constexpr int DST = DKH + 2;                      // stage stride (== 18 mod 32:
 constexpr int DXS = 4 * DB * (DB + 1) + 2 * 16 * 17;   // staging buffer: >= 32 * DST and the phase-C scratch
 constexpr size_t DIAG_LU2_LDS = sizeof(double) * (DXS + DB * 33 + DB * 34 + DB * 48);
 
-__global__ __launch_bounds__(256, 2) void k_diag_lu2(DevTables T, const int *__restrict__ nodes, int replace_tiny, double thresh,
-                                                     int *__restrict__ info)
+// MINB = 2 (default): at most 256 registers per lane, the kernel starts in the slot of ONE retiring Schur workgroup -- the compiler pays with
+// ~170 spilled VGPRs (scratch traffic in the phases that hold 2 x 28 operand fragments beside the accumulators).  MINB = 1: the whole register
+// file (256 VGPRs + 256 AGPRs, no scratch) for the levels where nothing else competes for the CU -- the single-supernode levels at the top
+// of the tree, whose trailing update is shorter than the panel chain (flag bit 2 of eng::diag_lu).
+template <int MINB>
+__global__ __launch_bounds__(256, MINB) void k_diag_lu2(DevTables T, const int *__restrict__ nodes, int replace_tiny, double thresh,
+                                                        int *__restrict__ info)
 {
     __builtin_amdgcn_s_setprio(3);   // panel chain: its waves go first when they share a SIMD with Schur tiles
     extern __shared__ double dsm[];
@@ -1928,7 +1960,8 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_panel_trsm<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_full_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) DIAG_LU2_LDS));
+    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) DIAG_LU2_LDS));
+    HIPCHK(hipFuncSetAttribute((const void *) k_diag_lu2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) DIAG_LU2_LDS));
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
@@ -1956,7 +1989,8 @@ void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx
     // bottom of the tree, thousands of blocks per launch) are throughput-bound, not latency-bound: the right-looking kernel with
     // its smaller footprint is faster there (0.85 vs 2.2 ms per launch at 100^3)
     if (!(replace_tiny & 2) && mx > 64) {
-        hipLaunchKernelGGL(k_diag_lu2, dim3(nn), dim3(256), DIAG_LU2_LDS, s, T, nodes, replace_tiny & 1, thresh, info);
+        if (replace_tiny & 4) hipLaunchKernelGGL(k_diag_lu2<1>, dim3(nn), dim3(256), DIAG_LU2_LDS, s, T, nodes, replace_tiny & 1, thresh, info);
+        else hipLaunchKernelGGL(k_diag_lu2<2>, dim3(nn), dim3(256), DIAG_LU2_LDS, s, T, nodes, replace_tiny & 1, thresh, info);
         return;
     }
     replace_tiny &= 1;

@@ -223,7 +223,7 @@ def test_copyback_policy_of_the_binding(grid, tmp_path):
     assert info_lazy == info_eager == info_cpu == info_cpu_lazy == info_ref == 0
     for res in (res_lazy, res_eager, res_cpu, res_cpu_lazy):
         assert res < 1e-10 and abs(res - res_ref) < 1e-10
-    assert res_lazy == res_eager            # the same device-resident factors and solves: the copy is not on the path
+    assert abs(res_lazy - res_eager) < 1e-12   # the same device-resident factors and solves (fp64 atomics: summation order differs run to run)
 
 
 @pytest.mark.skipif(not (os.path.exists(ZAMD) and os.path.exists(ZREF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
