@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs4", action="store_true",
                     help="skip the `configs4` block of the default line (BASELINE.json configs[4]: complex16 1000 x 1000 grid operator, 5 steps)")
+    ap.add_argument("--configs4-n", type=int, default=1000, help="grid side of the configs4 block (1000 = BASELINE.json configs[4]; the CPU flow test lowers it)")
     ap.add_argument("--cpu-grid-n", type=int, default=50,
                     help="grid side of the 2x2x2 leg of the CPU baseline (8 MPI ranks x host_cores/8 threads of the real reference); 0 = skip")
     ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d", "audikw_like"],
@@ -512,14 +513,14 @@ def main():
         if h is not None:
             h.destroy(); symb.free(); h, symb = None, None
         try:
-            Z4 = measure(1000, 5, 2, "zgrid2d", maxsup=64)
+            Z4 = measure(args.configs4_n, 5, 2, "zgrid2d", maxsup=64)
             hz = Z4["h"]
             hz.set_profile(True); hz.reset_values(); hz.pdgstrf3d(Z4["thresh"]); stpz = hz.stats(); hz.set_profile(False)
             stz = hz.stats()
             Fz = stz["flops_schur_exact"] + stz["flops_panel"]
             z_tf = stz["flops_schur_exact"] / (stpz["t_schur_ms"] * 1e-3) / 1e12 if stpz["t_schur_ms"] > 0 else 0.0
             z_gbs = 16.0 * float(stz["nnz_L"] + stz["nnz_U"]) / (np.mean(Z4["solve_ms"]) * 1e-3) / 1e9
-            out["configs4"] = {"workload": "pzdrive3d-equivalent on a 1000x1000 5-point complex16 grid operator (cg20 family, grid side x 50), 1x1x1 grid, "
+            out["configs4"] = {"workload": f"pzdrive3d-equivalent on a {args.configs4_n}x{args.configs4_n} 5-point complex16 grid operator (cg20 family, grid side x {args.configs4_n // 20}), 1x1x1 grid, "
                                            f"ND perm_c (leaf {args.leaf}), relax {args.relax}, maxsup 64, nrhs 1",
                                "dtype": "c128", "n": Z4["n"], "nnz_LU": int(stz["nnz_L"] + stz["nnz_U"]), "flops_per_step": Fz, "steps": Z4["steps"], "warmup": 2,
                                "value": Fz * Z4["steps"] / Z4["elapsed"] / 1e9, "unit": "GFLOP/s", "ms_per_step": 1e3 * Z4["elapsed"] / Z4["steps"],

@@ -244,6 +244,8 @@ struct Handle {
         int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
+        int level_split_min = 1024;  // SLUAMD_LEVEL_SPLIT_MIN: levels of at most this many supernodes are never cut (tests lower it)
+        bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
                                                    // profiles/r03_ab_dataflow_sweeps.txt; 1 = agent-scope fences; 2 = write-through x, no fences)
@@ -299,6 +301,8 @@ struct Handle {
     // K-fused updates (see DevTables): host images, built by build_schedule
     std::vector<int> h_fuse_prev, h_defer, h_pair_roff, h_pair_coff, h_pair_rowmap, h_pair_colinfo;
     int fused_pairs = 0;
+    int64_t xy_scratch_len = 0;    // values of the received-panel scratch (all copies)
+    int xy_scratch_copies = 0;     // XY layers: copies of the received-panel scratch (by level modulo this), 0 on a 1 x 1 layer
     int max_nsupc = 0;
     Comm *comm = nullptr;           // not owned; set by sluamd_dCreateLUHandleGrid / ...FromSymbGrid
     std::map<int, LevelSched::XSeg> xseg_cache;        // x-segment run lists of the grid solve (Z exchanges, owner rows), built once

@@ -26,6 +26,37 @@ static void dag_levels(const SlotInput &in, const std::vector<int> &list, int ns
     nlevels = list.empty() ? 0 : maxl + 1;
 }
 
+// XY layers: the panels a rank receives for one DAG level live in the exchange scratch until the level's tiles are done, so the
+// scratch is as large as the LARGEST level -- the leaf level of a nested-dissection tree, tens of thousands of independent small
+// supernodes (100^3: 9 142 of 10^5 supernodes).  The supernodes of one level are independent, so a level may be cut into
+// consecutive sub-levels (ascending supernode id) without touching any dependency: levels with more than
+// cap = max(1024 [SLUAMD_LEVEL_SPLIT_MIN], ceil(largest level / 4)) supernodes are exchanged in sub-batches of at most `cap` (<= 1/4 of the largest level),
+// and the look-ahead schedule pipelines the sub-batches like any other levels.  The rule reads only the forest's global node lists and
+// levels (identical on every rank of the layer), so all ranks cut alike.  (leaf-level remote-panel scratch in
+// <= 1/4-level sub-batches; the reference keeps every received panel of its look-ahead window, dtreeFactorization.c:295-716.)
+static void split_wide_levels(const std::vector<int> &list, std::vector<int> &lvl, int &nlevels, int min_cap)
+{
+    if (nlevels <= 0) return;
+    std::vector<int> cnt(nlevels, 0);
+    for (int k : list) cnt[lvl[k]]++;
+    const int nmax = *std::max_element(cnt.begin(), cnt.end());
+    const int cap = std::max(min_cap, (nmax + 3) / 4);
+    std::vector<int> first(nlevels + 1, 0), per(nlevels, 1);        // new id of the first sub-level of every level; sub-level size
+    for (int l = 0; l < nlevels; ++l) {
+        const int chunks = std::max(1, (cnt[l] + cap - 1) / cap);
+        per[l] = (cnt[l] + chunks - 1) / std::max(chunks, 1);
+        first[l + 1] = first[l] + chunks;
+    }
+    if (first[nlevels] == nlevels) return;
+    std::vector<int> seen(nlevels, 0);
+    for (int k : list) {   // ascending supernode id
+        const int l = lvl[k];
+        lvl[k] = first[l] + seen[l] / std::max(per[l], 1);
+        seen[l]++;
+    }
+    nlevels = first[nlevels];
+}
+
 // ---- block tables, tile lists, flop tallies (host images of DevTables) ---------------------------------------------
 // XY layers run the panel solves in their GEMM form too: the row / column peers of a diagonal block compute its full inverses
 // from the block they receive (SLUAMD_TRSM_PANELS=1: the blocked substitution of round 1)
@@ -186,11 +217,11 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
     for (int c = 0; c < ncolu_b; ++c) colinfo[2 * c + 1] = sa;
     const int la = t.sn_lb_off[a], lb = t.sn_lb_off[b];
     int rows_a = 0, cols_a = 0;
-    for (int x = 1; x < t.sn_nlb[a]; ++x) {
+    for (int x = t.sn_ldiag[a] ? 1 : 0; x < t.sn_nlb[a]; ++x) {     // (the diagonal block heads the slot only on the supernode's own process row)
         const int g = t.lb_gid[la + x];
         if (g <= b) continue;                      // a's updates of the chain members up to b: their urgent tiles
         int y = -1;
-        for (int q = 1; q < t.sn_nlb[b]; ++q) if (t.lb_gid[lb + q] == g) { y = q; break; }
+        for (int q = t.sn_ldiag[b] ? 1 : 0; q < t.sn_nlb[b]; ++q) if (t.lb_gid[lb + q] == g) { y = q; break; }
         if (y < 0) return false;
         const int *ra = hs.lidx.data() + hs.lidx_off[a] + t.lb_lptr[la + x], *rb = hs.lidx.data() + hs.lidx_off[b] + t.lb_lptr[lb + y];
         const int na = t.lb_nbrow[la + x], nb = t.lb_nbrow[lb + y];
@@ -221,7 +252,7 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
         }
         cols_a += na;
     }
-    const int rows_b = nsupr_b - nsupc_of(hs, b);
+    const int rows_b = nsupr_b - t.sn_ldiag[b];
     const int pct = H.env.fuse_min_pct;
     return rows_a > 0 && cols_a > 0 && 100 * (int64_t) rows_a >= (int64_t) pct * rows_b && 100 * (int64_t) cols_a >= (int64_t) pct * ncolu_b;
 }
@@ -500,10 +531,11 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     build_chain(H, t, lvl, S);
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
     // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
-    // (1 x 1 layers only: on an XY grid a deferred supernode's received panels would have to outlive two exchange phases.)
+    // XY layers (round 4): a deferred supernode's received panels outlive one more exchange -- three scratch copies by level modulo 3
+    // (plan_and_upload); the pair maps are in slot rows / non-empty slot columns of THIS rank's parts of the two supernodes.
     S.lvl_defer.assign(S.nlevels, 0);
     if (H.h_fuse_prev.empty()) { H.h_fuse_prev.assign(3 * (size_t) ns, -1); H.h_defer.assign(ns, 0); H.h_pair_roff.assign(3 * (size_t) ns, -1); H.h_pair_coff.assign(3 * (size_t) ns, -1); }
-    if (!H.env.no_fuse && !H.opt.deterministic && !H.z && H.grid.Pr * H.grid.Pc == 1) {
+    if (!H.env.no_fuse && !H.opt.deterministic && !H.z) {
         const int maxprev = H.env.fuse_max_prev;   // measured: pairs beat groups of 3-4 end to end (longer urgent tiles sit on the panel chain)
         std::vector<int> rowmap[3], colinfo[3];
         for (int l = 0; l + 1 < S.nlevels; ++l)
@@ -604,6 +636,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     const Grid &g = H->grid;
     const int ns = hs.nsupers;
     const bool xy = g.Pr * g.Pc > 1;
+    const size_t upload_mark = upload_bytes();
 
     const int nz = (int) in.lists.size();
     H->Pz = g.Pz; H->myz = g.z;
@@ -636,7 +669,10 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     // ---- 2. DAG levels per Z level ----
     std::vector<std::vector<int>> lvl(nz);
     std::vector<int> nlev(nz, 0);
-    for (int zl = 0; zl < nz; ++zl) dag_levels(in, in.lists[zl], ns, lvl[zl], nlev[zl]);
+    for (int zl = 0; zl < nz; ++zl) {
+        dag_levels(in, in.lists[zl], ns, lvl[zl], nlev[zl]);
+        if (xy && !H->env.no_level_split) split_wide_levels(in.lists[zl], lvl[zl], nlev[zl], std::max(1, H->env.level_split_min));
+    }
 
     // ---- 3. value arena layout ----
     // own slots: [L: zl 0 (level 0 | level 1 | ...) | zl 1 ... ][U: same order] -> one contiguous range per (zl, level) and
@@ -659,8 +695,15 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         if (pass == 0) hs.nnzL = cur; else hs.nnzU = cur - hs.nnzL;
     }
     H->own_len = cur;
-    // scratch sizes (max over levels): remote L + remote U slots; diagonal blocks (own staging + received)
-    int64_t rmax = 0, dmax = 0;
+    // scratch sizes: remote L + remote U slots of the level in flight, in NB copies by level modulo NB, each as large as the largest level
+    // of ITS class (round 3: two copies of the overall maximum); diagonal blocks (own staging + received), two copies by level parity.
+    // NB = 3 where K-fused pairs may form on the layer: the received panels of a deferred supernode of level l are read again by its
+    // partner's tiles at level l + 1, so they must outlive the exchange of level l + 2 -- with three copies the exchange of level m
+    // overwrites level m - 3, whose last readers are the tiles of level m - 2: exactly what panel(m) waits for already.
+    const bool xy_fuse = xy && !H->env.no_fuse && !H->opt.deterministic && !H->z;
+    const int NB = xy_fuse ? 3 : 2;
+    H->xy_scratch_copies = xy ? NB : 0;
+    int64_t rmaxc[3] = {0, 0, 0}, dmax = 0;
     if (xy)
         for (int zl = 0; zl < nz; ++zl) {
             if (!in.z_active[zl]) continue;
@@ -672,12 +715,15 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
                     if (!u_own) rr += hs.uval_len[k];
                     if (l_own || u_own) dd += (int64_t) nsupc_of(hs, k) * nsupc_of(hs, k);
                 }
-                rmax = std::max(rmax, rr); dmax = std::max(dmax, dd);
+                const int cls = (int) (&nodes - &lev_nodes[zl][0]) % NB;
+                rmaxc[cls] = std::max(rmaxc[cls], rr); dmax = std::max(dmax, dd);
             }
         }
-    const int64_t rbase[2] = {cur, cur + rmax};
-    const int64_t dbase[2] = {cur + 2 * rmax, cur + 2 * rmax + dmax};
-    H->arena_len = cur + 2 * rmax + 2 * dmax;
+    const int64_t rtot = rmaxc[0] + rmaxc[1] + rmaxc[2];
+    const int64_t rbase[3] = {cur, cur + rmaxc[0], cur + rmaxc[0] + rmaxc[1]};
+    const int64_t dbase[2] = {cur + rtot, cur + rtot + dmax};
+    H->arena_len = cur + rtot + 2 * dmax;
+    H->xy_scratch_len = rtot;
 
     // ---- 4. per-level exchange plan + offsets of the remote slots / scratch diagonal blocks ----
     H->sched.assign(nz, LevelSched());
@@ -726,7 +772,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
             }
             if (llen) for (int c2 = 0; c2 < g.Pc; ++c2) if (c2 != g.c) X.ps.push_back({g.rank_of(g.r, c2, g.z), lfirst, llen});
             if (ulen) for (int r2 = 0; r2 < g.Pr; ++r2) if (r2 != g.r) X.ps.push_back({g.rank_of(r2, g.c, g.z), ufirst, ulen});
-            int64_t roff = rbase[par];
+            int64_t roff = rbase[l % NB];
             for (int c2 = 0; c2 < g.Pc; ++c2) {
                 if (c2 == g.c) continue;
                 int64_t len = 0;
@@ -772,6 +818,23 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     // ---- 5. block tables, tiles ----
     int rc = build_tables(*H, t);
     if (rc) return rc;
+    if (xy_gemm_panels(*H)) {
+        // Linv / Uinv stores.  The diagonal OWNER keeps its pair for the triangular solves; the row / column peers of a diagonal block need
+        // theirs only between full_inv(l) and panel_gemm(l) of the block's own level -- two consecutive launches on the panel stream -- so all
+        // peer pairs of a level share ONE scratch region behind the owners' (round 3 kept every peer's pair for the lifetime of the handle:
+        // 1.0 GB beside 2.2 GB of factor values on the off-diagonal ranks of a 2 x 2 x 2 grid at 100^3, profiles/r04_grid_footprint.txt)
+        int64_t tot = 0, pmax = 0;
+        for (int k = 0; k < ns; ++k)
+            if (hs.present[k] && (t.sn_flags[k] & SNF_OWN_DIAG)) { t.sn_inv[k] = tot; tot += (int64_t) 2 * nsupc_of(hs, k) * nsupc_of(hs, k); }
+        for (int zl = 0; zl < nz; ++zl)
+            for (auto &nodes : lev_nodes[zl]) {
+                int64_t off = 0;
+                for (int k : nodes)
+                    if (hs.present[k] && (t.sn_flags[k] & SNF_HAS_DIAG) && !(t.sn_flags[k] & SNF_OWN_DIAG)) { t.sn_inv[k] = tot + off; off += (int64_t) 2 * nsupc_of(hs, k) * nsupc_of(hs, k); }
+                pmax = std::max(pmax, off);
+            }
+        t.inv_total = tot + pmax;
+    }
     for (int k = 0; k < ns; ++k) {
         if (!hs.present[k]) continue;
         // the owner factors the diagonal block in place at the top of its own L slot; its column / row peers read the image
@@ -900,8 +963,14 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     rc = eng::setup();
     if (rc) return rc;
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
-    const size_t idxb = (hs.lidx.size() + 3 * hs.uidx.size()) * sizeof(int);
-    H->st.bytes_device = (int64_t) ((size_t) H->arena_len * esz + idxb + (size_t) (t.dinv_total + t.inv_total) * 8);
+    // everything this handle allocated on the device: the value arena, the inverse stores and every uploaded table (index images, block / tile
+    // tables, tile lists, unit lists and records, pair maps; round 3 counted the index images only)
+    const size_t tables = upload_bytes() - upload_mark;
+    H->st.bytes_device = (int64_t) ((size_t) H->arena_len * esz + tables + (size_t) (t.dinv_total + t.inv_total) * 8);
+    if (getenv("SLUAMD_PLAN_DEBUG"))
+        fprintf(stderr, "[sluamd_plan] rank (%d,%d,%d): own values %.3f GB, exchange scratch %.3f GB (%d copies), diagonal scratch + own tail %.3f GB, inverses %.3f GB, "
+                        "tables %.3f GB, levels %d, fused pairs %d\n", g.r, g.c, g.z, esz * (double) H->own_len / 1e9, esz * (double) H->xy_scratch_len / 1e9, H->xy_scratch_copies,
+                esz * (double) (H->arena_len - H->own_len - H->xy_scratch_len) / 1e9, 8.0 * (double) (t.dinv_total + t.inv_total) / 1e9, tables / 1e9, H->st.num_levels, H->fused_pairs);
     return 0;
 }
 

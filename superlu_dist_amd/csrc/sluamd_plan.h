@@ -31,10 +31,12 @@ struct HostTables {
     std::vector<uint8_t> sn_big;   // 1: supernode uses the 128x128 Schur tile configuration
 };
 
+inline size_t &upload_bytes() { static thread_local size_t b = 0; return b; }   // bytes of the tables this thread uploaded (handle creation runs on one thread)
 template <class Tv>
 static int upload(std::vector<void *> &keep, const std::vector<Tv> &h, Tv **d)
 {
     size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(Tv);
+    upload_bytes() += bytes;
     HIPCHK(hipMalloc((void **) d, bytes));
     keep.push_back(*d);
     if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(Tv), hipMemcpyHostToDevice));

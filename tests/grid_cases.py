@@ -133,8 +133,9 @@ def check_fixture_on_one_rank_comm(g, comm):
     h.destroy()
 
 
-def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False, make_comms=None):
-    """Any CSR matrix (unpivoted LU must be stable for it) through the own pipeline on a Pr x Pc x Pz grid."""
+def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False, make_comms=None, stats_out=None):
+    """Any CSR matrix (unpivoted LU must be stable for it) through the own pipeline on a Pr x Pc x Pz grid.  stats_out: list that
+    receives every rank's sluamd_stats_t (after the factorisation) for assertions on the plan (levels, K-fused pairs)."""
     Pr, Pc, Pz = grid
     P = Pr * Pc * Pz
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, nrhs)
@@ -155,6 +156,8 @@ def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, 
     def rank_body(rank):
         h = grid3d.GridHandle.from_symbolic(symb, v, comms[rank], sn_tree)
         info = h.pdgstrf3d(0.0)
+        if stats_out is not None:
+            stats_out.append(dict(h.stats(), rank=rank))
         y = h.pdgstrs3d(xp)
         # distributed form (sluamd_pdgstrs3d_dist: pdReDistribute3d_B_to_X / X_to_B inside): my rows of b in, my rows of x out
         f0, f1 = (int(cuts[rank]), int(cuts[rank + 1])) if rank < nl0 else (0, 0)

@@ -137,6 +137,35 @@ def test_grid_drivers(sched, grid, mode, seed):
     _sched(sched, 0)
 
 
+@pytest.mark.parametrize("grid", [(2, 2, 1), (2, 1, 2)])
+@pytest.mark.parametrize("mode,seed", [(1, 3), (2, 1), (3, 5)])
+@pytest.mark.parametrize("stream_ordered", [False, True])
+def test_xy_layers_with_fused_pairs_and_cut_levels(sched, monkeypatch, grid, mode, seed, stream_ordered):
+    """Round 4 on XY layers: K-fused chain pairs (a deferred supernode's RECEIVED panels are read again by its partner's tiles one level
+    later: three scratch copies by level modulo 3, and the exchange of level m still has to wait for the bulk of level m - 2 -- deleting
+    that wait fails this test, scripts/stream_order_mutations.sh) and wide DAG levels cut into sub-levels of <= 1/4 of the largest one
+    (SLUAMD_LEVEL_SPLIT_MIN lowered so that the 28^3 tree is cut), under the adversarial scheduler over both in-process transports."""
+    monkeypatch.setenv("SLUAMD_LEVEL_SPLIT_MIN", "16")
+    N = 28
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(N)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    st = []
+    _sched(sched, mode, seed)
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=2, relax=64, maxsup=128, refactor=(mode == 1), stats_out=st,
+                                    make_comms=grid_cases.stream_ordered_comms if stream_ordered else None)
+    _sched(sched, 0)
+    assert max(s["reserved_i"] for s in st) >= 2           # K-fused pairs formed on the XY layer
+    monkeypatch.setenv("SLUAMD_NO_LEVEL_SPLIT", "1")
+    st0 = []
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=64, maxsup=128, stats_out=st0)
+    a = {s["rank"]: s for s in st}; b = {s["rank"]: s for s in st0}
+    assert all(a[r]["num_levels"] > b[r]["num_levels"] for r in a)                   # the leaf levels were cut (on every layer's forests) ...
+    assert sum(a[r]["bytes_device"] for r in a) < sum(b[r]["bytes_device"] for r in a)    # ... and the exchange scratch shrank with them
+
+
 @pytest.mark.parametrize("sched_env", ["1,11", "2,1", "3,4"])
 def test_reference_fixtures_under_the_scheduler(sched_env):
     """The per-rank parity tests against the reference's recorded grids (1x1x2, 2x1x1, 2x2x2 golden fixtures, own pipeline on seven
