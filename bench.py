@@ -307,6 +307,10 @@ def main():
                 raise SystemExit(f"bench.py: {N}^3 does not fit a {grid[0]}x{grid[1]}x{grid[2]} grid of {HBM_BYTES / 1e9:.0f} GB GPUs: the fullest rank stores "
                                  f"{vals.max() * 8 / 1e9:.1f} GB of factor values ({rep.max() * 8 / 1e9:.1f} GB of them ancestor panels replicated along Z), "
                                  f"~{need / 1e9:.0f} GB with scratch and tables; nnz(L+U) = {(symb.nnzL + symb.nnzU) * 8 / 1e9:.0f} GB in total")
+            if need > 0.7 * HBM_BYTES and "SLUAMD_NO_TILE_MAPS" not in os.environ:
+                # the per-tile records of the Schur kernel are an accelerator (2-4 ms at 100^3) that costs 20-29 % of the factor bytes: at sizes that
+                # fill the device they stay off (bench.py --gpus 8 --n 300 picks this by itself)
+                os.environ["SLUAMD_NO_TILE_MAPS"] = "1"
             if dist_backend == "rccl":
                 if "comm" not in comm_cache:
                     comm_cache["comm"] = grid3d.rccl_comm(dist, *grid, local_rank)

@@ -174,6 +174,14 @@ typedef struct sluamd_symb_s *sluamd_symb_t;
  * roles of sp_ienv_dist(2) / sp_ienv_dist(3) (sp_ienv.c:95-110). */
 int sluamd_dsymbfact(sluamd_symb_t *s, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
                      const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out);
+/* The same producer for UNSYMMETRIC patterns with the reference's own supernode rules (symbfact.c:83-200: relax_snode :221-265, the
+ * T2 / subset / maxsup boundary test of column_dfs :598-672): the exact structure of L and U of Pc A Pc^T under elimination without
+ * pivoting, U as per-column skyline segments -- the store the reference's symbfact + pddistribute3d build for the same perm_c, relax
+ * (sp_ienv_dist(2)) and maxsup (sp_ienv_dist(3)): xsup, every L block's row set and every Ufstnz entry agree (tests/test_symbolic_parity.py).
+ * The result feeds the same consumers as sluamd_dsymbfact (sluamd_symb_view, sluamd_ddistribute_host, sluamd_dCreateLUHandleFromSymb[Grid],
+ * sluamd_symb_partition, sluamd_symb_grid_footprint). */
+int sluamd_dsymbfact_unsym(sluamd_symb_t *s, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                           const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out);
 /* Fill-reducing ordering for matrices without geometry (the role of get_perm_c / METIS in the reference,
  * SRC/prec-independent/get_perm_c.c): nested dissection of the pattern of A + A^T by BFS level structures; perm_c[old] = new,
  * to be passed to sluamd_dsymbfact.  leaf = component size below which no further separator is sought (<= 0: 64). */

@@ -33,8 +33,9 @@ if create_only:
         ratio = st["bytes_device"] / (vals[r] * 8)
         worst = max(worst, ratio)
         print(f"  rank {r}: predicted values {vals[r] * 8 / 1e9:7.3f} GB (Z replicas {rep[r] * 8 / 1e9:6.3f} GB)  bytes_device {st['bytes_device'] / 1e9:7.3f} GB  ratio {ratio:.3f}  "
-              f"levels {st['num_levels']} fused pairs {st['reserved_i']}")
-    print(f"  worst allocated / values = {worst:.3f}")
+              f"levels {st['num_levels']} fused pairs {st['reserved_i']} planned Schur tile executions {st['schur_tiles']}")
+        tiles = tiles + st["schur_tiles"] if r else st["schur_tiles"]
+    print(f"  worst allocated / values = {worst:.3f}; planned Schur tile executions, sum over ranks = {tiles}")
     sys.exit(0)
 xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
 xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b

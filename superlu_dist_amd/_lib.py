@@ -43,7 +43,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "sluamd_default_options", "sluamd_dCreateLUHandle", "sluamd_dSetValues", "sluamd_pdgstrf3d",
     "sluamd_dCopyLU2Host", "sluamd_pdgstrs3d", "sluamd_pdgstrs3d_dev", "sluamd_pdgstrs3d_dist", "sluamd_pzgstrs3d_dist", "sluamd_dDestroyLUHandle",
-    "sluamd_get_stats", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_order_nd", "sluamd_symb_info",
+    "sluamd_get_stats", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_dsymbfact_unsym", "sluamd_order_nd", "sluamd_symb_info",
     "sluamd_symb_view", "sluamd_symb_grid_footprint", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
     "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
     "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",
@@ -75,6 +75,7 @@ def bind(L):
     L.sluamd_default_options.restype = None
     L.sluamd_comm_destroy.restype = None
     L.sluamd_dsymbfact.argtypes = [C.POINTER(C.c_void_p), C.c_int64, P_int, P_int, P_int, C.c_int32, C.c_int32, P_int]
+    L.sluamd_dsymbfact_unsym.argtypes = L.sluamd_dsymbfact.argtypes
     L.sluamd_order_nd.argtypes = [C.c_int64, P_int, P_int, C.c_int32, P_int]
     L.sluamd_symb_info.argtypes = [C.c_void_p, P_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), P_dbl]

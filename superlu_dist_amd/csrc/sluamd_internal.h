@@ -78,6 +78,13 @@ struct Symb {
     std::vector<int> supno;         // [n] column -> supernode
     std::vector<int64_t> srow_off;  // [nsupers+1] off-diagonal structure (sorted global rows > last column)
     std::vector<int> srows;
+    // unsymmetric structures (sluamd_dsymbfact_unsym; empty for the symmetric-pattern producer, whose U mirrors srows with full segments):
+    // per block row the columns that hold a segment (ascending), its first nonzero row and its value offset inside the row's skyline;
+    // supernodal parent in the etree of A + A^T (forest partition)
+    std::vector<int64_t> ucol_off;  // [nsupers+1]
+    std::vector<int> ucol_col, ucol_fnz;
+    std::vector<int64_t> ucol_voff;
+    std::vector<int> sn_parent;
     double flops = 0;
 };
 
@@ -244,7 +251,7 @@ struct Handle {
         int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
-        int level_split_min = 1024;  // SLUAMD_LEVEL_SPLIT_MIN: levels of at most this many supernodes are never cut (tests lower it)
+        int level_split_min = 4096;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
         bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,

@@ -30,7 +30,7 @@ static void dag_levels(const SlotInput &in, const std::vector<int> &list, int ns
 // scratch is as large as the LARGEST level -- the leaf level of a nested-dissection tree, tens of thousands of independent small
 // supernodes (100^3: 9 142 of 10^5 supernodes).  The supernodes of one level are independent, so a level may be cut into
 // consecutive sub-levels (ascending supernode id) without touching any dependency: levels with more than
-// cap = max(1024 [SLUAMD_LEVEL_SPLIT_MIN], ceil(largest level / 4)) supernodes are exchanged in sub-batches of at most `cap` (<= 1/4 of the largest level),
+// cap = ceil(largest level / 4) supernodes (forests whose largest level has at least 4 x 4096 [SLUAMD_LEVEL_SPLIT_MIN] of them: 150^3 and up) are exchanged in sub-batches of at most `cap` (<= 1/4 of the largest level),
 // and the look-ahead schedule pipelines the sub-batches like any other levels.  The rule reads only the forest's global node lists and
 // levels (identical on every rank of the layer), so all ranks cut alike.  (leaf-level remote-panel scratch in
 // <= 1/4-level sub-batches; the reference keeps every received panel of its look-ahead window, dtreeFactorization.c:295-716.)
@@ -40,6 +40,7 @@ static void split_wide_levels(const std::vector<int> &list, std::vector<int> &lv
     std::vector<int> cnt(nlevels, 0);
     for (int k : list) cnt[lvl[k]]++;
     const int nmax = *std::max_element(cnt.begin(), cnt.end());
+    if (nmax < 4 * min_cap) return;        // small forests: the scratch is small and every extra level costs two exchange phases of latency
     const int cap = std::max(min_cap, (nmax + 3) / 4);
     std::vector<int> first(nlevels + 1, 0), per(nlevels, 1);        // new id of the first sub-level of every level; sub-level size
     for (int l = 0; l < nlevels; ++l) {
@@ -959,6 +960,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         T.fuse_prev = p0; T.defer = p1; T.pair_roff = p2; T.pair_coff = p3; T.pair_rowmap = p4; T.pair_colinfo = p5;
     }
     H->st.reserved_i = H->fused_pairs;   // K-fused supernode pairs (diagnostic)
+    H->st.schur_tiles = 0;               // until the first factorisation: the PLANNED tile executions of one factorisation (list schedules)
+    for (auto &S : H->sched) H->st.schur_tiles += (int64_t) S.ulist.size();
     HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
     rc = eng::setup();
     if (rc) return rc;

@@ -49,35 +49,22 @@ void build_graph(int64_t n, const int *rowptr, const int *colind, const int *per
         }
 }
 
-}  // namespace
-
-extern "C" {
-
-int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
-                     const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out)
+// perm_c -> validated permutation composed with a postorder of the elimination tree of Pc (A + A^T) Pc^T (what sp_colorder does for the
+// reference, sp_colorder.c:137-166: sp_symetree_dist + postorder), the tree in the final labels, and the symmetric adjacency in the final labels
+static int order_and_etree(int64_t n, const int *rowptr, const int *colind, const int *perm_c, std::vector<int> &perm, std::vector<int> &parent,
+                           Graph &g, int *perm_c_out, const std::function<void(const char *)> &lap)
 {
-    if (!out || n <= 0 || !rowptr || !colind) { set_error("bad symbfact arguments"); return SLUAMD_EINVAL; }
-    if (maxsup < 1) maxsup = 256;
-    if (maxsup > 512) maxsup = 512;  // MAX_SUPER_SIZE, superlu_defs.h:154
-    if (relax < 1) relax = 1;
-    if (relax > maxsup) relax = maxsup;
-    double amalg_frac = 0.05;  // tolerated explicit-zero fraction when amalgamating along etree chains
-    if (const char *e = getenv("SLUAMD_AMALG_FRAC")) amalg_frac = atof(e);
-    std::vector<int> perm(n);
+    perm.resize(n);
     if (perm_c) std::copy(perm_c, perm_c + n, perm.begin()); else std::iota(perm.begin(), perm.end(), 0);
     {   // validate permutation
         std::vector<char> seen(n, 0);
         for (int64_t i = 0; i < n; ++i) { if (perm[i] < 0 || perm[i] >= n || seen[perm[i]]) { set_error("perm_c is not a permutation"); return SLUAMD_EINVAL; } seen[perm[i]] = 1; }
     }
-    Graph g;
-    static const bool timing = getenv("SLUAMD_SYMB_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_prev = now();
-    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[sluamd_dsymbfact] %-28s %.2f s\n", what, t - t_prev); t_prev = t; } };
     build_graph(n, rowptr, colind, perm.data(), g);
     lap("graph");
     // ---- elimination tree (Liu, path compression) ----
-    std::vector<int> parent(n, -1), anc(n, -1);
+    parent.assign(n, -1);
+    std::vector<int> anc(n, -1);
     for (int j = 0; j < n; ++j)
         for (int64_t e = g.up_off[j]; e < g.up_off[j + 1]; ++e) {
             int i = g.up[e];
@@ -116,6 +103,30 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     lap("etree + postorder");
     build_graph(n, rowptr, colind, perm.data(), g);  // adjacency in final labels
     lap("graph (final labels)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                     const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out)
+{
+    if (!out || n <= 0 || !rowptr || !colind) { set_error("bad symbfact arguments"); return SLUAMD_EINVAL; }
+    if (maxsup < 1) maxsup = 256;
+    if (maxsup > 512) maxsup = 512;  // MAX_SUPER_SIZE, superlu_defs.h:154
+    if (relax < 1) relax = 1;
+    if (relax > maxsup) relax = maxsup;
+    double amalg_frac = 0.05;  // tolerated explicit-zero fraction when amalgamating along etree chains
+    if (const char *e = getenv("SLUAMD_AMALG_FRAC")) amalg_frac = atof(e);
+    std::vector<int> perm, parent;
+    Graph g;
+    static const bool timing = getenv("SLUAMD_SYMB_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[sluamd_dsymbfact] %-28s %.2f s\n", what, t - t_prev); t_prev = t; } };
+    if (int rc = order_and_etree(n, rowptr, colind, perm_c, perm, parent, g, perm_c_out, lap)) return rc;
     // ---- subtree sizes, child counts, relaxed subtree roots ----
     std::vector<int> sz(n, 1), nchild(n, 0);
     for (int j = 0; j < n; ++j) if (parent[j] != -1) { sz[parent[j]] += sz[j]; nchild[parent[j]]++; }
@@ -288,6 +299,217 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     return 0;
 }
 
+// ---- unsymmetric-pattern symbolic factorisation with the reference's supernode rules ----------------
+// What symbfact() computes for the reference (SRC/prec-independent/symbfact.c:83-200): the EXACT structure of L and U of
+// A1 = Pc A Pc^T under elimination without pivoting -- struct((L + U)(:, j)) = the rows reachable from struct(A1(:, j)) through the
+// columns of L to the left of j -- L by columns and U as per-column segments inside supernodes (first nonzero row of the segment; the
+// rest of the supernode's rows below it are nonzero because the diagonal block of L is dense), with the supernode partition of
+//   relax_snode (symbfact.c:221-265): maximal etree subtrees walked up from a leaf while the parent has < relax descendants;
+//   column_dfs's boundary test (:598-672): column j continues the supernode of j - 1 iff struct(L(:, j)) is a subset of what column
+//     j - 1 marked, |struct(L(:, j))| = |struct(L(:, j - 1))| - 1 (T2_SUPER) and the supernode has fewer than maxsup columns.
+// The algorithm below is our own statement of that reach: supernode-level traversal over sorted row lists, symmetric pruning
+// (Eisenstat-Liu: once L(j, s) and U(s, j) are both nonzero the traversal of supernode s may stop at row j, a PREFIX of its sorted
+// list), no depth-first bookkeeping (the order of a column's segments is not part of the store).  The result is the reference's
+// stored structure for the same perm_c / relax / maxsup: xsup, the row sets of every L block, every Ufstnz entry -- pinned by
+// tests/test_symbolic_parity.py against the structures recorded from the real symbfact (tests/golden/*.npz).
+int sluamd_dsymbfact_unsym(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
+                           const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out)
+{
+    if (!out || n <= 0 || !rowptr || !colind) { set_error("bad symbfact arguments"); return SLUAMD_EINVAL; }
+    if (maxsup < 1) maxsup = 256;
+    if (maxsup > 512) maxsup = 512;  // MAX_SUPER_SIZE, superlu_defs.h:154
+    if (relax < 1) relax = 1;
+    std::vector<int> perm, parent;
+    Graph g;
+    static const bool timing = getenv("SLUAMD_SYMB_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[sluamd_dsymbfact_unsym] %-28s %.2f s\n", what, t - t_prev); t_prev = t; } };
+    if (int rc = order_and_etree(n, rowptr, colind, perm_c, perm, parent, g, perm_c_out, lap)) return rc;
+    g = Graph();
+    // columns of A1 (unsymmetric pattern, final labels)
+    std::vector<int64_t> acol(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) acol[perm[colind[e]] + 1]++;
+    for (int64_t j = 0; j < n; ++j) acol[j + 1] += acol[j];
+    std::vector<int> arow(acol[n]);
+    {
+        std::vector<int64_t> fillp(acol.begin(), acol.end() - 1);
+        for (int64_t i = 0; i < n; ++i) for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) arow[fillp[perm[colind[e]]]++] = perm[i];
+    }
+    // relaxed supernodes (relax_snode)
+    std::vector<int> desc(n + 1, 0), relax_end(n, -1);
+    for (int j = 0; j < n; ++j) if (parent[j] != -1) desc[parent[j]] += desc[j] + 1;
+    for (int j = 0; j < n;) {
+        int p = parent[j];
+        const int f = j;
+        while (p != -1 && desc[p] < relax) { j = p; p = parent[j]; }
+        relax_end[f] = j;
+        ++j;
+        while (j < n && desc[j] != 0) ++j;
+    }
+    auto *sy = new Symb();
+    HostStruct &hs = sy->hs;
+    hs.n = n;
+    sy->supno.assign(n, -1);
+    std::vector<std::vector<int>> lrows;          // per supernode: sorted struct of its first column (relaxed: union), diagonal rows included
+    std::vector<int> sfirst;                      // first column of every supernode
+    std::vector<int> prune_end;                   // traversal bound inside lrows[s] (symmetric pruning)
+    struct USeg { int col, fnz; };
+    std::vector<std::vector<USeg>> useg;          // per supernode (block row): segments of the columns to its right, ascending column
+    std::vector<int> mark(n, -1), segfnz, seglist, Lj, stack;
+    int prev_size = 0;                            // |struct(L(:, j - 1))| as the boundary test counts it
+    std::vector<uint8_t> relaxed;                 // per supernode: made by relax_snode
+    auto new_snode = [&](int first) { sfirst.push_back(first); lrows.emplace_back(); prune_end.push_back(0); useg.emplace_back(); segfnz.push_back(-1); relaxed.push_back(0); return (int) sfirst.size() - 1; };
+    for (int j = 0; j < n;) {
+        if (relax_end[j] >= 0) {                  // a relaxed supernode [j, k]: union of the columns' structures (snode_dfs, :283-377)
+            const int k = relax_end[j], s = new_snode(j);
+            relaxed[s] = 1;
+            std::vector<int> &R = lrows[s];
+            for (int c = j; c <= k; ++c)
+                for (int64_t e = acol[c]; e < acol[c + 1]; ++e) { const int r = arow[e]; if (mark[r] != k) { mark[r] = k; R.push_back(r); } }
+            std::sort(R.begin(), R.end());
+            if (R.empty() || R[0] < j) { delete sy; set_error("relaxed supernode with an entry above its diagonal block (perm_c is not an etree postorder)"); return SLUAMD_ESTRUCT; }
+            for (int c = j; c <= k; ++c) {
+                sy->supno[c] = s;
+                if (!std::binary_search(R.begin(), R.end(), c)) { delete sy; set_error("zero diagonal in the symbolic factorisation"); return SLUAMD_ESTRUCT; }
+            }
+            prune_end[s] = (int) R.size();
+            prev_size = (int) R.size();
+            j = k + 1;
+            continue;
+        }
+        // ---- one column: reach of struct(A1(:, j)) ----
+        const int cur = sfirst.empty() ? -1 : (int) sfirst.size() - 1;      // supernode of column j - 1
+        Lj.clear(); seglist.clear(); stack.clear();
+        bool subset = true;
+        auto visit = [&](int r) {
+            const int old = mark[r];
+            if (old == j) return;
+            if (r >= j) {
+                mark[r] = j;
+                Lj.push_back(r);
+                if (old != j - 1) subset = false;
+            } else {
+                const int s = sy->supno[r];
+                // a relaxed supernode is entered through the copy of its WHOLE row list (diagonal rows included, snode_dfs :353-366), whose
+                // already eliminated rows lower the first nonzero to the supernode's first column: its segments are always full height
+                const int r0 = relaxed[s] ? sfirst[s] : r;
+                if (segfnz[s] < 0) { segfnz[s] = r0; seglist.push_back(s); stack.push_back(s); }
+                else if (r0 < segfnz[s]) segfnz[s] = r0;
+            }
+        };
+        for (int64_t e = acol[j]; e < acol[j + 1]; ++e) {
+            visit(arow[e]);
+            while (!stack.empty()) {
+                const int s = stack.back(); stack.pop_back();
+                const std::vector<int> &R = lrows[s];
+                // rows of s beyond its own columns: closed supernodes start behind their diagonal rows, the one still growing at row j
+                const int last = (s == cur) ? j - 1 : ((s + 1 < (int) sfirst.size()) ? sfirst[s + 1] - 1 : j - 1);
+                const int b = (int) (std::upper_bound(R.begin(), R.end(), last) - R.begin());
+                const int e2 = (s == cur) ? (int) R.size() : prune_end[s];
+                for (int q = b; q < e2; ++q) visit(R[q]);
+            }
+        }
+        if (std::find(Lj.begin(), Lj.end(), j) == Lj.end()) { delete sy; set_error("zero diagonal in the symbolic factorisation"); return SLUAMD_ESTRUCT; }
+        // ---- supernode boundary (column_dfs :598-672) ----
+        bool cont = cur >= 0 && subset && (int) Lj.size() == prev_size - 1 && (j - sfirst[cur]) < maxsup;
+        int sj;
+        if (cont) sj = cur;
+        else {
+            sj = new_snode(j);
+            std::sort(Lj.begin(), Lj.end());
+            lrows[sj] = Lj;
+            prune_end[sj] = (int) Lj.size();
+        }
+        sy->supno[j] = sj;
+        prev_size = (int) Lj.size();
+        // ---- U segments + symmetric pruning ----
+        for (int s : seglist) {
+            if (s != sj) {
+                useg[s].push_back({j, segfnz[s]});
+                const std::vector<int> &R = lrows[s];
+                const int pe = prune_end[s];
+                const int q = (int) (std::upper_bound(R.begin(), R.begin() + pe, j) - R.begin());
+                if (q > 0 && R[q - 1] == j && q < pe) prune_end[s] = q;       // L(j, s) != 0 and U(s, j) != 0: nothing beyond row j needs s any more
+            }
+            segfnz[s] = -1;
+        }
+        ++j;
+    }
+    lap("reach + supernodes");
+    const int ns = (int) sfirst.size();
+    hs.nsupers = ns;
+    hs.xsup.assign(sfirst.begin(), sfirst.end());
+    hs.xsup.push_back((int) n);
+    // ---- stores in the reference formats ----
+    hs.lidx_off.assign(ns + 1, 0); hs.uidx_off.assign(ns + 1, 0); hs.lval_off.assign(ns + 1, 0); hs.uval_off.assign(ns + 1, 0);
+    sy->srow_off.assign(1, 0);
+    sy->ucol_off.assign(1, 0);
+    sy->sn_parent.assign(ns, -1);
+    double flops = 0;
+    for (int k = 0; k < ns; ++k) {
+        const int nsupc = hs.xsup[k + 1] - hs.xsup[k], klst = hs.xsup[k + 1];
+        const std::vector<int> &R = lrows[k];
+        if ((int) R.size() < nsupc || R[nsupc - 1] != klst - 1) { delete sy; set_error("supernode without its full diagonal block"); return SLUAMD_ESTRUCT; }
+        const int pl = parent[klst - 1];
+        sy->sn_parent[k] = pl >= 0 ? sy->supno[pl] : -1;
+        // L: blocks by supernode of the row (ascending, rows sorted), diagonal block first
+        std::vector<int> li(BC_HEADER, 0);
+        int nblk = 0;
+        for (size_t e = 0; e < R.size();) {
+            const int gb = sy->supno[R[e]];
+            size_t f = e;
+            while (f < R.size() && sy->supno[R[f]] == gb) ++f;
+            li.push_back(gb); li.push_back((int) (f - e));
+            li.insert(li.end(), R.begin() + e, R.begin() + f);
+            ++nblk; e = f;
+        }
+        li[0] = nblk; li[1] = (int) R.size();
+        hs.lidx.insert(hs.lidx.end(), li.begin(), li.end());
+        hs.lidx_off[k + 1] = (int64_t) hs.lidx.size();
+        hs.lval_off[k + 1] = hs.lval_off[k] + (int64_t) R.size() * nsupc;
+        sy->srows.insert(sy->srows.end(), R.begin() + nsupc, R.end());
+        sy->srow_off.push_back((int64_t) sy->srows.size());
+        // U: blocks by supernode of the column, a first-nonzero row per column (klst: empty)
+        const std::vector<USeg> &U = useg[k];
+        int64_t unz = 0; double segsq = 0, segsum = 0;
+        if (!U.empty()) {
+            std::vector<int> ui(BR_HEADER, 0);
+            int nub = 0;
+            for (size_t e = 0; e < U.size();) {
+                const int jb = sy->supno[U[e].col], nsj = hs.xsup[jb + 1] - hs.xsup[jb];
+                size_t f = e;
+                const size_t h0 = ui.size();
+                ui.push_back(jb); ui.push_back(0);
+                ui.resize(ui.size() + nsj, klst);
+                int bn = 0;
+                while (f < U.size() && sy->supno[U[f].col] == jb) {
+                    ui[h0 + UB_DESCRIPTOR + (U[f].col - hs.xsup[jb])] = U[f].fnz;
+                    sy->ucol_col.push_back(U[f].col); sy->ucol_fnz.push_back(U[f].fnz); sy->ucol_voff.push_back(unz + bn);
+                    const int seg = klst - U[f].fnz;
+                    bn += seg; segsq += (double) seg * seg; segsum += seg;
+                    ++f;
+                }
+                ui[h0 + 1] = bn; unz += bn; ++nub; e = f;
+            }
+            ui[0] = nub; ui[1] = (int) unz; ui[2] = (int) ui.size();
+            hs.uidx.insert(hs.uidx.end(), ui.begin(), ui.end());
+        }
+        hs.uidx_off[k + 1] = (int64_t) hs.uidx.size();
+        hs.uval_off[k + 1] = hs.uval_off[k] + unz;
+        sy->ucol_off.push_back((int64_t) sy->ucol_col.size());
+        const double r = (double) R.size() - nsupc;
+        flops += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc + (double) nsupc * nsupc * r + segsq + 2.0 * r * segsum;
+    }
+    sy->flops = flops;
+    hs.nnzL = hs.lval_off[ns]; hs.nnzU = hs.uval_off[ns];
+    lap("index arrays");
+    sy->perm_c_final = perm;
+    hs.present.assign(ns, 1);
+    *out = reinterpret_cast<sluamd_symb_t>(sy);
+    return 0;
+}
+
 int sluamd_symb_info(sluamd_symb_t s, int32_t *nsupers, int64_t *nnzL, int64_t *nnzU, int64_t *lidx_len,
                      int64_t *uidx_len, double *flops)
 {
@@ -335,7 +557,10 @@ int sluamd_ddistribute_host(sluamd_symb_t s, const sluamd_int_t *rowptr, const s
     sy->lval.assign(hs.nnzL, 0.0); sy->uval.assign(hs.nnzU, 0.0);
     std::vector<int64_t> pos; std::vector<uint8_t> isu;
     compute_scatter_positions(*sy, hs, hs.n, rowptr, colind, perm_c_final ? perm_c_final : sy->perm_c_final.data(), nullptr, pos, isu);
-    for (size_t e = 0; e < pos.size(); ++e) (isu[e] ? sy->uval : sy->lval)[pos[e]] = nzval[e];
+    for (size_t e = 0; e < pos.size(); ++e) {
+        if (pos[e] < 0) { set_error("A entry outside the symbolic structure"); return SLUAMD_ESTRUCT; }
+        (isu[e] ? sy->uval : sy->lval)[pos[e]] = nzval[e];
+    }
     return 0;
 }
 
@@ -386,6 +611,14 @@ void compute_scatter_positions(const Symb &sy, const HostStruct &hs, int64_t n, 
                 const int64_t lr = (pi < hs.xsup[s + 1]) ? (pi - hs.xsup[s]) : nsupc + rank_in(s, pi);
                 pos[e] = hs.lval_off[s] + lr + (int64_t) (pj - hs.xsup[s]) * nsupr;
                 is_u[e] = 0;
+            } else if (!sy.ucol_off.empty()) {      // unsymmetric structure (sluamd_dsymbfact_unsym): skyline segment of column pj in block row r
+                const int r = sy.supno[pi];
+                const int *b = sy.ucol_col.data() + sy.ucol_off[r], *en = sy.ucol_col.data() + sy.ucol_off[r + 1];
+                const int *f = std::lower_bound(b, en, pj);
+                const int64_t q = sy.ucol_off[r] + (f - b);
+                if (f == en || *f != pj || pi < sy.ucol_fnz[q]) { pos[e] = -1; is_u[e] = 1; continue; }     // outside the symbolic structure: reported by the caller
+                pos[e] = hs.uval_off[r] + sy.ucol_voff[q] + (pi - sy.ucol_fnz[q]);
+                is_u[e] = 1;
             } else {
                 const int r = sy.supno[pi];
                 const int nr = hs.xsup[r + 1] - hs.xsup[r];
@@ -413,7 +646,8 @@ void partition_forests(const Symb &sy, int npdep, std::vector<int> &sn_tree)
         const int64_t r = sy.srow_off[k + 1] - sy.srow_off[k];
         const double s = hs.xsup[k + 1] - hs.xsup[k];
         w[k] += (2.0 / 3.0) * s * s * s + 2.0 * s * s * r + 2.0 * s * (double) r * r;
-        if (r > 0) { parent[k] = sy.supno[sy.srows[sy.srow_off[k]]]; child[parent[k]].push_back(k); }
+        if (!sy.sn_parent.empty()) { if (sy.sn_parent[k] >= 0) { parent[k] = sy.sn_parent[k]; child[parent[k]].push_back(k); } }   // unsymmetric structure: the etree of A + A^T
+        else if (r > 0) { parent[k] = sy.supno[sy.srows[sy.srow_off[k]]]; child[parent[k]].push_back(k); }
     }
     for (int k = 0; k < ns; ++k) if (parent[k] >= 0) w[parent[k]] += w[k];   // subtree weights (postorder: k < parent)
     struct Job { std::vector<int> roots; int tree, depth; };

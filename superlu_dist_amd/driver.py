@@ -87,7 +87,8 @@ def order_nd(n, rowptr, colind, leaf=64):
 class Symbolic:
     """sluamd_dsymbfact result (our symbfact_dist + pddistribute3d stand-in for a 1x1 layer)."""
 
-    def __init__(self, n, rowptr, colind, perm_c=None, relax=32, maxsup=256):
+    def __init__(self, n, rowptr, colind, perm_c=None, relax=32, maxsup=256, unsym=False):
+        """unsym=True: sluamd_dsymbfact_unsym -- the exact unsymmetric structure with the reference's supernode rules (symbfact.c)"""
         L = _lib.load()
         self.n = int(n)
         self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
@@ -95,8 +96,9 @@ class Symbolic:
         self.perm_c = np.empty(self.n, dtype=np.int32)
         pin = None if perm_c is None else np.ascontiguousarray(perm_c, dtype=np.int32)
         self._h = C.c_void_p()
-        _lib.check(L.sluamd_dsymbfact(C.byref(self._h), self.n, _pi(self.rowptr), _pi(self.colind),
-                                      None if pin is None else _pi(pin), relax, maxsup, _pi(self.perm_c)), "sluamd_dsymbfact")
+        fn = L.sluamd_dsymbfact_unsym if unsym else L.sluamd_dsymbfact
+        _lib.check(fn(C.byref(self._h), self.n, _pi(self.rowptr), _pi(self.colind),
+                      None if pin is None else _pi(pin), relax, maxsup, _pi(self.perm_c)), "sluamd_dsymbfact")
         ns = C.c_int32(); nl = C.c_int64(); nu = C.c_int64(); li = C.c_int64(); ui = C.c_int64(); fl = C.c_double()
         L.sluamd_symb_info(self._h, C.byref(ns), C.byref(nl), C.byref(nu), C.byref(li), C.byref(ui), C.byref(fl))
         self.nsupers, self.nnzL, self.nnzU, self.flops = ns.value, nl.value, nu.value, fl.value

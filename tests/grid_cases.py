@@ -133,7 +133,7 @@ def check_fixture_on_one_rank_comm(g, comm):
     h.destroy()
 
 
-def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False, make_comms=None, stats_out=None):
+def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, refactor=False, make_comms=None, stats_out=None, unsym_symb=False):
     """Any CSR matrix (unpivoted LU must be stable for it) through the own pipeline on a Pr x Pc x Pz grid.  stats_out: list that
     receives every rank's sluamd_stats_t (after the factorisation) for assertions on the plan (levels, K-fused pairs)."""
     Pr, Pc, Pz = grid
@@ -141,7 +141,7 @@ def check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=1, relax=16, maxsup=64, 
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, nrhs)
     x1, info1, _ = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=relax, maxsup=maxsup)
     assert info1 == 0
-    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup, unsym=unsym_symb)     # unsym_symb: the exact unsymmetric structure (reference rules)
     sn_tree = symb.partition(Pz) if Pz > 1 else None
     comms = (make_comms or grid3d.local_comms)(Pr, Pc, Pz)
     xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b

@@ -149,3 +149,14 @@ def test_own_pipeline_complex16_on_xy_layers(emul, grid):
 def test_own_pipeline_complex16_with_wide_supernodes_on_xy_layers(emul, grid):
     """... with supernodes of 257..512 columns refined into pieces that stay with the owners of their supernode."""
     grid_cases.check_own_pipeline_complex16(grid[2], N=18, leaf=64, relax=64, maxsup=512, Pr=grid[0], Pc=grid[1])
+
+
+@pytest.mark.parametrize("grid", [(1, 1, 1), (2, 1, 1), (2, 2, 1), (1, 1, 2), (2, 2, 2)])
+def test_unsymmetric_symbolic_structure_on_grids(emul, grid):
+    """sluamd_dsymbfact_unsym (exact unsymmetric structure, the reference's supernode rules) through the own pipeline on process grids:
+    device-side distribution into ragged skylines, XY block-cyclic slots, forests from the etree of A + A^T; solution against the
+    single-rank run on the symmetrised structure."""
+    from superlu_dist_amd import matgen
+    n, rp, ci, v = matgen.stencil3d_unsym(10, drop=0.35, seed=7)
+    perm = matgen.nd_perm_grid3d(10, 10, 10, leaf=8)
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=2, relax=12, maxsup=48, unsym_symb=True, refactor=True)
