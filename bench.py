@@ -462,6 +462,19 @@ def main():
                      "flops_per_launch": st["flops_schur_exact"] / max(1, stp["schur_launches"]),
                      "schur_ms": stp["t_schur_ms"], "panel_ms": stp["t_panel_ms"], "profiled_factor_ms": stp["t_factor_ms"]},
     }
+    # the same Schur time split by tile configuration: `roofline` above is ALL Schur launches against the MFMA peak (the number to compare across
+    # rounds); the 128 x 128 instantiation -- supernodes of >= 96 columns, the MFMA-bound part by SURVEY 8(d)'s own criterion (s_k >~ 120) -- and the
+    # 64 x 64 configuration of the narrow supernodes at the bottom of the tree (HBM / latency-bound: fraction of the HBM peak on its algorithmic bytes)
+    tb = stp.get("t_schur_big_ms", 0.0)
+    if world == 1 and tb > 0 and stp["t_schur_ms"] > tb:
+        fb, bb = st["flops_schur_exact_big"], st["schur_bytes_alg_big"]
+        ts = stp["t_schur_ms"] - tb
+        out["roofline"]["by_configuration"] = {
+            "k_schur<128,128,8>": {"bound": "mfma", "ms": tb, "flops": fb, "achieved": fb / (tb * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                   "frac": fb / (tb * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS},
+            "k_schur<64,64,4>": {"bound": "hbm", "ms": ts, "flops": st["flops_schur_exact"] - fb, "achieved_tflops": (st["flops_schur_exact"] - fb) / (ts * 1e-3) / 1e12,
+                                 "algorithmic_bytes": st["schur_bytes_alg"] - bb, "achieved": (st["schur_bytes_alg"] - bb) / (ts * 1e-3) / 1e9, "unit": "GB/s",
+                                 "frac": (st["schur_bytes_alg"] - bb) / (ts * 1e-3) / 1e9 / PEAK_HBM_GBS}}
     # second roofline: the triangular solve is HBM-bound, 8 B per stored factor entry per solve (nrhs = 1)
     esz = 16 if zwork else 8
     solve_bytes = esz * float(st["nnz_L"] + st["nnz_U"])

@@ -110,6 +110,12 @@ typedef struct sluamd_stats {
     int32_t solve_launches;    /* kernel launches of the last sluamd_pdgstrs3d (one right-hand-side chunk) */
     double  t_exchange_ms;     /* grid handles, profiling on: time of the XY panel-exchange phases ... */
     double  t_reduce_ms;       /* ... and of the Z ancestor reduction inside the last sluamd_pdgstrf3d */
+    /* the Schur update by tile configuration (round 4): k_schur<128,128,8> -- supernodes of >= 96 columns whose block pairs fill 128 x 128
+     * tiles, the MFMA-bound part -- against the 64 x 64 configuration of the narrow supernodes at the bottom of the tree (HBM / latency-bound,
+     * "MFMA-bound only when s_k >~ 120") */
+    double  t_schur_big_ms;        /* profiling on: HIP-event time of the 128 x 128 launches (part of t_schur_ms) */
+    double  flops_schur_exact_big; /* exact-segment flops of the supernodes that use that configuration (part of flops_schur_exact) */
+    double  schur_bytes_alg_big;   /* ... and their algorithmic destination bytes (part of schur_bytes_alg) */
 } sluamd_stats_t;
 
 typedef struct sluamd_lu_handle_s *sluamd_handle_t;

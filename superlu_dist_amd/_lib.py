@@ -37,7 +37,8 @@ class Stats(C.Structure):
                 ("num_levels", C.c_int32), ("num_launches", C.c_int32), ("tiny_pivots", C.c_int32),
                 ("reserved_i", C.c_int32), ("schur_launches", C.c_int64), ("schur_tiles", C.c_int64),
                 ("schur_bytes_alg", C.c_double), ("chain_units", C.c_int64), ("chain_levels", C.c_int32),
-                ("solve_launches", C.c_int32), ("t_exchange_ms", C.c_double), ("t_reduce_ms", C.c_double)]
+                ("solve_launches", C.c_int32), ("t_exchange_ms", C.c_double), ("t_reduce_ms", C.c_double),
+                ("t_schur_big_ms", C.c_double), ("flops_schur_exact_big", C.c_double), ("schur_bytes_alg_big", C.c_double)]
 
 
 EXPORTS = [

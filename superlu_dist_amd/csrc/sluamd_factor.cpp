@@ -103,6 +103,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
                      const int4 *ulist, int prio = 0, const int *tmaps = nullptr) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
+        if (H->profile) { if (H->ev_schur_big.size() <= H->ev_schur_used) H->ev_schur_big.resize(H->ev_schur_used + 1); H->ev_schur_big[H->ev_schur_used] = big ? 1 : 0; }
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
         if (H->z) eng::zschur(st, big ? 0 : 1, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0);     // complex16: k_schur on the real embedding
         else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0);
@@ -442,6 +443,10 @@ int run_factor(Handle *H, double thresh, int *info)
             fprintf(stderr, "SCHUR level %d pass %d big %d tiles %d max_nsupc %d ms %.4f\n", r.level, r.pass, r.big, r.ntiles, r.mx, ems);
         }
     H->st.t_schur_ms = H->profile ? ev_sum(H->ev_schur, H->ev_schur_used) : 0.0;
+    H->st.t_schur_big_ms = 0.0;
+    if (H->profile)
+        for (size_t i = 0; i < H->ev_schur_used && i < H->ev_schur_big.size(); ++i)
+            if (H->ev_schur_big[i]) { float ms = 0; hipEventElapsedTime(&ms, H->ev_schur[i].first, H->ev_schur[i].second); H->st.t_schur_big_ms += ms; }
     H->st.t_panel_ms = H->profile ? ev_sum(H->ev_panel, H->ev_panel_used) : 0.0;
     H->st.t_exchange_ms = H->profile ? ev_sum(H->ev_xchg, H->ev_xchg_used) : 0.0;     // XY panel-exchange phases (inside t_panel_ms)
     H->st.t_reduce_ms = H->profile ? ev_sum(H->ev_red, H->ev_red_used) : 0.0;         // Z ancestor reduction

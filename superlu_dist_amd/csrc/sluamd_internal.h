@@ -298,6 +298,7 @@ struct Handle {
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel, ev_xchg, ev_red;
     size_t ev_schur_used = 0, ev_panel_used = 0, ev_xchg_used = 0, ev_red_used = 0;
+    std::vector<uint8_t> ev_schur_big;     // parallel to ev_schur: the launch ran the 128 x 128 tile configuration
     struct SchurRec { int level, pass, big, ntiles, mx; };
     std::vector<SchurRec> schur_rec;   // SLUAMD_PROFILE_DUMP: one record per profiled Schur launch (parallel to ev_schur)
     sluamd_stats_t st{};

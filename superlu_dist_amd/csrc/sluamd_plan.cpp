@@ -80,6 +80,7 @@ static int build_tables(Handle &H, HostTables &t)
     auto &st = H.st;
     st.flops_schur_padded = st.flops_schur_exact = st.flops_panel = 0;
     st.schur_bytes_alg = 0;
+    st.flops_schur_exact_big = st.schur_bytes_alg_big = 0;
     for (int k = 0; k < ns; ++k) {
         const int nsupc = nsupc_of(hs, k), klst = hs.xsup[k + 1];
         t.sn_lval[k] = hs.lval_off[k]; t.sn_uval[k] = hs.uval_off[k];
@@ -194,11 +195,12 @@ static int build_tables(Handle &H, HostTables &t)
         st.flops_schur_padded += 2.0 * rrows * ldu * ncol_tot;
         st.schur_bytes_alg += 16.0 * rrows * ncol_tot;   // read-modify-write of every updated destination element
         st.flops_schur_exact += 2.0 * rrows * exact;
+        if (t.sn_big[k]) { st.flops_schur_exact_big += 2.0 * rrows * exact; st.schur_bytes_alg_big += 16.0 * rrows * ncol_tot; }
         if (fl & SNF_OWN_DIAG) st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc;
         if (l_own) st.flops_panel += (double) nsupc * nsupc * rrows;
         if (u_own) st.flops_panel += (double) nsupc * exact;
     }
-    if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; }   // complex multiply-add = 8 flop
+    if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; st.flops_schur_exact_big *= 4; st.schur_bytes_alg_big *= 2; }   // complex multiply-add = 8 flop
     H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu; H.h_flags = t.sn_flags; H.h_ldiag = t.sn_ldiag;
     return 0;
 }
