@@ -137,9 +137,8 @@ def test_grid_drivers(sched, grid, mode, seed):
     _sched(sched, 0)
 
 
-@pytest.mark.parametrize("grid", [(2, 2, 1), (2, 1, 2)])
-@pytest.mark.parametrize("mode,seed", [(1, 3), (2, 1), (3, 5)])
-@pytest.mark.parametrize("stream_ordered", [False, True])
+@pytest.mark.parametrize("grid,mode,seed,stream_ordered", [((2, 2, 1), 1, 3, False), ((2, 2, 1), 2, 1, False), ((2, 2, 1), 3, 5, True), ((2, 2, 1), 2, 1, True),
+                                                           ((2, 1, 2), 2, 1, False), ((2, 1, 2), 3, 5, True)])
 def test_xy_layers_with_fused_pairs_and_cut_levels(sched, monkeypatch, grid, mode, seed, stream_ordered):
     """Round 4 on XY layers: K-fused chain pairs (a deferred supernode's RECEIVED panels are read again by its partner's tiles one level
     later: three scratch copies by level modulo 3, and the exchange of level m still has to wait for the bulk of level m - 2 -- deleting
