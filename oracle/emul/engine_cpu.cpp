@@ -225,7 +225,9 @@ static void schur_t(const DevTables &T, const int *nodes, const int *prefix, int
         const int nr = R.z, nc = C.z;
         const int ib = T.lb_gid[lb], jb = T.ub_gid[ub];
         const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
-        const int *lsub = T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
+        // merged row tile (list entry with destination -3): rows of several L blocks, all of them with gid >= jb; global ids from the flat row map
+        const bool merged = ulist && ulist[bid].w == -3;
+        const int *lsub = merged ? T.lrow + T.sn_lrow[k] + R.w : T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
         const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
         acc.assign((size_t) nr * nc, V(0));
         int nprev = 0;
@@ -260,6 +262,30 @@ static void schur_t(const DevTables &T, const int *nodes, const int *prefix, int
                     }
                 }
             }
+        }
+        if (merged) {
+            // every row must belong to a block row >= jb and exist in panel jb (found by a LINEAR search of the whole panel: independent of the
+            // kernel's binary search and of the planner's sortedness test); the tile list entry must agree with the tables
+            const int2 ri = T.rt_info[ulist[bid].y];
+            const int4 ci = T.ct_info[ulist[bid].z];
+            if (ri.x != ib || ci.x != jb || ib < jb || ci.y != uix0 || ci.z != T.ub_stcol[ub] + C.y || R.w + nr > T.sn_nsupr[k]) { std::fprintf(stderr, "engine_cpu: merged tile entry disagrees with the block tables\n"); std::abort(); }
+            const int *prow = T.lrow + T.sn_lrow[jb];
+            const int pn = T.sn_nsupr[jb];
+            V *dst = val + T.sn_lval[jb];
+            bool all = true;
+            std::vector<int> pos(nr, -1);
+            for (int r = 0; r < nr; ++r) {
+                if (lsub[r] < T.xsup[jb]) { std::fprintf(stderr, "engine_cpu: merged tile row above its destination panel\n"); std::abort(); }
+                for (int q = 0; q < pn; ++q) if (prow[q] == lsub[r]) { pos[r] = q; break; }
+                all = all && pos[r] >= 0;
+            }
+            if (!all) { info[2] += 1; continue; }
+            for (int r = 0; r < nr; ++r)
+                for (int c = 0; c < nc; ++c) {
+                    const int jj = T.unzcol[uix0 + C.y + c];
+                    dst[pos[r] + (size_t) jj * pn] -= acc[r + (size_t) c * nr];
+                }
+            continue;
         }
         // destination lookup + scatter
         const bool ldest = ib >= jb;

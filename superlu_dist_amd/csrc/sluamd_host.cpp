@@ -39,6 +39,7 @@ void read_env(Handle::Env &e)
     e.no_lookahead = getenv("SLUAMD_NO_LOOKAHEAD") != nullptr;
     e.no_tile_maps = getenv("SLUAMD_NO_TILE_MAPS") != nullptr;
     e.no_level_split = getenv("SLUAMD_NO_LEVEL_SPLIT") != nullptr;
+    e.no_merge_tiles = getenv("SLUAMD_NO_MERGE_TILES") != nullptr;
     if (const char *v = getenv("SLUAMD_LEVEL_SPLIT_MIN")) e.level_split_min = atoi(v);
     e.no_fuse = getenv("SLUAMD_NO_FUSE") != nullptr;
     e.no_big_tiles = getenv("SLUAMD_NO_BIG_TILES") != nullptr;

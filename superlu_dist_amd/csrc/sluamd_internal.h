@@ -252,6 +252,7 @@ struct Handle {
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
         int level_split_min = 4096;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
+        bool no_merge_tiles = false; // SLUAMD_NO_MERGE_TILES: every (L block, U block) pair keeps its own Schur tiles (round 3)
         bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,

@@ -1190,7 +1190,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             R = T.rtile[u.y]; C = T.ctile[u.z];
             const int2 ri = T.rt_info[u.y];
             const int4 ci = T.ct_info[u.z];
-            ib = ri.x; jb = ci.x; lsub = T.lidx + ri.y; stc = ci.z;
+            ib = ri.x; jb = ci.x; stc = ci.z;
+            // merged row tile (destination -3): rows of SEVERAL L blocks, all with gid >= jb -> their global ids come from the slot's flat row map
+            lsub = (dblk == -3) ? T.lrow + T.sn_lrow[k] + R.w : T.lidx + ri.y;
         } else {
             const int ni = find_node(prefix, nn, bid);
             k = nodes[ni];
@@ -1239,21 +1241,41 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             }
             if (ln == 0) s_dinfo[0] = pos < 0 ? -1 : (ldest ? o + T.lbs_idx[o + pos] : o + pos);
         }
+        const bool merged = !Z && dblk == -3;
+        if (merged && tid == 0) s_dinfo[0] = 0;
         __syncthreads();
+        if (merged) {
+            // every row of the tile lands in panel jb (block rows ib >= jb): its position there = its rank in the panel's ascending row list
+            // (the planner merges only into panels whose rows ascend over the whole slot); a row the panel lacks voids the tile like a missing block
+            const int *prow = T.lrow + T.sn_lrow[jb];
+            const int pn = T.sn_nsupr[jb];
+            for (int t = tid; t < TMv; t += NT) {
+                int v = 0;
+                if (t < nr) {
+                    const int gr = lsub[t];
+                    int lo = 0, hi = pn;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (prow[mid] < gr) lo = mid + 1; else hi = mid; }
+                    if (lo < pn && prow[lo] == gr) v = lo; else s_dinfo[0] = -1;
+                }
+                s_rowmap[t] = v;
+            }
+            for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * pn;
+            __syncthreads();
+        }
         if (dblk == -2) dblk = s_dinfo[0];
-        has_dst = dblk >= 0;
+        has_dst = merged ? s_dinfo[0] >= 0 : dblk >= 0;
         if (MM != 1 && !has_dst && tid == 0) atomicAdd(&info[2], 1);     // (the plan-time build pass only writes records: the factorisation's pass counts)
         // destination block: (row offset inside the panel, its row ids, its row count) of L(ib, jb), or the index position of U(ib, jb)
         int di0 = 0, di1 = 0, di2 = 0;
-        int64_t dbase = 0;
-        if (has_dst) {
+        int64_t dbase = merged ? T.sn_lval[jb] : 0;
+        if (has_dst && !merged) {
             if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = ZS * T.sn_lval[jb]; }
             else { di0 = T.ub_iukp[dblk]; dbase = ZS * T.sn_uval[ib]; }
         }
         // ---- destination maps (tile row / column -> offset inside the destination panel / U row), before the K loop: the first
         // source fetch is in flight behind these index loads, and the lines can be touched ahead of the scatter ----
         dst = T.val + dbase;
-        if (has_dst) {
+        if (has_dst && !merged) {
             if (ib >= jb) {
                 // indirect[rel] = position of global row (xsup[ib]+rel) inside destination block L(ib,jb)
                 const int *drows = T.lidx + T.sn_lidx[jb] + di1;

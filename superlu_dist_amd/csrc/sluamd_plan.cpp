@@ -75,6 +75,7 @@ static int build_tables(Handle &H, HostTables &t)
     t.sn_rt_off.resize(ns); t.sn_nrt.assign(ns, 0); t.sn_ct_off.resize(ns); t.sn_nct.assign(ns, 0);
     t.ucolptr.assign(hs.uidx.size(), 0); t.unzcol.assign(hs.uidx.size(), 0);
     t.sn_big.assign(ns, 0);
+    t.sn_rows_sorted.assign(ns, 0);
     t.sn_lrow.assign(ns, 0); t.sn_ucol.assign(ns, 0);
     H.max_nsupc = 0;
     auto &st = H.st;
@@ -122,6 +123,12 @@ static int build_tables(Handle &H, HostTables &t)
             rowoff += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
         if (rowoff != nsupr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
+        {
+            const int *rw = t.lrow.data() + t.sn_lrow[k];
+            bool asc = true;
+            for (int i = 1; i < nsupr && asc; ++i) asc = rw[i - 1] < rw[i];
+            t.sn_rows_sorted[k] = asc ? 1 : 0;
+        }
         if ((int64_t) nsupr * nsupc != hs.lval_len[k]) { set_error("L panel value count mismatch"); return SLUAMD_ESTRUCT; }
         std::sort(dir.begin(), dir.end());
         for (auto &d : dir) { t.lbs_gid.push_back(d.first); t.lbs_idx.push_back(d.second); }
@@ -200,6 +207,39 @@ static int build_tables(Handle &H, HostTables &t)
         if (l_own) st.flops_panel += (double) nsupc * nsupc * rrows;
         if (u_own) st.flops_panel += (double) nsupc * exact;
     }
+    // ---- merged row tiles ----
+    // The update L(ib, k) U(k, jb) of every block row ib >= jb lands in ONE destination panel (jb), and the rows of those blocks are contiguous in
+    // the slot of k (blocks ascending): tiles may run across the block boundaries instead of ending with a ragged tile per block -- a 144-row
+    // block costs two 128-row tiles of which the second is 1/8 full and still takes half the time of a full one (the chunk period has a latency
+    // floor).  Per U block the rows of the L blocks at and below it are re-cut into tiles when that saves a tile; the destination row map of such
+    // a tile is a search in the destination panel's (ascending) row list instead of one block's row list.  Real arithmetic, list schedules only.
+    t.ub_mrt_off.assign(t.ub_gid.size(), 0); t.ub_mrt_cnt.assign(t.ub_gid.size(), 0);
+    if (!H.z && !H.env.no_merge_tiles && !H.opt.deterministic)
+        for (int k = 0; k < ns; ++k) {
+            if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_rows_sorted[k]) continue;
+            const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k], nb = t.sn_nlb[k], nub = t.sn_nub[k];
+            const int bfirst = t.sn_ldiag[k] ? 1 : 0;
+            const int tm = t.sn_big[k] ? 128 : 64;
+            for (int u = 0; u < nub; ++u) {
+                const int jb = t.ub_gid[ub0 + u];
+                if (!t.sn_rows_sorted[jb] || !(t.sn_flags[jb] & SNF_L_OWN)) continue;
+                int bs = bfirst;
+                while (bs < nb && t.lb_gid[lb0 + bs] < jb) ++bs;
+                if (nb - bs < 2) continue;                                    // one block: nothing to merge
+                int regular = 0;
+                for (int b = bs; b < nb; ++b) regular += (t.lb_nbrow[lb0 + b] + tm - 1) / tm;
+                const int row0 = t.lb_rowoff[lb0 + bs], rows = t.sn_nsupr[k] - row0;
+                const int merged = (rows + tm - 1) / tm;
+                if (merged >= regular) continue;
+                t.ub_mrt_off[ub0 + u] = (int) t.rtile.size(); t.ub_mrt_cnt[ub0 + u] = merged;
+                int b = bs;
+                for (int r0 = 0; r0 < rows; r0 += tm) {
+                    while (b + 1 < nb && t.lb_rowoff[lb0 + b + 1] <= row0 + r0) ++b;        // block that holds the tile's first row
+                    t.rtile.push_back(make_int4(b, row0 + r0 - t.lb_rowoff[lb0 + b], std::min(tm, rows - r0), row0 + r0));
+                    t.rt_info.push_back(make_int2(t.lb_gid[lb0 + b], 0));
+                }
+            }
+        }
     if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; st.flops_schur_exact_big *= 4; st.schur_bytes_alg_big *= 2; }   // complex multiply-add = 8 flop
     H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu; H.h_flags = t.sn_flags; H.h_ldiag = t.sn_ldiag;
     return 0;
@@ -289,51 +329,72 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
     // A deferred (K-fused) supernode runs parts 0 and 1 only; its partner on the next level applies everything else.
     S.sn_level = lvl;
     S.u_off.assign(8 * S.nlevels + 1, 0);
-    std::vector<int8_t> rflag, cflag;
+    std::vector<int8_t> cflag;
     std::vector<int> dcache;
+    struct Cand { int a, c, w; };
+    std::vector<Cand> cand, bulk;
+    std::vector<int4> bucket[4];
     for (int l = 0; l < S.nlevels; ++l) {
         const int nbig = S.n_big[l];
-        for (int g = 0; g < 2; ++g)
-            for (int part = 0; part < 4; ++part) {
-                const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
-                for (int i = b; i < e; ++i) {
-                    const int k = S.nodes[i];
-                    const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
-                    if (!nrt || !nct) continue;
-                    if (part >= 2 && !defer.empty() && defer[k]) continue;
-                    const int r0 = t.sn_rt_off[k], c0 = t.sn_ct_off[k], nub = t.sn_nub[k];
-                    rflag.assign(nrt, 0); cflag.assign(nct, 0);   // 1: level l+1, 2: level l+2
-                    bool any = false;
-                    for (int r = 0; r < nrt; ++r) { const int d = lvl[t.rt_info[r0 + r].x] - l; rflag[r] = (d == 1 || d == 2) ? d : 0; any |= rflag[r] != 0; }
-                    for (int c = 0; c < nct; ++c) { const int d = lvl[t.ct_info[c0 + c].x] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; any |= cflag[c] != 0; }
-                    if (part < 3 && !any) continue;
-                    dcache.assign((size_t) t.sn_nlb[k] * std::max(nub, 1), -2);
-                    auto emit = [&](int r, int c) {
-                        int &d = dcache[(size_t) t.rtile[r0 + r].x * nub + t.ctile[c0 + c].x];
-                        if (d == -2) d = dest_block(t, t.rt_info[r0 + r].x, t.ct_info[c0 + c].x);
-                        S.ulist.push_back(make_int4(k, r0 + r, c0 + c, d));
-                    };
-                    if (part == 3) {
-                        for (int band = 0; band < nrt; band += 8) {
-                            const int bh = std::min(8, nrt - band);
-                            for (int c = 0; c < nct; ++c)
-                                for (int r = band; r < band + bh; ++r)
-                                    if (!(rflag[r] || cflag[c])) emit(r, c);
-                        }
-                        continue;
+        for (int g = 0; g < 2; ++g) {
+            for (auto &bk : bucket) bk.clear();
+            const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
+            for (int i = b; i < e; ++i) {
+                const int k = S.nodes[i];
+                const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
+                if (!nrt || !nct) continue;
+                const bool deferred = !defer.empty() && defer[k];               // runs parts 0 and 1 only
+                const int r0 = t.sn_rt_off[k], c0 = t.sn_ct_off[k], nub = t.sn_nub[k], ub0 = t.sn_ub_off[k];
+                const int tmk = t.sn_big[k] ? 128 : 64;
+                // the tiles of k as (absolute row tile, column tile) pairs: per column tile the block pairs' own row tiles, or -- where the U block
+                // has merged row tiles -- those for the block rows at and below the U block's supernode and the own tiles for the ones above it
+                cand.clear();
+                cflag.assign(nct, 0);   // 1: level l+1, 2: level l+2
+                for (int c = 0; c < nct; ++c) { const int d = lvl[t.ct_info[c0 + c].x] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; }
+                auto level_flag = [&](int a) { const int d = lvl[t.rt_info[a].x] - l; return (int8_t) ((d == 1 || d == 2) ? d : 0); };
+                for (int c = 0; c < nct; ++c) {
+                    const int ub = ub0 + t.ctile[c0 + c].x, jb = t.ct_info[c0 + c].x;
+                    const int mcnt = t.ub_mrt_cnt.empty() ? 0 : t.ub_mrt_cnt[ub];
+                    for (int r = 0; r < nrt; ++r) {
+                        if (mcnt && t.rt_info[r0 + r].x >= jb) continue;          // covered by the merged tiles of this U block
+                        cand.push_back({r0 + r, c, t.rtile[r0 + r].w});
                     }
-                    for (int r = 0; r < nrt; ++r)
-                        for (int c = 0; c < nct; ++c) {
-                            if (!(rflag[r] || cflag[c])) continue;
-                            const bool next = rflag[r] == 1 || cflag[c] == 1;          // feeds a level-(l+1) panel
-                            if (part == 2) { if (!next) emit(r, c); continue; }
-                            if (!next) continue;
-                            const bool diag = t.rt_info[r0 + r].x == t.ct_info[c0 + c].x;      // the diagonal block of a level-(l+1) supernode
-                            if ((part == 0) == diag) emit(r, c);
-                        }
+                    for (int m = 0; m < mcnt; ++m) cand.push_back({t.ub_mrt_off[ub] + m, c, t.rtile[t.ub_mrt_off[ub] + m].w});
                 }
+                dcache.assign((size_t) t.sn_nlb[k] * std::max(nub, 1), -2);
+                auto entry = [&](const Cand &q) {
+                    const bool merged = q.a < r0 || q.a >= r0 + nrt;
+                    int d = -3;                                                   // merged: the destination panel is searched row by row
+                    if (!merged) {
+                        int &dc = dcache[(size_t) t.rtile[q.a].x * nub + t.ctile[c0 + q.c].x];
+                        if (dc == -2) dc = dest_block(t, t.rt_info[q.a].x, t.ct_info[c0 + q.c].x);
+                        d = dc;
+                    }
+                    return make_int4(k, q.a, c0 + q.c, d);
+                };
+                std::sort(cand.begin(), cand.end(), [&](const Cand &x, const Cand &y) { return x.w != y.w ? x.w < y.w : x.c < y.c; });
+                bulk.clear();
+                for (auto &q : cand) {
+                    const int8_t rf = level_flag(q.a);
+                    if (!(rf || cflag[q.c])) { if (!deferred) bulk.push_back(q); continue; }
+                    const bool next = rf == 1 || cflag[q.c] == 1;          // feeds a level-(l+1) panel
+                    if (!next) { if (!deferred) bucket[2].push_back(entry(q)); continue; }
+                    const bool diag = t.rt_info[q.a].x == t.ct_info[c0 + q.c].x;      // (holds rows of) the diagonal block of a level-(l+1) supernode
+                    bucket[diag ? 0 : 1].push_back(entry(q));
+                }
+                // the bulk: bands of 8 row tiles' worth of slot rows, column tile after column tile inside a band
+                std::stable_sort(bulk.begin(), bulk.end(), [&](const Cand &x, const Cand &y) {
+                    const int bx = x.w / (8 * tmk), by = y.w / (8 * tmk);
+                    if (bx != by) return bx < by;
+                    if (x.c != y.c) return x.c < y.c;
+                    return x.w < y.w; });
+                for (auto &q : bulk) bucket[3].push_back(entry(q));
+            }
+            for (int part = 0; part < 4; ++part) {
+                S.ulist.insert(S.ulist.end(), bucket[part].begin(), bucket[part].end());
                 S.u_off[(2 * l + g) * 4 + part + 1] = (int) S.ulist.size();
             }
+        }
     }
 }
 

@@ -29,6 +29,11 @@ struct HostTables {
     std::vector<int2> rt_info;     // per row tile: (gid of its block row, offset of its row ids inside the lidx arena)
     std::vector<int4> ct_info;     // per column tile: (gid of its block column, offset of its U block inside the uidx arena, rank of its first column among the non-empty columns of the U row, 0)
     std::vector<uint8_t> sn_big;   // 1: supernode uses the 128x128 Schur tile configuration
+    // merged row tiles (round 4): per U block (index sn_ub_off[k] + b) a range of rtile entries that cover ALL slot rows of the L blocks with
+    // gid >= the U block's gid -- every one of them updates the same destination panel -- cut into tiles across block boundaries; count 0 = the
+    // block pairs keep their own tiles.  (ulist entries of merged tiles carry destination -3.)
+    std::vector<int> ub_mrt_off, ub_mrt_cnt;
+    std::vector<uint8_t> sn_rows_sorted;   // 1: the global row ids of the slot are strictly ascending over the whole slot (blocks ascending, rows ascending)
 };
 
 inline size_t &upload_bytes() { static thread_local size_t b = 0; return b; }   // bytes of the tables this thread uploaded (handle creation runs on one thread)
