@@ -227,6 +227,7 @@ static void schur_t(const DevTables &T, const int *nodes, const int *prefix, int
         const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
         // merged row tile (list entry with destination -3): rows of several L blocks, all of them with gid >= jb; global ids from the flat row map
         const bool merged = ulist && ulist[bid].w == -3;
+        const bool mergedU = ulist && ulist[bid].w == -4;     // merged column tile: columns of several U blocks (all with gid > ib), destination U row ib
         const int *lsub = merged ? T.lrow + T.sn_lrow[k] + R.w : T.lidx + T.sn_lidx[k] + T.lb_lptr[lb] + R.y;
         const int64_t uix0 = T.sn_uidx[k] + T.ub_iukp[ub];
         acc.assign((size_t) nr * nc, V(0));
@@ -253,8 +254,14 @@ static void schur_t(const DevTables &T, const int *nodes, const int *prefix, int
                 const int lda = T.sn_nsupr[k];
                 const V *Lp = val + T.sn_lval[k] + R.w, *Uv = val + T.sn_uval[k];
                 for (int c = 0; c < nc; ++c) {
-                    const int jj = T.unzcol[uix0 + C.y + c];
-                    const int lead = ns - (klst - T.uidx[uix0 + jj]), cp = T.ucolptr[uix0 + jj];
+                    int lead, cp;
+                    if (mergedU) {   // columns of several U blocks: the flat per-non-empty-column maps of the slot
+                        const int64_t f = T.sn_ucol[k] + T.ub_stcol[ub] + C.y + c;
+                        lead = T.ucol_ld[f]; cp = T.ucol_cp[f];
+                    } else {
+                        const int jj = T.unzcol[uix0 + C.y + c];
+                        lead = ns - (klst - T.uidx[uix0 + jj]); cp = T.ucolptr[uix0 + jj];
+                    }
                     for (int r = 0; r < nr; ++r) {
                         V a(0);
                         for (int kk = lead; kk < ns; ++kk) a += Lp[r + (size_t) kk * lda] * Uv[cp + (kk - lead)];
@@ -262,6 +269,33 @@ static void schur_t(const DevTables &T, const int *nodes, const int *prefix, int
                     }
                 }
             }
+        }
+        if (mergedU) {
+            const int2 ri = T.rt_info[ulist[bid].y];
+            const int4 ci = T.ct_info[ulist[bid].z];
+            if (ri.x != ib || ci.x != jb || ib >= jb || T.lidx + ri.y != lsub || ci.y != uix0 || ci.z != T.ub_stcol[ub] + C.y || ci.z + nc > T.sn_ncolu[k]) { std::fprintf(stderr, "engine_cpu: merged column tile entry disagrees with the block tables\n"); std::abort(); }
+            // destination of every column: LINEAR search of its global id among ALL columns of U row ib (block directory + fstnz: independent of the
+            // kernel's binary search in the flat maps)
+            const int o2 = T.sn_ub_off[ib], nb2 = T.sn_nub[ib];
+            V *dst = val + T.sn_uval[ib];
+            std::vector<int64_t> cmap(nc, INT64_MIN);
+            bool all = true;
+            for (int c = 0; c < nc; ++c) {
+                const int gc = T.ucol_gc[T.sn_ucol[k] + T.ub_stcol[ub] + C.y + c];
+                if (gc < T.xsup[ib + 1]) { std::fprintf(stderr, "engine_cpu: merged column tile column left of its destination row\n"); std::abort(); }
+                for (int q = 0; q < nb2 && cmap[c] == INT64_MIN; ++q) {
+                    const int jq = T.ub_gid[o2 + q];
+                    if (gc < T.xsup[jq] || gc >= T.xsup[jq + 1]) continue;
+                    const int64_t d0 = T.sn_uidx[ib] + T.ub_iukp[o2 + q];
+                    const int jj = gc - T.xsup[jq];
+                    if (T.uidx[d0 + jj] < T.xsup[ib + 1]) cmap[c] = (int64_t) T.ucolptr[d0 + jj] - T.uidx[d0 + jj];
+                }
+                all = all && cmap[c] != INT64_MIN;
+            }
+            if (!all) { info[2] += 1; continue; }
+            for (int c = 0; c < nc; ++c)
+                for (int r = 0; r < nr; ++r) dst[cmap[c] + lsub[r]] -= acc[r + (size_t) c * nr];
+            continue;
         }
         if (merged) {
             // every row must belong to a block row >= jb and exist in panel jb (found by a LINEAR search of the whole panel: independent of the

@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             const int fstj = T.xsup[jb];
             for (int t = tid; t < TNv; t += NT) {
                 int cp = 0, lead = ns, jj = 0;
-                if (t < nc) { cp = T.ucol_cp[cb + t]; lead = T.ucol_ld[cb + t]; jj = T.ucol_gc[cb + t] - fstj; }
+                if (t < nc) { cp = T.ucol_cp[cb + t]; lead = T.ucol_ld[cb + t]; jj = T.ucol_gc[cb + t] - (dblk == -4 ? 0 : fstj); }    // merged column tile: the GLOBAL column id
                 s_cptr[t] = cp; s_lead[t] = lead; s_jj[t] = jj;
             }
         }
@@ -1241,9 +1241,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             }
             if (ln == 0) s_dinfo[0] = pos < 0 ? -1 : (ldest ? o + T.lbs_idx[o + pos] : o + pos);
         }
-        const bool merged = !Z && dblk == -3;
+        const bool merged = !Z && (dblk == -3 || dblk == -4), mergedU = !Z && dblk == -4;
         if (merged && tid == 0) s_dinfo[0] = 0;
         __syncthreads();
+        if (mergedU) {
+            // merged COLUMN tile: rows of ONE L block (ib), columns of several U blocks, all with gid > ib -> every element lands in U row ib.  Row map =
+            // global row id (as for any U destination); column map = (value offset - first nonzero row) of the column's segment in row ib, found by
+            // the rank of the global column in that row's ascending list of non-empty columns
+            const int64_t cbi = T.sn_ucol[ib];
+            const int pn = T.sn_ncolu[ib], fib = T.xsup[ib];
+            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
+            for (int t = tid; t < TNv; t += NT) {
+                int cm = 0;
+                if (t < nc) {
+                    const int gc = s_jj[t];
+                    int lo = 0, hi = pn;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.ucol_gc[cbi + mid] < gc) lo = mid + 1; else hi = mid; }
+                    if (lo < pn && T.ucol_gc[cbi + lo] == gc) cm = T.ucol_cp[cbi + lo] - (fib + T.ucol_ld[cbi + lo]); else s_dinfo[0] = -1;
+                }
+                s_colmap[t] = cm;
+            }
+            __syncthreads();
+        } else
         if (merged) {
             // every row of the tile lands in panel jb (block rows ib >= jb): its position there = its rank in the panel's ascending row list
             // (the planner merges only into panels whose rows ascend over the whole slot); a row the panel lacks voids the tile like a missing block
@@ -1267,7 +1286,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         if (MM != 1 && !has_dst && tid == 0) atomicAdd(&info[2], 1);     // (the plan-time build pass only writes records: the factorisation's pass counts)
         // destination block: (row offset inside the panel, its row ids, its row count) of L(ib, jb), or the index position of U(ib, jb)
         int di0 = 0, di1 = 0, di2 = 0;
-        int64_t dbase = merged ? T.sn_lval[jb] : 0;
+        int64_t dbase = mergedU ? T.sn_uval[ib] : (merged ? T.sn_lval[jb] : 0);
         if (has_dst && !merged) {
             if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = ZS * T.sn_lval[jb]; }
             else { di0 = T.ub_iukp[dblk]; dbase = ZS * T.sn_uval[ib]; }

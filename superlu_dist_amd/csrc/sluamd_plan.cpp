@@ -75,7 +75,7 @@ static int build_tables(Handle &H, HostTables &t)
     t.sn_rt_off.resize(ns); t.sn_nrt.assign(ns, 0); t.sn_ct_off.resize(ns); t.sn_nct.assign(ns, 0);
     t.ucolptr.assign(hs.uidx.size(), 0); t.unzcol.assign(hs.uidx.size(), 0);
     t.sn_big.assign(ns, 0);
-    t.sn_rows_sorted.assign(ns, 0);
+    t.sn_rows_sorted.assign(ns, 0); t.sn_ucols_sorted.assign(ns, 0);
     t.sn_lrow.assign(ns, 0); t.sn_ucol.assign(ns, 0);
     H.max_nsupc = 0;
     auto &st = H.st;
@@ -164,6 +164,12 @@ static int build_tables(Handle &H, HostTables &t)
             if (rukp != hs.uval_len[k]) { set_error("U value count mismatch"); return SLUAMD_ESTRUCT; }
         }
         t.sn_nub[k] = nub; t.sn_ldu[k] = ldu; t.sn_ncolu[k] = ncol_tot;
+        {
+            const int *gc = t.ucol_gc.data() + t.sn_ucol[k];
+            bool asc = true;
+            for (int i = 1; i < ncol_tot && asc; ++i) asc = gc[i - 1] < gc[i];
+            t.sn_ucols_sorted[k] = asc ? 1 : 0;
+        }
         {   // tile configuration + tile lists of supernode k
             const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k];
             const int bfirst = ldiag ? 1 : 0;
@@ -237,6 +243,35 @@ static int build_tables(Handle &H, HostTables &t)
                     while (b + 1 < nb && t.lb_rowoff[lb0 + b + 1] <= row0 + r0) ++b;        // block that holds the tile's first row
                     t.rtile.push_back(make_int4(b, row0 + r0 - t.lb_rowoff[lb0 + b], std::min(tm, rows - r0), row0 + r0));
                     t.rt_info.push_back(make_int2(t.lb_gid[lb0 + b], 0));
+                }
+            }
+        }
+    // ... and merged COLUMN tiles: L(ib, k) U(k, jb) of every block column jb > ib lands in ONE destination U row (ib); the non-empty columns of
+    // those U blocks are contiguous in the U slot of k.  Destination column map = rank of the global column in row ib's ascending column list.
+    t.lb_mct_off.assign(t.lb_gid.size(), 0); t.lb_mct_cnt.assign(t.lb_gid.size(), 0);
+    if (!H.z && !H.env.no_merge_tiles && !H.opt.deterministic)
+        for (int k = 0; k < ns; ++k) {
+            if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_ucols_sorted[k]) continue;
+            const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k], nb = t.sn_nlb[k], nub = t.sn_nub[k];
+            const int bfirst = t.sn_ldiag[k] ? 1 : 0;
+            const int tn = t.sn_big[k] ? 128 : 64;
+            for (int b = bfirst; b < nb; ++b) {
+                const int ib = t.lb_gid[lb0 + b];
+                if (!t.sn_ucols_sorted[ib] || !(t.sn_flags[ib] & SNF_U_OWN)) continue;
+                int us = 0;
+                while (us < nub && t.ub_gid[ub0 + us] <= ib) ++us;
+                if (nub - us < 2) continue;
+                int regular = 0;
+                for (int u = us; u < nub; ++u) regular += (t.ub_ncols[ub0 + u] + tn - 1) / tn;
+                const int col0 = t.ub_stcol[ub0 + us], cols = t.sn_ncolu[k] - col0;
+                const int merged = (cols + tn - 1) / tn;
+                if (merged >= regular) continue;
+                t.lb_mct_off[lb0 + b] = (int) t.ctile.size(); t.lb_mct_cnt[lb0 + b] = merged;
+                int u = us;
+                for (int c0 = 0; c0 < cols; c0 += tn) {
+                    while (u + 1 < nub && t.ub_stcol[ub0 + u + 1] <= col0 + c0) ++u;        // U block that holds the tile's first column
+                    t.ctile.push_back(make_int4(u, col0 + c0 - t.ub_stcol[ub0 + u], std::min(tn, cols - c0), 0));
+                    t.ct_info.push_back(make_int4(t.ub_gid[ub0 + u], (int) (t.sn_uidx[k] + t.ub_iukp[ub0 + u]), col0 + c0, 0));
                 }
             }
         }
@@ -352,20 +387,30 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
                 cflag.assign(nct, 0);   // 1: level l+1, 2: level l+2
                 for (int c = 0; c < nct; ++c) { const int d = lvl[t.ct_info[c0 + c].x] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; }
                 auto level_flag = [&](int a) { const int d = lvl[t.rt_info[a].x] - l; return (int8_t) ((d == 1 || d == 2) ? d : 0); };
+                auto col_flag = [&](int c) { if (c >= 0 && c < nct) return cflag[c]; const int d = lvl[t.ct_info[c0 + c].x] - l; return (int8_t) ((d == 1 || d == 2) ? d : 0); };
+                const int lb0 = t.sn_lb_off[k];
                 for (int c = 0; c < nct; ++c) {
                     const int ub = ub0 + t.ctile[c0 + c].x, jb = t.ct_info[c0 + c].x;
                     const int mcnt = t.ub_mrt_cnt.empty() ? 0 : t.ub_mrt_cnt[ub];
                     for (int r = 0; r < nrt; ++r) {
-                        if (mcnt && t.rt_info[r0 + r].x >= jb) continue;          // covered by the merged tiles of this U block
+                        const int ib = t.rt_info[r0 + r].x;
+                        if (ib >= jb) { if (mcnt) continue; }                                                         // covered by the merged ROW tiles of this U block
+                        else if (!t.lb_mct_cnt.empty() && t.lb_mct_cnt[lb0 + t.rtile[r0 + r].x]) continue;           // covered by the merged COLUMN tiles of this L block
                         cand.push_back({r0 + r, c, t.rtile[r0 + r].w});
                     }
                     for (int m = 0; m < mcnt; ++m) cand.push_back({t.ub_mrt_off[ub] + m, c, t.rtile[t.ub_mrt_off[ub] + m].w});
                 }
+                if (!t.lb_mct_cnt.empty())
+                    for (int r = 0; r < nrt; ++r) {
+                        const int lb = lb0 + t.rtile[r0 + r].x;
+                        for (int m = 0; m < t.lb_mct_cnt[lb]; ++m) cand.push_back({r0 + r, t.lb_mct_off[lb] + m - c0, t.rtile[r0 + r].w});     // column index relative to c0 (beyond nct)
+                    }
                 dcache.assign((size_t) t.sn_nlb[k] * std::max(nub, 1), -2);
                 auto entry = [&](const Cand &q) {
                     const bool merged = q.a < r0 || q.a >= r0 + nrt;
-                    int d = -3;                                                   // merged: the destination panel is searched row by row
-                    if (!merged) {
+                    int d = -3;                                                   // merged rows: the destination panel is searched row by row
+                    if (q.c < 0 || q.c >= nct) d = -4;                            // merged columns: the destination U row is searched column by column
+                    else if (!merged) {
                         int &dc = dcache[(size_t) t.rtile[q.a].x * nub + t.ctile[c0 + q.c].x];
                         if (dc == -2) dc = dest_block(t, t.rt_info[q.a].x, t.ct_info[c0 + q.c].x);
                         d = dc;
@@ -376,8 +421,9 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
                 bulk.clear();
                 for (auto &q : cand) {
                     const int8_t rf = level_flag(q.a);
-                    if (!(rf || cflag[q.c])) { if (!deferred) bulk.push_back(q); continue; }
-                    const bool next = rf == 1 || cflag[q.c] == 1;          // feeds a level-(l+1) panel
+                    const int8_t cf = col_flag(q.c);
+                    if (!(rf || cf)) { if (!deferred) bulk.push_back(q); continue; }
+                    const bool next = rf == 1 || cf == 1;          // feeds a level-(l+1) panel
                     if (!next) { if (!deferred) bucket[2].push_back(entry(q)); continue; }
                     const bool diag = t.rt_info[q.a].x == t.ct_info[c0 + q.c].x;      // (holds rows of) the diagonal block of a level-(l+1) supernode
                     bucket[diag ? 0 : 1].push_back(entry(q));

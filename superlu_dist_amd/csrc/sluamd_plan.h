@@ -33,6 +33,10 @@ struct HostTables {
     // gid >= the U block's gid -- every one of them updates the same destination panel -- cut into tiles across block boundaries; count 0 = the
     // block pairs keep their own tiles.  (ulist entries of merged tiles carry destination -3.)
     std::vector<int> ub_mrt_off, ub_mrt_cnt;
+    // merged column tiles: per L block (index sn_lb_off[k] + b, gid ib) a range of ctile entries that cover ALL non-empty columns of the U blocks
+    // with gid > ib -- every one of them updates the same destination U row (ib) -- cut across block boundaries (ulist destination -4)
+    std::vector<int> lb_mct_off, lb_mct_cnt;
+    std::vector<uint8_t> sn_ucols_sorted;  // 1: the global ids of the non-empty columns of the U slot are strictly ascending
     std::vector<uint8_t> sn_rows_sorted;   // 1: the global row ids of the slot are strictly ascending over the whole slot (blocks ascending, rows ascending)
 };
 

@@ -160,3 +160,39 @@ def test_unsymmetric_symbolic_structure_on_grids(emul, grid):
     n, rp, ci, v = matgen.stencil3d_unsym(10, drop=0.35, seed=7)
     perm = matgen.nd_perm_grid3d(10, 10, 10, leaf=8)
     grid_cases.check_matrix_on_grid(n, rp, ci, v, perm, grid, nrhs=2, relax=12, maxsup=48, unsym_symb=True, refactor=True)
+
+
+def test_merged_schur_tiles_cover_the_same_updates(emul, monkeypatch):
+    """Merged Schur tiles (round 4): per U block the rows of all L blocks at and below its supernode -- one destination panel -- and per L block the
+    columns of all U blocks to its right -- one destination U row -- are re-cut into tiles across block boundaries.  Fewer tile executions, the
+    same factors (to summation order) as the one-tile-set-per-block-pair lists; the emulation engine checks every merged list entry against the block
+    tables and resolves its destinations by linear searches that share nothing with the kernel's binary searches."""
+    from superlu_dist_amd import driver, matgen
+    N = 18
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(3)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    out = {}
+    for mode in ("merged", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("SLUAMD_NO_MERGE_TILES", "1")
+        symb = driver.Symbolic(n, rp, ci, perm, relax=20, maxsup=96)
+        symb.distribute_host(v)
+        fs = symb.flat_store()
+        h = driver.LUHandle.from_store(fs)
+        planned = h.stats()["schur_tiles"]
+        assert h.pdgstrf3d(0.0) == 0
+        assert h.stats()["schur_tiles"] == planned          # what ran is what was planned
+        h.copy_to_host()
+        xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+        x = h.pdgstrs3d(xp)[symb.perm_c, :]
+        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-12
+        out[mode] = (planned, fs.Lnzval.copy(), fs.Unzval.copy())
+        h.destroy(); symb.free()
+    assert out["merged"][0] < 0.9 * out["plain"][0]
+    scale = np.abs(v).max()
+    assert np.abs(out["merged"][1] - out["plain"][1]).max() <= 1e-12 * scale
+    assert np.abs(out["merged"][2] - out["plain"][2]).max() <= 1e-12 * scale
