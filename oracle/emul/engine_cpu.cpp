@@ -659,7 +659,7 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 }
 
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int prio,
-           const int *, int mmode)
+           const int *, int mmode, int /* ksplit: shares of K per tile on the device; the restatement computes a tile once */)
 {
     if (mmode == 1) return;     // build pass of the per-tile records: the restatement reads the tables every time
     emul_enqueue(s, [=] { impl::schur(s, cfg, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio); });

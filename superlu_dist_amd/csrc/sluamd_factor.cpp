@@ -101,12 +101,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         }
     }
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
-                     const int4 *ulist, int prio = 0, const int *tmaps = nullptr) {
+                     const int4 *ulist, int prio = 0, const int *tmaps = nullptr, int ksplit = 1) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         if (H->profile) { if (H->ev_schur_big.size() <= H->ev_schur_used) H->ev_schur_big.resize(H->ev_schur_used + 1); H->ev_schur_big[H->ev_schur_used] = big ? 1 : 0; }
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
         if (H->z) eng::zschur(st, big ? 0 : 1, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0);     // complex16: k_schur on the real embedding
-        else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0);
+        else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0, ksplit);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -212,7 +212,9 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             if (!cnt) continue;
             const int u0 = S.u_off[(2 * l + g) * 4 + p0], nu = S.u_off[(2 * l + g) * 4 + p1 + 1] - u0;
             const int *tm = S.maps_state == 1 ? S.d_tmaps + S.m_off[2 * l + g] + (int64_t) (u0 - S.u_off[(2 * l + g) * 4]) * eng::schur_rec_ints(g == 0 ? 0 : 2, H->z) : nullptr;
-            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, (lookahead && p1 < 3) ? 1 : 0, tm);
+            // the diagonal-block tiles of the next level (part 0, on the panel stream) when they are few: split K over several workgroups per tile
+            const int ks = (lookahead && p0 == 0 && p1 == 0 && g == 0 && nu <= 64 && !H->z && !H->env.schur_4waves) ? H->env.ksplit : 1;
+            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, (lookahead && p1 < 3) ? 1 : 0, tm, ks);
         }
     };
     // deterministic mode: one supernode per launch over its full tile grid -- tiles of one k hit distinct destinations, the

@@ -252,6 +252,8 @@ struct Handle {
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
         int level_split_min = 4096;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
+        int ksplit = 4;              // SLUAMD_KSPLIT: workgroups per tile (shares of K) for the diagonal-block tiles on the panel chain when a launch has at most 64 of them (1 = off)
+        int big_util_pct = 50, big_min_cols = 96;   // SLUAMD_BIG_UTIL_PCT / SLUAMD_BIG_MIN_COLS: a supernode runs 128 x 128 tiles when it is at least this wide and its block pairs fill that share of them
         bool no_merge_tiles = false; // SLUAMD_NO_MERGE_TILES: every (L block, U block) pair keeps its own Schur tiles (round 3)
         bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
@@ -349,7 +351,7 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0);
+           const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0, int ksplit = 1 /* > 1: that many workgroups per tile, each a share of K (128 x 128 tiles) */);
 // per-tile records of the list schedules (k_schur): mmode 1 = build pass (writes the records of the launch's tiles at tmaps, no update),
 // mmode 2 = the tiles read their records; ints per record for a tile configuration
 inline int schur_rec_ints(int cfg, bool z) { return (cfg <= 1) ? 32 + 128 + 3 * 128 : 32 + 64 + 3 * 64; (void) z; }

@@ -1102,7 +1102,11 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 // so that U and the destination are read / written where they lie and only the L loader differs (it picks the part a ^ b with
 // a per-thread constant sign): the same tile machinery, every MFMA a useful one (2 (2m)(2K) n = 8 m K n flop).  A tile of
 // TMv real rows is TMv / 2 rows of the complex panel.
-template <int TMv, int TNv, int NW, bool Z = false, int MM = 0>   // MM 0: the tiles chase the tables; 1: and write their per-tile records instead of updating (plan-time build pass); 2: they read the records
+// SK (split K): the launch has gridDim.y workgroups per tile, each runs its share of every source's K chunks and scatters it (the scatter is fp64 atomics
+// anyway).  For the few tiles that sit on the panel chain -- the diagonal-block destinations of the next level, 4 tiles of K = 256 ... 512 on an otherwise
+// waiting device, where a lone workgroup is latency-bound at ~3.5 us per chunk -- the chain link gets the tile in a quarter of the time.  A separate
+// instantiation: the bulk instantiation's K loop (at the 128-VGPR cap) stays exactly what it was.
+template <int TMv, int TNv, int NW, bool Z = false, int MM = 0, bool SK = false>   // MM 0: the tiles chase the tables; 1: and write their per-tile records instead of updating (plan-time build pass); 2: they read the records
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : SCHUR64_WGS)))) void k_schur(DevTables T, const int *__restrict__ nodes,
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
@@ -1444,14 +1448,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             kbeg = kbeg_own;
             cpS = s_cptr; ldS = s_lead;
         }
+        int kend = ns_s;
+        if (SK) {   // this workgroup's share of the source's chunks
+            const int nch = (ns_s - kbeg + KC - 1) / KC;
+            const int c0 = nch * (int) blockIdx.y / (int) gridDim.y, c1 = nch * ((int) blockIdx.y + 1) / (int) gridDim.y;
+            kend = min(ns_s, kbeg + c1 * KC); kbeg += c0 * KC;
+            if (kbeg >= kend) continue;
+        }
         // chunk at which the destination lines are touched: the one before the last chunk of the last source
-        const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((ns_s - 1 - kbeg) / KC - 1) * KC) : -1;
+        const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((kend - 1 - kbeg) / KC - 1) * KC) : -1;
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
         fetch(kbeg);
         stash(buf);
         __syncthreads();
-        for (int k0 = kbeg; k0 < ns_s; k0 += KC) {
-            const bool more = k0 + KC < ns_s;
+        for (int k0 = kbeg; k0 < kend; k0 += KC) {
+            const bool more = k0 + KC < kend;
             if (more) fetch(k0 + KC);
             if (k0 == ktouch) {
                 // one chunk before the last: touch one element of every destination line (16 rows x 1 column of the tile) so
@@ -2063,10 +2074,15 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
         else hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 0>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps); \
     } while (0)
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, int prio, const int *tmaps, int mmode)
+           const int4 *ulist, int prio, const int *tmaps, int mmode, int ksplit)
 {
     if (ntiles <= 0) return;
     const int grid = ((ntiles + 7) / 8) * 8;
+    if (ksplit > 1 && cfg == 0 && mmode != 1) {   // split-K form of the 128 x 128 configuration (chain tiles)
+        if (mmode == 2) hipLaunchKernelGGL((k_schur<128, 128, 8, false, 2, true>), dim3(grid, ksplit), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps);
+        else hipLaunchKernelGGL((k_schur<128, 128, 8, false, 0, true>), dim3(grid, ksplit), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps);
+        return;
+    }
     if (cfg == 0) SCHUR_LAUNCH(128, 128, 8, false, 512);
     else if (cfg == 1) SCHUR_LAUNCH(128, 128, 4, false, 256);
     else SCHUR_LAUNCH(64, 64, 4, false, 256);

@@ -179,7 +179,7 @@ static int build_tables(Handle &H, HostTables &t)
             for (int b = 0; b < nub; ++b) t128c += (t.ub_ncols[ub0 + b] + 127) / 128;
             const double cells = (double) (nsupr - ldiag) * ncol_tot;
             const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * tmr_big * 128.0) : 0.0;
-            const bool big = nsupc >= (H.z ? 48 : 96) && util128 >= 0.5 && !H.env.no_big_tiles;
+            const bool big = nsupc >= (H.z ? 48 : H.env.big_min_cols) && util128 >= 0.01 * H.env.big_util_pct && !H.env.no_big_tiles;
             t.sn_big[k] = big;
             const int tm = big ? 128 : 64;
             const int tmr = H.z ? tm / 2 : tm;    // complex16: 64 (32) panel rows = 128 (64) real rows of the embedding
