@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+(timeout 1500 python -m pytest tests -m gpu -q -x --timeout=900 > gpurun_out/r04_gputest_final.log 2>&1; echo "pytest rc $?" >> gpurun_out/r04_gputest_final.log)
+tail -4 gpurun_out/r04_gputest_final.log
+bash scripts/final_measure.sh r04 > gpurun_out/r04_final_measure.log 2>&1
+tail -5 gpurun_out/r04_final_measure.log
+cp profiles/r04_pmc_schur.json gpurun_out/r04_pmc_schur_copy.json

@@ -331,3 +331,35 @@ def test_several_exact_zero_pivots_report_the_first_column():
         expected = min(int(symb.perm_c[z]) for z in (10, 41, 77)) + 1
         assert info == expected, (info, expected)
         h.destroy(); symb.free()
+
+
+@pytest.mark.parametrize("kind", ["stencil_unsym", "random_unsym"])
+def test_unsymmetric_symbolic_structure_on_the_device(kind):
+    """sluamd_dsymbfact_unsym (the exact unsymmetric structure with the reference's supernode rules, pinned to the real symbfact by
+    tests/test_symbolic_parity.py) through the device path: device-side distribution into ragged skylines, pdgstrf3d, pdgstrs3d -- every
+    factor value against the CPU oracle on the same store, the solution against x_true; the merged Schur tiles (rows across the L blocks of a
+    destination panel, columns across the U blocks of a destination row) are in the lists of these irregular structures."""
+    if kind == "stencil_unsym":
+        n, rp, ci, v = matgen.stencil3d_unsym(14, drop=0.3, seed=4); perm = matgen.nd_perm_grid3d(14, 14, 14, leaf=27)
+    else:
+        n, rp, ci, v = matgen.random_unsym(500, 0.02, seed=9); perm = None
+    symb = driver.Symbolic(n, rp, ci, perm, relax=24, maxsup=96, unsym=True)
+    symb.distribute_host(v)
+    fs = symb.flat_store()
+    o = orc.LUStore(fs.n, fs.xsup, fs.Lrowind_off, fs.Lrowind, fs.Lnzval_off, fs.Lnzval, fs.Ufstnz_off, fs.Ufstnz, fs.Unzval_off, fs.Unzval)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    assert h.pdgstrf3d(0.0) == 0
+    fs2 = symb.flat_store()
+    h2 = driver.LUHandle.from_store(fs2)             # the same structure through the caller's-view path
+    assert h2.pdgstrf3d(0.0) == 0
+    h2.copy_to_host()
+    orc.dfactor(o)
+    scale = np.abs(v).max()
+    assert np.abs(fs2.Lnzval - o.Lnzval).max() <= 1e-12 * scale and np.abs(fs2.Unzval - o.Unzval).max() <= 1e-12 * scale
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    for hh in (h, h2):
+        x = hh.pdgstrs3d(xp)[symb.perm_c, :]
+        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b) < 1e-10
+        assert np.abs(x - xt).max() < 1e-8 * max(1.0, np.abs(xt).max())
+    h.destroy(); h2.destroy(); symb.free()
