@@ -1018,6 +1018,65 @@ __global__ __launch_bounds__(FIS * 4) void k_full_inv(DevTables T, const int *__
     else panel_trsm_body<3, FIS>(T, k, u - per, sm);
 }
 
+// Linv / Uinv of diagonal blocks of AT MOST 64 COLUMNS -- the tens of thousands of leaf supernodes: k_full_inv's identity strips are 8 one-wave
+// workgroups of blocked substitution per block (0.7 ms for level 0 of the 100^3 tree, on the panel chain with nothing else to run).  With at most two
+// 32 x 32 diagonal sub-blocks the inverse of the triangle B (U_kk, or L_kk^T) is  [X00, -X00 B01 X11; 0, X11]  with X00, X11 the 32 x 32 inverses the
+// diagonal kernels already left in T.dinv: ONE wave per (block, triangle), two 32 x 32 x 32 products on fp64 MFMA whose operands come straight from
+// memory in fragment layout -- the accumulator layout of T = B01 X11 IS the B-operand layout of X00 T -- no LDS, no barrier.
+__global__ __launch_bounds__(256) void k_full_inv64(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix, int nn)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ni = w >> 1, typ = w & 1;            // typ 0: U_kk -> Uinv; 1: L_kk^T -> (Linv)^T
+    if (ni >= nn || prefix[ni + 1] == prefix[ni]) return;
+    const int k = nodes[ni];
+    const int ns = T.xsup[k + 1] - T.xsup[k], nblk = (ns + DB - 1) / DB, lda = T.sn_dlda[k];
+    const double *A = T.val + T.sn_dptr[k];
+    const double *D0 = T.dinv + T.sn_dinv[k] + (size_t) (typ * nblk) * DB * DB, *D1 = D0 + DB * DB;     // X(i, c) at [c * 32 + i], identity-padded past ns
+    double *out = T.inv + T.sn_inv[k] + (typ == 0 ? (size_t) ns * ns : 0);
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    // element (r, c) of the upper-triangular inverse X: Uinv(r, c) at [r + c ns] (typ 0), Linv(c, r) at [c + r ns] (typ 1)
+    auto put = [&](int r, int c, double v) { if (r < ns && c < ns) out[typ == 0 ? r + (size_t) c * ns : c + (size_t) r * ns] = v; };
+    for (int e = lane; e < DB * DB; e += 64) {
+        const int i = e & 31, c = e >> 5;
+        put(i, c, D0[c * DB + i]);
+        if (nblk == 2) { put(DB + i, DB + c, D1[c * DB + i]); put(DB + i, c, 0.0); }
+    }
+    if (nblk < 2) return;
+    // T = B01 X11:  B01(i, kk) = B(i, 32 + kk)
+    d4 t[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = 16 * it + li, kk = 4 * q + lk;
+                double a = 0.0;
+                if (DB + kk < ns) a = (typ == 0) ? A[i + (size_t) (DB + kk) * lda] : A[(DB + kk) + (size_t) i * lda];
+                const double b = D1[(16 * jt + li) * DB + kk];                 // X11(kk, 16 jt + li)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            t[it][jt] = acc;          // lane: T(16 it + lk + 4 r, 16 jt + li)
+        }
+    // X01 = -X00 T: the B operand of k-step 4 q' + lk of row tile kt is t[kt][jt][q']
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double a = D0[(16 * kt + 4 * q + lk) * DB + 16 * it + li];      // X00(16 it + li, 16 kt + 4 q + lk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, t[kt][jt][q], acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put(16 * it + lk + 4 * r, DB + 16 * jt + li, -acc[r]);
+        }
+}
+
 // ---- iterative refinement (pdgsrfs3d, SRC/double/pdgsrfs.c:345-510) --------------------------------
 // One pass over the CSR matrix does both of the reference's pdgsmv calls (abs = 0 and abs = 1, pdgsmv.c): residual
 // r = b - A x (stored permuted, r_perm[perm_c[i]] = r_i: the right-hand side of the triangular solves on Pc A Pc^T),
@@ -2096,8 +2155,10 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
     else hipLaunchKernelGGL(k_panel_gemm<64>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 
+static const bool g_full_inv64 = getenv("SLUAMD_NO_FULL_INV64") == nullptr;
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int mx)
 {
+    if (nwork > 0 && mx <= 64 && g_full_inv64) { hipLaunchKernelGGL(k_full_inv64, dim3((2 * nn + 3) / 4), dim3(256), 0, s, T, nodes, prefix, nn); return; }   // levels of narrow supernodes
     if (nwork > 0) hipLaunchKernelGGL(k_full_inv, dim3(nwork), dim3(FIS * 4), trsm_lds_bytes(FIS, (mx + 31) & ~31), s, T, nodes, prefix, nn);
 }
 
