@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             }
             if (ln == 0) s_dinfo[0] = pos < 0 ? -1 : (ldest ? o + T.lbs_idx[o + pos] : o + pos);
         }
-        const bool merged = !Z && (dblk == -3 || dblk == -4), mergedU = !Z && dblk == -4;
+        const bool merged = dblk == -3 || dblk == -4, mergedU = dblk == -4;      // (complex16: tile rows are REAL rows of the embedding, two per panel row)
         if (merged && tid == 0) s_dinfo[0] = 0;
         __syncthreads();
         if (mergedU) {
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             // the rank of the global column in that row's ascending list of non-empty columns
             const int64_t cbi = T.sn_ucol[ib];
             const int pn = T.sn_ncolu[ib], fib = T.xsup[ib];
-            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? lsub[t] : 0;
+            for (int t = tid; t < TMv; t += NT) s_rowmap[t] = (t < nr) ? ZS * lsub[t / ZS] + t % ZS : 0;
             for (int t = tid; t < TNv; t += NT) {
                 int cm = 0;
                 if (t < nc) {
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.ucol_gc[cbi + mid] < gc) lo = mid + 1; else hi = mid; }
                     if (lo < pn && T.ucol_gc[cbi + lo] == gc) cm = T.ucol_cp[cbi + lo] - (fib + T.ucol_ld[cbi + lo]); else s_dinfo[0] = -1;
                 }
-                s_colmap[t] = cm;
+                s_colmap[t] = ZS * cm;
             }
             __syncthreads();
         } else
@@ -1334,14 +1334,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             for (int t = tid; t < TMv; t += NT) {
                 int v = 0;
                 if (t < nr) {
-                    const int gr = lsub[t];
+                    const int gr = lsub[t / ZS];
                     int lo = 0, hi = pn;
                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (prow[mid] < gr) lo = mid + 1; else hi = mid; }
-                    if (lo < pn && prow[lo] == gr) v = lo; else s_dinfo[0] = -1;
+                    if (lo < pn && prow[lo] == gr) v = ZS * lo + t % ZS; else s_dinfo[0] = -1;
                 }
                 s_rowmap[t] = v;
             }
-            for (int t = tid; t < TNv; t += NT) s_colmap[t] = s_jj[t] * pn;
+            for (int t = tid; t < TNv; t += NT) s_colmap[t] = ZS * s_jj[t] * pn;
             __syncthreads();
         }
         if (dblk == -2) dblk = s_dinfo[0];
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         if (MM != 1 && !has_dst && tid == 0) atomicAdd(&info[2], 1);     // (the plan-time build pass only writes records: the factorisation's pass counts)
         // destination block: (row offset inside the panel, its row ids, its row count) of L(ib, jb), or the index position of U(ib, jb)
         int di0 = 0, di1 = 0, di2 = 0;
-        int64_t dbase = mergedU ? T.sn_uval[ib] : (merged ? T.sn_lval[jb] : 0);
+        int64_t dbase = mergedU ? ZS * T.sn_uval[ib] : (merged ? ZS * T.sn_lval[jb] : 0);
         if (has_dst && !merged) {
             if (ib >= jb) { di0 = T.lb_rowoff[dblk]; di1 = T.lb_lptr[dblk]; di2 = T.lb_nbrow[dblk]; dbase = ZS * T.sn_lval[jb]; }
             else { di0 = T.ub_iukp[dblk]; dbase = ZS * T.sn_uval[ib]; }

@@ -220,12 +220,12 @@ static int build_tables(Handle &H, HostTables &t)
     // floor).  Per U block the rows of the L blocks at and below it are re-cut into tiles when that saves a tile; the destination row map of such
     // a tile is a search in the destination panel's (ascending) row list instead of one block's row list.  Real arithmetic, list schedules only.
     t.ub_mrt_off.assign(t.ub_gid.size(), 0); t.ub_mrt_cnt.assign(t.ub_gid.size(), 0);
-    if (!H.z && !H.env.no_merge_tiles && !H.opt.deterministic)
+    if (!H.env.no_merge_tiles && !H.opt.deterministic)
         for (int k = 0; k < ns; ++k) {
             if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_rows_sorted[k]) continue;
             const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k], nb = t.sn_nlb[k], nub = t.sn_nub[k];
             const int bfirst = t.sn_ldiag[k] ? 1 : 0;
-            const int tm = t.sn_big[k] ? 128 : 64;
+            const int tm = (t.sn_big[k] ? 128 : 64) / (H.z ? 2 : 1);      // complex16: a tile is 64 / 32 panel rows (128 / 64 real rows of the embedding)
             for (int u = 0; u < nub; ++u) {
                 const int jb = t.ub_gid[ub0 + u];
                 if (!t.sn_rows_sorted[jb] || !(t.sn_flags[jb] & SNF_L_OWN)) continue;
@@ -249,7 +249,7 @@ static int build_tables(Handle &H, HostTables &t)
     // ... and merged COLUMN tiles: L(ib, k) U(k, jb) of every block column jb > ib lands in ONE destination U row (ib); the non-empty columns of
     // those U blocks are contiguous in the U slot of k.  Destination column map = rank of the global column in row ib's ascending column list.
     t.lb_mct_off.assign(t.lb_gid.size(), 0); t.lb_mct_cnt.assign(t.lb_gid.size(), 0);
-    if (!H.z && !H.env.no_merge_tiles && !H.opt.deterministic)
+    if (!H.env.no_merge_tiles && !H.opt.deterministic)
         for (int k = 0; k < ns; ++k) {
             if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_ucols_sorted[k]) continue;
             const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k], nb = t.sn_nlb[k], nub = t.sn_nub[k];
@@ -351,7 +351,7 @@ static int dest_block(const HostTables &t, int ib, int jb)
     return (p != g + nb && *p == jb) ? o + (int) (p - g) : -1;
 }
 
-static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, const std::vector<int> &defer, LevelSched &S)
+static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, const std::vector<int> &defer, LevelSched &S, bool zrows = false /* complex16: row tiles of 64 / 32 panel rows */)
 {
     // every Schur tile of the schedule as (supernode, absolute row tile, absolute column tile, destination block): ONE load gives a
     // workgroup what it otherwise chases through a prefix search and six tables.  Per level and tile-size group, four parts:
@@ -380,7 +380,7 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
                 if (!nrt || !nct) continue;
                 const bool deferred = !defer.empty() && defer[k];               // runs parts 0 and 1 only
                 const int r0 = t.sn_rt_off[k], c0 = t.sn_ct_off[k], nub = t.sn_nub[k], ub0 = t.sn_ub_off[k];
-                const int tmk = t.sn_big[k] ? 128 : 64;
+                const int tmk = (t.sn_big[k] ? 128 : 64) / (zrows ? 2 : 1);
                 // the tiles of k as (absolute row tile, column tile) pairs: per column tile the block pairs' own row tiles, or -- where the U block
                 // has merged row tiles -- those for the block rows at and below the U block's supernode and the own tiles for the ones above it
                 cand.clear();
@@ -675,7 +675,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
                 H.fused_pairs += 1;
             }
     }
-    build_tile_lists(t, lvl, H.h_defer, S);
+    build_tile_lists(t, lvl, H.h_defer, S, H.z);
 }
 
 static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
