@@ -252,6 +252,7 @@ struct Handle {
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
         int level_split_min = 4096;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
+        bool fuse_small = true;      // SLUAMD_FUSE_SMALL=0: K-fused pairs only where the 128 x 128 tile configuration runs (round 3)
         int ksplit = 4;              // SLUAMD_KSPLIT: workgroups per tile (shares of K) for the diagonal-block tiles on the panel chain when a launch has at most 64 of them (1 = off)
         int big_util_pct = 50, big_min_cols = 96;   // SLUAMD_BIG_UTIL_PCT / SLUAMD_BIG_MIN_COLS: a supernode runs 128 x 128 tiles when it is at least this wide and its block pairs fill that share of them
         bool no_merge_tiles = false; // SLUAMD_NO_MERGE_TILES: every (L block, U block) pair keeps its own Schur tiles (round 3)

@@ -651,7 +651,8 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
         for (int l = 0; l + 1 < S.nlevels; ++l)
             for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) {
                 const int b = S.nodes[i], a = b - 1;
-                if (a < 0 || lvl[a] != l || !t.sn_big[a] || !t.sn_big[b]) continue;
+                if (a < 0 || lvl[a] != l) continue;
+                if (!H.env.fuse_small && (!t.sn_big[a] || !t.sn_big[b])) continue;      // (SLUAMD_FUSE_SMALL: pairs whose successor runs the 64 x 64 configuration too)
                 int srcs[3] = {a, -1, -1}, nsrc = 1;
                 for (int j = 0; j < 3 && H.h_fuse_prev[3 * (size_t) a + j] >= 0; ++j) {
                     if (nsrc == maxprev) { nsrc = -1; break; }       // a already closes a full group: b starts a new one later
