@@ -364,6 +364,8 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
     // A deferred (K-fused) supernode runs parts 0 and 1 only; its partner on the next level applies everything else.
     S.sn_level = lvl;
     S.u_off.assign(8 * S.nlevels + 1, 0);
+    const bool plan_debug = getenv("SLUAMD_PLAN_DEBUG") != nullptr;
+    double dbg_exact[2] = {0, 0}, dbg_exec[2] = {0, 0}, dbg_full[2] = {0, 0}, dbg_tiles[2] = {0, 0};
     std::vector<int8_t> cflag;
     std::vector<int> dcache;
     struct Cand { int a, c, w; };
@@ -436,12 +438,29 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
                     return x.w < y.w; });
                 for (auto &q : bulk) bucket[3].push_back(entry(q));
             }
+            if (plan_debug)
+                for (int part = 0; part < 4; ++part)
+                    for (auto &u : bucket[part]) {       // executed MFMA area (in the granularity at which idle waves skip) against the useful area, weighted by the source width
+                        const int nr = t.rtile[u.y].z, nc = t.ctile[u.z].z;
+                        const double kw = S.sn_level.empty() ? 1.0 : 1.0;
+                        const int ksz = (int) (t.sn_ldu[u.x]);
+                        (void) kw;
+                        dbg_exact[g] += (double) nr * nc * ksz;
+                        dbg_exec[g] += (g == 0 ? (double) ((nr + 31) / 32 * 32) * ((nc + 63) / 64 * 64) : (double) ((nr + 31) / 32 * 32) * ((nc + 31) / 32 * 32)) * ksz;
+                        dbg_full[g] += (g == 0 ? 128.0 * 128.0 : 64.0 * 64.0) * ksz;
+                        dbg_tiles[g] += 1;
+                    }
             for (int part = 0; part < 4; ++part) {
                 S.ulist.insert(S.ulist.end(), bucket[part].begin(), bucket[part].end());
                 S.u_off[(2 * l + g) * 4 + part + 1] = (int) S.ulist.size();
             }
         }
     }
+    if (plan_debug)
+        for (int g = 0; g < 2; ++g)
+            fprintf(stderr, "[sluamd_plan] tile lists, %s configuration: %.0f tiles, useful area x K %.4g, executed (wave-skip granularity) %.4g = %.3f x, full tiles %.4g = %.3f x\n",
+                    g == 0 ? "128 x 128" : "64 x 64", dbg_tiles[g], dbg_exact[g], dbg_exec[g], dbg_exact[g] > 0 ? dbg_exec[g] / dbg_exact[g] : 0.0, dbg_full[g],
+                    dbg_exact[g] > 0 ? dbg_full[g] / dbg_exact[g] : 0.0);
 }
 
 // Dataflow unit lists of the sweeps over the top of the schedule (LevelSched::chain_l0 ...): the levels from the first one
