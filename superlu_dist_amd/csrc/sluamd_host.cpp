@@ -40,6 +40,8 @@ void read_env(Handle::Env &e)
     e.no_tile_maps = getenv("SLUAMD_NO_TILE_MAPS") != nullptr;
     e.no_level_split = getenv("SLUAMD_NO_LEVEL_SPLIT") != nullptr;
     e.no_merge_tiles = getenv("SLUAMD_NO_MERGE_TILES") != nullptr;
+    if (const char *v = getenv("SLUAMD_FUSE_TAIL_GUARD")) e.fuse_tail_guard = atoi(v);
+    if (const char *v = getenv("SLUAMD_FUSE_GROUP_MIN_NODES")) e.fuse_group_min_nodes = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_SMALL")) e.fuse_small = atoi(v) != 0;
     if (const char *v = getenv("SLUAMD_KSPLIT")) e.ksplit = std::max(1, std::min(16, atoi(v)));
     if (const char *v = getenv("SLUAMD_BIG_UTIL_PCT")) e.big_util_pct = atoi(v);

@@ -248,7 +248,9 @@ struct Handle {
     // environment switches, read ONCE at creation (they may differ per handle)
     struct Env {
         bool no_lookahead = false, no_fuse = false, no_big_tiles = false, schur_4waves = false, trsm_rs32 = false, profile = false, profile_dump = false, trsm_panels = false, diag_v1 = false;
-        int fuse_min_pct = 75, fuse_max_prev = 1, reserve_cus = 0;
+        int fuse_min_pct = 75, fuse_max_prev = 3, reserve_cus = 0;
+        int fuse_group_min_nodes = 8;   // SLUAMD_FUSE_GROUP_MIN_NODES: ... and only on levels of at least this many supernodes
+        int fuse_tail_guard = 0;    // SLUAMD_FUSE_TAIL_GUARD: groups of more than two K-fused supernodes (fuse_max_prev > 1) only below the last N levels
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
         int level_split_min = 4096;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)

@@ -665,9 +665,14 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     S.lvl_defer.assign(S.nlevels, 0);
     if (H.h_fuse_prev.empty()) { H.h_fuse_prev.assign(3 * (size_t) ns, -1); H.h_defer.assign(ns, 0); H.h_pair_roff.assign(3 * (size_t) ns, -1); H.h_pair_coff.assign(3 * (size_t) ns, -1); }
     if (!H.env.no_fuse && !H.opt.deterministic && !H.z) {
-        const int maxprev = H.env.fuse_max_prev;   // measured: pairs beat groups of 3-4 end to end (longer urgent tiles sit on the panel chain)
+        const int maxprev_env = H.env.fuse_max_prev;   // measured: pairs beat groups of 3-4 end to end (longer urgent tiles sit on the panel chain) ...
         std::vector<int> rowmap[3], colinfo[3];
-        for (int l = 0; l + 1 < S.nlevels; ++l)
+        for (int l = 0; l + 1 < S.nlevels; ++l) {
+            // ... so groups of more than two only form where the bulk launches hide the chain: below the last `fuse_tail_guard` levels
+            // (and whose level holds at least `fuse_group_min_nodes` supernodes: 100^3 -> the bottom ~20 levels, whatever the depth of the tree)
+            // XY layers: pairs only -- the three scratch copies keep a deferred supernode's received panels for ONE more level
+            const bool xy_layer = H.grid.Pr * H.grid.Pc > 1;
+            const int maxprev = (!xy_layer && S.nlevels - (l + 1) > H.env.fuse_tail_guard && S.lvl_off[l + 2] - S.lvl_off[l + 1] >= H.env.fuse_group_min_nodes) ? maxprev_env : 1;
             for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) {
                 const int b = S.nodes[i], a = b - 1;
                 if (a < 0 || lvl[a] != l) continue;
@@ -694,6 +699,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
                 S.lvl_defer[l] = 1;
                 H.fused_pairs += 1;
             }
+        }
     }
     build_tile_lists(t, lvl, H.h_defer, S, H.z);
 }

@@ -196,3 +196,39 @@ def test_merged_schur_tiles_cover_the_same_updates(emul, monkeypatch):
     scale = np.abs(v).max()
     assert np.abs(out["merged"][1] - out["plain"][1]).max() <= 1e-12 * scale
     assert np.abs(out["merged"][2] - out["plain"][2]).max() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("sched_mode", [0, 2])
+def test_k_fused_groups_of_three(emul, monkeypatch, sched_mode):
+    """K-fused GROUPS (round 4 default on 1 x 1 layers, on levels of >= 8 supernodes: a supernode's tiles also accumulate the deferred updates of its
+    two chain predecessors -- one prologue and one scatter for three sources): forced onto every level of a small tree
+    (SLUAMD_FUSE_GROUP_MIN_NODES=1), plain and under an adversarial stream schedule, against the same factorisation without any fusion."""
+    import ctypes
+    from superlu_dist_amd import driver, matgen
+    N = 28
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(11)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=128)
+    out = {}
+    for mode in ("groups", "none"):
+        monkeypatch.setenv("SLUAMD_FUSE_GROUP_MIN_NODES", "1")
+        if mode == "none":
+            monkeypatch.setenv("SLUAMD_NO_FUSE", "1")
+        symb.distribute_host(v)
+        fs = symb.flat_store()
+        h = driver.LUHandle.from_store(fs)
+        fused = h.stats()["reserved_i"]
+        if mode == "groups":
+            emul.sluamd_emul_sched(ctypes.c_int(sched_mode), ctypes.c_uint(5))
+        assert h.pdgstrf3d(0.0) == 0
+        emul.sluamd_emul_sched(ctypes.c_int(0), ctypes.c_uint(1))
+        h.copy_to_host(); h.destroy()
+        out[mode] = (fused, fs.Lnzval.copy(), fs.Unzval.copy())
+    symb.free()
+    assert out["groups"][0] >= 3 and out["none"][0] == 0
+    scale = np.abs(v).max()
+    assert np.abs(out["groups"][1] - out["none"][1]).max() <= 1e-12 * scale
+    assert np.abs(out["groups"][2] - out["none"][2]).max() <= 1e-12 * scale
