@@ -357,7 +357,7 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
            const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0, int ksplit = 1 /* > 1: that many workgroups per tile, each a share of K (128 x 128 tiles) */);
 // per-tile records of the list schedules (k_schur): mmode 1 = build pass (writes the records of the launch's tiles at tmaps, no update),
 // mmode 2 = the tiles read their records; ints per record for a tile configuration
-inline int schur_rec_ints(int cfg, bool z) { return (cfg <= 1) ? 32 + 128 + 3 * 128 : 32 + 64 + 3 * 64; (void) z; }
+inline int schur_rec_ints(int cfg, bool z) { return (cfg <= 1) ? 64 + 128 + 3 * 128 : 64 + 64 + 3 * 64; (void) z; }
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);

@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     __shared__ int s_lead2[TNv];
     __shared__ int s_jj[TNv];     // column id inside supernode jb
     __shared__ int s_dinfo[1];
-    constexpr int HDR = 32;                          // header ints of a tile record: [0,16) the tile itself, [16,32) its K-fused predecessor
+    constexpr int HDR = 64;                          // header ints of a tile record: [0,16) the tile itself, [16] number of K-fused predecessors, [17 + 11 j, 28 + 11 j) predecessor j (nearest first)
     __shared__ int s_hdr[HDR];
     constexpr int REC = HDR + TMv + 3 * TNv;         // ints per tile record (MM 1 / 2)
 
@@ -1393,14 +1393,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
                 if (!Z && T.fuse_prev) { while (np < 3 && T.fuse_prev[3 * k + np] >= 0) ++np; }
                 rec[16] = np;
                 for (int q = 17; q < HDR; ++q) rec[q] = 0;
-                if (np == 1) {
-                    const int pj = 3 * k, ks = T.fuse_prev[pj];
+                for (int j = 0; j < np; ++j) {
+                    const int pj = 3 * k + j, ks = T.fuse_prev[pj];
                     const int nss = T.xsup[ks + 1] - T.xsup[ks];
                     const int64_t lo = T.sn_lval[ks], uo = T.sn_uval[ks];
                     const int64_t co = 2 * (int64_t) (T.pair_coff[pj] + stc), ro = (int64_t) T.pair_roff[pj] + Rw;
-                    rec[17] = nss; rec[18] = T.sn_nsupr[ks]; rec[19] = (nss - T.sn_ldu[ks]) & ~3;
-                    rec[20] = (int) (uint32_t) lo; rec[21] = (int) (lo >> 32); rec[22] = (int) (uint32_t) uo; rec[23] = (int) (uo >> 32);
-                    rec[24] = (int) (uint32_t) co; rec[25] = (int) (co >> 32); rec[26] = (int) (uint32_t) ro; rec[27] = (int) (ro >> 32);
+                    int *r = rec + 17 + 11 * j;
+                    r[0] = nss; r[1] = T.sn_nsupr[ks]; r[2] = (nss - T.sn_ldu[ks]) & ~3;
+                    r[3] = (int) (uint32_t) lo; r[4] = (int) (lo >> 32); r[5] = (int) (uint32_t) uo; r[6] = (int) (uo >> 32);
+                    r[7] = (int) (uint32_t) co; r[8] = (int) (co >> 32); r[9] = (int) (uint32_t) ro; r[10] = (int) (ro >> 32);
                 }
             }
             for (int t = tid; t < TMv; t += NT) rec[HDR + t] = has_dst ? s_rowmap[t] : 0;
@@ -1472,10 +1473,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     int buf = 0;
     for (int src = 0; src <= nprev; ++src) {       // farthest predecessor first, k itself last
         int kbeg;
-        if (MM == 2 && src < nprev && nprev == 1) {
-            // the predecessor's scalars come with the record: its two maps are the only loads before its first fetch
-            const int nss = s_hdr[17];
-            const int64_t co = ((int64_t) s_hdr[25] << 32) | (uint32_t) s_hdr[24], ro = ((int64_t) s_hdr[27] << 32) | (uint32_t) s_hdr[26];
+        if (MM == 2 && src < nprev) {
+            // the predecessor's scalars come with the record (up to three of them, nearest first; the farthest runs first): its two maps are the only loads before its first fetch
+            const int *ph = s_hdr + 17 + 11 * (nprev - 1 - src);
+            const int nss = ph[0];
+            const int64_t co = ((int64_t) ph[8] << 32) | (uint32_t) ph[7], ro = ((int64_t) ph[10] << 32) | (uint32_t) ph[9];
             const int *cinfo = T.pair_colinfo + co;
             const int ra = (li < nr) ? T.pair_rowmap[ro + li] : -1;
             for (int t = tid; t < TNv; t += NT) {
@@ -1483,10 +1485,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
                 s_lead2[t] = (t < nc) ? cinfo[2 * t + 1] : nss;
             }
             __syncthreads();
-            ns_s = nss; lda_s = s_hdr[18];
-            Lrow = T.val + (((int64_t) s_hdr[21] << 32) | (uint32_t) s_hdr[20]) + max(ra, 0);
-            Uvs = T.val + (((int64_t) s_hdr[23] << 32) | (uint32_t) s_hdr[22]);
-            kbeg = s_hdr[19]; lrow_ok = ra >= 0;
+            ns_s = nss; lda_s = ph[1];
+            Lrow = T.val + (((int64_t) ph[4] << 32) | (uint32_t) ph[3]) + max(ra, 0);
+            Uvs = T.val + (((int64_t) ph[6] << 32) | (uint32_t) ph[5]);
+            kbeg = ph[2]; lrow_ok = ra >= 0;
             cpS = s_cptr2; ldS = s_lead2;
         } else if (src < nprev) {
             const int pj = 3 * k + (nprev - 1 - src);
