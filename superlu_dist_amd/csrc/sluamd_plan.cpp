@@ -76,6 +76,7 @@ static int build_tables(Handle &H, HostTables &t)
     t.ucolptr.assign(hs.uidx.size(), 0); t.unzcol.assign(hs.uidx.size(), 0);
     t.sn_big.assign(ns, 0);
     t.sn_rows_sorted.assign(ns, 0); t.sn_ucols_sorted.assign(ns, 0);
+    t.sn_flops_exact.assign(ns, 0.0); t.sn_bytes_alg.assign(ns, 0.0);
     t.sn_lrow.assign(ns, 0); t.sn_ucol.assign(ns, 0);
     H.max_nsupc = 0;
     auto &st = H.st;
@@ -208,7 +209,7 @@ static int build_tables(Handle &H, HostTables &t)
         st.flops_schur_padded += 2.0 * rrows * ldu * ncol_tot;
         st.schur_bytes_alg += 16.0 * rrows * ncol_tot;   // read-modify-write of every updated destination element
         st.flops_schur_exact += 2.0 * rrows * exact;
-        if (t.sn_big[k]) { st.flops_schur_exact_big += 2.0 * rrows * exact; st.schur_bytes_alg_big += 16.0 * rrows * ncol_tot; }
+        t.sn_flops_exact[k] = 2.0 * rrows * exact; t.sn_bytes_alg[k] = 16.0 * rrows * ncol_tot;      // attributed to a tile configuration once the K-fused groups are known (build_schedule)
         if (fl & SNF_OWN_DIAG) st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc;
         if (l_own) st.flops_panel += (double) nsupc * nsupc * rrows;
         if (u_own) st.flops_panel += (double) nsupc * exact;
@@ -275,7 +276,7 @@ static int build_tables(Handle &H, HostTables &t)
                 }
             }
         }
-    if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; st.flops_schur_exact_big *= 4; st.schur_bytes_alg_big *= 2; }   // complex multiply-add = 8 flop
+    if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; }   // complex multiply-add = 8 flop
     H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu; H.h_flags = t.sn_flags; H.h_ldiag = t.sn_ldiag;
     return 0;
 }
@@ -702,6 +703,13 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
         }
     }
     build_tile_lists(t, lvl, H.h_defer, S, H.z);
+    // by-configuration accounting: a supernode's Schur flops run in ITS tile configuration, except a deferred (K-fused) one's, whose update is applied by
+    // the tiles of the first non-deferred successor of its chain (the few urgent tiles it runs itself are counted there too)
+    for (int k : list) {
+        int ex = k;
+        while (ex + 1 < ns && !H.h_defer.empty() && H.h_defer[ex]) ++ex;
+        if (t.sn_big[ex]) { H.st.flops_schur_exact_big += (H.z ? 4.0 : 1.0) * t.sn_flops_exact[k]; H.st.schur_bytes_alg_big += (H.z ? 2.0 : 1.0) * t.sn_bytes_alg[k]; }
+    }
 }
 
 static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)

@@ -29,6 +29,7 @@ struct HostTables {
     std::vector<int2> rt_info;     // per row tile: (gid of its block row, offset of its row ids inside the lidx arena)
     std::vector<int4> ct_info;     // per column tile: (gid of its block column, offset of its U block inside the uidx arena, rank of its first column among the non-empty columns of the U row, 0)
     std::vector<uint8_t> sn_big;   // 1: supernode uses the 128x128 Schur tile configuration
+    std::vector<double> sn_flops_exact, sn_bytes_alg;   // per supernode: exact-segment Schur flops and algorithmic destination bytes (by-configuration accounting)
     // merged row tiles (round 4): per U block (index sn_ub_off[k] + b) a range of rtile entries that cover ALL slot rows of the L blocks with
     // gid >= the U block's gid -- every one of them updates the same destination panel -- cut into tiles across block boundaries; count 0 = the
     // block pairs keep their own tiles.  (ulist entries of merged tiles carry destination -3.)
