@@ -524,6 +524,112 @@ void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunit
     }
 }
 
+// ---- joined links (LevelSched::join; k_sweep's joined units) -------------------------------------------------------------------------------------------
+static inline int64_t rec64(int lo, int hi) { return ((int64_t) hi << 32) | (uint32_t) lo; }
+// regular units given by their records; near rows / columns are not theirs
+static void fwd_unit_rec(const DevTables &T, const int4 *rec, const double *xsrc, double *x, int64_t ldx, int nrhs)
+{
+    const int fst = rec[0].x, ns = rec[0].y & 0xffff, lda = rec[0].z, row0 = rec[0].w;
+    const int64_t loff = rec64(rec[1].x, rec[1].y), roff = rec64(rec[1].z, rec[1].w);
+    for (int r = 0; r < 64 && row0 + r < lda; ++r) {
+        if (T.lrow_near && T.lrow_near[roff + r]) continue;
+        const int grow = T.lrow[roff + r];
+        for (int q = 0; q < nrhs; ++q) {
+            double acc = 0.0;
+            for (int kk = 0; kk < ns; ++kk) acc += T.val[loff + r + (size_t) kk * lda] * xsrc[fst + kk + (int64_t) q * ldx];
+            x[grow + (int64_t) q * ldx] -= acc;
+        }
+    }
+}
+static void bwd_unit_rec(const DevTables &T, const int4 *rec, const double *xcols, double *x, int64_t ldx, int nrhs)
+{
+    const int fst = rec[0].x, ns = rec[0].y & 0xffff, ncol = rec[0].z;
+    const int64_t ci0 = rec64(rec[1].x, rec[1].y), uoff = rec64(rec[1].z, rec[1].w);
+    for (int c = 0; c < ncol; ++c) {
+        if (T.ucol_near && T.ucol_near[ci0 + c]) continue;
+        const int ld = T.ucol_ld[ci0 + c], cp = T.ucol_cp[ci0 + c], gc = T.ucol_gc[ci0 + c];
+        for (int q = 0; q < nrhs; ++q) {
+            const double xv = xcols[gc + (int64_t) q * ldx];
+            for (int i = ld; i < ns; ++i) x[fst + i + (int64_t) q * ldx] -= T.val[uoff + cp + (i - ld)] * xv;
+        }
+    }
+}
+// forward joined unit (s, c) of supernode j: t = b_j[block c] - (rows of the level-l panels in block c) x_k, then y_j[strip s] += Linv[s, c] t
+static void join_fwd_unit(const DevTables &T, const int4 *rec, const int4 *jaux, const double *xa, double *xb, int64_t ldx, int nrhs)
+{
+    const int fst = rec[0].x, ns = rec[0].y, st = rec[0].z, c = rec[0].w, nsrc = rec[1].z, ovf = rec[1].w;
+    const double *Li = T.inv + rec64(rec[1].x, rec[1].y);
+    if (c > st || 64 * st >= ns) { fprintf(stderr, "[emul] joined forward unit (%d, %d) of a %d-column supernode\n", st, c, ns); abort(); }
+    const int nc = std::min(64, ns - 64 * c);
+    for (int q = 0; q < nrhs; ++q) {
+        double t[64];
+        for (int i = 0; i < nc; ++i) t[i] = xa[fst + 64 * c + i + (int64_t) q * ldx];
+        for (int si = 0; si < nsrc; ++si) {
+            const int4 *sr = si < 3 ? rec + 2 + 2 * si : jaux + 2 * (size_t) (ovf + si - 3);
+            const int fk = sr[0].x, nk = sr[0].y, lda = sr[0].z, nr = sr[0].w;
+            const int64_t loff = rec64(sr[1].x, sr[1].y), roff = rec64(sr[1].z, sr[1].w);
+            for (int r = 0; r < nr; ++r) {
+                const int pos = T.lrow[roff + r] - fst - 64 * c;
+                if (pos < 0 || pos >= nc || !T.lrow_near || !T.lrow_near[roff + r]) { fprintf(stderr, "[emul] joined forward unit: source row outside its column block / not flagged near\n"); abort(); }
+                double acc = 0.0;
+                for (int kk = 0; kk < nk; ++kk) acc += T.val[loff + r + (size_t) kk * lda] * xb[fk + kk + (int64_t) q * ldx];
+                t[pos] -= acc;
+            }
+        }
+        for (int r = 64 * st; r < std::min(ns, 64 * st + 64); ++r) {
+            double a = 0.0;
+            for (int cc = 0; cc < nc; ++cc) if (64 * c + cc <= r) a += Li[r + (size_t) (64 * c + cc) * ns] * t[cc];
+            xb[fst + r + (int64_t) q * ldx] += a;
+        }
+    }
+}
+// backward joined unit (s, c) of supernode k: t = w_k[block c] - U(k rows of block c, columns of level l+1) x, then x_k[strip s] += Uinv[s, c] t
+static void join_bwd_unit(const DevTables &T, const int4 *rec, const int4 *jaux, double *xa, const double *xb, int64_t ldx, int nrhs)
+{
+    const int fst = rec[0].x, ns = rec[0].y, st = rec[0].z, c = rec[0].w, noff = rec[1].z, ncnt = rec[1].w;
+    const double *Ui = T.inv + rec64(rec[1].x, rec[1].y);
+    const int64_t uoff = rec64(rec[2].x, rec[2].y);
+    if (st > c || 64 * c >= ns) { fprintf(stderr, "[emul] joined backward unit (%d, %d) of a %d-column supernode\n", st, c, ns); abort(); }
+    const int nc = std::min(64, ns - 64 * c);
+    for (int q = 0; q < nrhs; ++q) {
+        double t[64];
+        for (int i = 0; i < nc; ++i) t[i] = xb[fst + 64 * c + i + (int64_t) q * ldx];
+        for (int e = 0; e < ncnt; ++e) {
+            const int4 col = jaux[noff + e];
+            const double xv = xa[col.z + (int64_t) q * ldx];
+            for (int i = std::max(col.x, 64 * c); i < 64 * c + nc; ++i) t[i - 64 * c] -= T.val[uoff + col.y + (i - col.x)] * xv;
+        }
+        for (int r = 64 * st; r < std::min(ns, 64 * st + 64); ++r) {
+            double a = 0.0;
+            for (int cc = 0; cc < nc; ++cc) if (64 * c + cc >= r) a += Ui[r + (size_t) (64 * c + cc) * ns] * t[cc];
+            xa[fst + r + (int64_t) q * ldx] += a;
+        }
+    }
+}
+// one joined link: the joined units and the regular units of the launch in ONE shuffled order under the adversarial modes (they are independent)
+void sweep_join(hipStream_t, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits, double *xa, double *xb,
+                int64_t ldx, int nrhs, int)
+{
+    const int total = std::max(nj, 0) + std::max(nunits, 0);
+    std::vector<int> order(total);
+    for (int i = 0; i < total; ++i) order[i] = i;
+    if (unsigned sd = emul_launch_seed()) { std::mt19937 rng(sd + 29); std::shuffle(order.begin(), order.end(), rng); }
+    for (int it = 0; it < total; ++it) {
+        const int w = order[it];
+        if (w < nj) {
+            if (lower) join_fwd_unit(T, jrecs + 8 * (size_t) w, jaux, xa, xb, ldx, nrhs);
+            else join_bwd_unit(T, jrecs + 4 * (size_t) w, jaux, xa, xb, ldx, nrhs);
+        } else if (lower) fwd_unit_rec(T, urecs + 2 * (size_t) (w - nj), xb, xa, ldx, nrhs);
+        else bwd_unit_rec(T, urecs + 2 * (size_t) (w - nj), xa, xb, ldx, nrhs);
+    }
+}
+void zero_nodes(hipStream_t, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs)
+{
+    for (int i = 0; i < nn; ++i)
+        for (int q = 0; q < nrhs; ++q)
+            for (int r = T.xsup[nodes[i]]; r < T.xsup[nodes[i] + 1]; ++r) x[r + (int64_t) q * ldx] = 0.0;
+}
+
 // Dataflow sweep (k_chain): the device runs a unit as soon as the flags it waits for have reached their values -- in ANY order
 // that honours those waits.  Here: immediate mode = list order; adversarial modes = a seeded random choice among the ready units,
 // so a wait missing from the host-built table changes the result on CPU.  A unit list that cannot complete (a signal nobody sends)
@@ -692,6 +798,19 @@ void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunit
 {
     if (ndu + nunits <= 0) return;
     emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, max_nsupc); });
+}
+
+void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits, double *xa, double *xb,
+                int64_t ldx, int nrhs, int max_nsupc)
+{
+    if (nj + nunits <= 0) return;
+    emul_enqueue(s, [=] { impl::sweep_join(s, lower, T, jrecs, nj, jaux, urecs, nunits, xa, xb, ldx, nrhs, max_nsupc); });
+}
+
+void zero_nodes(hipStream_t s, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs)
+{
+    if (nn <= 0) return;
+    emul_enqueue(s, [=] { impl::zero_nodes(s, T, nodes, nn, x, ldx, nrhs); });
 }
 
 void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs, int *flags, int nflags,

@@ -3,7 +3,7 @@
 tag=${1:-solve}; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kss
-env "$@" rocprofv3 --kernel-trace -d /tmp/kss -o run -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-scaling-point > /tmp/kss.json 2> /tmp/kss.err
+env "$@" rocprofv3 --kernel-trace -d /tmp/kss -o run -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-scaling-point --no-configs4 > /tmp/kss.json 2> /tmp/kss.err
 cd $R
 db=$(find /tmp/kss -name "*.db" | head -1)
 python scripts/solve_timeline.py $db 2 > gpurun_out/${tag}_solve_timeline.txt 2>&1

@@ -574,6 +574,54 @@ static int ensure_w(Handle *H, int64_t doubles)
     return 0;
 }
 
+// Joined links (LevelSched::join): ONE launch per level.  Forward: the joined units of level l + 1 apply the level-l updates to their own block of the
+// right-hand side and ADD their share of y_j = Linv_j (...) into w (zeroed first); every other row of the level-l panels is updated by the regular units in
+// the same launch.  Backward: the joined units of level l subtract U(k, columns of level l + 1) x themselves and ADD x_k = Uinv_k (...) into d_x (the forest's
+// rows zeroed first; the top level keeps the storing strips).
+static void zero_forest(Handle *H, LevelSched &S, double *x, int64_t ldx, int nrhs)
+{
+    if ((int) S.nodes.size() == H->hs.nsupers) { for (int q = 0; q < nrhs; ++q) hipMemsetAsync(x + (int64_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.xsup[H->hs.nsupers], H->stream); }
+    else eng::zero_nodes(H->stream, H->T, S.d_nodes, (int) S.nodes.size(), x, ldx, nrhs);
+}
+static int solve_fwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    const int nl = S.nlevels;
+    if (nl == 0) return 0;
+    double *w = H->d_w;
+    zero_forest(H, S, w, ldx, nrhs);
+    eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) S.jf_off[0], S.jf_off[1] - S.jf_off[0], S.d_jf_aux, nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0]);
+    H->st.solve_launches += 1;
+    for (int l = 0; l < nl; ++l) {
+        const int j0 = l + 1 < nl ? S.jf_off[l + 1] : 0, nj = l + 1 < nl ? S.jf_off[l + 2] - j0 : 0;
+        const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
+        eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) j0, nj, S.d_jf_aux, S.d_jfu_recs + 2 * (size_t) S.jfu_off[l], S.jfu_off[l + 1] - S.jfu_off[l], d_x, w, ldx, nrhs, mx);
+        H->st.solve_launches += 1;
+    }
+    return 0;
+}
+static int solve_bwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    const int nl = S.nlevels;
+    if (nl == 0) return 0;
+    double *w = H->d_w;
+    zero_forest(H, S, d_x, ldx, nrhs);
+    // the chunks of the top level first (columns of ancestors in other forests, solved before this sweep); then per level the joined units beside the chunks
+    // of the level below (columns of levels >= l + 1 only: level l is theirs to skip)
+    eng::sweep_join(s, false, T, nullptr, 0, nullptr, S.d_jbu_recs + 2 * (size_t) S.jbu_off[nl - 1], S.jbu_off[nl] - S.jbu_off[nl - 1], d_x, w, ldx, nrhs, S.max_nsupc[nl - 1]);
+    H->st.solve_launches += 1;
+    for (int l = nl - 1; l >= 0; --l) {
+        const int mx = std::max(S.max_nsupc[l], l > 0 ? S.max_nsupc[l - 1] : 0);
+        const int u0 = l > 0 ? S.jbu_off[l - 1] : 0, u1 = l > 0 ? S.jbu_off[l] : 0;
+        eng::sweep_join(s, false, T, S.d_jb_recs + 4 * (size_t) S.jb_off[l], S.jb_off[l + 1] - S.jb_off[l], S.d_jb_aux, S.d_jbu_recs + 2 * (size_t) u0, u1 - u0, d_x, w, ldx, nrhs, mx);
+        H->st.solve_launches += 1;
+    }
+    return 0;
+}
+
 // Forward links.  x (= d_x) holds the right-hand side minus the updates applied so far; w receives the solved blocks y_k = Linv (x_k)
 // and is what the updates read.  After the forward sweeps of all Z levels w holds y for every supernode solved on this rank.
 static int solve_fwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
@@ -649,6 +697,7 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));
+        if (!rc && S.join && !use_chain(H, S)) return solve_fwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_fwd_links(H, S, d_x, ldx, nrhs);
     }
     for (int l = 0; l < S.nlevels; ++l) {
@@ -676,6 +725,7 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));      // (already there: the forward sweep ran first)
+        if (!rc && S.join && !use_chain(H, S)) return solve_bwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_bwd_links(H, S, d_x, ldx, nrhs);
     }
     for (int l = S.nlevels - 1; l >= 0; --l) {

@@ -43,10 +43,13 @@ void read_env(Handle::Env &e)
     if (const char *v = getenv("SLUAMD_FUSE_TAIL_GUARD")) e.fuse_tail_guard = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_GROUP_MIN_NODES")) e.fuse_group_min_nodes = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_SMALL")) e.fuse_small = atoi(v) != 0;
+    if (const char *v = getenv("SLUAMD_SOLVE_JOIN")) e.solve_join = atoi(v) != 0;
     if (const char *v = getenv("SLUAMD_KSPLIT")) e.ksplit = std::max(1, std::min(16, atoi(v)));
     if (const char *v = getenv("SLUAMD_BIG_UTIL_PCT")) e.big_util_pct = atoi(v);
     if (const char *v = getenv("SLUAMD_BIG_MIN_COLS")) e.big_min_cols = atoi(v);
     if (const char *v = getenv("SLUAMD_LEVEL_SPLIT_MIN")) e.level_split_min = atoi(v);
+    if (const char *v = getenv("SLUAMD_LEVEL_SPLIT_WDIV")) e.level_split_wdiv = atoi(v);
+    if (const char *v = getenv("SLUAMD_LEVEL_SPLIT_WMIN")) e.level_split_wmin = atof(v);
     e.no_fuse = getenv("SLUAMD_NO_FUSE") != nullptr;
     e.no_big_tiles = getenv("SLUAMD_NO_BIG_TILES") != nullptr;
     e.schur_4waves = getenv("SLUAMD_SCHUR_4WAVES") != nullptr;

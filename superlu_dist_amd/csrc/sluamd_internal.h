@@ -153,6 +153,9 @@ struct DevTables {
     // pair_colinfo[2*(pair_coff[3k+j] + c)] = (value offset, leading zeros) of k's c-th non-empty U column inside the
     // predecessor's U row (leading zeros = predecessor width when absent)
     const int *fuse_prev, *defer, *pair_roff, *pair_coff, *pair_rowmap, *pair_colinfo;
+    // joined sweeps (1 x 1 layers, LevelSched::join): per entry of lrow / ucol_gc, 1 = the row / column belongs to a supernode of the NEXT level of
+    // the owner's schedule -- its update is applied inside the joined diagonal units of that level, the regular units skip it (null: not planned)
+    const uint8_t *lrow_near, *ucol_near;
 };
 
 // One exchange message of the XY panel exchange: a contiguous range of the value arena sent to / received from one peer
@@ -222,6 +225,22 @@ struct LevelSched {
     std::vector<int4> fwd_recs, bwd_recs, diag_recs;
     int4 *d_fwd_recs = nullptr, *d_bwd_recs = nullptr, *d_diag_recs = nullptr;
     int *d_dg_prefix = nullptr; int64_t *d_dg_off = nullptr;
+    // ---- joined sweeps (round 4; 1 x 1 layers, real) ----
+    // The level-set sweeps above pay TWO dependent launches per level: the urgent updates of level l, then the diagonal solves of level l + 1.  Joined
+    // form: the diagonal solve of supernode j (level l + 1) is cut into 64 x 64 blocks (s, c) of its inverse, and the unit of block (s, c) first applies the
+    // updates of level l to ITS 64 entries of the right-hand side itself -- the rows of the level-l panels that fall into column block c of j (forward), the
+    // columns of level l + 1 in U(k, :) over the rows of block c (backward) -- then multiplies by the inverse block and ADDS into the (zeroed) output rows of
+    // strip s.  The near rows / columns are recomputed by every strip that needs them (a 256-column supernode: 10 units, block c read by 4 - c of them) and
+    // skipped by the regular units (DevTables::lrow_near / ucol_near), which now ALL run beside the next level's joined units: one launch per level.
+    //   forward unit, 8 int4:  (fst_j, ns_j, s, c) (Linv offset lo, hi, sources, first overflow source in jf_aux) then up to 3 sources of 2 int4:
+    //                          (fst_k, ns_k, lda_k, rows) (value offset of the first row lo, hi, lrow index of the first row lo, hi)
+    //   backward unit, 4 int4: (fst_k, ns_k, s, c) (Uinv offset lo, hi, first near column in jb_aux, near columns) (U value offset lo, hi, 0, 0) (0)
+    //   jb_aux: one int4 (leading zeros, value offset, global column, 0) per near column
+    //   regular units: the 2-int4 records of fwd_recs / bwd_recs; bit 16 of .y (width) set = the unit has near rows / columns to skip
+    bool join = false;
+    std::vector<int4> jf_recs, jf_aux, jb_recs, jb_aux, jfu_recs, jbu_recs;
+    std::vector<int> jf_off, jb_off, jfu_off, jbu_off;     // [nlevels + 1] unit ranges per level
+    int4 *d_jf_recs = nullptr, *d_jf_aux = nullptr, *d_jb_recs = nullptr, *d_jb_aux = nullptr, *d_jfu_recs = nullptr, *d_jbu_recs = nullptr;
 };
 
 struct Comm;   // sluamd_comm.h
@@ -253,7 +272,10 @@ struct Handle {
         int fuse_tail_guard = 0;    // SLUAMD_FUSE_TAIL_GUARD: groups of more than two K-fused supernodes (fuse_max_prev > 1) only below the last N levels
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
-        int level_split_min = 4096;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
+        int level_split_min = 2048;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
+        int level_split_wdiv = 128;  // SLUAMD_LEVEL_SPLIT_WDIV: levels heavier (panel values, upper bound from the block graph) than 1 / this of the forest's total are cut too; <= 1: off
+        double level_split_wmin = 1e9;   // SLUAMD_LEVEL_SPLIT_WMIN: ... in forests of at least this many panel values in total
+        bool solve_join = true;      // SLUAMD_SOLVE_JOIN=0: the two-launch links of round 3 (urgent updates, then diagonal strips) instead of the joined units
         bool fuse_small = true;      // SLUAMD_FUSE_SMALL=0: K-fused pairs only where the 128 x 128 tile configuration runs (round 3)
         int ksplit = 4;              // SLUAMD_KSPLIT: workgroups per tile (shares of K) for the diagonal-block tiles on the panel chain when a launch has at most 64 of them (1 = off)
         int big_util_pct = 50, big_min_cols = 96;   // SLUAMD_BIG_UTIL_PCT / SLUAMD_BIG_MIN_COLS: a supernode runs 128 x 128 tiles when it is at least this wide and its block pairs fill that share of them
@@ -314,6 +336,7 @@ struct Handle {
     std::vector<int64_t> h_sn_dinv, h_dptr;
     // K-fused updates (see DevTables): host images, built by build_schedule
     std::vector<int> h_fuse_prev, h_defer, h_pair_roff, h_pair_coff, h_pair_rowmap, h_pair_colinfo;
+    std::vector<uint8_t> h_lrow_near, h_ucol_near;   // DevTables::lrow_near / ucol_near while the schedules are built
     int fused_pairs = 0;
     int64_t xy_scratch_len = 0;    // values of the received-panel scratch (all copies)
     int xy_scratch_copies = 0;     // XY layers: copies of the received-panel scratch (by level modulo this), 0 on a 1 x 1 layer
@@ -372,6 +395,12 @@ void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *
 // launch (max_nsupc over everything in the launch)
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
                 double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc, const int4 *drecs = nullptr, const int4 *urecs = nullptr);
+// joined link (LevelSched::join): `nj` joined diagonal units (jrecs: 8 int4 each forward, 4 backward; jaux: overflow sources / near columns) + `nunits` regular
+// units given by their records (urecs, near rows / columns skipped), one launch; the joined units ADD into xb (lower) / xa (upper): zeroed rows expected
+void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits,
+                double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc);
+// x[rows of the supernodes `nodes`] = 0 (all right-hand sides)
+void zero_nodes(hipStream_t s, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs);
 // dataflow sweep over a topologically ordered unit list (LevelSched::cf_* / cb_*): ONE persistent launch; `flags` zeroed on s first;
 // the same two vectors as sweep_step
 void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,

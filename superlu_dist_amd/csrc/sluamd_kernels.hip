@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
 //
 // lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414): workgroup = (supernode,
 // 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
-template <int NT, bool COH = false>
+template <int NT, bool COH = false, int NBT = 16>   // NBT: loads per thread and batch (16: one batch covers a 256-column supernode with 1024 threads; 8: the builds for 8 waves per SIMD)
 __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, const double *xsrc /* solved x_k */, double *xdst /* lsum accumulators */,
                                                 int64_t ldx, int nrhs, double *xk /* ns x nrhs */, const int4 *rec = nullptr)
 {
@@ -1647,9 +1647,10 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     // lookups behind the unit list entry: the values and x_k go in flight one round trip earlier
     int fst, ns, lda, row0;
     int64_t loff, roff;
+    bool chk = false;           // joined links: the strip holds rows of the NEXT level's supernodes (DevTables::lrow_near) -- not this unit's to update
     if (rec) {
         const int4 a = rec[0], b = rec[1];
-        fst = a.x; ns = a.y; lda = a.z; row0 = a.w;
+        fst = a.x; ns = a.y & 0xffff; lda = a.z; row0 = a.w; chk = (a.y >> 16) != 0;
         loff = ((int64_t) b.y << 32) | (uint32_t) b.x; roff = ((int64_t) b.w << 32) | (uint32_t) b.z;
     } else {
         fst = T.xsup[k]; ns = T.xsup[k + 1] - fst; lda = T.sn_nsupr[k]; row0 = T.sn_ldiag[k] + strip * 64;
@@ -1661,13 +1662,14 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     const bool rvalid = row < lda;
     const double *L = T.val + loff + r;
     const int grow = (rvalid && part == 0) ? T.lrow[roff + r] : 0;   // flat map: no walk over the slot's block descriptors
+    const bool mine = !(chk && rvalid && part == 0 && T.lrow_near[roff + r]);
     const int cpp = (ns + NP - 1) / NP;           // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
     // the thread's first batch of L (all of it for supernodes of <= 16 NP columns) goes in flight BEFORE x_k is staged: it does not depend
     // on x, and on the levels where a workgroup's life is a chain of round trips this removes one of them
-    double lv0[16];
+    double lv0[NBT];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) lv0[u] = (rvalid && ka + u < kb) ? __builtin_nontemporal_load(L + (size_t) (ka + u) * lda) : 0.0;
+    for (int u = 0; u < NBT; ++u) lv0[u] = (rvalid && ka + u < kb) ? __builtin_nontemporal_load(L + (size_t) (ka + u) * lda) : 0.0;
     for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(xsrc + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
     __syncthreads();
     for (int q = 0; q < nrhs; ++q) {
@@ -1675,20 +1677,20 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
         double acc[4] = {0, 0, 0, 0};
         if (rvalid) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u & 3] += lv0[u] * xq[min(ka + u, ns - 1)];     // lv0 is zero past kb
-            int kk = ka + 16;
-            for (; kk + 16 <= kb; kk += 16) {
-                double lv[16];
+            for (int u = 0; u < NBT; ++u) acc[u & 3] += lv0[u] * xq[min(ka + u, ns - 1)];     // lv0 is zero past kb
+            int kk = ka + NBT;
+            for (; kk + NBT <= kb; kk += NBT) {
+                double lv[NBT];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);
+                for (int u = 0; u < NBT; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u & 3] += lv[u] * xq[kk + u];
+                for (int u = 0; u < NBT; ++u) acc[u & 3] += lv[u] * xq[kk + u];
             }
             for (; kk < kb; ++kk) acc[0] += __builtin_nontemporal_load(L + (size_t) kk * lda) * xq[kk];
         }
         s_red[part][r] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
-        if (part == 0 && rvalid) {
+        if (part == 0 && rvalid && mine) {
             double a = 0.0;
 #pragma unroll
             for (int p2 = 0; p2 < NP; ++p2) a += s_red[p2][r];
@@ -1698,35 +1700,41 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+template <int NT, int NBT = 16, int MINW = NT / 256>     // MINW: waves per SIMD the build is for (__launch_bounds__' second argument)
+__global__ __launch_bounds__(NT, MINW) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
                                                    int nn, const double *xsrc, double *xdst, int64_t ldx, int nrhs, const int2 *__restrict__ units,
                                                    const int4 *__restrict__ recs)
 {
     extern __shared__ double xk[];  // ns x nrhs
-    if (recs) { fwd_update_body<NT>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
+    if (recs) { fwd_update_body<NT, false, NBT>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
     int k, strip;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; strip = u.y; }   // host-built (supernode, strip) list of one launch
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
-    fwd_update_body<NT>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
+    fwd_update_body<NT, false, NBT>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
 }
 
 // x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
 // lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
-template <int NT, bool COH = false>   // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block)
+template <int NT, bool COH = false, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true>
+// NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block);
+// RBv = 4 with NT = 512 / 256: supernodes of up to 256 columns in smaller workgroups (more of them resident per CU: levels of MANY units, where overlapping the phases
+// of a workgroup's life -- record, maps, values, reduction, atomics -- across workgroups counts for more than the length of one life);
+// CBT = columns per batch of loads (CBT x RBv loads per lane in flight), UNR = false: one batch in flight at a time (the builds for 8 waves per SIMD)
 __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int chunk, const double *xcols /* solved x of the chunk's columns */,
                                                 double *xrows /* accumulators of x_k */, int64_t ldx, int nrhs, const int4 *rec = nullptr)
 {
-    constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = (NT == 1024) ? 4 : 1;
+    constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = RBv, UF = UNR ? 16 : 1;
+    static_assert(CPW % CBT == 0, "columns per wave must be a multiple of the batch");
     __shared__ int s_cp[64], s_ld[64], s_gc[64];
     __shared__ double s_xc[64];
     __shared__ double s_red[NWV][64 * RB];
     int fst, ns, ncol;          // `rec`: (first column, width, columns of this chunk) + (first entry in the flat column maps, offset of U(k,:)) as in fwd_update_body
     int64_t ci0, uoff;
+    bool chk = false;           // joined links: columns of the NEXT level's supernodes (DevTables::ucol_near) belong to that level's joined units: treated as empty here
     if (rec) {
         const int4 a = rec[0], b = rec[1];
-        fst = a.x; ns = a.y; ncol = a.z;
+        fst = a.x; ns = a.y & 0xffff; ncol = a.z; chk = (a.y >> 16) != 0;
         ci0 = ((int64_t) b.y << 32) | (uint32_t) b.x; uoff = ((int64_t) b.w << 32) | (uint32_t) b.z;
     } else {
         fst = T.xsup[k]; ns = T.xsup[k + 1] - fst; ncol = min(64, T.sn_ncolu[k] - chunk * 64);
@@ -1735,25 +1743,28 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < ncol) {
         const int64_t ci = ci0 + tid;
-        s_ld[tid] = T.ucol_ld[ci]; s_cp[tid] = T.ucol_cp[ci]; s_gc[tid] = T.ucol_gc[ci];
+        s_ld[tid] = (chk && T.ucol_near[ci]) ? ns : T.ucol_ld[ci]; s_cp[tid] = T.ucol_cp[ci]; s_gc[tid] = T.ucol_gc[ci];
     }
     __syncthreads();
     const double *Uv = T.val + uoff;
-    // the wave's first four columns go in flight BEFORE the gather of x (they depend on the column maps only): one round trip less in the
-    // life of a workgroup on the levels where that is what a workgroup's life consists of
-    double uv0[4][RB];
+    auto load_batch = [&](double (&uv)[CBT][RB], int cb) {     // one batch: CBT columns of the wave x RB row blocks
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-        const int c = wave * CPW + cc;
-        const bool cok = c < ncol;
-        const int ld = cok ? s_ld[c] : ns;
-        const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
+        for (int cc = 0; cc < CBT; ++cc) {
+            const int c = wave * CPW + cb + cc;
+            const bool cok = c < ncol;
+            const int ld = cok ? s_ld[c] : ns;
+            const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
 #pragma unroll
-        for (int q = 0; q < RB; ++q) {
-            const int i = lane + 64 * q;
-            uv0[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+            for (int q = 0; q < RB; ++q) {
+                const int i = lane + 64 * q;
+                uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
+            }
         }
-    }
+    };
+    // the wave's first batch goes in flight BEFORE the gather of x (it depends on the column maps only): one round trip less in the
+    // life of a workgroup on the levels where that is what a workgroup's life consists of
+    double uv0[CBT][RB];
+    load_batch(uv0, 0);
     for (int r = 0; r < nrhs; ++r) {
         if (tid < ncol) s_xc[tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
         __syncthreads();
@@ -1761,29 +1772,21 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
             double a[RB];
 #pragma unroll
             for (int q = 0; q < RB; ++q) a[q] = 0.0;
+            auto accumulate = [&](const double (&uv)[CBT][RB], int cb) {
 #pragma unroll
-            for (int cb = 0; cb < CPW; cb += 4) {
-                double uv[4][RB];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int c = wave * CPW + cb + cc;
-                    const bool cok = c < ncol;
-                    const int ld = cok ? s_ld[c] : ns;
-                    const double *col = Uv + (cok ? s_cp[c] : 0) - ld;
-#pragma unroll
-                    for (int q = 0; q < RB; ++q) {
-                        const int i = lane + 64 * q;
-                        if (cb == 0) uv[cc][q] = uv0[cc][q];
-                        else uv[cc][q] = (i >= ld && i < ns) ? __builtin_nontemporal_load(col + i) : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
+                for (int cc = 0; cc < CBT; ++cc) {
                     const int c = wave * CPW + cb + cc;
                     const double xv = (c < ncol) ? s_xc[c] : 0.0;
 #pragma unroll
                     for (int q = 0; q < RB; ++q) a[q] += uv[cc][q] * xv;
                 }
+            };
+            accumulate(uv0, 0);
+#pragma unroll UF
+            for (int cb = CBT; cb < CPW; cb += CBT) {
+                double uv[CBT][RB];
+                load_batch(uv, cb);
+                accumulate(uv, cb);
             }
 #pragma unroll
             for (int q = 0; q < RB; ++q) s_red[wave][lane + 64 * q] = a[q];
@@ -1799,23 +1802,23 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
+template <int NT, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true, int MINW = NT / 256>
+__global__ __launch_bounds__(NT, MINW) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
                                                    int nn, const double *xcols, double *xrows, int64_t ldx, int nrhs, const int2 *__restrict__ units,
                                                    const int4 *__restrict__ recs)
 {
-    if (recs) { bwd_update_body<NT>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
+    if (recs) { bwd_update_body<NT, false, RBv, CBT, UNR>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
     int k, chunk;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; chunk = u.y; }
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
-    bwd_update_body<NT>(T, k, chunk, xcols, xrows, ldx, nrhs);
+    bwd_update_body<NT, false, RBv, CBT, UNR>(T, k, chunk, xcols, xrows, ldx, nrhs);
 }
 
 // One 64-row strip of a diagonal solve, OUT OF PLACE: xout_k[strip rows] = (Linv or Uinv)[strip rows, :] xin_k.  The diagonal solve of a
 // chain supernode sits on the critical path of the sweeps (one dependent launch per level): as ONE workgroup it streams the 512 KB
 // inverse through one CU (~10 us); as ns / 64 independent strips of the same GEMV shape as the panel update it takes what a launch
 // takes.  Independent only because input and output are different vectors (LevelSched sweeps ping-pong between x and a work vector).
-template <bool LOWER, int NT>
+template <bool LOWER, int NT, int NBT = 16>
 __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int strip, const double *xin, double *xout, int64_t ldx, int nrhs,
                                                 double *xk /* ns x nrhs */, const int4 *rec = nullptr)
 {
@@ -1841,9 +1844,9 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
     const int cpp = (c1 - c0 + NP - 1) / NP;
     const int ka = min(c1, c0 + part * cpp), kb = min(c1, ka + cpp);
     const double *Tr = Ti + row;
-    double tv0[16];                               // first batch of the inverse in flight before x_k is staged (as fwd_update_body)
+    double tv0[NBT];                               // first batch of the inverse in flight before x_k is staged (as fwd_update_body)
 #pragma unroll
-    for (int u = 0; u < 16; ++u) tv0[u] = (rvalid && ka + u < kb) ? Tr[(size_t) (ka + u) * ns] : 0.0;
+    for (int u = 0; u < NBT; ++u) tv0[u] = (rvalid && ka + u < kb) ? Tr[(size_t) (ka + u) * ns] : 0.0;
     for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = xin[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
     for (int q = 0; q < nrhs; ++q) {
@@ -1851,14 +1854,14 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
         double acc[4] = {0, 0, 0, 0};
         if (rvalid) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc[u & 3] += tv0[u] * xq[min(ka + u, ns - 1)];
-            int kk = ka + 16;
-            for (; kk + 16 <= kb; kk += 16) {
-                double tv[16];
+            for (int u = 0; u < NBT; ++u) acc[u & 3] += tv0[u] * xq[min(ka + u, ns - 1)];
+            int kk = ka + NBT;
+            for (; kk + NBT <= kb; kk += NBT) {
+                double tv[NBT];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) tv[u] = Tr[(size_t) (kk + u) * ns];
+                for (int u = 0; u < NBT; ++u) tv[u] = Tr[(size_t) (kk + u) * ns];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u & 3] += tv[u] * xq[kk + u];
+                for (int u = 0; u < NBT; ++u) acc[u & 3] += tv[u] * xq[kk + u];
             }
             for (; kk < kb; ++kk) acc[0] += Tr[(size_t) kk * ns] * xq[kk];
         }
@@ -1879,31 +1882,205 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
 // diagonal solve of a chain supernode hides behind the far updates of its predecessor.  Two vectors: forward, the accumulated
 // right-hand side lives in xa and the solved blocks go to xb (updates read xb, subtract from xa); backward, the accumulators are
 // xb (= the forward solution minus the updates) and the final x_k goes to xa (updates read xa, subtract from xb).
-template <bool LOWER, int NT>
-__global__ __launch_bounds__(NT) void k_sweep(DevTables T, const int2 *__restrict__ dunits, int ndu, const int2 *__restrict__ units,
+template <bool LOWER, int NT, int RBv = (NT == 1024 ? 4 : 1), int NBT = 16, int CBT = 4, bool UNR = true, int MINW = NT / 256>
+__global__ __launch_bounds__(NT, MINW) void k_sweep(DevTables T, const int2 *__restrict__ dunits, int ndu, const int2 *__restrict__ units,
                                               double *xa, double *xb, int64_t ldx, int nrhs, const int4 *__restrict__ drecs, const int4 *__restrict__ urecs)
 {
     extern __shared__ double dyn[];  // max_nsupc x nrhs
     const int bid = blockIdx.x;
     if (bid < ndu) {
         if (drecs) {     // unit records (same order as dunits)
-            if (LOWER) diag_strip_body<true, NT>(T, 0, 0, xa, xb, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
-            else diag_strip_body<false, NT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
+            if (LOWER) diag_strip_body<true, NT, NBT>(T, 0, 0, xa, xb, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
+            else diag_strip_body<false, NT, NBT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
             return;
         }
         const int2 d = dunits[bid];
-        if (LOWER) diag_strip_body<true, NT>(T, d.x, d.y, xa, xb, ldx, nrhs, dyn);
-        else diag_strip_body<false, NT>(T, d.x, d.y, xb, xa, ldx, nrhs, dyn);
+        if (LOWER) diag_strip_body<true, NT, NBT>(T, d.x, d.y, xa, xb, ldx, nrhs, dyn);
+        else diag_strip_body<false, NT, NBT>(T, d.x, d.y, xb, xa, ldx, nrhs, dyn);
         return;
     }
     if (urecs) {
-        if (LOWER) fwd_update_body<NT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - ndu));
-        else bwd_update_body<NT>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - ndu));
+        if (LOWER) fwd_update_body<NT, false, NBT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - ndu));
+        else bwd_update_body<NT, false, RBv, CBT, UNR>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - ndu));
         return;
     }
     const int2 u = units[bid - ndu];
-    if (LOWER) fwd_update_body<NT>(T, u.x, u.y, xb, xa, ldx, nrhs, dyn);
-    else bwd_update_body<NT>(T, u.x, u.y, xa, xb, ldx, nrhs);
+    if (LOWER) fwd_update_body<NT, false, NBT>(T, u.x, u.y, xb, xa, ldx, nrhs, dyn);
+    else bwd_update_body<NT, false, RBv, CBT, UNR>(T, u.x, u.y, xa, xb, ldx, nrhs);
+}
+
+// ---- joined links (LevelSched::join) -----------------------------------------------------------------------------------------------------------------
+// Forward unit (s, c) of supernode j (level l + 1):  t = b_j[block c] - sum over the level-l panels k of (rows of panel k inside block c) x_k, then
+// y_j[strip s] += Linv_j[s, c] t.  One round trip after the record: the inverse block, the panel rows, their positions, x_k and b_j go in flight together.
+template <int NT, int NBT>
+__device__ __forceinline__ void join_fwd_body(const DevTables &T, const int4 *rec, const int4 *jaux, const double *xa, double *xb, int64_t ldx, int nrhs, double *xk)
+{
+    constexpr int NP = NT / 64, CPB = 64 / NP;
+    __shared__ double s_t[64];
+    __shared__ double s_jred[NP][64 + 1];
+    __shared__ int s_pos[64];
+    const int4 a = rec[0], b = rec[1];
+    const int fst = a.x, ns = a.y, st = a.z, c = a.w, nsrc = b.z, ovf = b.w;
+    const double *Ti = T.inv + (((int64_t) b.y << 32) | (uint32_t) b.x);
+    const int tid = threadIdx.x, r = tid & 63, part = tid >> 6;
+    const int nc = min(64, ns - 64 * c), row = 64 * st + r;
+    const bool rv = row < ns;
+    double tv[CPB];
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) {
+        const int col = 64 * c + part * CPB + u;
+        tv[u] = (rv && col < ns) ? Ti[(size_t) col * ns + row] : 0.0;
+    }
+    for (int q = 0; q < nrhs; ++q) {
+        if (tid < 64) s_t[tid] = tid < nc ? xa[fst + 64 * c + tid + (int64_t) q * ldx] : 0.0;
+        for (int si = 0; si < nsrc; ++si) {
+            const int4 *sr = si < 3 ? rec + 2 + 2 * si : jaux + 2 * (size_t) (ovf + si - 3);
+            const int4 sa = sr[0], sb = sr[1];
+            const int fk = sa.x, nk = sa.y, lda = sa.z, nr = sa.w;
+            const double *L = T.val + (((int64_t) sb.y << 32) | (uint32_t) sb.x) + r;
+            const int64_t roff = ((int64_t) sb.w << 32) | (uint32_t) sb.z;
+            const int cpp = (nk + NP - 1) / NP;
+            const int ka = min(nk, part * cpp), kb = min(nk, ka + cpp);
+            const bool rok = r < nr;
+            double lv0[NBT];
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) lv0[u] = (rok && ka + u < kb) ? __builtin_nontemporal_load(L + (size_t) (ka + u) * lda) : 0.0;
+            __syncthreads();      // the previous source's x_k / positions are consumed; s_t initialised
+            for (int idx = tid; idx < nk; idx += NT) xk[idx] = xb[fk + idx + (int64_t) q * ldx];
+            if (tid < nr) s_pos[tid] = T.lrow[roff + tid] - fst - 64 * c;
+            __syncthreads();
+            double acc[4] = {0, 0, 0, 0};
+            if (rok) {
+#pragma unroll
+                for (int u = 0; u < NBT; ++u) acc[u & 3] += lv0[u] * xk[min(ka + u, nk - 1)];
+                int kk = ka + NBT;
+                for (; kk + NBT <= kb; kk += NBT) {
+                    double lv[NBT];
+#pragma unroll
+                    for (int u = 0; u < NBT; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);
+#pragma unroll
+                    for (int u = 0; u < NBT; ++u) acc[u & 3] += lv[u] * xk[kk + u];
+                }
+                for (; kk < kb; ++kk) acc[0] += __builtin_nontemporal_load(L + (size_t) kk * lda) * xk[kk];
+            }
+            s_jred[part][r] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            __syncthreads();
+            if (part == 0 && rok) {
+                double sum = 0.0;
+#pragma unroll
+                for (int p2 = 0; p2 < NP; ++p2) sum += s_jred[p2][r];
+                s_t[s_pos[r]] -= sum;       // the rows of one panel block are distinct rows of j
+            }
+        }
+        __syncthreads();
+        double a2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < CPB; ++u) a2 += tv[u] * s_t[part * CPB + u];
+        s_jred[part][r] = a2;
+        __syncthreads();
+        if (part == 0 && rv) {
+            double sum = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < NP; ++p2) sum += s_jred[p2][r];
+            atomic_sub_f64(xb + fst + row + (int64_t) q * ldx, -sum);
+        }
+        __syncthreads();
+    }
+}
+
+// Backward unit (s, c) of supernode k (level l):  t = w_k[block c] - U(k rows of block c, columns of level l + 1) x, then x_k[strip s] += Uinv_k[s, c] t.
+// Lanes run along the 64 rows of block c, waves take NBT near columns each per pass (their descriptors and x staged in LDS first).
+template <int NT, int NBT>
+__device__ __forceinline__ void join_bwd_body(const DevTables &T, const int4 *rec, const int4 *jaux, double *xa, const double *xb, int64_t ldx, int nrhs)
+{
+    constexpr int NWV = NT / 64, CPB = 64 / NWV, NCH = NWV * NBT;
+    __shared__ double s_bt[64];
+    __shared__ double s_bred[NWV][64 + 1];
+    __shared__ int s_nld[NCH], s_ncp[NCH];
+    __shared__ double s_nx[NCH];
+    const int4 a = rec[0], b = rec[1], c2 = rec[2];
+    const int fst = a.x, ns = a.y, st = a.z, c = a.w, noff = b.z, ncnt = b.w;
+    const double *Ti = T.inv + (((int64_t) b.y << 32) | (uint32_t) b.x);
+    const double *Uv = T.val + (((int64_t) c2.y << 32) | (uint32_t) c2.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = min(64, ns - 64 * c), row = 64 * st + lane, i = 64 * c + lane;
+    const bool rv = row < ns;
+    double tv[CPB];
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) {
+        const int col = 64 * c + wave * CPB + u;
+        tv[u] = (rv && col < ns) ? Ti[(size_t) col * ns + row] : 0.0;
+    }
+    for (int q = 0; q < nrhs; ++q) {
+        if (tid < 64) s_bt[tid] = tid < nc ? xb[fst + 64 * c + tid + (int64_t) q * ldx] : 0.0;
+        double acc = 0.0;
+        for (int e0 = 0; e0 < ncnt; e0 += NCH) {
+            const int cnt = min(NCH, ncnt - e0);
+            __syncthreads();
+            if (tid < cnt) {
+                const int4 col = jaux[noff + e0 + tid];
+                s_nld[tid] = col.x; s_ncp[tid] = col.y;
+                s_nx[tid] = xa[col.z + (int64_t) q * ldx];
+            }
+            __syncthreads();
+            double uv[NBT];
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                const int e = wave * NBT + u;
+                const int ld = e < cnt ? s_nld[e] : ns;
+                uv[u] = (i >= ld && i < ns) ? __builtin_nontemporal_load(Uv + s_ncp[min(e, cnt - 1)] - ld + i) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) { const int e = wave * NBT + u; acc += uv[u] * (e < cnt ? s_nx[e] : 0.0); }
+        }
+        s_bred[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < NWV; ++w2) sum += s_bred[w2][lane];
+            s_bt[lane] -= sum;
+        }
+        __syncthreads();
+        double a2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < CPB; ++u) a2 += tv[u] * s_bt[wave * CPB + u];
+        s_bred[wave][lane] = a2;
+        __syncthreads();
+        if (wave == 0 && rv) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < NWV; ++w2) sum += s_bred[w2][lane];
+            atomic_sub_f64(xa + fst + row + (int64_t) q * ldx, -sum);
+        }
+        __syncthreads();
+    }
+}
+
+// One joined link in ONE launch: workgroups [0, nj) run the joined diagonal units of the next level, the others the regular units of this one (near rows /
+// columns skipped).  Vectors as k_sweep: forward reads xa (right-hand side), reads / adds xb (solved blocks); backward reads xb, reads / adds xa.
+template <bool LOWER, int NT, int RBv, int NBT, int CBT, bool UNR, int MINW>
+__global__ __launch_bounds__(NT, MINW) void k_sweep_join(DevTables T, const int4 *__restrict__ jrecs, int nj, const int4 *__restrict__ jaux, const int4 *__restrict__ urecs,
+                                                         double *xa, double *xb, int64_t ldx, int nrhs)
+{
+    extern __shared__ double dyn[];  // max_nsupc x nrhs
+    const int bid = blockIdx.x;
+    if (bid < nj) {
+        if (LOWER) join_fwd_body<NT, NBT>(T, jrecs + 8 * (size_t) bid, jaux, xa, xb, ldx, nrhs, dyn);
+        else join_bwd_body<NT, NBT>(T, jrecs + 4 * (size_t) bid, jaux, xa, xb, ldx, nrhs);
+        return;
+    }
+    if (LOWER) fwd_update_body<NT, false, NBT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - nj));
+    else bwd_update_body<NT, false, RBv, CBT, UNR>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - nj));
+}
+
+__global__ __launch_bounds__(256) void k_zero_nodes(const int *__restrict__ xsup, const int *__restrict__ nodes, int nn, double *__restrict__ x, int64_t ldx, int nrhs)
+{
+    const int ni = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ni >= nn) return;
+    const int k = nodes[ni], f = xsup[k], l = xsup[k + 1];
+    for (int q = 0; q < nrhs; ++q)
+        for (int rr = f + lane; rr < l; rr += 64) x[rr + (int64_t) q * ldx] = 0.0;
 }
 
 // Dataflow sweeps over the top of the elimination DAG (LevelSched::chain_l0): ONE persistent launch walks a topologically
@@ -2067,6 +2244,7 @@ __global__ __launch_bounds__(256) void k_rows_copy(double *__restrict__ v, int64
 namespace eng {
 
 static int g_num_cus = 256;
+int sweep_attrs();
 int setup()
 {
     // kernels that keep a whole panel strip / diagonal block in LDS need more than the default 64 KiB
@@ -2078,20 +2256,15 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_chain<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_chain<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_chain<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_chain<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) g_num_cus = pr.multiProcessorCount; }
-    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     // the 256-thread variants stage max_nsupc (<= 64) x nrhs values: above 64 KiB when a matrix of narrow supernodes is solved for many right-hand sides
+    if (sweep_attrs()) return 1;
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     return 0;
 }
 
@@ -2177,34 +2350,117 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
     }
 }
 
+// Builds of the sweep kernels.  The work unit is the same in all of them (64 panel rows / 64 skyline columns of one supernode); what differs is how
+// many threads share it and how many workgroups a CU holds at a time:
+//   wide levels (supernodes of 65 .. 256 columns)
+//     0  1024 threads, one batch of 16 loads per thread, 1 workgroup per CU: the shortest life of a unit -- levels of a FEW units (the chain at the top)
+//     1   512 threads, two batches of 16, 2 workgroups per CU
+//     2   512 threads, batches of 8, built for 8 waves per SIMD: 4 workgroups per CU
+//     3   256 threads, batches of 8, 8 workgroups per CU
+//     4  1024 threads, batches of 8, 2 workgroups per CU
+//   narrow levels (<= 64 columns):  0  256 threads, batch of 16 (4 workgroups per CU);  1  256 threads, batches of 8, 8 workgroups per CU
+// A level of many units is bound by how much of a workgroup's life (record -> maps -> values -> reduction -> atomics: a chain of round trips) overlaps with
+// other workgroups' loads, not by the length of one life: SLUAMD_SWEEP_WIDE_V for launches of at least SLUAMD_SWEEP_WIDE_MIN units, SLUAMD_SWEEP_NARROW_V.
+static const int g_sweep_wide_v = getenv("SLUAMD_SWEEP_WIDE_V") ? atoi(getenv("SLUAMD_SWEEP_WIDE_V")) : 1;
+static const int g_sweep_wide_min = getenv("SLUAMD_SWEEP_WIDE_MIN") ? atoi(getenv("SLUAMD_SWEEP_WIDE_MIN")) : 256;
+static const int g_sweep_narrow_v = getenv("SLUAMD_SWEEP_NARROW_V") ? atoi(getenv("SLUAMD_SWEEP_NARROW_V")) : 0;
+static inline int sweep_variant(int nwork, int mx)    // 0 .. 4 wide, 10 / 11 narrow
+{
+    if (mx <= 64) return 10 + ((g_sweep_narrow_v >= 0 && g_sweep_narrow_v <= 2) ? g_sweep_narrow_v : 0);
+    if (mx > 256 || nwork < g_sweep_wide_min || g_sweep_wide_v < 0 || g_sweep_wide_v > 6) return 0;
+    return g_sweep_wide_v;
+}
+//                 threads  row blocks  loads/batch (fwd, diag)  columns/batch (bwd)  all batches in flight  waves per SIMD
+#define SWEEP_V0   1024,    4,          16,                      4,                   true,                  4
+#define SWEEP_V1   512,     4,          16,                      4,                   true,                  2
+#define SWEEP_V2   512,     4,          8,                       2,                   false,                 8
+#define SWEEP_V3   256,     4,          8,                       2,                   false,                 8
+#define SWEEP_V4   1024,    4,          8,                       2,                   false,                 8
+#define SWEEP_V5   512,     4,          8,                       2,                   false,                 6
+#define SWEEP_V6   256,     4,          8,                       2,                   false,                 6
+#define SWEEP_N0   256,     1,          16,                      4,                   true,                  1
+#define SWEEP_N2   256,     1,          8,                       4,                   false,                 6
+#define SWEEP_N1   256,     1,          8,                       4,                   false,                 8
+template <int NT, int RBv, int NBT, int CBT, bool UNR, int MINW> struct SweepCfg {
+    static void fwd(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int mx,
+                    const int2 *units, const int4 *recs)
+    { hipLaunchKernelGGL((k_fwd_update<NT, NBT, MINW>), dim3(nwork), dim3(NT), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs); }
+    static void bwd(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs,
+                    const int2 *units, const int4 *recs)
+    { hipLaunchKernelGGL((k_bwd_update<NT, RBv, CBT, UNR, MINW>), dim3(nwork), dim3(NT), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs); }
+    static void sweep(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits, double *xa, double *xb, int64_t ldx, int nrhs,
+                      int mx, const int4 *drecs, const int4 *urecs)
+    {
+        const size_t lds = (size_t) mx * nrhs * sizeof(double);
+        if (lower) hipLaunchKernelGGL((k_sweep<true, NT, RBv, NBT, CBT, UNR, MINW>), dim3(ndu + nunits), dim3(NT), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
+        else hipLaunchKernelGGL((k_sweep<false, NT, RBv, NBT, CBT, UNR, MINW>), dim3(ndu + nunits), dim3(NT), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
+    }
+    static void join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits, double *xa, double *xb, int64_t ldx,
+                     int nrhs, int mx)
+    {
+        const size_t lds = (size_t) mx * nrhs * sizeof(double);
+        if (lower) hipLaunchKernelGGL((k_sweep_join<true, NT, RBv, NBT, CBT, UNR, MINW>), dim3(nj + nunits), dim3(NT), lds, s, T, jrecs, nj, jaux, urecs, xa, xb, ldx, nrhs);
+        else hipLaunchKernelGGL((k_sweep_join<false, NT, RBv, NBT, CBT, UNR, MINW>), dim3(nj + nunits), dim3(NT), lds, s, T, jrecs, nj, jaux, urecs, xa, xb, ldx, nrhs);
+    }
+    static int attrs()
+    {
+        HIPCHK(hipFuncSetAttribute((const void *) k_sweep_join<true, NT, RBv, NBT, CBT, UNR, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<NT, NBT, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, NT, RBv, NBT, CBT, UNR, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, NT, RBv, NBT, CBT, UNR, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+        return 0;
+    }
+};
+#define SWEEP_DISPATCH(v, CALL) \
+    switch (v) { \
+    case 1: SweepCfg<SWEEP_V1>::CALL; break; \
+    case 2: SweepCfg<SWEEP_V2>::CALL; break; \
+    case 3: SweepCfg<SWEEP_V3>::CALL; break; \
+    case 4: SweepCfg<SWEEP_V4>::CALL; break; \
+    case 5: SweepCfg<SWEEP_V5>::CALL; break; \
+    case 6: SweepCfg<SWEEP_V6>::CALL; break; \
+    case 12: SweepCfg<SWEEP_N2>::CALL; break; \
+    case 10: SweepCfg<SWEEP_N0>::CALL; break; \
+    case 11: SweepCfg<SWEEP_N1>::CALL; break; \
+    default: SweepCfg<SWEEP_V0>::CALL; break; \
+    }
+int sweep_attrs()
+{
+    return SweepCfg<SWEEP_V0>::attrs() | SweepCfg<SWEEP_V1>::attrs() | SweepCfg<SWEEP_V2>::attrs() | SweepCfg<SWEEP_V3>::attrs() | SweepCfg<SWEEP_V4>::attrs() | SweepCfg<SWEEP_V5>::attrs() | SweepCfg<SWEEP_V6>::attrs() | SweepCfg<SWEEP_N2>::attrs() |
+           SweepCfg<SWEEP_N0>::attrs() | SweepCfg<SWEEP_N1>::attrs();
+}
+
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int mx,
                 const int2 *units, const int4 *recs)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_fwd_update<256>, dim3(nwork), dim3(256), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs);
-    else hipLaunchKernelGGL(k_fwd_update<1024>, dim3(nwork), dim3(1024), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs);
+    SWEEP_DISPATCH(sweep_variant(nwork, mx), fwd(s, T, nodes, prefix, nn, nwork, xsrc, x, ldx, nrhs, mx, units, recs))
 }
 
 void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int mx,
                 const int2 *units, const int4 *recs)
 {
     if (nwork <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_bwd_update<256>, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs);
-    else hipLaunchKernelGGL(k_bwd_update<1024>, dim3(nwork), dim3(1024), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs);
+    SWEEP_DISPATCH(sweep_variant(nwork, mx), bwd(s, T, nodes, prefix, nn, nwork, xcols, x, ldx, nrhs, units, recs))
 }
 
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
                 double *xa, double *xb, int64_t ldx, int nrhs, int mx, const int4 *drecs, const int4 *urecs)
 {
     if (ndu + nunits <= 0) return;
-    const size_t lds = (size_t) mx * nrhs * sizeof(double);
-    if (mx <= 64) {
-        if (lower) hipLaunchKernelGGL((k_sweep<true, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
-        else hipLaunchKernelGGL((k_sweep<false, 256>), dim3(ndu + nunits), dim3(256), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
-    } else {
-        if (lower) hipLaunchKernelGGL((k_sweep<true, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
-        else hipLaunchKernelGGL((k_sweep<false, 1024>), dim3(ndu + nunits), dim3(1024), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
-    }
+    SWEEP_DISPATCH(sweep_variant(ndu + nunits, mx), sweep(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, mx, drecs, urecs))
+}
+
+void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits,
+                double *xa, double *xb, int64_t ldx, int nrhs, int mx)
+{
+    if (nj + nunits <= 0) return;
+    SWEEP_DISPATCH(sweep_variant(nj + nunits, mx), join(s, lower, T, jrecs, nj, jaux, urecs, nunits, xa, xb, ldx, nrhs, mx))
+}
+
+void zero_nodes(hipStream_t s, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs)
+{
+    if (nn > 0) hipLaunchKernelGGL(k_zero_nodes, dim3((nn + 3) / 4), dim3(256), 0, s, T.xsup, nodes, nn, x, ldx, nrhs);
 }
 
 void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <cmath>
 #include "sluamd_comm.h"
 #include "sluamd_plan.h"
 
@@ -34,19 +35,39 @@ static void dag_levels(const SlotInput &in, const std::vector<int> &list, int ns
 // and the look-ahead schedule pipelines the sub-batches like any other levels.  The rule reads only the forest's global node lists and
 // levels (identical on every rank of the layer), so all ranks cut alike.  (leaf-level remote-panel scratch in
 // <= 1/4-level sub-batches; the reference keeps every received panel of its look-ahead window, dtreeFactorization.c:295-716.)
-static void split_wide_levels(const std::vector<int> &list, std::vector<int> &lvl, int &nlevels, int min_cap)
+// Round 4 (second half): the largest level BY BYTES is not the leaf level at 150^3 and up but the levels of the 128 .. 512-node separators
+// (few supernodes, long panels), which the count rule never cuts.  Second rule, same cut: w(k) = nsupc(k) x (nsupc(k) + sum of the widths of
+// the block rows of k) -- an upper bound of the panel of k in values, read from the global block graph, so identical on every rank -- and a
+// level heavier than 1 / wdiv of the FOREST's total weight (forests below `wmin` values in total are left alone) is cut into as many sub-levels
+// as that takes: three scratch copies of at most total / wdiv each, whatever the size of the problem.
+static void split_wide_levels(const SlotInput &in, const std::vector<int> &xsup, const std::vector<int> &list, std::vector<int> &lvl, int &nlevels, int min_cap,
+                              int wdiv, double wmin)
 {
     if (nlevels <= 0) return;
     std::vector<int> cnt(nlevels, 0);
-    for (int k : list) cnt[lvl[k]]++;
+    std::vector<double> wl(nlevels, 0.0);
+    for (int k : list) {
+        cnt[lvl[k]]++;
+        double rows = xsup[k + 1] - xsup[k];
+        for (int g : in.succ[k]) rows += xsup[g + 1] - xsup[g];
+        wl[lvl[k]] += rows * (xsup[k + 1] - xsup[k]);
+    }
     const int nmax = *std::max_element(cnt.begin(), cnt.end());
-    if (nmax < 4 * min_cap) return;        // small forests: the scratch is small and every extra level costs two exchange phases of latency
+    double wtot = 0.0;
+    for (double w : wl) wtot += w;
+    const bool by_count = nmax >= 4 * min_cap;        // small forests: the scratch is small and every extra level costs two exchange phases of latency
+    const bool by_weight = wdiv > 1 && wtot >= wmin;
+    if (!by_count && !by_weight) return;
     const int cap = std::max(min_cap, (nmax + 3) / 4);
+    const double wcap = wtot / std::max(wdiv, 1);
     std::vector<int> first(nlevels + 1, 0), per(nlevels, 1);        // new id of the first sub-level of every level; sub-level size
     for (int l = 0; l < nlevels; ++l) {
-        const int chunks = std::max(1, (cnt[l] + cap - 1) / cap);
-        per[l] = (cnt[l] + chunks - 1) / std::max(chunks, 1);
-        first[l + 1] = first[l] + chunks;
+        int chunks = 1;
+        if (by_count) chunks = std::max(chunks, (cnt[l] + cap - 1) / cap);
+        if (by_weight) chunks = std::max(chunks, std::min(cnt[l], (int) std::ceil(wl[l] / wcap - 1e-9)));
+        chunks = std::max(chunks, 1);
+        per[l] = (cnt[l] + chunks - 1) / chunks;
+        first[l + 1] = first[l] + (cnt[l] + std::max(per[l], 1) - 1) / std::max(per[l], 1);
     }
     if (first[nlevels] == nlevels) return;
     std::vector<int> seen(nlevels, 0);
@@ -712,6 +733,113 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     }
 }
 
+// Joined sweeps (LevelSched::join): near flags, joined diagonal units, regular unit records per level.  Returns false (nothing kept) when a panel's rows
+// inside one block are not ascending -- the rows of a column block of the target would not be one range.
+static bool build_join(Handle &H, LevelSched &S, const HostTables &t)
+{
+    const HostStruct &hs = H.hs;
+    const std::vector<int> &lev = S.sn_level;
+    const int nl = S.nlevels;
+    auto lohi = [](int64_t v, int &lo, int &hi) { lo = (int) (uint32_t) v; hi = (int) (v >> 32); };
+    struct Src { int k, bi; };
+    std::vector<std::vector<Src>> srcs(hs.nsupers);
+    // near flags + the sources of every supernode
+    for (int k : S.nodes) {
+        const int l = lev[k], fl = t.sn_flags[k];
+        if (fl & SNF_L_OWN)
+            for (int b = 0; b < t.sn_nlb[k]; ++b) {
+                const int bi = t.sn_lb_off[k] + b, g = t.lb_gid[bi];
+                if (g == k || lev[g] != l + 1) continue;
+                const int64_t r0 = t.sn_lrow[k] + t.lb_rowoff[bi];
+                for (int r = 0; r < t.lb_nbrow[bi]; ++r) {
+                    if (r && t.lrow[r0 + r] <= t.lrow[r0 + r - 1]) return false;
+                    H.h_lrow_near[r0 + r] = 1;
+                }
+                srcs[g].push_back({k, bi});
+            }
+        if (fl & SNF_U_OWN)
+            for (int b = 0; b < t.sn_nub[k]; ++b) {
+                const int bi = t.sn_ub_off[k] + b, g = t.ub_gid[bi];
+                if (!t.ub_ncols[bi] || lev[g] != l + 1) continue;
+                for (int c = 0; c < t.ub_ncols[bi]; ++c) H.h_ucol_near[t.sn_ucol[k] + t.ub_stcol[bi] + c] = 1;
+            }
+    }
+    S.jf_off.assign(nl + 1, 0); S.jb_off.assign(nl + 1, 0); S.jfu_off.assign(nl + 1, 0); S.jbu_off.assign(nl + 1, 0);
+    for (int l = 0; l < nl; ++l) {
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+            const int k = S.nodes[i], fl = t.sn_flags[k];
+            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst, nb = (ns + 63) / 64;
+            // regular units: every strip / chunk with something left to do
+            if (fl & SNF_L_OWN) {
+                const int ldiag = t.sn_ldiag[k], lda = t.sn_nsupr[k];
+                for (int row0 = ldiag; row0 < lda; row0 += 64) {
+                    int nnear = 0;
+                    const int nr = std::min(64, lda - row0);
+                    for (int r = 0; r < nr; ++r) nnear += H.h_lrow_near[t.sn_lrow[k] + row0 + r];
+                    if (nnear == nr) continue;
+                    int4 b; lohi(t.sn_lval[k] + row0, b.x, b.y); lohi(t.sn_lrow[k] + row0, b.z, b.w);
+                    S.jfu_recs.push_back(make_int4(fst, ns | (nnear ? 1 << 16 : 0), lda, row0)); S.jfu_recs.push_back(b);
+                }
+            }
+            if (fl & SNF_U_OWN) {
+                const int ncolu = t.sn_ncolu[k];
+                for (int c0 = 0; c0 < ncolu; c0 += 64) {
+                    int nnear = 0;
+                    const int nc = std::min(64, ncolu - c0);
+                    for (int c = 0; c < nc; ++c) nnear += H.h_ucol_near[t.sn_ucol[k] + c0 + c];
+                    if (nnear == nc) continue;
+                    int4 b; lohi(t.sn_ucol[k] + c0, b.x, b.y); lohi(t.sn_uval[k], b.z, b.w);
+                    S.jbu_recs.push_back(make_int4(fst, ns | (nnear ? 1 << 16 : 0), nc, 0)); S.jbu_recs.push_back(b);
+                }
+            }
+            if (!(fl & SNF_OWN_DIAG)) continue;
+            // forward joined units of j = k: block (s, c), c <= s, sources = the level-(l-1) panels with rows in column block c (none at level 0)
+            {
+                for (int c = 0; c < nb; ++c) {
+                    std::vector<int4> sv;
+                    for (const Src &q : srcs[k]) {
+                        const int64_t r0 = t.sn_lrow[q.k] + t.lb_rowoff[q.bi];
+                        const int nbr = t.lb_nbrow[q.bi];
+                        const int *rows = t.lrow.data() + r0;
+                        const int a = (int) (std::lower_bound(rows, rows + nbr, fst + 64 * c) - rows), e = (int) (std::lower_bound(rows, rows + nbr, fst + 64 * c + 64) - rows);
+                        if (e <= a) continue;
+                        const int fk = hs.xsup[q.k];
+                        int4 v; lohi(t.sn_lval[q.k] + t.lb_rowoff[q.bi] + a, v.x, v.y); lohi(r0 + a, v.z, v.w);
+                        sv.push_back(make_int4(fk, hs.xsup[q.k + 1] - fk, t.sn_nsupr[q.k], e - a)); sv.push_back(v);
+                    }
+                    const int nsrc = (int) sv.size() / 2;
+                    int ovf = 0;
+                    if (nsrc > 3) { ovf = (int) S.jf_aux.size() / 2; S.jf_aux.insert(S.jf_aux.end(), sv.begin() + 6, sv.end()); }
+                    for (int st = c; st < nb; ++st) {
+                        int4 b; lohi(t.sn_inv[k], b.x, b.y); b.z = nsrc; b.w = ovf;
+                        S.jf_recs.push_back(make_int4(fst, ns, st, c)); S.jf_recs.push_back(b);
+                        for (int q = 0; q < 6; ++q) S.jf_recs.push_back(q < (int) sv.size() ? sv[q] : make_int4(0, 0, 0, 0));
+                    }
+                }
+            }
+            // backward joined units of k: block (s, c), s <= c; near columns = every column of a level-(l+1) supernode in U(k, :) (none at the top level)
+            {
+                const int noff = (int) S.jb_aux.size();
+                if (fl & SNF_U_OWN)
+                    for (int c = 0; c < t.sn_ncolu[k]; ++c) {
+                        const int64_t ci = t.sn_ucol[k] + c;
+                        if (H.h_ucol_near[ci]) S.jb_aux.push_back(make_int4(t.ucol_ld[ci], t.ucol_cp[ci], t.ucol_gc[ci], 0));
+                    }
+                const int ncnt = (int) S.jb_aux.size() - noff;
+                for (int c = 0; c < nb; ++c)
+                    for (int st = 0; st <= c; ++st) {
+                        int4 b; lohi(t.sn_inv[k] + (int64_t) ns * ns, b.x, b.y); b.z = noff; b.w = ncnt;
+                        int4 u; lohi(t.sn_uval[k], u.x, u.y); u.z = u.w = 0;
+                        S.jb_recs.push_back(make_int4(fst, ns, st, c)); S.jb_recs.push_back(b); S.jb_recs.push_back(u); S.jb_recs.push_back(make_int4(0, 0, 0, 0));
+                    }
+            }
+        }
+        S.jf_off[l + 1] = (int) S.jf_recs.size() / 8; S.jb_off[l + 1] = (int) S.jb_recs.size() / 4;
+        S.jfu_off[l + 1] = (int) S.jfu_recs.size() / 2; S.jbu_off[l + 1] = (int) S.jbu_recs.size() / 2;
+    }
+    return true;
+}
+
 static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
 {
     if (upload(H.d_misc, S.nodes, &S.d_nodes)) return SLUAMD_EHIP;
@@ -756,6 +884,16 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
         }
         if (upload(H.d_misc, S.fwd_recs, &S.d_fwd_recs) || upload(H.d_misc, S.bwd_recs, &S.d_bwd_recs) || upload(H.d_misc, S.diag_recs, &S.d_diag_recs)) return SLUAMD_EHIP;
         std::vector<int4>().swap(S.fwd_recs); std::vector<int4>().swap(S.bwd_recs); std::vector<int4>().swap(S.diag_recs);
+        S.join = false;
+        if (H.grid.Pr * H.grid.Pc == 1 && H.env.solve_join && !H.h_lrow_near.empty()) {
+            const std::vector<uint8_t> keep_l = H.h_lrow_near, keep_u = H.h_ucol_near;
+            if (build_join(H, S, t)) {
+                S.join = true;
+                if (upload(H.d_misc, S.jf_recs, &S.d_jf_recs) || upload(H.d_misc, S.jf_aux, &S.d_jf_aux) || upload(H.d_misc, S.jb_recs, &S.d_jb_recs) ||
+                    upload(H.d_misc, S.jb_aux, &S.d_jb_aux) || upload(H.d_misc, S.jfu_recs, &S.d_jfu_recs) || upload(H.d_misc, S.jbu_recs, &S.d_jbu_recs)) return SLUAMD_EHIP;
+            } else { H.h_lrow_near = keep_l; H.h_ucol_near = keep_u; }
+            for (auto *v : {&S.jf_recs, &S.jf_aux, &S.jb_recs, &S.jb_aux, &S.jfu_recs, &S.jbu_recs}) std::vector<int4>().swap(*v);
+        }
     }
     if (S.chain_l0 >= 0) {
         if (upload(H.d_misc, S.cf_units, &S.d_cf_units) || upload(H.d_misc, S.cf_waits, &S.d_cf_waits) || upload(H.d_misc, S.cf_sigs, &S.d_cf_sigs)) return SLUAMD_EHIP;
@@ -815,7 +953,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     std::vector<int> nlev(nz, 0);
     for (int zl = 0; zl < nz; ++zl) {
         dag_levels(in, in.lists[zl], ns, lvl[zl], nlev[zl]);
-        if (xy && !H->env.no_level_split) split_wide_levels(in.lists[zl], lvl[zl], nlev[zl], std::max(1, H->env.level_split_min));
+        if (xy && !H->env.no_level_split)
+            split_wide_levels(in, hs.xsup, in.lists[zl], lvl[zl], nlev[zl], std::max(1, H->env.level_split_min), H->env.level_split_wdiv, H->env.level_split_wmin);
     }
 
     // ---- 3. value arena layout ----
@@ -861,6 +1000,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
                 }
                 const int cls = (int) (&nodes - &lev_nodes[zl][0]) % NB;
                 rmaxc[cls] = std::max(rmaxc[cls], rr); dmax = std::max(dmax, dd);
+                if (getenv("SLUAMD_PLAN_DEBUG") && atoi(getenv("SLUAMD_PLAN_DEBUG")) > 1)
+                    fprintf(stderr, "[sluamd plan] zl %d level %d nodes %zu received %.3f GB\n", zl, (int) (&nodes - &lev_nodes[zl][0]), nodes.size(), 8.0 * rr / 1e9);
             }
         }
     const int64_t rtot = rmaxc[0] + rmaxc[1] + rmaxc[2];
@@ -1095,7 +1236,15 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4) UP(rt_info, t.rt_info, int2) UP(ct_info, t.ct_info, int4)
     UP(lrow, t.lrow, int) UP(sn_lrow, t.sn_lrow, int64_t) UP(ucol_cp, t.ucol_cp, int) UP(ucol_ld, t.ucol_ld, int) UP(ucol_gc, t.ucol_gc, int) UP(sn_ucol, t.sn_ucol, int64_t)
 #undef UP
+    if (!H->z && g.Pr * g.Pc == 1 && H->env.solve_join) { H->h_lrow_near.assign(std::max<size_t>(t.lrow.size(), 1), 0); H->h_ucol_near.assign(std::max<size_t>(t.ucol_gc.size(), 1), 0); }
     for (auto &S : H->sched) if (upload_schedule(*H, S, t)) return SLUAMD_EHIP;
+    T.lrow_near = nullptr; T.ucol_near = nullptr;
+    if (!H->h_lrow_near.empty()) {
+        uint8_t *p0, *p1;
+        if (upload(K, H->h_lrow_near, &p0) || upload(K, H->h_ucol_near, &p1)) return SLUAMD_EHIP;
+        T.lrow_near = p0; T.ucol_near = p1;
+        std::vector<uint8_t>().swap(H->h_lrow_near); std::vector<uint8_t>().swap(H->h_ucol_near);
+    }
     if (H->fused_pairs) {
         int *p0, *p1, *p2, *p3, *p4, *p5;
         if (upload(K, H->h_fuse_prev, &p0) || upload(K, H->h_defer, &p1) || upload(K, H->h_pair_roff, &p2) ||

@@ -165,6 +165,31 @@ def test_xy_layers_with_fused_pairs_and_cut_levels(sched, monkeypatch, grid, mod
     assert sum(a[r]["bytes_device"] for r in a) < sum(b[r]["bytes_device"] for r in a)    # ... and the exchange scratch shrank with them
 
 
+def test_xy_levels_cut_by_panel_weight(sched, monkeypatch):
+    """The second cutting rule: levels whose panels (upper bound from the global block graph) outweigh 1/16 of the forest's total are cut
+    too -- at 150^3 the largest level by bytes is a level of 256 separator supernodes, not the leaves.  Threshold lowered so that the 28^3
+    tree qualifies; count rule disabled by a high SLUAMD_LEVEL_SPLIT_MIN.  Same results, more levels, less exchange scratch."""
+    N = 28
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(N + 1)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    monkeypatch.setenv("SLUAMD_LEVEL_SPLIT_MIN", "100000")
+    monkeypatch.setenv("SLUAMD_LEVEL_SPLIT_WMIN", "1")
+    monkeypatch.setenv("SLUAMD_LEVEL_SPLIT_WDIV", "16")
+    st = []
+    _sched(sched, 2, 3)
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, perm, (2, 2, 1), nrhs=2, relax=64, maxsup=128, refactor=True, stats_out=st)
+    _sched(sched, 0)
+    monkeypatch.setenv("SLUAMD_LEVEL_SPLIT_WDIV", "1")
+    st0 = []
+    grid_cases.check_matrix_on_grid(n, rp, ci, v, perm, (2, 2, 1), nrhs=1, relax=64, maxsup=128, stats_out=st0)
+    a = {s["rank"]: s for s in st}; b = {s["rank"]: s for s in st0}
+    assert all(a[r]["num_levels"] > b[r]["num_levels"] for r in a)
+    assert sum(a[r]["bytes_device"] for r in a) < sum(b[r]["bytes_device"] for r in a)
+
+
 @pytest.mark.parametrize("sched_env", ["1,11", "2,1", "3,4"])
 def test_reference_fixtures_under_the_scheduler(sched_env):
     """The per-rank parity tests against the reference's recorded grids (1x1x2, 2x1x1, 2x2x2 golden fixtures, own pipeline on seven
