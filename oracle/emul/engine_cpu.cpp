@@ -513,12 +513,15 @@ static void diag_strips(bool lower, const DevTables &T, const int2 *dunits, int 
 
 // the far units and the diagonal strips of one launch in either order (seed parity): a dependency inside one launch that should
 // not be there shows up under one of the two orders
+static void fwd_unit_rec(const DevTables &T, const int4 *rec, const double *xsrc, double *x, int64_t ldx, int nrhs);
+static void bwd_unit_rec(const DevTables &T, const int4 *rec, const double *xcols, double *x, int64_t ldx, int nrhs);
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
-                double *xa, double *xb, int64_t ldx, int nrhs, int mx)
+                double *xa, double *xb, int64_t ldx, int nrhs, int mx, const int4 *urecs = nullptr)
 {
     const bool diag_first = emul_launch_seed() & 1;
     for (int pass = 0; pass < 2; ++pass) {
         if ((pass == 0) == diag_first) { if (ndu > 0) diag_strips(lower, T, dunits, ndu, lower ? xa : xb, lower ? xb : xa, ldx, nrhs); }
+        else if (!units && urecs) { for (int u = 0; u < nunits; ++u) { if (lower) fwd_unit_rec(T, urecs + 2 * (size_t) u, xb, xa, ldx, nrhs); else bwd_unit_rec(T, urecs + 2 * (size_t) u, xa, xb, ldx, nrhs); } }
         else if (lower) fwd_update(s, T, nullptr, nullptr, 0, nunits, xb, xa, ldx, nrhs, mx, units);
         else bwd_update(s, T, nullptr, nullptr, 0, nunits, xa, xb, ldx, nrhs, mx, units);
     }
@@ -530,9 +533,10 @@ static inline int64_t rec64(int lo, int hi) { return ((int64_t) hi << 32) | (uin
 static void fwd_unit_rec(const DevTables &T, const int4 *rec, const double *xsrc, double *x, int64_t ldx, int nrhs)
 {
     const int fst = rec[0].x, ns = rec[0].y & 0xffff, lda = rec[0].z, row0 = rec[0].w;
+    const bool chk = (rec[0].y >> 16) != 0;      // as the kernel: the near flags are read only where the planner announced near rows
     const int64_t loff = rec64(rec[1].x, rec[1].y), roff = rec64(rec[1].z, rec[1].w);
     for (int r = 0; r < 64 && row0 + r < lda; ++r) {
-        if (T.lrow_near && T.lrow_near[roff + r]) continue;
+        if (chk && T.lrow_near[roff + r]) continue;
         const int grow = T.lrow[roff + r];
         for (int q = 0; q < nrhs; ++q) {
             double acc = 0.0;
@@ -544,9 +548,10 @@ static void fwd_unit_rec(const DevTables &T, const int4 *rec, const double *xsrc
 static void bwd_unit_rec(const DevTables &T, const int4 *rec, const double *xcols, double *x, int64_t ldx, int nrhs)
 {
     const int fst = rec[0].x, ns = rec[0].y & 0xffff, ncol = rec[0].z;
+    const bool chk = (rec[0].y >> 16) != 0;
     const int64_t ci0 = rec64(rec[1].x, rec[1].y), uoff = rec64(rec[1].z, rec[1].w);
     for (int c = 0; c < ncol; ++c) {
-        if (T.ucol_near && T.ucol_near[ci0 + c]) continue;
+        if (chk && T.ucol_near[ci0 + c]) continue;
         const int ld = T.ucol_ld[ci0 + c], cp = T.ucol_cp[ci0 + c], gc = T.ucol_gc[ci0 + c];
         for (int q = 0; q < nrhs; ++q) {
             const double xv = xcols[gc + (int64_t) q * ldx];
@@ -794,10 +799,10 @@ void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *
 }
 
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits, double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc,
-                const int4 *, const int4 *)
+                const int4 *, const int4 *urecs)
 {
     if (ndu + nunits <= 0) return;
-    emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, max_nsupc); });
+    emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, max_nsupc, urecs); });
 }
 
 void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits, double *xa, double *xb,

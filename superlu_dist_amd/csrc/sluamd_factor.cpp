@@ -583,6 +583,10 @@ static void zero_forest(Handle *H, LevelSched &S, double *x, int64_t ldx, int nr
     if ((int) S.nodes.size() == H->hs.nsupers) { for (int q = 0; q < nrhs; ++q) hipMemsetAsync(x + (int64_t) q * ldx, 0, sizeof(double) * (size_t) H->hs.xsup[H->hs.nsupers], H->stream); }
     else eng::zero_nodes(H->stream, H->T, S.d_nodes, (int) S.nodes.size(), x, ldx, nrhs);
 }
+// Per level m: joined when it holds at most SLUAMD_JOIN_MAX_NODES supernodes (the recomputation-free joined units win where a level is a chain of round
+// trips; levels of hundreds of supernodes with several sources each keep the two-launch form).  The two forms meet in any order: a level's diagonal blocks
+// are either stored by strips or added by joined units into zeroed rows, and the level below hands over exactly the rows / columns its successor's form expects.
+static inline bool level_joined(const Handle *H, const LevelSched &S, int m) { return S.lvl_off[m + 1] - S.lvl_off[m] <= H->env.join_max_nodes; }
 static int solve_fwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
@@ -590,14 +594,24 @@ static int solve_fwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, in
     const int nl = S.nlevels;
     if (nl == 0) return 0;
     double *w = H->d_w;
+    const int4 *fr = S.d_fwd_recs, *dr = S.d_diag_recs;
     zero_forest(H, S, w, ldx, nrhs);
-    eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) S.jf_off[0], S.jf_off[1] - S.jf_off[0], S.d_jf_aux, nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0]);
+    if (level_joined(H, S, 0)) eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) S.jf_off[0], S.jf_off[1] - S.jf_off[0], S.d_jf_aux, nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0]);
+    else eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[0], S.du_off[1] - S.du_off[0], nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0], dr + 2 * (size_t) S.du_off[0], nullptr);
     H->st.solve_launches += 1;
-    for (int l = 0; l < nl; ++l) {
-        const int j0 = l + 1 < nl ? S.jf_off[l + 1] : 0, nj = l + 1 < nl ? S.jf_off[l + 2] - j0 : 0;
+    for (int l = 0; l < nl; ++l) {      // the panels of level l, and the diagonal blocks of level l + 1
         const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
-        eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) j0, nj, S.d_jf_aux, S.d_jfu_recs + 2 * (size_t) S.jfu_off[l], S.jfu_off[l + 1] - S.jfu_off[l], d_x, w, ldx, nrhs, mx);
-        H->st.solve_launches += 1;
+        if (l + 1 == nl || level_joined(H, S, l + 1)) {
+            const int j0 = l + 1 < nl ? S.jf_off[l + 1] : 0, nj = l + 1 < nl ? S.jf_off[l + 2] - j0 : 0;
+            eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) j0, nj, S.d_jf_aux, S.d_jfu_recs + 2 * (size_t) S.jfu_off[l], S.jfu_off[l + 1] - S.jfu_off[l], d_x, w, ldx, nrhs, mx);
+            H->st.solve_launches += 1;
+        } else {
+            const int u0 = S.fu_off[2 * l], u1 = S.fu_off[2 * l + 1], u2 = S.fu_off[2 * l + 2];
+            const int nd = S.du_off[l + 2] - S.du_off[l + 1];
+            eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, w, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0, fr + 2 * (size_t) u0);
+            eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[l + 1], nd, S.d_fwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, mx, dr + 2 * (size_t) S.du_off[l + 1], fr + 2 * (size_t) u1);
+            H->st.solve_launches += 2;
+        }
     }
     return 0;
 }
@@ -608,16 +622,35 @@ static int solve_bwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, in
     const int nl = S.nlevels;
     if (nl == 0) return 0;
     double *w = H->d_w;
+    const int4 *br = S.d_bwd_recs, *dr = S.d_diag_recs;
     zero_forest(H, S, d_x, ldx, nrhs);
-    // the chunks of the top level first (columns of ancestors in other forests, solved before this sweep); then per level the joined units beside the chunks
-    // of the level below (columns of levels >= l + 1 only: level l is theirs to skip)
-    eng::sweep_join(s, false, T, nullptr, 0, nullptr, S.d_jbu_recs + 2 * (size_t) S.jbu_off[nl - 1], S.jbu_off[nl] - S.jbu_off[nl - 1], d_x, w, ldx, nrhs, S.max_nsupc[nl - 1]);
-    H->st.solve_launches += 1;
+    // the chunks of a level whose columns lie beyond the next level run beside the diagonal blocks of the level ABOVE; the top level's (columns of ancestors in
+    // other forests, solved before this sweep) run first, alone.  In which form a level's chunks come follows from its own form: joined -> every chunk, the
+    // columns of the next level skipped (its joined units apply them); two-launch -> the far chunks here, the urgent ones in their own launch later.
+    auto chunks = [&](int l, const int4 *&recs, const int2 *&units, int &n) {
+        if (l < 0) { recs = nullptr; units = nullptr; n = 0; }
+        else if (level_joined(H, S, l)) { recs = S.d_jbu_recs + 2 * (size_t) S.jbu_off[l]; units = nullptr; n = S.jbu_off[l + 1] - S.jbu_off[l]; }
+        else { const int b1 = S.bu_off[2 * l + 1], b2 = S.bu_off[2 * l + 2]; recs = br + 2 * (size_t) b1; units = S.d_bwd_units + b1; n = b2 - b1; }
+    };
+    {
+        const int4 *recs; const int2 *units; int n;
+        chunks(nl - 1, recs, units, n);
+        eng::sweep_step(s, false, T, nullptr, 0, units, n, d_x, w, ldx, nrhs, S.max_nsupc[nl - 1], nullptr, recs);
+        H->st.solve_launches += 1;
+    }
     for (int l = nl - 1; l >= 0; --l) {
         const int mx = std::max(S.max_nsupc[l], l > 0 ? S.max_nsupc[l - 1] : 0);
-        const int u0 = l > 0 ? S.jbu_off[l - 1] : 0, u1 = l > 0 ? S.jbu_off[l] : 0;
-        eng::sweep_join(s, false, T, S.d_jb_recs + 4 * (size_t) S.jb_off[l], S.jb_off[l + 1] - S.jb_off[l], S.d_jb_aux, S.d_jbu_recs + 2 * (size_t) u0, u1 - u0, d_x, w, ldx, nrhs, mx);
-        H->st.solve_launches += 1;
+        const int4 *recs; const int2 *units; int n;
+        chunks(l - 1, recs, units, n);
+        if (level_joined(H, S, l)) {
+            eng::sweep_join(s, false, T, S.d_jb_recs + 4 * (size_t) S.jb_off[l], S.jb_off[l + 1] - S.jb_off[l], S.d_jb_aux, recs, n, d_x, w, ldx, nrhs, mx);
+            H->st.solve_launches += 1;
+        } else {
+            const int u0 = S.bu_off[2 * l], u1 = S.bu_off[2 * l + 1];
+            eng::bwd_update(s, T, nullptr, nullptr, 0, u1 - u0, d_x, w, ldx, nrhs, S.max_nsupc[l], S.d_bwd_units + u0, br + 2 * (size_t) u0);
+            eng::sweep_step(s, false, T, S.d_diag_units + S.du_off[l], S.du_off[l + 1] - S.du_off[l], units, n, d_x, w, ldx, nrhs, mx, dr + 2 * (size_t) S.du_off[l], recs);
+            H->st.solve_launches += 2;
+        }
     }
     return 0;
 }

@@ -44,6 +44,7 @@ void read_env(Handle::Env &e)
     if (const char *v = getenv("SLUAMD_FUSE_GROUP_MIN_NODES")) e.fuse_group_min_nodes = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_SMALL")) e.fuse_small = atoi(v) != 0;
     if (const char *v = getenv("SLUAMD_SOLVE_JOIN")) e.solve_join = atoi(v) != 0;
+    if (const char *v = getenv("SLUAMD_JOIN_MAX_NODES")) e.join_max_nodes = atoi(v);
     if (const char *v = getenv("SLUAMD_KSPLIT")) e.ksplit = std::max(1, std::min(16, atoi(v)));
     if (const char *v = getenv("SLUAMD_BIG_UTIL_PCT")) e.big_util_pct = atoi(v);
     if (const char *v = getenv("SLUAMD_BIG_MIN_COLS")) e.big_min_cols = atoi(v);

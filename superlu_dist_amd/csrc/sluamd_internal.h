@@ -231,7 +231,10 @@ struct LevelSched {
     // updates of level l to ITS 64 entries of the right-hand side itself -- the rows of the level-l panels that fall into column block c of j (forward), the
     // columns of level l + 1 in U(k, :) over the rows of block c (backward) -- then multiplies by the inverse block and ADDS into the (zeroed) output rows of
     // strip s.  The near rows / columns are recomputed by every strip that needs them (a 256-column supernode: 10 units, block c read by 4 - c of them) and
-    // skipped by the regular units (DevTables::lrow_near / ucol_near), which now ALL run beside the next level's joined units: one launch per level.
+    // skipped by the regular units (DevTables::lrow_near / ucol_near), which ALL run beside the next level's joined units: one launch per level.  Chosen per
+    // level (SLUAMD_JOIN_MAX_NODES): on levels of many supernodes the recomputation costs bandwidth and they keep the two-launch form.  (One unit per column
+    // block c with all its strips -- no recomputation -- was built and measured slower on every level: 16 + 16 loads per thread in flight, spills at the
+    // register budgets of the multi-workgroup builds; profiles/r04_ab_solve_join.txt.)
     //   forward unit, 8 int4:  (fst_j, ns_j, s, c) (Linv offset lo, hi, sources, first overflow source in jf_aux) then up to 3 sources of 2 int4:
     //                          (fst_k, ns_k, lda_k, rows) (value offset of the first row lo, hi, lrow index of the first row lo, hi)
     //   backward unit, 4 int4: (fst_k, ns_k, s, c) (Uinv offset lo, hi, first near column in jb_aux, near columns) (U value offset lo, hi, 0, 0) (0)
@@ -275,6 +278,7 @@ struct Handle {
         int level_split_min = 2048;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
         int level_split_wdiv = 128;  // SLUAMD_LEVEL_SPLIT_WDIV: levels heavier (panel values, upper bound from the block graph) than 1 / this of the forest's total are cut too; <= 1: off
         double level_split_wmin = 1e9;   // SLUAMD_LEVEL_SPLIT_WMIN: ... in forests of at least this many panel values in total
+        int join_max_nodes = 32;     // SLUAMD_JOIN_MAX_NODES: levels of more supernodes than this keep the two-launch links
         bool solve_join = true;      // SLUAMD_SOLVE_JOIN=0: the two-launch links of round 3 (urgent updates, then diagonal strips) instead of the joined units
         bool fuse_small = true;      // SLUAMD_FUSE_SMALL=0: K-fused pairs only where the 128 x 128 tile configuration runs (round 3)
         int ksplit = 4;              // SLUAMD_KSPLIT: workgroups per tile (shares of K) for the diagonal-block tiles on the panel chain when a launch has at most 64 of them (1 = off)

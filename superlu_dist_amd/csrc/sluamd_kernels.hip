@@ -2361,7 +2361,7 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
 //   narrow levels (<= 64 columns):  0  256 threads, batch of 16 (4 workgroups per CU);  1  256 threads, batches of 8, 8 workgroups per CU
 // A level of many units is bound by how much of a workgroup's life (record -> maps -> values -> reduction -> atomics: a chain of round trips) overlaps with
 // other workgroups' loads, not by the length of one life: SLUAMD_SWEEP_WIDE_V for launches of at least SLUAMD_SWEEP_WIDE_MIN units, SLUAMD_SWEEP_NARROW_V.
-static const int g_sweep_wide_v = getenv("SLUAMD_SWEEP_WIDE_V") ? atoi(getenv("SLUAMD_SWEEP_WIDE_V")) : 1;
+static const int g_sweep_wide_v = getenv("SLUAMD_SWEEP_WIDE_V") ? atoi(getenv("SLUAMD_SWEEP_WIDE_V")) : 5;
 static const int g_sweep_wide_min = getenv("SLUAMD_SWEEP_WIDE_MIN") ? atoi(getenv("SLUAMD_SWEEP_WIDE_MIN")) : 256;
 static const int g_sweep_narrow_v = getenv("SLUAMD_SWEEP_NARROW_V") ? atoi(getenv("SLUAMD_SWEEP_NARROW_V")) : 0;
 static inline int sweep_variant(int nwork, int mx)    // 0 .. 4 wide, 10 / 11 narrow

@@ -196,3 +196,29 @@ def test_dataflow_sweeps_on_the_device(monkeypatch, mode):
         assert info == 0 and st["chain_levels"] >= 6
         assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
         assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("join_max", [1 << 30, 32, 4, 1])
+def test_joined_links_of_the_sweeps_on_the_device(monkeypatch, join_max):
+    """Round 4: one launch per level in the triangular sweeps of a 1 x 1 layer (k_sweep_join: the 64 x 64 blocks of the next level's diagonal inverses
+    apply the adjacent level's updates to their own block of the right-hand side and ADD into zeroed rows; the regular units skip those rows / columns)
+    against the two-launch links on the same matrix -- every level joined, the two forms mixed at three depths (SLUAMD_JOIN_MAX_NODES), three right-hand
+    sides, supernodes of up to 256 columns (ten blocks), unsymmetric values.  Oracle-sized twin: tests/test_stream_order.py::test_joined_links_*."""
+    import numpy as np
+    from superlu_dist_amd import driver, matgen
+    N = 28
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(17)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 3)
+    monkeypatch.setenv("SLUAMD_SOLVE_JOIN", "0")
+    x_ref, info, st0 = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=64, maxsup=256)
+    assert info == 0
+    monkeypatch.setenv("SLUAMD_SOLVE_JOIN", "1")
+    monkeypatch.setenv("SLUAMD_JOIN_MAX_NODES", str(join_max))
+    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=64, maxsup=256)
+    assert info == 0 and st["solve_launches"] < st0["solve_launches"]
+    assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
+    assert np.abs(x - xt).max() <= 1e-9 * np.abs(xt).max()
+    assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)

@@ -52,6 +52,43 @@ def test_lookahead_schedule_single_rank(sched, mode, seed):
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("join_max", [1 << 30, 6, 2, 1])
+@pytest.mark.parametrize("mode,seed", [(1, 2), (2, 3), (3, 7)])
+def test_joined_links_of_the_triangular_sweeps(sched, monkeypatch, join_max, mode, seed):
+    """Round 4: ONE launch per level in the sweeps of a 1 x 1 layer -- the 64-column-block units of the next level's diagonal inverses apply the adjacent
+    level's updates to their own block of the right-hand side themselves and ADD their share of the solved block into zeroed rows, the regular units skip
+    those rows / columns (LevelSched::join, k_sweep_join).  The emulated launch runs joined and regular units in one seeded order.  join_max: every level
+    joined / the two forms mixed at different depths (levels of more supernodes keep the two-launch links; the forms meet in both orders in the backward
+    sweep).  Three right-hand sides, unsymmetric values, supernodes of up to 200 columns (four column blocks, > 3 sources at the lower levels)."""
+    monkeypatch.setenv("SLUAMD_JOIN_MAX_NODES", str(join_max))
+    N = 14
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(11)
+    v = v * (1.0 + 0.4 * rng.random(v.size))
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=8)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 3)
+    monkeypatch.setenv("SLUAMD_SOLVE_JOIN", "0")
+    x_ref, info, st0 = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=4, maxsup=200)
+    monkeypatch.setenv("SLUAMD_SOLVE_JOIN", "1")
+    _sched(sched, mode, seed)
+    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=4, maxsup=200)
+    _sched(sched, 0)
+    assert info == 0
+    assert st["solve_launches"] < st0["solve_launches"]
+    assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
+    assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("grid", [(1, 1, 2), (1, 1, 4)])
+def test_joined_links_per_forest_on_z_layers(sched, monkeypatch, grid):
+    """Joined links on 1 x 1 x Pz grids: every forest of a layer's path zeroes ITS rows of the two vectors (k_zero_nodes, not a memset: the rows of the
+    ancestor forests carry the reduced right-hand side / the solved blocks of the other Z levels)."""
+    monkeypatch.setenv("SLUAMD_JOIN_MAX_NODES", "3")
+    _sched(sched, 2, 5)
+    grid_cases.check_own_pipeline(8, grid, nrhs=2, unsym=True, refactor=True)
+    _sched(sched, 0)
+
+
 @pytest.mark.parametrize("max_nodes", [8, 3, 100000])
 @pytest.mark.parametrize("mode,seed", [(0, 1), (1, 1), (1, 5), (2, 2), (3, 3)])
 def test_dataflow_sweeps_honour_only_their_dependency_table(sched, monkeypatch, max_nodes, mode, seed):
