@@ -480,7 +480,7 @@ def main():
     solve_bytes = esz * float(st["nnz_L"] + st["nnz_U"])
     solve_gbs = solve_bytes / (np.mean(solve_ms) * 1e-3) / 1e9 if np.mean(solve_ms) > 0 else 0.0
     if world == 1:
-        out["roofline_solve"] = {"bound": "hbm", "kernel": "k_sweep + k_fwd_update + k_bwd_update (level-set block solves)",
+        out["roofline_solve"] = {"bound": "hbm", "kernel": "k_sweep_join (one launch per level: joined diagonal blocks + regular update units) + k_sweep / k_fwd_update / k_bwd_update on the levels of many supernodes",
                                  "achieved": solve_gbs, "peak": 8000.0, "unit": "GB/s", "frac": solve_gbs / 8000.0,
                                  "algorithmic_bytes_per_solve": solve_bytes,
                                  "note": "%d levels x 4 launches per solve; 3-4.7 TB/s on the levels that hold the data, launch latency on the single-supernode levels of the top separator" % st["num_levels"]}

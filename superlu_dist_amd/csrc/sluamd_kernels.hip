@@ -2400,7 +2400,7 @@ template <int NT, int RBv, int NBT, int CBT, bool UNR, int MINW> struct SweepCfg
     {
         const size_t lds = (size_t) mx * nrhs * sizeof(double);
         if (lower) hipLaunchKernelGGL((k_sweep_join<true, NT, RBv, NBT, CBT, UNR, MINW>), dim3(nj + nunits), dim3(NT), lds, s, T, jrecs, nj, jaux, urecs, xa, xb, ldx, nrhs);
-        else hipLaunchKernelGGL((k_sweep_join<false, NT, RBv, NBT, CBT, UNR, MINW>), dim3(nj + nunits), dim3(NT), lds, s, T, jrecs, nj, jaux, urecs, xa, xb, ldx, nrhs);
+        else hipLaunchKernelGGL((k_sweep_join<false, NT, RBv, NBT, CBT, UNR, MINW>), dim3(nj + nunits), dim3(NT), 0, s, T, jrecs, nj, jaux, urecs, xa, xb, ldx, nrhs);   // the backward units stage nothing in the dynamic segment
     }
     static int attrs()
     {
