@@ -276,7 +276,8 @@ struct Handle {
         int diag_tail = 64;          // SLUAMD_DIAG_TAIL: last N single-supernode levels factor their diagonal block with the whole-register-file build of k_diag_lu2
         int trsm_tail = 64;          // SLUAMD_TRSM_TAIL: last N single-supernode levels of a 1 x 1 layer solve their panels by blocked substitution, full inverses off the chain
         int level_split_min = 2048;  // SLUAMD_LEVEL_SPLIT_MIN: sub-levels never get smaller than this, forests whose largest level has fewer than 4 x this are not cut (tests lower it)
-        int level_split_wdiv = 128;  // SLUAMD_LEVEL_SPLIT_WDIV: levels heavier (panel values, upper bound from the block graph) than 1 / this of the forest's total are cut too; <= 1: off
+        int level_split_wdiv = 0;    // SLUAMD_LEVEL_SPLIT_WDIV (opt-in, e.g. 128): levels heavier (panel values, upper bound from the block graph) than 1 / this of the forest's total are cut too;
+                                     // <= 1: off.  Off by default: cut levels break K-fused pairs (150^3 on 2x2x2 with 128: allocated / values 1.27-1.29 -> 1.17-1.24, tile executions + 20 %)
         double level_split_wmin = 1e9;   // SLUAMD_LEVEL_SPLIT_WMIN: ... in forests of at least this many panel values in total
         int join_max_nodes = 32;     // SLUAMD_JOIN_MAX_NODES: levels of more supernodes than this keep the two-launch links
         bool solve_join = true;      // SLUAMD_SOLVE_JOIN=0: the two-launch links of round 3 (urgent updates, then diagonal strips) instead of the joined units

@@ -2350,37 +2350,29 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
     }
 }
 
-// Builds of the sweep kernels.  The work unit is the same in all of them (64 panel rows / 64 skyline columns of one supernode); what differs is how
-// many threads share it and how many workgroups a CU holds at a time:
+// Builds of the sweep kernels.  The work unit is the same in all of them (64 panel rows / 64 skyline columns of one supernode, or one 64 x 64 block of a
+// diagonal inverse in the joined links); what differs is how many threads share it and how many workgroups a CU holds at a time:
 //   wide levels (supernodes of 65 .. 256 columns)
-//     0  1024 threads, one batch of 16 loads per thread, 1 workgroup per CU: the shortest life of a unit -- levels of a FEW units (the chain at the top)
+//     0  1024 threads, one batch of 16 loads per thread, 1 workgroup per CU: the shortest life of a unit -- launches of a FEW units (the chain at the top)
 //     1   512 threads, two batches of 16, 2 workgroups per CU
-//     2   512 threads, batches of 8, built for 8 waves per SIMD: 4 workgroups per CU
-//     3   256 threads, batches of 8, 8 workgroups per CU
-//     4  1024 threads, batches of 8, 2 workgroups per CU
-//   narrow levels (<= 64 columns):  0  256 threads, batch of 16 (4 workgroups per CU);  1  256 threads, batches of 8, 8 workgroups per CU
-// A level of many units is bound by how much of a workgroup's life (record -> maps -> values -> reduction -> atomics: a chain of round trips) overlaps with
-// other workgroups' loads, not by the length of one life: SLUAMD_SWEEP_WIDE_V for launches of at least SLUAMD_SWEEP_WIDE_MIN units, SLUAMD_SWEEP_NARROW_V.
+//     5   512 threads, batches of 8, built for 6 waves per SIMD (80 VGPRs, no spills): 3 workgroups per CU -- the default for launches of >= 256 units
+//   narrow levels (<= 64 columns): 256 threads, batch of 16 (4 workgroups per CU)
+// A launch of many units is bound by how much of a workgroup's life (record -> maps -> values -> reduction -> atomics: a chain of round trips) overlaps with
+// other workgroups' loads, not by the length of one life (profiles/r04_ab_solve_join.txt: 6.16 ms with build 0 everywhere, 5.53 with 1, 5.47 with 5; builds for
+// 8 waves per SIMD spill and lose, more workgroups of 256 threads are no better, the narrow levels do not react).  SLUAMD_SWEEP_WIDE_V / SLUAMD_SWEEP_WIDE_MIN.
 static const int g_sweep_wide_v = getenv("SLUAMD_SWEEP_WIDE_V") ? atoi(getenv("SLUAMD_SWEEP_WIDE_V")) : 5;
 static const int g_sweep_wide_min = getenv("SLUAMD_SWEEP_WIDE_MIN") ? atoi(getenv("SLUAMD_SWEEP_WIDE_MIN")) : 256;
-static const int g_sweep_narrow_v = getenv("SLUAMD_SWEEP_NARROW_V") ? atoi(getenv("SLUAMD_SWEEP_NARROW_V")) : 0;
-static inline int sweep_variant(int nwork, int mx)    // 0 .. 4 wide, 10 / 11 narrow
+static inline int sweep_variant(int nwork, int mx)    // 0 / 1 / 5 wide, 10 narrow
 {
-    if (mx <= 64) return 10 + ((g_sweep_narrow_v >= 0 && g_sweep_narrow_v <= 2) ? g_sweep_narrow_v : 0);
-    if (mx > 256 || nwork < g_sweep_wide_min || g_sweep_wide_v < 0 || g_sweep_wide_v > 6) return 0;
+    if (mx <= 64) return 10;
+    if (mx > 256 || nwork < g_sweep_wide_min || (g_sweep_wide_v != 1 && g_sweep_wide_v != 5)) return 0;
     return g_sweep_wide_v;
 }
 //                 threads  row blocks  loads/batch (fwd, diag)  columns/batch (bwd)  all batches in flight  waves per SIMD
 #define SWEEP_V0   1024,    4,          16,                      4,                   true,                  4
 #define SWEEP_V1   512,     4,          16,                      4,                   true,                  2
-#define SWEEP_V2   512,     4,          8,                       2,                   false,                 8
-#define SWEEP_V3   256,     4,          8,                       2,                   false,                 8
-#define SWEEP_V4   1024,    4,          8,                       2,                   false,                 8
 #define SWEEP_V5   512,     4,          8,                       2,                   false,                 6
-#define SWEEP_V6   256,     4,          8,                       2,                   false,                 6
 #define SWEEP_N0   256,     1,          16,                      4,                   true,                  1
-#define SWEEP_N2   256,     1,          8,                       4,                   false,                 6
-#define SWEEP_N1   256,     1,          8,                       4,                   false,                 8
 template <int NT, int RBv, int NBT, int CBT, bool UNR, int MINW> struct SweepCfg {
     static void fwd(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int mx,
                     const int2 *units, const int4 *recs)
@@ -2414,20 +2406,13 @@ template <int NT, int RBv, int NBT, int CBT, bool UNR, int MINW> struct SweepCfg
 #define SWEEP_DISPATCH(v, CALL) \
     switch (v) { \
     case 1: SweepCfg<SWEEP_V1>::CALL; break; \
-    case 2: SweepCfg<SWEEP_V2>::CALL; break; \
-    case 3: SweepCfg<SWEEP_V3>::CALL; break; \
-    case 4: SweepCfg<SWEEP_V4>::CALL; break; \
     case 5: SweepCfg<SWEEP_V5>::CALL; break; \
-    case 6: SweepCfg<SWEEP_V6>::CALL; break; \
-    case 12: SweepCfg<SWEEP_N2>::CALL; break; \
     case 10: SweepCfg<SWEEP_N0>::CALL; break; \
-    case 11: SweepCfg<SWEEP_N1>::CALL; break; \
     default: SweepCfg<SWEEP_V0>::CALL; break; \
     }
 int sweep_attrs()
 {
-    return SweepCfg<SWEEP_V0>::attrs() | SweepCfg<SWEEP_V1>::attrs() | SweepCfg<SWEEP_V2>::attrs() | SweepCfg<SWEEP_V3>::attrs() | SweepCfg<SWEEP_V4>::attrs() | SweepCfg<SWEEP_V5>::attrs() | SweepCfg<SWEEP_V6>::attrs() | SweepCfg<SWEEP_N2>::attrs() |
-           SweepCfg<SWEEP_N0>::attrs() | SweepCfg<SWEEP_N1>::attrs();
+    return SweepCfg<SWEEP_V0>::attrs() | SweepCfg<SWEEP_V1>::attrs() | SweepCfg<SWEEP_V5>::attrs() | SweepCfg<SWEEP_N0>::attrs();
 }
 
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int mx,

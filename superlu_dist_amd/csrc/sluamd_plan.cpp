@@ -39,7 +39,9 @@ static void dag_levels(const SlotInput &in, const std::vector<int> &list, int ns
 // (few supernodes, long panels), which the count rule never cuts.  Second rule, same cut: w(k) = nsupc(k) x (nsupc(k) + sum of the widths of
 // the block rows of k) -- an upper bound of the panel of k in values, read from the global block graph, so identical on every rank -- and a
 // level heavier than 1 / wdiv of the FOREST's total weight (forests below `wmin` values in total are left alone) is cut into as many sub-levels
-// as that takes: three scratch copies of at most total / wdiv each, whatever the size of the problem.
+// as that takes: three scratch copies of at most total / wdiv each, whatever the size of the problem.  OPT-IN (SLUAMD_LEVEL_SPLIT_WDIV): a K-fused pair needs its
+// two supernodes in consecutive levels, and cutting the separator levels takes most pairs apart -- measured at 150^3 on 2 x 2 x 2 with wdiv = 128: allocated / values
+// 1.27-1.29 -> 1.17-1.24, levels 219 -> 293, fused pairs per rank 830 -> 164, planned Schur tile executions + 20 % (profiles/r04_grid_work_and_footprint.txt).
 static void split_wide_levels(const SlotInput &in, const std::vector<int> &xsup, const std::vector<int> &list, std::vector<int> &lvl, int &nlevels, int min_cap,
                               int wdiv, double wmin)
 {
