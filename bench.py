@@ -483,7 +483,7 @@ def main():
         out["roofline_solve"] = {"bound": "hbm", "kernel": "k_sweep_join (one launch per level: joined diagonal blocks + regular update units) + k_sweep / k_fwd_update / k_bwd_update on the levels of many supernodes",
                                  "achieved": solve_gbs, "peak": 8000.0, "unit": "GB/s", "frac": solve_gbs / 8000.0,
                                  "algorithmic_bytes_per_solve": solve_bytes,
-                                 "note": "%d levels, %d launches per solve (one per level and sweep where a level holds <= 32 supernodes, two elsewhere); 4-5.5 TB/s on the levels that hold the data, ~9.5 us per single-supernode level of the top separator" % (st["num_levels"], st.get("solve_launches", 0))}
+                                 "note": "%d levels; one launch per level and sweep where a level holds <= 32 supernodes, two elsewhere (100^3: 223 launches per solve); 4-5.5 TB/s on the levels that hold the data, ~9.5 us per single-supernode level of the top separator" % st["num_levels"]}
     if world > 1:   # the dominant kernel is profiled in the N=1 run of this same command (here: this rank's share under the serial schedule)
         out["roofline"].update(achieved=None, frac=None, avg_launch_ms=None, flops_per_launch=None, algorithmic_bytes_per_launch=None,
                                note="per-kernel roofline is measured by the N=1 run (bench.py --gpus 1); N>1 lines report whole-job throughput; "
