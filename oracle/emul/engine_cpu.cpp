@@ -970,7 +970,7 @@ void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int, 
 {
     emul_enqueue(s, [=] { impl::zdiag_lu(T, nodes, nn, replace_tiny, thresh, info); });
 }
-void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *, const int *, int nn, int, int)
+void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *, const int *, int nn, int, int, int)
 {
     emul_enqueue(s, [=] { impl::zpanel_trsm(T, nodes, nn); });
 }

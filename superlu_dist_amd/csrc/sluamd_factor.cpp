@@ -170,7 +170,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         ev_begin(H, H->ev_panel, H->ev_panel_used, ps);
         if (H->z) {   // zLPanelTrSolve / zUPanelTrSolve (ztrfCommWrapper.c): 64-row strips / 64-column chunks
             const int znl = S.zltr_prefix[po + nn], znu = S.bwd_prefix[po + nn];
-            eng::zpanel_trsm(ps, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, znl, znu);
+            eng::zpanel_trsm(ps, T, nodes, S.d_zltr_prefix + po, S.d_bwd_prefix + po, nn, znl, znu, mx);
             if (xy) {
                 ev_begin(H, H->ev_xchg, H->ev_xchg_used, ps);
                 if (!rc_x) rc_x = exchange(H, S.x_panel_send[l], S.x_panel_recv[l], ps);   // zIBcastRecvLPanel / zIBcastRecvUPanel

@@ -430,7 +430,7 @@ void rows_copy(hipStream_t s, double *v, int64_t ldv, int nrhs, const int *idx, 
 int mfma_selftest(const double *A, const double *B, double *D);   // host pointers
 // complex16 twins (any grid: the diagonal-block operand comes from sn_dptr / sn_dlda like the double kernels')
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
-void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu);
+void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc);
 void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
             const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0);   // cfg 0: tiles of 64 panel rows x 128 columns, else 32 x 64
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int max_nsupc);

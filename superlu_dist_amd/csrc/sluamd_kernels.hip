@@ -2538,9 +2538,12 @@ void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int m
     else if (mx <= 64) hipLaunchKernelGGL(kz_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), zdiag_lds_bytes(mx), s, T, nodes, replace_tiny, thresh, info, mx | 1);
 }
-void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu)
+static const bool g_ztrsm_quad = getenv("SLUAMD_NO_ZTRSM_QUAD") == nullptr;
+void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int mx)
 {
-    if (nl + nu > 0) hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
+    if (nl + nu <= 0) return;
+    if (mx <= 64 && g_ztrsm_quad) hipLaunchKernelGGL(kz_panel_trsm_quad, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);   // four lanes per row / column
+    else hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
             const int4 *ulist, int prio, const int *tmaps, int mmode)
