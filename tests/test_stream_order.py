@@ -79,6 +79,36 @@ def test_joined_links_of_the_triangular_sweeps(sched, monkeypatch, join_max, mod
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
 
 
+def test_joined_links_fall_back_on_unsorted_panel_rows(emul):
+    """The joined units take the rows of a source panel that fall into one 64-column block of the target as ONE range, which needs the rows inside a block in
+    ascending order.  The reference's symbfact leaves them in discovery order: a store with shuffled block rows must be solved by the two-launch links (same
+    launch count as SLUAMD_SOLVE_JOIN=0), the sorted store of the same matrix by the joined ones, both to the same solution."""
+    N = 12
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(3)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=8)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=4, maxsup=96)
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    out = {}
+    for shuffled in (False, True):
+        symb.distribute_host(v)
+        fs = symb.flat_store()
+        if shuffled:
+            grid_cases.shuffle_block_rows(fs, 5)
+        h = driver.LUHandle.from_store(fs)
+        assert h.pdgstrf3d(0.0) == 0
+        x = h.pdgstrs3d(xp)[symb.perm_c, :]
+        out[shuffled] = (x, h.stats()["solve_launches"], h.stats()["num_levels"])
+        h.destroy()
+        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
+    symb.free()
+    nl = out[True][2]
+    assert out[False][1] < out[True][1] and out[True][1] >= 4 * nl - 3       # joined: about one launch per level and sweep; fallback: two
+    assert np.abs(out[False][0] - out[True][0]).max() <= 1e-11 * np.abs(xt).max()
+
+
 @pytest.mark.parametrize("grid", [(1, 1, 2), (1, 1, 4)])
 def test_joined_links_per_forest_on_z_layers(sched, monkeypatch, grid):
     """Joined links on 1 x 1 x Pz grids: every forest of a layer's path zeroes ITS rows of the two vectors (k_zero_nodes, not a memset: the rows of the
