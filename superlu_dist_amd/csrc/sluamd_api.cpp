@@ -31,32 +31,45 @@ static int copy_values(Handle *H, const sluamd_dLUview_t *lu, int dir)
     char *pin = reinterpret_cast<char *>(H->h_pinned);
     const size_t cap = H->pinned_bytes;
     char *dv = reinterpret_cast<char *>(H->d_val);
-    struct Piece { char *host; size_t bytes; };
+    // a piece = bytes of the staging buffer <-> host memory: a contiguous run (perm == null), or elements [e0, e0 + bytes / esz) of an L panel in the handle's
+    // row order, whose rows the caller keeps in another order inside its blocks (HostStruct::lrow_perm): element (r, c) of the panel <-> host[perm[r] + c * lda]
+    struct Piece { char *host; size_t bytes; const int *perm; int64_t e0; int lda; };
     std::vector<Piece> pieces;
     size_t fill = 0; int64_t dev_byte = -1;   // byte offset in the arena of the first staged byte
+    auto move_piece = [&](const Piece &p, char *stage_ptr) {
+        if (!p.perm) { if (dir == 0) std::memcpy(stage_ptr, p.host, p.bytes); else std::memcpy(p.host, stage_ptr, p.bytes); return; }
+        const int64_t ne = (int64_t) (p.bytes / esz);
+        int64_t c = p.e0 / p.lda; int r = (int) (p.e0 - c * p.lda);
+        for (int64_t i = 0; i < ne; ++i) {
+            char *hp = p.host + ((size_t) p.perm[r] + (size_t) c * p.lda) * esz;
+            if (dir == 0) std::memcpy(stage_ptr + (size_t) i * esz, hp, esz); else std::memcpy(hp, stage_ptr + (size_t) i * esz, esz);
+            if (++r == p.lda) { r = 0; ++c; }
+        }
+    };
     auto flush = [&]() -> int {
         if (!fill) return 0;
         if (dir == 0) {
             size_t o = 0;
-            for (auto &p : pieces) { std::memcpy(pin + o, p.host, p.bytes); o += p.bytes; }
+            for (auto &p : pieces) { move_piece(p, pin + o); o += p.bytes; }
             HIPCHK(hipMemcpy(dv + dev_byte, pin, fill, hipMemcpyHostToDevice));
         } else {
             HIPCHK(hipMemcpy(pin, dv + dev_byte, fill, hipMemcpyDeviceToHost));
             size_t o = 0;
-            for (auto &p : pieces) { std::memcpy(p.host, pin + o, p.bytes); o += p.bytes; }
+            for (auto &p : pieces) { move_piece(p, pin + o); o += p.bytes; }
         }
         pieces.clear(); fill = 0; dev_byte = -1;
         return 0;
     };
     // one contiguous host range -> the next bytes of the arena, through the pinned buffer
-    auto stage = [&](char *hp, size_t total, int64_t dev_elem_off) -> int {
+    auto stage = [&](char *hp, size_t total, int64_t dev_elem_off, const int *perm = nullptr, int lda = 0) -> int {
         size_t done = 0;
         while (done < total) {
             const int64_t byte_off = dev_elem_off * (int64_t) esz + (int64_t) done;
             if (fill && (dev_byte + (int64_t) fill != byte_off || fill == cap)) { int rc2 = flush(); if (rc2) return rc2; }
             if (!fill) dev_byte = byte_off;
-            const size_t n = std::min(total - done, cap - fill);
-            pieces.push_back({hp + done, n});
+            const size_t n = std::min(total - done, cap - fill);      // cap and done are multiples of the element size
+            if (perm) pieces.push_back({hp, n, perm, (int64_t) (done / esz), lda});
+            else pieces.push_back({hp + done, n, nullptr, 0, 0});
             fill += n; done += n;
         }
         return 0;
@@ -80,7 +93,12 @@ static int copy_values(Handle *H, const sluamd_dLUview_t *lu, int dir)
             }
             char *hp = reinterpret_cast<char *>(pass == 0 ? (void *) lu->Lnzval_bc_ptr[k / g.Pc] : (void *) lu->Unzval_br_ptr[k / g.Pr]);
             if (!hp) { set_error("value array missing for a stored panel"); return SLUAMD_ESTRUCT; }
-            if ((rc = stage(hp, (size_t) len * esz, off))) return rc;
+            const std::vector<int> *pm = (pass == 0 && (size_t) k < hs.lrow_perm.size() && !hs.lrow_perm[k].empty()) ? &hs.lrow_perm[k] : nullptr;
+            if (pm) {
+                const int lda = (int) pm->size();
+                if (!lda || len % lda) { set_error("internal: row permutation of an L panel does not match its slot"); return SLUAMD_ESTRUCT; }
+                if ((rc = stage(hp, (size_t) len * esz, off, pm->data(), lda))) return rc;
+            } else if ((rc = stage(hp, (size_t) len * esz, off))) return rc;
         }
         if ((rc = flush())) return rc;
     }

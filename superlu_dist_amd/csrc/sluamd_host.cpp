@@ -44,6 +44,7 @@ void read_env(Handle::Env &e)
     if (const char *v = getenv("SLUAMD_FUSE_GROUP_MIN_NODES")) e.fuse_group_min_nodes = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_SMALL")) e.fuse_small = atoi(v) != 0;
     if (const char *v = getenv("SLUAMD_SOLVE_JOIN")) e.solve_join = atoi(v) != 0;
+    if (const char *v = getenv("SLUAMD_SORT_BLOCK_ROWS")) e.sort_block_rows = atoi(v) != 0;
     if (const char *v = getenv("SLUAMD_JOIN_MAX_NODES")) e.join_max_nodes = atoi(v);
     if (const char *v = getenv("SLUAMD_KSPLIT")) e.ksplit = std::max(1, std::min(16, atoi(v)));
     if (const char *v = getenv("SLUAMD_BIG_UTIL_PCT")) e.big_util_pct = atoi(v);
@@ -318,6 +319,28 @@ static int split_wide_supernodes(Handle &H, SlotInput &in)
     return 0;
 }
 
+// rows of every block of an Lrowind image into ascending order; perm[internal slot row] = the caller's slot row (left empty when nothing moved)
+static void sort_block_rows(std::vector<int> &li, std::vector<int> &perm)
+{
+    perm.clear();
+    const int nb = li[0], nsupr = li[1];
+    std::vector<int> order;
+    int p = BC_HEADER, r0 = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int nr = li[p + 1];
+        int *rows = li.data() + p + LB_DESCRIPTOR;
+        if (!std::is_sorted(rows, rows + nr)) {
+            if (perm.empty()) { perm.resize(nsupr); std::iota(perm.begin(), perm.end(), 0); }
+            order.resize(nr); std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return rows[a] < rows[c]; });
+            std::vector<int> sorted(nr);
+            for (int i = 0; i < nr; ++i) { sorted[i] = rows[order[i]]; perm[r0 + i] = r0 + order[i]; }
+            std::copy(sorted.begin(), sorted.end(), rows);
+        }
+        p += LB_DESCRIPTOR + nr; r0 += nr;
+    }
+}
+
 int slots_from_view(Handle &H, const sluamd_dLUview_t *lu, const sluamd_forest_view_t *forests, Comm *comm, SlotInput &in)
 {
     if (!lu || !lu->xsup || lu->nsupers <= 0) { set_error("invalid LU view"); return SLUAMD_EINVAL; }
@@ -338,6 +361,11 @@ int slots_from_view(Handle &H, const sluamd_dLUview_t *lu, const sluamd_forest_v
     hs.present.assign(ns, 0);
     for (auto &l : in.lists) for (int k : l) hs.present[k] = 1;
     in.lidx.assign(ns, {}); in.uidx.assign(ns, {}); in.succ.assign(ns, {});
+    // rows inside the L blocks ascending (HostStruct::lrow_perm) -- unless a supernode is wider than 256 columns: the refinement into pieces (SplitMap) gathers
+    // from the caller's layout by runs of its own.  xsup is global, so every rank of the grid decides alike and the peers receive sorted index images.
+    bool sort_rows = H.env.sort_block_rows;
+    for (int k = 0; k < ns && sort_rows; ++k) if (hs.xsup[k + 1] - hs.xsup[k] > 256) sort_rows = false;
+    hs.lrow_perm.assign(ns, {});
     std::vector<int> own_l, own_u;
     for (int k = 0; k < ns; ++k) {
         if (!hs.present[k]) continue;
@@ -346,6 +374,7 @@ int slots_from_view(Handle &H, const sluamd_dLUview_t *lu, const sluamd_forest_v
             if (li) {
                 if (li[0] < 0 || li[1] < 0) { set_error("malformed L block column header"); return SLUAMD_ESTRUCT; }
                 in.lidx[k].assign(li, li + BC_HEADER + (int64_t) li[0] * LB_DESCRIPTOR + li[1]);
+                if (sort_rows) sort_block_rows(in.lidx[k], hs.lrow_perm[k]);
             } else if (g.krow(k) == g.r) { set_error("L panel with the diagonal block missing on its owner"); return SLUAMD_ESTRUCT; }
             own_l.push_back(k);
         }

@@ -66,6 +66,10 @@ struct HostStruct {
     std::vector<int> lidx, uidx;
     int64_t nnzL = 0, nnzU = 0;               // own stored elements
     std::vector<uint8_t> present;             // [nsupers] 0 = not in any forest of this rank's Z layer
+    // View path (round 4): the reference leaves the row subscripts INSIDE an L block in discovery order; the handle keeps them ascending (merged Schur tiles and
+    // the joined sweeps need that) and remembers, per own L panel that had an unsorted block, the caller's slot row of every internal slot row (empty: identical).
+    // Values are permuted on the way through the pinned staging buffer, both ways (copy_values); peers receive the sorted index image.
+    std::vector<std::vector<int>> lrow_perm;
 };
 
 // Symbolic object behind sluamd_symb_t
@@ -280,6 +284,7 @@ struct Handle {
                                      // <= 1: off.  Off by default: cut levels break K-fused pairs (150^3 on 2x2x2 with 128: allocated / values 1.27-1.29 -> 1.17-1.24, tile executions + 20 %)
         double level_split_wmin = 1e9;   // SLUAMD_LEVEL_SPLIT_WMIN: ... in forests of at least this many panel values in total
         int join_max_nodes = 32;     // SLUAMD_JOIN_MAX_NODES: levels of more supernodes than this keep the two-launch links
+        bool sort_block_rows = true; // SLUAMD_SORT_BLOCK_ROWS=0: keep the caller's row order inside the L blocks of a view (round 3: no merged tiles / joined sweeps on such panels)
         bool solve_join = true;      // SLUAMD_SOLVE_JOIN=0: the two-launch links of round 3 (urgent updates, then diagonal strips) instead of the joined units
         bool fuse_small = true;      // SLUAMD_FUSE_SMALL=0: K-fused pairs only where the 128 x 128 tile configuration runs (round 3)
         int ksplit = 4;              // SLUAMD_KSPLIT: workgroups per tile (shares of K) for the diagonal-block tiles on the panel chain when a launch has at most 64 of them (1 = off)

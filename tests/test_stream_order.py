@@ -79,10 +79,15 @@ def test_joined_links_of_the_triangular_sweeps(sched, monkeypatch, join_max, mod
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
 
 
-def test_joined_links_fall_back_on_unsorted_panel_rows(emul):
-    """The joined units take the rows of a source panel that fall into one 64-column block of the target as ONE range, which needs the rows inside a block in
-    ascending order.  The reference's symbfact leaves them in discovery order: a store with shuffled block rows must be solved by the two-launch links (same
-    launch count as SLUAMD_SOLVE_JOIN=0), the sorted store of the same matrix by the joined ones, both to the same solution."""
+@pytest.mark.parametrize("sort_rows", [True, False])
+def test_unsorted_panel_rows_of_a_view(emul, monkeypatch, sort_rows):
+    """The reference's symbfact leaves the row subscripts INSIDE an L block in discovery order.  Round 4: a handle created from such a view keeps the rows
+    ascending internally (the values are permuted on their way through the staging buffer, both directions) so that the merged Schur tiles and the joined
+    sweeps -- which take the rows of a block that fall into one 64-column block of the target as ONE range -- apply to reference-produced stores as well:
+    same launch count as the sorted store of the same matrix, the factors copied back in the CALLER's row order equal to the oracle's factorisation of the
+    shuffled store.  SLUAMD_SORT_BLOCK_ROWS=0: the store is taken as it is and the sweeps fall back to the two-launch links."""
+    import oracle as orc
+    monkeypatch.setenv("SLUAMD_SORT_BLOCK_ROWS", "1" if sort_rows else "0")
     N = 12
     n, rp, ci, v = matgen.poisson3d(N)
     rng = np.random.default_rng(3)
@@ -97,15 +102,24 @@ def test_joined_links_fall_back_on_unsorted_panel_rows(emul):
         fs = symb.flat_store()
         if shuffled:
             grid_cases.shuffle_block_rows(fs, 5)
+        o = orc.LUStore(fs.n, fs.xsup, fs.Lrowind_off, fs.Lrowind.copy(), fs.Lnzval_off, fs.Lnzval.copy(), fs.Ufstnz_off, fs.Ufstnz, fs.Unzval_off, fs.Unzval.copy())
+        assert orc.dfactor(o)[0] == 0
+        rows_before = fs.Lrowind.copy()
         h = driver.LUHandle.from_store(fs)
         assert h.pdgstrf3d(0.0) == 0
         x = h.pdgstrs3d(xp)[symb.perm_c, :]
-        out[shuffled] = (x, h.stats()["solve_launches"], h.stats()["num_levels"])
+        st = h.stats()
+        h.copy_to_host()
         h.destroy()
+        assert np.array_equal(fs.Lrowind, rows_before)                      # the caller's index arrays are not touched
+        scale = np.abs(o.Lnzval).max()
+        assert np.abs(fs.Lnzval - o.Lnzval).max() <= 1e-12 * scale and np.abs(fs.Unzval - o.Unzval).max() <= 1e-12 * scale
         assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
+        out[shuffled] = (x, st["solve_launches"], st["num_levels"])
     symb.free()
     nl = out[True][2]
-    assert out[False][1] < out[True][1] and out[True][1] >= 4 * nl - 3       # joined: about one launch per level and sweep; fallback: two
+    if sort_rows: assert out[True][1] == out[False][1]
+    else: assert out[False][1] < out[True][1] and out[True][1] >= 4 * nl - 3       # joined: about one launch per level and sweep; fallback: two
     assert np.abs(out[False][0] - out[True][0]).max() <= 1e-11 * np.abs(xt).max()
 
 
