@@ -1,6 +1,7 @@
 // sluamd_api.cpp -- the C ABI of include/superlu_dist_amd.h (handle life cycle, value upload / download, factor / solve /
 // refinement entry points).  No CPU fallback: every entry point fails when no HIP device is present.
 #include <algorithm>
+#include <cstdint>
 #include <cstring>
 #include "sluamd_comm.h"
 #include "sluamd_plan.h"
@@ -38,12 +39,20 @@ static int copy_values(Handle *H, const sluamd_dLUview_t *lu, int dir)
     size_t fill = 0; int64_t dev_byte = -1;   // byte offset in the arena of the first staged byte
     auto move_piece = [&](const Piece &p, char *stage_ptr) {
         if (!p.perm) { if (dir == 0) std::memcpy(stage_ptr, p.host, p.bytes); else std::memcpy(p.host, stage_ptr, p.bytes); return; }
+        // column by column, a tight gather / scatter over the rows of the piece (8-byte words: one per double, two per doublecomplex)
         const int64_t ne = (int64_t) (p.bytes / esz);
+        const int w = (int) (esz / 8);
         int64_t c = p.e0 / p.lda; int r = (int) (p.e0 - c * p.lda);
-        for (int64_t i = 0; i < ne; ++i) {
-            char *hp = p.host + ((size_t) p.perm[r] + (size_t) c * p.lda) * esz;
-            if (dir == 0) std::memcpy(stage_ptr + (size_t) i * esz, hp, esz); else std::memcpy(hp, stage_ptr + (size_t) i * esz, esz);
-            if (++r == p.lda) { r = 0; ++c; }
+        uint64_t *st8 = reinterpret_cast<uint64_t *>(stage_ptr);
+        for (int64_t i = 0; i < ne;) {
+            const int nr = (int) std::min<int64_t>(p.lda - r, ne - i);
+            uint64_t *col = reinterpret_cast<uint64_t *>(p.host) + (size_t) c * p.lda * w;
+            const int *pm = p.perm + r;
+            uint64_t *sp = st8 + (size_t) i * w;
+            if (w == 1) { if (dir == 0) for (int q = 0; q < nr; ++q) sp[q] = col[pm[q]]; else for (int q = 0; q < nr; ++q) col[pm[q]] = sp[q]; }
+            else if (dir == 0) for (int q = 0; q < nr; ++q) { sp[2 * q] = col[2 * (size_t) pm[q]]; sp[2 * q + 1] = col[2 * (size_t) pm[q] + 1]; }
+            else for (int q = 0; q < nr; ++q) { col[2 * (size_t) pm[q]] = sp[2 * q]; col[2 * (size_t) pm[q] + 1] = sp[2 * q + 1]; }
+            i += nr; r = 0; ++c;
         }
     };
     auto flush = [&]() -> int {
