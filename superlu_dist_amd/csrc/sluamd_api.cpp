@@ -2,6 +2,7 @@
 // refinement entry points).  No CPU fallback: every entry point fails when no HIP device is present.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include "sluamd_comm.h"
 #include "sluamd_plan.h"
@@ -14,7 +15,8 @@ namespace sluamd {
 static int ensure_pinned(Handle *H)
 {
     if (H->h_pinned) return 0;
-    const size_t want = (size_t) 64 << 20;
+    size_t want = (size_t) 64 << 20;
+    if (const char *v = getenv("SLUAMD_PINNED_BYTES")) want = std::max<size_t>(256, (size_t) atoll(v) & ~(size_t) 15);   // test knob: slots split across many flushes
     HIPCHK(hipHostMalloc(&H->h_pinned, want, hipHostMallocDefault));
     H->pinned_bytes = want;
     return 0;

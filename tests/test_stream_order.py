@@ -79,15 +79,16 @@ def test_joined_links_of_the_triangular_sweeps(sched, monkeypatch, join_max, mod
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
 
 
-@pytest.mark.parametrize("sort_rows", [True, False])
-def test_unsorted_panel_rows_of_a_view(emul, monkeypatch, sort_rows):
+@pytest.mark.parametrize("sort_rows,pinned", [(True, None), (False, None), (True, 4096), (True, 1000)])
+def test_unsorted_panel_rows_of_a_view(emul, monkeypatch, sort_rows, pinned):
     """The reference's symbfact leaves the row subscripts INSIDE an L block in discovery order.  Round 4: a handle created from such a view keeps the rows
     ascending internally (the values are permuted on their way through the staging buffer, both directions) so that the merged Schur tiles and the joined
     sweeps -- which take the rows of a block that fall into one 64-column block of the target as ONE range -- apply to reference-produced stores as well:
     same launch count as the sorted store of the same matrix, the factors copied back in the CALLER's row order equal to the oracle's factorisation of the
-    shuffled store.  SLUAMD_SORT_BLOCK_ROWS=0: the store is taken as it is and the sweeps fall back to the two-launch links."""
+    shuffled store (also with a staging buffer so small that every panel crosses many flushes).  SLUAMD_SORT_BLOCK_ROWS=0: the store is taken as it is and the sweeps fall back to the two-launch links."""
     import oracle as orc
     monkeypatch.setenv("SLUAMD_SORT_BLOCK_ROWS", "1" if sort_rows else "0")
+    if pinned: monkeypatch.setenv("SLUAMD_PINNED_BYTES", str(pinned))      # a staging buffer of a few hundred values: every panel is split, pieces start mid-column
     N = 12
     n, rp, ci, v = matgen.poisson3d(N)
     rng = np.random.default_rng(3)
