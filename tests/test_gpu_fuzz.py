@@ -1,11 +1,13 @@
 """Randomised own-pipeline parity on the device: irregular patterns (random sparse, perturbed stencils, the elasticity-like stand-in), graph
 ordering, random supernode parameters, double and complex16, 1..5 right-hand sides -- every factor value and the solve against the CPU oracle
 (oracle/, TEST INFRASTRUCTURE).  Covers what the structured cases do not: ragged tiles of every shape through the per-tile records, tiles
-without destination, fused pairs next to unfused ones, the unit records of the sweeps on irregular level structures."""
+without destination, fused pairs next to unfused ones, the unit records of the sweeps on irregular level structures, and (every fourth case) L blocks whose rows
+come in a random order, which the handle sorts at creation."""
 import os
 import numpy as np
 import pytest
 import oracle as orc
+import grid_cases
 from superlu_dist_amd import driver, matgen
 
 pytestmark = pytest.mark.gpu
@@ -36,12 +38,19 @@ def test_random_matrices_match_oracle(seed, complex16):
         v = matgen.complex_shift(v, rp, ci, seed=seed)
     perm = driver.order_nd(n, rp, ci, leaf=int(rng.choice([8, 27, 64])))
     symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+    shuffle = seed % 4 == 3      # every fourth case: the rows INSIDE the L blocks in a random order, as the reference's symbfact leaves them (the handle sorts
+                                 # them at creation and permutes the values in its staging buffer, both ways: copy_to_host must return the caller's order)
     if complex16:
         symb.distribute_host(v.real); fr = symb.flat_store()
         symb.distribute_host(v.imag); fi = symb.flat_store()
+        if shuffle:
+            grid_cases.shuffle_block_rows(fr, seed); grid_cases.shuffle_block_rows(fi, seed)      # same structure, same seed: the same permutations
+            assert np.array_equal(fr.Lrowind, fi.Lrowind)
         Lz, Uz = fr.Lnzval + 1j * fi.Lnzval, fr.Unzval + 1j * fi.Unzval
     else:
         symb.distribute_host(v); fr = symb.flat_store()
+        if shuffle:
+            grid_cases.shuffle_block_rows(fr, seed)
         Lz, Uz = fr.Lnzval, fr.Unzval
     o = orc.LUStore(fr.n, fr.xsup, fr.Lrowind_off, fr.Lrowind, fr.Lnzval_off, Lz, fr.Ufstnz_off, fr.Ufstnz, fr.Unzval_off, Uz)
     fs = driver.FlatStore(fr.n, fr.xsup, fr.Lrowind_off, fr.Lrowind, fr.Lnzval_off, Lz.copy(), fr.Ufstnz_off, fr.Ufstnz, fr.Unzval_off, Uz.copy())
