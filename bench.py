@@ -66,16 +66,84 @@ def build_problem(N, leaf, workload="poisson3d"):
     return n, rp, ci, v, perm, xt, b
 
 
-def cpu_baseline_grid(N, leaf, relax, maxsup, ref_bin, host_cores):
+def _mkl_reference():
+    """The reference built on the image's MKL (oracle/ref/Makefile target ref_mkl: -DUSE_VENDOR_BLAS -DSLU_HAVE_LAPACK, no CBLAS objects): its path
+    and a description of the BLAS, or (None, reason) when the binary or the library did not travel / is not on this box."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref_mkl", "slu_ref_dump")
+    if not os.path.exists(ref_bin):
+        return None, "oracle/_ref_mkl/slu_ref_dump not built (make -C oracle/ref ref_mkl where /root/reference exists)"
+    lib = "/opt/conda/lib/libmkl_rt.so"
+    if not os.path.exists(lib):
+        return None, lib + " not on this box"
+    ver = ""
+    try:
+        import ctypes
+        m = ctypes.CDLL(lib, mode=ctypes.RTLD_LOCAL)
+        buf = ctypes.create_string_buffer(200)
+        m.mkl_get_version_string(buf, 200)
+        ver = buf.value.decode(errors="replace").strip()
+    except Exception:
+        pass
+    return ref_bin, (ver or "Intel MKL (libmkl_rt)")
+
+
+def _run_reference(ref_bin, args, env, nproc=1, wrap_dir=None, threads=1, timeout=150):
+    """One run of the reference harness (slu_ref_dump); nproc > 1 goes through mpiexec with every rank pinned to its own core range when taskset
+    and a known rank variable allow it.  Returns (record or None, pinned, wall seconds, error text)."""
+    import shutil
+    pinned = False
+    cmd = [ref_bin] + args
+    if nproc > 1:
+        mpiexec = os.environ.get("SLUAMD_MPIEXEC") or shutil.which("mpiexec") or ("/opt/conda/bin/mpiexec" if os.path.exists("/opt/conda/bin/mpiexec") else None)
+        if not mpiexec:
+            return None, False, 0.0, "mpiexec not available (SLUAMD_MPIEXEC / PATH / /opt/conda/bin)"
+        allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+        if shutil.which("taskset") and len(allowed) >= nproc * threads and wrap_dir:
+            # rank q -> the q-th run of `threads` CPUs this process may use; the rank comes from whichever variable the launcher sets (MPICH / Hydra:
+            # PMI_RANK, Open MPI: OMPI_COMM_WORLD_RANK, PMIx launchers: PMIX_RANK); the wrapper REPORTS what it did, the record follows it
+            wrap = os.path.join(wrap_dir, "rank.sh")
+            with open(wrap, "w") as f:
+                f.write("#!/bin/sh\nr=${PMI_RANK:-${OMPI_COMM_WORLD_RANK:-${PMIX_RANK:-}}}\ncase \"$r\" in\n")
+                for q in range(nproc):
+                    f.write(f"{q}) echo PINNED {q} >&2; exec taskset -c {','.join(str(c) for c in allowed[q * threads:(q + 1) * threads])} {ref_bin} {' '.join(args)};;\n")
+                f.write(f"*) echo UNPINNED >&2; exec {ref_bin} {' '.join(args)};;\nesac\n")
+            os.chmod(wrap, 0o755)
+            cmd = [mpiexec, "-n", str(nproc), wrap]
+        else:
+            cmd = [mpiexec, "-n", str(nproc), ref_bin] + args
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return None, False, time.perf_counter() - t0, f"timeout {timeout} s"
+    wall = time.perf_counter() - t0
+    if nproc > 1:
+        pinned = "UNPINNED" not in r.stderr and sum(1 for l in r.stderr.splitlines() if l.startswith("PINNED ")) >= nproc
+    line = [l for l in r.stdout.splitlines() if l.startswith("REFTIMES")]
+    if r.returncode != 0 or not line:
+        return None, pinned, wall, ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-200:]
+    tok = line[0].split()
+    res = [l for l in r.stdout.splitlines() if l.startswith("RESIDUAL")]
+    return {"factor_s": float(tok[4]), "solve_s": float(tok[7]), "ops_FACT": float(tok[10]),
+            "residual": float(res[0].split()[1]) if res else None}, pinned, wall, None
+
+
+def _ref_env(threads, relax, maxsup, mkl_layer=None):
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", SUPERLU_MAXSUP=str(maxsup), SUPERLU_RELAX=str(relax))
+    env.pop("LD_LIBRARY_PATH", None)     # the binaries carry RUNPATH=/opt/conda/lib (MPICH, MKL)
+    if mkl_layer:
+        # libmkl_rt picks Intel's OpenMP runtime by default -- two OpenMP runtimes in one process with the reference's libgomp regions give WRONG
+        # factors (seen here: residual O(1) at 8 threads); SEQUENTIAL = one MKL call per OpenMP thread of the reference, GNU = MKL threads on libgomp
+        env["MKL_THREADING_LAYER"] = mkl_layer
+    return env
+
+
+def cpu_baseline_grid(N, leaf, relax, maxsup, ref_bin, host_cores, mkl=None):
     """SURVEY 8(d)'s second CPU leg: the real reference on a 2 x 2 x 2 process grid, 8 MPI ranks x host_cores/8 OpenMP threads (capped at 8:
     the reference stops scaling past ~8 threads per rank, see the 1-rank sweep), every rank pinned to its own contiguous core range.
     RowPerm stays at the reference's default (LargeDiag_MC64: the identity on this diagonally dominant matrix; v9.2.1's pdgssvx3d fails in
     symbfact with NOROWPERM on a 2 x 2 x 2 grid), everything else as the 1-rank leg.  Timer = stat.utime[FACT] of rank 0 (pdgstrf3d.c:331,395)."""
-    import shutil
     from superlu_dist_amd import driver, matgen
-    mpiexec = "/opt/conda/bin/mpiexec"
-    if not os.path.exists(mpiexec):
-        return {"error": "mpiexec not available"}
     n, rp, ci, v, perm, xt, b = build_problem(N, leaf)
     symb = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
     flops = symb.flops
@@ -85,44 +153,24 @@ def cpu_baseline_grid(N, leaf, relax, maxsup, ref_bin, host_cores):
         mpath = os.path.join(tmp, "a.dat"); ppath = os.path.join(tmp, "a.perm")
         matgen.write_triplet_dat(mpath, n, rp, ci, v)
         np.savetxt(ppath, perm, fmt="%d")
-        env = dict(os.environ, OMP_NUM_THREADS=str(th), SUPERLU_MAXSUP=str(maxsup), SUPERLU_RELAX=str(relax))
-        env.pop("LD_LIBRARY_PATH", None)
-        args = f"{ref_bin} -r 2 -c 2 -d 2 -e 0 -p 1 -i 0 -Q 1 -P {ppath} -o none {mpath}"
-        allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(host_cores))
-        pinned = bool(shutil.which("taskset")) and len(allowed) >= 8 * th
-        if pinned:   # rank q -> the q-th run of `th` CPUs this process may use: OpenMP's close / cores placement then stays inside the rank's own range
-            env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
-            wrap = os.path.join(tmp, "rank.sh")
-            with open(wrap, "w") as f:
-                f.write("#!/bin/sh\ncase $PMI_RANK in\n")
-                for q in range(8):
-                    f.write(f"{q}) exec taskset -c {','.join(str(c) for c in allowed[q * th:(q + 1) * th])} {args};;\n")
-                f.write(f"*) exec {args};;\nesac\n")
-            os.chmod(wrap, 0o755)
-            cmd = [mpiexec, "-n", "8", wrap]
-        else:
-            cmd = [mpiexec, "-n", "8"] + args.split()
-        t0 = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
-        except subprocess.TimeoutExpired:
-            return {"error": "timeout 150 s", "sample": f"{N}^3", "ranks": 8, "threads_per_rank": th}
-        wall = time.perf_counter() - t0
-    line = [l for l in r.stdout.splitlines() if l.startswith("REFTIMES")]
-    if r.returncode != 0 or not line:
-        return {"error": ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-200:]}
-    tok = line[0].split()
-    res = [l for l in r.stdout.splitlines() if l.startswith("RESIDUAL")]
-    return {"kind": "reference", "grid": "2x2x2", "ranks": 8, "threads_per_rank": th, "cores": 8 * th, "pinned": pinned,
+        env = _ref_env(th, relax, maxsup, "SEQUENTIAL" if mkl else None)
+        args = ["-r", "2", "-c", "2", "-d", "2", "-e", "0", "-p", "1", "-i", "0", "-Q", "1", "-P", ppath, "-o", "none", mpath]
+        rec, pinned, wall, err = _run_reference(ref_bin, args, env, nproc=8, wrap_dir=tmp, threads=th, timeout=150)
+    if rec is None:
+        return {"error": err, "sample": f"{N}^3", "ranks": 8, "threads_per_rank": th}
+    return {"kind": "reference+mkl" if mkl else "reference", "blas": mkl or "vendored f2c CBLAS (scalar dgemm)",
+            "grid": "2x2x2", "ranks": 8, "threads_per_rank": th, "cores": 8 * th, "pinned": pinned,
             "sample": f"{N}^3 7-pt Poisson, same ND perm_c/relax/maxsup, 2x2x2 grid (mpiexec -n 8), nrhs=1", "flops": flops,
-            "factor_s": float(tok[4]), "solve_s": float(tok[7]), "value": flops / float(tok[4]) / 1e9, "unit": "GFLOP/s",
-            "reference_ops_FACT": float(tok[10]), "residual": float(res[0].split()[1]) if res else None, "wall_s": wall}
+            "factor_s": rec["factor_s"], "solve_s": rec["solve_s"], "value": flops / rec["factor_s"] / 1e9, "unit": "GFLOP/s",
+            "reference_ops_FACT": rec["ops_FACT"], "residual": rec["residual"], "wall_s": wall}
 
 
-def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0):
-    """Time the CPU leg on a bounded sample (N^3 Poisson, same ordering / supernode parameters).
-    kind = "reference": the real reference's pdgstrf3d (oracle/_ref/slu_ref_dump, OpenMP, internal CBLAS)
-    kind = "port":      oracle/slu_oracle.c (our CPU restatement, OpenMP over (L block, U block) pairs)."""
+def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0, mkl_n=60, mkl_grid_n=70):
+    """Time the CPU legs on bounded samples (N^3 Poisson, same ordering / supernode parameters as the benched problem).
+    kind = "reference+mkl": the real reference's pdgstrf3d built with its own vendor-BLAS switch (-DUSE_VENDOR_BLAS, CMakeLists.txt:389-407,
+                            dsuperlu_blas.c:40-99) on the image's MKL -- oracle/_ref_mkl/slu_ref_dump; the headline CPU number when it is on the box
+    kind = "reference":     the same on the reference's vendored f2c CBLAS (oracle/_ref/slu_ref_dump: the parity oracle's build)
+    kind = "port":          oracle/slu_oracle.c (our CPU restatement, OpenMP over (L block, U block) pairs)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     cores = min(os.cpu_count() or 1, 32)      # more threads only add OpenMP fork/join overhead on these loop sizes
     os.environ["OMP_NUM_THREADS"] = str(cores)   # before libgomp is loaded by the oracle library
@@ -148,65 +196,97 @@ def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0):
     x = y[symb.perm_c, :]
     res = float(np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) / np.linalg.norm(b))
     out.update({"kind": "port", "value": flops / t_port / 1e9, "cores": orc.num_threads(), "factor_s": t_port,
-                "solve_s": t_port_solve, "residual": res})
+                "solve_s": t_port_solve, "residual": res, "port_value": flops / t_port / 1e9})
     symb.free()
-    # ---- real reference, when its prebuilt binary travelled with the snapshot: thread sweep, best run reported ----
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "slu_ref_dump")
     host_cores = os.cpu_count() or 1
     out["host_cores"] = host_cores
-    if want_reference and os.path.exists(ref_bin):
+    if not want_reference:
+        return out
+
+    def sweep_leg(ref_bin, Ns, layer, budget_s, thread_list):
+        """thread sweep of one reference binary on the Ns^3 sample: small counts first, ends once more threads only slow it down or the budget is spent"""
+        n2, rp2, ci2, v2, perm2, _, _ = build_problem(Ns, leaf)
+        sy = driver.Symbolic(n2, rp2, ci2, perm2, relax=relax, maxsup=maxsup)
+        fl2 = sy.flops
+        sy.free()
+        sweep, spent, best = [], 0.0, None
+        with tempfile.TemporaryDirectory() as tmp:
+            mpath = os.path.join(tmp, "a.dat"); ppath = os.path.join(tmp, "a.perm")
+            matgen.write_triplet_dat(mpath, n2, rp2, ci2, v2)
+            np.savetxt(ppath, perm2, fmt="%d")
+            args = ["-r", "1", "-c", "1", "-d", "1", "-e", "0", "-p", "0", "-i", "0", "-Q", "1", "-P", ppath, "-o", "none", mpath]
+            for th in [t for t in thread_list if t <= host_cores] or [host_cores]:
+                if spent > budget_s:
+                    break
+                if best and th > best["threads"] and sweep and sweep[-1].get("factor_s", 0) > 1.25 * best["factor_s"]:
+                    continue                 # more threads already made it slower
+                rec, _, wall, err = _run_reference(ref_bin, args, _ref_env(th, relax, maxsup, layer), timeout=max(30, int(budget_s)))
+                spent += wall
+                if rec is None:
+                    sweep.append({"threads": th, "error": err})
+                    continue
+                rec = dict(threads=th, gflops=fl2 / rec["factor_s"] / 1e9, **rec)
+                if layer: rec["mkl_threading_layer"] = layer
+                sweep.append(rec)
+                if rec["residual"] is not None and rec["residual"] < 1e-10 and (best is None or rec["factor_s"] < best["factor_s"]):
+                    best = rec
+            if best and layer == "SEQUENTIAL" and spent < budget_s:     # one more point: MKL's own threads (on libgomp) at the best thread count
+                rec, _, wall, err = _run_reference(ref_bin, args, _ref_env(best["threads"], relax, maxsup, "GNU"), timeout=max(30, int(budget_s)))
+                if rec is not None:
+                    rec = dict(threads=best["threads"], gflops=fl2 / rec["factor_s"] / 1e9, mkl_threading_layer="GNU", **rec)
+                    sweep.append(rec)
+                    if rec["residual"] is not None and rec["residual"] < 1e-10 and rec["factor_s"] < best["factor_s"]:
+                        best = rec
+        return fl2, sweep, best
+
+    # ---- the real reference on its vendored CBLAS (the parity oracle's build), one bounded thread sweep on the N^3 sample ----
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "slu_ref_dump")
+    cblas = None
+    if os.path.exists(ref_bin):
         try:
-            with tempfile.TemporaryDirectory() as tmp:
-                mpath = os.path.join(tmp, "a.dat"); ppath = os.path.join(tmp, "a.perm")
-                matgen.write_triplet_dat(mpath, n, rp, ci, v)
-                np.savetxt(ppath, perm, fmt="%d")
-                sweep, spent, best = [], 0.0, None
-                # thread sweep, small counts first (the old list tried 32 and 64 threads only -- the two worst points; the
-                # reference's OpenMP regions are per (L block, U block) pair and its vendored f2c dgemm is scalar, so it stops scaling
-                # after a few cores), threads pinned to cores; the sweep ends early once a count is clearly past the optimum
-                for th in [t for t in (8, 16, 32, 4) if t <= host_cores] or [host_cores]:
-                    if spent > 100.0:            # bounded: the whole CPU leg stays within a couple of minutes
-                        break
-                    if best and th > best["threads"] and sweep and sweep[-1].get("factor_s", 0) > 1.5 * best["factor_s"]:
-                        continue                 # more threads already made it slower
-                    env = dict(os.environ, OMP_NUM_THREADS=str(th), OMP_PROC_BIND="close", OMP_PLACES="cores",
-                               SUPERLU_MAXSUP=str(maxsup), SUPERLU_RELAX=str(relax))
-                    env.pop("LD_LIBRARY_PATH", None)     # the binary carries RUNPATH=/opt/conda/lib for MPICH
-                    t0 = time.perf_counter()
-                    try:
-                        r = subprocess.run([ref_bin, "-r", "1", "-c", "1", "-d", "1", "-e", "0", "-p", "0", "-i", "0", "-Q", "1",
-                                            "-P", ppath, "-o", "none", mpath], env=env, capture_output=True, text=True, timeout=90)
-                    except subprocess.TimeoutExpired:
-                        spent += time.perf_counter() - t0
-                        sweep.append({"threads": th, "timeout_s": 90})
-                        continue
-                    spent += time.perf_counter() - t0
-                    line = [l for l in r.stdout.splitlines() if l.startswith("REFTIMES")]
-                    if r.returncode == 0 and line:
-                        tok = line[0].split()
-                        rec = {"threads": th, "factor_s": float(tok[4]), "solve_s": float(tok[7]), "ops_FACT": float(tok[10]),
-                               "gflops": flops / float(tok[4]) / 1e9}
-                        sweep.append(rec)
-                        if best is None or rec["factor_s"] < best["factor_s"]:
-                            best = rec
-                if best:
-                    out.update({"kind": "reference", "value": flops / best["factor_s"] / 1e9, "cores": best["threads"],
-                                "factor_s": best["factor_s"], "solve_s": best["solve_s"], "port_value": flops / t_port / 1e9,
-                                "reference_ops_FACT": best["ops_FACT"], "thread_sweep": sweep,
-                                "gflops_per_core": flops / best["factor_s"] / 1e9 / best["threads"],
-                                "note": "reference v9.2.1 pdgstrf3d (OpenMP, OMP_PROC_BIND=close OMP_PLACES=cores, vendored f2c CBLAS: "
-                                        "scalar dgemm, ~1 GFLOP/s per core) timed by stat.utime[FACT], best of the thread sweep; "
-                                        "GFLOP/s uses our symbolic flop count of OUR supernode partition (reference_ops_FACT = the "
-                                        "reference's own tally on the same matrix).  Measured on the bounded sample only: the "
-                                        "reference's rate on the benched 100^3 problem is NOT measured (270x the flops of the sample: "
-                                        "hours at this rate); supernodes are wider there, so its GFLOP/s would be somewhat higher"})
-        except Exception as e:  # the reference leg is best-effort; the port leg above stands
+            fl2, sweep, best = sweep_leg(ref_bin, N, None, 45.0, (8, 16, 4))
+            if best:
+                cblas = {"kind": "reference", "blas": "vendored f2c CBLAS (scalar dgemm)", "sample": out["sample"], "flops": fl2,
+                         "value": fl2 / best["factor_s"] / 1e9, "unit": "GFLOP/s", "cores": best["threads"], "factor_s": best["factor_s"],
+                         "solve_s": best["solve_s"], "reference_ops_FACT": best["ops_FACT"], "residual": best["residual"], "thread_sweep": sweep}
+        except Exception as e:
             out["reference_error"] = str(e)[:200]
-        if grid_n:
-            try:
-                out["grid_2x2x2"] = cpu_baseline_grid(grid_n, leaf, relax, maxsup, ref_bin, host_cores)
-            except Exception as e:
-                out["grid_2x2x2"] = {"error": str(e)[:200]}
+    # ---- the real reference on MKL (its own USE_VENDOR_BLAS switch): the headline CPU leg ----
+    mkl_bin, mkl_desc = _mkl_reference()
+    mkl = None
+    if mkl_bin:
+        try:
+            fl2, sweep, best = sweep_leg(mkl_bin, mkl_n, "SEQUENTIAL", 110.0, (8, 16, 32))
+            if best:
+                mkl = {"kind": "reference+mkl", "blas": mkl_desc, "mkl_threading_layer": best.get("mkl_threading_layer"),
+                       "sample": f"{mkl_n}^3 7-pt Poisson, same ND perm_c/relax/maxsup, 1x1x1 grid, nrhs=1", "flops": fl2,
+                       "value": fl2 / best["factor_s"] / 1e9, "unit": "GFLOP/s", "cores": best["threads"], "factor_s": best["factor_s"],
+                       "solve_s": best["solve_s"], "reference_ops_FACT": best["ops_FACT"], "residual": best["residual"], "thread_sweep": sweep,
+                       "gflops_per_core": fl2 / best["factor_s"] / 1e9 / best["threads"]}
+        except Exception as e:
+            out["reference_mkl_error"] = str(e)[:200]
+    else:
+        out["reference_mkl_unavailable"] = mkl_desc
+    head = mkl or cblas
+    if head:
+        out.update({k: head[k] for k in ("kind", "blas", "sample", "flops", "value", "cores", "factor_s", "solve_s", "reference_ops_FACT", "residual", "thread_sweep")})
+        out["gflops_per_core"] = head["value"] / head["cores"]
+        if mkl:
+            out["mkl_threading_layer"] = mkl["mkl_threading_layer"]
+            if cblas: out["reference_cblas"] = cblas
+        out["note"] = ("reference v9.2.1 pdgstrf3d (OpenMP over block pairs, OMP_PROC_BIND=close OMP_PLACES=cores) timed by stat.utime[FACT], best of the "
+                       "thread sweep; " + ("BLAS = MKL through the reference's own -DUSE_VENDOR_BLAS switch (dgemm / dtrsm / dger inside its OpenMP regions), "
+                                           "LAPACK on (-DSLU_HAVE_LAPACK); `reference_cblas` is the same code on its vendored scalar CBLAS. " if mkl else
+                                           "BLAS = the reference's vendored f2c CBLAS (scalar dgemm, ~1 GFLOP/s per core): oracle/_ref_mkl or libmkl_rt absent on this box. ")
+                       + "GFLOP/s uses our symbolic flop count of OUR supernode partition (reference_ops_FACT = the reference's own tally on the same matrix). "
+                         "Measured on the bounded sample only: the reference's rate on the benched 100^3 problem is NOT measured (hours at these rates); "
+                         "supernodes are wider there, so its GFLOP/s would be somewhat higher")
+    if grid_n:
+        try:
+            out["grid_2x2x2"] = (cpu_baseline_grid(mkl_grid_n, leaf, relax, maxsup, mkl_bin, host_cores, mkl=mkl_desc) if mkl_bin and mkl
+                                 else cpu_baseline_grid(grid_n, leaf, relax, maxsup, ref_bin, host_cores))
+        except Exception as e:
+            out["grid_2x2x2"] = {"error": str(e)[:200]}
     return out
 
 
@@ -232,7 +312,9 @@ def main():
                     help="skip the `configs4` block of the default line (BASELINE.json configs[4]: complex16 1000 x 1000 grid operator, 5 steps)")
     ap.add_argument("--configs4-n", type=int, default=1000, help="grid side of the configs4 block (1000 = BASELINE.json configs[4]; the CPU flow test lowers it)")
     ap.add_argument("--cpu-grid-n", type=int, default=50,
-                    help="grid side of the 2x2x2 leg of the CPU baseline (8 MPI ranks x host_cores/8 threads of the real reference); 0 = skip")
+                    help="grid side of the 2x2x2 leg of the CPU baseline (8 MPI ranks x host_cores/8 threads of the real reference) on the vendored CBLAS; 0 = skip")
+    ap.add_argument("--cpu-mkl-n", type=int, default=60, help="grid side of the 1-rank CPU leg when the MKL build of the reference is on the box (oracle/_ref_mkl)")
+    ap.add_argument("--cpu-mkl-grid-n", type=int, default=70, help="grid side of the 2x2x2 CPU leg with the MKL build")
     ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "zgrid2d", "audikw_like"],
                     help="poisson3d = BASELINE configs[1] (default, the metric's config); zgrid2d = configs[4] family "
                          "(complex16 2-D grid operator, use --n 1000); audikw_like = configs[3] stand-in (use --n 68)")
@@ -559,7 +641,7 @@ def main():
             out["configs4"] = {"error": str(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "poisson3d":
         try:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.leaf, args.relax, args.maxsup, grid_n=args.cpu_grid_n)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.leaf, args.relax, args.maxsup, grid_n=args.cpu_grid_n, mkl_n=args.cpu_mkl_n, mkl_grid_n=args.cpu_mkl_grid_n)
         except Exception as e:
             out["cpu_baseline"] = {"error": str(e)[:300]}
     if rank == 0:

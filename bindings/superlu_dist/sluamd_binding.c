@@ -198,7 +198,7 @@ static int m_allmin(void *ctx, int32_t *v)
 static struct {
     sluamd_handle_t h; sluamd_comm_t comm; int n;
     /* lazy copy-back: the factors of the last factorisation live on the device only until a host consumer asks for them */
-    int host_stale; xLUstruct_t *LUstruct; gridinfo3d_t *grid3d;
+    int host_stale; xLUstruct_t *LUstruct; gridinfo3d_t *grid3d; int_t nsupers;
 } G;
 static int bind_comm_create(MPI_Comm comm, int Pr, int Pc, int Pz, int myrow, int mycol, int myz, int use_rccl)
 {
@@ -226,7 +226,7 @@ static int bind_comm_create(MPI_Comm comm, int Pr, int Pc, int Pz, int myrow, in
 static void sluamd_bind_release(void)
 {
     if (G.h) { S.destroy(G.h); G.h = NULL; }
-    G.host_stale = 0;
+    G.host_stale = 0; G.LUstruct = NULL; G.grid3d = NULL;
     if (G.comm) { S.comm_destroy(G.comm); G.comm = NULL; }
 }
 
@@ -270,34 +270,49 @@ static void bind_view_free(LUVIEW_T *v)
     sluamd_narrow_release();
 }
 
-/* Copy-back policy.  The reference's GPU path copies the factors to the host after every factorisation
- * (dCopyLUGPU2Host, pdgssvx3d.c:1013-1021): 17 GB at 100^3, longer than the factorisation itself -- and nothing reads them when both
- * triangular solves are bound to the library, which keeps the factors on the device.
- *   SLUAMD_BIND_COPYBACK=eager  copy after every factorisation (the reference's behaviour)
- *   SLUAMD_BIND_COPYBACK=lazy   leave them on the device; BIND_SYNC_HOST() copies on the first host consumer -- call it before anything
- *                               reads LUstruct->Llu's values on the host (the CPU solves pdgstrs3d[_newsolve] when they are NOT bound,
- *                               pdCompute_Diag_Inv, dgatherAllFactoredLU, dwriteLUtoDisk / dDumpLblocks3D); dbroadcastAncestor3d after
- *                               the factorisation only feeds the CPU solve and may run on the stale host values; dDestroy_LU needs none
- *   unset                       lazy when the solves are bound (SLUAMD_BIND_SOLVE unset or non-zero), eager with SLUAMD_BIND_SOLVE=0:
- *                               tests/test_gpu_dropin.py::test_factor_only_binding shows the CPU solves need the copy */
+/* Copy-back policy.  The reference's GPU path copies the factors to the host after every factorisation (dCopyLUGPU2Host,
+ * pdgssvx3d.c:1013-1021): 17 GB at 100^3, longer than the factorisation itself -- and nothing reads them when both triangular solves
+ * are bound to the library, which keeps the factors on the device.  But the binding cannot see at link time whether the solves were
+ * wrapped: an integration that replaces pdgstrf3d only (the reference's own GPU flow: copy back, then the CPU pdgstrs3d) must find the
+ * factored values in LUstruct->Llu.  So the DEFAULT IS EAGER, like the reference, and the copy is deferred only when somebody said so:
+ *   SLUAMD_BIND_COPYBACK=eager  copy after every factorisation (the reference's behaviour; the default)
+ *   SLUAMD_BIND_COPYBACK=lazy   leave them on the device; BIND_SYNC_HOST[_FOR]() copies on the first host consumer -- call it before
+ *                               anything reads LUstruct->Llu's values on the host (the CPU solves pdgstrs3d[_newsolve] when they are NOT
+ *                               bound, pdCompute_Diag_Inv, dbroadcastAncestor3d + the CPU solve on a Z-replicated grid,
+ *                               dgatherAllFactoredLU, dwriteLUtoDisk / dDumpLblocks3D); dDestroy_LU needs none
+ *   unset                       lazy only if (a) the integrator declared the solves bound -- sluamd_bind_[dz]solves_bound(1), one call
+ *                               next to the place where the --wrap / call-site replacement of pdgstrs3d[_newsolve] is made -- or (b) a
+ *                               bound solve has already run in this process (the binding then KNOWS the solves land in the library);
+ *                               otherwise eager.  The first deferred copy prints one line on stderr (SLUAMD_BIND_QUIET=1 silences it). */
+static int g_solves_declared = 0, g_solve_seen = 0;
+#ifndef Z_PREC
+#define BIND_SYNC_HOST sluamd_bind_dsync_host
+#define BIND_SYNC_HOST_FOR sluamd_bind_dsync_host_for
+#define BIND_SOLVES_BOUND sluamd_bind_dsolves_bound
+#define BIND_INVALIDATE sluamd_bind_dinvalidate
+#else
+#define BIND_SYNC_HOST sluamd_bind_zsync_host
+#define BIND_SYNC_HOST_FOR sluamd_bind_zsync_host_for
+#define BIND_SOLVES_BOUND sluamd_bind_zsolves_bound
+#define BIND_INVALIDATE sluamd_bind_zinvalidate
+#endif
+void BIND_SOLVES_BOUND(int yes) { g_solves_declared = yes != 0; }
 static int bind_copyback_lazy(void)
 {
     const char *cb = getenv("SLUAMD_BIND_COPYBACK");
     if (cb) return !strcmp(cb, "lazy");
-    const char *bs = getenv("SLUAMD_BIND_SOLVE");
-    return !bs || atoi(bs) != 0;
+    return g_solves_declared || g_solve_seen;
 }
-#ifndef Z_PREC
-#define BIND_SYNC_HOST sluamd_bind_dsync_host
-#else
-#define BIND_SYNC_HOST sluamd_bind_zsync_host
-#endif
-/* the factors of the last factorisation -> LUstruct's host arrays, if they are not there yet; returns 1 when a copy was made */
-int BIND_SYNC_HOST(void)
+/* The factors of the last factorisation -> the host arrays of (LUstruct, grid3d), if they are not there yet; returns 1 when a copy was
+ * made, 0 when there was nothing to do, -1 when LUstruct does not describe the factored matrix any more (other supernode partition).
+ * The caller passes the structures it is about to read: nothing cached is dereferenced. */
+int BIND_SYNC_HOST_FOR(xLUstruct_t *LUstruct, gridinfo3d_t *grid3d)
 {
     if (!G.h || !G.host_stale) return 0;
+    if (!LUstruct || !grid3d || !LUstruct->Glu_persist || !LUstruct->Llu || !LUstruct->Glu_persist->supno || !LUstruct->Glu_persist->xsup) return -1;
+    if (G.n <= 0 || (int_t) LUstruct->Glu_persist->supno[G.n - 1] + 1 != G.nsupers || (int_t) LUstruct->Glu_persist->xsup[G.nsupers] != (int_t) G.n) return -1;
     LUVIEW_T v;
-    bind_view_build(&v, G.n, G.LUstruct, G.grid3d);
+    bind_view_build(&v, G.n, LUstruct, grid3d);
     const double t0 = SuperLU_timer_();
     int rc = S.copy2host(G.h, &v);                                           /* was dCopyLUGPU2Host       */
     bind_view_free(&v);
@@ -306,6 +321,11 @@ int BIND_SYNC_HOST(void)
     if (getenv("SLUAMD_BIND_DEBUG")) fprintf(stderr, "[sluamd_bind] copyback on demand %.3f ms\n", 1e3 * (SuperLU_timer_() - t0));
     return 1;
 }
+/* the same on the structures pdgstrf3d was called with.  Only valid while they are alive: call BIND_INVALIDATE() before dDestroy_LU /
+ * dLUstructFree / superlu_gridexit3d or a re-distribution that reallocates Llu's arrays -- or use BIND_SYNC_HOST_FOR, which caches nothing */
+int BIND_SYNC_HOST(void) { return BIND_SYNC_HOST_FOR(G.LUstruct, G.grid3d); }
+/* forget the structures of the last factorisation (a pending deferred copy is dropped: the host arrays are going away) */
+void BIND_INVALIDATE(void) { G.LUstruct = NULL; G.grid3d = NULL; G.host_stale = 0; }
 
 int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
                             xtrf3Dpartition_t *trf3Dpartition, SCT_t *SCT, xLUstruct_t *LUstruct,
@@ -355,7 +375,7 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
         rc = S.create(&G.h, &v, &fv, &o);
     }
     if (rc) ABORT(S.last_error());
-    G.n = n;
+    G.n = n; G.nsupers = (int_t) v.nsupers;
     double thresh = smach_dist("Epsilon") * anorm;                           /* pdgstrf3d.c:132-133       */
     rc = S.factor(G.h, thresh, info);                                        /* was pdgstrf3d_LUv1: collective, info already MIN over the grid */
     if (rc) ABORT(S.last_error());
@@ -366,7 +386,21 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
         if (rc) ABORT(S.last_error());
         G.host_stale = 0;
         if (getenv("SLUAMD_BIND_DEBUG")) fprintf(stderr, "[sluamd_bind] copyback eager %.3f ms\n", 1e3 * (SuperLU_timer_() - t0));
-    } else if (getenv("SLUAMD_BIND_DEBUG")) fprintf(stderr, "[sluamd_bind] copyback deferred (factors stay on the device)\n");
+    } else {
+        static int warned = 0;
+        if (!warned && !getenv("SLUAMD_BIND_QUIET") && myrow + mycol + myz == 0) {
+            warned = 1;
+            fprintf(stderr, "[sluamd_bind] the factors stay on the device (deferred copy-back): LUstruct->Llu holds UNFACTORED values until "
+                            "sluamd_bind_%csync_host[_for]() is called; SLUAMD_BIND_COPYBACK=eager restores the reference's copy\n",
+#ifdef Z_PREC
+                    'z'
+#else
+                    'd'
+#endif
+                    );
+        }
+        if (getenv("SLUAMD_BIND_DEBUG")) fprintf(stderr, "[sluamd_bind] copyback deferred (factors stay on the device)\n");
+    }
     sluamd_stats_t st;
     S.stats(G.h, &st);
     if (getenv("SLUAMD_BIND_DEBUG")) {
@@ -408,6 +442,7 @@ static void bind_solve(int_t n, xScalePermstruct_t *SP, gridinfo3d_t *grid3d, bi
     if (n < 0) { *info = -1; return; }
     if (nrhs < 0) { *info = -9; return; }
     if (!G.h || G.n != n) ABORT("sluamd binding: the triangular solve was called without a factorisation on the device");
+    g_solve_seen = 1;                                                        /* the solves DO land here: later factorisations may defer their copy-back */
     if (nrhs == 0) return;
     static sluamd_int_t *perm = NULL; static int_t perm_n = -1;
     if (perm_n != n) { free(perm); perm = (sluamd_int_t *) malloc(sizeof(sluamd_int_t) * (size_t) (n ? n : 1)); perm_n = n; }

@@ -204,16 +204,23 @@ int_t WRAP(gstrf3d)(superlu_dist_options_t *options, int m, int n, double anorm,
 #endif
     extern int_t BIND_NAME(superlu_dist_options_t *, int, int, double, xtrf3Dpartition_t *, SCT_t *,
                            xLUstruct_t *, gridinfo3d_t *, SuperLUStat_t *, int *);
-    int_t r = BIND_NAME(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
 #ifdef Z_PREC
-#define BIND_SYNC_HOST sluamd_bind_zsync_host
+#define BIND_SYNC_HOST sluamd_bind_zsync_host_for
+#define BIND_SOLVES_BOUND sluamd_bind_zsolves_bound
 #else
-#define BIND_SYNC_HOST sluamd_bind_dsync_host
+#define BIND_SYNC_HOST sluamd_bind_dsync_host_for
+#define BIND_SOLVES_BOUND sluamd_bind_dsolves_bound
 #endif
-    extern int BIND_SYNC_HOST(void);
+    extern int BIND_SYNC_HOST(xLUstruct_t *, gridinfo3d_t *);
+    extern void BIND_SOLVES_BOUND(int);
+    /* this driver KNOWS at link time that its solve wrappers below forward to the library unless SLUAMD_BIND_SOLVE=0: it declares so, which is
+     * what lets the binding defer the copy-back (its default is the reference's eager copy) */
+    if (!getenv("SLUAMD_REFDUMP_NO_DECLARE"))    /* test hook: an integrator who wrapped the solves but never told the binding */
+        BIND_SOLVES_BOUND(!getenv("SLUAMD_BIND_SOLVE") || atoi(getenv("SLUAMD_BIND_SOLVE")));
+    int_t r = BIND_NAME(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
     /* lazy copy-back (SLUAMD_BIND_COPYBACK): this driver is a host consumer of the factors when it records them, and when the CPU
      * solves of a Z-replicated grid follow (dbroadcastAncestor3d reads the host panels right after this call) */
-    if (g_out || (getenv("SLUAMD_BIND_SOLVE") && !atoi(getenv("SLUAMD_BIND_SOLVE")))) BIND_SYNC_HOST();
+    if (g_out || (getenv("SLUAMD_BIND_SOLVE") && !atoi(getenv("SLUAMD_BIND_SOLVE")))) BIND_SYNC_HOST(LUstruct, grid3d);
 #else
     int_t r = REAL(gstrf3d)(options, m, n, anorm, part, SCT, LUstruct, grid3d, stat, info);
 #endif

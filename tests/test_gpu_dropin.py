@@ -199,10 +199,12 @@ def test_reference_pipeline_with_our_pzgstrf3d(kind, tmp_path):
 @pytest.mark.skipif(not (os.path.exists(AMD) and os.path.exists(REF) and os.path.exists(MPIEXEC)), reason="prebuilt reference binaries / mpiexec not available")
 @pytest.mark.parametrize("grid", [(1, 1, 1), (2, 2, 2)])
 def test_copyback_policy_of_the_binding(grid, tmp_path):
-    """SLUAMD_BIND_COPYBACK (replaces the unconditional dCopyLUGPU2Host of pdgssvx3d.c:1013-1021): with both solves bound the
-    factors stay on the device (default = lazy: no device-to-host copy at all, same residual as the eager run); eager copies after the
-    factorisation; lazy with the CPU solves (SLUAMD_BIND_SOLVE=0) copies on the first host consumer through sluamd_bind_dsync_host and the
-    reference's own solves then give the reference's residual."""
+    """SLUAMD_BIND_COPYBACK (replaces the unconditional dCopyLUGPU2Host of pdgssvx3d.c:1013-1021).  The binding's default is the reference's
+    eager copy (it cannot know at link time whether the solves were wrapped); it defers the copy only when the integrator DECLARED the
+    solves bound (sluamd_bind_dsolves_bound, which the test driver calls because it wraps them itself) or asked for it (=lazy): then no
+    device-to-host copy at all, same residual as the eager run; lazy with the CPU solves (SLUAMD_BIND_SOLVE=0) copies on the first host consumer
+    through sluamd_bind_dsync_host_for and the reference's own solves then give the reference's residual; an integrator who wrapped the solves
+    without declaring it gets the eager copy (correct, just slower)."""
     N = 14
     n, rp, ci, v = matgen.poisson3d(N)
     matgen.write_triplet_dat(str(tmp_path / "a.dat"), n, rp, ci, v)
@@ -212,8 +214,12 @@ def test_copyback_policy_of_the_binding(grid, tmp_path):
     dbg = {"SLUAMD_BIND_DEBUG": "1"}
     res_lazy, info_lazy = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dbg)
     assert "copyback deferred" in _last["stderr"] and "copyback eager" not in _last["stderr"] and "copyback on demand" not in _last["stderr"]
+    assert "factors stay on the device (deferred copy-back)" in _last["stderr"]      # the one-time warning of a deferred copy
     res_eager, info_eager = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dict(dbg, SLUAMD_BIND_COPYBACK="eager"))
     assert "copyback eager" in _last["stderr"] and "copyback deferred" not in _last["stderr"]
+    res_undecl, info_undecl = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dict(dbg, SLUAMD_REFDUMP_NO_DECLARE="1"))
+    assert "copyback eager" in _last["stderr"] and "copyback deferred" not in _last["stderr"]      # nobody said the solves are bound: the reference's copy
+    assert info_undecl == 0 and res_undecl < 1e-10
     # CPU solves: the default turns eager by itself; an explicit lazy is served by the sync call of the first host consumer
     res_cpu, info_cpu = _run(AMD, args, tmp_path, threads="1", nproc=P, extra_env=dict(dbg, SLUAMD_BIND_SOLVE="0"))
     assert "copyback eager" in _last["stderr"]
