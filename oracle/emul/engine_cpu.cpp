@@ -43,7 +43,7 @@ void diag_lu(hipStream_t, const DevTables &T, const int *nodes, int nn, int, int
         for (int j = 0; j < ns; ++j) {
             double p = A[j + (size_t) j * lda];
             if (replace_tiny && std::fabs(p) < thresh) { p = (p < 0) ? -thresh : thresh; A[j + (size_t) j * lda] = p; info[1] += 1; }
-            if (p == 0.0) info[0] = std::min(info[0], fst + j + 1);
+            if (p == 0.0) { info[0] = std::min(info[0], fst + j + 1); info[4] = std::max(info[4], fst + j + 1); }
             const double rinv = (p != 0.0) ? 1.0 / p : 1.0;
             for (int r = j + 1; r < ns; ++r) A[r + (size_t) j * lda] *= rinv;
             for (int c = j + 1; c < ns; ++c) {
@@ -906,7 +906,7 @@ static void zdiag_lu(const DevTables &T, const int *nodes, int nn, int replace_t
                 A[j + (size_t) j * lda] = p; info[1] += 1;
             }
             const bool zero = p == zc(0.0, 0.0);
-            if (zero) info[0] = std::min(info[0], fst + j + 1);
+            if (zero) { info[0] = std::min(info[0], fst + j + 1); info[4] = std::max(info[4], fst + j + 1); }
             const zc rinv = zero ? zc(1.0, 0.0) : z_div(zc(1.0, 0.0), p);
             for (int i = j + 1; i < ns; ++i) {
                 zc l = A[i + (size_t) j * lda];

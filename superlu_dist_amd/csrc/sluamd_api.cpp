@@ -329,9 +329,9 @@ int sluamd_pzgstrf3d(sluamd_handle_t h, double thresh, int *info)
 int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny)
 {
     if (!h) return SLUAMD_EINVAL;
-    int res[4];
+    int res[8];
     HIPCHK(hipMemcpy(res, h->H.d_info, sizeof(res), hipMemcpyDeviceToHost));
-    if (info) *info = (res[0] == 0x7fffffff) ? 0 : res[0];
+    if (info) *info = h->H.env.info_last ? res[4] : ((res[0] == 0x7fffffff) ? 0 : res[0]);
     if (tiny) *tiny = res[1];
     return 0;
 }

@@ -407,7 +407,7 @@ int run_factor(Handle *H, double thresh, int *info)
     HIPCHK(hipSetDevice(H->device));
     const Grid &g = H->grid;
     if (g.size() > 1 && !H->comm) { set_error("handle of a multi-rank grid has no communicator"); return SLUAMD_EINVAL; }
-    int init[4] = {0x7fffffff, 0, 0, 0};
+    int init[8] = {0x7fffffff, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(H->d_info, init, sizeof(init), hipMemcpyHostToDevice, H->stream));
     H->st.num_launches = 0; H->st.schur_launches = 0; H->st.schur_tiles = 0;
     H->profile = H->opt.verbose >= 2 || H->env.profile;
@@ -432,7 +432,7 @@ int run_factor(Handle *H, double thresh, int *info)
     }
     if (H->red_all) { HIPCHK(hipStreamWaitEvent(H->stream, H->red_all, 0)); H->red_events.clear(); }   // the last reduction's additions belong to the factorisation
     HIPCHK(hipEventRecord(H->ev1, H->stream));
-    int res[4];
+    int res[8];
     HIPCHK(hipMemcpyAsync(res, H->d_info, sizeof(res), hipMemcpyDeviceToHost, H->stream));
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
@@ -453,7 +453,9 @@ int run_factor(Handle *H, double thresh, int *info)
     H->st.t_exchange_ms = H->profile ? ev_sum(H->ev_xchg, H->ev_xchg_used) : 0.0;     // XY panel-exchange phases (inside t_panel_ms)
     H->st.t_reduce_ms = H->profile ? ev_sum(H->ev_red, H->ev_red_used) : 0.0;         // Z ancestor reduction
     H->st.tiny_pivots = res[1];
-    int linfo = (res[0] == 0x7fffffff) ? 0 : res[0];
+    // zero-pivot rule: the smallest column (the reference's DOCUMENTED meaning of info, pdgstrf2.c:493-497) or, SLUAMD_INFO_LAST=1, what its code leaves:
+    // each rank keeps the zero pivot it met last (Local_Dgstrf2 overwrites *info, :568-571; supernodes in elimination order), pdgstrf3d takes the MIN over ranks
+    int linfo = H->env.info_last ? res[4] : ((res[0] == 0x7fffffff) ? 0 : res[0]);
     int missing = res[2];
     if (g.size() > 1) {   // info = first zero pivot over the whole grid (MPI_Allreduce MIN, pdgstrf3d.c:388-392)
         int v[2] = {linfo ? linfo : 0x7fffffff, -missing};   // one collective for both, on the library's stream

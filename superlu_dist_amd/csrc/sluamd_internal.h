@@ -291,6 +291,7 @@ struct Handle {
         int big_util_pct = 50, big_min_cols = 96;   // SLUAMD_BIG_UTIL_PCT / SLUAMD_BIG_MIN_COLS: a supernode runs 128 x 128 tiles when it is at least this wide and its block pairs fill that share of them
         bool no_merge_tiles = false; // SLUAMD_NO_MERGE_TILES: every (L block, U block) pair keeps its own Schur tiles (round 3)
         bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
+        bool info_last = false;      // SLUAMD_INFO_LAST=1: `info` = the zero pivot met LAST on a rank (largest column; what pdgstrf2.c:568-571 leaves in *info), MIN over the ranks (pdgstrf3d.c:388-392); default: the first column
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
                                                    // profiles/r03_ab_dataflow_sweeps.txt; 1 = agent-scope fences; 2 = write-through x, no fences)
@@ -320,7 +321,7 @@ struct Handle {
     hipEvent_t red_all = nullptr;            // everything queued on rstream so far
     std::vector<hipEvent_t> ev_pool;        // look-ahead dependency events
     size_t ev_pool_used = 0;
-    int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks
+    int *d_info = nullptr;      // [0]=first zero pivot column (INT_MAX if none), [1]=tiny pivots, [2]=missing dest blocks, [3]=sink, [4]=last zero pivot column (0 if none)
     double *d_x = nullptr; int64_t x_cap = 0;
     double *d_xtmp = nullptr; int64_t xtmp_cap = 0;   // exchange staging of the distributed solve / ancestor reduction
     double *d_w = nullptr; int64_t w_cap = 0;         // second vector of the 1 x 1-layer sweeps (out-of-place diagonal solves: forward solution, backward accumulators)

@@ -49,7 +49,7 @@ __device__ __forceinline__ void pivot_fix(double *p, int col1based, int replace_
 {
     double v = *p;
     if (replace_tiny && fabs(v) < thresh) { v = (v < 0) ? -thresh : thresh; *p = v; atomicAdd(&info[1], 1); }
-    if (v == 0.0) atomicMin(&info[0], col1based);
+    if (v == 0.0) { atomicMin(&info[0], col1based); atomicMax(&info[4], col1based); }
     *s_piv = v;
 }
 
@@ -83,7 +83,7 @@ __device__ __forceinline__ double wave_pivot(double &acol, int j, int lane, int 
         if (lane == j) acol = p;
         if (lane == 0) atomicAdd(&info[1], 1);
     }
-    if (p == 0.0 && lane == 0) atomicMin(&info[0], col1based);
+    if (p == 0.0 && lane == 0) { atomicMin(&info[0], col1based); atomicMax(&info[4], col1based); }
     return (p != 0.0) ? pivot_recip(p) : 1.0;
 }
 

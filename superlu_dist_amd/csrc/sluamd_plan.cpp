@@ -1256,7 +1256,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     H->st.reserved_i = H->fused_pairs;   // K-fused supernode pairs (diagnostic)
     H->st.schur_tiles = 0;               // until the first factorisation: the PLANNED tile executions of one factorisation (list schedules)
     for (auto &S : H->sched) H->st.schur_tiles += (int64_t) S.ulist.size();
-    HIPCHK(hipMalloc((void **) &H->d_info, 4 * sizeof(int)));
+    HIPCHK(hipMalloc((void **) &H->d_info, 8 * sizeof(int)));
     rc = eng::setup();
     if (rc) return rc;
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;

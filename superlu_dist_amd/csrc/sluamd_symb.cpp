@@ -319,6 +319,9 @@ int sluamd_dsymbfact_unsym(sluamd_symb_t *out, int64_t n, const sluamd_int_t *ro
     if (maxsup < 1) maxsup = 256;
     if (maxsup > 512) maxsup = 512;  // MAX_SUPER_SIZE, superlu_defs.h:154
     if (relax < 1) relax = 1;
+    // relax_snode (symbfact.c:221-265) can build relaxed supernodes of up to `relax` columns whatever maxsup says; the handle's refinement takes
+    // supernodes of <= 512 columns: reject instead of producing a structure that cannot be factored
+    if (relax > 512) { set_error("sluamd_dsymbfact_unsym: relax > 512 (MAX_SUPER_SIZE) is not supported"); return SLUAMD_EINVAL; }
     std::vector<int> perm, parent;
     Graph g;
     static const bool timing = getenv("SLUAMD_SYMB_TIMING") != nullptr;
@@ -491,6 +494,9 @@ int sluamd_dsymbfact_unsym(sluamd_symb_t *out, int64_t n, const sluamd_int_t *ro
                     ++f;
                 }
                 ui[h0 + 1] = bn; unz += bn; ++nub; e = f;
+            }
+            if (unz > 0x7fffffffLL || ui.size() > 0x7fffffffULL) {   // the reference's 32-bit header words (Ufstnz[1], [2]); one block row above 2^31 values needs _LONGINT
+                set_error("sluamd_dsymbfact_unsym: a U block row holds more than 2^31 - 1 values"); delete sy; return SLUAMD_ESTRUCT;
             }
             ui[0] = nub; ui[1] = (int) unz; ui[2] = (int) ui.size();
             hs.uidx.insert(hs.uidx.end(), ui.begin(), ui.end());

@@ -331,6 +331,17 @@ def test_several_exact_zero_pivots_report_the_first_column():
         expected = min(int(symb.perm_c[z]) for z in (10, 41, 77)) + 1
         assert info == expected, (info, expected)
         h.destroy(); symb.free()
+    # SLUAMD_INFO_LAST=1: the rule the reference's CODE implements -- Local_Dgstrf2 overwrites *info at every zero pivot (pdgstrf2.c:568-571), so a rank
+    # keeps the one it met LAST in elimination order (here: the largest column), pdgstrf3d takes the MIN over the ranks (pdgstrf3d.c:388-392)
+    os.environ["SLUAMD_INFO_LAST"] = "1"
+    try:
+        symb = driver.Symbolic(n, rp, ci, perm, relax=4, maxsup=8)
+        h = driver.LUHandle.from_symbolic(symb, v)
+        info = h.pdgstrf3d(0.0)
+        assert info == max(int(symb.perm_c[z]) for z in (10, 41, 77)) + 1, info
+        h.destroy(); symb.free()
+    finally:
+        del os.environ["SLUAMD_INFO_LAST"]
 
 
 @pytest.mark.parametrize("kind", ["stencil_unsym", "random_unsym"])
