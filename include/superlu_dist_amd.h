@@ -162,6 +162,9 @@ int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, in
 void sluamd_dDestroyLUHandle(sluamd_handle_t h);
 
 int sluamd_get_stats(sluamd_handle_t h, sluamd_stats_t *out);
+/* wall-clock breakdown of the handle's creation as "phase=seconds;phase=seconds;..." (host planner phases, arena allocation, table uploads,
+ * distribution of A): the pre-processing a caller pays once per sparsity structure (pddistribute3d + the GPU handle set-up of the reference) */
+int sluamd_setup_times(sluamd_handle_t h, char *buf, int32_t cap);
 const char *sluamd_last_error(void);
 /* number of visible HIP devices (0 when none) -- lets callers fail loudly instead of falling back */
 int sluamd_device_count(void);

@@ -226,11 +226,14 @@ static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_
     if (hipGetDevice(&H->device) != hipSuccess) { set_error("hipGetDevice failed"); return fail(SLUAMD_EHIP); }
     SlotInput in;
     HostTables t;
+    H->setup.start();
     if ((rc = slots_from_symb(*H, *sy, g, sn_tree, in))) return fail(rc);
+    H->setup.lap("slots_from_symbolic");
     if ((rc = plan_and_upload(H, in, t))) return fail(rc);
     {   // device-side distribution of A's values (the arena is zero-filled)
         std::vector<int64_t> pos;
         if ((rc = scatter_positions(*H, *sy, t, rowptr, colind, perm_c_final, pos))) return fail(rc);
+        H->setup.lap("scatter_positions");
         const int w = z ? 2 : 1;   // doubles per value
         std::vector<int64_t> pos2; std::vector<double> val2;
         pos2.reserve(pos.size()); val2.reserve(pos.size() * w);
@@ -248,6 +251,7 @@ static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_
             else eng::scatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, nnz);
         }
         if (hipStreamSynchronize(H->stream) != hipSuccess) { set_error("distribution kernel failed"); return fail(SLUAMD_EHIP); }
+        H->setup.lap("values_upload_scatter");
     }
     *out = hh;
     return 0;
@@ -604,6 +608,16 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->red_all) hipEventDestroy(H->red_all);
     if (H->stream) hipStreamDestroy(H->stream);
     delete h;
+}
+
+int sluamd_setup_times(sluamd_handle_t h, char *buf, int32_t cap)
+{
+    if (!h || !buf || cap < 1) return SLUAMD_EINVAL;
+    std::string s;
+    for (auto &l : h->H.setup.laps) { char t[96]; snprintf(t, sizeof t, "%s%s=%.6f", s.empty() ? "" : ";", l.first.c_str(), l.second); s += t; }
+    if ((int) s.size() + 1 > cap) return SLUAMD_EINVAL;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
 }
 
 int sluamd_get_stats(sluamd_handle_t h, sluamd_stats_t *out)

@@ -8,6 +8,7 @@
 //
 // There is NO CPU fallback in the product library: every entry point fails when no HIP device is present.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,7 @@ namespace sluamd {
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
+double SetupTimer::now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 const std::string &get_error() { return g_err; }
 
 int check_device(int dev)

@@ -265,8 +265,18 @@ struct SplitMap {
 };
 
 
+// wall-clock laps of handle creation (sluamd_setup_times): where the pre-processing of a handle goes
+struct SetupTimer {
+    std::vector<std::pair<std::string, double>> laps;
+    double t_prev = -1.0;
+    static double now();
+    void start() { t_prev = now(); }
+    void lap(const char *what) { const double t = now(); if (t_prev < 0) t_prev = t; laps.emplace_back(what, t - t_prev); t_prev = t; }
+};
+
 struct Handle {
     int device = 0;
+    SetupTimer setup;
     sluamd_options_t opt{};
     HostStruct hs;
     Grid grid;

@@ -950,6 +950,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         in.lidx[k] = std::vector<int>(); in.uidx[k] = std::vector<int>();
     }
 
+    H->setup.lap("index_arenas");
     // ---- 2. DAG levels per Z level ----
     std::vector<std::vector<int>> lvl(nz);
     std::vector<int> nlev(nz, 0);
@@ -1102,9 +1103,11 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         }
     }
 
+    H->setup.lap("levels_layout_exchange_plan");
     // ---- 5. block tables, tiles ----
     int rc = build_tables(*H, t);
     if (rc) return rc;
+    H->setup.lap("block_tile_tables");
     if (xy_gemm_panels(*H)) {
         // Linv / Uinv stores.  The diagonal OWNER keeps its pair for the triangular solves; the row / column peers of a diagonal block need
         // theirs only between full_inv(l) and panel_gemm(l) of the block's own level -- two consecutive launches on the panel stream -- so all
@@ -1172,6 +1175,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         }
     }
     H->st.num_levels = nlevtot;
+    H->setup.lap("schedules_tile_lists_sweep_units");
     H->st.chain_levels = 0; H->st.chain_units = 0;
     for (auto &S : H->sched) if (S.chain_l0 >= 0) { H->st.chain_levels += S.nlevels - S.chain_l0; H->st.chain_units += (int64_t) S.cf_units.size() / 8; }
 
@@ -1189,6 +1193,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         return SLUAMD_ENOMEM;
     }
     HIPCHK(hipMemset(H->d_val, 0, esz * (size_t) H->arena_len));
+    H->setup.lap("arena_alloc_zero");
     if (H->env.reserve_cus > 0) {
         // keep `reserve_cus` compute units out of the main (Schur tile) stream: the panel kernels of the look-ahead stream then
         // always find a free CU (LDS for a whole TRSM strip / diagonal block) instead of waiting for a Schur workgroup to retire
@@ -1259,6 +1264,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     HIPCHK(hipMalloc((void **) &H->d_info, 8 * sizeof(int)));
     rc = eng::setup();
     if (rc) return rc;
+    H->setup.lap("table_uploads");
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     // everything this handle allocated on the device: the value arena, the inverse stores and every uploaded table (index images, block / tile
     // tables, tile lists, unit lists and records, pair maps; round 3 counted the index images only)

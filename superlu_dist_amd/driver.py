@@ -283,6 +283,18 @@ class LUHandle:
         _lib.load().sluamd_get_stats(self._h, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
 
+    def setup_times(self):
+        """{phase: seconds} of this handle's creation (sluamd_setup_times)"""
+        buf = C.create_string_buffer(4096)
+        if _lib.load().sluamd_setup_times(self._h, buf, 4096):
+            return {}
+        out = {}
+        for tok in buf.value.decode().split(";"):
+            if "=" in tok:
+                k, v = tok.split("=")
+                out[k] = out.get(k, 0.0) + float(v)
+        return out
+
     def destroy(self):
         if self._h:
             _lib.load().sluamd_dDestroyLUHandle(self._h)
