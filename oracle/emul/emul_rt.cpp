@@ -206,8 +206,20 @@ extern "C" void sluamd_emul_sched_stats(unsigned long long *run, unsigned long l
     *run = g_run; *reordered = g_reordered;
 }
 
-hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void *p) { hipDeviceSynchronize(); std::free(p); return hipSuccess; }
+// SLUAMD_EMUL_LAZY_ZERO=1 (planning / footprint runs of problems whose factors exceed this host's memory, scripts/setup_breakdown.py): allocations of
+// >= 256 MiB come from calloc -- untouched zero pages -- and the first whole-buffer hipMemset(0) of such a buffer is skipped, so that creating a handle
+// never touches the value arena.  Nothing else changes; a factorisation would still commit every page it writes.
+static std::map<const char *, size_t> g_fresh_zero;
+static bool lazy_zero() { static const bool on = getenv("SLUAMD_EMUL_LAZY_ZERO") != nullptr; return on; }
+hipError_t hipMalloc(void **p, size_t n)
+{
+    if (lazy_zero() && n >= ((size_t) 256 << 20)) {
+        *p = std::calloc(n, 1);
+        if (*p) { Guard lk; g_fresh_zero[(const char *) *p] = n; }
+    } else *p = std::malloc(n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void *p) { hipDeviceSynchronize(); { Guard lk; g_fresh_zero.erase((const char *) p); } std::free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned)
 {
     Guard lk;
@@ -235,6 +247,10 @@ hipError_t hipMemset(void *d, int v, size_t n)
 {
     Guard lk;
     flush(nullptr, blocking_empty);
+    if (v == 0 && !g_fresh_zero.empty()) {
+        auto it = g_fresh_zero.find((const char *) d);
+        if (it != g_fresh_zero.end()) { const bool whole = it->second <= n; g_fresh_zero.erase(it); if (whole) return hipSuccess; }
+    }
     if (n) std::memset(d, v, n);
     return hipSuccess;
 }

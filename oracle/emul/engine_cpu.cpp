@@ -111,15 +111,15 @@ static void row_trsm(double *x, int ns, int nsp, const double *dinv, TF tfun)
     (void) ns;
 }
 
-void panel_trsm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs, int)
+void panel_trsm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs, int, const int2 *units)
 {
     std::vector<double> x;
     for (int w = 0; w < nl + nu; ++w) {
         const bool lmode = w < nl;
         const int id = lmode ? w : w - nl;
-        const int ni = find_node(lmode ? lprefix : uprefix, nn, id);
-        const int k = nodes[ni];
-        const int strip = id - (lmode ? lprefix : uprefix)[ni];
+        const int ni = units ? 0 : find_node(lmode ? lprefix : uprefix, nn, id);
+        const int k = units ? units[w].x : nodes[ni];
+        const int strip = units ? units[w].y : id - (lmode ? lprefix : uprefix)[ni];
         const int klst = T.xsup[k + 1], ns = klst - T.xsup[k], nsp = (ns + DB - 1) & ~(DB - 1), nblk = nsp / DB;
         const int lda = T.sn_nsupr[k], ldd = T.sn_dlda[k];
         double *A = T.val + T.sn_lval[k];
@@ -158,15 +158,15 @@ void panel_trsm(hipStream_t, const DevTables &T, const int *nodes, const int *lp
     }
 }
 
-void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int)
+void panel_gemm(hipStream_t, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int, const int2 *units)
 {
     std::vector<double> x, o;
     for (int w = 0; w < nl + nu; ++w) {
         const bool lmode = w < nl;
         const int id = lmode ? w : w - nl;
-        const int ni = find_node(lmode ? lprefix : uprefix, nn, id);
-        const int k = nodes[ni];
-        const int strip = id - (lmode ? lprefix : uprefix)[ni];
+        const int ni = units ? 0 : find_node(lmode ? lprefix : uprefix, nn, id);
+        const int k = units ? units[w].x : nodes[ni];
+        const int strip = units ? units[w].y : id - (lmode ? lprefix : uprefix)[ni];
         const int klst = T.xsup[k + 1], ns = klst - T.xsup[k];
         const int lda = T.sn_nsupr[k];
         double *A = T.val + T.sn_lval[k];
@@ -759,14 +759,14 @@ void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *pr
     emul_enqueue(s, [=] { impl::diag_inv(s, T, nodes, prefix, nn, ntask); });
 }
 
-void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs, int max_nsupc)
+void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs, int max_nsupc, const int2 *units)
 {
-    emul_enqueue(s, [=] { impl::panel_trsm(s, T, nodes, lprefix, uprefix, nn, nl, nu, rs, max_nsupc); });
+    emul_enqueue(s, [=] { impl::panel_trsm(s, T, nodes, lprefix, uprefix, nn, nl, nu, rs, max_nsupc, units); });
 }
 
-void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc)
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc, const int2 *units)
 {
-    emul_enqueue(s, [=] { impl::panel_gemm(s, T, nodes, lprefix, uprefix, nn, nl, nu, max_nsupc); });
+    emul_enqueue(s, [=] { impl::panel_gemm(s, T, nodes, lprefix, uprefix, nn, nl, nu, max_nsupc, units); });
 }
 
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int prio,

@@ -171,7 +171,10 @@ static int scatter_positions(const Handle &H, const Symb &sy, const HostTables &
     pos.assign((size_t) rowptr[n], -1);
     // supernode of a column in the handle's (possibly refined: H.split) partition
     auto snode = [&](int col) { return H.split.active ? (int) (std::upper_bound(hs.xsup.begin(), hs.xsup.end(), col) - hs.xsup.begin()) - 1 : sy.supno[col]; };
-    for (int64_t i = 0; i < n; ++i)
+    // every entry of A finds its arena position on its own: rows in dynamic chunks over the planner's threads
+    std::atomic<int> err{0};     // 1: outside L, 2: outside U, 3: above the skyline
+    parallel_chunks(n, 8192, [&](int64_t i0, int64_t i1) {
+    for (int64_t i = i0; i < i1; ++i)
         for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
             const int pi = perm[i], pj = perm[colind[e]];
             const int s = snode(pj);
@@ -182,11 +185,11 @@ static int scatter_positions(const Handle &H, const Symb &sy, const HostTables &
                 const int o = t.sn_lb_off[s], nb = t.sn_nlb[s];
                 const int *dir = t.lbs_gid.data() + o;
                 const int *f = std::lower_bound(dir, dir + nb, ib);
-                if (f == dir + nb || *f != ib) { set_error("A entry outside the symbolic structure of L"); return SLUAMD_ESTRUCT; }
+                if (f == dir + nb || *f != ib) { err = 1; return; }
                 const int b = o + t.lbs_idx[o + (int) (f - dir)];
                 const int *rows = hs.lidx.data() + hs.lidx_off[s] + t.lb_lptr[b];
                 const int *fr = std::lower_bound(rows, rows + t.lb_nbrow[b], pi);
-                if (fr == rows + t.lb_nbrow[b] || *fr != pi) { fr = std::find(rows, rows + t.lb_nbrow[b], pi); if (fr == rows + t.lb_nbrow[b]) { set_error("A entry outside the symbolic structure of L"); return SLUAMD_ESTRUCT; } }
+                if (fr == rows + t.lb_nbrow[b] || *fr != pi) { fr = std::find(rows, rows + t.lb_nbrow[b], pi); if (fr == rows + t.lb_nbrow[b]) { err = 1; return; } }
                 pos[e] = hs.lval_off[s] + t.lb_rowoff[b] + (fr - rows) + (int64_t) (pj - hs.xsup[s]) * t.sn_nsupr[s];
             } else {                       // U(r, s), r = supernode of row pi
                 const int r = snode(pi);
@@ -194,13 +197,15 @@ static int scatter_positions(const Handle &H, const Symb &sy, const HostTables &
                 const int o = t.sn_ub_off[r], nb = t.sn_nub[r];
                 const int *dir = t.ub_gid.data() + o;
                 const int *f = std::lower_bound(dir, dir + nb, s);
-                if (f == dir + nb || *f != s) { set_error("A entry outside the symbolic structure of U"); return SLUAMD_ESTRUCT; }
+                if (f == dir + nb || *f != s) { err = 2; return; }
                 const int64_t ip = hs.uidx_off[r] + t.ub_iukp[o + (int) (f - dir)] + (pj - hs.xsup[s]);
                 const int fst = hs.uidx[ip];
-                if (pi < fst) { set_error("A entry above the skyline of U"); return SLUAMD_ESTRUCT; }
+                if (pi < fst) { err = 3; return; }
                 pos[e] = hs.uval_off[r] + t.ucolptr[ip] + (pi - fst);
             }
         }
+    });
+    if (err) { set_error(err == 1 ? "A entry outside the symbolic structure of L" : err == 2 ? "A entry outside the symbolic structure of U" : "A entry above the skyline of U"); return SLUAMD_ESTRUCT; }
     return 0;
 }
 

@@ -162,6 +162,19 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         ev_end(H, H->ev_panel, H->ev_panel_used, ps);
         H->st.num_launches += 1 + (inv_here ? 1 : 0) + (xy ? 2 : 0);
     };
+    // Split panel solves (LevelSched::ps_units, look-ahead schedule only): part 0 = the strips / chunks the level's part-0 tiles read, on the panel stream;
+    // part 1 = all the others, on the urgent-tile stream beside the next level's diagonal LU.  The GPU form of what the reference's look-ahead window does
+    // with its panel factorisations (dsparseTreeFactor_ASYNC, dtreeFactorization.c:381-470: the panels of the look-ahead supernodes first).
+    auto level_split = [&](int l) { return lookahead && !S.ps_off.empty() && S.ps_off[4 * l + 4] > S.ps_off[4 * l]; };
+    auto panelB_part = [&](hipStream_t st, int l, int part) {
+        const int mx = S.max_nsupc[l];
+        const int o0 = S.ps_off[4 * l + 2 * part], o1 = S.ps_off[4 * l + 2 * part + 1], o2 = S.ps_off[4 * l + 2 * part + 2];
+        const int nl = o1 - o0, nu = o2 - o1;
+        if (nl + nu == 0) return;
+        if (gemm_panels && !tail_level(l)) eng::panel_gemm(st, T, nullptr, nullptr, nullptr, 0, nl, nu, mx, S.d_ps_units + o0);
+        else eng::panel_trsm(st, T, nullptr, nullptr, nullptr, 0, nl, nu, 64, mx, S.d_ps_units + o0);
+        H->st.num_launches++;
+    };
     auto panelB = [&](int l) {
         const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
         const int *nodes = S.d_nodes + n0;
@@ -239,6 +252,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         hipEventRecord(e, on); hipStreamWaitEvent(waiter, e, 0);
         return e;
     };
+    hipEvent_t e_split_urgent = nullptr; // level l's panels were solved in two parts: the urgent part's event (the rest is queued on us)
     hipEvent_t e_u2_prev = nullptr;      // U2(l-1) done
     hipEvent_t e_bulk_prev = nullptr, e_bulk_prev2 = nullptr;   // bulk(l-1), bulk(l-2) done (stream order: and every earlier one)
     if (S.nlevels) { panelA(0); panelB(0); if (!lookahead && tail_level(0)) deferred_inv(s, 0); }
@@ -255,9 +269,20 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             if (rc_x) return rc_x;
             continue;
         }
-        hipEvent_t e_p = next_event(H);  // panel(l) done
-        hipEventRecord(e_p, ps);
-        hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);
+        if (e_split_urgent) {
+            // level l was solved in two parts: its urgent strips on ps (event e_split_urgent), the others on us, queued there already.  The part-0 tiles
+            // below follow the urgent strips in stream order; everything else needs both parts
+            hipStreamWaitEvent(us, e_split_urgent, 0);
+            hipEvent_t e_rest = next_event(H);
+            hipEventRecord(e_rest, us);
+            hipStreamWaitEvent(u2s, e_split_urgent, 0); hipStreamWaitEvent(u2s, e_rest, 0);
+            hipStreamWaitEvent(s, e_split_urgent, 0); hipStreamWaitEvent(s, e_rest, 0);
+            e_split_urgent = nullptr;
+        } else {
+            hipEvent_t e_p = next_event(H);  // panel(l) done
+            hipEventRecord(e_p, ps);
+            hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);
+        }
         if (tail_level(l)) deferred_inv(s, l);        // off the chain: the bulk stream waits for panel(l) anyway
         cur_pass = 0; list_launch(ps, l, 0, 0);   // on the panel stream itself: diag_lu(l+1) follows in stream order, no event hop
         cur_pass = 1; list_launch(us, l, 1, 1);
@@ -271,8 +296,17 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             if (e_bulk_prev2) hipStreamWaitEvent(ps, e_bulk_prev2, 0);
             if (xy && e_bulk_prev) hipStreamWaitEvent(ps, e_bulk_prev, 0);   // XY layer: the received panels of level l-1 share the scratch copy (level parity) that panel(l+1)'s exchange fills
             panelA(l + 1);
-            hipStreamWaitEvent(ps, e_u1, 0);
-            panelB(l + 1);
+            if (level_split(l + 1)) {
+                hipEvent_t e_pa = next_event(H); hipEventRecord(e_pa, ps);     // diagonal blocks (and inverses) of level l + 1 done
+                hipStreamWaitEvent(ps, e_u1, 0);
+                panelB_part(ps, l + 1, 0);                                     // urgent strips: what diag_lu(l + 2) waits for, through the part-0 tiles
+                e_split_urgent = next_event(H); hipEventRecord(e_split_urgent, ps);
+                hipStreamWaitEvent(us, e_pa, 0);                               // (after U1(l) in stream order; U2(l - 1) and the bulk of levels <= l - 2 through e_pa)
+                panelB_part(us, l + 1, 1);                                     // the other strips, beside diag_lu(l + 2)
+            } else {
+                hipStreamWaitEvent(ps, e_u1, 0);
+                panelB(l + 1);
+            }
         }
         e_u2_prev = e_u2; e_bulk_prev2 = e_bulk_prev; e_bulk_prev = e_bulk;
         if (rc_x) return rc_x;

@@ -202,6 +202,13 @@ struct LevelSched {
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> max_nsupc;     // per level
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
+    // Split panel solves (look-ahead schedule, 1 x 1 layers, real): per level the 64-row strips of L(:, k) / 64-column chunks of U(k, :) that the level's
+    // part-0 tiles (destination: a diagonal block of the next level) read -- "urgent": solved first, on the panel stream, so that the next level's diagonal
+    // LU starts after those strips and their tiles alone -- and all the others, solved beside that diagonal LU on the urgent-tile stream.
+    // ps_units: per split level [urgent L | urgent U | rest L | rest U]; ps_off[4 l .. 4 l + 4] its boundaries (equal: level not split)
+    std::vector<int2> ps_units;
+    std::vector<int> ps_off;        // [4*nlevels+1]
+    int2 *d_ps_units = nullptr;
     std::vector<int> sn_level;      // [nsupers] level of each supernode in this schedule (-1: not in it)
     std::vector<int4> ulist;        // tile lists (k, absolute row tile, absolute column tile, destination block or -1): per level and tile-size group
                                     // [diagonal blocks of level l+1 | rest of the level-(l+1) panels | level-(l+2) panels | bulk, 8 x 8 bands per supernode]
@@ -301,6 +308,7 @@ struct Handle {
         int big_util_pct = 50, big_min_cols = 96;   // SLUAMD_BIG_UTIL_PCT / SLUAMD_BIG_MIN_COLS: a supernode runs 128 x 128 tiles when it is at least this wide and its block pairs fill that share of them
         bool no_merge_tiles = false; // SLUAMD_NO_MERGE_TILES: every (L block, U block) pair keeps its own Schur tiles (round 3)
         bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
+        int panel_split_max_nodes = 1024;   // SLUAMD_PANEL_SPLIT: levels of at most this many supernodes solve their panels in two parts (urgent strips on the chain, the rest beside the next diagonal LU); 0 = off
         bool info_last = false;      // SLUAMD_INFO_LAST=1: `info` = the zero pivot met LAST on a rank (largest column; what pdgstrf2.c:568-571 leaves in *info), MIN over the ranks (pdgstrf3d.c:388-392); default: the first column
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
@@ -393,9 +401,11 @@ void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int ma
 void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int ntask);
 // L strips (work units [0, nl)) and U column strips ([nl, nl + nu)); strip height rs = 32 or 64
 void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu,
-                int rs, int max_nsupc);
+                int rs, int max_nsupc, const int2 *units = nullptr);
 // the same two panel solves as GEMMs with the full inverses T.inv (1 x 1 layers; 64-high work units)
-void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc);
+// units (both): explicit (supernode, strip / chunk) list [nl L units | nu U units] instead of the prefix arrays -- one part of a split panel solve
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc,
+                const int2 *units = nullptr);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
            const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0, int ksplit = 1 /* > 1: that many workgroups per tile, each a share of K (128 x 128 tiles) */);

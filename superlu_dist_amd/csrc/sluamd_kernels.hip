@@ -876,9 +876,15 @@ __device__ __forceinline__ void panel_trsm_body(const DevTables &T, int k, int s
 template <int RSv>
 __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *__restrict__ nodes,
                                                         const int *__restrict__ lprefix, const int *__restrict__ uprefix,
-                                                        int nn, int nl)
+                                                        int nn, int nl, const int2 *__restrict__ units)
 {
     extern __shared__ double sm[];
+    if (units) {   // explicit (supernode, strip) list [L strips | U chunks]: the urgent / remaining parts of a split panel solve (run_factor_sched)
+        const int2 u = units[blockIdx.x];
+        if ((int) blockIdx.x < nl) panel_trsm_body<0, RSv>(T, u.x, u.y, sm);
+        else panel_trsm_body<1, RSv>(T, u.x, u.y, sm);
+        return;
+    }
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
         panel_trsm_body<0, RSv>(T, nodes[ni], blockIdx.x - lprefix[ni], sm);
@@ -987,10 +993,16 @@ __device__ __forceinline__ void panel_gemm_wg(const DevTables &T, int k, int uni
 // (the same 64-high work units as k_panel_trsm<64>)
 template <int NQ>
 __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__restrict__ nodes, const int *__restrict__ lprefix,
-                                                    const int *__restrict__ uprefix, int nn, int nl)
+                                                    const int *__restrict__ uprefix, int nn, int nl, const int2 *__restrict__ units)
 {
     __builtin_amdgcn_s_setprio(3);   // panel chain: its waves go first when they share a SIMD with Schur tiles
     __shared__ double Ts[PG_LDS];
+    if (units) {   // explicit (supernode, 64-row / 64-column unit) list [L units | U units]: one part of a split panel solve
+        const int2 u = units[blockIdx.x];
+        if ((int) blockIdx.x < nl) panel_gemm_wg<0, NQ>(T, u.x, u.y, Ts);
+        else panel_gemm_wg<1, NQ>(T, u.x, u.y, Ts);
+        return;
+    }
     if ((int) blockIdx.x < nl) {
         const int ni = find_node(lprefix, nn, blockIdx.x);
         panel_gemm_wg<0, NQ>(T, nodes[ni], blockIdx.x - lprefix[ni], Ts);
@@ -2293,12 +2305,12 @@ void diag_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *pr
 }
 
 void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int rs,
-                int mx)
+                int mx, const int2 *units)
 {
     if (nl + nu <= 0) return;
     const size_t lds = trsm_lds_bytes(rs, (mx + 31) & ~31);
-    if (rs == 32) hipLaunchKernelGGL(k_panel_trsm<32>, dim3(nl + nu), dim3(128), lds, s, T, nodes, lprefix, uprefix, nn, nl);
-    else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nl + nu), dim3(256), lds, s, T, nodes, lprefix, uprefix, nn, nl);
+    if (rs == 32) hipLaunchKernelGGL(k_panel_trsm<32>, dim3(nl + nu), dim3(128), lds, s, T, nodes, lprefix, uprefix, nn, nl, units);
+    else hipLaunchKernelGGL(k_panel_trsm<64>, dim3(nl + nu), dim3(256), lds, s, T, nodes, lprefix, uprefix, nn, nl, units);
 }
 
 #define SCHUR_LAUNCH(TM, TN, NWV, ZV, THREADS) \
@@ -2322,12 +2334,12 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
     else SCHUR_LAUNCH(64, 64, 4, false, 256);
 }
 
-void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int mx)
+void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int mx, const int2 *units)
 {
     if (nl + nu <= 0) return;
-    if (mx <= 64) hipLaunchKernelGGL(k_panel_gemm<16>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
-    else if (mx <= 128) hipLaunchKernelGGL(k_panel_gemm<32>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
-    else hipLaunchKernelGGL(k_panel_gemm<64>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);
+    if (mx <= 64) hipLaunchKernelGGL(k_panel_gemm<16>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl, units);
+    else if (mx <= 128) hipLaunchKernelGGL(k_panel_gemm<32>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl, units);
+    else hipLaunchKernelGGL(k_panel_gemm<64>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl, units);
 }
 
 static const bool g_full_inv64 = getenv("SLUAMD_NO_FULL_INV64") == nullptr;

@@ -106,137 +106,193 @@ static int build_tables(Handle &H, HostTables &t)
     st.flops_schur_padded = st.flops_schur_exact = st.flops_panel = 0;
     st.schur_bytes_alg = 0;
     st.flops_schur_exact_big = st.schur_bytes_alg_big = 0;
-    for (int k = 0; k < ns; ++k) {
+    // Two passes over the supernodes, each embarrassingly parallel (a supernode's table entries depend on its own two index arrays only):
+    // count (and validate) -> serial prefix sums -> fill.  Pass 1 also settles the tile configuration (it needs the block sizes only).
+    struct SnCnt { int nb = 0, nsupr = 0, nub = 0, ncol = 0, ldu = 0, nrt = 0, nct = 0, ldiag = 0, fl = 0; double exact = 0; uint8_t big = 0; };
+    std::vector<SnCnt> cnt(ns);
+    std::atomic<int> ecode{0};
+    const char *emsg = nullptr;
+    auto fail = [&](const char *m, int code) { int z = 0; if (ecode.compare_exchange_strong(z, code)) emsg = m; return false; };
+    const int tmr_big = H.z ? 64 : 128;   // complex16: a tile is 64 / 32 panel rows (128 / 64 real rows of the embedding) x 128 / 64 columns
+    auto count_one = [&](int k) -> bool {
+        SnCnt &c = cnt[k];
+        if (!hs.present[k]) return true;
         const int nsupc = nsupc_of(hs, k), klst = hs.xsup[k + 1];
-        t.sn_lval[k] = hs.lval_off[k]; t.sn_uval[k] = hs.uval_off[k];
-        t.sn_lidx[k] = hs.lidx_off[k]; t.sn_uidx[k] = hs.uidx_off[k];
-        t.sn_lb_off[k] = (int) t.lb_gid.size(); t.sn_ub_off[k] = (int) t.ub_gid.size();
-        t.sn_rt_off[k] = (int) t.rtile.size(); t.sn_ct_off[k] = (int) t.ctile.size();
-        t.sn_dinv[k] = t.dinv_total; t.sn_inv[k] = t.inv_total;
-        t.sn_lrow[k] = (int64_t) t.lrow.size(); t.sn_ucol[k] = (int64_t) t.ucol_cp.size();
-        if (!hs.present[k]) continue;
-        H.max_nsupc = std::max(H.max_nsupc, nsupc);
-        if (nsupc > 256) { set_error("supernodes wider than 256 columns are not supported yet (set SUPERLU_MAXSUP <= 256)"); return SLUAMD_EINVAL; }
+        if (nsupc > 256) return fail("supernodes wider than 256 columns are not supported yet (set SUPERLU_MAXSUP <= 256)", SLUAMD_EINVAL);
         const bool l_own = g.kcol(k) == g.c, u_own = g.krow(k) == g.r;
-        int fl = 0;
-        if (l_own) fl |= SNF_L_OWN;
-        if (u_own) fl |= SNF_U_OWN;
-        if (l_own && u_own) fl |= SNF_OWN_DIAG;
-        if (l_own || u_own) fl |= SNF_HAS_DIAG;
-        t.sn_flags[k] = fl;
-        if (fl & SNF_HAS_DIAG) t.dinv_total += (int64_t) 2 * ((nsupc + 31) / 32) * 32 * 32;
-        if (fl & (xy_gemm ? SNF_HAS_DIAG : SNF_OWN_DIAG)) t.inv_total += (int64_t) 2 * nsupc * nsupc;   // Linv / Uinv: the diagonal owner (solve, panel solves); on an XY
-                                                                                                  // layer also the row / column peers (GEMM-form panel solves with the block they receive)
+        c.fl = (l_own ? SNF_L_OWN : 0) | (u_own ? SNF_U_OWN : 0) | ((l_own && u_own) ? SNF_OWN_DIAG : 0) | ((l_own || u_own) ? SNF_HAS_DIAG : 0);
         const int *li = hs.lidx.data() + hs.lidx_off[k];      // always >= BC_HEADER ints (empty slots carry {0, 0})
         const int nb = li[0], nsupr = li[1];
-        t.sn_nsupr[k] = nsupr;
-        t.sn_nlb[k] = nb;
+        c.nb = nb; c.nsupr = nsupr;
         const int ldiag = (u_own && nb > 0) ? nsupc : 0;      // the process row of k holds the diagonal block at the top of its part
-        t.sn_ldiag[k] = ldiag;
+        c.ldiag = ldiag;
         int p = BC_HEADER, rowoff = 0;
-        std::vector<std::pair<int, int>> dir;
+        long t128r = 0, t64r = 0;
         for (int b = 0; b < nb; ++b) {
             const int gid = li[p], nbrow = li[p + 1];
-            if (gid < k || gid >= ns || nbrow <= 0 || rowoff + nbrow > nsupr) { set_error("malformed L block"); return SLUAMD_ESTRUCT; }
-            if (g.krow(gid) != g.r) { set_error("L block stored on the wrong process row"); return SLUAMD_ESTRUCT; }
-            if (b == 0 && u_own && (gid != k || nbrow != nsupc)) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
-            if (b > 0 && gid == k) { set_error("diagonal block must be the first L block of its panel"); return SLUAMD_ESTRUCT; }
-            t.lb_gid.push_back(gid); t.lb_nbrow.push_back(nbrow); t.lb_rowoff.push_back(rowoff); t.lb_lptr.push_back(p + LB_DESCRIPTOR);
-            t.lrow.insert(t.lrow.end(), li + p + LB_DESCRIPTOR, li + p + LB_DESCRIPTOR + nbrow);
-            dir.emplace_back(gid, b);
+            if (gid < k || gid >= ns || nbrow <= 0 || rowoff + nbrow > nsupr) return fail("malformed L block", SLUAMD_ESTRUCT);
+            if (g.krow(gid) != g.r) return fail("L block stored on the wrong process row", SLUAMD_ESTRUCT);
+            if (b == 0 && u_own && (gid != k || nbrow != nsupc)) return fail("diagonal block must be the first L block of its panel", SLUAMD_ESTRUCT);
+            if (b > 0 && gid == k) return fail("diagonal block must be the first L block of its panel", SLUAMD_ESTRUCT);
+            if (b >= (ldiag ? 1 : 0)) { t128r += (nbrow + tmr_big - 1) / tmr_big; t64r += (nbrow + tmr_big / 2 - 1) / (tmr_big / 2); }
             rowoff += nbrow; p += LB_DESCRIPTOR + nbrow;
         }
-        if (rowoff != nsupr) { set_error("L panel row count mismatch"); return SLUAMD_ESTRUCT; }
-        {
-            const int *rw = t.lrow.data() + t.sn_lrow[k];
-            bool asc = true;
-            for (int i = 1; i < nsupr && asc; ++i) asc = rw[i - 1] < rw[i];
-            t.sn_rows_sorted[k] = asc ? 1 : 0;
-        }
-        if ((int64_t) nsupr * nsupc != hs.lval_len[k]) { set_error("L panel value count mismatch"); return SLUAMD_ESTRUCT; }
-        std::sort(dir.begin(), dir.end());
-        for (auto &d : dir) { t.lbs_gid.push_back(d.first); t.lbs_idx.push_back(d.second); }
-        // U block row
-        int nub = 0, ldu = 0, ncol_tot = 0;
-        double exact = 0;
+        if (rowoff != nsupr) return fail("L panel row count mismatch", SLUAMD_ESTRUCT);
+        if ((int64_t) nsupr * nsupc != hs.lval_len[k]) return fail("L panel value count mismatch", SLUAMD_ESTRUCT);
+        long t128c = 0, t64c = 0;
         if (hs.uidx_off[k + 1] > hs.uidx_off[k]) {
             const int *ui = hs.uidx.data() + hs.uidx_off[k];
-            int *cp = t.ucolptr.data() + hs.uidx_off[k];
-            int *nz = t.unzcol.data() + hs.uidx_off[k];
-            nub = ui[0];
+            c.nub = ui[0];
             int iukp = BR_HEADER; int64_t rukp = 0; int prev = k;
-            for (int b = 0; b < nub; ++b) {
+            for (int b = 0; b < c.nub; ++b) {
                 const int jb = ui[iukp];
-                if (jb <= prev || jb >= ns) { set_error("U blocks must be sorted by block column"); return SLUAMD_ESTRUCT; }
-                if (g.kcol(jb) != g.c) { set_error("U block stored on the wrong process column"); return SLUAMD_ESTRUCT; }
+                if (jb <= prev || jb >= ns) return fail("U blocks must be sorted by block column", SLUAMD_ESTRUCT);
+                if (g.kcol(jb) != g.c) return fail("U block stored on the wrong process column", SLUAMD_ESTRUCT);
                 prev = jb;
                 const int nsj = nsupc_of(hs, jb);
                 int nc = 0;
                 for (int jj = 0; jj < nsj; ++jj) {
                     const int seg = klst - ui[iukp + UB_DESCRIPTOR + jj];
-                    if (seg < 0 || seg > nsupc) { set_error("bad U segment"); return SLUAMD_ESTRUCT; }
+                    if (seg < 0 || seg > nsupc) return fail("bad U segment", SLUAMD_ESTRUCT);
+                    if (seg) { ++nc; rukp += seg; c.ldu = std::max(c.ldu, seg); c.exact += seg; }
+                }
+                c.ncol += nc;
+                t128c += (nc + 127) / 128; t64c += (nc + 63) / 64;
+                iukp += UB_DESCRIPTOR + nsj;
+            }
+            if (rukp != hs.uval_len[k]) return fail("U value count mismatch", SLUAMD_ESTRUCT);
+        }
+        const double cells = (double) (nsupr - ldiag) * c.ncol;
+        const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * tmr_big * 128.0) : 0.0;
+        c.big = nsupc >= (H.z ? 48 : H.env.big_min_cols) && util128 >= 0.01 * H.env.big_util_pct && !H.env.no_big_tiles;
+        c.nrt = (int) (c.big ? t128r : t64r); c.nct = (int) (c.big ? t128c : t64c);
+        return true;
+    };
+    parallel_chunks(ns, 256, [&](int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1 && !ecode; ++k) if (!count_one((int) k)) return; });
+    if (ecode) { set_error(emsg); return ecode; }
+    {   // offsets, totals and the statistics (summed in supernode order: the same values whatever the thread count)
+        int64_t lb = 0, ub = 0, rt = 0, ct = 0, lrow = 0, ucol = 0;
+        for (int k = 0; k < ns; ++k) {
+            const SnCnt &c = cnt[k];
+            const int nsupc = nsupc_of(hs, k);
+            t.sn_lval[k] = hs.lval_off[k]; t.sn_uval[k] = hs.uval_off[k];
+            t.sn_lidx[k] = hs.lidx_off[k]; t.sn_uidx[k] = hs.uidx_off[k];
+            if (std::max(std::max(lb, ub), std::max(rt, ct)) > 0x7fffffff) { set_error("block / tile tables too large for 32-bit offsets"); return SLUAMD_ESTRUCT; }
+            t.sn_lb_off[k] = (int) lb; t.sn_ub_off[k] = (int) ub; t.sn_rt_off[k] = (int) rt; t.sn_ct_off[k] = (int) ct;
+            t.sn_dinv[k] = t.dinv_total; t.sn_inv[k] = t.inv_total;
+            t.sn_lrow[k] = lrow; t.sn_ucol[k] = ucol;
+            if (!hs.present[k]) continue;
+            H.max_nsupc = std::max(H.max_nsupc, nsupc);
+            t.sn_flags[k] = c.fl;
+            if (c.fl & SNF_HAS_DIAG) t.dinv_total += (int64_t) 2 * ((nsupc + 31) / 32) * 32 * 32;
+            if (c.fl & (xy_gemm ? SNF_HAS_DIAG : SNF_OWN_DIAG)) t.inv_total += (int64_t) 2 * nsupc * nsupc;   // Linv / Uinv: the diagonal owner (solve, panel solves); on an XY
+                                                                                                        // layer also the row / column peers (GEMM-form panel solves with the block they receive)
+            t.sn_nsupr[k] = c.nsupr; t.sn_nlb[k] = c.nb; t.sn_ldiag[k] = c.ldiag;
+            t.sn_nub[k] = c.nub; t.sn_ldu[k] = c.ldu; t.sn_ncolu[k] = c.ncol;
+            t.sn_big[k] = c.big; t.sn_nrt[k] = c.nrt; t.sn_nct[k] = c.nct;
+            lb += c.nb; ub += c.nub; rt += c.nrt; ct += c.nct; lrow += c.nsupr; ucol += c.ncol;
+            const double rrows = c.nsupr - c.ldiag;
+            st.flops_schur_padded += 2.0 * rrows * c.ldu * c.ncol;
+            st.schur_bytes_alg += 16.0 * rrows * c.ncol;   // read-modify-write of every updated destination element
+            st.flops_schur_exact += 2.0 * rrows * c.exact;
+            t.sn_flops_exact[k] = 2.0 * rrows * c.exact; t.sn_bytes_alg[k] = 16.0 * rrows * c.ncol;      // attributed to a tile configuration once the K-fused groups are known (build_schedule)
+            if (c.fl & SNF_OWN_DIAG) st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc;
+            if (c.fl & SNF_L_OWN) st.flops_panel += (double) nsupc * nsupc * rrows;
+            if (c.fl & SNF_U_OWN) st.flops_panel += (double) nsupc * c.exact;
+        }
+        t.lb_gid.resize(lb); t.lb_nbrow.resize(lb); t.lb_rowoff.resize(lb); t.lb_lptr.resize(lb); t.lbs_gid.resize(lb); t.lbs_idx.resize(lb);
+        t.ub_gid.resize(ub); t.ub_ncols.resize(ub); t.ub_iukp.resize(ub); t.ub_stcol.resize(ub);
+        t.lrow.resize(lrow); t.ucol_cp.resize(ucol); t.ucol_ld.resize(ucol); t.ucol_gc.resize(ucol);
+        t.rtile.resize(rt); t.rt_info.resize(rt); t.ctile.resize(ct); t.ct_info.resize(ct);
+    }
+    auto fill_one = [&](int k, std::vector<std::pair<int, int>> &dir) -> bool {
+        if (!hs.present[k]) return true;
+        const SnCnt &c = cnt[k];
+        const int nsupc = nsupc_of(hs, k), klst = hs.xsup[k + 1];
+        const int *li = hs.lidx.data() + hs.lidx_off[k];
+        const int nb = c.nb, nsupr = c.nsupr, nub = c.nub, ldiag = c.ldiag;
+        const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k];
+        int *lrow = t.lrow.data() + t.sn_lrow[k];
+        int p = BC_HEADER, rowoff = 0;
+        dir.clear();
+        for (int b = 0; b < nb; ++b) {
+            const int gid = li[p], nbrow = li[p + 1];
+            t.lb_gid[lb0 + b] = gid; t.lb_nbrow[lb0 + b] = nbrow; t.lb_rowoff[lb0 + b] = rowoff; t.lb_lptr[lb0 + b] = p + LB_DESCRIPTOR;
+            std::copy(li + p + LB_DESCRIPTOR, li + p + LB_DESCRIPTOR + nbrow, lrow + rowoff);
+            dir.emplace_back(gid, b);
+            rowoff += nbrow; p += LB_DESCRIPTOR + nbrow;
+        }
+        {
+            bool asc = true;
+            for (int i = 1; i < nsupr && asc; ++i) asc = lrow[i - 1] < lrow[i];
+            t.sn_rows_sorted[k] = asc ? 1 : 0;
+        }
+        std::sort(dir.begin(), dir.end());
+        for (int b = 0; b < nb; ++b) { t.lbs_gid[lb0 + b] = dir[b].first; t.lbs_idx[lb0 + b] = dir[b].second; }
+        // U block row
+        int ncol_tot = 0;
+        if (nub) {
+            const int *ui = hs.uidx.data() + hs.uidx_off[k];
+            int *cp = t.ucolptr.data() + hs.uidx_off[k];
+            int *nz = t.unzcol.data() + hs.uidx_off[k];
+            int *ucp = t.ucol_cp.data() + t.sn_ucol[k], *uld = t.ucol_ld.data() + t.sn_ucol[k], *ugc = t.ucol_gc.data() + t.sn_ucol[k];
+            int iukp = BR_HEADER; int64_t rukp = 0;
+            for (int b = 0; b < nub; ++b) {
+                const int jb = ui[iukp];
+                const int nsj = nsupc_of(hs, jb);
+                int nc = 0;
+                for (int jj = 0; jj < nsj; ++jj) {
+                    const int seg = klst - ui[iukp + UB_DESCRIPTOR + jj];
                     cp[iukp + UB_DESCRIPTOR + jj] = (int) rukp;
                     if (seg) {
-                        t.ucol_cp.push_back((int) rukp); t.ucol_ld.push_back(nsupc - seg); t.ucol_gc.push_back(hs.xsup[jb] + jj);
-                        nz[iukp + UB_DESCRIPTOR + nc] = jj; ++nc; rukp += seg; ldu = std::max(ldu, seg); exact += seg;
+                        ucp[ncol_tot + nc] = (int) rukp; uld[ncol_tot + nc] = nsupc - seg; ugc[ncol_tot + nc] = hs.xsup[jb] + jj;
+                        nz[iukp + UB_DESCRIPTOR + nc] = jj; ++nc; rukp += seg;
                     }
                 }
-                t.ub_gid.push_back(jb); t.ub_ncols.push_back(nc); t.ub_iukp.push_back(iukp + UB_DESCRIPTOR); t.ub_stcol.push_back(ncol_tot);
+                t.ub_gid[ub0 + b] = jb; t.ub_ncols[ub0 + b] = nc; t.ub_iukp[ub0 + b] = iukp + UB_DESCRIPTOR; t.ub_stcol[ub0 + b] = ncol_tot;
                 ncol_tot += nc;
                 iukp += UB_DESCRIPTOR + nsj;
             }
-            if (rukp != hs.uval_len[k]) { set_error("U value count mismatch"); return SLUAMD_ESTRUCT; }
         }
-        t.sn_nub[k] = nub; t.sn_ldu[k] = ldu; t.sn_ncolu[k] = ncol_tot;
         {
             const int *gc = t.ucol_gc.data() + t.sn_ucol[k];
             bool asc = true;
             for (int i = 1; i < ncol_tot && asc; ++i) asc = gc[i - 1] < gc[i];
             t.sn_ucols_sorted[k] = asc ? 1 : 0;
         }
-        {   // tile configuration + tile lists of supernode k
-            const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k];
+        {   // tile lists of supernode k in its configuration
             const int bfirst = ldiag ? 1 : 0;
-            long t128r = 0, t128c = 0;
-            const int tmr_big = H.z ? 64 : 128;   // complex16: a tile is 64 / 32 panel rows (128 / 64 real rows of the embedding) x 128 / 64 columns
-            for (int b = bfirst; b < nb; ++b) t128r += (t.lb_nbrow[lb0 + b] + tmr_big - 1) / tmr_big;
-            for (int b = 0; b < nub; ++b) t128c += (t.ub_ncols[ub0 + b] + 127) / 128;
-            const double cells = (double) (nsupr - ldiag) * ncol_tot;
-            const double util128 = (t128r * t128c) ? cells / ((double) t128r * t128c * tmr_big * 128.0) : 0.0;
-            const bool big = nsupc >= (H.z ? 48 : H.env.big_min_cols) && util128 >= 0.01 * H.env.big_util_pct && !H.env.no_big_tiles;
-            t.sn_big[k] = big;
-            const int tm = big ? 128 : 64;
+            const int tm = c.big ? 128 : 64;
             const int tmr = H.z ? tm / 2 : tm;    // complex16: 64 (32) panel rows = 128 (64) real rows of the embedding
+            int rt = t.sn_rt_off[k], ct = t.sn_ct_off[k];
             for (int b = bfirst; b < nb; ++b) {
                 const int nbrow = t.lb_nbrow[lb0 + b], ro = t.lb_rowoff[lb0 + b];
-                for (int r0 = 0; r0 < nbrow; r0 += tmr) {
-                    t.rtile.push_back(make_int4(b, r0, std::min(tmr, nbrow - r0), ro + r0));
+                for (int r0 = 0; r0 < nbrow; r0 += tmr, ++rt) {
+                    t.rtile[rt] = make_int4(b, r0, std::min(tmr, nbrow - r0), ro + r0);
                     const int64_t lo = t.sn_lidx[k] + t.lb_lptr[lb0 + b] + r0;
-                    if (lo > 0x7fffffff) { set_error("index arena too large for 32-bit tile descriptors"); return SLUAMD_ESTRUCT; }
-                    t.rt_info.push_back(make_int2(t.lb_gid[lb0 + b], (int) lo));
+                    if (lo > 0x7fffffff) return fail("index arena too large for 32-bit tile descriptors", SLUAMD_ESTRUCT);
+                    t.rt_info[rt] = make_int2(t.lb_gid[lb0 + b], (int) lo);
                 }
             }
-            t.sn_nrt[k] = (int) t.rtile.size() - t.sn_rt_off[k];
             for (int b = 0; b < nub; ++b) {
                 const int nc = t.ub_ncols[ub0 + b];
-                for (int c0 = 0; c0 < nc; c0 += tm) {
-                    t.ctile.push_back(make_int4(b, c0, std::min(tm, nc - c0), 0));
+                for (int c0 = 0; c0 < nc; c0 += tm, ++ct) {
+                    t.ctile[ct] = make_int4(b, c0, std::min(tm, nc - c0), 0);
                     const int64_t uo = t.sn_uidx[k] + t.ub_iukp[ub0 + b];
-                    if (uo > 0x7fffffff) { set_error("index arena too large for 32-bit tile descriptors"); return SLUAMD_ESTRUCT; }
-                    t.ct_info.push_back(make_int4(t.ub_gid[ub0 + b], (int) uo, t.ub_stcol[ub0 + b] + c0, 0));
+                    if (uo > 0x7fffffff) return fail("index arena too large for 32-bit tile descriptors", SLUAMD_ESTRUCT);
+                    t.ct_info[ct] = make_int4(t.ub_gid[ub0 + b], (int) uo, t.ub_stcol[ub0 + b] + c0, 0);
                 }
             }
-            t.sn_nct[k] = (int) t.ctile.size() - t.sn_ct_off[k];
+            if (rt != t.sn_rt_off[k] + c.nrt || ct != t.sn_ct_off[k] + c.nct) return fail("internal: tile counts of the two table passes differ", SLUAMD_ESTRUCT);
         }
-        const double rrows = nsupr - ldiag;
-        st.flops_schur_padded += 2.0 * rrows * ldu * ncol_tot;
-        st.schur_bytes_alg += 16.0 * rrows * ncol_tot;   // read-modify-write of every updated destination element
-        st.flops_schur_exact += 2.0 * rrows * exact;
-        t.sn_flops_exact[k] = 2.0 * rrows * exact; t.sn_bytes_alg[k] = 16.0 * rrows * ncol_tot;      // attributed to a tile configuration once the K-fused groups are known (build_schedule)
-        if (fl & SNF_OWN_DIAG) st.flops_panel += (2.0 / 3.0) * nsupc * (double) nsupc * nsupc;
-        if (l_own) st.flops_panel += (double) nsupc * nsupc * rrows;
-        if (u_own) st.flops_panel += (double) nsupc * exact;
-    }
+        return true;
+    };
+    parallel_chunks(ns, 256, [&](int64_t k0, int64_t k1) {
+        std::vector<std::pair<int, int>> dir;
+        for (int64_t k = k0; k < k1 && !ecode; ++k) if (!fill_one((int) k, dir)) return;
+    });
+    if (ecode) { set_error(emsg); return ecode; }
+    H.setup.lap("tables.blocks_and_tiles");
     // ---- merged row tiles ----
     // The update L(ib, k) U(k, jb) of every block row ib >= jb lands in ONE destination panel (jb), and the rows of those blocks are contiguous in
     // the slot of k (blocks ascending): tiles may run across the block boundaries instead of ending with a ragged tile per block -- a 144-row
@@ -299,6 +355,7 @@ static int build_tables(Handle &H, HostTables &t)
                 }
             }
         }
+    H.setup.lap("tables.merged_tiles");
     if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; }   // complex multiply-add = 8 flop
     H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu; H.h_flags = t.sn_flags; H.h_ldiag = t.sn_ldiag;
     return 0;
@@ -328,7 +385,8 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
         const int *ra = hs.lidx.data() + hs.lidx_off[a] + t.lb_lptr[la + x], *rb = hs.lidx.data() + hs.lidx_off[b] + t.lb_lptr[lb + y];
         const int na = t.lb_nbrow[la + x], nb = t.lb_nbrow[lb + y];
         for (int i = 0; i < na; ++i) {
-            const int *f = std::find(rb, rb + nb, ra[i]);
+            const int *f = std::lower_bound(rb, rb + nb, ra[i]);                    // the rows of a block are ascending in every store the handle builds ...
+            if (f == rb + nb || *f != ra[i]) f = std::find(rb, rb + nb, ra[i]);     // ... (a caller's unsorted block: linear search)
             if (f == rb + nb) return false;
             rowmap[t.lb_rowoff[lb + y] + (int) (f - rb)] = t.lb_rowoff[la + x] + i;
         }
@@ -346,8 +404,8 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
         const int *ca = t.unzcol.data() + pa, *cb = t.unzcol.data() + pb;
         const int na = t.ub_ncols[ua + x], nb = t.ub_ncols[ub + y];
         for (int i = 0; i < na; ++i) {
-            const int *f = std::find(cb, cb + nb, ca[i]);
-            if (f == cb + nb) return false;
+            const int *f = std::lower_bound(cb, cb + nb, ca[i]);                    // non-empty columns of a U block: ascending by construction (build_tables)
+            if (f == cb + nb || *f != ca[i]) return false;
             const int c = t.ub_stcol[ub + y] + (int) (f - cb), jj = ca[i];
             colinfo[2 * c] = t.ucolptr[pa + jj];
             colinfo[2 * c + 1] = sa - (klst_a - hs.uidx[pa + jj]);
@@ -390,93 +448,102 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
     S.u_off.assign(8 * S.nlevels + 1, 0);
     const bool plan_debug = getenv("SLUAMD_PLAN_DEBUG") != nullptr;
     double dbg_exact[2] = {0, 0}, dbg_exec[2] = {0, 0}, dbg_full[2] = {0, 0}, dbg_tiles[2] = {0, 0};
-    std::vector<int8_t> cflag;
-    std::vector<int> dcache;
     struct Cand { int a, c, w; };
-    std::vector<Cand> cand, bulk;
-    std::vector<int4> bucket[4];
+    // per supernode, independent of every other one: its tiles in the four parts (parallel over the planner's threads, dynamic chunks -- a leaf has a
+    // handful of tiles, a supernode of the top separator tens of thousands), concatenated afterwards in schedule order
+    struct NodeTiles { std::vector<int4> part[4]; };
+    std::vector<NodeTiles> nt(S.nodes.size());
+    parallel_chunks((int64_t) S.nodes.size(), 16, [&](int64_t i0, int64_t i1) {
+        std::vector<int8_t> cflag;
+        std::vector<int> dcache;
+        std::vector<Cand> cand, bulk;
+        for (int64_t i = i0; i < i1; ++i) {
+            const int k = S.nodes[i], l = lvl[k];
+            std::vector<int4> *bucket = nt[i].part;
+            const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
+            if (!nrt || !nct) continue;
+            const bool deferred = !defer.empty() && defer[k];               // runs parts 0 and 1 only
+            const int r0 = t.sn_rt_off[k], c0 = t.sn_ct_off[k], nub = t.sn_nub[k], ub0 = t.sn_ub_off[k];
+            const int tmk = (t.sn_big[k] ? 128 : 64) / (zrows ? 2 : 1);
+            // the tiles of k as (absolute row tile, column tile) pairs: per column tile the block pairs' own row tiles, or -- where the U block
+            // has merged row tiles -- those for the block rows at and below the U block's supernode and the own tiles for the ones above it
+            cand.clear();
+            cflag.assign(nct, 0);   // 1: level l+1, 2: level l+2
+            for (int c = 0; c < nct; ++c) { const int d = lvl[t.ct_info[c0 + c].x] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; }
+            auto level_flag = [&](int a) { const int d = lvl[t.rt_info[a].x] - l; return (int8_t) ((d == 1 || d == 2) ? d : 0); };
+            auto col_flag = [&](int c) { if (c >= 0 && c < nct) return cflag[c]; const int d = lvl[t.ct_info[c0 + c].x] - l; return (int8_t) ((d == 1 || d == 2) ? d : 0); };
+            const int lb0 = t.sn_lb_off[k];
+            for (int c = 0; c < nct; ++c) {
+                const int ub = ub0 + t.ctile[c0 + c].x, jb = t.ct_info[c0 + c].x;
+                const int mcnt = t.ub_mrt_cnt.empty() ? 0 : t.ub_mrt_cnt[ub];
+                for (int r = 0; r < nrt; ++r) {
+                    const int ib = t.rt_info[r0 + r].x;
+                    if (ib >= jb) { if (mcnt) continue; }                                                         // covered by the merged ROW tiles of this U block
+                    else if (!t.lb_mct_cnt.empty() && t.lb_mct_cnt[lb0 + t.rtile[r0 + r].x]) continue;           // covered by the merged COLUMN tiles of this L block
+                    cand.push_back({r0 + r, c, t.rtile[r0 + r].w});
+                }
+                for (int m = 0; m < mcnt; ++m) cand.push_back({t.ub_mrt_off[ub] + m, c, t.rtile[t.ub_mrt_off[ub] + m].w});
+            }
+            if (!t.lb_mct_cnt.empty())
+                for (int r = 0; r < nrt; ++r) {
+                    const int lb = lb0 + t.rtile[r0 + r].x;
+                    for (int m = 0; m < t.lb_mct_cnt[lb]; ++m) cand.push_back({r0 + r, t.lb_mct_off[lb] + m - c0, t.rtile[r0 + r].w});     // column index relative to c0 (beyond nct)
+                }
+            dcache.assign((size_t) t.sn_nlb[k] * std::max(nub, 1), -2);
+            auto entry = [&](const Cand &q) {
+                const bool merged = q.a < r0 || q.a >= r0 + nrt;
+                int d = -3;                                                   // merged rows: the destination panel is searched row by row
+                if (q.c < 0 || q.c >= nct) d = -4;                            // merged columns: the destination U row is searched column by column
+                else if (!merged) {
+                    int &dc = dcache[(size_t) t.rtile[q.a].x * nub + t.ctile[c0 + q.c].x];
+                    if (dc == -2) dc = dest_block(t, t.rt_info[q.a].x, t.ct_info[c0 + q.c].x);
+                    d = dc;
+                }
+                return make_int4(k, q.a, c0 + q.c, d);
+            };
+            std::sort(cand.begin(), cand.end(), [&](const Cand &x, const Cand &y) { return x.w != y.w ? x.w < y.w : x.c < y.c; });
+            bulk.clear();
+            for (auto &q : cand) {
+                const int8_t rf = level_flag(q.a);
+                const int8_t cf = col_flag(q.c);
+                if (!(rf || cf)) { if (!deferred) bulk.push_back(q); continue; }
+                const bool next = rf == 1 || cf == 1;          // feeds a level-(l+1) panel
+                if (!next) { if (!deferred) bucket[2].push_back(entry(q)); continue; }
+                const bool diag = t.rt_info[q.a].x == t.ct_info[c0 + q.c].x;      // (holds rows of) the diagonal block of a level-(l+1) supernode
+                bucket[diag ? 0 : 1].push_back(entry(q));
+            }
+            // the bulk: bands of 8 row tiles' worth of slot rows, column tile after column tile inside a band
+            std::stable_sort(bulk.begin(), bulk.end(), [&](const Cand &x, const Cand &y) {
+                const int bx = x.w / (8 * tmk), by = y.w / (8 * tmk);
+                if (bx != by) return bx < by;
+                if (x.c != y.c) return x.c < y.c;
+                return x.w < y.w; });
+            for (auto &q : bulk) bucket[3].push_back(entry(q));
+        }
+    });
+    {
+        size_t tot = 0;
+        for (auto &q : nt) for (auto &v : q.part) tot += v.size();
+        S.ulist.reserve(S.ulist.size() + tot);
+    }
     for (int l = 0; l < S.nlevels; ++l) {
         const int nbig = S.n_big[l];
         for (int g = 0; g < 2; ++g) {
-            for (auto &bk : bucket) bk.clear();
             const int b = S.lvl_off[l] + (g == 0 ? 0 : nbig), e = (g == 0) ? S.lvl_off[l] + nbig : S.lvl_off[l + 1];
-            for (int i = b; i < e; ++i) {
-                const int k = S.nodes[i];
-                const int nrt = t.sn_nrt[k], nct = t.sn_nct[k];
-                if (!nrt || !nct) continue;
-                const bool deferred = !defer.empty() && defer[k];               // runs parts 0 and 1 only
-                const int r0 = t.sn_rt_off[k], c0 = t.sn_ct_off[k], nub = t.sn_nub[k], ub0 = t.sn_ub_off[k];
-                const int tmk = (t.sn_big[k] ? 128 : 64) / (zrows ? 2 : 1);
-                // the tiles of k as (absolute row tile, column tile) pairs: per column tile the block pairs' own row tiles, or -- where the U block
-                // has merged row tiles -- those for the block rows at and below the U block's supernode and the own tiles for the ones above it
-                cand.clear();
-                cflag.assign(nct, 0);   // 1: level l+1, 2: level l+2
-                for (int c = 0; c < nct; ++c) { const int d = lvl[t.ct_info[c0 + c].x] - l; cflag[c] = (d == 1 || d == 2) ? d : 0; }
-                auto level_flag = [&](int a) { const int d = lvl[t.rt_info[a].x] - l; return (int8_t) ((d == 1 || d == 2) ? d : 0); };
-                auto col_flag = [&](int c) { if (c >= 0 && c < nct) return cflag[c]; const int d = lvl[t.ct_info[c0 + c].x] - l; return (int8_t) ((d == 1 || d == 2) ? d : 0); };
-                const int lb0 = t.sn_lb_off[k];
-                for (int c = 0; c < nct; ++c) {
-                    const int ub = ub0 + t.ctile[c0 + c].x, jb = t.ct_info[c0 + c].x;
-                    const int mcnt = t.ub_mrt_cnt.empty() ? 0 : t.ub_mrt_cnt[ub];
-                    for (int r = 0; r < nrt; ++r) {
-                        const int ib = t.rt_info[r0 + r].x;
-                        if (ib >= jb) { if (mcnt) continue; }                                                         // covered by the merged ROW tiles of this U block
-                        else if (!t.lb_mct_cnt.empty() && t.lb_mct_cnt[lb0 + t.rtile[r0 + r].x]) continue;           // covered by the merged COLUMN tiles of this L block
-                        cand.push_back({r0 + r, c, t.rtile[r0 + r].w});
-                    }
-                    for (int m = 0; m < mcnt; ++m) cand.push_back({t.ub_mrt_off[ub] + m, c, t.rtile[t.ub_mrt_off[ub] + m].w});
-                }
-                if (!t.lb_mct_cnt.empty())
-                    for (int r = 0; r < nrt; ++r) {
-                        const int lb = lb0 + t.rtile[r0 + r].x;
-                        for (int m = 0; m < t.lb_mct_cnt[lb]; ++m) cand.push_back({r0 + r, t.lb_mct_off[lb] + m - c0, t.rtile[r0 + r].w});     // column index relative to c0 (beyond nct)
-                    }
-                dcache.assign((size_t) t.sn_nlb[k] * std::max(nub, 1), -2);
-                auto entry = [&](const Cand &q) {
-                    const bool merged = q.a < r0 || q.a >= r0 + nrt;
-                    int d = -3;                                                   // merged rows: the destination panel is searched row by row
-                    if (q.c < 0 || q.c >= nct) d = -4;                            // merged columns: the destination U row is searched column by column
-                    else if (!merged) {
-                        int &dc = dcache[(size_t) t.rtile[q.a].x * nub + t.ctile[c0 + q.c].x];
-                        if (dc == -2) dc = dest_block(t, t.rt_info[q.a].x, t.ct_info[c0 + q.c].x);
-                        d = dc;
-                    }
-                    return make_int4(k, q.a, c0 + q.c, d);
-                };
-                std::sort(cand.begin(), cand.end(), [&](const Cand &x, const Cand &y) { return x.w != y.w ? x.w < y.w : x.c < y.c; });
-                bulk.clear();
-                for (auto &q : cand) {
-                    const int8_t rf = level_flag(q.a);
-                    const int8_t cf = col_flag(q.c);
-                    if (!(rf || cf)) { if (!deferred) bulk.push_back(q); continue; }
-                    const bool next = rf == 1 || cf == 1;          // feeds a level-(l+1) panel
-                    if (!next) { if (!deferred) bucket[2].push_back(entry(q)); continue; }
-                    const bool diag = t.rt_info[q.a].x == t.ct_info[c0 + q.c].x;      // (holds rows of) the diagonal block of a level-(l+1) supernode
-                    bucket[diag ? 0 : 1].push_back(entry(q));
-                }
-                // the bulk: bands of 8 row tiles' worth of slot rows, column tile after column tile inside a band
-                std::stable_sort(bulk.begin(), bulk.end(), [&](const Cand &x, const Cand &y) {
-                    const int bx = x.w / (8 * tmk), by = y.w / (8 * tmk);
-                    if (bx != by) return bx < by;
-                    if (x.c != y.c) return x.c < y.c;
-                    return x.w < y.w; });
-                for (auto &q : bulk) bucket[3].push_back(entry(q));
-            }
-            if (plan_debug)
-                for (int part = 0; part < 4; ++part)
-                    for (auto &u : bucket[part]) {       // executed MFMA area (in the granularity at which idle waves skip) against the useful area, weighted by the source width
+            for (int part = 0; part < 4; ++part) {
+                const size_t first = S.ulist.size();
+                for (int i = b; i < e; ++i) S.ulist.insert(S.ulist.end(), nt[i].part[part].begin(), nt[i].part[part].end());
+                S.u_off[(2 * l + g) * 4 + part + 1] = (int) S.ulist.size();
+                if (plan_debug)
+                    for (size_t q = first; q < S.ulist.size(); ++q) {       // executed MFMA area (in the granularity at which idle waves skip) against the useful area, weighted by the source width
+                        const int4 u = S.ulist[q];
                         const int nr = t.rtile[u.y].z, nc = t.ctile[u.z].z;
-                        const double kw = S.sn_level.empty() ? 1.0 : 1.0;
                         const int ksz = (int) (t.sn_ldu[u.x]);
-                        (void) kw;
                         dbg_exact[g] += (double) nr * nc * ksz;
                         dbg_exec[g] += (g == 0 ? (double) ((nr + 31) / 32 * 32) * ((nc + 63) / 64 * 64) : (double) ((nr + 31) / 32 * 32) * ((nc + 31) / 32 * 32)) * ksz;
                         dbg_full[g] += (g == 0 ? 128.0 * 128.0 : 64.0 * 64.0) * ksz;
                         dbg_tiles[g] += 1;
                     }
-            for (int part = 0; part < 4; ++part) {
-                S.ulist.insert(S.ulist.end(), bucket[part].begin(), bucket[part].end());
-                S.u_off[(2 * l + g) * 4 + part + 1] = (int) S.ulist.size();
             }
         }
     }
@@ -485,6 +552,66 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
             fprintf(stderr, "[sluamd_plan] tile lists, %s configuration: %.0f tiles, useful area x K %.4g, executed (wave-skip granularity) %.4g = %.3f x, full tiles %.4g = %.3f x\n",
                     g == 0 ? "128 x 128" : "64 x 64", dbg_tiles[g], dbg_exact[g], dbg_exec[g], dbg_exact[g] > 0 ? dbg_exec[g] / dbg_exact[g] : 0.0, dbg_full[g],
                     dbg_exact[g] > 0 ? dbg_full[g] / dbg_exact[g] : 0.0);
+}
+
+// Split panel solves (LevelSched::ps_units): per level the strips of L(:, k) / chunks of U(k, :) its part-0 tiles read.  Derived from the tile lists
+// themselves -- merged row / column tiles run across block boundaries, so "the rows of the blocks whose supernode is in the next level" would miss rows.
+// Levels that are split: 1 x 1 layers, real arithmetic, 64-high units, not the first level (its panels are solved before the loop) nor the last (no
+// successor to hurry for), at most SLUAMD_PANEL_SPLIT supernodes, and at least one strip on each side of the cut.
+static void build_panel_split(const Handle &H, const HostTables &t, LevelSched &S)
+{
+    S.ps_units.clear();
+    S.ps_off.assign(4 * (size_t) S.nlevels + 1, 0);
+    const bool eligible = H.grid.Pr * H.grid.Pc == 1 && !H.z && !H.opt.deterministic && H.env.panel_split_max_nodes > 0 && !H.env.trsm_panels;
+    std::vector<uint8_t> lurg, uurg;
+    std::vector<int> loff, uoff;     // per node of the level: first strip / chunk in lurg / uurg
+    std::vector<int> idx_of(H.hs.nsupers, -1);   // position of a supernode inside its level
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0;
+        const size_t base = S.ps_units.size();
+        bool split = eligible && l > 0 && l + 1 < S.nlevels && nn <= H.env.panel_split_max_nodes && trsm_rs(H, (S.max_nsupc[l] + 31) & ~31) == 64;
+        if (split) {
+            loff.assign(nn + 1, 0); uoff.assign(nn + 1, 0);
+            for (int i = 0; i < nn; ++i) {
+                const int k = S.nodes[n0 + i];
+                idx_of[k] = i;
+                loff[i + 1] = loff[i] + (t.sn_nsupr[k] - t.sn_ldiag[k] + 63) / 64;
+                uoff[i + 1] = uoff[i] + (t.sn_ncolu[k] + 63) / 64;
+            }
+            lurg.assign(loff[nn], 0); uurg.assign(uoff[nn], 0);
+            for (int g = 0; g < 2; ++g)
+                for (int u = S.u_off[(2 * l + g) * 4]; u < S.u_off[(2 * l + g) * 4 + 1]; ++u) {      // part 0 of the level's two tile-size groups
+                    const int4 e = S.ulist[u];
+                    const int k = e.x;
+                    const int idx = idx_of[k];
+                    const int4 rt = t.rtile[e.y], ct = t.ctile[e.z];
+                    const int r0 = rt.w - t.sn_ldiag[k], r1 = r0 + rt.z - 1;                          // slot rows below the diagonal block
+                    for (int s = r0 / 64; s <= r1 / 64; ++s) lurg[loff[idx] + s] = 1;
+                    const int c0 = t.ct_info[e.z].z, c1 = c0 + ct.z - 1;                               // ranks among the non-empty columns of U(k, :)
+                    for (int c = c0 / 64; c <= c1 / 64; ++c) uurg[uoff[idx] + c] = 1;
+                }
+            size_t nu_l = 0, nu_u = 0;
+            for (uint8_t f : lurg) nu_l += f;
+            for (uint8_t f : uurg) nu_u += f;
+            if (nu_l + nu_u == 0 || nu_l + nu_u == lurg.size() + uurg.size()) split = false;         // nothing to hurry for, or nothing left to defer
+        }
+        if (split)
+            for (int part = 0; part < 2; ++part) {            // [urgent L | urgent U | rest L | rest U]
+                for (int i = 0; i < nn; ++i)
+                    for (int s = loff[i]; s < loff[i + 1]; ++s) if ((lurg[s] != 0) == (part == 0)) S.ps_units.push_back(make_int2(S.nodes[n0 + i], s - loff[i]));
+                S.ps_off[4 * l + 2 * part + 1] = (int) S.ps_units.size();
+                for (int i = 0; i < nn; ++i)
+                    for (int c = uoff[i]; c < uoff[i + 1]; ++c) if ((uurg[c] != 0) == (part == 0)) S.ps_units.push_back(make_int2(S.nodes[n0 + i], c - uoff[i]));
+                S.ps_off[4 * l + 2 * part + 2] = (int) S.ps_units.size();
+            }
+        else for (int q = 1; q <= 4; ++q) S.ps_off[4 * l + q] = (int) base;
+        if (l + 1 < S.nlevels) S.ps_off[4 * (l + 1)] = S.ps_off[4 * l + 4];
+    }
+    if (getenv("SLUAMD_PLAN_DEBUG")) {
+        int nsplit = 0; int64_t urg = 0, rest = 0;
+        for (int l = 0; l < S.nlevels; ++l) if (S.ps_off[4 * l + 4] > S.ps_off[4 * l]) { ++nsplit; urg += S.ps_off[4 * l + 2] - S.ps_off[4 * l]; rest += S.ps_off[4 * l + 4] - S.ps_off[4 * l + 2]; }
+        fprintf(stderr, "[sluamd_plan] split panel solves: %d of %d levels, %lld urgent / %lld other 64-high units\n", nsplit, S.nlevels, (long long) urg, (long long) rest);
+    }
 }
 
 // Dataflow unit lists of the sweeps over the top of the schedule (LevelSched::chain_l0 ...): the levels from the first one
@@ -681,6 +808,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
         }
         S.du_off[l + 1] = (int) S.diag_units.size();
     }
+    H.setup.lap("sched.prefixes_sweep_units");
     build_chain(H, t, lvl, S);
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
     // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
@@ -725,7 +853,10 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             }
         }
     }
+    H.setup.lap("sched.fused_pair_maps");
     build_tile_lists(t, lvl, H.h_defer, S, H.z);
+    H.setup.lap("sched.tile_lists");
+    build_panel_split(H, t, S);
     // by-configuration accounting: a supernode's Schur flops run in ITS tile configuration, except a deferred (K-fused) one's, whose update is applied by
     // the tiles of the first non-deferred successor of its chain (the few urgent tiles it runs itself are counted there too)
     for (int k : list) {
@@ -861,6 +992,8 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
     if (upload(H.d_misc, S.fwd_units, &S.d_fwd_units)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.bwd_units, &S.d_bwd_units)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.diag_units, &S.d_diag_units)) return SLUAMD_EHIP;
+    if (!S.ps_units.empty() && upload(H.d_misc, S.ps_units, &S.d_ps_units)) return SLUAMD_EHIP;
+    H.setup.lap("upload.schedule_lists");
     if (!H.z) {
         // unit records (k_sweep / k_fwd_update / k_bwd_update): the scalars of every unit in the order of the unit lists
         const HostStruct &hs = H.hs;
@@ -886,6 +1019,7 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
         }
         if (upload(H.d_misc, S.fwd_recs, &S.d_fwd_recs) || upload(H.d_misc, S.bwd_recs, &S.d_bwd_recs) || upload(H.d_misc, S.diag_recs, &S.d_diag_recs)) return SLUAMD_EHIP;
         std::vector<int4>().swap(S.fwd_recs); std::vector<int4>().swap(S.bwd_recs); std::vector<int4>().swap(S.diag_recs);
+        H.setup.lap("upload.sweep_unit_records");
         S.join = false;
         if (H.grid.Pr * H.grid.Pc == 1 && H.env.solve_join && !H.h_lrow_near.empty()) {
             const std::vector<uint8_t> keep_l = H.h_lrow_near, keep_u = H.h_ucol_near;
@@ -895,6 +1029,7 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
                     upload(H.d_misc, S.jb_aux, &S.d_jb_aux) || upload(H.d_misc, S.jfu_recs, &S.d_jfu_recs) || upload(H.d_misc, S.jbu_recs, &S.d_jbu_recs)) return SLUAMD_EHIP;
             } else { H.h_lrow_near = keep_l; H.h_ucol_near = keep_u; }
             for (auto *v : {&S.jf_recs, &S.jf_aux, &S.jb_recs, &S.jb_aux, &S.jfu_recs, &S.jbu_recs}) std::vector<int4>().swap(*v);
+            H.setup.lap("upload.joined_sweep_tables");
         }
     }
     if (S.chain_l0 >= 0) {
@@ -1107,7 +1242,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     // ---- 5. block tables, tiles ----
     int rc = build_tables(*H, t);
     if (rc) return rc;
-    H->setup.lap("block_tile_tables");
+    H->setup.lap("tables.rest");
     if (xy_gemm_panels(*H)) {
         // Linv / Uinv stores.  The diagonal OWNER keeps its pair for the triangular solves; the row / column peers of a diagonal block need
         // theirs only between full_inv(l) and panel_gemm(l) of the block's own level -- two consecutive launches on the panel stream -- so all
@@ -1175,7 +1310,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         }
     }
     H->st.num_levels = nlevtot;
-    H->setup.lap("schedules_tile_lists_sweep_units");
+    H->setup.lap("sched.rest");
     H->st.chain_levels = 0; H->st.chain_units = 0;
     for (auto &S : H->sched) if (S.chain_l0 >= 0) { H->st.chain_levels += S.nlevels - S.chain_l0; H->st.chain_units += (int64_t) S.cf_units.size() / 8; }
 
@@ -1244,6 +1379,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     UP(lrow, t.lrow, int) UP(sn_lrow, t.sn_lrow, int64_t) UP(ucol_cp, t.ucol_cp, int) UP(ucol_ld, t.ucol_ld, int) UP(ucol_gc, t.ucol_gc, int) UP(sn_ucol, t.sn_ucol, int64_t)
 #undef UP
     if (!H->z && g.Pr * g.Pc == 1 && H->env.solve_join) { H->h_lrow_near.assign(std::max<size_t>(t.lrow.size(), 1), 0); H->h_ucol_near.assign(std::max<size_t>(t.ucol_gc.size(), 1), 0); }
+    H->setup.lap("upload.block_tile_tables");
     for (auto &S : H->sched) if (upload_schedule(*H, S, t)) return SLUAMD_EHIP;
     T.lrow_near = nullptr; T.ucol_near = nullptr;
     if (!H->h_lrow_near.empty()) {
@@ -1264,7 +1400,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     HIPCHK(hipMalloc((void **) &H->d_info, 8 * sizeof(int)));
     rc = eng::setup();
     if (rc) return rc;
-    H->setup.lap("table_uploads");
+    H->setup.lap("upload.rest");
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     // everything this handle allocated on the device: the value arena, the inverse stores and every uploaded table (index images, block / tile
     // tables, tile lists, unit lists and records, pair maps; round 3 counted the index images only)

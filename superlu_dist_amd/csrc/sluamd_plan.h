@@ -1,9 +1,34 @@
 // sluamd_plan.h -- internal: creation-time planning (slot structures -> device tables, schedules, exchange plans)
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
 #include "sluamd_internal.h"
 
 namespace sluamd {
+
+// Host threads of the planner (SLUAMD_PLAN_THREADS; default: the hardware's, at most 16 -- the pre-processing of a handle is integer / index work over
+// millions of supernode blocks, memory-bound beyond a dozen cores).
+inline int plan_threads()
+{
+    static const int want = getenv("SLUAMD_PLAN_THREADS") ? std::max(1, atoi(getenv("SLUAMD_PLAN_THREADS"))) : (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return want;
+}
+// body(b, e) over [0, count) in chunks of `grain` handed out dynamically (the work per supernode spans four orders of magnitude); serial when one chunk or one thread.
+template <class F> inline void parallel_chunks(int64_t count, int64_t grain, F &&body)
+{
+    if (count <= 0) return;
+    grain = std::max<int64_t>(grain, 1);
+    const int T = (int) std::min<int64_t>(plan_threads(), (count + grain - 1) / grain);
+    if (T <= 1) { body((int64_t) 0, count); return; }
+    std::atomic<int64_t> next{0};
+    auto worker = [&] { for (;;) { const int64_t b = next.fetch_add(grain); if (b >= count) return; body(b, std::min(count, b + grain)); } };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(worker);
+    worker();
+    for (auto &x : th) x.join();
+}
 
 struct Comm;
 
