@@ -305,6 +305,9 @@ def main():
     ap.add_argument("--scale-n", type=int, default=150,
                     help="grid side of the SCALING POINT reported beside the headline configuration at every N (150^3: 1.5e14 flop, "
                          "90 GB of factors -- seconds of work per step, so that exchange latency does not dominate the N > 1 runs); 0 = skip")
+    ap.add_argument("--scale-n2", type=int, default=180,
+                    help="grid side of the STRONG-SCALING point (180^3: 188 GB of factors, the largest cube one 288 GB GPU holds, so the 1-GPU time exists; "
+                         "one timed step after one warm-up step); 0 = skip")
     ap.add_argument("--no-scaling-point", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -593,29 +596,49 @@ def main():
     # ---- scaling point: the same job one size up, reported beside the headline configuration at EVERY N (100^3 is a
     # 0.3 s job -- its N > 1 runs are exchange-latency-bound; 150^3 is 3 s of work and fits one GPU at 90 GB).  `value` stays the
     # headline configuration so that the driver's efficiency figure compares equal jobs; this block lets it be recomputed on 150^3.
-    if args.workload == "poisson3d" and not args.no_scaling_point and args.scale_n and args.scale_n != args.n:
-        h.destroy(); symb.free()
-        try:
-            S2 = measure(args.scale_n, max(1, min(args.steps, 2)), 1, args.workload)
-            st2 = S2["h"].stats()
-            F2 = S2["symb"].flops
-            out["scaling_point"] = {"workload": f"{args.scale_n}^3 7-point Poisson (double), {S2['grid'][0]}x{S2['grid'][1]}x{S2['grid'][2]} grid, same ordering / supernode parameters",
-                                    "n": S2["n"], "flops_per_step": F2, "steps": S2["steps"], "warmup": 1,
-                                    "value": F2 * S2["steps"] / S2["elapsed"] / 1e9, "unit": "GFLOP/s", "ms_per_step": 1e3 * S2["elapsed"] / S2["steps"],
-                                    "factor_ms": float(np.mean(S2["fact_ms"])), "solve_ms": float(np.mean(S2["solve_ms"])),
-                                    "factor_gflops_kernel_only": F2 / (np.mean(S2["fact_ms"]) * 1e-3) / 1e9,
-                                    "residual": S2["res"], "nnz_LU_this_rank": int(st2["nnz_L"] + st2["nnz_U"]),
-                                    "bytes_device_this_rank": int(st2["bytes_device"]), "setup_s": S2["t_setup"], "setup_breakdown": S2["setup_breakdown"]}
-            if world == 1:
-                out["scaling_point"]["solve_hbm_frac"] = 8.0 * float(st2["nnz_L"] + st2["nnz_U"]) / (np.mean(S2["solve_ms"]) * 1e-3) / 1e9 / PEAK_HBM_GBS
-            if S2["res"] > 1e-10:
-                raise SystemExit(f"bench.py: scaling-point residual {S2['res']:.3e} exceeds 1e-10")
-            h, symb = S2["h"], S2["symb"]
-        except SystemExit:
-            raise
-        except Exception as e:      # e.g. not enough HBM on this rank: reported, the headline line stands
-            out["scaling_point"] = {"error": str(e)[:300]}
-            h, symb = None, None
+    def scaling_block(side, steps, prof_phases):
+        """the same job at another size, same ordering / supernode parameters: throughput, phase times, bytes, set-up"""
+        S2 = measure(side, steps, 1, args.workload)
+        st2 = S2["h"].stats()
+        F2 = S2["symb"].flops
+        blk = {"workload": f"{side}^3 7-point Poisson (double), {S2['grid'][0]}x{S2['grid'][1]}x{S2['grid'][2]} grid, same ordering / supernode parameters",
+               "n": S2["n"], "flops_per_step": F2, "steps": S2["steps"], "warmup": 1,
+               "value": F2 * S2["steps"] / S2["elapsed"] / 1e9, "unit": "GFLOP/s", "ms_per_step": 1e3 * S2["elapsed"] / S2["steps"],
+               "factor_ms": float(np.mean(S2["fact_ms"])), "solve_ms": float(np.mean(S2["solve_ms"])),
+               "factor_gflops_kernel_only": F2 / (np.mean(S2["fact_ms"]) * 1e-3) / 1e9,
+               "residual": S2["res"], "nnz_LU_this_rank": int(st2["nnz_L"] + st2["nnz_U"]),
+               "bytes_device_this_rank": int(st2["bytes_device"]), "setup_s": S2["t_setup"], "setup_breakdown": S2["setup_breakdown"]}
+        if world == 1:
+            blk["solve_hbm_frac"] = 8.0 * float(st2["nnz_L"] + st2["nnz_U"]) / (np.mean(S2["solve_ms"]) * 1e-3) / 1e9 / PEAK_HBM_GBS
+        elif prof_phases:   # N > 1: where the time goes beside the kernels -- one extra factorisation under the serial schedule, HIP events, max over ranks
+            import torch
+            hh = S2["h"]
+            hh.set_profile(True); hh.reset_values(); hh.pdgstrf3d(S2["thresh"]); sp = hh.stats(); hh.set_profile(False)
+            ph = torch.tensor([sp["t_exchange_ms"], sp["t_reduce_ms"], sp["t_schur_ms"], sp["t_panel_ms"], sp["t_factor_ms"]], dtype=torch.float64)
+            dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+            blk["phases"] = {"exchange_ms": float(ph[0]), "reduce_ms": float(ph[1]), "schur_ms": float(ph[2]), "panel_ms": float(ph[3]), "profiled_factor_ms": float(ph[4])}
+        if S2["res"] > 1e-10:
+            raise SystemExit(f"bench.py: scaling-point residual {S2['res']:.3e} exceeds 1e-10 at {side}^3")
+        return blk, S2
+
+    # ---- scaling points: the same job at larger sizes, reported beside the headline configuration at EVERY N (VERDICT r2: 100^3 is a
+    # 0.3 s job -- its N > 1 runs are exchange-latency-bound).  `value` stays the headline configuration so that the driver's efficiency figure
+    # compares equal jobs; these blocks let it be recomputed on 150^3 (90 GB of factors, ~3 s per step) and on 180^3 (188 GB: the largest cube
+    # ONE GPU holds, so T_1 exists -- the strong-scaling problem of VERDICT r4 item 6-iii; 4.5e14 flop, ~9 s per step on one GPU).
+    if args.workload == "poisson3d" and not args.no_scaling_point:
+        for key, side, nsteps in (("scaling_point", args.scale_n, max(1, min(args.steps, 2))), ("strong_scaling_point", args.scale_n2, 1)):
+            if not side or side == args.n:
+                continue
+            if h is not None:
+                h.destroy(); symb.free(); h, symb = None, None
+            try:
+                out[key], S2 = scaling_block(side, nsteps, world > 1)
+                h, symb = S2["h"], S2["symb"]
+            except SystemExit:
+                raise
+            except Exception as e:      # e.g. not enough HBM on this rank: reported, the headline line stands
+                out[key] = {"error": str(e)[:300]}
+                h, symb = None, None
     # ---- configs4: BASELINE.json configs[4] (pzdrive3d complex16, cg20 family scaled 50x per grid side = 1000 x 1000 5-point complex grid
     # operator, 1 GPU) measured by the SAME default command, so that the driver's record carries it (VERDICT r3 item 2):
     # 5 timed steps after 2 warm-up steps, MFMA fraction of k_schur<Z> from one extra profiled factorisation, HBM fraction of the solve

@@ -60,7 +60,7 @@ assert s.count(m) >= 1, (m, s.count(m))      # (a wait that exists in the split 
 open(p, 'w').write(s.replace(m, '/* mutated */'))
 PY
   make -C oracle >/dev/null 2>&1
-  out=$(timeout 900 python -m pytest tests/test_stream_order.py -q -k 'not under_the_scheduler' 2>&1 | grep -E ' (passed|failed)' | tail -1)
+  out=$(timeout 900 python -m pytest tests/test_stream_order.py -q -x --timeout=120 -k 'not under_the_scheduler' 2>&1 | grep -E ' (passed|failed)' | tail -1)   # a hang is a failure (per-test timeout), the first failure is enough
   echo "without '$m': $out"
   case "$out" in *failed*) ;; *) bad=1; echo "  NOT CAUGHT";; esac
 done

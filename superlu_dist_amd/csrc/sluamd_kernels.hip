@@ -2540,6 +2540,10 @@ int mfma_selftest(const double *A, const double *B, double *D)
 }
 
 // ---- complex16 ----
+// SLUAMD_ZLU4_MAX_NODES: levels of at most this many 33 .. 64-column blocks factor them with kz_diag_lu_wave4 (four waves per block).  OFF by default: measured
+// (profiles/r05_ab_zlu4.txt) a lone block takes 53-55 us there against 48-52 us in the one-wave kernel -- an elimination step is bound by the v_readlane
+// broadcasts of the owner's columns and by the pivot hand-off, not by the column updates the extra waves take over -- and pzgstrf3d 17.5 against 16.9 ms
+static const int g_zlu4_max_nodes = getenv("SLUAMD_ZLU4_MAX_NODES") ? atoi(getenv("SLUAMD_ZLU4_MAX_NODES")) : 0;
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx, int replace_tiny, double thresh, int *info)
 {
     if (nn <= 0) return;
@@ -2547,6 +2551,7 @@ void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int m
     if (mx <= 8) hipLaunchKernelGGL(kz_diag_lu_wave_small<8>, dim3(nn), dim3(64), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else if (mx <= 16) hipLaunchKernelGGL(kz_diag_lu_wave_small<16>, dim3(nn), dim3(64), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else if (mx <= 32) hipLaunchKernelGGL(kz_diag_lu_wave_small<32>, dim3(nn), dim3(64), 0, s, T, nodes, nn, replace_tiny, thresh, info);
+    else if (mx <= 64 && nn <= g_zlu4_max_nodes) hipLaunchKernelGGL(kz_diag_lu_wave4, dim3(nn), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);   // few blocks: four waves per block (the panel chain)
     else if (mx <= 64) hipLaunchKernelGGL(kz_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else hipLaunchKernelGGL(kz_diag_lu, dim3(nn), dim3(256), zdiag_lds_bytes(mx), s, T, nodes, replace_tiny, thresh, info, mx | 1);
 }
@@ -2554,7 +2559,9 @@ static const bool g_ztrsm_quad = getenv("SLUAMD_NO_ZTRSM_QUAD") == nullptr;
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int mx)
 {
     if (nl + nu <= 0) return;
-    if (mx <= 64 && g_ztrsm_quad) hipLaunchKernelGGL(kz_panel_trsm_quad, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);   // four lanes per row / column
+    if (mx <= 16 && g_ztrsm_quad) hipLaunchKernelGGL(kz_panel_trsm_quad<4>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);       // four lanes per row / column, 16 x 17 triangle
+    else if (mx <= 32 && g_ztrsm_quad) hipLaunchKernelGGL(kz_panel_trsm_quad<8>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl);  // 32 x 33
+    else if (mx <= 64 && g_ztrsm_quad) hipLaunchKernelGGL(kz_panel_trsm_quad<16>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl); // 64 x 65
     else hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,

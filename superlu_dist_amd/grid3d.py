@@ -203,6 +203,11 @@ class GridHandle:
         _lib.load().sluamd_get_stats(self._h, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in _lib.Stats._fields_}
 
+    def setup_times(self):
+        """{phase: seconds} of this rank's handle creation (sluamd_setup_times)"""
+        from .driver import LUHandle
+        return LUHandle.setup_times(self)
+
     def destroy(self):
         if self._h:
             _lib.load().sluamd_dDestroyLUHandle(self._h)

@@ -125,7 +125,7 @@ def test_bench_script_flow_on_the_emulation(ngpu, tmp_path):
     env = dict(os.environ, SLUAMD_LIB=os.path.join(ROOT, "oracle", "libsluamd_emul.so"), SLUAMD_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
     env.pop("SLUAMD_EMUL_SCHED", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ngpu), "--grid-side", "12", "--steps", "2", "--warmup", "2",
-                        "--no-cpu-baseline", "--scale-n", "14", "--configs4-n", "40"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+                        "--no-cpu-baseline", "--scale-n", "14", "--scale-n2", "16", "--configs4-n", "40"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-1500:]
@@ -136,6 +136,11 @@ def test_bench_script_flow_on_the_emulation(ngpu, tmp_path):
     assert j["n_gpus"] == ngpu and j["steps"] == 2 and j["value"] > 0 and j["residual"] < 1e-10
     sp = j["scaling_point"]                # the same job one size up, at every N
     assert "error" not in sp and sp["n"] == 14 ** 3 and sp["value"] > 0 and sp["residual"] < 1e-10
+    ss = j["strong_scaling_point"]         # ... and the strong-scaling size (180^3 in the measured line: the largest cube one GPU holds)
+    assert "error" not in ss and ss["n"] == 16 ** 3 and ss["value"] > 0 and ss["residual"] < 1e-10 and "setup_breakdown" in ss
+    assert "problem_generation_ordering_rhs_s" in j["setup_breakdown"] and "symbolic_s" in j["setup_breakdown"]
+    if ngpu > 1:
+        assert set(("exchange_ms", "reduce_ms", "schur_ms", "panel_ms")) <= set(ss["phases"])
     if ngpu == 1:                          # BASELINE.json configs[4] rides in the default N = 1 line (here on a 40 x 40 member of the family)
         c4 = j["configs4"]
         assert "error" not in c4 and c4["dtype"] == "c128" and c4["n"] == 1600 and c4["value"] > 0 and c4["residual"] < 1e-10 and c4["info"] == 0
