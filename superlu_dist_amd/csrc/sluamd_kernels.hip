@@ -134,7 +134,7 @@ __device__ __forceinline__ void wave_lu32(double *P, int ld, int nb, int col1, i
 __global__ __launch_bounds__(256, 2) void k_diag_lu_wave(DevTables T, const int *__restrict__ nodes, int nn, int replace_tiny, double thresh,
                                                          int *__restrict__ info)
 {
-    const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int bi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per block; the launch chooses how many waves share a workgroup
     if (bi >= nn) return;
     const int k = nodes[bi];
     if (!(T.sn_flags[k] & SNF_OWN_DIAG)) return;
@@ -2292,6 +2292,7 @@ void diag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int mx
         return;
     }
     replace_tiny &= 1;
+    // (four blocks per 256-thread workgroup; one or two per workgroup measured the same beside the bulk tiles: 290.1-290.9 / 290.5-291.1 / 290.5 ms, gpurun call 9)
     if (mx <= 64) hipLaunchKernelGGL(k_diag_lu_wave, dim3((nn + 3) / 4), dim3(256), 0, s, T, nodes, nn, replace_tiny, thresh, info);
     else if (mx <= 128) hipLaunchKernelGGL(k_diag_lu<128>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);
     else hipLaunchKernelGGL(k_diag_lu<256>, dim3(nn), dim3(256), 0, s, T, nodes, replace_tiny, thresh, info);

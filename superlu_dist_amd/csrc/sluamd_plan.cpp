@@ -818,34 +818,50 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     if (H.h_fuse_prev.empty()) { H.h_fuse_prev.assign(3 * (size_t) ns, -1); H.h_defer.assign(ns, 0); H.h_pair_roff.assign(3 * (size_t) ns, -1); H.h_pair_coff.assign(3 * (size_t) ns, -1); }
     if (!H.env.no_fuse && !H.opt.deterministic && !H.z) {
         const int maxprev_env = H.env.fuse_max_prev;   // measured: pairs beat groups of 3-4 end to end (longer urgent tiles sit on the panel chain) ...
-        std::vector<int> rowmap[3], colinfo[3];
+        // per level: the candidates (b, its predecessor a = b - 1 in the level below) are independent of each other -- only a's OWN group, formed one level
+        // earlier, is read -- so their maps are built on the planner's threads and committed in schedule order
+        struct PairCand { int b = 0, nsrc = 0, srcs[3] = {-1, -1, -1}; bool ok = false; std::vector<int> rowmap[3], colinfo[3]; };
+        std::vector<PairCand> cands;
         for (int l = 0; l + 1 < S.nlevels; ++l) {
             // ... so groups of more than two only form where the bulk launches hide the chain: below the last `fuse_tail_guard` levels
             // (and whose level holds at least `fuse_group_min_nodes` supernodes: 100^3 -> the bottom ~20 levels, whatever the depth of the tree)
             // XY layers: pairs only -- the three scratch copies keep a deferred supernode's received panels for ONE more level
             const bool xy_layer = H.grid.Pr * H.grid.Pc > 1;
             const int maxprev = (!xy_layer && S.nlevels - (l + 1) > H.env.fuse_tail_guard && S.lvl_off[l + 2] - S.lvl_off[l + 1] >= H.env.fuse_group_min_nodes) ? maxprev_env : 1;
+            cands.clear();
             for (int i = S.lvl_off[l + 1]; i < S.lvl_off[l + 2]; ++i) {
                 const int b = S.nodes[i], a = b - 1;
                 if (a < 0 || lvl[a] != l) continue;
                 if (!H.env.fuse_small && (!t.sn_big[a] || !t.sn_big[b])) continue;      // (SLUAMD_FUSE_SMALL: pairs whose successor runs the 64 x 64 configuration too)
-                int srcs[3] = {a, -1, -1}, nsrc = 1;
+                PairCand c;
+                c.b = b; c.srcs[0] = a; c.nsrc = 1;
                 for (int j = 0; j < 3 && H.h_fuse_prev[3 * (size_t) a + j] >= 0; ++j) {
-                    if (nsrc == maxprev) { nsrc = -1; break; }       // a already closes a full group: b starts a new one later
-                    srcs[nsrc++] = H.h_fuse_prev[3 * (size_t) a + j];
+                    if (c.nsrc == maxprev) { c.nsrc = -1; break; }       // a already closes a full group: b starts a new one later
+                    c.srcs[c.nsrc++] = H.h_fuse_prev[3 * (size_t) a + j];
                 }
-                if (nsrc < 0) continue;
-                bool ok = true;
-                for (int j = 0; j < nsrc && ok; ++j) ok = build_pair_maps(H, t, srcs[j], b, rowmap[j], colinfo[j]);
-                if (!ok) {   // the far members do not fit b: fall back to the plain pair when a is not fused itself
-                    if (nsrc > 1 || !build_pair_maps(H, t, a, b, rowmap[0], colinfo[0])) continue;
+                if (c.nsrc < 0) continue;
+                cands.push_back(std::move(c));
+            }
+            parallel_chunks((int64_t) cands.size(), 4, [&](int64_t c0, int64_t c1) {
+                for (int64_t ci = c0; ci < c1; ++ci) {
+                    PairCand &c = cands[ci];
+                    bool ok = true;
+                    for (int j = 0; j < c.nsrc && ok; ++j) ok = build_pair_maps(H, t, c.srcs[j], c.b, c.rowmap[j], c.colinfo[j]);
+                    if (!ok) {   // the far members do not fit b: fall back to the plain pair when a is not fused itself
+                        if (c.nsrc > 1 || !build_pair_maps(H, t, c.srcs[0], c.b, c.rowmap[0], c.colinfo[0])) continue;
+                    }
+                    c.ok = true;
                 }
-                for (int j = 0; j < nsrc; ++j) {
+            });
+            for (PairCand &c : cands) {
+                if (!c.ok) continue;
+                const int b = c.b, a = c.srcs[0];
+                for (int j = 0; j < c.nsrc; ++j) {
                     const size_t pj = 3 * (size_t) b + j;
-                    H.h_fuse_prev[pj] = srcs[j];
+                    H.h_fuse_prev[pj] = c.srcs[j];
                     H.h_pair_roff[pj] = (int) H.h_pair_rowmap.size(); H.h_pair_coff[pj] = (int) (H.h_pair_colinfo.size() / 2);
-                    H.h_pair_rowmap.insert(H.h_pair_rowmap.end(), rowmap[j].begin(), rowmap[j].end());
-                    H.h_pair_colinfo.insert(H.h_pair_colinfo.end(), colinfo[j].begin(), colinfo[j].end());
+                    H.h_pair_rowmap.insert(H.h_pair_rowmap.end(), c.rowmap[j].begin(), c.rowmap[j].end());
+                    H.h_pair_colinfo.insert(H.h_pair_colinfo.end(), c.colinfo[j].begin(), c.colinfo[j].end());
                 }
                 H.h_defer[a] = 1;
                 S.lvl_defer[l] = 1;
@@ -1147,6 +1163,18 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     const int64_t dbase[2] = {cur + rtot, cur + rtot + dmax};
     H->arena_len = cur + rtot + 2 * dmax;
     H->xy_scratch_len = rtot;
+    // The value arena is allocated and zero-filled by a helper thread from here on, beside the rest of the planning: on a freshly leased device the first
+    // large hipMalloc + fill costs 0.4-0.6 s for 17 GB (the driver hands out cleared pages; later processes on the same box pay 0.02 s), which is as long
+    // as all the host-side planning below.  Joined before the first upload (step 7), and by the guard on every error return.
+    const size_t esz = H->z ? 16 : 8;
+    const size_t arena_bytes = esz * (size_t) std::max<int64_t>(H->arena_len, 1);
+    std::atomic<int> arena_rc{0};
+    struct Joiner { std::thread th; ~Joiner() { if (th.joinable()) th.join(); } } arena_job;
+    arena_job.th = std::thread([H, arena_bytes, &arena_rc] {
+        if (hipSetDevice(H->device) != hipSuccess) { arena_rc = 3; return; }
+        if (hipMalloc((void **) &H->d_val, arena_bytes) != hipSuccess) { H->d_val = nullptr; arena_rc = 1; return; }
+        if (hipMemset(H->d_val, 0, arena_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) arena_rc = 2;
+    });
 
     // ---- 4. per-level exchange plan + offsets of the remote slots / scratch diagonal blocks ----
     H->sched.assign(nz, LevelSched());
@@ -1315,8 +1343,9 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     for (auto &S : H->sched) if (S.chain_l0 >= 0) { H->st.chain_levels += S.nlevels - S.chain_l0; H->st.chain_units += (int64_t) S.cf_units.size() / 8; }
 
     // ---- 7. device allocations + uploads ----
-    const size_t esz = H->z ? 16 : 8;
-    if (hipMalloc((void **) &H->d_val, esz * (size_t) std::max<int64_t>(H->arena_len, 1)) != hipSuccess) {
+    arena_job.th.join();
+    if (arena_rc == 1) {
+        (void) hipGetLastError();
         size_t fr = 0, tot = 0;
         hipMemGetInfo(&fr, &tot);
         char msg[512];
@@ -1327,8 +1356,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         set_error(msg);
         return SLUAMD_ENOMEM;
     }
-    HIPCHK(hipMemset(H->d_val, 0, esz * (size_t) H->arena_len));
-    H->setup.lap("arena_alloc_zero");
+    if (arena_rc) { set_error("allocation / zero fill of the value arena failed"); return SLUAMD_EHIP; }
+    H->setup.lap("arena_alloc_zero_wait");
     if (H->env.reserve_cus > 0) {
         // keep `reserve_cus` compute units out of the main (Schur tile) stream: the panel kernels of the look-ahead stream then
         // always find a free CU (LDS for a whole TRSM strip / diagonal block) instead of waiting for a Schur workgroup to retire
