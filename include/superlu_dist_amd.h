@@ -195,6 +195,10 @@ int sluamd_dsymbfact_unsym(sluamd_symb_t *s, int64_t n, const sluamd_int_t *rowp
  * SRC/prec-independent/get_perm_c.c): nested dissection of the pattern of A + A^T by BFS level structures; perm_c[old] = new,
  * to be passed to sluamd_dsymbfact.  leaf = component size below which no further separator is sought (<= 0: 64). */
 int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind, int32_t leaf, sluamd_int_t *perm_c);
+/* The synthetic operator of SURVEY.md 8(d) / BASELINE.json configs[1-2] for harnesses: 7-point Poisson on an nx x ny x nz grid, natural index (i ny + j) nz + k,
+ * diagonal 6, off-diagonals -1, Dirichlet truncation, CSR with ascending column indices.  rowptr: nx ny nz + 1 entries, colind / nzval:
+ * 7 n - 2 (nx ny + ny nz + nx nz) entries; returns that count (or a negative error code). */
+int64_t sluamd_poisson3d(int32_t nx, int32_t ny, int32_t nz, sluamd_int_t *rowptr, sluamd_int_t *colind, double *nzval);
 int sluamd_symb_info(sluamd_symb_t s, int32_t *nsupers, int64_t *nnzL, int64_t *nnzU, int64_t *lidx_len,
                      int64_t *uidx_len, double *flops);
 /* borrow the store in the reference's formats (valid until sluamd_symb_free) */

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <numeric>
 #include "sluamd_internal.h"
+#include "sluamd_plan.h"
 
 using namespace sluamd;
 
@@ -28,25 +29,32 @@ struct Graph {           // permuted symmetric pattern, strictly-lower and stric
 
 void build_graph(int64_t n, const int *rowptr, const int *colind, const int *perm, Graph &g)
 {
+    // two passes over the rows of A on the planner's threads: degrees (relaxed atomic increments), serial prefix sums, fill (atomic slot claims).
+    // The order of the entries inside an adjacency list therefore varies from run to run; every consumer is order-independent (Liu's elimination
+    // tree is unique, the structure pass sorts what it collects).
     std::vector<int64_t> cl(n + 1, 0), cu(n + 1, 0);
-    for (int64_t i = 0; i < n; ++i)
-        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-            int a = perm[i], b = perm[colind[e]];
-            if (a == b) continue;
-            int lo = std::min(a, b), hi = std::max(a, b);
-            cl[lo + 1]++; cu[hi + 1]++;
-        }
+    parallel_chunks(n, 16384, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i)
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                const int a = perm[i], b = perm[colind[e]];
+                if (a == b) continue;
+                const int lo = std::min(a, b), hi = std::max(a, b);
+                __atomic_fetch_add(&cl[lo + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&cu[hi + 1], 1, __ATOMIC_RELAXED);
+            }
+    });
     for (int64_t i = 0; i < n; ++i) { cl[i + 1] += cl[i]; cu[i + 1] += cu[i]; }
     g.lo_off = cl; g.up_off = cu;
     g.lo.resize(cl[n]); g.up.resize(cu[n]);
     std::vector<int64_t> pl(cl.begin(), cl.end() - 1), pu(cu.begin(), cu.end() - 1);
-    for (int64_t i = 0; i < n; ++i)
-        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-            int a = perm[i], b = perm[colind[e]];
-            if (a == b) continue;
-            int lo = std::min(a, b), hi = std::max(a, b);
-            g.lo[pl[lo]++] = hi; g.up[pu[hi]++] = lo;
-        }
+    parallel_chunks(n, 16384, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i)
+            for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                const int a = perm[i], b = perm[colind[e]];
+                if (a == b) continue;
+                const int lo = std::min(a, b), hi = std::max(a, b);
+                g.lo[__atomic_fetch_add(&pl[lo], 1, __ATOMIC_RELAXED)] = hi; g.up[__atomic_fetch_add(&pu[hi], 1, __ATOMIC_RELAXED)] = lo;
+            }
+    });
 }
 
 // perm_c -> validated permutation composed with a postorder of the elimination tree of Pc (A + A^T) Pc^T (what sp_colorder does for the
@@ -109,6 +117,40 @@ static int order_and_etree(int64_t n, const int *rowptr, const int *colind, cons
 }  // namespace
 
 extern "C" {
+
+int64_t sluamd_poisson3d(int32_t nx, int32_t ny, int32_t nz, sluamd_int_t *rowptr, sluamd_int_t *colind, double *nzval)
+{
+    if (nx < 1 || ny < 1 || nz < 1 || !rowptr || !colind || !nzval) { set_error("bad sluamd_poisson3d arguments"); return SLUAMD_EINVAL; }
+    const int64_t n = (int64_t) nx * ny * nz;
+    const int64_t nnz = 7 * n - 2 * ((int64_t) nx * ny + (int64_t) ny * nz + (int64_t) nx * nz);
+    if (n > 0x7fffffff || nnz > 0x7fffffff) { set_error("sluamd_poisson3d: the operator does not fit 32-bit CSR indices"); return SLUAMD_EINVAL; }
+    // entries of row (i, j, k): the plane i holds ny nz rows of the same count pattern, so the row pointer of a plane start is a closed form
+    // and planes are written independently
+    std::vector<int64_t> plane_off(nx + 1, 0);
+    for (int i = 0; i < nx; ++i) {
+        const int64_t full = (int64_t) ny * nz * (5 + (i > 0) + (i < nx - 1));      // 1 + four in-plane neighbours + the planes before / after
+        plane_off[i + 1] = plane_off[i] + full - 2 * (int64_t) nz - 2 * (int64_t) ny;     // in-plane neighbours missing on the plane's four edges
+    }
+    sluamd::parallel_chunks(nx, 1, [&](int64_t i0, int64_t i1) {
+        for (int i = (int) i0; i < (int) i1; ++i) {
+            int64_t p = plane_off[i];
+            for (int j = 0; j < ny; ++j)
+                for (int k = 0; k < nz; ++k) {
+                    const int64_t r = ((int64_t) i * ny + j) * nz + k;
+                    rowptr[r] = (sluamd_int_t) p;
+                    if (i > 0) { colind[p] = (sluamd_int_t) (r - (int64_t) ny * nz); nzval[p++] = -1.0; }
+                    if (j > 0) { colind[p] = (sluamd_int_t) (r - nz); nzval[p++] = -1.0; }
+                    if (k > 0) { colind[p] = (sluamd_int_t) (r - 1); nzval[p++] = -1.0; }
+                    colind[p] = (sluamd_int_t) r; nzval[p++] = 6.0;
+                    if (k < nz - 1) { colind[p] = (sluamd_int_t) (r + 1); nzval[p++] = -1.0; }
+                    if (j < ny - 1) { colind[p] = (sluamd_int_t) (r + nz); nzval[p++] = -1.0; }
+                    if (i < nx - 1) { colind[p] = (sluamd_int_t) (r + (int64_t) ny * nz); nzval[p++] = -1.0; }
+                }
+        }
+    });
+    rowptr[n] = (sluamd_int_t) nnz;
+    return plane_off[nx] == nnz ? nnz : (int64_t) SLUAMD_ESTRUCT;
+}
 
 int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, const sluamd_int_t *colind,
                      const sluamd_int_t *perm_c, int32_t relax, int32_t maxsup, sluamd_int_t *perm_c_out)
@@ -223,13 +265,8 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     // Two passes over the supernodes, both embarrassingly parallel (every supernode's arrays depend on its own row structure only):
     // sizes -> serial prefix sums -> fill.  Worker threads over contiguous supernode ranges (SLUAMD_SYMB_THREADS, default: the
     // hardware's, at most 16): at 200^3 this phase is half of the symbolic factorisation.
-    auto parallel_for = [&](int count, const std::function<void(int, int)> &body) {
-        static const int want = getenv("SLUAMD_SYMB_THREADS") ? std::max(1, atoi(getenv("SLUAMD_SYMB_THREADS"))) : (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-        const int T = std::max(1, std::min(want, count / 4096));
-        if (T == 1) { body(0, count); return; }
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back(body, (int) ((int64_t) count * t / T), (int) ((int64_t) count * (t + 1) / T));
-        for (auto &x : th) x.join();
+    auto parallel_for = [&](int count, const std::function<void(int, int)> &body) {      // dynamic chunks: the supernodes of the top separators carry most of the entries
+        parallel_chunks(count, 64, [&](int64_t b, int64_t e) { body((int) b, (int) e); });
     };
     std::vector<int64_t> sz_lidx(ns), sz_lval(ns), sz_uidx(ns), sz_uval(ns);
     std::vector<double> fl(ns);

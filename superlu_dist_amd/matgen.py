@@ -16,6 +16,19 @@ import numpy as np
 def poisson3d(N, nx=None, ny=None, nz=None):
     nx = nx or N; ny = ny or N; nz = nz or N
     n = nx * ny * nz
+    if n >= 200000:      # bench sizes: the library's own generator (sluamd_poisson3d, the same operator entry for entry -- tests/test_host_symbolic.py compares the two)
+        try:
+            import ctypes as C
+            from . import _lib
+            L = _lib.load()
+            nnz = 7 * n - 2 * (nx * ny + ny * nz + nx * nz)
+            rp = np.empty(n + 1, dtype=np.int32); ci = np.empty(nnz, dtype=np.int32); v = np.empty(nnz)
+            P_int, P_dbl = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+            got = L.sluamd_poisson3d(nx, ny, nz, rp.ctypes.data_as(P_int), ci.ctypes.data_as(P_int), v.ctypes.data_as(P_dbl))
+            if got == nnz:
+                return n, rp, ci, v
+        except Exception:
+            pass             # (library not built yet: the numpy construction below)
     idx = np.arange(n, dtype=np.int64)
     i = idx // (ny * nz); j = (idx // nz) % ny; k = idx % nz
     rows = [idx]; cols = [idx]; vals = [np.full(n, 6.0)]

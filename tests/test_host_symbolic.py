@@ -108,3 +108,19 @@ def test_graph_nested_dissection_ordering(emul):
     p2 = driver.order_nd(n2, rp2, ci2)
     assert sorted(p2.tolist()) == list(range(n2))
     assert sorted(driver.order_nd(1, np.array([0, 1], dtype=np.int32), np.array([0], dtype=np.int32)).tolist()) == [0]
+
+
+def test_library_poisson_generator_equals_the_numpy_construction():
+    """sluamd_poisson3d (what matgen.poisson3d calls at bench sizes) writes the same CSR arrays, entry for entry, as the numpy construction the
+    small test problems use -- also on a non-cubic grid and on degenerate ones (a line, a single point)."""
+    import ctypes as C
+    from superlu_dist_amd import _lib
+    L = _lib.load()
+    P_int, P_dbl = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    for nx, ny, nz in ((7, 5, 3), (1, 1, 9), (1, 1, 1), (4, 1, 6), (12, 12, 12)):
+        n, rp, ci, v = matgen.poisson3d(0, nx, ny, nz)          # numpy path (below the size threshold)
+        nnz = 7 * n - 2 * (nx * ny + ny * nz + nx * nz)
+        assert len(v) == nnz
+        rp2 = np.empty(n + 1, dtype=np.int32); ci2 = np.empty(nnz, dtype=np.int32); v2 = np.empty(nnz)
+        got = L.sluamd_poisson3d(nx, ny, nz, rp2.ctypes.data_as(P_int), ci2.ctypes.data_as(P_int), v2.ctypes.data_as(P_dbl))
+        assert got == nnz and (rp2 == rp).all() and (ci2 == ci).all() and (v2 == v).all(), (nx, ny, nz)
