@@ -992,6 +992,35 @@ void zbwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int 
 {
     emul_enqueue(s, [=] { impl::bwd_update_t<impl::zc>(T, nodes, prefix, nn, nwork, static_cast<const impl::zc *>(x), static_cast<impl::zc *>(x), ldx, nrhs, nullptr); });
 }
+// fused links of the complex16 sweeps: the same results as the two launches they replace, out of place (forward: y to w; backward: accumulators in w, solution to x)
+void zsweep_fused(hipStream_t s, bool lower, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *xv, void *wv, int64_t ldx, int nrhs, int, int *)
+{
+    if (nwork <= 0) return;
+    emul_enqueue(s, [=] {
+        impl::zc *x = static_cast<impl::zc *>(xv), *w = static_cast<impl::zc *>(wv);
+        auto copy_blocks = [&](const impl::zc *src, impl::zc *dst) {
+            for (int i = 0; i < nn; ++i) {
+                const int k = nodes[i];
+                if (!(T.sn_flags[k] & SNF_OWN_DIAG)) continue;
+                for (int r = 0; r < nrhs; ++r) for (int c = T.xsup[k]; c < T.xsup[k + 1]; ++c) dst[c + (int64_t) r * ldx] = src[c + (int64_t) r * ldx];
+            }
+        };
+        // units of the fused prefixes: strip / chunk `u` of a supernode beyond its real count is the placeholder of a supernode without off-diagonal part
+        std::vector<int> real(nn + 1, 0);
+        if (lower) {
+            copy_blocks(x, w);
+            impl::zsolve_diag(true, T, nodes, nn, w, ldx, nrhs);
+            for (int i = 0; i < nn; ++i) { const int k = nodes[i]; const int lrows = (T.sn_flags[k] & SNF_L_OWN) ? T.sn_nsupr[k] - T.sn_ldiag[k] : 0; real[i + 1] = real[i] + (lrows + 255) / 256; }
+            impl::fwd_update_t<impl::zc, 256>(T, nodes, real.data(), nn, real[nn], w, x, ldx, nrhs, nullptr);
+        } else {
+            for (int i = 0; i < nn; ++i) { const int k = nodes[i]; const int ucols = (T.sn_flags[k] & SNF_U_OWN) ? T.sn_ncolu[k] : 0; real[i + 1] = real[i] + (ucols + 63) / 64; }
+            impl::bwd_update_t<impl::zc>(T, nodes, real.data(), nn, real[nn], x, w, ldx, nrhs, nullptr);
+            copy_blocks(w, x);
+            impl::zsolve_diag(false, T, nodes, nn, x, ldx, nrhs);
+        }
+        (void) prefix;
+    });
+}
 void zscatter_values(hipStream_t s, void *val, const int64_t *pos, const void *a, int64_t nnz)
 {
     emul_enqueue(s, [=] {

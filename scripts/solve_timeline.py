@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = cur.execute("select name, start, end from kernels order by start").fetchall()
 rows = [(re.sub(r"\(.*", "", n).replace("void sluamd::", "").replace("sluamd::", ""), s, e) for n, s, e in rows]
-issolve = lambda n: n.startswith(("k_solve_diag", "k_fwd_update", "k_bwd_update", "k_sweep"))
+issolve = lambda n: n.startswith(("k_solve_diag", "k_fwd_update", "k_bwd_update", "k_sweep", "kz_solve_diag", "kz_fwd", "kz_bwd", "k_zero_nodes"))
 # a solve = maximal run of solve kernels
 runs, curr = [], []
 for r in rows:

@@ -822,6 +822,47 @@ static int max_rhs_chunk(const Handle *H)
     return std::max(1, (96 * 1024) / std::max(per, 1));
 }
 
+// complex16 on one rank, every supernode <= 64 columns: ONE launch per level and sweep (eng::zsweep_fused) instead of two -- the complex path's stand-in for the
+// joined links of the double path (it keeps no inverses).  Forward: x holds the accumulated right-hand side, w receives y; backward: w accumulates, x receives the solution.
+static bool zsweeps_fused(const Handle *H) { return H->z && H->grid.size() == 1 && H->max_nsupc <= 64 && H->env.z_fuse_max_nodes > 0 && !H->profile && H->d_ztickets; }
+// Per level, the same form in both sweeps: fused (levels of few supernodes -- the chain at the top of the tree, where a level is launch latency) or the two in-place
+// launches (levels of thousands of supernodes: every strip re-solving its diagonal block and every chunk paying an agent-scope release cost more than a launch:
+// all levels fused 8.2 ms against 3.14 ms on the 1000 x 1000 configuration).  The forms meet in any order: right-hand-side accumulators always live in x; a fused
+// level keeps its y_k / backward accumulators in w, an in-place level in x_k itself; final solutions are always in x.
+static int zsolve_fused(Handle *H, double *x, int64_t ldx, int nr)
+{
+    const DevTables &T = H->T;
+    hipStream_t s = H->stream;
+    auto fused = [&](const LevelSched &S, int l) { return S.lvl_off[l + 1] - S.lvl_off[l] <= H->env.z_fuse_max_nodes; };
+    for (auto &S : H->sched)
+        for (int l = 0; l < S.nlevels; ++l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            if (fused(S, l)) {
+                eng::zsweep_fused(s, true, T, S.d_nodes + n0, S.d_zffu_prefix + po, nn, S.zffu_prefix[po + nn], x, H->d_w, ldx, nr, S.max_nsupc[l], nullptr);
+                H->st.solve_launches += 1;
+            } else {
+                eng::zsolve_diag(s, true, T, S.d_nodes + n0, nn, x, ldx, nr, S.max_nsupc[l]);
+                eng::zfwd_update(s, T, S.d_nodes + n0, S.d_zfwd_prefix + po, nn, S.zfwd_prefix[po + nn], x, ldx, nr, S.max_nsupc[l]);
+                H->st.solve_launches += 2;
+            }
+        }
+    for (int z = (int) H->sched.size() - 1; z >= 0; --z) {
+        LevelSched &S = H->sched[z];
+        for (int l = S.nlevels - 1; l >= 0; --l) {
+            const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
+            if (fused(S, l)) {
+                eng::zsweep_fused(s, false, T, S.d_nodes + n0, S.d_zbfu_prefix + po, nn, S.zbfu_prefix[po + nn], x, H->d_w, ldx, nr, S.max_nsupc[l], H->d_ztickets);
+                H->st.solve_launches += 1;
+            } else {
+                eng::zbwd_update(s, T, S.d_nodes + n0, S.d_bwd_prefix + po, nn, S.bwd_prefix[po + nn], x, ldx, nr);
+                eng::zsolve_diag(s, false, T, S.d_nodes + n0, nn, x, ldx, nr, S.max_nsupc[l]);
+                H->st.solve_launches += 2;
+            }
+        }
+    }
+    return 0;
+}
+
 int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
 {
     int rc = H->z ? 0 : ensure_inv(H);
@@ -829,9 +870,15 @@ int run_solve_local(Handle *H, double *d_x, int64_t ldx, int nrhs)
     H->st.solve_launches = 0;
     const int ch = max_rhs_chunk(H);
     const int vs = H->z ? 2 : 1;
+    const bool zf = zsweeps_fused(H);
+    if (zf && (rc = ensure_w(H, 2 * ldx * (int64_t) ch))) return rc;
+    static const bool dbg = getenv("SLUAMD_SOLVE_DEBUG") != nullptr;
+    const double t_enq0 = dbg ? SetupTimer::now() : 0.0;
+    struct EnqTimer { bool on; double t0; Handle *H; ~EnqTimer() { if (on) fprintf(stderr, "[sluamd solve] host enqueue of %d launches: %.3f ms\n", H->st.solve_launches, 1e3 * (SetupTimer::now() - t0)); } } enq_timer{dbg, t_enq0, H};
     for (int j0 = 0; j0 < nrhs; j0 += ch) {
         const int nr = std::min(ch, nrhs - j0);
         double *x = d_x + (size_t) j0 * ldx * vs;
+        if (zf) { if ((rc = zsolve_fused(H, x, ldx, nr))) return rc; continue; }
         for (int z = 0; z < (int) H->sched.size(); ++z) if ((rc = solve_fwd_z(H, z, x, ldx, nr))) return rc;
         for (int z = (int) H->sched.size() - 1; z >= 0; --z) if ((rc = solve_bwd_z(H, z, x, ldx, nr))) return rc;
     }

@@ -179,6 +179,8 @@ struct LevelSched {
     std::vector<int> n_big;         // per level: nodes using the 128x128 tile configuration (listed first)
     std::vector<int> fwd_prefix, bwd_prefix;  // solve work units: 64-row L strips / 64-column U chunks
     std::vector<int> zfwd_prefix;             // complex path: 256-row L strips
+    std::vector<int> zffu_prefix, zbfu_prefix; // complex path, fused links (eng::zsweep_fused): 256-row strips / 64-column chunks with AT LEAST ONE unit per owned diagonal block
+    int *d_zffu_prefix = nullptr, *d_zbfu_prefix = nullptr;
     // the same units as explicit (supernode, strip / chunk) lists, per level [urgent | bulk]: urgent = touches a supernode of the
     // adjacent level (l+1: rows the forward update writes / columns the backward update reads) = what the next diagonal solve of the
     // chain waits for, bulk = levels >= l+2 only (launched together with that diagonal solve, eng::sweep_step)
@@ -309,6 +311,7 @@ struct Handle {
         bool no_merge_tiles = false; // SLUAMD_NO_MERGE_TILES: every (L block, U block) pair keeps its own Schur tiles (round 3)
         bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
         int panel_split_max_nodes = 1024;   // SLUAMD_PANEL_SPLIT: levels of at most this many supernodes solve their panels in two parts (urgent strips on the chain, the rest beside the next diagonal LU); 0 = off
+        int z_fuse_max_nodes = 16;   // SLUAMD_ZFUSE_MAX_NODES: complex16 sweeps run the levels of at most this many supernodes as fused links (one launch per level and sweep); 0 = never
         bool info_last = false;      // SLUAMD_INFO_LAST=1: `info` = the zero pivot met LAST on a rank (largest column; what pdgstrf2.c:568-571 leaves in *info), MIN over the ranks (pdgstrf3d.c:388-392); default: the first column
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
         int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
@@ -351,6 +354,7 @@ struct Handle {
     bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
     bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
     bool inv_ready = false;                                 // T.inv (Linv / Uinv) too
+    int *d_ztickets = nullptr;                              // complex fused backward links: one ticket counter per supernode (zero between sweeps)
     int *chain_abort = nullptr;                             // pinned host word written by k_chain when a dependency never arrives (checked after every solve)
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel, ev_xchg, ev_red;
@@ -463,6 +467,10 @@ void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes
 void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs,
                  int max_nsupc);
 void zbwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs);
+// one link of a complex16 sweep in ONE launch (supernodes of <= 64 columns): forward = every strip solves y_k itself (strip 0 stores it to w), then x[rows] -= L y_k;
+// backward = w_k -= U(k, chunk) x, the workgroup taking the last ticket of k solves x_k = inv(U_kk) w_k.  prefix: >= 1 unit per supernode (LevelSched::zffu / zbfu)
+void zsweep_fused(hipStream_t s, bool lower, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, void *w, int64_t ldx, int nrhs,
+                  int max_nsupc, int *tickets);
 void zscatter_values(hipStream_t s, void *val, const int64_t *pos, const void *a, int64_t nnz);
 }  // namespace eng
 

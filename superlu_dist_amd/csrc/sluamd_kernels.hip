@@ -2590,6 +2590,12 @@ void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int 
 {
     if (nwork > 0) hipLaunchKernelGGL(kz_fwd_update, dim3(nwork), dim3(256), (size_t) mx * nrhs * 16, s, T, nodes, prefix, nn, reinterpret_cast<zc *>(x), ldx, nrhs);
 }
+void zsweep_fused(hipStream_t s, bool lower, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, void *w, int64_t ldx, int nrhs, int mx, int *tickets)
+{
+    if (nwork <= 0) return;
+    if (lower) hipLaunchKernelGGL(kz_fwd_fused, dim3(nwork), dim3(256), (size_t) mx * nrhs * 16, s, T, nodes, prefix, nn, reinterpret_cast<zc *>(x), reinterpret_cast<zc *>(w), ldx, nrhs);
+    else hipLaunchKernelGGL(kz_bwd_fused, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, reinterpret_cast<zc *>(x), reinterpret_cast<zc *>(w), ldx, nrhs, tickets);
+}
 void zbwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs)
 {
     if (nwork > 0) hipLaunchKernelGGL(kz_bwd_update, dim3(nwork), dim3(256), 0, s, T, nodes, prefix, nn, reinterpret_cast<zc *>(x), ldx, nrhs);

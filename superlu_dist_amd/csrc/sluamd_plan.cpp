@@ -738,6 +738,7 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     S.fwd_prefix.assign(psz, 0); S.bwd_prefix.assign(psz, 0); S.inv_prefix.assign(psz, 0); S.zltr_prefix.assign(psz, 0);
     S.dg_prefix.assign(psz, 0); S.dg_off.assign(psz, 0);
     S.finv_prefix.assign(psz, 0); S.zfwd_prefix.assign(psz, 0);
+    S.zffu_prefix.assign(psz, 0); S.zbfu_prefix.assign(psz, 0);
     S.max_nsupc.assign(S.nlevels, 0);
     for (int l = 0; l < S.nlevels; ++l)
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i)
@@ -761,6 +762,8 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
             S.zltr_prefix[po + 1] = S.zltr_prefix[po] + (lrows + 63) / 64;
             S.fwd_prefix[po + 1] = S.fwd_prefix[po] + (lrows + 63) / 64;
             S.zfwd_prefix[po + 1] = S.zfwd_prefix[po] + (lrows + 255) / 256;
+            S.zffu_prefix[po + 1] = S.zffu_prefix[po] + ((fl & SNF_OWN_DIAG) ? std::max(1, (lrows + 255) / 256) : (lrows + 255) / 256);
+            S.zbfu_prefix[po + 1] = S.zbfu_prefix[po] + ((fl & SNF_OWN_DIAG) ? std::max(1, (ucols + 63) / 64) : (ucols + 63) / 64);
             S.bwd_prefix[po + 1] = S.bwd_prefix[po] + (ucols + 63) / 64;
             S.finv_prefix[po + 1] = S.finv_prefix[po] + ((fl & (xy_gemm ? SNF_HAS_DIAG : SNF_OWN_DIAG)) ? 2 * ((nsupc + 15) / 16) : 0);    // FIS = 16-row identity strips
         }
@@ -1003,6 +1006,7 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
     if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_prefix, &S.d_dg_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.zfwd_prefix, &S.d_zfwd_prefix)) return SLUAMD_EHIP;
+    if (H.z && (upload(H.d_misc, S.zffu_prefix, &S.d_zffu_prefix) || upload(H.d_misc, S.zbfu_prefix, &S.d_zbfu_prefix))) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.finv_prefix, &S.d_finv_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_off, &S.d_dg_off)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.fwd_units, &S.d_fwd_units)) return SLUAMD_EHIP;
@@ -1427,6 +1431,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     H->st.schur_tiles = 0;               // until the first factorisation: the PLANNED tile executions of one factorisation (list schedules)
     for (auto &S : H->sched) H->st.schur_tiles += (int64_t) S.ulist.size();
     HIPCHK(hipMalloc((void **) &H->d_info, 8 * sizeof(int)));
+    if (H->z) { std::vector<int> zero(std::max(ns, 1), 0); if (upload(K, zero, &H->d_ztickets)) return SLUAMD_EHIP; }
     rc = eng::setup();
     if (rc) return rc;
     H->setup.lap("upload.rest");
