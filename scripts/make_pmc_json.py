@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build profiles/rNN_pmc_schur.json (bench.py reads profiles/r04_pmc_schur.json) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite) of
+"""Build profiles/rNN_pmc_schur.json (bench.py reads profiles/r05_pmc_schur.json) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd SQLite) of
 `python bench.py --steps 1 --warmup 2 --no-cpu-baseline` (4 factorisations per run: counted from the k_scatter_values launches).
 usage: make_pmc_json.py fetch.db write.db n_factorisations "source text" > profiles/r01_pmc_schur.json"""
 import hashlib, json, os, re, sqlite3, sys
