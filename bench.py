@@ -230,7 +230,7 @@ def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0, mkl_n=60
                 sweep.append(rec)
                 if rec["residual"] is not None and rec["residual"] < 1e-10 and (best is None or rec["factor_s"] < best["factor_s"]):
                     best = rec
-            if best and layer == "SEQUENTIAL" and spent < budget_s:     # one more point: MKL's own threads (on libgomp) at the best thread count
+            if best and layer == "SEQUENTIAL" and spent + 1.5 * best["factor_s"] < budget_s:     # one more point, if it fits the budget: MKL's own threads (on libgomp) at the best thread count
                 rec, _, wall, err = _run_reference(ref_bin, args, _ref_env(best["threads"], relax, maxsup, "GNU"), timeout=max(30, int(budget_s)))
                 if rec is not None:
                     rec = dict(threads=best["threads"], gflops=fl2 / rec["factor_s"] / 1e9, mkl_threading_layer="GNU", **rec)
@@ -256,7 +256,7 @@ def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0, mkl_n=60
     mkl = None
     if mkl_bin:
         try:
-            fl2, sweep, best = sweep_leg(mkl_bin, mkl_n, "SEQUENTIAL", 110.0, (8, 16, 32))
+            fl2, sweep, best = sweep_leg(mkl_bin, mkl_n, "SEQUENTIAL", 100.0, (8, 16, 32))
             if best:
                 mkl = {"kind": "reference+mkl", "blas": mkl_desc, "mkl_threading_layer": best.get("mkl_threading_layer"),
                        "sample": f"{mkl_n}^3 7-pt Poisson, same ND perm_c/relax/maxsup, 1x1x1 grid, nrhs=1", "flops": fl2,

@@ -235,6 +235,10 @@ int sluamd_dResetValues(sluamd_handle_t h);
 int sluamd_device_synchronize(void);
 int sluamd_set_profile(sluamd_handle_t h, int on);         /* per-kernel-family HIP-event timing in stats */
 int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny_pivots);
+/* Linv / Uinv of the diagonal block of supernode k as the handle keeps them for the panel solves and the triangular sweeps -- what pdCompute_Diag_Inv
+ * (SRC/double/pdgstrs.c:842-959: dtrtri on the factored block) leaves in Llu->Linv_bc_ptr / Uinv_bc_ptr: column-major nsupc x nsupc each, unit-lower and
+ * upper inverse with explicit zeros in the other triangle.  Host buffers; the rank must own the diagonal block; double handles after a factorisation. */
+int sluamd_dGetDiagInv(sluamd_handle_t h, int32_t k, double *Linv, double *Uinv);
 int sluamd_mfma_selftest(const double *A16x4, const double *B4x16, double *D16x16);
 
 /* ---- iterative refinement: pdgsrfs3d (SRC/double/pdgsrfs.c:345-510) with its SpMV pdgsmv (SRC/double/pdgsmv.c) on the

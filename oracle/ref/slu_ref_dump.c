@@ -263,6 +263,32 @@ void WRAP(gstrs3d_newsolve)(superlu_dist_options_t *options, int_t n, xLUstruct_
                                xSOLVEstruct_t *SOLVEstruct, SuperLUStat_t *stat, int *info)
 {
     dump_solve("newsolve", n, SP, B, m_loc, fst_row, ldb, nrhs, 0);
+#ifndef Z_PREC
+    if (g_out && g_solve_count == 0 && options->DiagInv == YES && LUstruct->Llu->inv == 1) {
+        /* pdCompute_Diag_Inv's result (pdgstrs.c:842-959, dtrtri on the factored diagonal blocks): Linv / Uinv of every diagonal block this rank owns,
+         * column-major nsupc x nsupc each, concatenated in supernode order with their offsets -- the direct fixture of SURVEY 8(f)-3 */
+        gridinfo_t *grid = &grid3d->grid2d;
+        Glu_persist_t *Glu = LUstruct->Glu_persist;
+        xLocalLU_t *Llu = LUstruct->Llu;
+        int_t ns = g_nsupers_dump, *xsup = Glu->xsup;
+        int myrow = MYROW(grid->iam, grid), mycol = MYCOL(grid->iam, grid);
+        long long *off = (long long *) calloc(ns + 1, 8);
+        for (int_t k = 0; k < ns; ++k) {
+            long long w = xsup[k + 1] - xsup[k];
+            int own = PROW(k, grid) == myrow && PCOL(k, grid) == mycol && Llu->Lrowind_bc_ptr[LBj(k, grid)];
+            off[k + 1] = off[k] + (own ? w * w : 0);
+        }
+        double *li = (double *) malloc(8 * (off[ns] + 1)), *ui = (double *) malloc(8 * (off[ns] + 1));
+        for (int_t k = 0; k < ns; ++k)
+            if (off[k + 1] > off[k]) {
+                memcpy(li + off[k], Llu->Linv_bc_ptr[LBj(k, grid)], 8 * (off[k + 1] - off[k]));
+                memcpy(ui + off[k], Llu->Uinv_bc_ptr[LBj(k, grid)], 8 * (off[k + 1] - off[k]));
+            }
+        put("diaginv_off", 1, ns + 1, off);
+        put("Linv", 2, off[ns], li); put("Uinv", 2, off[ns], ui);
+        free(off); free(li); free(ui);
+    }
+#endif
 #if defined(USE_SLUAMD)   /* slu_ref_amd / slu_ref_zamd: OUR triangular solves on the device-resident factors (SLUAMD_BIND_SOLVE=0: the reference's) */
 #ifdef Z_PREC
 #define BIND_SOLVE_NEW sluamd_bind_pzgstrs3d_newsolve
@@ -316,7 +342,7 @@ int main(int argc, char *argv[])
     double *berr;
     scalar_t *b, *xtrue;
     int nprow = 1, npcol = 1, npdep = 1, nrhs = 1;
-    int equil = -1, colperm = -1, rowperm = -1, ir = -1, tiny = -1, quiet = 0;
+    int equil = -1, colperm = -1, rowperm = -1, ir = -1, tiny = -1, quiet = 0; int diaginv = -1;
     int info, ldb, ldx;
     const char *outp = "slu_dump", *permfile = NULL, *matfile = NULL;
     FILE *fp = NULL;
@@ -337,6 +363,7 @@ int main(int argc, char *argv[])
             case 'i': ir = atoi(v); break;
             case 's': nrhs = atoi(v); break;
             case 'T': tiny = atoi(v); break;
+            case 'D': diaginv = atoi(v); break;
             case 'P': permfile = v; break;
             case 'o': outp = v; break;
             case 'Q': quiet = atoi(v); break;
@@ -354,6 +381,7 @@ int main(int argc, char *argv[])
     if (colperm != -1) options.ColPerm = colperm;
     if (ir != -1) options.IterRefine = ir;
     if (tiny != -1) options.ReplaceTinyPivot = tiny ? YES : NO;
+    if (diaginv != -1) options.DiagInv = diaginv ? YES : NO;      /* needs a LAPACK build (oracle/_ref_mkl): pdCompute_Diag_Inv is empty otherwise (pdgstrs.c:845) */
     if (permfile) options.ColPerm = MY_PERMC;
     options.PrintStat = quiet ? NO : YES;
 

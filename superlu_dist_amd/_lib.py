@@ -44,7 +44,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "sluamd_default_options", "sluamd_dCreateLUHandle", "sluamd_dSetValues", "sluamd_pdgstrf3d",
     "sluamd_dCopyLU2Host", "sluamd_pdgstrs3d", "sluamd_pdgstrs3d_dev", "sluamd_pdgstrs3d_dist", "sluamd_pzgstrs3d_dist", "sluamd_dDestroyLUHandle",
-    "sluamd_get_stats", "sluamd_setup_times", "sluamd_poisson3d", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_dsymbfact_unsym", "sluamd_order_nd", "sluamd_symb_info",
+    "sluamd_get_stats", "sluamd_setup_times", "sluamd_poisson3d", "sluamd_dGetDiagInv", "sluamd_last_error", "sluamd_device_count", "sluamd_dsymbfact", "sluamd_dsymbfact_unsym", "sluamd_order_nd", "sluamd_symb_info",
     "sluamd_symb_view", "sluamd_symb_grid_footprint", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
     "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
     "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",
@@ -117,6 +117,7 @@ def bind(L):
     L.sluamd_setup_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.sluamd_poisson3d.argtypes = [C.c_int32, C.c_int32, C.c_int32, P_int, P_int, P_dbl]
     L.sluamd_poisson3d.restype = C.c_int64
+    L.sluamd_dGetDiagInv.argtypes = [C.c_void_p, C.c_int32, P_dbl, P_dbl]
     L.sluamd_dAttachMatrix.argtypes = [C.c_void_p, C.c_int32, P_int, P_int, P_dbl, P_int]
     L.sluamd_pdgsrfs3d.argtypes = [C.c_void_p, P_dbl, C.c_int64, P_dbl, C.c_int64, C.c_int32, P_dbl, P_int]
     L.sluamd_pdgsrfs3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, P_dbl, P_int]

@@ -345,6 +345,24 @@ int sluamd_factor_info(sluamd_handle_t h, int *info, int *tiny)
     return 0;
 }
 
+int sluamd_dGetDiagInv(sluamd_handle_t h, int32_t k, double *Linv, double *Uinv)
+{
+    if (!h || h->H.z || !Linv || !Uinv) { set_error("bad sluamd_dGetDiagInv arguments"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    if (H->split.active) { set_error("sluamd_dGetDiagInv: the handle refined supernodes wider than 256 columns into pieces; their inverses are per piece"); return SLUAMD_EINVAL; }
+    if (k < 0 || k >= H->hs.nsupers || !(H->h_flags[k] & SNF_OWN_DIAG)) { set_error("sluamd_dGetDiagInv: this rank does not own the diagonal block of that supernode"); return SLUAMD_EINVAL; }
+    HIPCHK(hipSetDevice(H->device));
+    int rc = ensure_inv(H);       // (computed by the factorisation already unless the panel solves ran as substitutions)
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(H->stream));
+    const int64_t ns = H->hs.xsup[k + 1] - H->hs.xsup[k];
+    std::vector<int64_t> off(1);
+    HIPCHK(hipMemcpy(off.data(), H->T.sn_inv + k, sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Linv, H->T.inv + off[0], sizeof(double) * (size_t) (ns * ns), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Uinv, H->T.inv + off[0] + ns * ns, sizeof(double) * (size_t) (ns * ns), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sluamd_dCopyLU2Host(sluamd_handle_t h, const sluamd_dLUview_t *lu)
 {
     if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }

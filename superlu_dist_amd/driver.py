@@ -283,6 +283,12 @@ class LUHandle:
         _lib.load().sluamd_get_stats(self._h, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
 
+    def diag_inv(self, k, ns):
+        """(Linv, Uinv) of the diagonal block of supernode k: ns x ns, column-major (sluamd_dGetDiagInv)"""
+        li = np.zeros((ns, ns), order="F"); ui = np.zeros((ns, ns), order="F")
+        _lib.check(_lib.load().sluamd_dGetDiagInv(self._h, int(k), _pd(li), _pd(ui)), "sluamd_dGetDiagInv")
+        return li, ui
+
     def setup_times(self):
         """{phase: seconds} of this handle's creation (sluamd_setup_times)"""
         buf = C.create_string_buffer(4096)

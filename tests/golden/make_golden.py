@@ -20,6 +20,7 @@ from slud import read_slud  # noqa: E402
 
 DUMP = os.path.join(ROOT, "oracle", "_ref", "slu_ref_dump")
 ZDUMP = os.path.join(ROOT, "oracle", "_ref", "slu_ref_zdump")
+MKL_DUMP = os.path.join(ROOT, "oracle", "_ref_mkl", "slu_ref_dump")     # the LAPACK build (make -C oracle/ref ref_mkl): DiagInv = YES only
 REF_EX = "/root/reference/EXAMPLE"
 
 # name -> dict(matrix=..., grid=(r,c,d), flags=[...], nd=bool)
@@ -43,6 +44,10 @@ CASES = {
     "poisson8_nd_refine": dict(matrix=("poisson", 8), grid=(1, 1, 1), nd=16, flags=["-e", "0", "-p", "0", "-i", "2"]),
     "weakdiag150_refine": dict(matrix=("weakdiag", 150, 0.04, 11), grid=(1, 1, 1), flags=["-e", "0", "-p", "0", "-i", "2", "-T", "1"]),
     "weakdiag150_refine_nrhs2": dict(matrix=("weakdiag", 150, 0.04, 11), grid=(1, 1, 1), flags=["-e", "0", "-p", "0", "-i", "2", "-T", "1", "-s", "2"]),
+    # DiagInv = YES (pdCompute_Diag_Inv, pdgstrs.c:842-959: dtrtri on the factored diagonal blocks; needs LAPACK -> the MKL build of the reference): Linv / Uinv of
+    # every diagonal block recorded beside the usual hot-path records -- the direct fixture of the library's k_full_inv / k_full_inv64
+    "poisson10_nd_diaginv": dict(matrix=("poisson", 10), grid=(1, 1, 1), nd=27, flags=["-e", "0", "-p", "0", "-i", "0", "-D", "1"], mkl=True),
+    "unsym300_diaginv": dict(matrix=("unsym", 300, 0.02, 7), grid=(1, 1, 1), flags=["-D", "1"], mkl=True),
     # ---- complex16 (pzgssvx3d / pzgstrf3d / pzgstrs3d): BASELINE.json config 5 family ----
     "z_cg20_1x1x1": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 1), flags=[], z=True),
     "z_cg20_1x1x1_nrhs2": dict(matrix=("file", f"{REF_EX}/cg20.cua"), grid=(1, 1, 1), flags=["-s", "2"], z=True),
@@ -90,9 +95,9 @@ def build_case(name, spec, tmp):
     r, c, d = spec["grid"]
     nproc = r * c * d
     outp = os.path.join(tmp, name)
-    cmd = ["/opt/conda/bin/mpiexec", "-n", str(nproc), ZDUMP if spec.get("z") else DUMP, "-r", str(r), "-c", str(c), "-d", str(d),
+    cmd = ["/opt/conda/bin/mpiexec", "-n", str(nproc), ZDUMP if spec.get("z") else MKL_DUMP if spec.get("mkl") else DUMP, "-r", str(r), "-c", str(c), "-d", str(d),
            "-Q", "1", "-o", outp] + flags + [mpath]
-    env = dict(os.environ, OMP_NUM_THREADS="1", LD_LIBRARY_PATH="/opt/conda/lib")
+    env = dict(os.environ, OMP_NUM_THREADS="1", LD_LIBRARY_PATH="/opt/conda/lib", MKL_THREADING_LAYER="SEQUENTIAL")
     env.update(spec.get("env", {}))
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     if res.returncode != 0:

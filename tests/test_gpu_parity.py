@@ -70,6 +70,32 @@ def test_solve_matches_reference(golden, case):
     h.destroy()
 
 
+@pytest.mark.parametrize("case", ["poisson10_nd_diaginv", "unsym300_diaginv"])
+def test_diagonal_inverses_match_the_reference(golden, case):
+    """Linv / Uinv of every diagonal block (k_full_inv / k_full_inv64 from the 32 x 32 inverses of the diagonal kernels) against what the reference's
+    pdCompute_Diag_Inv left in Llu->Linv_bc_ptr / Uinv_bc_ptr (dtrtri; recorded from a DiagInv = YES run of the reference built on LAPACK, oracle/_ref_mkl):
+    1e-10 relative to the largest entry of each inverse, explicit zeros in the other triangle, and the factors of that run as usual."""
+    g = golden(case)
+    st, h, info = _factor(g)
+    assert info == int(g["r0__info"][0])
+    scale = max(np.abs(g["r0__Lnzval_pre"]).max(), np.abs(g["r0__Unzval_pre"]).max())
+    assert np.abs(st.Lnzval - g["r0__Lnzval_post"]).max() <= 1e-12 * scale
+    xs, off = g["r0__xsup"], g["r0__diaginv_off"]
+    checked = 0
+    for k in range(len(xs) - 1):
+        ns = int(xs[k + 1] - xs[k])
+        if off[k + 1] == off[k]:
+            continue
+        Lr = g["r0__Linv"][off[k]:off[k + 1]].reshape((ns, ns), order="F"); Ur = g["r0__Uinv"][off[k]:off[k + 1]].reshape((ns, ns), order="F")
+        Li, Ui = h.diag_inv(k, ns)
+        assert np.abs(Li - Lr).max() <= 1e-10 * max(1.0, np.abs(Lr).max()), k
+        assert np.abs(Ui - Ur).max() <= 1e-10 * max(1.0, np.abs(Ur).max()), k
+        assert np.all(np.triu(Li, 1) == 0) and np.all(np.tril(Ui, -1) == 0) and np.all(np.diag(Li) == 1.0)
+        checked += 1
+    assert checked == len(xs) - 1
+    h.destroy()
+
+
 def test_deterministic_mode_is_bitwise_reproducible(golden):
     g = golden("poisson10_nd")
     a, h1, _ = _factor(g, deterministic=True)
