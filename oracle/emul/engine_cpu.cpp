@@ -602,7 +602,9 @@ static void join_bwd_unit(const DevTables &T, const int4 *rec, const int4 *jaux,
         for (int e = 0; e < ncnt; ++e) {
             const int4 col = jaux[noff + e];
             const double xv = xa[col.z + (int64_t) q * ldx];
-            for (int i = std::max(col.x, 64 * c); i < 64 * c + nc; ++i) t[i - 64 * c] -= T.val[uoff + col.y + (i - col.x)] * xv;
+            // rows of block c inside the supernode whose U row this is: a member of a merged group starts at column rec[2].z of the group and is rec[2].w wide
+            const int moff = rec[2].z, nsm = rec[2].w;
+            for (int i = std::max(col.x, 64 * c - moff); i < std::min(nsm, 64 * c - moff + nc); ++i) t[i + moff - 64 * c] -= T.val[uoff + col.y + (i - col.x)] * xv;
         }
         for (int r = 64 * st; r < std::min(ns, 64 * st + 64); ++r) {
             double a = 0.0;
@@ -1019,6 +1021,67 @@ void zsweep_fused(hipStream_t s, bool lower, const DevTables &T, const int *node
             impl::zsolve_diag(false, T, nodes, nn, x, ldx, nrhs);
         }
         (void) prefix;
+    });
+}
+// merged chain groups: the same gather and products as the device kernels, element by element
+void grp_gather(hipStream_t s, const DevTables &T, const GrpDesc *gd, double *scr)
+{
+    emul_enqueue(s, [=] {
+        const GrpDesc g = *gd;
+        const int nG = g.nG;
+        double *LinvG = T.inv + g.ginv, *UinvG = LinvG + (int64_t) nG * nG, *LG = scr, *UG = scr + GRP_SCR;
+        for (int t = 0; t < g.nm; ++t) {
+            const int k = g.k[t], o = g.o[t], w = g.w[t];
+            const double *Li = T.inv + T.sn_inv[k], *Ui = Li + (int64_t) w * w;
+            for (int c = 0; c < w; ++c) for (int r = 0; r < w; ++r) {
+                LinvG[(o + r) + (int64_t) (o + c) * nG] = Li[r + (int64_t) c * w];
+                UinvG[(o + r) + (int64_t) (o + c) * nG] = Ui[r + (int64_t) c * w];
+            }
+        }
+        for (int i = 1; i < g.nm; ++i)
+            for (int kk = 0; kk < i; ++kk) {
+                {   // L block of member i in panel kk
+                    const int mi = g.k[i], mk = g.k[kk], oi = g.o[i], ok = g.o[kk], wk = g.w[kk];
+                    const int lb0 = T.sn_lb_off[mk], nb = T.sn_nlb[mk];
+                    for (int q = 0; q < nb; ++q) {
+                        if (T.lb_gid[lb0 + q] != mi) continue;
+                        const int b = lb0 + q, nbrow = T.lb_nbrow[b], ro = T.lb_rowoff[b], lda = T.sn_nsupr[mk], f = T.xsup[mi];
+                        for (int c = 0; c < wk; ++c) for (int r = 0; r < nbrow; ++r)
+                            LG[(oi + T.lrow[T.sn_lrow[mk] + ro + r] - f) + (int64_t) (ok + c) * nG] = T.val[T.sn_lval[mk] + ro + r + (int64_t) c * lda];
+                    }
+                }
+                {   // U block (row member kk, column member i)
+                    const int mr = g.k[kk], mc = g.k[i], orr = g.o[kk], oc = g.o[i], wr = g.w[kk];
+                    const int ub0 = T.sn_ub_off[mr], nub = T.sn_nub[mr];
+                    for (int q = 0; q < nub; ++q) {
+                        if (T.ub_gid[ub0 + q] != mc) continue;
+                        const int b = ub0 + q, ncol = T.ub_ncols[b], st = T.ub_stcol[b], f = T.xsup[mc];
+                        for (int cq = 0; cq < ncol; ++cq) {
+                            const int64_t ci = T.sn_ucol[mr] + st + cq;
+                            const int ld = T.ucol_ld[ci];
+                            for (int r = ld; r < wr; ++r) UG[(orr + r) + (int64_t) (oc + T.ucol_gc[ci] - f) * nG] = T.val[T.sn_uval[mr] + T.ucol_cp[ci] + (r - ld)];
+                        }
+                    }
+                }
+            }
+    });
+}
+void gemm_batched(hipStream_t s, const DevTables &T, const GemmDesc *descs, const int4 *tiles, int ntiles, double *scr)
+{
+    if (ntiles <= 0) return;
+    emul_enqueue(s, [=] {
+        for (int t = 0; t < ntiles; ++t) {
+            const int4 tl = tiles[t];
+            const GemmDesc d = descs[tl.x];
+            const double *A = (d.abase ? scr : T.inv) + d.a, *B = (d.bbase ? scr : T.inv) + d.b;
+            double *C = (d.cbase ? scr : T.inv) + d.c;
+            for (int col = 64 * tl.z; col < std::min(d.N, 64 * tl.z + 64); ++col)
+                for (int row = 64 * tl.y; row < std::min(d.M, 64 * tl.y + 64); ++row) {
+                    double acc = 0.0;
+                    for (int k = 0; k < d.K; ++k) acc += A[row + (int64_t) k * d.lda] * B[k + (int64_t) col * d.ldb];
+                    C[row + (int64_t) col * d.ldc] = d.neg ? -acc : acc;
+                }
+        }
     });
 }
 void zscatter_values(hipStream_t s, void *val, const int64_t *pos, const void *a, int64_t nnz)

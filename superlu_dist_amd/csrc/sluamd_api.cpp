@@ -627,6 +627,7 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->ustream) hipStreamDestroy(H->ustream);
     if (H->u2stream) hipStreamDestroy(H->u2stream);
     if (H->rstream) hipStreamDestroy(H->rstream);
+    if (H->gstream) hipStreamDestroy(H->gstream);
     for (auto e : H->red_pool) hipEventDestroy(e);
     if (H->red_all) hipEventDestroy(H->red_all);
     if (H->stream) hipStreamDestroy(H->stream);

@@ -52,6 +52,19 @@ static int exchange(Handle *H, const std::vector<XMsg> &sends, const std::vector
 // the reference's look-ahead pipeline (dsparseTreeFactor_ASYNC, dtreeFactorization.c:381-706, num_lookaheads).
 static hipEvent_t red_wait_event(const Handle *H, int64_t lend, int64_t uend);     // pipelined Z reduction, below
 
+// Inverse of the block triangle of one merged chain group (Handle::groups) into its pair of T.inv: zero fill, gather (diagonal blocks = the members' Linv / Uinv,
+// off-diagonal blocks of the panels / skylines into dense images), then the block substitutions by distance as batched dense products -- all on stream st.
+static void group_inverse(Handle *H, int gi, hipStream_t st)
+{
+    const Handle::SolveGroup &G = H->groups[gi];
+    hipMemsetAsync(H->T.inv + G.ginv, 0, sizeof(double) * (size_t) 2 * G.nG * G.nG, st);
+    hipMemsetAsync(H->d_gscr, 0, sizeof(double) * (size_t) (2 * GRP_SCR), st);       // LG | UG (the sums TL / TU are written before they are read)
+    eng::grp_gather(st, H->T, H->d_grpdesc + gi, H->d_gscr);
+    for (int q = 0; q + 1 < 7; ++q)
+        if (G.tile_off[q + 1] > G.tile_off[q]) { eng::gemm_batched(st, H->T, H->d_gemmdesc, H->d_gemmtiles + G.tile_off[q], G.tile_off[q + 1] - G.tile_off[q], H->d_gscr); H->st.num_launches++; }
+    H->st.num_launches += 1;
+}
+
 static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
 {
     const DevTables &T = H->T;
@@ -265,7 +278,11 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             if (H->opt.deterministic) { cur_pass = 3; grid_launch(s, l); }
             else if (T.defer && S.lvl_defer[l]) { cur_pass = 0; list_launch(s, l, 0, 0); cur_pass = 1; list_launch(s, l, 1, 1); cur_pass = 3; list_launch(s, l, 2, 3); }
             else { cur_pass = 3; list_launch(s, l, 0, 3); }
-            if (more) { panelA(l + 1); panelB(l + 1); if (tail_level(l + 1)) deferred_inv(s, l + 1); }
+            if (more) {
+                panelA(l + 1); panelB(l + 1);
+                if (tail_level(l + 1)) deferred_inv(s, l + 1);
+                if (!H->lvl_groups.empty() && &S == &H->sched[0]) for (int gi : H->lvl_groups[l + 1]) group_inverse(H, gi, s);
+            }
             if (rc_x) return rc_x;
             continue;
         }
@@ -284,6 +301,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);
         }
         if (tail_level(l)) deferred_inv(s, l);        // off the chain: the bulk stream waits for panel(l) anyway
+        if (!H->lvl_groups.empty() && &S == &H->sched[0] && !H->lvl_groups[l].empty()) {
+            // merged chain groups whose last member was factored at this level: their inverses on a stream of their own, after the members' panels and inverses
+            hipEvent_t e_g = next_event(H);
+            hipEventRecord(e_g, s); hipStreamWaitEvent(H->gstream, e_g, 0);
+            for (int gi : H->lvl_groups[l]) group_inverse(H, gi, H->gstream);
+        }
         cur_pass = 0; list_launch(ps, l, 0, 0);   // on the panel stream itself: diag_lu(l+1) follows in stream order, no event hop
         cur_pass = 1; list_launch(us, l, 1, 1);
         hipEvent_t e_u1 = next_event(H); hipEventRecord(e_u1, us);
@@ -311,7 +334,7 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         e_u2_prev = e_u2; e_bulk_prev2 = e_bulk_prev; e_bulk_prev = e_bulk;
         if (rc_x) return rc_x;
     }
-    if (lookahead && S.nlevels) { wait_on(s, ps); wait_on(s, us); wait_on(s, u2s); }
+    if (lookahead && S.nlevels) { wait_on(s, ps); wait_on(s, us); wait_on(s, u2s); if (!H->lvl_groups.empty() && H->gstream) wait_on(s, H->gstream); }
     HIPCHK(hipGetLastError());
     return rc_x;
 }
@@ -530,6 +553,7 @@ int ensure_inv(Handle *H)
             const int n0 = S.lvl_off[l], nn = S.lvl_off[l + 1] - n0, po = S.lvl_poff[l];
             eng::full_inv(H->stream, H->T, S.d_nodes + n0, S.d_finv_prefix + po, nn, S.finv_prefix[po + nn], S.max_nsupc[l]);
         }
+    for (size_t gi = 0; gi < H->groups.size(); ++gi) group_inverse(H, (int) gi, H->stream);
     H->inv_ready = true;
     return 0;
 }
@@ -622,7 +646,10 @@ static void zero_forest(Handle *H, LevelSched &S, double *x, int64_t ldx, int nr
 // Per level m: joined when it holds at most SLUAMD_JOIN_MAX_NODES supernodes (the recomputation-free joined units win where a level is a chain of round
 // trips; levels of hundreds of supernodes with several sources each keep the two-launch form).  The two forms meet in any order: a level's diagonal blocks
 // are either stored by strips or added by joined units into zeroed rows, and the level below hands over exactly the rows / columns its successor's form expects.
-static inline bool level_joined(const Handle *H, const LevelSched &S, int m) { return S.lvl_off[m + 1] - S.lvl_off[m] <= H->env.join_max_nodes; }
+static inline bool level_joined(const Handle *H, const LevelSched &S, int m)
+{
+    return S.lvl_off[m + 1] - S.lvl_off[m] <= H->env.join_max_nodes || (!S.lvl_has_group.empty() && S.lvl_has_group[m]);
+}
 static int solve_fwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
@@ -766,6 +793,7 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));
+        if (!rc && !H->ssched.empty() && H->ssched[z].join) return solve_fwd_join(H, H->ssched[z], d_x, ldx, nrhs);     // merged chain groups: the contracted schedule
         if (!rc && S.join && !use_chain(H, S)) return solve_fwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_fwd_links(H, S, d_x, ldx, nrhs);
     }
@@ -794,6 +822,7 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));      // (already there: the forward sweep ran first)
+        if (!rc && !H->ssched.empty() && H->ssched[z].join) return solve_bwd_join(H, H->ssched[z], d_x, ldx, nrhs);
         if (!rc && S.join && !use_chain(H, S)) return solve_bwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_bwd_links(H, S, d_x, ldx, nrhs);
     }

@@ -203,6 +203,8 @@ struct LevelSched {
     int2 *d_cf_waits = nullptr, *d_cb_waits = nullptr;
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> max_nsupc;     // per level
+    std::vector<uint8_t> lvl_has_group;   // (contracted schedule of the sweeps) the level holds a merged chain group: always run as a joined link
+    bool no_join = false;           // the sweeps follow Handle::ssched: no joined tables for this schedule
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner
     // Split panel solves (look-ahead schedule, 1 x 1 layers, real): per level the 64-row strips of L(:, k) / 64-column chunks of U(k, :) that the level's
     // part-0 tiles (destination: a diagonal block of the next level) read -- "urgent": solved first, on the panel stream, so that the next level's diagonal
@@ -274,6 +276,11 @@ struct SplitMap {
 };
 
 
+// merged chain groups of the sweeps (Handle::groups): device descriptors of eng::grp_gather / eng::gemm_batched
+struct GrpDesc { int nm, nG; int64_t ginv; int k[4], o[4], w[4]; };                                  // members: supernode, column offset inside the group, width
+struct GemmDesc { int64_t a, b, c; int lda, ldb, ldc, M, N, K, abase, bbase, cbase, neg; };        // 64 bytes
+constexpr int64_t GRP_SCR = 1024 * 1024;                                                           // doubles per scratch image: [LG | UG | TL | TU]
+
 // wall-clock laps of handle creation (sluamd_setup_times): where the pre-processing of a handle goes
 struct SetupTimer {
     std::vector<std::pair<std::string, double>> laps;
@@ -311,6 +318,8 @@ struct Handle {
         bool no_merge_tiles = false; // SLUAMD_NO_MERGE_TILES: every (L block, U block) pair keeps its own Schur tiles (round 3)
         bool no_level_split = false; // SLUAMD_NO_LEVEL_SPLIT: XY layers keep whole DAG levels (round 3's exchange scratch: the largest level)
         int panel_split_max_nodes = 1024;   // SLUAMD_PANEL_SPLIT: levels of at most this many supernodes solve their panels in two parts (urgent strips on the chain, the rest beside the next diagonal LU); 0 = off
+        bool solve_groups = false;   // SLUAMD_SOLVE_GROUPS=1: merged chain groups of the sweeps (Handle::groups)
+        int solve_group_level_nodes = 8;   // SLUAMD_SOLVE_GROUP_LEVEL_NODES: ... only where every member's level holds at most this many supernodes (latency-bound levels)
         int z_fuse_max_nodes = 16;   // SLUAMD_ZFUSE_MAX_NODES: complex16 sweeps run the levels of at most this many supernodes as fused links (one launch per level and sweep); 0 = never
         bool info_last = false;      // SLUAMD_INFO_LAST=1: `info` = the zero pivot met LAST on a rank (largest column; what pdgstrf2.c:568-571 leaves in *info), MIN over the ranks (pdgstrf3d.c:388-392); default: the first column
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
@@ -325,6 +334,17 @@ struct Handle {
     std::vector<void *> d_misc;  // everything else to free
     DevTables T{};
     std::vector<LevelSched> sched;  // one per Z level (forests) or a single one
+    // Merged chain groups of the sweeps (round 5; 1 x 1 x 1 grids, real, SLUAMD_SOLVE_GROUPS): up to four consecutive supernodes of a chain -- the pieces of one
+    // separator: every member but the first has the previous member as its ONLY child -- solved as ONE block of <= 1024 columns with the inverse of their block
+    // triangle (computed during the factorisation, beside the panel chain: group_inverse), so that four single-supernode levels of the sweeps become one.
+    // ssched: the level schedule of the sweeps on the DAG with every group contracted to one node (empty: the sweeps follow `sched`).
+    struct SolveGroup { int nm = 0, nG = 0, k[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0}; int64_t ginv = 0; int last_level = 0; int tile_off[7] = {0, 0, 0, 0, 0, 0, 0}; };
+    std::vector<SolveGroup> groups;
+    std::vector<int> grp_of;                  // [nsupers] group of a supernode, -1: none
+    std::vector<std::vector<int>> lvl_groups;  // [factor level] groups whose last member is factored at that level
+    std::vector<LevelSched> ssched;
+    GrpDesc *d_grpdesc = nullptr; GemmDesc *d_gemmdesc = nullptr; int4 *d_gemmtiles = nullptr; double *d_gscr = nullptr;
+    hipStream_t gstream = nullptr;            // group inverses run here, beside the factorisation
     std::vector<std::vector<int>> forest_nodes;   // ascending supernodes of the forest of every Z level on this layer's path (even when not factored here)
     std::vector<uint8_t> z_active;  // [Z levels] this layer factors that level's forest (!myZeroTrIdxs)
     std::vector<int> own_l_order, own_u_order;   // own L / U slots in value-arena order
@@ -418,6 +438,12 @@ void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const i
 inline int schur_rec_ints(int cfg, bool z) { return (cfg <= 1) ? 64 + 128 + 3 * 128 : 64 + 64 + 3 * 64; (void) z; }
 // Linv / Uinv of every owned diagonal block of `nodes` from the factored blocks + dinv (pdCompute_Diag_Inv, pdgstrs.c:842)
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int max_nsupc);
+// ---- merged chain groups of the sweeps (round 5): the inverse of the (<= 1024)-column block triangle of up to four consecutive chain supernodes ----
+// grp_gather: zero-fills nothing (the caller does), copies the members' Linv / Uinv into the diagonal blocks of the group's pair in T.inv and gathers the
+// off-diagonal blocks of the members' panels / skylines into the dense scratch images LG / UG (ld = nG); gemm_batched: C = (-)A B on 64 x 64 tiles (fp64 MFMA),
+// operands in T.inv (base 0) or the scratch (base 1)
+void grp_gather(hipStream_t s, const DevTables &T, const GrpDesc *d_desc, double *scratch);
+void gemm_batched(hipStream_t s, const DevTables &T, const GemmDesc *d_descs, const int4 *d_tiles, int ntiles, double *scratch);
 void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs, int max_nsupc);
 // units != null: the launch runs the host-built (supernode, strip / chunk) list `units[0 .. nwork)` instead of the level's prefix arrays.
 // Two vectors (they may be the same one: XY layers, profiling): the update reads solved blocks from xsrc / xcols and subtracts from x

@@ -2015,7 +2015,8 @@ __device__ __forceinline__ void join_bwd_body(const DevTables &T, const int4 *re
     const double *Ti = T.inv + (((int64_t) b.y << 32) | (uint32_t) b.x);
     const double *Uv = T.val + (((int64_t) c2.y << 32) | (uint32_t) c2.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nc = min(64, ns - 64 * c), row = 64 * st + lane, i = 64 * c + lane;
+    const int nc = min(64, ns - 64 * c), row = 64 * st + lane;
+    const int i = 64 * c + lane - c2.z, nsm = c2.w;     // row inside the supernode whose U row holds block c (a member of a merged group: offset c2.z, width c2.w)
     const bool rv = row < ns;
     double tv[CPB];
 #pragma unroll
@@ -2039,8 +2040,8 @@ __device__ __forceinline__ void join_bwd_body(const DevTables &T, const int4 *re
 #pragma unroll
             for (int u = 0; u < NBT; ++u) {
                 const int e = wave * NBT + u;
-                const int ld = e < cnt ? s_nld[e] : ns;
-                uv[u] = (i >= ld && i < ns) ? __builtin_nontemporal_load(Uv + s_ncp[min(e, cnt - 1)] - ld + i) : 0.0;
+                const int ld = e < cnt ? s_nld[e] : nsm;
+                uv[u] = (i >= ld && i < nsm) ? __builtin_nontemporal_load(Uv + s_ncp[min(e, cnt - 1)] - ld + i) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < NBT; ++u) { const int e = wave * NBT + u; acc += uv[u] * (e < cnt ? s_nx[e] : 0.0); }
@@ -2343,7 +2344,108 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
     else hipLaunchKernelGGL(k_panel_gemm<64>, dim3(nl + nu), dim3(256), 0, s, T, nodes, lprefix, uprefix, nn, nl, units);
 }
 
+// ---- merged chain groups (sluamd_internal.h): gather of the group's block triangle, batched dense products ----------------------------------------------------------
+// One workgroup per task of ONE group: task t < nm: diagonal member t (its Linv / Uinv into the group's pair); then the member pairs (i > k): L block of member i in
+// panel k -> LG, and (i < k): U block of column member k in row i -> UG.  Rows / columns absent from a block stay zero (the caller zero-fills the images).
+__global__ __launch_bounds__(256) void k_grp_gather(DevTables T, const GrpDesc *__restrict__ gd, double *__restrict__ scr)
+{
+    const GrpDesc g = *gd;
+    const int nG = g.nG, tid = threadIdx.x;
+    double *LinvG = T.inv + g.ginv, *UinvG = LinvG + (int64_t) nG * nG;
+    double *LG = scr, *UG = scr + GRP_SCR;
+    int t = blockIdx.x;
+    if (t < g.nm) {
+        const int k = g.k[t], o = g.o[t], w = g.w[t];
+        const double *Li = T.inv + T.sn_inv[k], *Ui = Li + (int64_t) w * w;
+        for (int idx = tid; idx < w * w; idx += 256) {
+            const int r = idx % w, c = idx / w;
+            LinvG[(o + r) + (int64_t) (o + c) * nG] = Li[idx];
+            UinvG[(o + r) + (int64_t) (o + c) * nG] = Ui[idx];
+        }
+        return;
+    }
+    t -= g.nm;
+    const int npair = g.nm * (g.nm - 1) / 2;
+    const bool upper = t >= npair;
+    if (upper) t -= npair;
+    int i = 1, kk = 0;                                        // pair index t -> (i, kk), kk < i
+    for (int q = 0; q < t; ++q) { if (++kk == i) { ++i; kk = 0; } }
+    if (i >= g.nm) return;
+    if (!upper) {      // rows of member i inside the panel of member kk
+        const int mi = g.k[i], mk = g.k[kk], oi = g.o[i], ok = g.o[kk], wk = g.w[kk];
+        const int lb0 = T.sn_lb_off[mk], nb = T.sn_nlb[mk];
+        int b = -1;
+        for (int q = 0; q < nb; ++q) if (T.lb_gid[lb0 + q] == mi) { b = lb0 + q; break; }
+        if (b < 0) return;
+        const int nbrow = T.lb_nbrow[b], ro = T.lb_rowoff[b], lda = T.sn_nsupr[mk], f = T.xsup[mi];
+        const double *Lp = T.val + T.sn_lval[mk] + ro;
+        const int *rows = T.lrow + T.sn_lrow[mk] + ro;
+        for (int idx = tid; idx < nbrow * wk; idx += 256) {
+            const int r = idx % nbrow, c = idx / nbrow;
+            LG[(oi + rows[r] - f) + (int64_t) (ok + c) * nG] = Lp[r + (size_t) c * lda];
+        }
+    } else {           // columns of member i (as the LATER member) inside the U row of member kk: block (kk, i), kk < i
+        const int mr = g.k[kk], mc = g.k[i], orr = g.o[kk], oc = g.o[i], wr = g.w[kk];
+        const int ub0 = T.sn_ub_off[mr], nub = T.sn_nub[mr];
+        int b = -1;
+        for (int q = 0; q < nub; ++q) if (T.ub_gid[ub0 + q] == mc) { b = ub0 + q; break; }
+        if (b < 0) return;
+        const int ncol = T.ub_ncols[b], st = T.ub_stcol[b], f = T.xsup[mc];
+        const double *Uv = T.val + T.sn_uval[mr];
+        const int64_t c0 = T.sn_ucol[mr] + st;
+        for (int idx = tid; idx < ncol * wr; idx += 256) {
+            const int r = idx % wr, q = idx / wr;
+            const int ld = T.ucol_ld[c0 + q];
+            if (r >= ld) UG[(orr + r) + (int64_t) (oc + T.ucol_gc[c0 + q] - f) * nG] = Uv[T.ucol_cp[c0 + q] + (r - ld)];
+        }
+    }
+}
+
+// C (M x N) = (-) A (M x K) B (K x N), column-major, 64 x 64 tile per workgroup, 32 x 32 per wave, operand fragments straight from memory (L2-resident panels of
+// <= 8 MB): D[(l >> 4) + 4 r][l & 15] = sum_k A[l & 15][l >> 4] B[l >> 4][l & 15].  M, N multiples of 16, K of 4 (supernode widths of grouped members are).
+__global__ __launch_bounds__(256) void k_gemm_batched(DevTables T, const GemmDesc *__restrict__ descs, const int4 *__restrict__ tiles, double *__restrict__ scr)
+{
+    const int4 tl = tiles[blockIdx.x];
+    const GemmDesc d = descs[tl.x];
+    const double *A = (d.abase ? scr : T.inv) + d.a, *B = (d.bbase ? scr : T.inv) + d.b;
+    double *C = (d.cbase ? scr : T.inv) + d.c;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int row0 = 64 * tl.y + 32 * (wave & 1), col0 = 64 * tl.z + 32 * (wave >> 1);
+    if (row0 >= d.M || col0 >= d.N) return;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int ra0 = min(row0 + li, d.M - 1), ra1 = min(row0 + 16 + li, d.M - 1), cb0 = min(col0 + li, d.N - 1), cb1 = min(col0 + 16 + li, d.N - 1);
+    for (int k4 = 0; k4 < d.K; k4 += 4) {
+        const int kq = k4 + lk;
+        const double a0 = A[ra0 + (size_t) kq * d.lda], a1 = A[ra1 + (size_t) kq * d.lda];
+        const double b0 = B[kq + (size_t) cb0 * d.ldb], b1 = B[kq + (size_t) cb1 * d.ldb];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    const double sg = d.neg ? -1.0 : 1.0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * a + lk + 4 * r, col = col0 + 16 * b + li;
+                if (row < d.M && col < d.N) C[row + (size_t) col * d.ldc] = sg * acc[a][b][r];
+            }
+}
+
 static const bool g_full_inv64 = getenv("SLUAMD_NO_FULL_INV64") == nullptr;
+void grp_gather(hipStream_t s, const DevTables &T, const GrpDesc *d_desc, double *scratch)
+{
+    hipLaunchKernelGGL(k_grp_gather, dim3(4 + 6 + 6), dim3(256), 0, s, T, d_desc, scratch);
+}
+void gemm_batched(hipStream_t s, const DevTables &T, const GemmDesc *d_descs, const int4 *d_tiles, int ntiles, double *scratch)
+{
+    if (ntiles > 0) hipLaunchKernelGGL(k_gemm_batched, dim3(ntiles), dim3(256), 0, s, T, d_descs, d_tiles, scratch);
+}
 void full_inv(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, int mx)
 {
     if (nwork > 0 && mx <= 64 && g_full_inv64) { hipLaunchKernelGGL(k_full_inv64, dim3((2 * nn + 3) / 4), dim3(256), 0, s, T, nodes, prefix, nn); return; }   // levels of narrow supernodes

@@ -887,47 +887,56 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
 
 // Joined sweeps (LevelSched::join): near flags, joined diagonal units, regular unit records per level.  Returns false (nothing kept) when a panel's rows
 // inside one block are not ascending -- the rows of a column block of the target would not be one range.
+// Merged chain groups (Handle::groups; S is then the contracted schedule Handle::ssched): a group is ONE node of its level -- its joined units are the 64 x 64 blocks
+// of the GROUP's inverse (up to 1024 columns), their sources the panels of the previous level with rows in ANY member; rows / columns of a member's panel / U row that
+// belong to a later member of the same group are nobody's to update (the group's inverse couples the members): flagged 2 ("dead"), skipped by the regular units.
 static bool build_join(Handle &H, LevelSched &S, const HostTables &t)
 {
     const HostStruct &hs = H.hs;
     const std::vector<int> &lev = S.sn_level;
     const int nl = S.nlevels;
     auto lohi = [](int64_t v, int &lo, int &hi) { lo = (int) (uint32_t) v; hi = (int) (v >> 32); };
+    auto grp = [&](int k) { return H.grp_of.empty() ? -1 : H.grp_of[k]; };
     struct Src { int k, bi; };
     std::vector<std::vector<Src>> srcs(hs.nsupers);
+    std::vector<int> near_off(hs.nsupers, 0), near_cnt(hs.nsupers, 0);      // per supernode: its near columns in S.jb_aux
     // near flags + the sources of every supernode
     for (int k : S.nodes) {
-        const int l = lev[k], fl = t.sn_flags[k];
+        const int l = lev[k], fl = t.sn_flags[k], gk = grp(k);
         if (fl & SNF_L_OWN)
             for (int b = 0; b < t.sn_nlb[k]; ++b) {
                 const int bi = t.sn_lb_off[k] + b, g = t.lb_gid[bi];
-                if (g == k || lev[g] != l + 1) continue;
+                if (g == k) continue;
+                const bool dead = gk >= 0 && grp(g) == gk;
+                if (!dead && lev[g] != l + 1) continue;
                 const int64_t r0 = t.sn_lrow[k] + t.lb_rowoff[bi];
                 for (int r = 0; r < t.lb_nbrow[bi]; ++r) {
                     if (r && t.lrow[r0 + r] <= t.lrow[r0 + r - 1]) return false;
-                    H.h_lrow_near[r0 + r] = 1;
+                    H.h_lrow_near[r0 + r] = dead ? 2 : 1;
                 }
-                srcs[g].push_back({k, bi});
+                if (!dead) srcs[g].push_back({k, bi});
             }
         if (fl & SNF_U_OWN)
             for (int b = 0; b < t.sn_nub[k]; ++b) {
                 const int bi = t.sn_ub_off[k] + b, g = t.ub_gid[bi];
-                if (!t.ub_ncols[bi] || lev[g] != l + 1) continue;
-                for (int c = 0; c < t.ub_ncols[bi]; ++c) H.h_ucol_near[t.sn_ucol[k] + t.ub_stcol[bi] + c] = 1;
+                if (!t.ub_ncols[bi]) continue;
+                const bool dead = gk >= 0 && grp(g) == gk;
+                if (!dead && lev[g] != l + 1) continue;
+                for (int c = 0; c < t.ub_ncols[bi]; ++c) H.h_ucol_near[t.sn_ucol[k] + t.ub_stcol[bi] + c] = dead ? 2 : 1;
             }
     }
     S.jf_off.assign(nl + 1, 0); S.jb_off.assign(nl + 1, 0); S.jfu_off.assign(nl + 1, 0); S.jbu_off.assign(nl + 1, 0);
     for (int l = 0; l < nl; ++l) {
+        // regular units of every supernode of the level (members of groups included), and the near-column lists of the backward joined units
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
             const int k = S.nodes[i], fl = t.sn_flags[k];
-            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst, nb = (ns + 63) / 64;
-            // regular units: every strip / chunk with something left to do
+            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst;
             if (fl & SNF_L_OWN) {
                 const int ldiag = t.sn_ldiag[k], lda = t.sn_nsupr[k];
                 for (int row0 = ldiag; row0 < lda; row0 += 64) {
                     int nnear = 0;
                     const int nr = std::min(64, lda - row0);
-                    for (int r = 0; r < nr; ++r) nnear += H.h_lrow_near[t.sn_lrow[k] + row0 + r];
+                    for (int r = 0; r < nr; ++r) nnear += H.h_lrow_near[t.sn_lrow[k] + row0 + r] != 0;
                     if (nnear == nr) continue;
                     int4 b; lohi(t.sn_lval[k] + row0, b.x, b.y); lohi(t.sn_lrow[k] + row0, b.z, b.w);
                     S.jfu_recs.push_back(make_int4(fst, ns | (nnear ? 1 << 16 : 0), lda, row0)); S.jfu_recs.push_back(b);
@@ -938,58 +947,235 @@ static bool build_join(Handle &H, LevelSched &S, const HostTables &t)
                 for (int c0 = 0; c0 < ncolu; c0 += 64) {
                     int nnear = 0;
                     const int nc = std::min(64, ncolu - c0);
-                    for (int c = 0; c < nc; ++c) nnear += H.h_ucol_near[t.sn_ucol[k] + c0 + c];
+                    for (int c = 0; c < nc; ++c) nnear += H.h_ucol_near[t.sn_ucol[k] + c0 + c] != 0;
                     if (nnear == nc) continue;
                     int4 b; lohi(t.sn_ucol[k] + c0, b.x, b.y); lohi(t.sn_uval[k], b.z, b.w);
                     S.jbu_recs.push_back(make_int4(fst, ns | (nnear ? 1 << 16 : 0), nc, 0)); S.jbu_recs.push_back(b);
                 }
+                near_off[k] = (int) S.jb_aux.size();
+                for (int c = 0; c < ncolu; ++c) {
+                    const int64_t ci = t.sn_ucol[k] + c;
+                    if (H.h_ucol_near[ci] == 1) S.jb_aux.push_back(make_int4(t.ucol_ld[ci], t.ucol_cp[ci], t.ucol_gc[ci], 0));
+                }
+                near_cnt[k] = (int) S.jb_aux.size() - near_off[k];
             }
-            if (!(fl & SNF_OWN_DIAG)) continue;
-            // forward joined units of j = k: block (s, c), c <= s, sources = the level-(l-1) panels with rows in column block c (none at level 0)
-            {
-                for (int c = 0; c < nb; ++c) {
-                    std::vector<int4> sv;
-                    for (const Src &q : srcs[k]) {
-                        const int64_t r0 = t.sn_lrow[q.k] + t.lb_rowoff[q.bi];
-                        const int nbr = t.lb_nbrow[q.bi];
-                        const int *rows = t.lrow.data() + r0;
-                        const int a = (int) (std::lower_bound(rows, rows + nbr, fst + 64 * c) - rows), e = (int) (std::lower_bound(rows, rows + nbr, fst + 64 * c + 64) - rows);
-                        if (e <= a) continue;
-                        const int fk = hs.xsup[q.k];
-                        int4 v; lohi(t.sn_lval[q.k] + t.lb_rowoff[q.bi] + a, v.x, v.y); lohi(r0 + a, v.z, v.w);
-                        sv.push_back(make_int4(fk, hs.xsup[q.k + 1] - fk, t.sn_nsupr[q.k], e - a)); sv.push_back(v);
-                    }
-                    const int nsrc = (int) sv.size() / 2;
-                    int ovf = 0;
-                    if (nsrc > 3) { ovf = (int) S.jf_aux.size() / 2; S.jf_aux.insert(S.jf_aux.end(), sv.begin() + 6, sv.end()); }
-                    for (int st = c; st < nb; ++st) {
-                        int4 b; lohi(t.sn_inv[k], b.x, b.y); b.z = nsrc; b.w = ovf;
-                        S.jf_recs.push_back(make_int4(fst, ns, st, c)); S.jf_recs.push_back(b);
-                        for (int q = 0; q < 6; ++q) S.jf_recs.push_back(q < (int) sv.size() ? sv[q] : make_int4(0, 0, 0, 0));
-                    }
+        }
+        // joined units: one node = one supernode, or one merged group (emitted at its first member; all members are in this level)
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+            const int k = S.nodes[i];
+            if (!(t.sn_flags[k] & SNF_OWN_DIAG)) continue;
+            const int gk = grp(k);
+            int nm = 1, mem[4] = {k, 0, 0, 0}, mo[4] = {0, 0, 0, 0}, mw[4] = {hs.xsup[k + 1] - hs.xsup[k], 0, 0, 0};
+            int64_t linv = t.sn_inv[k], uinv = t.sn_inv[k] + (int64_t) mw[0] * mw[0];
+            if (gk >= 0) {
+                const Handle::SolveGroup &G = H.groups[gk];
+                if (G.k[0] != k) continue;                        // the group was emitted with its first member
+                nm = G.nm;
+                for (int m = 0; m < nm; ++m) { mem[m] = G.k[m]; mo[m] = G.o[m]; mw[m] = G.w[m]; }
+                linv = G.ginv; uinv = G.ginv + (int64_t) G.nG * G.nG;
+            }
+            const int fst = hs.xsup[k], ns = mo[nm - 1] + mw[nm - 1], nb = (ns + 63) / 64;
+            auto member_of_block = [&](int c) { int m = 0; while (m + 1 < nm && mo[m + 1] <= 64 * c) ++m; return m; };
+            // forward: block (s, c), c <= s, sources = the panels of the previous level with rows in column block c (none at level 0)
+            for (int c = 0; c < nb; ++c) {
+                const int m = member_of_block(c);
+                std::vector<int4> sv;
+                for (const Src &q : srcs[mem[m]]) {
+                    const int64_t r0 = t.sn_lrow[q.k] + t.lb_rowoff[q.bi];
+                    const int nbr = t.lb_nbrow[q.bi];
+                    const int *rows = t.lrow.data() + r0;
+                    const int a = (int) (std::lower_bound(rows, rows + nbr, fst + 64 * c) - rows), e = (int) (std::lower_bound(rows, rows + nbr, fst + 64 * c + 64) - rows);
+                    if (e <= a) continue;
+                    const int fk = hs.xsup[q.k];
+                    int4 v; lohi(t.sn_lval[q.k] + t.lb_rowoff[q.bi] + a, v.x, v.y); lohi(r0 + a, v.z, v.w);
+                    sv.push_back(make_int4(fk, hs.xsup[q.k + 1] - fk, t.sn_nsupr[q.k], e - a)); sv.push_back(v);
+                }
+                const int nsrc = (int) sv.size() / 2;
+                int ovf = 0;
+                if (nsrc > 3) { ovf = (int) S.jf_aux.size() / 2; S.jf_aux.insert(S.jf_aux.end(), sv.begin() + 6, sv.end()); }
+                for (int st = c; st < nb; ++st) {
+                    int4 b; lohi(linv, b.x, b.y); b.z = nsrc; b.w = ovf;
+                    S.jf_recs.push_back(make_int4(fst, ns, st, c)); S.jf_recs.push_back(b);
+                    for (int q = 0; q < 6; ++q) S.jf_recs.push_back(q < (int) sv.size() ? sv[q] : make_int4(0, 0, 0, 0));
                 }
             }
-            // backward joined units of k: block (s, c), s <= c; near columns = every column of a level-(l+1) supernode in U(k, :) (none at the top level)
-            {
-                const int noff = (int) S.jb_aux.size();
-                if (fl & SNF_U_OWN)
-                    for (int c = 0; c < t.sn_ncolu[k]; ++c) {
-                        const int64_t ci = t.sn_ucol[k] + c;
-                        if (H.h_ucol_near[ci]) S.jb_aux.push_back(make_int4(t.ucol_ld[ci], t.ucol_cp[ci], t.ucol_gc[ci], 0));
-                    }
-                const int ncnt = (int) S.jb_aux.size() - noff;
-                for (int c = 0; c < nb; ++c)
-                    for (int st = 0; st <= c; ++st) {
-                        int4 b; lohi(t.sn_inv[k] + (int64_t) ns * ns, b.x, b.y); b.z = noff; b.w = ncnt;
-                        int4 u; lohi(t.sn_uval[k], u.x, u.y); u.z = u.w = 0;
-                        S.jb_recs.push_back(make_int4(fst, ns, st, c)); S.jb_recs.push_back(b); S.jb_recs.push_back(u); S.jb_recs.push_back(make_int4(0, 0, 0, 0));
-                    }
+            // backward: block (s, c), s <= c; near columns = every column of the next level in the U row of the member that holds block c
+            for (int c = 0; c < nb; ++c) {
+                const int m = member_of_block(c), km = mem[m];
+                for (int st = 0; st <= c; ++st) {
+                    int4 b; lohi(uinv, b.x, b.y); b.z = near_off[km]; b.w = near_cnt[km];
+                    int4 u; lohi(t.sn_uval[km], u.x, u.y); u.z = mo[m]; u.w = mw[m];
+                    S.jb_recs.push_back(make_int4(fst, ns, st, c)); S.jb_recs.push_back(b); S.jb_recs.push_back(u); S.jb_recs.push_back(make_int4(0, 0, 0, 0));
+                }
             }
         }
         S.jf_off[l + 1] = (int) S.jf_recs.size() / 8; S.jb_off[l + 1] = (int) S.jb_recs.size() / 4;
         S.jfu_off[l + 1] = (int) S.jfu_recs.size() / 2; S.jbu_off[l + 1] = (int) S.jbu_recs.size() / 2;
     }
     return true;
+}
+
+// Merged chain groups: detection, storage of their inverses behind the per-supernode pairs of T.inv, the dense products that build them (eng::gemm_batched
+// descriptors + tiles per stage) and the solve levels of the DAG with every group contracted to one node.
+//   lower:  X_ij = -Linv_ii sum_{k = j .. i-1} L_ik X_kj   (i > j; by distance d = i - j)        upper:  X_ij = -Uinv_ii sum_{k = i+1 .. j} U_ik X_kj   (i < j)
+// with the block rows of L_G / U_G gathered into dense images (eng::grp_gather): T_ij = LG[rows of i, columns of j .. i-1] LinvG[rows of j .. i-1, columns of j] is ONE product.
+static void build_solve_groups(Handle &H, const SlotInput &in, HostTables &t, const std::vector<int> &list, const std::vector<int> &lvl, const LevelSched &S,
+                               std::vector<int> &slev, int &nslev, std::vector<GemmDesc> &descs, std::vector<int4> &tiles)
+{
+    const HostStruct &hs = H.hs;
+    const int ns = hs.nsupers;
+    H.grp_of.assign(ns, -1);
+    std::vector<int> parent(ns, -1), nchild(ns, 0);
+    for (int k : list) {
+        int p = -1;
+        for (int g : in.succ[k]) if (g > k && (p < 0 || g < p)) p = g;
+        parent[k] = p;
+        if (p >= 0) nchild[p]++;
+    }
+    auto level_nodes = [&](int l) { return S.lvl_off[l + 1] - S.lvl_off[l]; };
+    const int cap = H.env.solve_group_level_nodes;
+    for (size_t ii = 0; ii < list.size(); ++ii) {
+        const int k0 = list[ii];
+        if (H.grp_of[k0] >= 0 || !(t.sn_flags[k0] & SNF_OWN_DIAG) || level_nodes(lvl[k0]) > cap) continue;
+        Handle::SolveGroup G;
+        int cur = k0, off = 0;
+        auto width = [&](int k) { return hs.xsup[k + 1] - hs.xsup[k]; };
+        if (width(k0) % 16) continue;
+        G.k[0] = k0; G.o[0] = 0; G.w[0] = width(k0); G.nm = 1; off = width(k0);
+        while (G.nm < 4) {
+            const int nx = cur + 1;
+            if (nx >= ns || parent[cur] != nx || nchild[nx] != 1 || lvl[nx] != lvl[cur] + 1 || level_nodes(lvl[nx]) > cap || H.grp_of[nx] >= 0) break;
+            if (width(cur) % 64 || width(nx) % 16 || off + width(nx) > 1024 || !(t.sn_flags[nx] & SNF_OWN_DIAG)) break;
+            G.k[G.nm] = nx; G.o[G.nm] = off; G.w[G.nm] = width(nx); off += width(nx); ++G.nm; cur = nx;
+        }
+        if (G.nm < 2) continue;
+        G.nG = off;
+        G.ginv = t.inv_total; t.inv_total += (int64_t) 2 * G.nG * G.nG;
+        G.last_level = lvl[G.k[G.nm - 1]];
+        const int gi = (int) H.groups.size();
+        for (int m = 0; m < G.nm; ++m) H.grp_of[G.k[m]] = gi;
+        // the products, stage by stage: 2 (d - 1) = sums T, 2 (d - 1) + 1 = X = -inv T, both triangles in one launch
+        const int nG = G.nG;
+        const int64_t LinvG = G.ginv, UinvG = G.ginv + (int64_t) nG * nG, LGs = 0, UGs = GRP_SCR, TLs = 2 * GRP_SCR, TUs = 3 * GRP_SCR;
+        auto at = [&](int64_t base, int r, int c) { return base + r + (int64_t) c * nG; };
+        auto add = [&](const GemmDesc &d) {
+            const int di = (int) descs.size();
+            descs.push_back(d);
+            for (int tc = 0; tc < (d.N + 63) / 64; ++tc) for (int tr = 0; tr < (d.M + 63) / 64; ++tr) tiles.push_back(make_int4(di, tr, tc, 0));
+        };
+        G.tile_off[0] = (int) tiles.size();
+        for (int d = 1; d < G.nm; ++d) {
+            for (int i = d; i < G.nm; ++i) {          // lower sums
+                const int j = i - d;
+                add(GemmDesc{at(LGs, G.o[i], G.o[j]), at(LinvG, G.o[j], G.o[j]), at(TLs, G.o[i], G.o[j]), nG, nG, nG, G.w[i], G.w[j], G.o[i] - G.o[j], 1, 0, 1, 0});
+            }
+            for (int i = 0; i + d < G.nm; ++i) {      // upper sums
+                const int j = i + d;
+                add(GemmDesc{at(UGs, G.o[i], G.o[i + 1]), at(UinvG, G.o[i + 1], G.o[j]), at(TUs, G.o[i], G.o[j]), nG, nG, nG, G.w[i], G.w[j], G.o[j] + G.w[j] - G.o[i + 1], 1, 0, 1, 0});
+            }
+            G.tile_off[2 * d - 1] = (int) tiles.size();
+            for (int i = d; i < G.nm; ++i) {
+                const int j = i - d;
+                add(GemmDesc{at(LinvG, G.o[i], G.o[i]), at(TLs, G.o[i], G.o[j]), at(LinvG, G.o[i], G.o[j]), nG, nG, nG, G.w[i], G.w[j], G.w[i], 0, 1, 0, 1});
+            }
+            for (int i = 0; i + d < G.nm; ++i) {
+                const int j = i + d;
+                add(GemmDesc{at(UinvG, G.o[i], G.o[i]), at(TUs, G.o[i], G.o[j]), at(UinvG, G.o[i], G.o[j]), nG, nG, nG, G.w[i], G.w[j], G.w[i], 0, 1, 0, 1});
+            }
+            G.tile_off[2 * d] = (int) tiles.size();
+        }
+        for (int q = 2 * G.nm - 1; q < 7; ++q) G.tile_off[q] = (int) tiles.size();
+        H.groups.push_back(G);
+    }
+    H.lvl_groups.assign(S.nlevels, {});
+    for (size_t gi = 0; gi < H.groups.size(); ++gi) H.lvl_groups[H.groups[gi].last_level].push_back((int) gi);
+    // solve levels: longest path in the DAG with every group contracted (members are consecutive supernodes: every external predecessor of a member precedes the first)
+    std::vector<int> nlev_of(ns, -1);
+    auto node = [&](int k) { return H.grp_of[k] >= 0 ? H.groups[H.grp_of[k]].k[0] : k; };
+    for (int k : list) nlev_of[k] = 0;
+    int maxl = 0;
+    for (int k : list) {
+        const int nk = node(k), l1 = nlev_of[nk] + 1;
+        for (int g : in.succ[k]) { if (nlev_of[g] < 0) continue; const int ng = node(g); if (ng != nk && nlev_of[ng] < l1) nlev_of[ng] = l1; }
+        maxl = std::max(maxl, nlev_of[nk]);
+    }
+    slev.assign(ns, -1);
+    for (int k : list) slev[k] = nlev_of[node(k)];
+    nslev = list.empty() ? 0 : maxl + 1;
+}
+
+// The schedule of the sweeps on the contracted DAG: the fields of LevelSched the solve drivers and upload_schedule read (node lists, unit lists of the two-launch
+// form, diagonal strips); the factorisation keeps its own schedule.
+static void build_solve_sched(Handle &H, const HostTables &t, const std::vector<int> &list, const std::vector<int> &slev, int nslev, LevelSched &S)
+{
+    const HostStruct &hs = H.hs;
+    S.nlevels = nslev;
+    S.sn_level = slev;
+    S.lvl_off.assign(nslev + 1, 0);
+    for (int k : list) S.lvl_off[slev[k] + 1]++;
+    for (int l = 0; l < nslev; ++l) S.lvl_off[l + 1] += S.lvl_off[l];
+    S.nodes.resize(list.size());
+    std::vector<int> fill(S.lvl_off.begin(), S.lvl_off.end() - (nslev ? 1 : 0));
+    for (int k : list) S.nodes[fill[slev[k]]++] = k;
+    S.n_big.assign(nslev, 0);
+    S.lvl_soff.assign(nslev + 1, 0); S.lvl_poff.assign(nslev + 1, 0);
+    for (int l = 0; l < nslev; ++l) { S.lvl_soff[l + 1] = S.lvl_soff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 2; S.lvl_poff[l + 1] = S.lvl_poff[l] + (S.lvl_off[l + 1] - S.lvl_off[l]) + 1; }
+    S.max_nsupc.assign(nslev, 0);
+    for (int l = 0; l < nslev; ++l)
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+            const int k = S.nodes[i];
+            const int w = H.grp_of[k] >= 0 ? H.groups[H.grp_of[k]].nG : nsupc_of(hs, k);      // the joined units stage a source's x (<= 256) and index up to the node's width
+            S.max_nsupc[l] = std::max(S.max_nsupc[l], std::min(w, 256));
+        }
+    S.fu_off.assign(2 * nslev + 1, 0); S.bu_off.assign(2 * nslev + 1, 0);
+    std::vector<uint8_t> urg;
+    for (int l = 0; l < nslev; ++l)
+        for (int part = 0; part < 2; ++part) {
+            for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+                const int k = S.nodes[i], fl = t.sn_flags[k];
+                const int ldiag = t.sn_ldiag[k];
+                const int nstrip = (fl & SNF_L_OWN) ? (t.sn_nsupr[k] - ldiag + 63) / 64 : 0;
+                urg.assign(nstrip, 0);
+                for (int b = 0; b < t.sn_nlb[k] && nstrip; ++b) {
+                    const int bi = t.sn_lb_off[k] + b;
+                    if (t.lb_gid[bi] == k || slev[t.lb_gid[bi]] != l + 1) continue;
+                    const int r0 = t.lb_rowoff[bi] - ldiag, r1 = r0 + t.lb_nbrow[bi] - 1;
+                    for (int sidx = r0 / 64; sidx <= r1 / 64; ++sidx) urg[sidx] = 1;
+                }
+                for (int sidx = 0; sidx < nstrip; ++sidx) if ((urg[sidx] != 0) == (part == 0)) S.fwd_units.push_back(make_int2(k, sidx));
+                const int nchunk = (fl & SNF_U_OWN) ? (t.sn_ncolu[k] + 63) / 64 : 0;
+                urg.assign(nchunk, 0);
+                for (int b = 0; b < t.sn_nub[k] && nchunk; ++b) {
+                    const int bi = t.sn_ub_off[k] + b;
+                    if (!t.ub_ncols[bi] || slev[t.ub_gid[bi]] != l + 1) continue;
+                    const int c0 = t.ub_stcol[bi], c1 = c0 + t.ub_ncols[bi] - 1;
+                    for (int c = c0 / 64; c <= c1 / 64; ++c) urg[c] = 1;
+                }
+                for (int c = 0; c < nchunk; ++c) if ((urg[c] != 0) == (part == 0)) S.bwd_units.push_back(make_int2(k, c));
+            }
+            S.fu_off[2 * l + part + 1] = (int) S.fwd_units.size();
+            S.bu_off[2 * l + part + 1] = (int) S.bwd_units.size();
+        }
+    S.diag_units.clear(); S.du_off.assign(nslev + 1, 0);
+    for (int l = 0; l < nslev; ++l) {
+        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
+            const int k = S.nodes[i];
+            if (!(t.sn_flags[k] & SNF_OWN_DIAG)) continue;
+            for (int st = 0; st < (nsupc_of(hs, k) + 63) / 64; ++st) S.diag_units.push_back(make_int2(k, st));
+        }
+        S.du_off[l + 1] = (int) S.diag_units.size();
+    }
+    S.lvl_has_group.assign(nslev, 0);
+    for (int k : list) if (H.grp_of[k] >= 0) S.lvl_has_group[slev[k]] = 1;
+    S.chain_l0 = -1;
+    S.lvl_defer.assign(nslev, 0);
+    S.u_off.assign(8 * nslev + 1, 0);
+    S.ps_off.assign(4 * (size_t) nslev + 1, 0);
+    const int psz = S.lvl_poff[nslev];
+    for (auto *v : {&S.tile_prefix}) v->assign(S.lvl_soff[nslev], 0);
+    for (auto *v : {&S.ltr_prefix, &S.utr_prefix, &S.fwd_prefix, &S.bwd_prefix, &S.inv_prefix, &S.zltr_prefix, &S.dg_prefix, &S.finv_prefix, &S.zfwd_prefix, &S.zffu_prefix, &S.zbfu_prefix})
+        v->assign(psz, 0);
+    S.dg_off.assign(psz, 0);
 }
 
 static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
@@ -1041,7 +1227,7 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
         std::vector<int4>().swap(S.fwd_recs); std::vector<int4>().swap(S.bwd_recs); std::vector<int4>().swap(S.diag_recs);
         H.setup.lap("upload.sweep_unit_records");
         S.join = false;
-        if (H.grid.Pr * H.grid.Pc == 1 && H.env.solve_join && !H.h_lrow_near.empty()) {
+        if (H.grid.Pr * H.grid.Pc == 1 && H.env.solve_join && !H.h_lrow_near.empty() && !S.no_join) {
             const std::vector<uint8_t> keep_l = H.h_lrow_near, keep_u = H.h_ucol_near;
             if (build_join(H, S, t)) {
                 S.join = true;
@@ -1303,11 +1489,24 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
 
     // ---- 6. schedules ----
     int nlevtot = 0;
+    std::vector<GemmDesc> grp_descs;
+    std::vector<int4> grp_tiles;
     for (int zl = 0; zl < nz; ++zl) {
         if (!in.z_active[zl]) continue;
         LevelSched &S = H->sched[zl];
         build_schedule(*H, t, in.lists[zl], lvl[zl], nlev[zl], S);
         nlevtot += S.nlevels;
+        // merged chain groups of the sweeps: one rank, one forest, real arithmetic, the list schedules (not the deterministic mode)
+        if (H->env.solve_groups && !xy && nz == 1 && g.size() == 1 && !H->z && !H->opt.deterministic && H->env.solve_join) {
+            std::vector<int> slev;
+            int nslev = 0;
+            build_solve_groups(*H, in, t, in.lists[zl], lvl[zl], S, slev, nslev, grp_descs, grp_tiles);
+            if (!H->groups.empty()) {
+                H->ssched.assign(nz, LevelSched());
+                build_solve_sched(*H, t, in.lists[zl], slev, nslev, H->ssched[zl]);
+                S.no_join = true;
+            } else H->grp_of.clear();
+        }
         // exchange plan into the schedule; own diagonal blocks of each level packed in ascending supernode order
         if (xy) {
             S.x_diag_send.resize(S.nlevels); S.x_diag_recv.resize(S.nlevels); S.x_panel_send.resize(S.nlevels); S.x_panel_recv.resize(S.nlevels);
@@ -1414,6 +1613,27 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     if (!H->z && g.Pr * g.Pc == 1 && H->env.solve_join) { H->h_lrow_near.assign(std::max<size_t>(t.lrow.size(), 1), 0); H->h_ucol_near.assign(std::max<size_t>(t.ucol_gc.size(), 1), 0); }
     H->setup.lap("upload.block_tile_tables");
     for (auto &S : H->sched) if (upload_schedule(*H, S, t)) return SLUAMD_EHIP;
+    for (auto &S : H->ssched) if (S.nlevels && upload_schedule(*H, S, t)) return SLUAMD_EHIP;
+    if (!H->groups.empty()) {
+        std::vector<GrpDesc> gd(H->groups.size());
+        for (size_t gi = 0; gi < gd.size(); ++gi) {
+            const Handle::SolveGroup &G = H->groups[gi];
+            gd[gi].nm = G.nm; gd[gi].nG = G.nG; gd[gi].ginv = G.ginv;
+            for (int m = 0; m < 4; ++m) { gd[gi].k[m] = G.k[m]; gd[gi].o[m] = G.o[m]; gd[gi].w[m] = G.w[m]; }
+        }
+        if (upload(K, gd, &H->d_grpdesc) || upload(K, grp_descs, &H->d_gemmdesc) || upload(K, grp_tiles, &H->d_gemmtiles)) return SLUAMD_EHIP;
+        if (hipMalloc((void **) &H->d_gscr, sizeof(double) * (size_t) (4 * GRP_SCR)) != hipSuccess) { set_error("hipMalloc of the group scratch failed"); return SLUAMD_ENOMEM; }
+        K.push_back(H->d_gscr);
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&H->gstream, hipStreamNonBlocking, lo));
+        if (getenv("SLUAMD_PLAN_DEBUG")) {
+            int64_t cols = 0, vals = 0;
+            for (auto &G : H->groups) { cols += G.nG; vals += (int64_t) 2 * G.nG * G.nG; }
+            fprintf(stderr, "[sluamd_plan] merged chain groups of the sweeps: %zu groups, %lld columns, %.3f GB of group inverses, sweep levels %d -> %d\n", H->groups.size(),
+                    (long long) cols, 8.0 * vals / 1e9, H->sched[0].nlevels, H->ssched[0].nlevels);
+        }
+    }
     T.lrow_near = nullptr; T.ucol_near = nullptr;
     if (!H->h_lrow_near.empty()) {
         uint8_t *p0, *p1;
