@@ -492,15 +492,20 @@ void bwd_update(hipStream_t, const DevTables &T, const int *nodes, const int *pr
 
 // out-of-place diagonal-solve strips (diag_strip_body): xout_k[64-row strip] = inverse[strip rows, :] xin_k, in a shuffled order under the
 // adversarial modes -- the strips of one supernode are independent only because xin != xout
-static void diag_strips(bool lower, const DevTables &T, const int2 *dunits, int ndu, const double *xin, double *xout, int64_t ldx, int nrhs)
+static void diag_strips(bool lower, const DevTables &T, const int2 *dunits, int ndu, const double *xin, double *xout, int64_t ldx, int nrhs, const int4 *drecs = nullptr)
 {
     std::vector<int> order(std::max(ndu, 0));
     for (int i = 0; i < ndu; ++i) order[i] = i;
     if (unsigned sd = emul_launch_seed()) { std::mt19937 rng(sd + 17); std::shuffle(order.begin(), order.end(), rng); }
     for (int it = 0; it < ndu; ++it) {
-        const int k = dunits[order[it]].x, strip = dunits[order[it]].y;
-        const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
+        int k = dunits[order[it]].x, strip = dunits[order[it]].y;
+        int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
         const double *Ti = T.inv + T.sn_inv[k] + (lower ? 0 : (size_t) ns * ns);
+        if (drecs) {      // unit records (as the kernel): a merged group's strips carry the GROUP's width and inverse
+            const int4 a = drecs[2 * (size_t) order[it]], b = drecs[2 * (size_t) order[it] + 1];
+            fst = a.x; ns = a.y; strip = a.z;
+            Ti = T.inv + (lower ? (((int64_t) b.y << 32) | (uint32_t) b.x) : (((int64_t) b.w << 32) | (uint32_t) b.z));
+        }
         for (int q = 0; q < nrhs; ++q)
             for (int i = strip * 64; i < std::min(ns, strip * 64 + 64); ++i) {
                 double a = 0.0;
@@ -516,12 +521,12 @@ static void diag_strips(bool lower, const DevTables &T, const int2 *dunits, int 
 static void fwd_unit_rec(const DevTables &T, const int4 *rec, const double *xsrc, double *x, int64_t ldx, int nrhs);
 static void bwd_unit_rec(const DevTables &T, const int4 *rec, const double *xcols, double *x, int64_t ldx, int nrhs);
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
-                double *xa, double *xb, int64_t ldx, int nrhs, int mx, const int4 *urecs = nullptr)
+                double *xa, double *xb, int64_t ldx, int nrhs, int mx, const int4 *urecs = nullptr, const int4 *drecs = nullptr)
 {
     const bool diag_first = emul_launch_seed() & 1;
     for (int pass = 0; pass < 2; ++pass) {
-        if ((pass == 0) == diag_first) { if (ndu > 0) diag_strips(lower, T, dunits, ndu, lower ? xa : xb, lower ? xb : xa, ldx, nrhs); }
-        else if (!units && urecs) { for (int u = 0; u < nunits; ++u) { if (lower) fwd_unit_rec(T, urecs + 2 * (size_t) u, xb, xa, ldx, nrhs); else bwd_unit_rec(T, urecs + 2 * (size_t) u, xa, xb, ldx, nrhs); } }
+        if ((pass == 0) == diag_first) { if (ndu > 0) diag_strips(lower, T, dunits, ndu, lower ? xa : xb, lower ? xb : xa, ldx, nrhs, drecs); }
+        else if (urecs) { for (int u = 0; u < nunits; ++u) { if (lower) fwd_unit_rec(T, urecs + 2 * (size_t) u, xb, xa, ldx, nrhs); else bwd_unit_rec(T, urecs + 2 * (size_t) u, xa, xb, ldx, nrhs); } }
         else if (lower) fwd_update(s, T, nullptr, nullptr, 0, nunits, xb, xa, ldx, nrhs, mx, units);
         else bwd_update(s, T, nullptr, nullptr, 0, nunits, xa, xb, ldx, nrhs, mx, units);
     }
@@ -533,10 +538,10 @@ static inline int64_t rec64(int lo, int hi) { return ((int64_t) hi << 32) | (uin
 static void fwd_unit_rec(const DevTables &T, const int4 *rec, const double *xsrc, double *x, int64_t ldx, int nrhs)
 {
     const int fst = rec[0].x, ns = rec[0].y & 0xffff, lda = rec[0].z, row0 = rec[0].w;
-    const bool chk = (rec[0].y >> 16) != 0;      // as the kernel: the near flags are read only where the planner announced near rows
+    const int chk = rec[0].y >> 16;      // as the kernel: the near flags are read only where the planner announced near rows (1: any flag, 2: dead rows only)
     const int64_t loff = rec64(rec[1].x, rec[1].y), roff = rec64(rec[1].z, rec[1].w);
     for (int r = 0; r < 64 && row0 + r < lda; ++r) {
-        if (chk && T.lrow_near[roff + r]) continue;
+        if (chk && T.lrow_near[roff + r] >= chk) continue;
         const int grow = T.lrow[roff + r];
         for (int q = 0; q < nrhs; ++q) {
             double acc = 0.0;
@@ -548,16 +553,24 @@ static void fwd_unit_rec(const DevTables &T, const int4 *rec, const double *xsrc
 static void bwd_unit_rec(const DevTables &T, const int4 *rec, const double *xcols, double *x, int64_t ldx, int nrhs)
 {
     const int fst = rec[0].x, ns = rec[0].y & 0xffff, ncol = rec[0].z;
-    const bool chk = (rec[0].y >> 16) != 0;
+    const int chk = rec[0].y >> 16;
     const int64_t ci0 = rec64(rec[1].x, rec[1].y), uoff = rec64(rec[1].z, rec[1].w);
     for (int c = 0; c < ncol; ++c) {
-        if (chk && T.ucol_near[ci0 + c]) continue;
+        if (chk && T.ucol_near[ci0 + c] >= chk) continue;
         const int ld = T.ucol_ld[ci0 + c], cp = T.ucol_cp[ci0 + c], gc = T.ucol_gc[ci0 + c];
         for (int q = 0; q < nrhs; ++q) {
             const double xv = xcols[gc + (int64_t) q * ldx];
             for (int i = ld; i < ns; ++i) x[fst + i + (int64_t) q * ldx] -= T.val[uoff + cp + (i - ld)] * xv;
         }
     }
+}
+// a launch of regular units given by their records, in a shuffled order under the adversarial modes
+static void units_by_records(bool lower, const DevTables &T, const int4 *recs, int n, const double *xsrc, double *x, int64_t ldx, int nrhs)
+{
+    std::vector<int> order(std::max(n, 0));
+    for (int i = 0; i < n; ++i) order[i] = i;
+    if (unsigned sd = emul_launch_seed()) { std::mt19937 rng(sd); std::shuffle(order.begin(), order.end(), rng); }
+    for (int it = 0; it < n; ++it) { if (lower) fwd_unit_rec(T, recs + 2 * (size_t) order[it], xsrc, x, ldx, nrhs); else bwd_unit_rec(T, recs + 2 * (size_t) order[it], xsrc, x, ldx, nrhs); }
 }
 // forward joined unit (s, c) of supernode j: t = b_j[block c] - (rows of the level-l panels in block c) x_k, then y_j[strip s] += Linv[s, c] t
 static void join_fwd_unit(const DevTables &T, const int4 *rec, const int4 *jaux, const double *xa, double *xb, int64_t ldx, int nrhs)
@@ -789,22 +802,24 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
 }
 
 void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units,
-                const int4 *)      // unit records: the restatement reads the tables
+                const int4 *recs)      // unit records where the caller has them (as the kernel), the tables otherwise
 {
+    if (recs) { emul_enqueue(s, [=] { impl::units_by_records(true, T, recs, nwork, xsrc, x, ldx, nrhs); }); return; }
     emul_enqueue(s, [=] { impl::fwd_update(s, T, nodes, prefix, nn, nwork, xsrc, x, ldx, nrhs, max_nsupc, units); });
 }
 
 void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int max_nsupc, const int2 *units,
-                const int4 *)
+                const int4 *recs)
 {
+    if (recs) { emul_enqueue(s, [=] { impl::units_by_records(false, T, recs, nwork, xcols, x, ldx, nrhs); }); return; }
     emul_enqueue(s, [=] { impl::bwd_update(s, T, nodes, prefix, nn, nwork, xcols, x, ldx, nrhs, max_nsupc, units); });
 }
 
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits, double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc,
-                const int4 *, const int4 *urecs)
+                const int4 *drecs, const int4 *urecs)
 {
     if (ndu + nunits <= 0) return;
-    emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, max_nsupc, urecs); });
+    emul_enqueue(s, [=] { impl::sweep_step(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, max_nsupc, urecs, drecs); });
 }
 
 void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits, double *xa, double *xb,
@@ -1075,8 +1090,8 @@ void gemm_batched(hipStream_t s, const DevTables &T, const GemmDesc *descs, cons
             const GemmDesc d = descs[tl.x];
             const double *A = (d.abase ? scr : T.inv) + d.a, *B = (d.bbase ? scr : T.inv) + d.b;
             double *C = (d.cbase ? scr : T.inv) + d.c;
-            for (int col = 64 * tl.z; col < std::min(d.N, 64 * tl.z + 64); ++col)
-                for (int row = 64 * tl.y; row < std::min(d.M, 64 * tl.y + 64); ++row) {
+            for (int col = 32 * tl.z; col < std::min(d.N, 32 * tl.z + 32); ++col)
+                for (int row = 32 * tl.y; row < std::min(d.M, 32 * tl.y + 32); ++row) {
                     double acc = 0.0;
                     for (int k = 0; k < d.K; ++k) acc += A[row + (int64_t) k * d.lda] * B[k + (int64_t) col * d.ldb];
                     C[row + (int64_t) col * d.ldc] = d.neg ? -acc : acc;

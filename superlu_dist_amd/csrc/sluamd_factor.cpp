@@ -648,7 +648,8 @@ static void zero_forest(Handle *H, LevelSched &S, double *x, int64_t ldx, int nr
 // are either stored by strips or added by joined units into zeroed rows, and the level below hands over exactly the rows / columns its successor's form expects.
 static inline bool level_joined(const Handle *H, const LevelSched &S, int m)
 {
-    return S.lvl_off[m + 1] - S.lvl_off[m] <= H->env.join_max_nodes || (!S.lvl_has_group.empty() && S.lvl_has_group[m]);
+    if (!S.lvl_has_group.empty() && S.lvl_has_group[m]) return false;      // merged groups: strips of the group inverse, two launches for up to four levels
+    return S.lvl_off[m + 1] - S.lvl_off[m] <= H->env.join_max_nodes;
 }
 static int solve_fwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, int nrhs)
 {
@@ -785,6 +786,13 @@ static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
     return 0;
 }
 
+// the strips of a merged group stage the group's right-hand sides in LDS (nG x nrhs doubles): wider blocks of right-hand sides take the ungrouped schedule
+static inline bool groups_fit(const Handle *H, int nrhs)
+{
+    int w = 0;
+    for (const Handle::SolveGroup &G : H->groups) w = std::max(w, G.nG);
+    return (size_t) w * nrhs * sizeof(double) <= 48 * 1024;
+}
 static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
 {
     const DevTables &T = H->T;
@@ -793,7 +801,7 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));
-        if (!rc && !H->ssched.empty() && H->ssched[z].join) return solve_fwd_join(H, H->ssched[z], d_x, ldx, nrhs);     // merged chain groups: the contracted schedule
+        if (!rc && !H->ssched.empty() && H->ssched[z].join && groups_fit(H, nrhs)) return solve_fwd_join(H, H->ssched[z], d_x, ldx, nrhs);     // merged chain groups: the contracted schedule
         if (!rc && S.join && !use_chain(H, S)) return solve_fwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_fwd_links(H, S, d_x, ldx, nrhs);
     }
@@ -822,7 +830,7 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     const bool xy = H->grid.Pr * H->grid.Pc > 1;
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));      // (already there: the forward sweep ran first)
-        if (!rc && !H->ssched.empty() && H->ssched[z].join) return solve_bwd_join(H, H->ssched[z], d_x, ldx, nrhs);
+        if (!rc && !H->ssched.empty() && H->ssched[z].join && groups_fit(H, nrhs)) return solve_bwd_join(H, H->ssched[z], d_x, ldx, nrhs);
         if (!rc && S.join && !use_chain(H, S)) return solve_bwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_bwd_links(H, S, d_x, ldx, nrhs);
     }

@@ -1659,10 +1659,11 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     // lookups behind the unit list entry: the values and x_k go in flight one round trip earlier
     int fst, ns, lda, row0;
     int64_t loff, roff;
-    bool chk = false;           // joined links: the strip holds rows of the NEXT level's supernodes (DevTables::lrow_near) -- not this unit's to update
+    int chk = 0;                // 1: joined links, the strip holds rows of the NEXT level's supernodes (DevTables::lrow_near != 0) -- not this unit's to update;
+                                // 2: only the rows of a later member of the unit's own merged group (flag 2) are nobody's
     if (rec) {
         const int4 a = rec[0], b = rec[1];
-        fst = a.x; ns = a.y & 0xffff; lda = a.z; row0 = a.w; chk = (a.y >> 16) != 0;
+        fst = a.x; ns = a.y & 0xffff; lda = a.z; row0 = a.w; chk = a.y >> 16;
         loff = ((int64_t) b.y << 32) | (uint32_t) b.x; roff = ((int64_t) b.w << 32) | (uint32_t) b.z;
     } else {
         fst = T.xsup[k]; ns = T.xsup[k + 1] - fst; lda = T.sn_nsupr[k]; row0 = T.sn_ldiag[k] + strip * 64;
@@ -1674,7 +1675,7 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     const bool rvalid = row < lda;
     const double *L = T.val + loff + r;
     const int grow = (rvalid && part == 0) ? T.lrow[roff + r] : 0;   // flat map: no walk over the slot's block descriptors
-    const bool mine = !(chk && rvalid && part == 0 && T.lrow_near[roff + r]);
+    const bool mine = !(chk && rvalid && part == 0 && T.lrow_near[roff + r] >= chk);
     const int cpp = (ns + NP - 1) / NP;           // columns per slice
     const int ka = min(ns, part * cpp), kb = min(ns, ka + cpp);
     // the thread's first batch of L (all of it for supernodes of <= 16 NP columns) goes in flight BEFORE x_k is staged: it does not depend
@@ -1743,10 +1744,11 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     __shared__ double s_red[NWV][64 * RB];
     int fst, ns, ncol;          // `rec`: (first column, width, columns of this chunk) + (first entry in the flat column maps, offset of U(k,:)) as in fwd_update_body
     int64_t ci0, uoff;
-    bool chk = false;           // joined links: columns of the NEXT level's supernodes (DevTables::ucol_near) belong to that level's joined units: treated as empty here
+    int chk = 0;                // 1: joined links, columns of the NEXT level's supernodes (DevTables::ucol_near != 0) belong to that level's joined units: treated as empty here;
+                                // 2: only the columns of a later member of the row's own merged group (flag 2)
     if (rec) {
         const int4 a = rec[0], b = rec[1];
-        fst = a.x; ns = a.y & 0xffff; ncol = a.z; chk = (a.y >> 16) != 0;
+        fst = a.x; ns = a.y & 0xffff; ncol = a.z; chk = a.y >> 16;
         ci0 = ((int64_t) b.y << 32) | (uint32_t) b.x; uoff = ((int64_t) b.w << 32) | (uint32_t) b.z;
     } else {
         fst = T.xsup[k]; ns = T.xsup[k + 1] - fst; ncol = min(64, T.sn_ncolu[k] - chunk * 64);
@@ -1755,7 +1757,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < ncol) {
         const int64_t ci = ci0 + tid;
-        s_ld[tid] = (chk && T.ucol_near[ci]) ? ns : T.ucol_ld[ci]; s_cp[tid] = T.ucol_cp[ci]; s_gc[tid] = T.ucol_gc[ci];
+        s_ld[tid] = (chk && T.ucol_near[ci] >= chk) ? ns : T.ucol_ld[ci]; s_cp[tid] = T.ucol_cp[ci]; s_gc[tid] = T.ucol_gc[ci];
     }
     __syncthreads();
     const double *Uv = T.val + uoff;
@@ -2349,15 +2351,17 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 // panel k -> LG, and (i < k): U block of column member k in row i -> UG.  Rows / columns absent from a block stay zero (the caller zero-fills the images).
 __global__ __launch_bounds__(256) void k_grp_gather(DevTables T, const GrpDesc *__restrict__ gd, double *__restrict__ scr)
 {
+    // grid (task, slice): every task's elements dealt over 64 workgroups (a task is up to 256 x 256 elements behind two dependent index loads: as ONE workgroup it
+    // is a 180 us chain of round trips on the side stream of the factorisation)
     const GrpDesc g = *gd;
-    const int nG = g.nG, tid = threadIdx.x;
+    const int nG = g.nG, tid = threadIdx.x + 256 * blockIdx.y, nth = 256 * gridDim.y;
     double *LinvG = T.inv + g.ginv, *UinvG = LinvG + (int64_t) nG * nG;
     double *LG = scr, *UG = scr + GRP_SCR;
     int t = blockIdx.x;
     if (t < g.nm) {
         const int k = g.k[t], o = g.o[t], w = g.w[t];
         const double *Li = T.inv + T.sn_inv[k], *Ui = Li + (int64_t) w * w;
-        for (int idx = tid; idx < w * w; idx += 256) {
+        for (int idx = tid; idx < w * w; idx += nth) {
             const int r = idx % w, c = idx / w;
             LinvG[(o + r) + (int64_t) (o + c) * nG] = Li[idx];
             UinvG[(o + r) + (int64_t) (o + c) * nG] = Ui[idx];
@@ -2380,7 +2384,7 @@ __global__ __launch_bounds__(256) void k_grp_gather(DevTables T, const GrpDesc *
         const int nbrow = T.lb_nbrow[b], ro = T.lb_rowoff[b], lda = T.sn_nsupr[mk], f = T.xsup[mi];
         const double *Lp = T.val + T.sn_lval[mk] + ro;
         const int *rows = T.lrow + T.sn_lrow[mk] + ro;
-        for (int idx = tid; idx < nbrow * wk; idx += 256) {
+        for (int idx = tid; idx < nbrow * wk; idx += nth) {
             const int r = idx % nbrow, c = idx / nbrow;
             LG[(oi + rows[r] - f) + (int64_t) (ok + c) * nG] = Lp[r + (size_t) c * lda];
         }
@@ -2393,7 +2397,7 @@ __global__ __launch_bounds__(256) void k_grp_gather(DevTables T, const GrpDesc *
         const int ncol = T.ub_ncols[b], st = T.ub_stcol[b], f = T.xsup[mc];
         const double *Uv = T.val + T.sn_uval[mr];
         const int64_t c0 = T.sn_ucol[mr] + st;
-        for (int idx = tid; idx < ncol * wr; idx += 256) {
+        for (int idx = tid; idx < ncol * wr; idx += nth) {
             const int r = idx % wr, q = idx / wr;
             const int ld = T.ucol_ld[c0 + q];
             if (r >= ld) UG[(orr + r) + (int64_t) (oc + T.ucol_gc[c0 + q] - f) * nG] = Uv[T.ucol_cp[c0 + q] + (r - ld)];
@@ -2401,46 +2405,73 @@ __global__ __launch_bounds__(256) void k_grp_gather(DevTables T, const GrpDesc *
     }
 }
 
-// C (M x N) = (-) A (M x K) B (K x N), column-major, 64 x 64 tile per workgroup, 32 x 32 per wave, operand fragments straight from memory (L2-resident panels of
-// <= 8 MB): D[(l >> 4) + 4 r][l & 15] = sum_k A[l & 15][l >> 4] B[l >> 4][l & 15].  M, N multiples of 16, K of 4 (supernode widths of grouped members are).
+// C (M x N) = (-) A (M x K) B (K x N), column-major.  One workgroup per 32 x 32 tile of C, its four waves split K (the products of a group are a chain of six
+// dependent launches of few tiles each: the length of ONE wave's K loop is what a launch lasts), partial tiles summed through LDS; operand fragments straight
+// from memory (L2-resident images of <= 8 MB), four k-steps of loads in flight ahead of the MFMAs.  D[(l >> 4) + 4 r][l & 15] = sum_k A[l & 15][l >> 4] B[l >> 4][l & 15].
+// M, N multiples of 16, K of 16 (the widths of grouped members are).
 __global__ __launch_bounds__(256) void k_gemm_batched(DevTables T, const GemmDesc *__restrict__ descs, const int4 *__restrict__ tiles, double *__restrict__ scr)
 {
+    __shared__ double s_part[4][32 * 33];
     const int4 tl = tiles[blockIdx.x];
     const GemmDesc d = descs[tl.x];
     const double *A = (d.abase ? scr : T.inv) + d.a, *B = (d.bbase ? scr : T.inv) + d.b;
     double *C = (d.cbase ? scr : T.inv) + d.c;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const int row0 = 64 * tl.y + 32 * (wave & 1), col0 = 64 * tl.z + 32 * (wave >> 1);
-    if (row0 >= d.M || col0 >= d.N) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int row0 = 32 * tl.y, col0 = 32 * tl.z;
     d4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
     const int ra0 = min(row0 + li, d.M - 1), ra1 = min(row0 + 16 + li, d.M - 1), cb0 = min(col0 + li, d.N - 1), cb1 = min(col0 + 16 + li, d.N - 1);
-    for (int k4 = 0; k4 < d.K; k4 += 4) {
-        const int kq = k4 + lk;
-        const double a0 = A[ra0 + (size_t) kq * d.lda], a1 = A[ra1 + (size_t) kq * d.lda];
-        const double b0 = B[kq + (size_t) cb0 * d.ldb], b1 = B[kq + (size_t) cb1 * d.ldb];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    const int kq4 = (d.K >> 2) >> 2;                          // k-steps of four per wave
+    const int kbeg = 4 * kq4 * wave, kend = (wave == 3) ? d.K : kbeg + 4 * kq4;
+    const double *Ap0 = A + ra0, *Ap1 = A + ra1, *Bp0 = B + (size_t) cb0 * d.ldb, *Bp1 = B + (size_t) cb1 * d.ldb;
+    constexpr int U = 4;
+    double a0[U], a1[U], b0[U], b1[U];
+    auto load = [&](int k4, double (&x0)[U], double (&x1)[U], double (&y0)[U], double (&y1)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kq = min(k4 + 4 * u + lk, d.K - 1);
+            x0[u] = Ap0[(size_t) kq * d.lda]; x1[u] = Ap1[(size_t) kq * d.lda]; y0[u] = Bp0[kq]; y1[u] = Bp1[kq];
+        }
+    };
+    if (kbeg < kend) load(kbeg, a0, a1, b0, b1);
+    for (int k4 = kbeg; k4 < kend; k4 += 4 * U) {
+        double n0[U], n1[U], m0[U], m1[U];
+        const bool more = k4 + 4 * U < kend;
+        if (more) load(k4 + 4 * U, n0, n1, m0, m1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k4 + 4 * u < kend) {                          // wave-uniform
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a0[u] = n0[u]; a1[u] = n1[u]; b0[u] = m0[u]; b1[u] = m1[u]; }
+        }
     }
-    const double sg = d.neg ? -1.0 : 1.0;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 16 * a + lk + 4 * r, col = col0 + 16 * b + li;
-                if (row < d.M && col < d.N) C[row + (size_t) col * d.ldc] = sg * acc[a][b][r];
-            }
+            for (int r = 0; r < 4; ++r) s_part[wave][(16 * b + li) * 33 + 16 * a + lk + 4 * r] = acc[a][b][r];
+    __syncthreads();
+    const double sg = d.neg ? -1.0 : 1.0;
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int r = e & 31, c = e >> 5;
+        if (row0 + r < d.M && col0 + c < d.N)
+            C[row0 + r + (size_t) (col0 + c) * d.ldc] = sg * ((s_part[0][c * 33 + r] + s_part[1][c * 33 + r]) + (s_part[2][c * 33 + r] + s_part[3][c * 33 + r]));
+    }
 }
 
 static const bool g_full_inv64 = getenv("SLUAMD_NO_FULL_INV64") == nullptr;
 void grp_gather(hipStream_t s, const DevTables &T, const GrpDesc *d_desc, double *scratch)
 {
-    hipLaunchKernelGGL(k_grp_gather, dim3(4 + 6 + 6), dim3(256), 0, s, T, d_desc, scratch);
+    hipLaunchKernelGGL(k_grp_gather, dim3(4 + 6 + 6, 64), dim3(256), 0, s, T, d_desc, scratch);
 }
 void gemm_batched(hipStream_t s, const DevTables &T, const GemmDesc *d_descs, const int4 *d_tiles, int ntiles, double *scratch)
 {

@@ -887,9 +887,10 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
 
 // Joined sweeps (LevelSched::join): near flags, joined diagonal units, regular unit records per level.  Returns false (nothing kept) when a panel's rows
 // inside one block are not ascending -- the rows of a column block of the target would not be one range.
-// Merged chain groups (Handle::groups; S is then the contracted schedule Handle::ssched): a group is ONE node of its level -- its joined units are the 64 x 64 blocks
-// of the GROUP's inverse (up to 1024 columns), their sources the panels of the previous level with rows in ANY member; rows / columns of a member's panel / U row that
-// belong to a later member of the same group are nobody's to update (the group's inverse couples the members): flagged 2 ("dead"), skipped by the regular units.
+// Merged chain groups (Handle::groups; S is then the contracted schedule Handle::ssched): a group is ONE node of its level, solved by the strips of the GROUP's
+// inverse (up to 1024 columns) in the two-launch form -- joined units would read every source panel once per strip of the group (16 x); rows / columns of a member's
+// panel / U row that belong to a later member of the same group are nobody's to update (the group's inverse couples the members): flagged 2 ("dead"), skipped by the
+// regular units of either form (record bit 16 = skip every flagged entry, bit 17 = skip the dead ones only).
 static bool build_join(Handle &H, LevelSched &S, const HostTables &t)
 {
     const HostStruct &hs = H.hs;
@@ -967,13 +968,7 @@ static bool build_join(Handle &H, LevelSched &S, const HostTables &t)
             const int gk = grp(k);
             int nm = 1, mem[4] = {k, 0, 0, 0}, mo[4] = {0, 0, 0, 0}, mw[4] = {hs.xsup[k + 1] - hs.xsup[k], 0, 0, 0};
             int64_t linv = t.sn_inv[k], uinv = t.sn_inv[k] + (int64_t) mw[0] * mw[0];
-            if (gk >= 0) {
-                const Handle::SolveGroup &G = H.groups[gk];
-                if (G.k[0] != k) continue;                        // the group was emitted with its first member
-                nm = G.nm;
-                for (int m = 0; m < nm; ++m) { mem[m] = G.k[m]; mo[m] = G.o[m]; mw[m] = G.w[m]; }
-                linv = G.ginv; uinv = G.ginv + (int64_t) G.nG * G.nG;
-            }
+            if (gk >= 0) continue;                                // a level that holds a merged group keeps the two-launch form (level_joined)
             const int fst = hs.xsup[k], ns = mo[nm - 1] + mw[nm - 1], nb = (ns + 63) / 64;
             auto member_of_block = [&](int c) { int m = 0; while (m + 1 < nm && mo[m + 1] <= 64 * c) ++m; return m; };
             // forward: block (s, c), c <= s, sources = the panels of the previous level with rows in column block c (none at level 0)
@@ -1061,7 +1056,7 @@ static void build_solve_groups(Handle &H, const SlotInput &in, HostTables &t, co
         auto add = [&](const GemmDesc &d) {
             const int di = (int) descs.size();
             descs.push_back(d);
-            for (int tc = 0; tc < (d.N + 63) / 64; ++tc) for (int tr = 0; tr < (d.M + 63) / 64; ++tr) tiles.push_back(make_int4(di, tr, tc, 0));
+            for (int tc = 0; tc < (d.N + 31) / 32; ++tc) for (int tr = 0; tr < (d.M + 31) / 32; ++tr) tiles.push_back(make_int4(di, tr, tc, 0));      // 32 x 32 tiles (eng::gemm_batched)
         };
         G.tile_off[0] = (int) tiles.size();
         for (int d = 1; d < G.nm; ++d) {
@@ -1124,8 +1119,8 @@ static void build_solve_sched(Handle &H, const HostTables &t, const std::vector<
     for (int l = 0; l < nslev; ++l)
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
             const int k = S.nodes[i];
-            const int w = H.grp_of[k] >= 0 ? H.groups[H.grp_of[k]].nG : nsupc_of(hs, k);      // the joined units stage a source's x (<= 256) and index up to the node's width
-            S.max_nsupc[l] = std::max(S.max_nsupc[l], std::min(w, 256));
+            const int w = H.grp_of[k] >= 0 ? H.groups[H.grp_of[k]].nG : nsupc_of(hs, k);      // the strips of a group stage the group's whole right-hand side
+            S.max_nsupc[l] = std::max(S.max_nsupc[l], w);
         }
     S.fu_off.assign(2 * nslev + 1, 0); S.bu_off.assign(2 * nslev + 1, 0);
     std::vector<uint8_t> urg;
@@ -1161,7 +1156,9 @@ static void build_solve_sched(Handle &H, const HostTables &t, const std::vector<
         for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
             const int k = S.nodes[i];
             if (!(t.sn_flags[k] & SNF_OWN_DIAG)) continue;
-            for (int st = 0; st < (nsupc_of(hs, k) + 63) / 64; ++st) S.diag_units.push_back(make_int2(k, st));
+            int w = nsupc_of(hs, k);
+            if (H.grp_of[k] >= 0) { const Handle::SolveGroup &G = H.groups[H.grp_of[k]]; if (G.k[0] != k) continue; w = G.nG; }      // the group's strips, at its first member
+            for (int st = 0; st < (w + 63) / 64; ++st) S.diag_units.push_back(make_int2(k, st));
         }
         S.du_off[l + 1] = (int) S.diag_units.size();
     }
@@ -1205,22 +1202,46 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
         const HostStruct &hs = H.hs;
         auto lohi = [](int64_t v, int &lo, int &hi) { lo = (int) (uint32_t) v; hi = (int) (v >> 32); };
         S.fwd_recs.resize(2 * S.fwd_units.size()); S.bwd_recs.resize(2 * S.bwd_units.size()); S.diag_recs.resize(2 * S.diag_units.size());
+        const bool grouped = !S.lvl_has_group.empty() && !H.grp_of.empty() && !H.h_lrow_near.empty();
+        auto grp = [&](int k) { return grouped ? H.grp_of[k] : -1; };
+        if (grouped)        // the dead rows / columns of the members (see build_join), before the records that announce them
+            for (int k : S.nodes) {
+                const int gk = grp(k);
+                if (gk < 0) continue;
+                if (t.sn_flags[k] & SNF_L_OWN)
+                    for (int b = 0; b < t.sn_nlb[k]; ++b) {
+                        const int bi = t.sn_lb_off[k] + b, g = t.lb_gid[bi];
+                        if (g != k && grp(g) == gk) for (int r = 0; r < t.lb_nbrow[bi]; ++r) H.h_lrow_near[t.sn_lrow[k] + t.lb_rowoff[bi] + r] = 2;
+                    }
+                if (t.sn_flags[k] & SNF_U_OWN)
+                    for (int b = 0; b < t.sn_nub[k]; ++b) {
+                        const int bi = t.sn_ub_off[k] + b;
+                        if (t.ub_ncols[bi] && grp(t.ub_gid[bi]) == gk) for (int c = 0; c < t.ub_ncols[bi]; ++c) H.h_ucol_near[t.sn_ucol[k] + t.ub_stcol[bi] + c] = 2;
+                    }
+            }
         for (size_t u = 0; u < S.fwd_units.size(); ++u) {
             const int k = S.fwd_units[u].x, strip = S.fwd_units[u].y;
             const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst, row0 = t.sn_ldiag[k] + strip * 64;
             int4 b; lohi(t.sn_lval[k] + row0, b.x, b.y); lohi(t.sn_lrow[k] + row0, b.z, b.w);
-            S.fwd_recs[2 * u] = make_int4(fst, ns, t.sn_nsupr[k], row0); S.fwd_recs[2 * u + 1] = b;
+            int dead = 0;
+            if (grp(k) >= 0) for (int r = row0; r < std::min(row0 + 64, t.sn_nsupr[k]); ++r) dead |= H.h_lrow_near[t.sn_lrow[k] + r] == 2;
+            S.fwd_recs[2 * u] = make_int4(fst, ns | (dead ? 2 << 16 : 0), t.sn_nsupr[k], row0); S.fwd_recs[2 * u + 1] = b;
         }
         for (size_t u = 0; u < S.bwd_units.size(); ++u) {
             const int k = S.bwd_units[u].x, chunk = S.bwd_units[u].y;
-            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst;
+            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst, nc = std::min(64, t.sn_ncolu[k] - chunk * 64);
             int4 b; lohi(t.sn_ucol[k] + (int64_t) chunk * 64, b.x, b.y); lohi(t.sn_uval[k], b.z, b.w);
-            S.bwd_recs[2 * u] = make_int4(fst, ns, std::min(64, t.sn_ncolu[k] - chunk * 64), 0); S.bwd_recs[2 * u + 1] = b;
+            int dead = 0;
+            if (grp(k) >= 0) for (int c = 0; c < nc; ++c) dead |= H.h_ucol_near[t.sn_ucol[k] + (int64_t) chunk * 64 + c] == 2;
+            S.bwd_recs[2 * u] = make_int4(fst, ns | (dead ? 2 << 16 : 0), nc, 0); S.bwd_recs[2 * u + 1] = b;
         }
         for (size_t u = 0; u < S.diag_units.size(); ++u) {
             const int k = S.diag_units[u].x, strip = S.diag_units[u].y;
-            const int fst = hs.xsup[k], ns = hs.xsup[k + 1] - fst;
-            int4 b; lohi(t.sn_inv[k], b.x, b.y); lohi(t.sn_inv[k] + (int64_t) ns * ns, b.z, b.w);
+            const int fst = hs.xsup[k];
+            int ns = hs.xsup[k + 1] - fst;
+            int64_t li = t.sn_inv[k];
+            if (grp(k) >= 0) { const Handle::SolveGroup &G = H.groups[grp(k)]; ns = G.nG; li = G.ginv; }
+            int4 b; lohi(li, b.x, b.y); lohi(li + (int64_t) ns * ns, b.z, b.w);
             S.diag_recs[2 * u] = make_int4(fst, ns, strip, 0); S.diag_recs[2 * u + 1] = b;
         }
         if (upload(H.d_misc, S.fwd_recs, &S.d_fwd_recs) || upload(H.d_misc, S.bwd_recs, &S.d_bwd_recs) || upload(H.d_misc, S.diag_recs, &S.d_diag_recs)) return SLUAMD_EHIP;

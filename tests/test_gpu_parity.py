@@ -70,6 +70,42 @@ def test_solve_matches_reference(golden, case):
     h.destroy()
 
 
+def test_merged_chain_groups_of_the_sweeps_give_the_ungrouped_solution():
+    """SLUAMD_SOLVE_GROUPS=1 (opt-in): chains of up to four separator supernodes solved as ONE node of the sweeps through the inverse of their block triangle
+    (built during pdgstrf3d by batched dense products) -- same factors, fewer launches, the solution of the ungrouped sweeps to rounding; a block of right-hand
+    sides too wide for the group strips' staging takes the ungrouped schedule."""
+    N = 24
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    rng = np.random.default_rng(5)
+    out = {}
+    for grouped in (False, True):
+        if grouped:
+            os.environ["SLUAMD_SOLVE_GROUPS"] = "1"
+        try:
+            symb = driver.Symbolic(n, rp, ci, perm, relax=32, maxsup=64)
+            h = driver.LUHandle.from_symbolic(symb, v)
+            assert h.pdgstrf3d(0.0) == 0
+            xs, launches = [], None
+            for nrhs in (1, 3, 200):
+                xt = np.asfortranarray(np.random.default_rng(nrhs).standard_normal((n, nrhs)))
+                b = np.column_stack([matgen.csr_matvec(n, rp, ci, v, xt[:, q]) for q in range(nrhs)])
+                pc = np.asarray(symb.perm_c)
+                bp = np.zeros_like(b); bp[pc] = b                   # the factored system: P A P^T
+                x = h.pdgstrs3d(bp)[pc]
+                assert np.abs(x - xt).max() <= 1e-10 * max(1.0, np.abs(xt).max()), (grouped, nrhs, np.abs(x - xt).max())
+                xs.append(x)
+                if launches is None:
+                    launches = h.stats()["solve_launches"]
+            out[grouped] = (xs, launches)
+            h.destroy(); symb.free()
+        finally:
+            os.environ.pop("SLUAMD_SOLVE_GROUPS", None)
+    for a, b in zip(out[False][0], out[True][0]):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())
+    assert out[True][1] < out[False][1], (out[True][1], out[False][1])      # the groups were found and used
+
+
 @pytest.mark.parametrize("case", ["poisson10_nd_diaginv", "unsym300_diaginv"])
 def test_diagonal_inverses_match_the_reference(golden, case):
     """Linv / Uinv of every diagonal block (k_full_inv / k_full_inv64 from the 32 x 32 inverses of the diagonal kernels) against what the reference's
