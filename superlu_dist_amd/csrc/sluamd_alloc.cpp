@@ -1,0 +1,37 @@
+// Host allocations of THIS library on transparent huge pages.
+//
+// Handle creation builds ~1.5 GB of host tables at 100^3 (index images, block / tile tables, tile lists, pair maps, scatter positions); every one above glibc's
+// mmap threshold is a fresh mapping whose first touch takes a 4 KB page fault per page -- a third of the planner's time on the MI355X hosts
+// (profiles/r05_setup.txt: setup 0.82 -> 0.63 s with the process-wide glibc.malloc.hugetlb=1 tunable).  A library cannot set a tunable of its host process, so
+// it asks for the same thing for its own blocks: operator new of this shared object (made LOCAL by the link's version script, sluamd.map: the replacement binds
+// the library's own calls only, nobody else's) returns blocks of 4 MB and more 2 MB-aligned and madvise(MADV_HUGEPAGE)d before their first touch; everything comes from malloc's
+// arena and goes back through free(), so a block may cross into code that uses the default operators.  Kernels with THP "never" ignore the advice;
+// SLUAMD_NO_THP=1 turns it off.
+#include <cstdlib>
+#include <new>
+#include <sys/mman.h>
+
+namespace {
+constexpr std::size_t kHuge = std::size_t(2) << 20, kBig = std::size_t(4) << 20;
+inline bool thp_on() { static const bool on = getenv("SLUAMD_NO_THP") == nullptr; return on; }
+inline void *host_alloc(std::size_t n) noexcept
+{
+    if (n >= kBig && thp_on()) {
+        const std::size_t r = (n + kHuge - 1) & ~(kHuge - 1);
+        if (void *p = aligned_alloc(kHuge, r)) { madvise(p, r, MADV_HUGEPAGE); return p; }
+    }
+    return malloc(n ? n : 1);
+}
+}  // namespace
+
+#define SLUAMD_LOCAL
+SLUAMD_LOCAL void *operator new(std::size_t n) { if (void *p = host_alloc(n)) return p; throw std::bad_alloc(); }
+SLUAMD_LOCAL void *operator new[](std::size_t n) { if (void *p = host_alloc(n)) return p; throw std::bad_alloc(); }
+SLUAMD_LOCAL void *operator new(std::size_t n, const std::nothrow_t &) noexcept { return host_alloc(n); }
+SLUAMD_LOCAL void *operator new[](std::size_t n, const std::nothrow_t &) noexcept { return host_alloc(n); }
+SLUAMD_LOCAL void operator delete(void *p) noexcept { free(p); }
+SLUAMD_LOCAL void operator delete[](void *p) noexcept { free(p); }
+SLUAMD_LOCAL void operator delete(void *p, std::size_t) noexcept { free(p); }
+SLUAMD_LOCAL void operator delete[](void *p, std::size_t) noexcept { free(p); }
+SLUAMD_LOCAL void operator delete(void *p, const std::nothrow_t &) noexcept { free(p); }
+SLUAMD_LOCAL void operator delete[](void *p, const std::nothrow_t &) noexcept { free(p); }

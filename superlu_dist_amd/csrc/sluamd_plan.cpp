@@ -1508,6 +1508,38 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     }
     H->h_dptr = t.sn_dptr;
 
+    // The block / tile tables are final here: a helper thread uploads them (pageable copies, ~4 GB/s) while this one builds the schedules.  Nothing below
+    // writes the vectors it reads or touches H->d_misc / H->T until the join in step 7.
+    int table_rc = 0;
+    size_t table_bytes = 0;
+    struct TJoiner { std::thread th; ~TJoiner() { if (th.joinable()) th.join(); } } table_job;
+    table_job.th = std::thread([H, &t, &hs, &table_rc, &table_bytes] {
+        table_rc = [&]() -> int {
+            HIPCHK(hipSetDevice(H->device));
+            auto &K = H->d_misc;
+            DevTables &T = H->T;
+            const size_t mark = upload_bytes();
+            if (upload(K, hs.lidx, &H->d_lidx) || upload(K, hs.uidx, &H->d_uidx) || upload(K, t.ucolptr, &H->d_ucolptr) ||
+                upload(K, t.unzcol, &H->d_unzcol) || upload(K, hs.xsup, &H->d_xsup)) return SLUAMD_EHIP;
+            T.lidx = H->d_lidx; T.uidx = H->d_uidx; T.ucolptr = H->d_ucolptr; T.unzcol = H->d_unzcol; T.xsup = H->d_xsup;
+#define UP(field, vec, type) { type *p_; if (upload(K, vec, &p_)) return SLUAMD_EHIP; T.field = p_; }
+            UP(sn_lval, t.sn_lval, int64_t) UP(sn_uval, t.sn_uval, int64_t) UP(sn_lidx, t.sn_lidx, int64_t) UP(sn_uidx, t.sn_uidx, int64_t)
+            UP(sn_dinv, t.sn_dinv, int64_t) UP(sn_dptr, t.sn_dptr, int64_t) UP(sn_inv, t.sn_inv, int64_t)
+            UP(sn_nsupr, t.sn_nsupr, int) UP(sn_flags, t.sn_flags, int) UP(sn_ldiag, t.sn_ldiag, int) UP(sn_dlda, t.sn_dlda, int)
+            UP(sn_ldu, t.sn_ldu, int) UP(sn_ncolu, t.sn_ncolu, int)
+            UP(sn_lb_off, t.sn_lb_off, int) UP(sn_nlb, t.sn_nlb, int) UP(sn_ub_off, t.sn_ub_off, int) UP(sn_nub, t.sn_nub, int)
+            UP(sn_rt_off, t.sn_rt_off, int) UP(sn_nrt, t.sn_nrt, int) UP(sn_ct_off, t.sn_ct_off, int) UP(sn_nct, t.sn_nct, int)
+            UP(lb_gid, t.lb_gid, int) UP(lb_nbrow, t.lb_nbrow, int) UP(lb_rowoff, t.lb_rowoff, int) UP(lb_lptr, t.lb_lptr, int)
+            UP(lbs_gid, t.lbs_gid, int) UP(lbs_idx, t.lbs_idx, int)
+            UP(ub_gid, t.ub_gid, int) UP(ub_ncols, t.ub_ncols, int) UP(ub_iukp, t.ub_iukp, int) UP(ub_stcol, t.ub_stcol, int)
+            UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4) UP(rt_info, t.rt_info, int2) UP(ct_info, t.ct_info, int4)
+            UP(lrow, t.lrow, int) UP(sn_lrow, t.sn_lrow, int64_t) UP(ucol_cp, t.ucol_cp, int) UP(ucol_ld, t.ucol_ld, int) UP(ucol_gc, t.ucol_gc, int) UP(sn_ucol, t.sn_ucol, int64_t)
+#undef UP
+            table_bytes = upload_bytes() - mark;
+            return 0;
+        }();
+    });
+
     // ---- 6. schedules ----
     int nlevtot = 0;
     std::vector<GemmDesc> grp_descs;
@@ -1604,12 +1636,9 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     auto &K = H->d_misc;
     DevTables &T = H->T;
     T.val = H->d_val;
-    if (upload(K, hs.lidx, &H->d_lidx) || upload(K, hs.uidx, &H->d_uidx) || upload(K, t.ucolptr, &H->d_ucolptr) ||
-        upload(K, t.unzcol, &H->d_unzcol) || upload(K, hs.xsup, &H->d_xsup)) return SLUAMD_EHIP;
-    T.lidx = H->d_lidx; T.uidx = H->d_uidx; T.ucolptr = H->d_ucolptr; T.unzcol = H->d_unzcol; T.xsup = H->d_xsup;
-#define UP(field, vec, type) { type *p_; if (upload(K, vec, &p_)) return SLUAMD_EHIP; T.field = p_; }
-    UP(sn_lval, t.sn_lval, int64_t) UP(sn_uval, t.sn_uval, int64_t) UP(sn_lidx, t.sn_lidx, int64_t) UP(sn_uidx, t.sn_uidx, int64_t)
-    UP(sn_dinv, t.sn_dinv, int64_t) UP(sn_dptr, t.sn_dptr, int64_t) UP(sn_inv, t.sn_inv, int64_t)
+    table_job.th.join();          // the block / tile tables went up beside the schedule construction
+    if (table_rc) return table_rc;
+    upload_bytes() += table_bytes;
     H->h_sn_dinv = t.sn_dinv;
     {
         double *dv;
@@ -1621,16 +1650,6 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
         if (hipMalloc((void **) &iv, sizeof(double) * (size_t) std::max<int64_t>(t.inv_total, 1)) != hipSuccess) { set_error("hipMalloc(inv) failed"); return SLUAMD_ENOMEM; }
         K.push_back(iv); T.inv = iv;
     }
-    UP(sn_nsupr, t.sn_nsupr, int) UP(sn_flags, t.sn_flags, int) UP(sn_ldiag, t.sn_ldiag, int) UP(sn_dlda, t.sn_dlda, int)
-    UP(sn_ldu, t.sn_ldu, int) UP(sn_ncolu, t.sn_ncolu, int)
-    UP(sn_lb_off, t.sn_lb_off, int) UP(sn_nlb, t.sn_nlb, int) UP(sn_ub_off, t.sn_ub_off, int) UP(sn_nub, t.sn_nub, int)
-    UP(sn_rt_off, t.sn_rt_off, int) UP(sn_nrt, t.sn_nrt, int) UP(sn_ct_off, t.sn_ct_off, int) UP(sn_nct, t.sn_nct, int)
-    UP(lb_gid, t.lb_gid, int) UP(lb_nbrow, t.lb_nbrow, int) UP(lb_rowoff, t.lb_rowoff, int) UP(lb_lptr, t.lb_lptr, int)
-    UP(lbs_gid, t.lbs_gid, int) UP(lbs_idx, t.lbs_idx, int)
-    UP(ub_gid, t.ub_gid, int) UP(ub_ncols, t.ub_ncols, int) UP(ub_iukp, t.ub_iukp, int) UP(ub_stcol, t.ub_stcol, int)
-    UP(rtile, t.rtile, int4) UP(ctile, t.ctile, int4) UP(rt_info, t.rt_info, int2) UP(ct_info, t.ct_info, int4)
-    UP(lrow, t.lrow, int) UP(sn_lrow, t.sn_lrow, int64_t) UP(ucol_cp, t.ucol_cp, int) UP(ucol_ld, t.ucol_ld, int) UP(ucol_gc, t.ucol_gc, int) UP(sn_ucol, t.sn_ucol, int64_t)
-#undef UP
     if (!H->z && g.Pr * g.Pc == 1 && H->env.solve_join) { H->h_lrow_near.assign(std::max<size_t>(t.lrow.size(), 1), 0); H->h_ucol_near.assign(std::max<size_t>(t.ucol_gc.size(), 1), 0); }
     H->setup.lap("upload.block_tile_tables");
     for (auto &S : H->sched) if (upload_schedule(*H, S, t)) return SLUAMD_EHIP;

@@ -167,7 +167,7 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     static const bool timing = getenv("SLUAMD_SYMB_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
-    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[sluamd_dsymbfact] %-28s %.2f s\n", what, t - t_prev); t_prev = t; } };
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[sluamd_dsymbfact] %-28s %.3f s\n", what, t - t_prev); t_prev = t; } };
     if (int rc = order_and_etree(n, rowptr, colind, perm_c, perm, parent, g, perm_c_out, lap)) return rc;
     // ---- subtree sizes, child counts, relaxed subtree roots ----
     std::vector<int> sz(n, 1), nchild(n, 0);
@@ -179,58 +179,56 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     for (int j = 0; j < n; ++j)
         if (sz[j] <= relax && (parent[j] == -1 || sz[parent[j]] > relax)) relax_end[j - sz[j] + 1] = j;
     // ---- supernodal structure ----
+    // One supernode ("unit") at a time in column order: its row structure is the union of the adjacency of its columns and of the row structures of the
+    // units pending on them (children in the supernodal tree).  In parallel: the etree is postordered, so a subtree is a contiguous column range that needs
+    // nothing from outside it -- disjoint subtrees of at most `cut` columns are tasks for the worker threads; what is left (the supernode that holds a task's
+    // root column -- it may continue into the parent, which waits for OTHER subtrees -- and everything above the cut) runs serially afterwards with the task
+    // units as its children.  The result is the serial one (order of discovery only feeds sorted lists and counts), whatever the number of threads.
     auto *sy = new Symb();
     HostStruct &hs = sy->hs;
     hs.n = n;
     sy->supno.assign(n, -1);
-    std::vector<int> mark(n, -1);
-    std::vector<int> pend_head(n, -1), pend_next;  // child units pending on a column (linked by unit id)
-    std::vector<int> ufirst, ulast;
-    sy->srow_off.push_back(0);
-    std::vector<int> cur;
-    int j = 0;
-    while (j < n) {
-        const int u = (int) ufirst.size();
-        int a = j, b;
+    struct Unit { int first, last, ctx; int64_t off; int len; };
+    struct Ctx { std::vector<int> rows; std::vector<Unit> units; std::vector<std::pair<int, int>> pend_out; int stop = 0; };      // pend_out: (local unit, column it pends on) beyond the task
+    static const bool equal_split = getenv("SLUAMD_SYMB_EQUAL_SPLIT") != nullptr;   // development: round-2 rule (equal pieces)
+    // grows the unit that starts at column a.  children(c, f): f(rows, len) for every unit pending on column c; lim: last column the unit may examine
+    // (task: its root; returns -1 when the unit reaches it -- not this task's to finish).  Appends the sorted rows > b to `out`, returns b.
+    auto grow = [&](int a, int lim, int stamp, std::vector<int> &mark, std::vector<int> &cur, std::vector<int> &extra, auto &&children, std::vector<int> &out) -> int {
+        int b;
+        const bool bounded = lim < (int) n;
         cur.clear();
         auto add_adj = [&](int c) {
-            for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != u) { mark[r] = u; cur.push_back(r); } }
+            for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != stamp) { mark[r] = stamp; cur.push_back(r); } }
         };
-        auto add_children_of = [&](int c) {
-            for (int cu = pend_head[c]; cu != -1; cu = pend_next[cu])
-                for (int64_t e = sy->srow_off[cu]; e < sy->srow_off[cu + 1]; ++e) { int r = sy->srows[e]; if (mark[r] != u) { mark[r] = u; cur.push_back(r); } }
-        };
-        if (relax_end[j] >= 0) {
-            b = relax_end[j];
+        if (relax_end[a] >= 0) {
+            b = relax_end[a];
+            if (bounded && b >= lim) return -1;
             for (int c = a; c <= b; ++c) add_adj(c);  // full subtree: no child unit lies outside [a,b]
         } else {
             b = a;
-            add_adj(a); add_children_of(a);
+            if (bounded && a >= lim) return -1;
+            add_adj(a);
+            children(a, [&](const int *rows, int len) { for (int i = 0; i < len; ++i) { const int r = rows[i]; if (mark[r] != stamp) { mark[r] = stamp; cur.push_back(r); } } });
             // extend the supernode by column c = b+1 (its etree parent) while struct(c) ~= struct(b) \ {c}.
             // Non-fundamental supernodes are allowed (other children of c may hang anywhere), and so is a small
             // amount of explicit-zero padding (relaxed amalgamation): where two ND separators meet, every
             // separator column brings ONE private row of the ancestor separator, which would otherwise shatter
             // the separator into singleton supernodes.
             double zacc = 0;
-            std::vector<int> extra;
             // split long chains (separators) into pieces of exactly maxsup columns (full 128-wide Schur tiles and K chunks
             // when maxsup is a multiple of 128); the tail of a chain is never a sliver: a remainder below maxsup / 2 is
             // merged with the piece before it and that is halved (to a multiple of 16)
             const int rem = chain[a];
             int cap = maxsup;
-            static const bool equal_split = getenv("SLUAMD_SYMB_EQUAL_SPLIT") != nullptr;   // development: round-2 rule (equal pieces)
             if (equal_split) { const int pieces = (rem + maxsup - 1) / maxsup; cap = (rem + pieces - 1) / pieces; } else
             if (rem <= maxsup) cap = rem;
             else if (rem < 2 * maxsup && rem - maxsup < maxsup / 2) cap = std::min(maxsup, ((rem + 1) / 2 + 15) & ~15);
             while (b + 1 < n && (b - a + 1) < cap && parent[b] == b + 1 && relax_end[b + 1] < 0) {
                 const int c = b + 1;
+                if (bounded && c >= lim) return -1;
                 extra.clear();
-                for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != u) { mark[r] = u; extra.push_back(r); } }
-                for (int cu = pend_head[c]; cu != -1; cu = pend_next[cu])
-                    for (int64_t e = sy->srow_off[cu]; e < sy->srow_off[cu + 1]; ++e) {
-                        const int r = sy->srows[e];
-                        if (r > c && mark[r] != u) { mark[r] = u; extra.push_back(r); }
-                    }
+                for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != stamp) { mark[r] = stamp; extra.push_back(r); } }
+                children(c, [&](const int *rows, int len) { for (int i = 0; i < len; ++i) { const int r = rows[i]; if (r > c && mark[r] != stamp) { mark[r] = stamp; extra.push_back(r); } } });
                 const double cols = c - a, rows = (double) cur.size();
                 const double znew = zacc + (double) extra.size() * cols;
                 const bool ok = extra.empty() ||
@@ -246,14 +244,94 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
         for (size_t i = 0; i < cur.size(); ++i) if (cur[i] > b) cur[w++] = cur[i];
         cur.resize(w);
         std::sort(cur.begin(), cur.end());
-        sy->srows.insert(sy->srows.end(), cur.begin(), cur.end());
-        sy->srow_off.push_back((int64_t) sy->srows.size());
-        ufirst.push_back(a); ulast.push_back(b);
-        for (int c = a; c <= b; ++c) sy->supno[c] = u;
-        pend_next.push_back(-1);
-        if (parent[b] != -1) { pend_next[u] = pend_head[parent[b]]; pend_head[parent[b]] = u; }
-        j = b + 1;
+        out.insert(out.end(), cur.begin(), cur.end());
+        return b;
+    };
+    // tasks: the maximal subtrees of at most `cut` columns (roots in column order)
+    const int nthr = plan_threads();
+    int cut = (int) std::max<int64_t>(2048, n / (8 * (int64_t) std::max(nthr, 1))), tmin = 256;
+    bool tasks_on = nthr > 1 && n >= 50000;
+    if (const char *e = getenv("SLUAMD_SYMB_CUT")) { cut = atoi(e); tmin = 1; tasks_on = cut > 0; }      // tests: the task path on small structures
+    std::vector<int> troot;
+    if (tasks_on)
+        for (int jj = 0; jj < n; ++jj) if (sz[jj] <= cut && sz[jj] >= tmin && (parent[jj] == -1 || sz[parent[jj]] > cut)) troot.push_back(jj);
+    std::vector<Ctx> ctx(troot.size() + 1);
+    std::vector<int> skip_to(n, -1);      // first column of a task's range -> first column the task left
+    parallel_chunks((int64_t) troot.size(), 1, [&](int64_t t0, int64_t t1) {
+        std::vector<int> mark(n, -1), cur, extra;
+        int stamp = 0;
+        for (int64_t t = t0; t < t1; ++t) {
+            Ctx &cx = ctx[t];
+            const int root = troot[t], lo = root - sz[root] + 1, len = root - lo + 1;
+            std::vector<int> pend_head(len, -1), pend_next;
+            auto children = [&](int c, auto &&f) {
+                for (int cu = pend_head[c - lo]; cu != -1; cu = pend_next[cu]) f(cx.rows.data() + cx.units[cu].off, cx.units[cu].len);
+            };
+            int j = lo;
+            while (j <= root) {
+                const int64_t off = (int64_t) cx.rows.size();
+                const int b = grow(j, root, stamp++, mark, cur, extra, children, cx.rows);
+                if (b < 0) break;                 // the unit that reaches the root: left to the serial pass
+                const int u = (int) cx.units.size();
+                cx.units.push_back(Unit{j, b, (int) t, off, (int) (cx.rows.size() - off)});
+                pend_next.push_back(-1);
+                const int pb = parent[b];
+                if (pb != -1) {
+                    if (pb <= root) { pend_next[u] = pend_head[pb - lo]; pend_head[pb - lo] = u; }
+                    else cx.pend_out.push_back({u, pb});
+                }
+                j = b + 1;
+            }
+            cx.stop = j;
+            // units pending on columns the task did not finish go to the serial pass too
+            for (int c = std::max(j, lo); c <= root; ++c) for (int cu = pend_head[c - lo]; cu != -1; cu = pend_next[cu]) cx.pend_out.push_back({cu, c});
+            if (j > lo) skip_to[lo] = j;
+        }
+    });
+    // the serial pass over what is left, the task units as children
+    std::vector<Unit> units;
+    for (size_t t = 0; t < troot.size(); ++t) units.insert(units.end(), ctx[t].units.begin(), ctx[t].units.end());
+    {
+        Ctx &cs = ctx.back();
+        const int sctx = (int) troot.size();
+        std::vector<int> pend_head(n, -1), pend_next(units.size(), -1);
+        size_t base = 0;
+        for (size_t t = 0; t < troot.size(); ++t) {
+            for (const auto &po : ctx[t].pend_out) { const int u = (int) base + po.first; pend_next[u] = pend_head[po.second]; pend_head[po.second] = u; }
+            base += ctx[t].units.size();
+        }
+        auto children = [&](int c, auto &&f) {
+            for (int cu = pend_head[c]; cu != -1; cu = pend_next[cu]) { const Unit &q = units[cu]; f(ctx[q.ctx].rows.data() + q.off, q.len); }
+        };
+        std::vector<int> mark(n, -1), cur, extra;
+        int stamp = 0, j = 0;
+        while (j < n) {
+            if (skip_to[j] > j) { j = skip_to[j]; continue; }
+            const int64_t off = (int64_t) cs.rows.size();
+            const int b = grow(j, (int) n, stamp++, mark, cur, extra, children, cs.rows);
+            const int u = (int) units.size();
+            units.push_back(Unit{j, b, sctx, off, (int) (cs.rows.size() - off)});
+            pend_next.push_back(-1);
+            if (parent[b] != -1) { pend_next[u] = pend_head[parent[b]]; pend_head[parent[b]] = u; }
+            j = b + 1;
+        }
     }
+    // units in column order; rows gathered into one array
+    std::vector<int> uord(units.size());
+    std::iota(uord.begin(), uord.end(), 0);
+    std::sort(uord.begin(), uord.end(), [&](int x, int y) { return units[x].first < units[y].first; });
+    std::vector<int> ufirst(units.size()), ulast(units.size());
+    sy->srow_off.assign(units.size() + 1, 0);
+    for (size_t i = 0; i < uord.size(); ++i) { const Unit &q = units[uord[i]]; ufirst[i] = q.first; ulast[i] = q.last; sy->srow_off[i + 1] = sy->srow_off[i] + q.len; }
+    sy->srows.resize(sy->srow_off[units.size()]);
+    parallel_chunks((int64_t) uord.size(), 64, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            const Unit &q = units[uord[i]];
+            std::copy(ctx[q.ctx].rows.data() + q.off, ctx[q.ctx].rows.data() + q.off + q.len, sy->srows.data() + sy->srow_off[i]);
+            for (int c = q.first; c <= q.last; ++c) sy->supno[c] = (int) i;
+        }
+    });
+    std::vector<Ctx>().swap(ctx);
     lap("supernodal structure");
     const int ns = (int) ufirst.size();
     hs.nsupers = ns;
@@ -364,7 +442,7 @@ int sluamd_dsymbfact_unsym(sluamd_symb_t *out, int64_t n, const sluamd_int_t *ro
     static const bool timing = getenv("SLUAMD_SYMB_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
-    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[sluamd_dsymbfact_unsym] %-28s %.2f s\n", what, t - t_prev); t_prev = t; } };
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[sluamd_dsymbfact_unsym] %-28s %.3f s\n", what, t - t_prev); t_prev = t; } };
     if (int rc = order_and_etree(n, rowptr, colind, perm_c, perm, parent, g, perm_c_out, lap)) return rc;
     g = Graph();
     // columns of A1 (unsymmetric pattern, final labels)

@@ -124,3 +124,29 @@ def test_library_poisson_generator_equals_the_numpy_construction():
         rp2 = np.empty(n + 1, dtype=np.int32); ci2 = np.empty(nnz, dtype=np.int32); v2 = np.empty(nnz)
         got = L.sluamd_poisson3d(nx, ny, nz, rp2.ctypes.data_as(P_int), ci2.ctypes.data_as(P_int), v2.ctypes.data_as(P_dbl))
         assert got == nnz and (rp2 == rp).all() and (ci2 == ci).all() and (v2 == v).all(), (nx, ny, nz)
+
+
+@pytest.mark.parametrize("case", ["poisson_nd", "stencil_unsym", "natural"])
+def test_parallel_supernodal_structure_equals_the_serial_pass(case, monkeypatch):
+    """sluamd_dsymbfact builds the row structures of disjoint etree subtrees on worker threads and finishes the supernodes that reach a subtree's root (and
+    everything above the cut) serially: the structure (supernode partition, L index, U index, value offsets, final perm_c) must be the serial pass's,
+    whatever the cut -- SLUAMD_SYMB_CUT forces the task path on small structures (0: serial)."""
+    import os
+    if case == "poisson_nd":
+        n, rp, ci, v = matgen.poisson3d(18); perm = matgen.nd_perm_grid3d(18, 18, 18, leaf=27); relax, maxsup = 8, 64
+    elif case == "stencil_unsym":
+        n, rp, ci, v = matgen.stencil3d_unsym(12, drop=0.3, seed=4); perm = matgen.nd_perm_grid3d(12, 12, 12, leaf=27); relax, maxsup = 4, 32
+    else:
+        n, rp, ci, v = matgen.poisson3d(12); perm = None; relax, maxsup = 1, 16
+    ref = None
+    for cut in ["0", "1", "7", "150", "100000"]:
+        monkeypatch.setenv("SLUAMD_SYMB_CUT", cut)
+        s = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
+        fs = s.flat_store(values=False)
+        got = (fs.xsup.copy(), fs.Lrowind.copy(), fs.Ufstnz.copy(), fs.Lnzval_off.copy(), fs.Unzval_off.copy(), np.asarray(s.perm_c).copy())
+        s.free()
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), (case, cut)
