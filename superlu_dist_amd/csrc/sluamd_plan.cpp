@@ -1513,7 +1513,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     int table_rc = 0;
     size_t table_bytes = 0;
     struct TJoiner { std::thread th; ~TJoiner() { if (th.joinable()) th.join(); } } table_job;
-    table_job.th = std::thread([H, &t, &hs, &table_rc, &table_bytes] {
+    static const bool sync_tables = getenv("SLUAMD_SYNC_TABLE_UPLOAD") != nullptr;      // development: the upload at its old place, on this thread
+    auto table_upload = [H, &t, &hs, &table_rc, &table_bytes] {
         table_rc = [&]() -> int {
             HIPCHK(hipSetDevice(H->device));
             auto &K = H->d_misc;
@@ -1538,7 +1539,8 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
             table_bytes = upload_bytes() - mark;
             return 0;
         }();
-    });
+    };
+    if (!sync_tables) table_job.th = std::thread(table_upload);
 
     // ---- 6. schedules ----
     int nlevtot = 0;
@@ -1636,7 +1638,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     auto &K = H->d_misc;
     DevTables &T = H->T;
     T.val = H->d_val;
-    table_job.th.join();          // the block / tile tables went up beside the schedule construction
+    if (sync_tables) { table_upload(); table_bytes = 0; } else table_job.th.join();          // the block / tile tables went up beside the schedule construction
     if (table_rc) return table_rc;
     upload_bytes() += table_bytes;
     H->h_sn_dinv = t.sn_dinv;

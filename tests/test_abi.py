@@ -31,3 +31,18 @@ def test_no_cpu_fallback_without_device():
     n, rp, ci, v = matgen.poisson3d(3)
     with pytest.raises(RuntimeError, match="no HIP device|failed"):
         driver.pdgssvx3d(n, rp, ci, v, np.ones(n))
+
+
+def test_replaced_allocation_operators_stay_inside_the_library():
+    """sluamd_alloc.cpp replaces operator new / delete for the library's OWN host tables (2 MB-aligned, MADV_HUGEPAGE blocks); the link's version script
+    (csrc/sluamd.map) must keep them local -- a drop-in library that exported them would replace the host application's allocator."""
+    import shutil, subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    lib = os.path.join(ROOT, "superlu_dist_amd", "libsluamd.so")
+    if not os.path.exists(lib) or not (shutil.which("nm") or os.path.exists(nm)):
+        pytest.skip("library or nm not present")
+    dyn = subprocess.run([nm, "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    leaked = [ln for ln in dyn.splitlines() if re.search(r"\b_Z(nw|na|dl|da)[mP]", ln)]
+    assert not leaked, leaked
+    local = subprocess.run([nm, lib], capture_output=True, text=True, check=True).stdout
+    assert re.search(r" t _Znwm$", local, flags=re.M), "the library's own operator new is missing (sluamd_alloc.cpp not linked?)"
