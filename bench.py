@@ -571,6 +571,13 @@ def main():
             "k_schur<64,64,4>": {"bound": "hbm", "ms": ts, "flops": st["flops_schur_exact"] - fb, "achieved_tflops": (st["flops_schur_exact"] - fb) / (ts * 1e-3) / 1e12,
                                  "algorithmic_bytes": st["schur_bytes_alg"] - bb, "achieved": (st["schur_bytes_alg"] - bb) / (ts * 1e-3) / 1e9, "unit": "GB/s",
                                  "frac": (st["schur_bytes_alg"] - bb) / (ts * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+        # The epilogue of either configuration is one fp64 atomic per updated element (16 algorithmic bytes): the unit the small-tile configuration actually
+        # saturates is the L2 atomic pipe, measured at 168-188 G elements/s on this part (profiles/r02_ubench_atomic_f64.txt), not HBM
+        ATOMIC_PEAK_GELEM_S = 187.7
+        for key, nbytes, ms in (("k_schur<128,128,8>", bb, tb), ("k_schur<64,64,4>", st["schur_bytes_alg"] - bb, ts)):
+            rate = nbytes / 16.0 / (ms * 1e-3) / 1e9
+            out["roofline"]["by_configuration"][key]["atomics"] = {"achieved": rate, "peak": ATOMIC_PEAK_GELEM_S, "unit": "G fp64 atomics/s", "frac": rate / ATOMIC_PEAK_GELEM_S,
+                                                                   "peak_source": "profiles/r02_ubench_atomic_f64.txt (cold destinations)"}
     # second roofline: the triangular solve is HBM-bound, 8 B per stored factor entry per solve (nrhs = 1)
     esz = 16 if zwork else 8
     solve_bytes = esz * float(st["nnz_L"] + st["nnz_U"])
