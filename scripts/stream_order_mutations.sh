@@ -22,6 +22,9 @@ muts=(
   'hipStreamWaitEvent(us, e_split_urgent, 0);'
   'hipStreamWaitEvent(u2s, e_split_urgent, 0); hipStreamWaitEvent(u2s, e_rest, 0);'
   'hipStreamWaitEvent(s, e_split_urgent, 0); hipStreamWaitEvent(s, e_rest, 0);'
+  # merged chain groups (round 5, SLUAMD_SOLVE_GROUPS=1): the group stream waits for the members' panels / inverses; the factorisation for the group stream
+  'hipEventRecord(e_g, s); hipStreamWaitEvent(H->gstream, e_g, 0);'
+  'if (!H->lvl_groups.empty() && H->gstream) wait_on(s, H->gstream);'
 )
 # dependency table of the dataflow sweeps: forward update waits for its supernode's diagonal solve; diagonal solve waits for the
 # updates it receives (forward / backward); backward update waits for the supernodes whose x it reads

@@ -79,6 +79,29 @@ def test_joined_links_of_the_triangular_sweeps(sched, monkeypatch, join_max, mod
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 4), (2, 2), (3, 5), (3, 9)])
+def test_merged_chain_groups_of_the_sweeps(sched, monkeypatch, mode, seed):
+    """SLUAMD_SOLVE_GROUPS=1 (opt-in): the inverse of a group's block triangle is built during pdgstrf3d on a stream of its OWN (gather of the members' panels and
+    inverses, then up to six dependent batches of dense products) -- after the panels and inverses of the group's last member (event on the bulk stream), before the
+    factorisation returns (the bulk stream waits for the group stream); the sweeps then run the contracted schedule (group strips in the two-launch form, dead rows /
+    columns skipped).  Under the adversarial scheduler a missing wait on either side gives a wrong solution."""
+    N = 20
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(7)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    x_ref, info, st0 = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=16, maxsup=64)
+    monkeypatch.setenv("SLUAMD_SOLVE_GROUPS", "1")
+    _sched(sched, mode, seed)
+    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=16, maxsup=64)
+    _sched(sched, 0)
+    assert info == 0
+    assert st["solve_launches"] < st0["solve_launches"]                 # groups were found
+    assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
+    assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
+
+
 @pytest.mark.parametrize("sort_rows,pinned", [(True, None), (False, None), (True, 4096), (True, 1000)])
 def test_unsorted_panel_rows_of_a_view(emul, monkeypatch, sort_rows, pinned):
     """The reference's symbfact leaves the row subscripts INSIDE an L block in discovery order.  Round 4: a handle created from such a view keeps the rows
