@@ -8,6 +8,9 @@
 // sp_ienv_dist(3).  The algorithm is our own: elimination tree of A+A^T (Liu), postorder composed into
 // perm_c (as sp_colorder does), supernodal structure by child-structure union.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <thread>
 #include <chrono>
@@ -888,56 +891,56 @@ extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const slua
         for (int64_t i = 0; i < n; ++i)
             for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) { const int j = colind[e]; if (j != i) { adj[pos[i]++] = j; adj[pos[j]++] = (int) i; } }
     }   // (duplicate edges of a symmetric input are harmless to BFS)
+    // Recursive bisection as independent jobs.  A job = a vertex set + the END of its label range: labels are handed out from the end (separators last), the set's
+    // separator takes the top of the range, the far half the labels below it, the near half the rest -- exactly what the depth-first order of a single stack gives,
+    // so the permutation does not depend on how many threads run the jobs (plan_threads(); sets of <= 4096 vertices stay on the thread that produced them).
+    // Shared arrays are touched per vertex by the job that owns the vertex; a BFS reads `part` of foreign neighbours, whose value is never this job's id.
     std::vector<int> part(n, 0);            // id of the vertex set a vertex currently belongs to; -1 = numbered
-    std::vector<int> level(n, -1), queue; queue.reserve(1024);
-    struct Job { std::vector<int> verts; };
-    std::vector<Job> stack;
-    { Job all; all.verts.resize(n); std::iota(all.verts.begin(), all.verts.end(), 0); stack.push_back(std::move(all)); }
-    int64_t next = n;                        // labels are handed out from the end: separators last
-    int next_part = 1;
-    auto number = [&](const std::vector<int> &vs) { for (auto it = vs.rbegin(); it != vs.rend(); ++it) { perm_c[*it] = (int) --next; part[*it] = -1; } };
-    // BFS inside the set `id` from `root`; fills queue (visit order) and level[]; returns the number of levels
-    auto bfs = [&](int root, int id) {
-        queue.clear(); queue.push_back(root); level[root] = 0;
-        int nl = 1;
-        for (size_t h = 0; h < queue.size(); ++h) {
-            const int v = queue[h];
-            for (int64_t e = off[v]; e < off[v + 1]; ++e) {
-                const int w = adj[e];
-                if (part[w] == id && level[w] < 0) { level[w] = level[v] + 1; nl = level[w] + 1; queue.push_back(w); }
-            }
-        }
-        return nl;
-    };
-    while (!stack.empty()) {
-        Job job = std::move(stack.back()); stack.pop_back();
+    std::vector<int> level(n, -1);
+    struct Job { std::vector<int> verts; int64_t end; };
+    std::atomic<int> next_part{1};
+    std::atomic<int64_t> numbered{0};
+    auto process = [&](Job &job, std::vector<int> &queue, std::vector<Job> &out) {
         std::vector<int> &V = job.verts;
-        if (V.empty()) continue;
-        const int id = next_part++;
+        if (V.empty()) return;
+        const int id = next_part.fetch_add(1);
+        auto number = [&](const std::vector<int> &vs, int64_t end) { int64_t nx = end; for (auto it = vs.rbegin(); it != vs.rend(); ++it) { perm_c[*it] = (int) --nx; part[*it] = -1; } numbered.fetch_add((int64_t) vs.size()); };
+        // BFS inside the set `id` from `root`; fills queue (visit order) and level[]; returns the number of levels
+        auto bfs = [&](int root) {
+            queue.clear(); queue.push_back(root); level[root] = 0;
+            int nl = 1;
+            for (size_t h = 0; h < queue.size(); ++h) {
+                const int v = queue[h];
+                for (int64_t e = off[v]; e < off[v + 1]; ++e) {
+                    const int w = adj[e];
+                    if (part[w] == id && level[w] < 0) { level[w] = level[v] + 1; nl = level[w] + 1; queue.push_back(w); }
+                }
+            }
+            return nl;
+        };
         for (int v : V) part[v] = id;
-        if ((int) V.size() <= leaf) { number(V); continue; }
+        if ((int) V.size() <= leaf) { number(V, job.end); return; }
         // disconnected set: label ALL its connected components in one sweep (one BFS each, every vertex visited once -- peeling one
-        // component per iteration and rescanning the rest costs O(|V| * #components) on block-diagonal inputs) and push them
-        // in reverse discovery order, so that they are dissected in discovery order as before
-        int nl = bfs(V[0], id);
+        // component per iteration and rescanning the rest costs O(|V| * #components) on block-diagonal inputs); they are
+        // dissected -- and numbered -- in discovery order
+        int nl = bfs(V[0]);
         if (queue.size() < V.size()) {
-            std::vector<Job> comps;
-            { Job c; c.verts = queue; comps.push_back(std::move(c)); }
-            for (int v : V) if (level[v] < 0) { bfs(v, id); Job c; c.verts = queue; comps.push_back(std::move(c)); }
+            int64_t end = job.end;
+            { Job c; c.verts = queue; c.end = end; end -= (int64_t) c.verts.size(); out.push_back(std::move(c)); }
+            for (int v : V) if (level[v] < 0) { bfs(v); Job c; c.verts = queue; c.end = end; end -= (int64_t) c.verts.size(); out.push_back(std::move(c)); }
             for (int v : V) level[v] = -1;
-            for (size_t q = comps.size(); q-- > 0;) stack.push_back(std::move(comps[q]));
-            continue;
+            return;
         }
         // pseudo-peripheral root: restart from a vertex of the last level while the level structure gets deeper
         for (int it = 0; it < 4; ++it) {
             int far = queue.back(), best = (int) (off[far + 1] - off[far]);
             for (size_t q = queue.size(); q-- > 0 && level[queue[q]] == nl - 1;) { const int v = queue[q], dg = (int) (off[v + 1] - off[v]); if (dg < best) { best = dg; far = v; } }
             for (int v : queue) level[v] = -1;
-            const int nl2 = bfs(far, id);
+            const int nl2 = bfs(far);
             if (nl2 <= nl) { nl = nl2; break; }
             nl = nl2;
         }
-        if (nl < 3) { for (int v : queue) level[v] = -1; number(V); continue; }     // (near-)clique: nothing to dissect
+        if (nl < 3) { for (int v : queue) level[v] = -1; number(V, job.end); return; }     // (near-)clique: nothing to dissect
         // the level that halves the component; among the levels around it the smallest one
         std::vector<int64_t> cnt(nl, 0);
         for (int v : queue) cnt[level[v]]++;
@@ -957,9 +960,51 @@ extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const slua
             }
         }
         for (int v : queue) level[v] = -1;
-        number(sep);
-        stack.push_back(std::move(lo)); stack.push_back(std::move(hi));
+        number(sep, job.end);
+        hi.end = job.end - (int64_t) sep.size();
+        lo.end = hi.end - (int64_t) hi.verts.size();
+        out.push_back(std::move(hi)); out.push_back(std::move(lo));
+    };
+    {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<Job> shared;
+        int active = 0;
+        { Job all; all.verts.resize(n); std::iota(all.verts.begin(), all.verts.end(), 0); all.end = n; shared.push_back(std::move(all)); }
+        const int nthr = std::max(1, plan_threads());
+        auto worker = [&]() {
+            std::vector<int> queue; queue.reserve(1024);
+            std::vector<Job> local, out;
+            for (;;) {
+                Job job;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !shared.empty() || active == 0; });
+                    if (shared.empty()) { cv.notify_all(); return; }
+                    job = std::move(shared.back()); shared.pop_back(); ++active;
+                }
+                local.clear(); local.push_back(std::move(job));
+                while (!local.empty()) {
+                    Job j = std::move(local.back()); local.pop_back();
+                    out.clear();
+                    process(j, queue, out);
+                    bool gave = false;
+                    for (Job &c : out) {
+                        if (nthr > 1 && c.verts.size() > 4096) { std::lock_guard<std::mutex> lk(mu); shared.push_back(std::move(c)); gave = true; }
+                        else local.push_back(std::move(c));
+                    }
+                    if (gave) cv.notify_all();
+                }
+                { std::lock_guard<std::mutex> lk(mu); --active; }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthr; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
     }
+    const int64_t next = n - numbered.load();
     if (next != 0) { set_error("ordering did not number every vertex"); return SLUAMD_ESTRUCT; }
     return 0;
 }

@@ -150,3 +150,26 @@ def test_parallel_supernodal_structure_equals_the_serial_pass(case, monkeypatch)
         else:
             for a, b in zip(ref, got):
                 assert np.array_equal(a, b), (case, cut)
+
+
+def test_nested_dissection_ordering_does_not_depend_on_the_thread_count():
+    """sluamd_order_nd runs the recursive bisection as independent jobs on the planner's host threads; every job carries the end of its label range (separator on
+    top, far half below it, near half last), so the permutation is the one of the depth-first single-thread order whatever the number of threads."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+            "from superlu_dist_amd import driver, matgen\n"
+            "out = []\n"
+            "for gen, leaf in ((lambda: matgen.poisson3d(0, 120, 120, 1), 32), (lambda: matgen.elasticity3d_like(12, drop=0.05, seed=1), 64), (lambda: matgen.random_unsym(4000, 0.002, seed=3), 16)):\n"
+            "    n, rp, ci, v = gen()\n"
+            "    p = driver.order_nd(n, rp, ci, leaf=leaf)\n"
+            "    assert np.array_equal(np.sort(p), np.arange(n))\n"
+            "    out.append(hashlib.sha1(np.ascontiguousarray(p).tobytes()).hexdigest())\n"
+            "print(' '.join(out))\n") % root
+    res = {}
+    for threads in ("1", "2", "7", "16"):
+        env = dict(os.environ, SLUAMD_PLAN_THREADS=threads)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[threads] = r.stdout.strip().splitlines()[-1]
+    assert len(set(res.values())) == 1, res
