@@ -1600,22 +1600,7 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     H->st.chain_levels = 0; H->st.chain_units = 0;
     for (auto &S : H->sched) if (S.chain_l0 >= 0) { H->st.chain_levels += S.nlevels - S.chain_l0; H->st.chain_units += (int64_t) S.cf_units.size() / 8; }
 
-    // ---- 7. device allocations + uploads ----
-    arena_job.th.join();
-    if (arena_rc == 1) {
-        (void) hipGetLastError();
-        size_t fr = 0, tot = 0;
-        hipMemGetInfo(&fr, &tot);
-        char msg[512];
-        snprintf(msg, sizeof msg, "hipMalloc of the value arena failed: rank (%d,%d,%d) of the %d x %d x %d grid needs %.1f GB (own L/U slots %.1f GB + exchange scratch %.1f GB) "
-                 "and %.1f GB of %.1f GB are free on device %d -- use a larger process grid (scripts/capacity.py prints the per-rank storage of a grid)",
-                 H->grid.r, H->grid.c, H->grid.z, H->grid.Pr, H->grid.Pc, H->grid.Pz, esz * (double) H->arena_len / 1e9, esz * (double) H->own_len / 1e9,
-                 esz * (double) (H->arena_len - H->own_len) / 1e9, fr / 1e9, tot / 1e9, H->device);
-        set_error(msg);
-        return SLUAMD_ENOMEM;
-    }
-    if (arena_rc) { set_error("allocation / zero fill of the value arena failed"); return SLUAMD_EHIP; }
-    H->setup.lap("arena_alloc_zero_wait");
+    // ---- 7. device allocations + uploads (the value arena is still being allocated and zero-filled by its helper thread: joined at the end, nothing here touches it) ----
     if (H->env.reserve_cus > 0) {
         // keep `reserve_cus` compute units out of the main (Schur tile) stream: the panel kernels of the look-ahead stream then
         // always find a free CU (LDS for a whole TRSM strip / diagonal block) instead of waiting for a Schur workgroup to retire
@@ -1637,7 +1622,6 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     HIPCHK(hipEventCreate(&H->ev0)); HIPCHK(hipEventCreate(&H->ev1));
     auto &K = H->d_misc;
     DevTables &T = H->T;
-    T.val = H->d_val;
     if (sync_tables) { table_upload(); table_bytes = 0; } else table_job.th.join();          // the block / tile tables went up beside the schedule construction
     if (table_rc) return table_rc;
     upload_bytes() += table_bytes;
@@ -1697,6 +1681,22 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     rc = eng::setup();
     if (rc) return rc;
     H->setup.lap("upload.rest");
+    arena_job.th.join();
+    if (arena_rc == 1) {
+        (void) hipGetLastError();
+        size_t fr = 0, tot = 0;
+        hipMemGetInfo(&fr, &tot);
+        char msg[512];
+        snprintf(msg, sizeof msg, "hipMalloc of the value arena failed: rank (%d,%d,%d) of the %d x %d x %d grid needs %.1f GB (own L/U slots %.1f GB + exchange scratch %.1f GB) "
+                 "and %.1f GB of %.1f GB are free on device %d -- use a larger process grid (scripts/capacity.py prints the per-rank storage of a grid)",
+                 H->grid.r, H->grid.c, H->grid.z, H->grid.Pr, H->grid.Pc, H->grid.Pz, esz * (double) H->arena_len / 1e9, esz * (double) H->own_len / 1e9,
+                 esz * (double) (H->arena_len - H->own_len) / 1e9, fr / 1e9, tot / 1e9, H->device);
+        set_error(msg);
+        return SLUAMD_ENOMEM;
+    }
+    if (arena_rc) { set_error("allocation / zero fill of the value arena failed"); return SLUAMD_EHIP; }
+    H->setup.lap("arena_alloc_zero_wait");
+    T.val = H->d_val;
     H->st.nnz_L = hs.nnzL; H->st.nnz_U = hs.nnzU;
     // everything this handle allocated on the device: the value arena, the inverse stores and every uploaded table (index images, block / tile
     // tables, tile lists, unit lists and records, pair maps; round 3 counted the index images only)
