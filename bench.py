@@ -337,6 +337,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     dist_backend = os.environ.get("SLUAMD_DIST_BACKEND", "rccl")
+    dist_backend_used = [dist_backend]      # "gloo" after a failed RCCL communicator creation (N > 1)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -398,9 +399,23 @@ def main():
                 # the per-tile records of the Schur kernel are an accelerator (2-4 ms at 100^3) that costs 20-29 % of the factor bytes: at sizes that
                 # fill the device they stay off (bench.py --gpus 8 --n 300 picks this by itself)
                 os.environ["SLUAMD_NO_TILE_MAPS"] = "1"
-            if dist_backend == "rccl":
-                if "comm" not in comm_cache:
+            if dist_backend == "rccl" and "comm" not in comm_cache:
+                # the communicator is created by the library (ncclCommInitRank); if that fails on ANY rank (no peer access, a driver without dmabuf IPC ...)
+                # every rank falls back to the host-staged transport together, and the line says so: a slow measured number instead of a hung job
+                import torch
+                err = ""
+                try:
                     comm_cache["comm"] = grid3d.rccl_comm(dist, *grid, local_rank)
+                except Exception as e:     # noqa: BLE001 -- reported in the JSON line
+                    err = str(e)[:300]
+                bad = torch.tensor([1 if err else 0])
+                dist.all_reduce(bad)
+                if int(bad.item()):
+                    comm_cache.pop("comm", None)
+                    comm_cache["rccl_error"] = err or "communicator creation failed on another rank"
+                    dist_backend_used[0] = "gloo"
+            if dist_backend_used[0] == "rccl":
+                pass
             elif "comm" not in comm_cache:
                 comm_cache["tcomm"] = grid3d.TorchComm(dist, *grid)
                 comm_cache["comm"] = comm_cache["tcomm"].handle
@@ -541,7 +556,7 @@ def main():
                    "n": n, "nnz_A": int(len(v)), "nnz_LU": int(st["nnz_L"] + st["nnz_U"]), "nsupers": symb.nsupers,
                    "parallelism": "single GPU" if world == 1 else
                    f"{grid[0]}x{grid[1]}x{grid[2]} process grid, one rank per GPU: XY block-cyclic panels + Z-sharded elimination forests; "
-                   f"panel exchange / ancestor reduction / solve exchanges by the library's C driver over {'RCCL (ncclSend/ncclRecv)' if dist_backend == 'rccl' else 'host-staged gloo callbacks'}"},
+                   f"panel exchange / ancestor reduction / solve exchanges by the library's C driver over {'RCCL (ncclSend/ncclRecv)' if dist_backend_used[0] == 'rccl' else 'host-staged gloo callbacks' + (' -- RCCL communicator creation FAILED: ' + comm_cache['rccl_error'] if comm_cache.get('rccl_error') else '')}"},
         "flops_per_step": F, "flops_schur_padded": st["flops_schur_padded"],
         "factor_ms": float(np.mean(fact_ms)), "solve_ms": float(np.mean(solve_ms)),
         "factor_gflops_kernel_only": F / (np.mean(fact_ms) * 1e-3) / 1e9,

@@ -103,10 +103,16 @@ def rccl_comm(dist, Pr, Pc, Pz, device):
     L = _lib.load()
     rank = dist.get_rank()
     idbuf = (C.c_char * 128)()
+    obj = [None]
     if rank == 0:
-        _lib.check(L.sluamd_comm_rccl_unique_id(idbuf), "sluamd_comm_rccl_unique_id")
-    obj = [bytes(idbuf) if rank == 0 else None]
+        try:
+            _lib.check(L.sluamd_comm_rccl_unique_id(idbuf), "sluamd_comm_rccl_unique_id")
+            obj = [bytes(idbuf)]
+        except Exception as e:     # noqa: BLE001 -- the other ranks wait in the broadcast: tell them, then everybody raises
+            obj = ["ERROR: " + str(e)]
     dist.broadcast_object_list(obj, src=0)
+    if not isinstance(obj[0], (bytes, bytearray)):
+        raise RuntimeError("sluamd_comm_rccl_unique_id failed on rank 0: " + str(obj[0]))
     idbuf = (C.c_char * 128).from_buffer_copy(obj[0])
     r, c, z = grid_coords(rank, Pr, Pc, Pz)
     h = C.c_void_p()

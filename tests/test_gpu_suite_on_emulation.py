@@ -149,3 +149,20 @@ def test_bench_script_flow_on_the_emulation(ngpu, tmp_path):
         assert set(("exchange_ms", "reduce_ms", "schur_ms", "panel_ms")) <= set(j["phases"])
         assert j["phases"]["reduce_ms"] > 0 and (ngpu < 8 or j["phases"]["exchange_ms"] > 0)
     assert ("1x1x1" if ngpu == 1 else "1x1x2" if ngpu == 2 else "2x2x2") in j["config"]["workload"]
+
+
+def test_bench_falls_back_to_staged_exchanges_when_the_rccl_communicator_cannot_be_created(tmp_path):
+    """bench.py --gpus 2 with the measured transport selected (RCCL) on a library that cannot create an RCCL communicator (the CPU test build has none): every
+    rank must fall back to the host-staged exchanges TOGETHER -- a measured line that names the failure, not a job hung in a barrier."""
+    import json
+    env = dict(os.environ, SLUAMD_LIB=os.path.join(ROOT, "oracle", "libsluamd_emul.so"), OMP_NUM_THREADS="1")
+    env.pop("SLUAMD_EMUL_SCHED", None); env.pop("SLUAMD_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29583",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid-side", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-scaling-point"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["residual"] < 1e-10
+    assert "RCCL communicator creation FAILED" in j["config"]["parallelism"] and "host-staged" in j["config"]["parallelism"]
