@@ -79,9 +79,9 @@ def test_merged_chain_groups_of_the_sweeps_give_the_ungrouped_solution():
     perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
     rng = np.random.default_rng(5)
     out = {}
+    saved = os.environ.get("SLUAMD_SOLVE_GROUPS")
     for grouped in (False, True):
-        if grouped:
-            os.environ["SLUAMD_SOLVE_GROUPS"] = "1"
+        os.environ["SLUAMD_SOLVE_GROUPS"] = "1" if grouped else "0"       # explicit both ways: the suite may be run with the variable set
         try:
             symb = driver.Symbolic(n, rp, ci, perm, relax=32, maxsup=64)
             h = driver.LUHandle.from_symbolic(symb, v)
@@ -100,7 +100,8 @@ def test_merged_chain_groups_of_the_sweeps_give_the_ungrouped_solution():
             out[grouped] = (xs, launches)
             h.destroy(); symb.free()
         finally:
-            os.environ.pop("SLUAMD_SOLVE_GROUPS", None)
+            if saved is None: os.environ.pop("SLUAMD_SOLVE_GROUPS", None)
+            else: os.environ["SLUAMD_SOLVE_GROUPS"] = saved
     for a, b in zip(out[False][0], out[True][0]):
         assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())
     assert out[True][1] < out[False][1], (out[True][1], out[False][1])      # the groups were found and used

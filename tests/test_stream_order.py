@@ -91,6 +91,7 @@ def test_merged_chain_groups_of_the_sweeps(sched, monkeypatch, mode, seed):
     v = v * (1.0 + 0.3 * rng.random(v.size))
     perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
     xt, b = matgen.xtrue_rhs(n, rp, ci, v, 2)
+    monkeypatch.setenv("SLUAMD_SOLVE_GROUPS", "0")
     x_ref, info, st0 = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=16, maxsup=64)
     monkeypatch.setenv("SLUAMD_SOLVE_GROUPS", "1")
     _sched(sched, mode, seed)
