@@ -4,6 +4,7 @@
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -m gpu -q -x --timeout=900 > gpurun_out/r05_gputest_final.log 2>&1; echo "pytest rc $?" >> gpurun_out/r05_gputest_final.log)
 tail -4 gpurun_out/r05_gputest_final.log
+python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' 2>&1 | tail -2
 python bench.py > gpurun_out/r05_bench100_final.json 2> gpurun_out/r05_bench100_final.err
 python - <<'PY'
 import json
