@@ -30,8 +30,9 @@ struct Graph {           // permuted symmetric pattern, strictly-lower and stric
     std::vector<int> lo, up;   // lo: rows > col ; up: rows < col
 };
 
-void build_graph(int64_t n, const int *rowptr, const int *colind, const int *perm, Graph &g)
+void build_graph(int64_t n, const int *rowptr, const int *colind, const int *perm, Graph &g, bool want_lo = true, bool want_up = true)
 {
+    // (want_lo / want_up: the elimination tree reads only the upper lists, the structure pass only the lower ones -- each caller builds the half it uses)
     // two passes over the rows of A on the planner's threads: degrees (relaxed atomic increments), serial prefix sums, fill (atomic slot claims).
     // The order of the entries inside an adjacency list therefore varies from run to run; every consumer is order-independent (Liu's elimination
     // tree is unique, the structure pass sorts what it collects).
@@ -42,7 +43,8 @@ void build_graph(int64_t n, const int *rowptr, const int *colind, const int *per
                 const int a = perm[i], b = perm[colind[e]];
                 if (a == b) continue;
                 const int lo = std::min(a, b), hi = std::max(a, b);
-                __atomic_fetch_add(&cl[lo + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&cu[hi + 1], 1, __ATOMIC_RELAXED);
+                if (want_lo) __atomic_fetch_add(&cl[lo + 1], 1, __ATOMIC_RELAXED);
+                if (want_up) __atomic_fetch_add(&cu[hi + 1], 1, __ATOMIC_RELAXED);
             }
     });
     for (int64_t i = 0; i < n; ++i) { cl[i + 1] += cl[i]; cu[i + 1] += cu[i]; }
@@ -55,7 +57,8 @@ void build_graph(int64_t n, const int *rowptr, const int *colind, const int *per
                 const int a = perm[i], b = perm[colind[e]];
                 if (a == b) continue;
                 const int lo = std::min(a, b), hi = std::max(a, b);
-                g.lo[__atomic_fetch_add(&pl[lo], 1, __ATOMIC_RELAXED)] = hi; g.up[__atomic_fetch_add(&pu[hi], 1, __ATOMIC_RELAXED)] = lo;
+                if (want_lo) g.lo[__atomic_fetch_add(&pl[lo], 1, __ATOMIC_RELAXED)] = hi;
+                if (want_up) g.up[__atomic_fetch_add(&pu[hi], 1, __ATOMIC_RELAXED)] = lo;
             }
     });
 }
@@ -71,7 +74,7 @@ static int order_and_etree(int64_t n, const int *rowptr, const int *colind, cons
         std::vector<char> seen(n, 0);
         for (int64_t i = 0; i < n; ++i) { if (perm[i] < 0 || perm[i] >= n || seen[perm[i]]) { set_error("perm_c is not a permutation"); return SLUAMD_EINVAL; } seen[perm[i]] = 1; }
     }
-    build_graph(n, rowptr, colind, perm.data(), g);
+    build_graph(n, rowptr, colind, perm.data(), g, false, true);      // upper lists: the elimination tree
     lap("graph");
     // ---- elimination tree (Liu, path compression) ----
     parent.assign(n, -1);
@@ -112,7 +115,7 @@ static int order_and_etree(int64_t n, const int *rowptr, const int *colind, cons
         parent.swap(p2);
     }
     lap("etree + postorder");
-    build_graph(n, rowptr, colind, perm.data(), g);  // adjacency in final labels
+    build_graph(n, rowptr, colind, perm.data(), g, true, false);  // lower adjacency in final labels: the structure pass
     lap("graph (final labels)");
     return 0;
 }
