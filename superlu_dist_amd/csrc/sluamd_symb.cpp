@@ -203,6 +203,8 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
         int b;
         const bool bounded = lim < (int) n;
         cur.clear();
+        int nrun = 0;
+        size_t run_off[10] = {0};
         auto add_adj = [&](int c) {
             for (int64_t e = g.lo_off[c]; e < g.lo_off[c + 1]; ++e) { int r = g.lo[e]; if (mark[r] != stamp) { mark[r] = stamp; cur.push_back(r); } }
         };
@@ -214,7 +216,12 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
             b = a;
             if (bounded && a >= lim) return -1;
             add_adj(a);
-            children(a, [&](const int *rows, int len) { for (int i = 0; i < len; ++i) { const int r = rows[i]; if (mark[r] != stamp) { mark[r] = stamp; cur.push_back(r); } } });
+            // the rows taken from one child unit stay ascending (a subsequence of its sorted list): remembered as runs, merged instead of sorted below
+            nrun = 0; run_off[0] = cur.size();
+            children(a, [&](const int *rows, int len) {
+                for (int i = 0; i < len; ++i) { const int r = rows[i]; if (mark[r] != stamp) { mark[r] = stamp; cur.push_back(r); } }
+                if (nrun < 8) run_off[++nrun] = cur.size(); else nrun = 9;
+            });
             // extend the supernode by column c = b+1 (its etree parent) while struct(c) ~= struct(b) \ {c}.
             // Non-fundamental supernodes are allowed (other children of c may hang anywhere), and so is a small
             // amount of explicit-zero padding (relaxed amalgamation): where two ND separators meet, every
@@ -245,7 +252,18 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
                 b = c;
             }
         }
-        // finalize: rows > b, sorted
+        // finalize: rows > b, sorted.  A separator piece takes tens of thousands of rows from ONE or two children (the previous piece of its chain, the two
+        // subtrees below a separator's first column) and a handful from its own columns: sort the handfuls, merge the runs -- the sort of every piece was the
+        // serial share of this pass at 150^3
+        if (nrun >= 1 && nrun <= 8 && cur.size() > 2048) {
+            std::sort(cur.begin(), cur.begin() + run_off[0]);
+            std::sort(cur.begin() + run_off[nrun], cur.end());
+            for (int q = 0; q < nrun; ++q) std::inplace_merge(cur.begin(), cur.begin() + run_off[q], cur.begin() + run_off[q + 1]);
+            std::inplace_merge(cur.begin(), cur.begin() + run_off[nrun], cur.end());
+            const size_t skip = std::upper_bound(cur.begin(), cur.end(), b) - cur.begin();      // the unit's own columns a + 1 .. b
+            out.insert(out.end(), cur.begin() + skip, cur.end());
+            return b;
+        }
         size_t w = 0;
         for (size_t i = 0; i < cur.size(); ++i) if (cur[i] > b) cur[w++] = cur[i];
         cur.resize(w);
@@ -294,6 +312,7 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
             if (j > lo) skip_to[lo] = j;
         }
     });
+    lap("structure: subtree tasks");
     // the serial pass over what is left, the task units as children
     std::vector<Unit> units;
     for (size_t t = 0; t < troot.size(); ++t) units.insert(units.end(), ctx[t].units.begin(), ctx[t].units.end());
@@ -311,6 +330,7 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
         };
         std::vector<int> mark(n, -1), cur, extra;
         int stamp = 0, j = 0;
+        int64_t dbg_units = 0, dbg_cols = 0, dbg_rows = 0;
         while (j < n) {
             if (skip_to[j] > j) { j = skip_to[j]; continue; }
             const int64_t off = (int64_t) cs.rows.size();
@@ -319,9 +339,12 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
             units.push_back(Unit{j, b, sctx, off, (int) (cs.rows.size() - off)});
             pend_next.push_back(-1);
             if (parent[b] != -1) { pend_next[u] = pend_head[parent[b]]; pend_head[parent[b]] = u; }
+            dbg_units++; dbg_cols += b - j + 1; dbg_rows += (int64_t) (cs.rows.size() - off);
             j = b + 1;
         }
+        if (timing) fprintf(stderr, "[sluamd_dsymbfact] serial pass: %lld units, %lld columns, %lld rows kept; %zu task units\n", (long long) dbg_units, (long long) dbg_cols, (long long) dbg_rows, units.size() - (size_t) dbg_units);
     }
+    lap("structure: serial top");
     // units in column order; rows gathered into one array
     std::vector<int> uord(units.size());
     std::iota(uord.begin(), uord.end(), 0);
@@ -338,7 +361,7 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
         }
     });
     std::vector<Ctx>().swap(ctx);
-    lap("supernodal structure");
+    lap("structure: gather");
     const int ns = (int) ufirst.size();
     hs.nsupers = ns;
     hs.xsup.resize(ns + 1);
