@@ -299,13 +299,15 @@ static int build_tables(Handle &H, HostTables &t)
     // block costs two 128-row tiles of which the second is 1/8 full and still takes half the time of a full one (the chunk period has a latency
     // floor).  Per U block the rows of the L blocks at and below it are re-cut into tiles when that saves a tile; the destination row map of such
     // a tile is a search in the destination panel's (ascending) row list instead of one block's row list.  Real arithmetic, list schedules only.
+    // (two passes over the supernodes on the planner's threads, like the block tables above: count -> prefix sums -> fill; the tables come out as the serial loop wrote them)
     t.ub_mrt_off.assign(t.ub_gid.size(), 0); t.ub_mrt_cnt.assign(t.ub_gid.size(), 0);
-    if (!H.env.no_merge_tiles && !H.opt.deterministic)
-        for (int k = 0; k < ns; ++k) {
-            if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_rows_sorted[k]) continue;
+    if (!H.env.no_merge_tiles && !H.opt.deterministic) {
+        auto rows_of = [&](int k, int64_t base, bool write) -> int64_t {
+            if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_rows_sorted[k]) return 0;
             const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k], nb = t.sn_nlb[k], nub = t.sn_nub[k];
             const int bfirst = t.sn_ldiag[k] ? 1 : 0;
             const int tm = (t.sn_big[k] ? 128 : 64) / (H.z ? 2 : 1);      // complex16: a tile is 64 / 32 panel rows (128 / 64 real rows of the embedding)
+            int64_t cnt = 0;
             for (int u = 0; u < nub; ++u) {
                 const int jb = t.ub_gid[ub0 + u];
                 if (!t.sn_rows_sorted[jb] || !(t.sn_flags[jb] & SNF_L_OWN)) continue;
@@ -317,24 +319,37 @@ static int build_tables(Handle &H, HostTables &t)
                 const int row0 = t.lb_rowoff[lb0 + bs], rows = t.sn_nsupr[k] - row0;
                 const int merged = (rows + tm - 1) / tm;
                 if (merged >= regular) continue;
-                t.ub_mrt_off[ub0 + u] = (int) t.rtile.size(); t.ub_mrt_cnt[ub0 + u] = merged;
-                int b = bs;
-                for (int r0 = 0; r0 < rows; r0 += tm) {
-                    while (b + 1 < nb && t.lb_rowoff[lb0 + b + 1] <= row0 + r0) ++b;        // block that holds the tile's first row
-                    t.rtile.push_back(make_int4(b, row0 + r0 - t.lb_rowoff[lb0 + b], std::min(tm, rows - r0), row0 + r0));
-                    t.rt_info.push_back(make_int2(t.lb_gid[lb0 + b], 0));
+                if (write) {
+                    t.ub_mrt_off[ub0 + u] = (int) (base + cnt); t.ub_mrt_cnt[ub0 + u] = merged;
+                    int b = bs;
+                    int64_t w = base + cnt;
+                    for (int r0 = 0; r0 < rows; r0 += tm, ++w) {
+                        while (b + 1 < nb && t.lb_rowoff[lb0 + b + 1] <= row0 + r0) ++b;        // block that holds the tile's first row
+                        t.rtile[w] = make_int4(b, row0 + r0 - t.lb_rowoff[lb0 + b], std::min(tm, rows - r0), row0 + r0);
+                        t.rt_info[w] = make_int2(t.lb_gid[lb0 + b], 0);
+                    }
                 }
+                cnt += merged;
             }
-        }
+            return cnt;
+        };
+        std::vector<int64_t> off(ns + 1, 0);
+        parallel_chunks(ns, 64, [&](int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; ++k) off[k + 1] = rows_of((int) k, 0, false); });
+        const int64_t base0 = (int64_t) t.rtile.size();
+        for (int k = 0; k < ns; ++k) off[k + 1] += off[k];
+        t.rtile.resize(base0 + off[ns]); t.rt_info.resize(base0 + off[ns]);
+        parallel_chunks(ns, 64, [&](int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; ++k) rows_of((int) k, base0 + off[k], true); });
+    }
     // ... and merged COLUMN tiles: L(ib, k) U(k, jb) of every block column jb > ib lands in ONE destination U row (ib); the non-empty columns of
     // those U blocks are contiguous in the U slot of k.  Destination column map = rank of the global column in row ib's ascending column list.
     t.lb_mct_off.assign(t.lb_gid.size(), 0); t.lb_mct_cnt.assign(t.lb_gid.size(), 0);
-    if (!H.env.no_merge_tiles && !H.opt.deterministic)
-        for (int k = 0; k < ns; ++k) {
-            if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_ucols_sorted[k]) continue;
+    if (!H.env.no_merge_tiles && !H.opt.deterministic) {
+        auto cols_of = [&](int k, int64_t base, bool write) -> int64_t {
+            if (!hs.present[k] || !t.sn_nrt[k] || !t.sn_nct[k] || !t.sn_ucols_sorted[k]) return 0;
             const int lb0 = t.sn_lb_off[k], ub0 = t.sn_ub_off[k], nb = t.sn_nlb[k], nub = t.sn_nub[k];
             const int bfirst = t.sn_ldiag[k] ? 1 : 0;
             const int tn = t.sn_big[k] ? 128 : 64;
+            int64_t cnt = 0;
             for (int b = bfirst; b < nb; ++b) {
                 const int ib = t.lb_gid[lb0 + b];
                 if (!t.sn_ucols_sorted[ib] || !(t.sn_flags[ib] & SNF_U_OWN)) continue;
@@ -346,15 +361,27 @@ static int build_tables(Handle &H, HostTables &t)
                 const int col0 = t.ub_stcol[ub0 + us], cols = t.sn_ncolu[k] - col0;
                 const int merged = (cols + tn - 1) / tn;
                 if (merged >= regular) continue;
-                t.lb_mct_off[lb0 + b] = (int) t.ctile.size(); t.lb_mct_cnt[lb0 + b] = merged;
-                int u = us;
-                for (int c0 = 0; c0 < cols; c0 += tn) {
-                    while (u + 1 < nub && t.ub_stcol[ub0 + u + 1] <= col0 + c0) ++u;        // U block that holds the tile's first column
-                    t.ctile.push_back(make_int4(u, col0 + c0 - t.ub_stcol[ub0 + u], std::min(tn, cols - c0), 0));
-                    t.ct_info.push_back(make_int4(t.ub_gid[ub0 + u], (int) (t.sn_uidx[k] + t.ub_iukp[ub0 + u]), col0 + c0, 0));
+                if (write) {
+                    t.lb_mct_off[lb0 + b] = (int) (base + cnt); t.lb_mct_cnt[lb0 + b] = merged;
+                    int u = us;
+                    int64_t w = base + cnt;
+                    for (int c0 = 0; c0 < cols; c0 += tn, ++w) {
+                        while (u + 1 < nub && t.ub_stcol[ub0 + u + 1] <= col0 + c0) ++u;        // U block that holds the tile's first column
+                        t.ctile[w] = make_int4(u, col0 + c0 - t.ub_stcol[ub0 + u], std::min(tn, cols - c0), 0);
+                        t.ct_info[w] = make_int4(t.ub_gid[ub0 + u], (int) (t.sn_uidx[k] + t.ub_iukp[ub0 + u]), col0 + c0, 0);
+                    }
                 }
+                cnt += merged;
             }
-        }
+            return cnt;
+        };
+        std::vector<int64_t> off(ns + 1, 0);
+        parallel_chunks(ns, 64, [&](int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; ++k) off[k + 1] = cols_of((int) k, 0, false); });
+        const int64_t base0 = (int64_t) t.ctile.size();
+        for (int k = 0; k < ns; ++k) off[k + 1] += off[k];
+        t.ctile.resize(base0 + off[ns]); t.ct_info.resize(base0 + off[ns]);
+        parallel_chunks(ns, 64, [&](int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; ++k) cols_of((int) k, base0 + off[k], true); });
+    }
     H.setup.lap("tables.merged_tiles");
     if (H.z) { st.flops_schur_padded *= 4; st.flops_schur_exact *= 4; st.flops_panel *= 4; st.schur_bytes_alg *= 2; }   // complex multiply-add = 8 flop
     H.h_nsupr = t.sn_nsupr; H.h_ldu = t.sn_ldu; H.h_ncolu = t.sn_ncolu; H.h_flags = t.sn_flags; H.h_ldiag = t.sn_ldiag;
