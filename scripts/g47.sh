@@ -1,4 +1,4 @@
-for t in 16 1; do
+for t in 16; do
 echo "== SLUAMD_PLAN_THREADS=$t"
 SLUAMD_PLAN_THREADS=$t python - <<'PY' 2>&1 | tail -3
 import time

@@ -468,7 +468,9 @@ int slots_from_symb(Handle &H, const Symb &sy, const Grid &g, const int32_t *sn_
     hs.present.assign(ns, 0);
     for (auto &l : in.lists) for (int k : l) hs.present[k] = 1;
     in.lidx.assign(ns, {}); in.uidx.assign(ns, {}); in.succ.assign(ns, {});
-    for (int k = 0; k < ns; ++k) {
+    // (every supernode fills its own three lists: on the planner's threads)
+    parallel_chunks(ns, 64, [&](int64_t kk0, int64_t kk1) {
+    for (int k = (int) kk0; k < (int) kk1; ++k) {
         if (!hs.present[k]) continue;
         const int *li = full.lidx.data() + full.lidx_off[k];
         const int64_t ulen = full.uidx_off[k + 1] - full.uidx_off[k];
@@ -506,8 +508,9 @@ int slots_from_symb(Handle &H, const Symb &sy, const Grid &g, const int32_t *sn_
             o[0] = nb; o[1] = nnz; o[2] = (int) o.size();
             if (!nb) o.clear();
         }
+        { auto &sc = in.succ[k]; std::sort(sc.begin(), sc.end()); sc.erase(std::unique(sc.begin(), sc.end()), sc.end()); }      // (finish_succ, per supernode)
     }
-    finish_succ(in);
+    });
     return split_wide_supernodes(H, in);   // supernodes of 257..512 columns (maxsup up to MAX_SUPER_SIZE): refined like the view path
 }
 

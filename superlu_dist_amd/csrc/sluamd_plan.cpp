@@ -2,6 +2,7 @@
 // (own slots ordered by Z level, DAG level, supernode so that every exchange moves ONE contiguous range), device block
 // tables / tile lists (dSchurComplementSetup's job, dtrfAux.c:102-491, done once), XY panel-exchange plans.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -411,10 +412,16 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
         if (y < 0) return false;
         const int *ra = hs.lidx.data() + hs.lidx_off[a] + t.lb_lptr[la + x], *rb = hs.lidx.data() + hs.lidx_off[b] + t.lb_lptr[lb + y];
         const int na = t.lb_nbrow[la + x], nb = t.lb_nbrow[lb + y];
+        const int *walk = rb;                      // both lists ascending (every store the handle builds): one merge walk instead of a search per row
         for (int i = 0; i < na; ++i) {
-            const int *f = std::lower_bound(rb, rb + nb, ra[i]);                    // the rows of a block are ascending in every store the handle builds ...
-            if (f == rb + nb || *f != ra[i]) f = std::find(rb, rb + nb, ra[i]);     // ... (a caller's unsorted block: linear search)
-            if (f == rb + nb) return false;
+            while (walk < rb + nb && *walk < ra[i]) ++walk;
+            const int *f = walk;
+            if (f == rb + nb || *f != ra[i]) {
+                f = std::lower_bound(rb, rb + nb, ra[i]);
+                if (f == rb + nb || *f != ra[i]) f = std::find(rb, rb + nb, ra[i]);     // (a caller's unsorted block: linear search)
+                if (f == rb + nb) return false;
+                walk = rb;                         // order broken: the walk restarts, the searches above carry the block
+            }
             rowmap[t.lb_rowoff[lb + y] + (int) (f - rb)] = t.lb_rowoff[la + x] + i;
         }
         rows_a += na;
@@ -430,8 +437,11 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
         const int64_t pa = hs.uidx_off[a] + t.ub_iukp[ua + x], pb = hs.uidx_off[b] + t.ub_iukp[ub + y];
         const int *ca = t.unzcol.data() + pa, *cb = t.unzcol.data() + pb;
         const int na = t.ub_ncols[ua + x], nb = t.ub_ncols[ub + y];
+        const int *walk = cb;
         for (int i = 0; i < na; ++i) {
-            const int *f = std::lower_bound(cb, cb + nb, ca[i]);                    // non-empty columns of a U block: ascending by construction (build_tables)
+            while (walk < cb + nb && *walk < ca[i]) ++walk;                         // non-empty columns of a U block: ascending by construction (build_tables)
+            const int *f = walk;
+            if (f == cb + nb || *f != ca[i]) { f = std::lower_bound(cb, cb + nb, ca[i]); walk = cb; }
             if (f == cb + nb || *f != ca[i]) return false;
             const int c = t.ub_stcol[ub + y] + (int) (f - cb), jj = ca[i];
             colinfo[2 * c] = t.ucolptr[pa + jj];
@@ -1324,19 +1334,26 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     }
     hs.lidx.assign(hs.lidx_off[ns], 0); hs.uidx.assign(hs.uidx_off[ns], 0);
     hs.lval_len.assign(ns, 0); hs.uval_len.assign(ns, 0);
-    for (int k = 0; k < ns; ++k) {
-        if (!hs.present[k]) continue;
-        if (!in.lidx[k].empty()) {
-            if ((int64_t) in.lidx[k].size() != BC_HEADER + (int64_t) in.lidx[k][0] * LB_DESCRIPTOR + in.lidx[k][1]) { set_error("L index array length mismatch"); return SLUAMD_ESTRUCT; }
-            std::copy(in.lidx[k].begin(), in.lidx[k].end(), hs.lidx.begin() + hs.lidx_off[k]);
-            hs.lval_len[k] = (int64_t) in.lidx[k][1] * nsupc_of(hs, k);
-        }
-        if (!in.uidx[k].empty()) {
-            if (in.uidx[k].size() < (size_t) BR_HEADER || in.uidx[k][2] != (int) in.uidx[k].size()) { set_error("U index array length mismatch"); return SLUAMD_ESTRUCT; }
-            std::copy(in.uidx[k].begin(), in.uidx[k].end(), hs.uidx.begin() + hs.uidx_off[k]);
-            hs.uval_len[k] = in.uidx[k][1];
-        }
-        in.lidx[k] = std::vector<int>(); in.uidx[k] = std::vector<int>();
+    {
+        std::atomic<int> bad{0};      // 1: L index array, 2: U index array
+        parallel_chunks(ns, 64, [&](int64_t k0, int64_t k1) {
+            for (int k = (int) k0; k < (int) k1; ++k) {
+                if (!hs.present[k]) continue;
+                if (!in.lidx[k].empty()) {
+                    if ((int64_t) in.lidx[k].size() != BC_HEADER + (int64_t) in.lidx[k][0] * LB_DESCRIPTOR + in.lidx[k][1]) { bad = 1; continue; }
+                    std::copy(in.lidx[k].begin(), in.lidx[k].end(), hs.lidx.begin() + hs.lidx_off[k]);
+                    hs.lval_len[k] = (int64_t) in.lidx[k][1] * nsupc_of(hs, k);
+                }
+                if (!in.uidx[k].empty()) {
+                    if (in.uidx[k].size() < (size_t) BR_HEADER || in.uidx[k][2] != (int) in.uidx[k].size()) { bad = 2; continue; }
+                    std::copy(in.uidx[k].begin(), in.uidx[k].end(), hs.uidx.begin() + hs.uidx_off[k]);
+                    hs.uval_len[k] = in.uidx[k][1];
+                }
+                in.lidx[k] = std::vector<int>(); in.uidx[k] = std::vector<int>();
+            }
+        });
+        if (bad == 1) { set_error("L index array length mismatch"); return SLUAMD_ESTRUCT; }
+        if (bad == 2) { set_error("U index array length mismatch"); return SLUAMD_ESTRUCT; }
     }
 
     H->setup.lap("index_arenas");
