@@ -197,6 +197,7 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     struct Unit { int first, last, ctx; int64_t off; int len; };
     struct Ctx { std::vector<int> rows; std::vector<Unit> units; std::vector<std::pair<int, int>> pend_out; int stop = 0; };      // pend_out: (local unit, column it pends on) beyond the task
     static const bool equal_split = getenv("SLUAMD_SYMB_EQUAL_SPLIT") != nullptr;   // development: round-2 rule (equal pieces)
+    const bool run_merge = getenv("SLUAMD_SYMB_NO_RUN_MERGE") == nullptr;           // tests: sort every unit's rows instead of merging the child runs
     // grows the unit that starts at column a.  children(c, f): f(rows, len) for every unit pending on column c; lim: last column the unit may examine
     // (task: its root; returns -1 when the unit reaches it -- not this task's to finish).  Appends the sorted rows > b to `out`, returns b.
     auto grow = [&](int a, int lim, int stamp, std::vector<int> &mark, std::vector<int> &cur, std::vector<int> &extra, auto &&children, std::vector<int> &out) -> int {
@@ -255,7 +256,7 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
         // finalize: rows > b, sorted.  A separator piece takes tens of thousands of rows from ONE or two children (the previous piece of its chain, the two
         // subtrees below a separator's first column) and a handful from its own columns: sort the handfuls, merge the runs -- the sort of every piece was the
         // serial share of this pass at 150^3
-        if (nrun >= 1 && nrun <= 8 && cur.size() > 2048) {
+        if (run_merge && nrun >= 1 && nrun <= 8 && cur.size() > 2048) {
             std::sort(cur.begin(), cur.begin() + run_off[0]);
             std::sort(cur.begin() + run_off[nrun], cur.end());
             for (int q = 0; q < nrun; ++q) std::inplace_merge(cur.begin(), cur.begin() + run_off[q], cur.begin() + run_off[q + 1]);

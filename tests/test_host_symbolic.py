@@ -173,3 +173,20 @@ def test_nested_dissection_ordering_does_not_depend_on_the_thread_count():
         assert r.returncode == 0, r.stderr[-2000:]
         res[threads] = r.stdout.strip().splitlines()[-1]
     assert len(set(res.values())) == 1, res
+
+
+def test_merged_child_runs_give_the_sorted_row_structure(monkeypatch):
+    """The structure pass keeps the rows a unit takes from each child unit as ascending runs and merges them (units of more than 2048 collected rows) instead of
+    sorting the collection; SLUAMD_SYMB_NO_RUN_MERGE=1 restores the sort.  60^3: the pieces of the top separators collect up to ~7000 rows."""
+    N = 60
+    n, rp, ci, v = matgen.poisson3d(N); perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    got = {}
+    for key, env in (("merge", None), ("sort", "1")):
+        if env: monkeypatch.setenv("SLUAMD_SYMB_NO_RUN_MERGE", env)
+        else: monkeypatch.delenv("SLUAMD_SYMB_NO_RUN_MERGE", raising=False)
+        s = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=256)
+        fs = s.flat_store(values=False)
+        got[key] = (fs.xsup.copy(), fs.Lrowind.copy(), fs.Ufstnz.copy(), fs.Lnzval_off.copy(), fs.Unzval_off.copy(), np.asarray(s.perm_c).copy())
+        s.free()
+    for a, b in zip(got["merge"], got["sort"]):
+        assert np.array_equal(a, b)
