@@ -353,6 +353,7 @@ int_t BIND_NAME(superlu_dist_options_t *options, int m, int n, double anorm,
     sluamd_options_t o;
     S.default_options(&o);
     o.replace_tiny_pivot = (options->ReplaceTinyPivot == YES);
+    o.info_rule = SLUAMD_INFO_REFERENCE;       /* a drop-in user gets the zero-pivot rule of the reference's code (pdgstrf2.c:568-571, MIN over ranks pdgstrf3d.c:388-392) */
 
     int rc;
     const char *tr = getenv("SLUAMD_BIND_TRANSPORT");

@@ -87,8 +87,17 @@ typedef struct sluamd_options {
     int32_t deterministic;      /* 1: one supernode per Schur launch -> fixed summation order of the factors (the solve
                                  *    still accumulates lsum with fp64 atomics)                 */
     int32_t verbose;
-    double  reserved[4];
+    int32_t info_rule;          /* which zero pivot `info` names on an exactly singular matrix (round 6; a former reserved slot -- the struct's size and the
+                                 * offsets of the fields above are unchanged):
+                                 *   SLUAMD_INFO_FIRST (0, sluamd_default_options): the smallest zero-pivot column -- the DOCUMENTED meaning (pdgstrf2.c:493-497)
+                                 *   SLUAMD_INFO_REFERENCE (1): what the reference's CODE leaves -- Local_Dgstrf2 overwrites *info at every zero pivot
+                                 *     (pdgstrf2.c:568-571), so a rank keeps the one it met LAST; pdgstrf3d takes the MIN over the ranks (pdgstrf3d.c:388-392).
+                                 *     The reference-side binding (bindings/superlu_dist/sluamd_binding.c) selects this one. */
+    int32_t reserved_i;
+    double  reserved[3];
 } sluamd_options_t;
+#define SLUAMD_INFO_FIRST 0
+#define SLUAMD_INFO_REFERENCE 1
 
 typedef struct sluamd_stats {
     double flops_schur_padded; /* reference tally 2*nbrow*ldu*ncols (sec_structs.c:692-693), in double */

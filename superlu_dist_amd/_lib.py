@@ -26,7 +26,7 @@ class ForestView(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("replace_tiny_pivot", C.c_int32), ("deterministic", C.c_int32),
-                ("verbose", C.c_int32), ("reserved", C.c_double * 4)]
+                ("verbose", C.c_int32), ("info_rule", C.c_int32), ("reserved_i", C.c_int32), ("reserved", C.c_double * 3)]
 
 
 class Stats(C.Structure):

@@ -143,6 +143,7 @@ static int create_from_view(sluamd_handle_t *out, const sluamd_dLUview_t *lu, co
     H->opt = o;
     H->z = z;
     H->comm = comm;
+    H->env.info_last = o.info_rule == SLUAMD_INFO_REFERENCE;
     read_env(H->env);
     auto fail = [&](int code) { sluamd_dDestroyLUHandle(hh); return code; };
     if (hipGetDevice(&H->device) != hipSuccess) { set_error("hipGetDevice failed"); return fail(SLUAMD_EHIP); }
@@ -226,6 +227,7 @@ static int create_from_symb(sluamd_handle_t *out, sluamd_symb_t s, const sluamd_
     H->opt = o;
     H->z = z;
     H->comm = comm;
+    H->env.info_last = o.info_rule == SLUAMD_INFO_REFERENCE;
     read_env(H->env);
     auto fail = [&](int code) { sluamd_dDestroyLUHandle(hh); return code; };
     if (hipGetDevice(&H->device) != hipSuccess) { set_error("hipGetDevice failed"); return fail(SLUAMD_EHIP); }

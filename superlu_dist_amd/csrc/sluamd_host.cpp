@@ -40,7 +40,7 @@ void read_env(Handle::Env &e)
 {
     e.no_lookahead = getenv("SLUAMD_NO_LOOKAHEAD") != nullptr;
     e.no_tile_maps = getenv("SLUAMD_NO_TILE_MAPS") != nullptr;
-    if (const char *il = getenv("SLUAMD_INFO_LAST")) e.info_last = atoi(il) != 0;
+    if (const char *il = getenv("SLUAMD_INFO_LAST")) e.info_last = atoi(il) != 0;   // overrides sluamd_options_t::info_rule (the callers set e.info_last from it first)
     if (const char *sg = getenv("SLUAMD_SOLVE_GROUPS")) e.solve_groups = atoi(sg) != 0;
     if (const char *sg = getenv("SLUAMD_SOLVE_GROUP_LEVEL_NODES")) e.solve_group_level_nodes = std::max(1, atoi(sg));
     if (const char *zf = getenv("SLUAMD_ZFUSE_MAX_NODES")) e.z_fuse_max_nodes = std::max(0, atoi(zf));

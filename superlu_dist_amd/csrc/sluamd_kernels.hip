@@ -1163,6 +1163,34 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
     }
 }
 
+// Instrumentation switches of the epilogue decomposition (scripts/ab_epilogue.sh builds the variants; the product build never sets them):
+//   SLUAMD_EXP_EPI    2 = the product's epilogue (one fp64 atomic per updated element), 1 = plain load-subtract-store (racy between concurrent
+//                     sources of one destination: timing only), 0 = no scatter at all (the accumulators are kept alive by an impossible branch)
+//   SLUAMD_EXP_NOLOAD 1 = the K loop's operands are constants: no global loads between the prologue and the epilogue (LDS stores, reads, barriers, MFMAs stay)
+#ifndef SLUAMD_EXP_EPI
+#define SLUAMD_EXP_EPI 2
+#endif
+#ifndef SLUAMD_EXP_NOLOAD
+#define SLUAMD_EXP_NOLOAD 0
+#endif
+// prefetch depth of the K loop of the two-stage (128 x 128) configurations: 1 = the next chunk is in flight while the current one runs (rounds 1-5);
+// 2 = TWO register sets -- the chunk after next is requested before the current chunk's MFMAs, the next chunk's set is stashed behind them: a load has two chunk
+// periods to arrive, so a workgroup that runs alone on its CU (its neighbour in its prologue / epilogue) no longer waits for it
+#ifndef SLUAMD_SCHUR_PD
+#define SLUAMD_SCHUR_PD 1
+#endif
+#ifndef SLUAMD_SCHUR_FETCH2
+#define SLUAMD_SCHUR_FETCH2 1     // 0: the loader of rounds 1-5 (kept for the same-box A/B)
+#endif
+// a pointer every lane holds alike, moved to SGPRs so that loads take the (SGPR base + 32-bit VGPR offset) form
+typedef const char __attribute__((address_space(1))) *gbytes_t;     // (global address space kept through the integer round trip: global_load, not flat_load)
+typedef const double __attribute__((address_space(1))) *gdouble_t;
+__device__ __forceinline__ gbytes_t uniform_ptr(const double *p)
+{
+    const uint64_t v = (uint64_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) v), hi = __builtin_amdgcn_readfirstlane((uint32_t) (v >> 32));
+    return (gbytes_t) (((uint64_t) hi << 32) | lo);
+}
 #ifndef SCHUR64_WGS
 #define SCHUR64_WGS 5   // workgroups per CU the 64 x 64 tile configuration is built for (<= 4: two LDS stages, as the 128 x 128 one); the complex
                         // variant fits six without spills (76 VGPRs) and is built for six: zgrid2d 1000 24.8 -> 23.9 ms; the double one spills at 80: +1.6 ms
@@ -1448,7 +1476,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
 
     const int li = tid % TMv, lk = tid / TMv;           // L loader: row li, k = lk + LKS*q
     const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + UJS*q
+    constexpr int PD = (NBUF == 2 && !SK) ? SLUAMD_SCHUR_PD : 1;      // (the split-K chain tiles keep the one-set loop: their sources are a few chunks long)
     double pl[LQ], pu[UQ];
+    double pl2[PD == 2 ? LQ : 1], pu2[PD == 2 ? UQ : 1];
     const int *cpS = s_cptr, *ldS = s_lead;   // column maps of the current source (LDS): re-read per chunk, registers are scarce
     bool lrow_ok = li < nr;
     // complex L loader: real row li = (panel row li / 2, part a), the thread's k all have parity b = lk & 1: it reads part a ^ b,
@@ -1459,28 +1489,78 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     // per-source state of the K loop (source 0 = fused predecessor ka, source 1 = k itself); ns_s counts REAL k (2 per complex one)
     int ns_s = ZS * ns, lda_s = lda;
     const double *Lrow = Lp + lrow0, *Uvs = Uv;
+    const double *Lsrc = Lp;                              // SLUAMD_SCHUR_FETCH2: the source panel's base (uniform) and this thread's byte offset from it
+    uint32_t lvo = (uint32_t) (lrow0 + lk * lda) << 3;    //   (row of the tile + its k phase; a slot is far below 2^29 values)
 
-    auto fetch = [&](int k0) {
+    auto fetch_into = [&](double *pl, double *pu, int k0, bool restart = false) {
+#if SLUAMD_EXP_NOLOAD
+        // 1: no loads at all; 2: none at the (re)start of a source's pipeline only; 3: none in the steady state only
+        if (SLUAMD_EXP_NOLOAD == 1 || (SLUAMD_EXP_NOLOAD <= 3 && (SLUAMD_EXP_NOLOAD == 2) == restart)) {
+#pragma unroll
+            for (int q = 0; q < LQ; ++q) pl[q] = 1.0 + 1e-9 * (k0 + q);
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) pu[q] = 1.0 - 1e-9 * (k0 + q);
+            return;
+        }
+#endif
+#if SLUAMD_SCHUR_FETCH2
+        if (!Z) {
+            // Round 6: the loader's issue cost, not the latency of its loads, is what the K loop pays for (profiles/r06_ab_schur_epilogue.txt: no loads at all
+            // -36 ms in the steady state, the same loads served by L1 / L2 / MALL -6 ... -4 ms, a second register set in flight 0 ms): the compiler's form was four
+            // 64-bit multiply-adds for the L addresses and, per U column, TWO dependent LDS round trips (leading zeros -> branch -> value offset) before each load,
+            // serialised by exec-mask branches -- ~1000 cycles per chunk in which the wave issues no MFMA.  Here: wave-uniform 64-bit bases in SGPRs (the panel
+            // column k0 + LKS q is a scalar multiply), one 32-bit byte offset per thread, all eight map entries read by one batch of LDS loads.
+            const gbytes_t Lb0 = uniform_ptr(Lsrc), Ub0 = uniform_ptr(Uvs);
+#pragma unroll
+            for (int q = 0; q < LQ; ++q) {
+                const int kq = k0 + LKS * q;                                   // uniform
+                const gbytes_t sb = Lb0 + ((uint64_t) kq * (uint64_t) lda_s << 3);   // uniform: SALU
+                pl[q] = (lrow_ok && kq + lk < ns_s) ? *(gdouble_t) (sb + (uint64_t) lvo) : 0.0;
+            }
+            int ldq[UQ], cpq[UQ];
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) { ldq[q] = ldS[uj + UJS * q]; cpq[q] = cpS[uj + UJS * q]; }
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) { asm volatile("" : "+v"(ldq[q]), "+v"(cpq[q])); }      // (keeps the eight reads in ONE batch in front of the branches)
+            const int kg = k0 + uk;
+#pragma unroll
+            for (int q = 0; q < UQ; ++q) {
+                const uint32_t uvo = (uint32_t) (cpq[q] - ldq[q] + kg) << 3;
+                pu[q] = (kg >= ldq[q] && kg < ns_s) ? *(gdouble_t) (Ub0 + (uint64_t) uvo) : 0.0;
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int q = 0; q < LQ; ++q) {
             const int kg = k0 + lk + LKS * q;
             if (Z) pl[q] = (lrow_ok && kg < ns_s) ? zsgn * Lrow[(size_t) (kg >> 1) * 2 * lda_s] : 0.0;
+#if SLUAMD_EXP_NOLOAD >= 4      // 4 / 5 / 6: the same load instructions with their addresses wrapped into a 2 MB / 16 KB / 64 MB window of the arena (always L2 / L1 / MALL hits)
+            else pl[q] = (lrow_ok && kg < ns_s) ? T.val[((size_t) (Lrow - T.val) + (size_t) kg * lda_s) & (SLUAMD_EXP_NOLOAD == 4 ? 0x3FFFF : (SLUAMD_EXP_NOLOAD == 5 ? 0x7FF : 0x7FFFFF))] : 0.0;
+#else
             else pl[q] = (lrow_ok && kg < ns_s) ? Lrow[(size_t) kg * lda_s] : 0.0;
+#endif
         }
         const int kg = k0 + uk;
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
             const int ld = ldS[uj + UJS * q];
             if (Z) pu[q] = ((kg >> 1) >= ld && kg < ns_s) ? Uvs[2 * (cpS[uj + UJS * q] + ((kg >> 1) - ld)) + (kg & 1)] : 0.0;
+#if SLUAMD_EXP_NOLOAD >= 4
+            else pu[q] = (kg >= ld && kg < ns_s) ? T.val[((size_t) (Uvs - T.val) + cpS[uj + UJS * q] + (kg - ld)) & (SLUAMD_EXP_NOLOAD == 4 ? 0x3FFFF : (SLUAMD_EXP_NOLOAD == 5 ? 0x7FF : 0x7FFFFF))] : 0.0;
+#else
             else pu[q] = (kg >= ld && kg < ns_s) ? Uvs[cpS[uj + UJS * q] + (kg - ld)] : 0.0;
+#endif
         }
     };
-    auto stash = [&](int buf) {
+    auto stash_from = [&](const double *pl, const double *pu, int buf) {
 #pragma unroll
         for (int q = 0; q < LQ; ++q) Ls[buf][(lk + LKS * q) * LDL + li] = pl[q];
 #pragma unroll
         for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + UJS * q] = pu[q];
     };
+    auto fetch = [&](int k0, bool restart = false) { fetch_into(pl, pu, k0, restart); };
+    auto stash = [&](int buf) { stash_from(pl, pu, buf); };
 
     int buf = 0;
     for (int src = 0; src <= nprev; ++src) {       // farthest predecessor first, k itself last
@@ -1498,6 +1578,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             }
             __syncthreads();
             ns_s = nss; lda_s = ph[1];
+            Lsrc = T.val + (((int64_t) ph[4] << 32) | (uint32_t) ph[3]); lvo = (uint32_t) (max(ra, 0) + lk * lda_s) << 3;
             Lrow = T.val + (((int64_t) ph[4] << 32) | (uint32_t) ph[3]) + max(ra, 0);
             Uvs = T.val + (((int64_t) ph[6] << 32) | (uint32_t) ph[5]);
             kbeg = ph[2]; lrow_ok = ra >= 0;
@@ -1514,10 +1595,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             }
             __syncthreads();
             ns_s = nss; lda_s = T.sn_nsupr[ks]; Lrow = T.val + T.sn_lval[ks] + max(ra, 0); Uvs = T.val + T.sn_uval[ks];
+            Lsrc = T.val + T.sn_lval[ks]; lvo = (uint32_t) (max(ra, 0) + lk * lda_s) << 3;
             kbeg = (nss - T.sn_ldu[ks]) & ~3; lrow_ok = ra >= 0;
             cpS = s_cptr2; ldS = s_lead2;
         } else {
             ns_s = ZS * ns; lda_s = lda; Lrow = Lp + lrow0; Uvs = Uv; lrow_ok = li < nr;
+            Lsrc = Lp; lvo = (uint32_t) (lrow0 + lk * lda) << 3;
             kbeg = kbeg_own;
             cpS = s_cptr; ldS = s_lead;
         }
@@ -1531,7 +1614,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         // chunk at which the destination lines are touched: the one before the last chunk of the last source
         const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((kend - 1 - kbeg) / KC - 1) * KC) : -1;
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
-        fetch(kbeg);
+        if (PD == 2) {
+            // two register sets: set A = chunks kbeg, kbeg + 2 KC, ...; set B = the odd ones.  A fetch past the source's end is a masked-off load (zeros).
+            auto touch = [&]() {
+                constexpr int RG = TMv / 16;
+                const int id0 = tid, id1 = tid + NT;
+                const int c0 = id0 / RG, g0 = id0 % RG, c1 = id1 / RG, g1 = id1 % RG;
+                if (id0 < TNv * RG && c0 < nc && g0 * 16 < nr) touch0 = dst[s_colmap[c0] + s_rowmap[g0 * 16]];
+                if (id1 < TNv * RG && c1 < nc && g1 * 16 < nr) touch1 = dst[s_colmap[c1] + s_rowmap[g1 * 16]];
+            };
+            const int ke = SK ? kend : ns_s;          // loads beyond kend but inside the source are never stashed
+            (void) ke;
+            fetch_into(pl, pu, kbeg);
+            fetch_into(pl2, pu2, kbeg + KC);
+            stash_from(pl, pu, buf);
+            __syncthreads();
+            for (int k0 = kbeg;;) {
+                fetch_into(pl, pu, k0 + 2 * KC);
+                if (k0 == ktouch) touch();
+                if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Ls[buf], Us[buf], rm0, cn0, lane, acc);
+                bool more = k0 + KC < kend;
+                if (more) stash_from(pl2, pu2, buf ^ 1);
+                buf ^= 1;
+                __syncthreads();
+                if (!more) break;
+                k0 += KC;
+                fetch_into(pl2, pu2, k0 + 2 * KC);
+                if (k0 == ktouch) touch();
+                if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Ls[buf], Us[buf], rm0, cn0, lane, acc);
+                more = k0 + KC < kend;
+                if (more) stash_from(pl, pu, buf ^ 1);
+                buf ^= 1;
+                __syncthreads();
+                if (!more) break;
+                k0 += KC;
+            }
+            continue;
+        }
+        fetch(kbeg, true);
         stash(buf);
         __syncthreads();
         for (int k0 = kbeg; k0 < kend; k0 += KC) {
@@ -1557,6 +1677,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     // ---- scatter (epilogue) ----------------------------------------------------------------------
     if (!has_dst) return;
     if (__builtin_expect(touch0 == 1.2345e-300 && touch1 == 1.2345e-300, 0)) atomicAdd(&info[3], 1);   // keeps the touch loads alive
+#if SLUAMD_EXP_EPI == 0
+    {
+        double keep = 0.0;
+#pragma unroll
+        for (int ci = 0; ci < NBC; ++ci)
+#pragma unroll
+            for (int ri = 0; ri < NBR; ++ri) keep += (acc[ci][ri][0] + acc[ci][ri][1]) + (acc[ci][ri][2] + acc[ci][ri][3]);
+        if (__builtin_expect(keep == 1.2345e-300, 0)) atomicAdd(&info[3], 1);
+        return;
+    }
+#endif
 #pragma unroll
     for (int ci = 0; ci < NBC; ++ci)
 #pragma unroll
@@ -1567,7 +1698,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
 #pragma unroll
                 for (int ri = 0; ri < NBR; ++ri) {
                     const int row = rm0 + 16 * ri + (lane & 15);
+#if SLUAMD_EXP_EPI == 1
+                    if (row < nr) dcol[s_rowmap[row]] -= acc[ci][ri][r];
+#else
                     if (row < nr) atomic_sub_f64(dcol + s_rowmap[row], acc[ci][ri][r]);
+#endif
                 }
             }
         }

@@ -279,12 +279,25 @@ int sluamd_dsymbfact(sluamd_symb_t *out, int64_t n, const sluamd_int_t *rowptr, 
     if (const char *e = getenv("SLUAMD_SYMB_CUT")) { cut = atoi(e); tmin = 1; tasks_on = cut > 0; }      // tests: the task path on small structures
     std::vector<int> troot;
     if (tasks_on)
-        for (int jj = 0; jj < n; ++jj) if (sz[jj] <= cut && sz[jj] >= tmin && (parent[jj] == -1 || sz[parent[jj]] > cut)) troot.push_back(jj);
+        for (int jj = 0; jj < n; ++jj)
+            if (sz[jj] <= cut && sz[jj] >= tmin && (parent[jj] == -1 || sz[parent[jj]] > cut)
+                && (parent[jj] == -1 || sz[parent[jj]] > relax))      // never strictly INSIDE a relaxed subtree (cut < relax): its unit [a, b] is one task's or the serial pass's, whole
+                troot.push_back(jj);
     std::vector<Ctx> ctx(troot.size() + 1);
     std::vector<int> skip_to(n, -1);      // first column of a task's range -> first column the task left
+    // one mark / cur / extra set per WORKER, handed from chunk to chunk with its stamp (a fresh n-sized mark array per task cost O(n * #tasks) writes: a forest of
+    // thousands of 256..cut-column subtrees ran slower threaded than serial)
+    struct Scratch { std::vector<int> mark, cur, extra; int stamp = 0; };
+    std::vector<std::unique_ptr<Scratch>> pool;
+    std::mutex pool_mu;
     parallel_chunks((int64_t) troot.size(), 1, [&](int64_t t0, int64_t t1) {
-        std::vector<int> mark(n, -1), cur, extra;
-        int stamp = 0;
+        std::unique_ptr<Scratch> sc;
+        { std::lock_guard<std::mutex> g(pool_mu); if (!pool.empty()) { sc = std::move(pool.back()); pool.pop_back(); } }
+        if (!sc) { sc.reset(new Scratch()); sc->mark.assign(n, -1); }
+        std::vector<int> &mark = sc->mark, &cur = sc->cur, &extra = sc->extra;
+        int &stamp = sc->stamp;
+        struct Back { std::unique_ptr<Scratch> &sc; std::vector<std::unique_ptr<Scratch>> &pool; std::mutex &mu;
+                      ~Back() { std::lock_guard<std::mutex> g(mu); pool.push_back(std::move(sc)); } } back{sc, pool, pool_mu};
         for (int64_t t = t0; t < t1; ++t) {
             Ctx &cx = ctx[t];
             const int root = troot[t], lo = root - sz[root] + 1, len = root - lo + 1;
@@ -923,6 +936,10 @@ extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const slua
     // so the permutation does not depend on how many threads run the jobs (plan_threads(); sets of <= 4096 vertices stay on the thread that produced them).
     // Shared arrays are touched per vertex by the job that owns the vertex; a BFS reads `part` of foreign neighbours, whose value is never this job's id.
     std::vector<int> part(n, 0);            // id of the vertex set a vertex currently belongs to; -1 = numbered
+    // `part` is read by concurrently running jobs (the BFS of one job looks at neighbours another job owns and may be writing): relaxed atomic accesses, so that the
+    // benign race is a defined one (free on x86).  `level` is only ever touched after part[w] == id, i.e. by the owner.
+    auto pget = [&](int v) { return __atomic_load_n(&part[v], __ATOMIC_RELAXED); };
+    auto pset = [&](int v, int x) { __atomic_store_n(&part[v], x, __ATOMIC_RELAXED); };
     std::vector<int> level(n, -1);
     struct Job { std::vector<int> verts; int64_t end; };
     std::atomic<int> next_part{1};
@@ -931,7 +948,7 @@ extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const slua
         std::vector<int> &V = job.verts;
         if (V.empty()) return;
         const int id = next_part.fetch_add(1);
-        auto number = [&](const std::vector<int> &vs, int64_t end) { int64_t nx = end; for (auto it = vs.rbegin(); it != vs.rend(); ++it) { perm_c[*it] = (int) --nx; part[*it] = -1; } numbered.fetch_add((int64_t) vs.size()); };
+        auto number = [&](const std::vector<int> &vs, int64_t end) { int64_t nx = end; for (auto it = vs.rbegin(); it != vs.rend(); ++it) { perm_c[*it] = (int) --nx; pset(*it, -1); } numbered.fetch_add((int64_t) vs.size()); };
         // BFS inside the set `id` from `root`; fills queue (visit order) and level[]; returns the number of levels
         auto bfs = [&](int root) {
             queue.clear(); queue.push_back(root); level[root] = 0;
@@ -940,12 +957,12 @@ extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const slua
                 const int v = queue[h];
                 for (int64_t e = off[v]; e < off[v + 1]; ++e) {
                     const int w = adj[e];
-                    if (part[w] == id && level[w] < 0) { level[w] = level[v] + 1; nl = level[w] + 1; queue.push_back(w); }
+                    if (pget(w) == id && level[w] < 0) { level[w] = level[v] + 1; nl = level[w] + 1; queue.push_back(w); }
                 }
             }
             return nl;
         };
-        for (int v : V) part[v] = id;
+        for (int v : V) pset(v, id);
         if ((int) V.size() <= leaf) { number(V, job.end); return; }
         // disconnected set: label ALL its connected components in one sweep (one BFS each, every vertex visited once -- peeling one
         // component per iteration and rescanning the rest costs O(|V| * #components) on block-diagonal inputs); they are
@@ -982,7 +999,7 @@ extern "C" int sluamd_order_nd(int64_t n, const sluamd_int_t *rowptr, const slua
             else if (level[v] > m) hi.verts.push_back(v);
             else {   // thinning: a separator-level vertex without a neighbour in level m + 1 belongs to the near side
                 bool touches = false;
-                for (int64_t e = off[v]; e < off[v + 1] && !touches; ++e) touches = part[adj[e]] == id && level[adj[e]] == m + 1;
+                for (int64_t e = off[v]; e < off[v + 1] && !touches; ++e) touches = pget(adj[e]) == id && level[adj[e]] == m + 1;
                 if (touches) sep.push_back(v); else lo.verts.push_back(v);
             }
         }

@@ -170,10 +170,11 @@ class LUHandle:
         self.z = False
 
     @staticmethod
-    def _opts(replace_tiny=False, deterministic=False, device=-1):
+    def _opts(replace_tiny=False, deterministic=False, device=-1, info_rule=0):
         o = Options()
         _lib.load().sluamd_default_options(C.byref(o))
         o.device = device; o.replace_tiny_pivot = int(replace_tiny); o.deterministic = int(deterministic)
+        o.info_rule = int(info_rule)        # 1 = SLUAMD_INFO_REFERENCE: the zero-pivot rule of the reference's code (what the binding selects)
         return o
 
     @classmethod

@@ -405,6 +405,12 @@ def test_several_exact_zero_pivots_report_the_first_column():
         h.destroy(); symb.free()
     finally:
         del os.environ["SLUAMD_INFO_LAST"]
+    # the same rule through the ABI (sluamd_options_t::info_rule = SLUAMD_INFO_REFERENCE: what bindings/superlu_dist/sluamd_binding.c sets)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=4, maxsup=8)
+    h = driver.LUHandle.from_symbolic(symb, v, info_rule=1)
+    info = h.pdgstrf3d(0.0)
+    assert info == max(int(symb.perm_c[z]) for z in (10, 41, 77)) + 1, info
+    h.destroy(); symb.free()
 
 
 @pytest.mark.parametrize("kind", ["stencil_unsym", "random_unsym"])
