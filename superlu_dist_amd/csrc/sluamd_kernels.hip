@@ -1183,6 +1183,11 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 #define SLUAMD_SCHUR_FETCH2 1     // 0: the loader of rounds 1-5 (kept for the same-box A/B)
 #endif
 // a pointer every lane holds alike, moved to SGPRs so that loads take the (SGPR base + 32-bit VGPR offset) form
+#ifndef SLUAMD_SCHUR_FETCH3
+#define SLUAMD_SCHUR_FETCH3 1     // the loader in 16-byte loads (two tile rows of one panel column / two k of one U column per lane): half the load instructions,
+#endif                            // map reads and predicates of SLUAMD_SCHUR_FETCH2; 0: that loader
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef const d2 __attribute__((address_space(1), aligned(8))) *gd2_t;      // (the pairs are 8-byte aligned only: panel leading dimensions and segment offsets are arbitrary)
 typedef const char __attribute__((address_space(1))) *gbytes_t;     // (global address space kept through the integer round trip: global_load, not flat_load)
 typedef const double __attribute__((address_space(1))) *gdouble_t;
 __device__ __forceinline__ gbytes_t uniform_ptr(const double *p)
@@ -1491,6 +1496,60 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     const double *Lrow = Lp + lrow0, *Uvs = Uv;
     const double *Lsrc = Lp;                              // SLUAMD_SCHUR_FETCH2: the source panel's base (uniform) and this thread's byte offset from it
     uint32_t lvo = (uint32_t) (lrow0 + lk * lda) << 3;    //   (row of the tile + its k phase; a slot is far below 2^29 values)
+    // SLUAMD_SCHUR_FETCH3: thread = (pair of tile rows 2 li2, 2 li2 + 1; panel column lk3 + LKS3 q) and (pair of k 2 uk2, 2 uk2 + 1; tile column uj3 + UJS3 q)
+    constexpr bool F3 = SLUAMD_SCHUR_FETCH3 && !Z && PD == 1;
+    constexpr int LRP = TMv / 2, LKS3 = NT / LRP, LQ3 = KC / LKS3, UJS3 = NT / 8, UQ3 = TNv / UJS3;
+    const int li2 = tid % LRP, lk3 = tid / LRP, uk2 = tid & 7, uj3 = tid >> 3;
+    d2 wl[F3 ? LQ3 : 1], wu[F3 ? UQ3 : 1];        // the raw 16-byte loads; zeros / halves are selected at the stash, when they have arrived
+    bool un0[F3 ? UQ3 : 1], un1[F3 ? UQ3 : 1];    // per U load: element k / k + 1 is a stored one (at or below the column's leading zeros, inside the source)
+    // per source: which of the two rows exist there (own source: inside the tile; a K-fused predecessor: present in its panel), the byte offset of the first
+    // existing one, and -- rows that are not neighbours in a predecessor's panel (its blocks may come in another order) -- the second one's own offset
+    bool l_has0 = 2 * li2 < nr, l_has1 = 2 * li2 + 1 < nr;
+    bool lon[F3 ? LQ3 : 1];                       // per L load: its panel column lies inside the source
+    uint32_t lvo3 = (uint32_t) (2 * li2 + lk3 * lda) << 3;
+    // (two rows that both exist in a predecessor's panel are neighbours there: the planner only fuses pairs whose row map is monotone, build_pair_maps)
+    auto l3_source = [&](int ra0, int ra1, int ldas) {
+        l_has0 = ra0 >= 0; l_has1 = ra1 >= 0;
+        lvo3 = (uint32_t) ((l_has0 ? ra0 : max(ra1, 0)) + lk3 * ldas) << 3;
+    };
+    // Every load is UNCONDITIONAL (a lane with nothing to fetch reads the first 16 bytes of the source instead): no exec-mask branches, no zero initialisation of
+    // the destination registers -- which the compiler guards with s_waitcnt vmcnt(0), i.e. with the arrival of the loads issued just before
+    auto fetch3 = [&](int k0) {
+        const gbytes_t Lb0 = uniform_ptr(Lsrc), Ub0 = uniform_ptr(Uvs);
+#pragma unroll
+        for (int q = 0; q < LQ3; ++q) {
+            const int kbq = k0 + LKS3 * q;                                            // uniform
+            lon[q] = kbq + lk3 < ns_s;
+            const uint64_t off = lon[q] ? ((uint64_t) kbq * (uint64_t) lda_s << 3) + (uint64_t) lvo3 : 0;
+            wl[q] = *(gd2_t) (Lb0 + off);
+        }
+        int ldq[UQ3], cpq[UQ3];
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) { ldq[q] = ldS[uj3 + UJS3 * q]; cpq[q] = cpS[uj3 + UJS3 * q]; }
+        const int kg = k0 + 2 * uk2;
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) {
+            un0[q] = kg >= ldq[q] && kg < ns_s;
+            un1[q] = kg + 1 >= ldq[q] && kg + 1 < ns_s;
+            const uint32_t uvo = (un0[q] || un1[q]) ? (uint32_t) (cpq[q] + max(kg - ldq[q], 0)) << 3 : 0;     // first stored element of the pair (only k + 1 stored: the segment's first)
+            wu[q] = *(gd2_t) (Ub0 + (uint64_t) uvo);
+        }
+    };
+    auto stash3 = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LQ3; ++q) {
+            d2 v;
+            v.x = (lon[q] && l_has0) ? wl[q].x : 0.0;
+            v.y = (lon[q] && l_has1) ? (l_has0 ? wl[q].y : wl[q].x) : 0.0;
+            *(d2 *) &Ls[buf][(lk3 + LKS3 * q) * LDL + 2 * li2] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) {
+            const double y0 = un0[q] ? wu[q].x : 0.0, y1 = un1[q] ? (un0[q] ? wu[q].y : wu[q].x) : 0.0;
+            Us[buf][(2 * uk2) * LDU + uj3 + UJS3 * q] = y0;
+            Us[buf][(2 * uk2 + 1) * LDU + uj3 + UJS3 * q] = y1;
+        }
+    };
 
     auto fetch_into = [&](double *pl, double *pu, int k0, bool restart = false) {
 #if SLUAMD_EXP_NOLOAD
@@ -1559,8 +1618,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
 #pragma unroll
         for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + UJS * q] = pu[q];
     };
-    auto fetch = [&](int k0, bool restart = false) { fetch_into(pl, pu, k0, restart); };
-    auto stash = [&](int buf) { stash_from(pl, pu, buf); };
+    auto fetch = [&](int k0, bool restart = false) { if (F3 && !SLUAMD_EXP_NOLOAD) fetch3(k0); else fetch_into(pl, pu, k0, restart); };
+    auto stash = [&](int buf) { if (F3 && !SLUAMD_EXP_NOLOAD) stash3(buf); else stash_from(pl, pu, buf); };
 
     int buf = 0;
     for (int src = 0; src <= nprev; ++src) {       // farthest predecessor first, k itself last
@@ -1579,6 +1638,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             __syncthreads();
             ns_s = nss; lda_s = ph[1];
             Lsrc = T.val + (((int64_t) ph[4] << 32) | (uint32_t) ph[3]); lvo = (uint32_t) (max(ra, 0) + lk * lda_s) << 3;
+            if (F3) l3_source(2 * li2 < nr ? T.pair_rowmap[ro + 2 * li2] : -1, 2 * li2 + 1 < nr ? T.pair_rowmap[ro + 2 * li2 + 1] : -1, lda_s);
             Lrow = T.val + (((int64_t) ph[4] << 32) | (uint32_t) ph[3]) + max(ra, 0);
             Uvs = T.val + (((int64_t) ph[6] << 32) | (uint32_t) ph[5]);
             kbeg = ph[2]; lrow_ok = ra >= 0;
@@ -1596,11 +1656,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             __syncthreads();
             ns_s = nss; lda_s = T.sn_nsupr[ks]; Lrow = T.val + T.sn_lval[ks] + max(ra, 0); Uvs = T.val + T.sn_uval[ks];
             Lsrc = T.val + T.sn_lval[ks]; lvo = (uint32_t) (max(ra, 0) + lk * lda_s) << 3;
+            if (F3) { const int64_t ro = (int64_t) T.pair_roff[pj] + Rw; l3_source(2 * li2 < nr ? T.pair_rowmap[ro + 2 * li2] : -1, 2 * li2 + 1 < nr ? T.pair_rowmap[ro + 2 * li2 + 1] : -1, lda_s); }
             kbeg = (nss - T.sn_ldu[ks]) & ~3; lrow_ok = ra >= 0;
             cpS = s_cptr2; ldS = s_lead2;
         } else {
             ns_s = ZS * ns; lda_s = lda; Lrow = Lp + lrow0; Uvs = Uv; lrow_ok = li < nr;
             Lsrc = Lp; lvo = (uint32_t) (lrow0 + lk * lda) << 3;
+            if (F3) l3_source(2 * li2 < nr ? 2 * li2 : -1, 2 * li2 + 1 < nr ? 2 * li2 + 1 : -1, lda);
             kbeg = kbeg_own;
             cpS = s_cptr; ldS = s_lead;
         }

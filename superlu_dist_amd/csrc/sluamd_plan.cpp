@@ -449,6 +449,10 @@ static bool build_pair_maps(const Handle &H, const HostTables &t, int a, int b, 
         }
         cols_a += na;
     }
+    // the Schur loader fetches two neighbouring rows of b's tile with ONE 16-byte load from a's panel (k_schur, SLUAMD_SCHUR_FETCH3): rows that both exist
+    // there must be neighbours there too -- true whenever both panels list their blocks in the same order (every store the handle builds); otherwise no pair
+    for (int i = 0; i + 1 < nsupr_b; ++i)
+        if (rowmap[i] >= 0 && rowmap[i + 1] >= 0 && rowmap[i + 1] != rowmap[i] + 1) return false;
     const int rows_b = nsupr_b - t.sn_ldiag[b];
     const int pct = H.env.fuse_min_pct;
     return rows_a > 0 && cols_a > 0 && 100 * (int64_t) rows_a >= (int64_t) pct * rows_b && 100 * (int64_t) cols_a >= (int64_t) pct * ncolu_b;
