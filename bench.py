@@ -290,6 +290,65 @@ def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0, mkl_n=60
     return out
 
 
+class ClockSampler:
+    """Shader clock of the device while the timed steps run (a 0.57-vs-0.60 box difference should explain itself): a thread polls the
+    current sclk level of the PCI device HIP device `dev` maps to (sysfs pp_dpm_sclk, the line marked '*') every 50 ms.  Harness only -- nothing of the hot path."""
+
+    def __init__(self, dev=0):
+        import threading
+        self.samples, self._stop, self.path = [], threading.Event(), None
+        bus = None
+        try:
+            import ctypes
+            from superlu_dist_amd import _lib
+            buf = ctypes.create_string_buffer(64)
+            if _lib.load().sluamd_device_pci_bus_id(int(dev), buf, 64) == 0:
+                bus = buf.value.decode().lower()          # "0000:c5:00.0"
+        except Exception:
+            bus = None
+        import glob
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if bus:
+            for c in cands:
+                if os.path.basename(os.path.realpath(os.path.dirname(c))).lower() == bus:
+                    self.path = c
+        self.cands = cands
+        self._thr = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, path):
+        try:
+            for ln in open(path):
+                if "*" in ln:
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            if self.path:
+                v = self._read(self.path)
+            else:          # device not identified: the busiest visible card (the one this job drives)
+                vs = [x for x in (self._read(c) for c in self.cands) if x]
+                v = max(vs) if vs else None
+            if v:
+                self.samples.append(v)
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        self._thr.start(); return self
+
+    def __exit__(self, *a):
+        self._stop.set(); self._thr.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        x = sorted(self.samples)
+        return {"sclk_mhz_min": x[0], "sclk_mhz_median": x[len(x) // 2], "sclk_mhz_max": x[-1], "samples": len(x),
+                "source": (self.path or "max over /sys/class/drm/card*/device/pp_dpm_sclk") + ", 50 ms polls during the timed steps and the profiled passes"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -495,15 +554,22 @@ def main():
     n_warm = max(2, args.warmup)
     if args.matrix:
         args.workload = args.matrix
+    clock = ClockSampler(local_rank)
+    clock.__enter__()
     M = measure(args.n, args.steps, n_warm, args.workload)
     n, rp, ci, v, xt, b, symb, h, grid, thresh = (M[k] for k in ("n", "rp", "ci", "v", "xt", "b", "symb", "h", "grid", "thresh"))
     t_setup, info, x, fact_ms, solve_ms, elapsed, res, err = (M[k] for k in ("t_setup", "info", "x", "fact_ms", "solve_ms", "elapsed", "res", "err"))
 
     # one extra profiled step: per-kernel-family HIP-event times on the compute stream
+    # (three passes at N = 1: roofline.frac is reported from the FASTEST with the spread beside it, so that box-to-box and run-to-run differences read off the line)
     h.set_profile(True)                  # N > 1: collective like every factorisation (serial schedule on every rank)
-    h.reset_values(); h.pdgstrf3d(thresh)
-    stp = h.stats()
+    prof_passes = []
+    for _ in range(3 if world == 1 else 1):
+        h.reset_values(); h.pdgstrf3d(thresh)
+        prof_passes.append(h.stats())
+    stp = min(prof_passes, key=lambda q: q["t_schur_ms"])
     h.set_profile(False)
+    clock.__exit__()
 
     # accuracy row: one untimed pass of IterRefine=SLU_DOUBLE (pdgsrfs3d on the device) on the last solution
     accuracy = None
@@ -543,7 +609,11 @@ def main():
     out = {
         "metric": "LU factorization GFLOP/s (pdgstrf3d) + solve time",
         "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
-        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "ms_per_step": ms_per_step,
+        # the headline configuration's own numbers FIRST (the driver keeps the parsed head and the tail of the line)
+        "factor_ms": float(np.mean(fact_ms)), "factor_ms_min": float(np.min(fact_ms)), "factor_ms_max": float(np.max(fact_ms)),
+        "solve_ms": float(np.mean(solve_ms)), "setup_s": t_setup, "residual": res,
+        "higher_is_better": True,
         "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "c128" if zwork else "f64", "data": "synthetic",
         "config": {"workload": (f"pzdrive3d-equivalent on a {args.n}x{args.n} 5-point complex16 grid operator (cg20 family), 1x1x1 grid, "
                                 if zwork else
@@ -558,10 +628,10 @@ def main():
                    f"{grid[0]}x{grid[1]}x{grid[2]} process grid, one rank per GPU: XY block-cyclic panels + Z-sharded elimination forests; "
                    f"panel exchange / ancestor reduction / solve exchanges by the library's C driver over {'RCCL (ncclSend/ncclRecv)' if dist_backend_used[0] == 'rccl' else 'host-staged gloo callbacks' + (' -- RCCL communicator creation FAILED: ' + comm_cache['rccl_error'] if comm_cache.get('rccl_error') else '')}"},
         "flops_per_step": F, "flops_schur_padded": st["flops_schur_padded"],
-        "factor_ms": float(np.mean(fact_ms)), "solve_ms": float(np.mean(solve_ms)),
         "factor_gflops_kernel_only": F / (np.mean(fact_ms) * 1e-3) / 1e9,
-        "residual": res, "max_abs_err_vs_xtrue": err, "info": int(info), "accuracy": accuracy,
-        "levels": st["num_levels"], "fused_level_pairs": st["reserved_i"], "launches_per_factor": st["num_launches"], "setup_s": t_setup, "setup_breakdown": M["setup_breakdown"],
+        "max_abs_err_vs_xtrue": err, "info": int(info), "accuracy": accuracy,
+        "levels": st["num_levels"], "fused_level_pairs": st["reserved_i"], "launches_per_factor": st["num_launches"], "setup_breakdown": M["setup_breakdown"],
+        "device_clock": clock.summary(),
         "bytes_device_this_rank": int(st["bytes_device"]),
         "roofline": {"bound": "mfma", "kernel": "k_schur<Z> (the double kernel on the real embedding of the complex update: fused gather + fp64 MFMA + scatter; 8 real flop per complex multiply-add)" if zwork else
                      "k_schur (fused gather + fp64 MFMA GEMM + scatter)",
@@ -571,7 +641,10 @@ def main():
                      "launches": int(stp["schur_launches"]),
                      "avg_launch_ms": stp["t_schur_ms"] / max(1, stp["schur_launches"]),
                      "flops_per_launch": st["flops_schur_exact"] / max(1, stp["schur_launches"]),
-                     "schur_ms": stp["t_schur_ms"], "panel_ms": stp["t_panel_ms"], "profiled_factor_ms": stp["t_factor_ms"]},
+                     "schur_ms": stp["t_schur_ms"], "panel_ms": stp["t_panel_ms"], "profiled_factor_ms": stp["t_factor_ms"],
+                     "frac_min": min(st["flops_schur_exact"] / (q["t_schur_ms"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS for q in prof_passes if q["t_schur_ms"] > 0) if prof_passes and prof_passes[0]["t_schur_ms"] > 0 else None,
+                     "frac_max": max(st["flops_schur_exact"] / (q["t_schur_ms"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS for q in prof_passes if q["t_schur_ms"] > 0) if prof_passes and prof_passes[0]["t_schur_ms"] > 0 else None,
+                     "profiled_passes": len(prof_passes)},
     }
     # the same Schur time split by tile configuration: `roofline` above is ALL Schur launches against the MFMA peak (the number to compare across
     # rounds); the 128 x 128 instantiation -- supernodes of >= 96 columns, the MFMA-bound part by SURVEY 8(d)'s own criterion (s_k >~ 120) -- and the

@@ -177,6 +177,9 @@ int sluamd_setup_times(sluamd_handle_t h, char *buf, int32_t cap);
 const char *sluamd_last_error(void);
 /* number of visible HIP devices (0 when none) -- lets callers fail loudly instead of falling back */
 int sluamd_device_count(void);
+/* "domain:bus:device.function" of HIP device `dev` (hipDeviceGetPCIBusId): lets a harness find the device's sysfs node, e.g. to sample its clock beside a
+ * measurement (bench.py `device_clock`).  buf of at least 16 bytes. */
+int sluamd_device_pci_bus_id(int dev, char *buf, int len);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-side producers of the L/U store (rows of SURVEY.md section 8(f) that the hot path needs when the

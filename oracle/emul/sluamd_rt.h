@@ -13,7 +13,7 @@
 #include <functional>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
 inline const char *hipGetErrorString(hipError_t) { return "emulated HIP error"; }
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 struct emul_stream_s;
@@ -58,6 +58,7 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipEventDestroy(hipEvent_t e);
 inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = *tot = (size_t) 1 << 40; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char *buf, int len, int) { if (len > 0) buf[0] = 0; return hipErrorUnknown; }     // (no device behind the emulation)
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }

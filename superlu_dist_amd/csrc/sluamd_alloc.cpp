@@ -7,6 +7,14 @@
 // the library's own calls only, nobody else's) returns blocks of 4 MB and more 2 MB-aligned and madvise(MADV_HUGEPAGE)d before their first touch; everything comes from malloc's
 // arena and goes back through free(), so a block may cross into code that uses the default operators.  Kernels with THP "never" ignore the advice;
 // SLUAMD_NO_THP=1 turns it off.
+//
+// CONSTRAINT: blocks cross between this object's inline code and out-of-line libstdc++ code (std::string, std::thread state, exceptions), which
+// uses the PROCESS-global operators -- so the process-global operator new / delete must be malloc / free compatible (glibc's, tcmalloc's, jemalloc's and
+// mimalloc's replacements of malloc all are; a host application that replaces operator new with an allocator whose blocks free() cannot take must build this
+// library with -DSLUAMD_NO_LOCAL_NEW, which compiles this file to nothing).  The replacements must stay LOCAL: the Makefile fails the link when one of them
+// shows up in the dynamic symbol table (no GNU --version-script), and tests/test_abi.py checks the shipped object.  Over-aligned (align_val_t) requests are
+// not routed here: nothing in the library makes them, the global operators serve them and their deletes.
+#ifndef SLUAMD_NO_LOCAL_NEW
 #include <cstdlib>
 #include <new>
 #include <sys/mman.h>
@@ -35,3 +43,4 @@ SLUAMD_LOCAL void operator delete(void *p, std::size_t) noexcept { free(p); }
 SLUAMD_LOCAL void operator delete[](void *p, std::size_t) noexcept { free(p); }
 SLUAMD_LOCAL void operator delete(void *p, const std::nothrow_t &) noexcept { free(p); }
 SLUAMD_LOCAL void operator delete[](void *p, const std::nothrow_t &) noexcept { free(p); }
+#endif

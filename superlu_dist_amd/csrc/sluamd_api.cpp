@@ -277,6 +277,13 @@ int sluamd_device_count(void)
     return n;
 }
 
+int sluamd_device_pci_bus_id(int dev, char *buf, int len)
+{
+    if (!buf || len < 16) { set_error("sluamd_device_pci_bus_id: buffer of at least 16 bytes"); return SLUAMD_EINVAL; }
+    HIPCHK(hipDeviceGetPCIBusId(buf, len, dev));
+    return 0;
+}
+
 void sluamd_default_options(sluamd_options_t *opt)
 {
     std::memset(opt, 0, sizeof(*opt));
@@ -314,7 +321,7 @@ int sluamd_dSetValues(sluamd_handle_t h, const sluamd_dLUview_t *lu)
 {
     if (!h || !lu) { set_error("null argument"); return SLUAMD_EINVAL; }
     HIPCHK(hipSetDevice(h->H.device));
-    h->H.dinv_ready = false; h->H.inv_ready = false;
+    h->H.dinv_ready = false; h->H.inv_ready = false; h->H.factored = false;
     return timed_copy(&h->H, lu, 0);
 }
 
@@ -352,6 +359,8 @@ int sluamd_dGetDiagInv(sluamd_handle_t h, int32_t k, double *Linv, double *Uinv)
     if (!h || h->H.z || !Linv || !Uinv) { set_error("bad sluamd_dGetDiagInv arguments"); return SLUAMD_EINVAL; }
     Handle *H = &h->H;
     if (H->split.active) { set_error("sluamd_dGetDiagInv: the handle refined supernodes wider than 256 columns into pieces; their inverses are per piece"); return SLUAMD_EINVAL; }
+    if (!H->factored) { set_error("sluamd_dGetDiagInv: no factorisation has run on the handle's current values (the inverses are those of the FACTORED diagonal blocks)"); return SLUAMD_EINVAL; }
+    if (H->grid.Pr * H->grid.Pc > 1) { set_error("sluamd_dGetDiagInv: XY layers keep the inverses of their peers' blocks in a per-level scratch; use a 1 x 1 layer"); return SLUAMD_EINVAL; }
     if (k < 0 || k >= H->hs.nsupers || !(H->h_flags[k] & SNF_OWN_DIAG)) { set_error("sluamd_dGetDiagInv: this rank does not own the diagonal block of that supernode"); return SLUAMD_EINVAL; }
     HIPCHK(hipSetDevice(H->device));
     int rc = ensure_inv(H);       // (computed by the factorisation already unless the panel solves ran as substitutions)
@@ -691,7 +700,7 @@ int sluamd_dResetValues(sluamd_handle_t h)
     if (!h || !h->H.d_apos) { set_error("handle has no device-side copy of A"); return SLUAMD_EINVAL; }
     Handle *H = &h->H;
     HIPCHK(hipSetDevice(H->device));
-    H->dinv_ready = false; H->inv_ready = false;
+    H->dinv_ready = false; H->inv_ready = false; H->factored = false;
     HIPCHK(hipMemsetAsync(H->d_val, 0, (H->z ? 16 : 8) * (size_t) H->own_len, H->stream));
     if (H->a_nnz && !H->z) eng::scatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, H->a_nnz);
     if (H->a_nnz && H->z) eng::zscatter_values(H->stream, H->d_val, H->d_apos, H->d_aval, H->a_nnz);

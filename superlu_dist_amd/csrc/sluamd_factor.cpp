@@ -494,7 +494,7 @@ int run_factor(Handle *H, double thresh, int *info)
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
-    H->dinv_ready = true; H->inv_ready = !H->env.trsm_panels && !H->z;
+    H->dinv_ready = true; H->inv_ready = !H->env.trsm_panels && !H->z; H->factored = true;
     if (H->profile && H->env.profile_dump && H->schur_rec.size() == H->ev_schur_used)
         for (size_t i = 0; i < H->ev_schur_used; ++i) {
             float ems = 0; hipEventElapsedTime(&ems, H->ev_schur[i].first, H->ev_schur[i].second);

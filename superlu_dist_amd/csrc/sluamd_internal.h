@@ -374,6 +374,7 @@ struct Handle {
     bool z = false;                                         // complex16 (doublecomplex) values: 16-byte elements
     bool dinv_ready = false;                                // T.dinv holds the inverses for the current factors
     bool inv_ready = false;                                 // T.inv (Linv / Uinv) too
+    bool factored = false;                                  // the resident values are FACTORS (run_factor since the last SetValues / ResetValues): sluamd_dGetDiagInv refuses otherwise
     int *d_ztickets = nullptr;                              // complex fused backward links: one ticket counter per supernode (zero between sweeps)
     int *chain_abort = nullptr;                             // pinned host word written by k_chain when a dependency never arrives (checked after every solve)
     bool profile = false;                                   // per-kernel-family HIP-event timing

@@ -1173,12 +1173,6 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 #ifndef SLUAMD_EXP_NOLOAD
 #define SLUAMD_EXP_NOLOAD 0
 #endif
-// prefetch depth of the K loop of the two-stage (128 x 128) configurations: 1 = the next chunk is in flight while the current one runs (rounds 1-5);
-// 2 = TWO register sets -- the chunk after next is requested before the current chunk's MFMAs, the next chunk's set is stashed behind them: a load has two chunk
-// periods to arrive, so a workgroup that runs alone on its CU (its neighbour in its prologue / epilogue) no longer waits for it
-#ifndef SLUAMD_SCHUR_PD
-#define SLUAMD_SCHUR_PD 1
-#endif
 #ifndef SLUAMD_SCHUR_FETCH2
 #define SLUAMD_SCHUR_FETCH2 1     // 0: the loader of rounds 1-5 (kept for the same-box A/B)
 #endif
@@ -1481,9 +1475,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
 
     const int li = tid % TMv, lk = tid / TMv;           // L loader: row li, k = lk + LKS*q
     const int uk = tid & 15, uj = tid >> 4;             // U loader: k = uk, col = uj + UJS*q
-    constexpr int PD = (NBUF == 2 && !SK) ? SLUAMD_SCHUR_PD : 1;      // (the split-K chain tiles keep the one-set loop: their sources are a few chunks long)
     double pl[LQ], pu[UQ];
-    double pl2[PD == 2 ? LQ : 1], pu2[PD == 2 ? UQ : 1];
     const int *cpS = s_cptr, *ldS = s_lead;   // column maps of the current source (LDS): re-read per chunk, registers are scarce
     bool lrow_ok = li < nr;
     // complex L loader: real row li = (panel row li / 2, part a), the thread's k all have parity b = lk & 1: it reads part a ^ b,
@@ -1497,9 +1489,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     const double *Lsrc = Lp;                              // SLUAMD_SCHUR_FETCH2: the source panel's base (uniform) and this thread's byte offset from it
     uint32_t lvo = (uint32_t) (lrow0 + lk * lda) << 3;    //   (row of the tile + its k phase; a slot is far below 2^29 values)
     // SLUAMD_SCHUR_FETCH3: thread = (pair of tile rows 2 li2, 2 li2 + 1; panel column lk3 + LKS3 q) and (pair of k 2 uk2, 2 uk2 + 1; tile column uj3 + UJS3 q)
-    constexpr bool F3 = SLUAMD_SCHUR_FETCH3 && !Z && PD == 1;
+    constexpr bool F3 = SLUAMD_SCHUR_FETCH3 && !Z;
     constexpr int LRP = TMv / 2, LKS3 = NT / LRP, LQ3 = KC / LKS3, UJS3 = NT / 8, UQ3 = TNv / UJS3;
     const int li2 = tid % LRP, lk3 = tid / LRP, uk2 = tid & 7, uj3 = tid >> 3;
+    // (Measured and not kept, profiles/r06_ab_*.txt: a SECOND register set in flight -- 0 ms in the 4-wave configuration with 256 VGPRs, spills and +35 ms at this
+    //  configuration's 128-VGPR cap; ONE software pipeline across the K-fused sources with all their maps staged in LDS up front -- 0 ms; s_setprio around the MFMA
+    //  phase -- 0 ms; the scatter's maps read in one batch -- 0 ms.  What the K loop paid for was the ISSUE cost of its loader.)
     d2 wl[F3 ? LQ3 : 1], wu[F3 ? UQ3 : 1];        // the raw 16-byte loads; zeros / halves are selected at the stash, when they have arrived
     bool un0[F3 ? UQ3 : 1], un1[F3 ? UQ3 : 1];    // per U load: element k / k + 1 is a stored one (at or below the column's leading zeros, inside the source)
     // per source: which of the two rows exist there (own source: inside the tile; a K-fused predecessor: present in its panel), the byte offset of the first
@@ -1676,43 +1671,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         // chunk at which the destination lines are touched: the one before the last chunk of the last source
         const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((kend - 1 - kbeg) / KC - 1) * KC) : -1;
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
-        if (PD == 2) {
-            // two register sets: set A = chunks kbeg, kbeg + 2 KC, ...; set B = the odd ones.  A fetch past the source's end is a masked-off load (zeros).
-            auto touch = [&]() {
-                constexpr int RG = TMv / 16;
-                const int id0 = tid, id1 = tid + NT;
-                const int c0 = id0 / RG, g0 = id0 % RG, c1 = id1 / RG, g1 = id1 % RG;
-                if (id0 < TNv * RG && c0 < nc && g0 * 16 < nr) touch0 = dst[s_colmap[c0] + s_rowmap[g0 * 16]];
-                if (id1 < TNv * RG && c1 < nc && g1 * 16 < nr) touch1 = dst[s_colmap[c1] + s_rowmap[g1 * 16]];
-            };
-            const int ke = SK ? kend : ns_s;          // loads beyond kend but inside the source are never stashed
-            (void) ke;
-            fetch_into(pl, pu, kbeg);
-            fetch_into(pl2, pu2, kbeg + KC);
-            stash_from(pl, pu, buf);
-            __syncthreads();
-            for (int k0 = kbeg;;) {
-                fetch_into(pl, pu, k0 + 2 * KC);
-                if (k0 == ktouch) touch();
-                if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Ls[buf], Us[buf], rm0, cn0, lane, acc);
-                bool more = k0 + KC < kend;
-                if (more) stash_from(pl2, pu2, buf ^ 1);
-                buf ^= 1;
-                __syncthreads();
-                if (!more) break;
-                k0 += KC;
-                fetch_into(pl2, pu2, k0 + 2 * KC);
-                if (k0 == ktouch) touch();
-                if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Ls[buf], Us[buf], rm0, cn0, lane, acc);
-                more = k0 + KC < kend;
-                if (more) stash_from(pl, pu, buf ^ 1);
-                buf ^= 1;
-                __syncthreads();
-                if (!more) break;
-                k0 += KC;
-            }
-            continue;
-        }
         fetch(kbeg, true);
         stash(buf);
         __syncthreads();

@@ -130,6 +130,10 @@ def test_diagonal_inverses_match_the_reference(golden, case):
         assert np.all(np.triu(Li, 1) == 0) and np.all(np.tril(Ui, -1) == 0) and np.all(np.diag(Li) == 1.0)
         checked += 1
     assert checked == len(xs) - 1
+    # the inverses belong to FACTORED blocks: after new values went up the call refuses until the next factorisation
+    h.set_values(driver.FlatStore.from_golden(g, 0, "pre"))
+    with pytest.raises(RuntimeError):
+        h.diag_inv(0, int(xs[1] - xs[0]))
     h.destroy()
 
 
