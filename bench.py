@@ -336,10 +336,14 @@ class ClockSampler:
             self._stop.wait(0.05)
 
     def __enter__(self):
-        self._thr.start(); return self
+        if not os.environ.get("SLUAMD_BENCH_NO_CLOCK"):
+            self._thr.start()
+        return self
 
     def __exit__(self, *a):
-        self._stop.set(); self._thr.join(timeout=1.0)
+        self._stop.set()
+        if self._thr.is_alive():
+            self._thr.join(timeout=1.0)
 
     def summary(self):
         if not self.samples:
@@ -538,6 +542,26 @@ def main():
         return dict(n=n, rp=rp, ci=ci, v=v, xt=xt, b=b, symb=symb, h=h, grid=grid, thresh=thresh, t_setup=t_setup, info=info, x=x,
                     fact_ms=fact_ms, solve_ms=solve_ms, elapsed=elapsed, res=res, err=err, steps=steps, setup_breakdown=setup_breakdown)
 
+    def predicted_block(hh, nn, flops, measured_ms):
+        """N > 1: what superlu_dist_amd/scale_model.py predicts for THIS run from the ranks' own plan tables (gathered over the out-of-band channel), beside what
+        was measured -- so that the first hardware scaling run is compared against something (VERDICT r5 item 4-i).  predicted_efficiency = model T_1 / (N x model T_N);
+        the model's one-GPU time needs the one-rank plan, which an N > 1 run does not have: it is recomputed from the SAME constants by scripts/scale_model.py and,
+        for the default sizes, kept in profiles/r06_scale_model.txt -- here T_1 is the sum of the ranks' Schur and panel work at the one-GPU rates (no exchange)."""
+        try:
+            from superlu_dist_amd import scale_model
+            tab = hh.plan_table()
+            tabs = [None] * world
+            dist.all_gather_object(tabs, np.asarray(tab))
+            Th, Te, _rows = scale_model.predict(tabs)
+            p = scale_model.DEFAULTS
+            work = sum(float(t[:, 4].sum()) for t in tabs) / (p["r_big"] * 1e12) + sum(float(t[:, 6].sum()) for t in tabs) / (p["r_panel"] * 1e12)
+            return {"model": "superlu_dist_amd/scale_model.py", "constants": p, "pdgstrf3d_ms_reductions_hidden": 1e3 * Th, "pdgstrf3d_ms_reductions_exposed": 1e3 * Te,
+                    "measured_factor_ms": measured_ms, "measured_over_predicted": measured_ms / (1e3 * Te) if Te > 0 else None,
+                    "one_gpu_work_ms_at_model_rates": 1e3 * work, "predicted_efficiency": work / (world * Te) if Te > 0 else None,
+                    "note": "link constants (GB/s per peer and direction, us per exchange phase) are assumptions until this line exists on hardware"}
+        except Exception as e:      # noqa: BLE001 -- reported in the line
+            return {"error": str(e)[:200]}
+
     def sync():
         L.sluamd_device_synchronize()
         if dist is not None:
@@ -660,7 +684,7 @@ def main():
                                  "algorithmic_bytes": st["schur_bytes_alg"] - bb, "achieved": (st["schur_bytes_alg"] - bb) / (ts * 1e-3) / 1e9, "unit": "GB/s",
                                  "frac": (st["schur_bytes_alg"] - bb) / (ts * 1e-3) / 1e9 / PEAK_HBM_GBS}}
         # The epilogue of either configuration is one fp64 atomic per updated element (16 algorithmic bytes): the unit the small-tile configuration actually
-        # saturates is the L2 atomic pipe, measured at 168-188 G elements/s on this part (profiles/r02_ubench_atomic_f64.txt), not HBM
+        # saturates is the L2 atomic pipe, measured at 168-188 G elements/s on this part (profiles/r02_ubench_atomic_f64.txt), not HBM (NOTEBOOK.md section 5)
         ATOMIC_PEAK_GELEM_S = 187.7
         for key, nbytes, ms in (("k_schur<128,128,8>", bb, tb), ("k_schur<64,64,4>", st["schur_bytes_alg"] - bb, ts)):
             rate = nbytes / 16.0 / (ms * 1e-3) / 1e9
@@ -670,6 +694,26 @@ def main():
     esz = 16 if zwork else 8
     solve_bytes = esz * float(st["nnz_L"] + st["nnz_U"])
     solve_gbs = solve_bytes / (np.mean(solve_ms) * 1e-3) / 1e9 if np.mean(solve_ms) > 0 else 0.0
+    if world == 1 and not zwork and h is not None:
+        # second roofline point of the sweep kernels: nrhs = 16 in ONE call -- the reference's pdgstrs3d takes any nrhs and its lsum updates are
+        # GEMMs there (pdgstrs_lsum.c:414-960); the factors are still read once per solve when the right-hand sides ride along (8 B per entry per solve), so the
+        # achieved bytes / s against the HBM peak is the comparable figure; `ms_per_rhs` shows what a block of right-hand sides buys
+        try:
+            R = 16
+            xt16 = np.asfortranarray(np.where(((np.arange(n)[:, None] + np.arange(R)[None, :]) % 2) == 1, 1.0, -1.0) * (1.0 + 0.25 * np.arange(R)[None, :]))
+            b16 = np.asfortranarray(np.column_stack([matgen.csr_matvec(n, rp, ci, v, xt16[:, q:q + 1])[:, 0] for q in range(R)]))
+            xp16 = np.zeros_like(b16, order="F"); xp16[symb.perm_c, :] = b16
+            h.pdgstrs3d(xp16.copy(order="F"))                          # untimed warm-up of this shape
+            y16 = h.pdgstrs3d(xp16)
+            ms16 = h.stats()["t_solve_ms"]
+            x16 = y16[symb.perm_c, :]
+            r16 = max(float(np.linalg.norm(b16[:, q] - matgen.csr_matvec(n, rp, ci, v, x16[:, q:q + 1])[:, 0]) / np.linalg.norm(b16[:, q])) for q in range(R))
+            out["solve_nrhs16"] = {"nrhs": R, "solve_ms": ms16, "ms_per_rhs": ms16 / R, "residual_max": r16,
+                                   "algorithmic_bytes": solve_bytes + 2.0 * 8.0 * n * R, "achieved": (solve_bytes + 2.0 * 8.0 * n * R) / (ms16 * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": (solve_bytes + 2.0 * 8.0 * n * R) / (ms16 * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "flops": 2.0 * float(st["nnz_L"] + st["nnz_U"]) * R, "tflops": 2.0 * float(st["nnz_L"] + st["nnz_U"]) * R / (ms16 * 1e-3) / 1e12}
+        except Exception as e:
+            out["solve_nrhs16"] = {"error": str(e)[:200]}
     if world == 1:
         out["roofline_solve"] = {"bound": "hbm", "kernel": "k_sweep_join (one launch per level: joined diagonal blocks + regular update units) + k_sweep / k_fwd_update / k_bwd_update on the levels of many supernodes",
                                  "achieved": solve_gbs, "peak": 8000.0, "unit": "GB/s", "frac": solve_gbs / 8000.0,
@@ -688,6 +732,8 @@ def main():
                          "note": "one extra factorisation under the serial (profiling) schedule, HIP events, max over ranks: exchange = the XY "
                                  "panel-exchange phases (dDiagFactIBCast + L / U panel broadcasts; part of panel_ms), reduce = the Z ancestor "
                                  "reduction (dreduceAllAncestors3d); the timed steps overlap the exchanges with the Schur tiles of the previous level"}
+    if world > 1:
+        out["predicted"] = predicted_block(h, n, symb.flops, float(np.mean(fact_ms)))
     # ---- scaling point: the same job one size up, reported beside the headline configuration at EVERY N (100^3 is a
     # 0.3 s job -- its N > 1 runs are exchange-latency-bound; 150^3 is 3 s of work and fits one GPU at 90 GB).  `value` stays the
     # headline configuration so that the driver's efficiency figure compares equal jobs; this block lets it be recomputed on 150^3.

@@ -174,6 +174,12 @@ int sluamd_get_stats(sluamd_handle_t h, sluamd_stats_t *out);
 /* wall-clock breakdown of the handle's creation as "phase=seconds;phase=seconds;..." (host planner phases, arena allocation, table uploads,
  * distribution of A): the pre-processing a caller pays once per sparsity structure (pddistribute3d + the GPU handle set-up of the reference) */
 int sluamd_setup_times(sluamd_handle_t h, char *buf, int32_t cap);
+/* The plan of this rank, one row of SLUAMD_PLAN_COLS doubles per (Z level, DAG level): supernodes, Schur / panel flops of THIS rank, bytes and messages of the two XY
+ * exchange phases, bytes of the Z reduction that follows the Z level (column list at the definition, sluamd_api.cpp).  buf may be NULL: *rows = rows needed.
+ * Host data only (no device work): what a scaling model needs from the library (scripts/scale_model.py; the reference prints the same quantities as its
+ * SCT counters commVolFactor / commVolRed, sec_structs.c). */
+#define SLUAMD_PLAN_COLS 20
+int sluamd_plan_table(sluamd_handle_t h, double *buf, int64_t cap_rows, int64_t *rows);
 const char *sluamd_last_error(void);
 /* number of visible HIP devices (0 when none) -- lets callers fail loudly instead of falling back */
 int sluamd_device_count(void);

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <deque>
 #include <map>
+#include <sys/mman.h>
 #include <memory>
 #include <mutex>
 #include <random>
@@ -209,17 +210,26 @@ extern "C" void sluamd_emul_sched_stats(unsigned long long *run, unsigned long l
 // SLUAMD_EMUL_LAZY_ZERO=1 (planning / footprint runs of problems whose factors exceed this host's memory, scripts/setup_breakdown.py): allocations of
 // >= 256 MiB come from calloc -- untouched zero pages -- and the first whole-buffer hipMemset(0) of such a buffer is skipped, so that creating a handle
 // never touches the value arena.  Nothing else changes; a factorisation would still commit every page it writes.
-static std::map<const char *, size_t> g_fresh_zero;
+// (round 6: the untouched zero pages come from mmap(MAP_NORESERVE) -- calloc of an arena larger than RAM + swap is refused under the kernel's heuristic overcommit)
+static std::map<const char *, size_t> g_fresh_zero, g_mapped;
 static bool lazy_zero() { static const bool on = getenv("SLUAMD_EMUL_LAZY_ZERO") != nullptr; return on; }
 hipError_t hipMalloc(void **p, size_t n)
 {
     if (lazy_zero() && n >= ((size_t) 256 << 20)) {
-        *p = std::calloc(n, 1);
-        if (*p) { Guard lk; g_fresh_zero[(const char *) *p] = n; }
+        void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        *p = m == MAP_FAILED ? nullptr : m;
+        if (*p) { Guard lk; g_fresh_zero[(const char *) *p] = n; g_mapped[(const char *) *p] = n; }
     } else *p = std::malloc(n ? n : 1);
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
-hipError_t hipFree(void *p) { hipDeviceSynchronize(); { Guard lk; g_fresh_zero.erase((const char *) p); } std::free(p); return hipSuccess; }
+hipError_t hipFree(void *p)
+{
+    hipDeviceSynchronize();
+    size_t mapped = 0;
+    { Guard lk; g_fresh_zero.erase((const char *) p); auto it = g_mapped.find((const char *) p); if (it != g_mapped.end()) { mapped = it->second; g_mapped.erase(it); } }
+    if (mapped) munmap(p, mapped); else std::free(p);
+    return hipSuccess;
+}
 hipError_t hipHostMalloc(void **p, size_t n, unsigned)
 {
     Guard lk;

@@ -655,6 +655,60 @@ int sluamd_setup_times(sluamd_handle_t h, char *buf, int32_t cap)
     return 0;
 }
 
+// One row of SLUAMD_PLAN_COLS doubles per (Z level, DAG level) of THIS rank's schedule -- what the level costs this rank, from the plan alone:
+//   0 Z level, 1 DAG level, 2 supernodes, 3 widest supernode, 4 exact-segment Schur flops of this rank's tiles, 5 its planned Schur tile executions,
+//   6 diagonal LU + panel-solve flops it owns, 7/8 bytes / messages it SENDS in exchange phase 1 (factored diagonal blocks), 9/10 bytes / messages it receives there,
+//   11/12 bytes / messages sent in phase 2 (L panels along the process row, U panels down the process column), 13/14 received there,
+//   15 bytes this rank sends (+) or receives (-) in the Z reduction of the ancestors that follows the Z level (on the row of the Z level's LAST DAG level; 0 elsewhere),
+//   16/17 bytes to / from the busiest single peer in phase 1, 18/19 in phase 2
+int sluamd_plan_table(sluamd_handle_t h, double *buf, int64_t cap_rows, int64_t *rows)
+{
+    if (!h || !rows) { set_error("null argument"); return SLUAMD_EINVAL; }
+    Handle *H = &h->H;
+    const int64_t esz = H->z ? 16 : 8;
+    int64_t n = 0;
+    for (size_t zl = 0; zl < H->sched.size(); ++zl) {
+        const LevelSched &S = H->sched[zl];
+        for (int l = 0; l < S.nlevels; ++l, ++n) {
+            if (!buf || n >= cap_rows) continue;
+            double *r = buf + SLUAMD_PLAN_COLS * n;
+            for (int c = 0; c < SLUAMD_PLAN_COLS; ++c) r[c] = 0.0;
+            r[0] = (double) zl; r[1] = l; r[2] = S.lvl_off[l + 1] - S.lvl_off[l]; r[3] = S.max_nsupc.empty() ? 0 : S.max_nsupc[l];
+            r[4] = l < (int) S.lvl_flops_schur.size() ? S.lvl_flops_schur[l] : 0.0;
+            if (!S.u_off.empty()) r[5] = (double) (S.u_off[8 * (l + 1)] - S.u_off[8 * l]);
+            r[6] = l < (int) S.lvl_flops_panel.size() ? S.lvl_flops_panel[l] : 0.0;
+            auto tally = [&](const std::vector<std::vector<XMsg>> &v, double &bytes, double &msgs) {
+                if (l < (int) v.size()) for (const XMsg &m : v[l]) { bytes += (double) (esz * m.len); msgs += 1.0; }
+            };
+            tally(S.x_diag_send, r[7], r[8]); tally(S.x_diag_recv, r[9], r[10]);
+            tally(S.x_panel_send, r[11], r[12]); tally(S.x_panel_recv, r[13], r[14]);
+            // 16..19: the most bytes one PEER gets from / sends to this rank in phase 1 / phase 2 (xGMI is point to point: a phase lasts what its busiest link takes)
+            auto busiest = [&](const std::vector<std::vector<XMsg>> &v) {
+                double mx = 0.0;
+                if (l < (int) v.size()) for (const XMsg &m : v[l]) { double b = 0.0; for (const XMsg &q : v[l]) if (q.peer == m.peer) b += (double) (esz * q.len); mx = std::max(mx, b); }
+                return mx;
+            };
+            r[16] = busiest(S.x_diag_send); r[17] = busiest(S.x_diag_recv); r[18] = busiest(S.x_panel_send); r[19] = busiest(S.x_panel_recv);
+            if (l == S.nlevels - 1 && H->grid.Pz > 1 && zl + 1 < H->forest_nodes.size()) {
+                // dreduceAllAncestors3d after Z level zl (pd3dcomm.c:1046-1081): layer z + 2^zl sends its copies of every ancestor forest to layer z (z % 2^(zl+1) == 0)
+                const int step = 1 << zl, z = H->grid.z;
+                const bool recv = z % (2 * step) == 0 && z + step < H->grid.Pz, send = z % (2 * step) == step;
+                if (recv || send) {
+                    double b = 0.0;
+                    for (size_t a = zl + 1; a < H->forest_nodes.size(); ++a)
+                        for (int k : H->forest_nodes[a]) {
+                            if (H->grid.kcol(k) == H->grid.c) b += (double) (esz * H->hs.lval_len[k]);
+                            if (H->grid.krow(k) == H->grid.r) b += (double) (esz * H->hs.uval_len[k]);
+                        }
+                    r[15] = send ? b : -b;
+                }
+            }
+        }
+    }
+    *rows = n;
+    return 0;
+}
+
 int sluamd_get_stats(sluamd_handle_t h, sluamd_stats_t *out)
 {
     if (!h || !out) return SLUAMD_EINVAL;

@@ -203,6 +203,7 @@ struct LevelSched {
     int2 *d_cf_waits = nullptr, *d_cb_waits = nullptr;
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> max_nsupc;     // per level
+    std::vector<double> lvl_flops_schur, lvl_flops_panel;   // per level, THIS rank's share: exact-segment Schur flops of its tiles; diagonal LU + panel solves it owns (sluamd_plan_table)
     std::vector<uint8_t> lvl_has_group;   // (contracted schedule of the sweeps) the level holds a merged chain group: always run as a joined link
     bool no_join = false;           // the sweeps follow Handle::ssched: no joined tables for this schedule
     std::vector<uint8_t> lvl_defer; // per level: some supernode's non-urgent tiles are deferred to its K-fused partner

@@ -919,6 +919,18 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     build_panel_split(H, t, S);
     // by-configuration accounting: a supernode's Schur flops run in ITS tile configuration, except a deferred (K-fused) one's, whose update is applied by
     // the tiles of the first non-deferred successor of its chain (the few urgent tiles it runs itself are counted there too)
+    // per level, this rank's share of the work (sluamd_plan_table: the scaling model of scripts/scale_model.py reads it)
+    S.lvl_flops_schur.assign(S.nlevels, 0.0); S.lvl_flops_panel.assign(S.nlevels, 0.0);
+    for (int k : list) {
+        const int l = lvl[k];
+        if (l < 0 || l >= S.nlevels) continue;
+        const double zf = H.z ? 4.0 : 1.0, nsupc = nsupc_of(hs, k), rrows = t.sn_nsupr[k] - t.sn_ldiag[k];
+        S.lvl_flops_schur[l] += zf * t.sn_flops_exact[k];
+        const int fl = t.sn_flags[k];
+        if (fl & SNF_OWN_DIAG) S.lvl_flops_panel[l] += zf * (2.0 / 3.0) * nsupc * nsupc * nsupc;
+        if (fl & SNF_L_OWN) S.lvl_flops_panel[l] += zf * nsupc * nsupc * rrows;
+        if ((fl & SNF_U_OWN) && rrows > 0) S.lvl_flops_panel[l] += zf * nsupc * (t.sn_flops_exact[k] / (2.0 * rrows));
+    }
     for (int k : list) {
         int ex = k;
         while (ex + 1 < ns && !H.h_defer.empty() && H.h_defer[ex]) ++ex;

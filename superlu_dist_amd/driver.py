@@ -160,6 +160,18 @@ class Symbolic:
             pass
 
 
+PLAN_COLS = 20
+
+
+def plan_table(h):
+    L = _lib.load()
+    rows = C.c_int64(0)
+    _lib.check(L.sluamd_plan_table(h, None, 0, C.byref(rows)), "sluamd_plan_table")
+    out = np.zeros((max(rows.value, 1), PLAN_COLS))
+    _lib.check(L.sluamd_plan_table(h, out.ctypes.data_as(C.POINTER(C.c_double)), rows.value, C.byref(rows)), "sluamd_plan_table")
+    return out[:rows.value]
+
+
 class LUHandle:
     """Device-resident L/U (sluamd_handle_t): dCreateLUgpuHandle / pdgstrf3d_LUv1 / dCopyLUGPU2Host /
     dDestroyLUgpuHandle replacement (SRC/CplusplusFactor/LUgpuCHandle_interface_impl.cu:11-73)."""
@@ -283,6 +295,10 @@ class LUHandle:
         s = Stats()
         _lib.load().sluamd_get_stats(self._h, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def plan_table(self):
+        """this rank's plan, one row per (Z level, DAG level): columns as documented at sluamd_plan_table (include/superlu_dist_amd.h)"""
+        return plan_table(self._h)
 
     def diag_inv(self, k, ns):
         """(Linv, Uinv) of the diagonal block of supernode k: ns x ns, column-major (sluamd_dGetDiagInv)"""

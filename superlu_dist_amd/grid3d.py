@@ -126,6 +126,10 @@ class GridHandle:
     def __init__(self, h, comm, n, z=False):
         self._h, self.comm, self.n, self.z = h, comm, n, z
 
+    def plan_table(self):
+        from .driver import plan_table
+        return plan_table(self._h)
+
     @classmethod
     def from_store(cls, store, forests, comm, **opts):
         from .driver import LUHandle, _forest_view

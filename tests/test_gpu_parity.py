@@ -373,7 +373,7 @@ def test_distributed_boundary_on_a_single_rank(nrhs):
 def test_several_exact_zero_pivots_report_the_first_column():
     """A structurally non-singular matrix whose unpivoted elimination meets several exact zero pivots, in different supernodes and
     levels of the elimination DAG: `info` is the smallest 1-based column with a zero pivot -- what the reference's documentation of
-    `info` says (pdgstrf2.c:493-497; its code keeps the one met LAST in execution order, :568-571: DESIGN section 2) -- the same on
+    `info` says (pdgstrf2.c:493-497; its code keeps the one met LAST in execution order, :568-571: DESIGN.md section 1) -- the same on
     every run, whatever order the workgroups reach them in."""
     n = 96
     rows, cols, vals = [], [], []

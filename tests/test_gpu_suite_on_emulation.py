@@ -148,6 +148,8 @@ def test_bench_script_flow_on_the_emulation(ngpu, tmp_path):
     if ngpu > 1:                           # per-phase times of the profiled factorisation (max over ranks)
         assert set(("exchange_ms", "reduce_ms", "schur_ms", "panel_ms")) <= set(j["phases"])
         assert j["phases"]["reduce_ms"] > 0 and (ngpu < 8 or j["phases"]["exchange_ms"] > 0)
+        pr = j["predicted"]                # the scaling model's figure for this very run, from the ranks' own plan tables
+        assert "error" not in pr and pr["pdgstrf3d_ms_reductions_exposed"] >= pr["pdgstrf3d_ms_reductions_hidden"] > 0 and 0 < pr["predicted_efficiency"] <= 1.0
     assert ("1x1x1" if ngpu == 1 else "1x1x2" if ngpu == 2 else "2x2x2") in j["config"]["workload"]
 
 
