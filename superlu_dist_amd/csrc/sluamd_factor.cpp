@@ -646,8 +646,9 @@ static void zero_forest(Handle *H, LevelSched &S, double *x, int64_t ldx, int nr
 // Per level m: joined when it holds at most SLUAMD_JOIN_MAX_NODES supernodes (the recomputation-free joined units win where a level is a chain of round
 // trips; levels of hundreds of supernodes with several sources each keep the two-launch form).  The two forms meet in any order: a level's diagonal blocks
 // are either stored by strips or added by joined units into zeroed rows, and the level below hands over exactly the rows / columns its successor's form expects.
-static inline bool level_joined(const Handle *H, const LevelSched &S, int m)
+static inline bool level_joined(const Handle *H, const LevelSched &S, int m, int nrhs = 1)
 {
+    if (nrhs >= 4) return false;       // blocks of right-hand sides take the two-launch links: their units read the factor entries once per FOUR right-hand sides (k_sweep / k_fwd_update / k_bwd_update <.., RK = 4>), the joined units once per right-hand side
     if (!S.lvl_has_group.empty() && S.lvl_has_group[m]) return false;      // merged groups: strips of the group inverse, two launches for up to four levels
     return S.lvl_off[m + 1] - S.lvl_off[m] <= H->env.join_max_nodes;
 }
@@ -660,18 +661,18 @@ static int solve_fwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, in
     double *w = H->d_w;
     const int4 *fr = S.d_fwd_recs, *dr = S.d_diag_recs;
     zero_forest(H, S, w, ldx, nrhs);
-    if (level_joined(H, S, 0)) eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) S.jf_off[0], S.jf_off[1] - S.jf_off[0], S.d_jf_aux, nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0]);
+    if (level_joined(H, S, 0, nrhs)) eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) S.jf_off[0], S.jf_off[1] - S.jf_off[0], S.d_jf_aux, nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0]);
     else eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[0], S.du_off[1] - S.du_off[0], nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0], dr + 2 * (size_t) S.du_off[0], nullptr);
     H->st.solve_launches += 1;
     for (int l = 0; l < nl; ++l) {      // the panels of level l, and the diagonal blocks of level l + 1
         const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
-        if (l + 1 == nl || level_joined(H, S, l + 1)) {
+        if (nrhs < 4 && (l + 1 == nl || level_joined(H, S, l + 1))) {
             const int j0 = l + 1 < nl ? S.jf_off[l + 1] : 0, nj = l + 1 < nl ? S.jf_off[l + 2] - j0 : 0;
             eng::sweep_join(s, true, T, S.d_jf_recs + 8 * (size_t) j0, nj, S.d_jf_aux, S.d_jfu_recs + 2 * (size_t) S.jfu_off[l], S.jfu_off[l + 1] - S.jfu_off[l], d_x, w, ldx, nrhs, mx);
             H->st.solve_launches += 1;
         } else {
             const int u0 = S.fu_off[2 * l], u1 = S.fu_off[2 * l + 1], u2 = S.fu_off[2 * l + 2];
-            const int nd = S.du_off[l + 2] - S.du_off[l + 1];
+            const int nd = l + 1 < nl ? S.du_off[l + 2] - S.du_off[l + 1] : 0;       // (the last level's panels update other forests' rows only: no diagonal strips beside them)
             eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, w, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0, fr + 2 * (size_t) u0);
             eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[l + 1], nd, S.d_fwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, mx, dr + 2 * (size_t) S.du_off[l + 1], fr + 2 * (size_t) u1);
             H->st.solve_launches += 2;
@@ -693,7 +694,7 @@ static int solve_bwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, in
     // columns of the next level skipped (its joined units apply them); two-launch -> the far chunks here, the urgent ones in their own launch later.
     auto chunks = [&](int l, const int4 *&recs, const int2 *&units, int &n) {
         if (l < 0) { recs = nullptr; units = nullptr; n = 0; }
-        else if (level_joined(H, S, l)) { recs = S.d_jbu_recs + 2 * (size_t) S.jbu_off[l]; units = nullptr; n = S.jbu_off[l + 1] - S.jbu_off[l]; }
+        else if (level_joined(H, S, l, nrhs)) { recs = S.d_jbu_recs + 2 * (size_t) S.jbu_off[l]; units = nullptr; n = S.jbu_off[l + 1] - S.jbu_off[l]; }
         else { const int b1 = S.bu_off[2 * l + 1], b2 = S.bu_off[2 * l + 2]; recs = br + 2 * (size_t) b1; units = S.d_bwd_units + b1; n = b2 - b1; }
     };
     {
@@ -706,7 +707,7 @@ static int solve_bwd_join(Handle *H, LevelSched &S, double *d_x, int64_t ldx, in
         const int mx = std::max(S.max_nsupc[l], l > 0 ? S.max_nsupc[l - 1] : 0);
         const int4 *recs; const int2 *units; int n;
         chunks(l - 1, recs, units, n);
-        if (level_joined(H, S, l)) {
+        if (level_joined(H, S, l, nrhs)) {
             eng::sweep_join(s, false, T, S.d_jb_recs + 4 * (size_t) S.jb_off[l], S.jb_off[l + 1] - S.jb_off[l], S.d_jb_aux, recs, n, d_x, w, ldx, nrhs, mx);
             H->st.solve_launches += 1;
         } else {

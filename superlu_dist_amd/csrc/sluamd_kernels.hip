@@ -1803,7 +1803,10 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
 //
 // lsum_i -= L_ik x_k for the off-diagonal rows of panel k (dlsum_fmod_inv, pdgstrs_lsum.c:414): workgroup = (supernode,
 // 64-row strip); thread = (row, one of 16 column slices); x_k staged in LDS; fp64 atomics into x.
-template <int NT, bool COH = false, int NBT = 16>   // NBT: loads per thread and batch (16: one batch covers a 256-column supernode with 1024 threads; 8: the builds for 8 waves per SIMD)
+// RK (round 6): right-hand sides per pass over the values.  1 = the loop of rounds 1-5 (every right-hand side re-reads the unit's factor entries: right for nrhs = 1);
+// 4 = a block of four right-hand sides rides along each batch of loads -- the reference's nrhs > 1 path is a GEMM there (pdgstrs_lsum.c:414-960) -- chosen by the
+// launch wrappers when nrhs >= 2: nrhs = 16 reads the factors 4 x instead of 16 x
+template <int NT, bool COH = false, int NBT = 16, int RK = 1>   // NBT: loads per thread and batch (16: one batch covers a 256-column supernode with 1024 threads; 8: the builds for 8 waves per SIMD)
 __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, const double *xsrc /* solved x_k */, double *xdst /* lsum accumulators */,
                                                 int64_t ldx, int nrhs, double *xk /* ns x nrhs */, const int4 *rec = nullptr)
 {
@@ -1840,6 +1843,53 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     for (int u = 0; u < NBT; ++u) lv0[u] = (rvalid && ka + u < kb) ? __builtin_nontemporal_load(L + (size_t) (ka + u) * lda) : 0.0;
     for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(xsrc + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
     __syncthreads();
+    if (RK > 1) {
+        for (int q0 = 0; q0 < nrhs; q0 += RK) {
+            const double *xq[RK];
+#pragma unroll
+            for (int j = 0; j < RK; ++j) xq[j] = xk + min(q0 + j, nrhs - 1) * ns;      // (a block past the last right-hand side repeats it; its sums are dropped)
+            double acc[RK];
+#pragma unroll
+            for (int j = 0; j < RK; ++j) acc[j] = 0.0;
+            if (rvalid) {
+#pragma unroll
+                for (int u = 0; u < NBT; ++u) {
+                    const int c = min(ka + u, ns - 1);
+#pragma unroll
+                    for (int j = 0; j < RK; ++j) acc[j] += lv0[u] * xq[j][c];           // lv0 is zero past kb
+                }
+                int kk = ka + NBT;
+                for (; kk + NBT <= kb; kk += NBT) {
+                    double lv[NBT];
+#pragma unroll
+                    for (int u = 0; u < NBT; ++u) lv[u] = __builtin_nontemporal_load(L + (size_t) (kk + u) * lda);
+#pragma unroll
+                    for (int u = 0; u < NBT; ++u)
+#pragma unroll
+                        for (int j = 0; j < RK; ++j) acc[j] += lv[u] * xq[j][kk + u];
+                }
+                for (; kk < kb; ++kk) {
+                    const double l1 = __builtin_nontemporal_load(L + (size_t) kk * lda);
+#pragma unroll
+                    for (int j = 0; j < RK; ++j) acc[j] += l1 * xq[j][kk];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RK; ++j) {
+                if (q0 + j >= nrhs) break;
+                s_red[part][r] = acc[j];
+                __syncthreads();
+                if (part == 0 && rvalid && mine) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) a += s_red[p2][r];
+                    atomic_sub_f64(xdst + grow + (int64_t) (q0 + j) * ldx, a);
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     for (int q = 0; q < nrhs; ++q) {
         const double *xq = xk + q * ns;
         double acc[4] = {0, 0, 0, 0};
@@ -1868,23 +1918,23 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     }
 }
 
-template <int NT, int NBT = 16, int MINW = NT / 256>     // MINW: waves per SIMD the build is for (__launch_bounds__' second argument)
+template <int NT, int NBT = 16, int MINW = NT / 256, int RK = 1>     // MINW: waves per SIMD the build is for (__launch_bounds__' second argument)
 __global__ __launch_bounds__(NT, MINW) void k_fwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
                                                    int nn, const double *xsrc, double *xdst, int64_t ldx, int nrhs, const int2 *__restrict__ units,
                                                    const int4 *__restrict__ recs)
 {
     extern __shared__ double xk[];  // ns x nrhs
-    if (recs) { fwd_update_body<NT, false, NBT>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
+    if (recs) { fwd_update_body<NT, false, NBT, RK>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
     int k, strip;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; strip = u.y; }   // host-built (supernode, strip) list of one launch
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
-    fwd_update_body<NT, false, NBT>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
+    fwd_update_body<NT, false, NBT, RK>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
 }
 
 // x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
 // lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
-template <int NT, bool COH = false, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true>
+template <int NT, bool COH = false, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true, int RK = 1>
 // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block);
 // RBv = 4 with NT = 512 / 256: supernodes of up to 256 columns in smaller workgroups (more of them resident per CU: levels of MANY units, where overlapping the phases
 // of a workgroup's life -- record, maps, values, reduction, atomics -- across workgroups counts for more than the length of one life);
@@ -1895,7 +1945,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     constexpr int NWV = NT / 64, CPW = 64 / NWV, RB = RBv, UF = UNR ? 16 : 1;
     static_assert(CPW % CBT == 0, "columns per wave must be a multiple of the batch");
     __shared__ int s_cp[64], s_ld[64], s_gc[64];
-    __shared__ double s_xc[64];
+    __shared__ double s_xc[RK][64];
     __shared__ double s_red[NWV][64 * RB];
     int fst, ns, ncol;          // `rec`: (first column, width, columns of this chunk) + (first entry in the flat column maps, offset of U(k,:)) as in fwd_update_body
     int64_t ci0, uoff;
@@ -1934,8 +1984,56 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     // life of a workgroup on the levels where that is what a workgroup's life consists of
     double uv0[CBT][RB];
     load_batch(uv0, 0);
+    if (RK > 1) {
+        for (int r0 = 0; r0 < nrhs; r0 += RK) {
+            if (tid < ncol)
+#pragma unroll
+                for (int j = 0; j < RK; ++j) s_xc[j][tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) min(r0 + j, nrhs - 1) * ldx);
+            __syncthreads();
+            double a[RK][RB];
+#pragma unroll
+            for (int j = 0; j < RK; ++j)
+#pragma unroll
+                for (int q = 0; q < RB; ++q) a[j][q] = 0.0;
+            auto accumulate = [&](const double (&uv)[CBT][RB], int cb) {
+#pragma unroll
+                for (int cc = 0; cc < CBT; ++cc) {
+                    const int c = wave * CPW + cb + cc;
+#pragma unroll
+                    for (int j = 0; j < RK; ++j) {
+                        const double xv = (c < ncol) ? s_xc[j][c] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < RB; ++q) a[j][q] += uv[cc][q] * xv;
+                    }
+                }
+            };
+            if (r0 == 0) accumulate(uv0, 0);
+            else { double uv[CBT][RB]; load_batch(uv, 0); accumulate(uv, 0); }
+#pragma unroll UF
+            for (int cb = CBT; cb < CPW; cb += CBT) {
+                double uv[CBT][RB];
+                load_batch(uv, cb);
+                accumulate(uv, cb);
+            }
+#pragma unroll
+            for (int j = 0; j < RK; ++j) {
+                if (r0 + j >= nrhs) break;
+#pragma unroll
+                for (int q = 0; q < RB; ++q) s_red[wave][lane + 64 * q] = a[j][q];
+                __syncthreads();
+                if (tid < ns) {
+                    double sv = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w) sv += s_red[w][tid];
+                    if (sv != 0.0) atomic_sub_f64(xrows + fst + tid + (int64_t) (r0 + j) * ldx, sv);
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     for (int r = 0; r < nrhs; ++r) {
-        if (tid < ncol) s_xc[tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
+        if (tid < ncol) s_xc[0][tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
         __syncthreads();
         {
             double a[RB];
@@ -1945,7 +2043,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
 #pragma unroll
                 for (int cc = 0; cc < CBT; ++cc) {
                     const int c = wave * CPW + cb + cc;
-                    const double xv = (c < ncol) ? s_xc[c] : 0.0;
+                    const double xv = (c < ncol) ? s_xc[0][c] : 0.0;
 #pragma unroll
                     for (int q = 0; q < RB; ++q) a[q] += uv[cc][q] * xv;
                 }
@@ -1971,23 +2069,23 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
     }
 }
 
-template <int NT, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true, int MINW = NT / 256>
+template <int NT, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true, int MINW = NT / 256, int RK = 1>
 __global__ __launch_bounds__(NT, MINW) void k_bwd_update(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
                                                    int nn, const double *xcols, double *xrows, int64_t ldx, int nrhs, const int2 *__restrict__ units,
                                                    const int4 *__restrict__ recs)
 {
-    if (recs) { bwd_update_body<NT, false, RBv, CBT, UNR>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
+    if (recs) { bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
     int k, chunk;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; chunk = u.y; }
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
-    bwd_update_body<NT, false, RBv, CBT, UNR>(T, k, chunk, xcols, xrows, ldx, nrhs);
+    bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, k, chunk, xcols, xrows, ldx, nrhs);
 }
 
 // One 64-row strip of a diagonal solve, OUT OF PLACE: xout_k[strip rows] = (Linv or Uinv)[strip rows, :] xin_k.  The diagonal solve of a
 // chain supernode sits on the critical path of the sweeps (one dependent launch per level): as ONE workgroup it streams the 512 KB
 // inverse through one CU (~10 us); as ns / 64 independent strips of the same GEMV shape as the panel update it takes what a launch
 // takes.  Independent only because input and output are different vectors (LevelSched sweeps ping-pong between x and a work vector).
-template <bool LOWER, int NT, int NBT = 16>
+template <bool LOWER, int NT, int NBT = 16, int RK = 1>
 __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int strip, const double *xin, double *xout, int64_t ldx, int nrhs,
                                                 double *xk /* ns x nrhs */, const int4 *rec = nullptr)
 {
@@ -2018,6 +2116,53 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
     for (int u = 0; u < NBT; ++u) tv0[u] = (rvalid && ka + u < kb) ? Tr[(size_t) (ka + u) * ns] : 0.0;
     for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = xin[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
+    if (RK > 1) {
+        for (int q0 = 0; q0 < nrhs; q0 += RK) {
+            const double *xq[RK];
+#pragma unroll
+            for (int j = 0; j < RK; ++j) xq[j] = xk + min(q0 + j, nrhs - 1) * ns;
+            double acc[RK];
+#pragma unroll
+            for (int j = 0; j < RK; ++j) acc[j] = 0.0;
+            if (rvalid) {
+#pragma unroll
+                for (int u = 0; u < NBT; ++u) {
+                    const int c = min(ka + u, ns - 1);
+#pragma unroll
+                    for (int j = 0; j < RK; ++j) acc[j] += tv0[u] * xq[j][c];
+                }
+                int kk = ka + NBT;
+                for (; kk + NBT <= kb; kk += NBT) {
+                    double tv[NBT];
+#pragma unroll
+                    for (int u = 0; u < NBT; ++u) tv[u] = Tr[(size_t) (kk + u) * ns];
+#pragma unroll
+                    for (int u = 0; u < NBT; ++u)
+#pragma unroll
+                        for (int j = 0; j < RK; ++j) acc[j] += tv[u] * xq[j][kk + u];
+                }
+                for (; kk < kb; ++kk) {
+                    const double t1 = Tr[(size_t) kk * ns];
+#pragma unroll
+                    for (int j = 0; j < RK; ++j) acc[j] += t1 * xq[j][kk];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RK; ++j) {
+                if (q0 + j >= nrhs) break;
+                s_dred[part][r] = acc[j];
+                __syncthreads();
+                if (part == 0 && rvalid) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) a += s_dred[p2][r];
+                    xout[fst + row + (int64_t) (q0 + j) * ldx] = a;
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     for (int q = 0; q < nrhs; ++q) {
         const double *xq = xk + q * ns;
         double acc[4] = {0, 0, 0, 0};
@@ -2051,7 +2196,7 @@ __device__ __forceinline__ void diag_strip_body(const DevTables &T, int k, int s
 // diagonal solve of a chain supernode hides behind the far updates of its predecessor.  Two vectors: forward, the accumulated
 // right-hand side lives in xa and the solved blocks go to xb (updates read xb, subtract from xa); backward, the accumulators are
 // xb (= the forward solution minus the updates) and the final x_k goes to xa (updates read xa, subtract from xb).
-template <bool LOWER, int NT, int RBv = (NT == 1024 ? 4 : 1), int NBT = 16, int CBT = 4, bool UNR = true, int MINW = NT / 256>
+template <bool LOWER, int NT, int RBv = (NT == 1024 ? 4 : 1), int NBT = 16, int CBT = 4, bool UNR = true, int MINW = NT / 256, int RK = 1>
 __global__ __launch_bounds__(NT, MINW) void k_sweep(DevTables T, const int2 *__restrict__ dunits, int ndu, const int2 *__restrict__ units,
                                               double *xa, double *xb, int64_t ldx, int nrhs, const int4 *__restrict__ drecs, const int4 *__restrict__ urecs)
 {
@@ -2059,23 +2204,23 @@ __global__ __launch_bounds__(NT, MINW) void k_sweep(DevTables T, const int2 *__r
     const int bid = blockIdx.x;
     if (bid < ndu) {
         if (drecs) {     // unit records (same order as dunits)
-            if (LOWER) diag_strip_body<true, NT, NBT>(T, 0, 0, xa, xb, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
-            else diag_strip_body<false, NT, NBT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
+            if (LOWER) diag_strip_body<true, NT, NBT, RK>(T, 0, 0, xa, xb, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
+            else diag_strip_body<false, NT, NBT, RK>(T, 0, 0, xb, xa, ldx, nrhs, dyn, drecs + 2 * (size_t) bid);
             return;
         }
         const int2 d = dunits[bid];
-        if (LOWER) diag_strip_body<true, NT, NBT>(T, d.x, d.y, xa, xb, ldx, nrhs, dyn);
-        else diag_strip_body<false, NT, NBT>(T, d.x, d.y, xb, xa, ldx, nrhs, dyn);
+        if (LOWER) diag_strip_body<true, NT, NBT, RK>(T, d.x, d.y, xa, xb, ldx, nrhs, dyn);
+        else diag_strip_body<false, NT, NBT, RK>(T, d.x, d.y, xb, xa, ldx, nrhs, dyn);
         return;
     }
     if (urecs) {
-        if (LOWER) fwd_update_body<NT, false, NBT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - ndu));
-        else bwd_update_body<NT, false, RBv, CBT, UNR>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - ndu));
+        if (LOWER) fwd_update_body<NT, false, NBT, RK>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - ndu));
+        else bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - ndu));
         return;
     }
     const int2 u = units[bid - ndu];
-    if (LOWER) fwd_update_body<NT, false, NBT>(T, u.x, u.y, xb, xa, ldx, nrhs, dyn);
-    else bwd_update_body<NT, false, RBv, CBT, UNR>(T, u.x, u.y, xa, xb, ldx, nrhs);
+    if (LOWER) fwd_update_body<NT, false, NBT, RK>(T, u.x, u.y, xb, xa, ldx, nrhs, dyn);
+    else bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, u.x, u.y, xa, xb, ldx, nrhs);
 }
 
 // ---- joined links (LevelSched::join) -----------------------------------------------------------------------------------------------------------------
@@ -2663,10 +2808,11 @@ void solve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes,
 // 8 waves per SIMD spill and lose, more workgroups of 256 threads are no better, the narrow levels do not react).  SLUAMD_SWEEP_WIDE_V / SLUAMD_SWEEP_WIDE_MIN.
 static const int g_sweep_wide_v = getenv("SLUAMD_SWEEP_WIDE_V") ? atoi(getenv("SLUAMD_SWEEP_WIDE_V")) : 5;
 static const int g_sweep_wide_min = getenv("SLUAMD_SWEEP_WIDE_MIN") ? atoi(getenv("SLUAMD_SWEEP_WIDE_MIN")) : 256;
-static inline int sweep_variant(int nwork, int mx)    // 0 / 1 / 5 wide, 10 narrow
+static inline int sweep_variant(int nwork, int mx, int nrhs = 1)    // 0 / 1 / 5 wide, 10 narrow
 {
     if (mx <= 64) return 10;
     if (mx > 256 || nwork < g_sweep_wide_min || (g_sweep_wide_v != 1 && g_sweep_wide_v != 5)) return 0;
+    if (nrhs >= 2 && g_sweep_wide_v == 5) return 1;      // the blocked right-hand-side units need more than build 5's 80 registers (they spill there)
     return g_sweep_wide_v;
 }
 //                 threads  row blocks  loads/batch (fwd, diag)  columns/batch (bwd)  all batches in flight  waves per SIMD
@@ -2674,17 +2820,32 @@ static inline int sweep_variant(int nwork, int mx)    // 0 / 1 / 5 wide, 10 narr
 #define SWEEP_V1   512,     4,          16,                      4,                   true,                  2
 #define SWEEP_V5   512,     4,          8,                       2,                   false,                 6
 #define SWEEP_N0   256,     1,          16,                      4,                   true,                  1
+#ifndef SLUAMD_SWEEP_RK
+#define SLUAMD_SWEEP_RK 4
+#endif
+constexpr int SWEEP_RK = SLUAMD_SWEEP_RK;      // right-hand sides per pass over the factor entries in the nrhs >= 2 builds of the update / diagonal-strip units
 template <int NT, int RBv, int NBT, int CBT, bool UNR, int MINW> struct SweepCfg {
     static void fwd(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xsrc, double *x, int64_t ldx, int nrhs, int mx,
                     const int2 *units, const int4 *recs)
-    { hipLaunchKernelGGL((k_fwd_update<NT, NBT, MINW>), dim3(nwork), dim3(NT), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs); }
+    {
+        if (nrhs >= 2) hipLaunchKernelGGL((k_fwd_update<NT, NBT, MINW, SWEEP_RK>), dim3(nwork), dim3(NT), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs);
+        else hipLaunchKernelGGL((k_fwd_update<NT, NBT, MINW>), dim3(nwork), dim3(NT), (size_t) mx * nrhs * sizeof(double), s, T, nodes, prefix, nn, xsrc, x, ldx, nrhs, units, recs);
+    }
     static void bwd(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs,
                     const int2 *units, const int4 *recs)
-    { hipLaunchKernelGGL((k_bwd_update<NT, RBv, CBT, UNR, MINW>), dim3(nwork), dim3(NT), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs); }
+    {
+        if (nrhs >= 2) hipLaunchKernelGGL((k_bwd_update<NT, RBv, CBT, UNR, MINW, SWEEP_RK>), dim3(nwork), dim3(NT), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs);
+        else hipLaunchKernelGGL((k_bwd_update<NT, RBv, CBT, UNR, MINW>), dim3(nwork), dim3(NT), 0, s, T, nodes, prefix, nn, xcols, x, ldx, nrhs, units, recs);
+    }
     static void sweep(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits, double *xa, double *xb, int64_t ldx, int nrhs,
                       int mx, const int4 *drecs, const int4 *urecs)
     {
         const size_t lds = (size_t) mx * nrhs * sizeof(double);
+        if (nrhs >= 2) {
+            if (lower) hipLaunchKernelGGL((k_sweep<true, NT, RBv, NBT, CBT, UNR, MINW, SWEEP_RK>), dim3(ndu + nunits), dim3(NT), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
+            else hipLaunchKernelGGL((k_sweep<false, NT, RBv, NBT, CBT, UNR, MINW, SWEEP_RK>), dim3(ndu + nunits), dim3(NT), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
+            return;
+        }
         if (lower) hipLaunchKernelGGL((k_sweep<true, NT, RBv, NBT, CBT, UNR, MINW>), dim3(ndu + nunits), dim3(NT), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
         else hipLaunchKernelGGL((k_sweep<false, NT, RBv, NBT, CBT, UNR, MINW>), dim3(ndu + nunits), dim3(NT), lds, s, T, dunits, ndu, units, xa, xb, ldx, nrhs, drecs, urecs);
     }
@@ -2701,6 +2862,9 @@ template <int NT, int RBv, int NBT, int CBT, bool UNR, int MINW> struct SweepCfg
         HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<NT, NBT, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, NT, RBv, NBT, CBT, UNR, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, NT, RBv, NBT, CBT, UNR, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_fwd_update<NT, NBT, MINW, SWEEP_RK>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_sweep<true, NT, RBv, NBT, CBT, UNR, MINW, SWEEP_RK>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) k_sweep<false, NT, RBv, NBT, CBT, UNR, MINW, SWEEP_RK>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
         return 0;
     }
 };
@@ -2720,21 +2884,21 @@ void fwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *
                 const int2 *units, const int4 *recs)
 {
     if (nwork <= 0) return;
-    SWEEP_DISPATCH(sweep_variant(nwork, mx), fwd(s, T, nodes, prefix, nn, nwork, xsrc, x, ldx, nrhs, mx, units, recs))
+    SWEEP_DISPATCH(sweep_variant(nwork, mx, nrhs), fwd(s, T, nodes, prefix, nn, nwork, xsrc, x, ldx, nrhs, mx, units, recs))
 }
 
 void bwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, const double *xcols, double *x, int64_t ldx, int nrhs, int mx,
                 const int2 *units, const int4 *recs)
 {
     if (nwork <= 0) return;
-    SWEEP_DISPATCH(sweep_variant(nwork, mx), bwd(s, T, nodes, prefix, nn, nwork, xcols, x, ldx, nrhs, units, recs))
+    SWEEP_DISPATCH(sweep_variant(nwork, mx, nrhs), bwd(s, T, nodes, prefix, nn, nwork, xcols, x, ldx, nrhs, units, recs))
 }
 
 void sweep_step(hipStream_t s, bool lower, const DevTables &T, const int2 *dunits, int ndu, const int2 *units, int nunits,
                 double *xa, double *xb, int64_t ldx, int nrhs, int mx, const int4 *drecs, const int4 *urecs)
 {
     if (ndu + nunits <= 0) return;
-    SWEEP_DISPATCH(sweep_variant(ndu + nunits, mx), sweep(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, mx, drecs, urecs))
+    SWEEP_DISPATCH(sweep_variant(ndu + nunits, mx, nrhs), sweep(s, lower, T, dunits, ndu, units, nunits, xa, xb, ldx, nrhs, mx, drecs, urecs))
 }
 
 void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs, int nj, const int4 *jaux, const int4 *urecs, int nunits,

@@ -222,3 +222,30 @@ def test_joined_links_of_the_sweeps_on_the_device(monkeypatch, join_max):
     assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
     assert np.abs(x - xt).max() <= 1e-9 * np.abs(xt).max()
     assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("nrhs", [2, 3, 4, 5, 9, 16])
+def test_blocks_of_right_hand_sides_against_single_solves(nrhs):
+    """Round 6: with nrhs >= 2 the update and diagonal-strip units of the sweeps take FOUR right-hand sides per pass over their factor entries (the reference's
+    nrhs > 1 path is a GEMM, pdgstrs_lsum.c:414-960), from nrhs >= 4 on every level in the two-launch form: each column of a block solve must be what a
+    solve of that column alone gives (same factors, nrhs = 1 path), on a problem with narrow, mid and 256-column supernodes and unsymmetric values."""
+    import numpy as np
+    from superlu_dist_amd import driver, matgen
+    N = 26
+    n, rp, ci, v = matgen.poisson3d(N)
+    rng = np.random.default_rng(23)
+    v = v * (1.0 + 0.3 * rng.random(v.size))
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=256)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    assert h.pdgstrf3d(0.0) == 0
+    xt = rng.standard_normal((n, nrhs))
+    b = np.asfortranarray(np.column_stack([matgen.csr_matvec(n, rp, ci, v, xt[:, q:q + 1])[:, 0] for q in range(nrhs)]))
+    xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+    y = h.pdgstrs3d(xp.copy(order="F"))
+    for q in range(nrhs):
+        y1 = h.pdgstrs3d(np.asfortranarray(xp[:, q:q + 1].copy()))
+        assert np.abs(y[:, q] - y1[:, 0]).max() <= 1e-12 * np.abs(y1).max(), q
+    x = y[symb.perm_c, :]
+    assert np.abs(x - xt).max() <= 1e-9 * np.abs(xt).max()
+    h.destroy(); symb.free()
