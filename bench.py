@@ -618,13 +618,13 @@ def main():
     # HBM traffic of the dominant kernel from PMC counters: cannot be collected inside this process (rocprofv3 --pmc
     # needs its own passes), so the value measured on this same command line is kept under profiles/ with its provenance
     traffic, traffic_src, traffic_stale = None, None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r05_pmc_schur.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r06_pmc_schur.json")
     if world == 1 and args.n == 100 and not zwork and os.path.exists(pmc_path):
         try:
             pj = json.load(open(pmc_path))
             if pj.get("kernel_source_sha16") == kernel_source_hash():
                 traffic = pj["traffic_bytes_per_factorisation"] / max(1, stp["schur_launches"])   # per launch, like `achieved`
-                traffic_src = "profiles/r05_pmc_schur.json: " + pj["source"]
+                traffic_src = "profiles/r06_pmc_schur.json: " + pj["source"]
             else:
                 traffic_stale = True     # the kernels changed since the counters were collected: scripts/collect_pmc.sh regenerates them
         except Exception:

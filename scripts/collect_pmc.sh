@@ -3,7 +3,7 @@
 #   two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) + one MFMA-busy pass of the default bench workload,
 #   kernel-trace only (no sys/hip/hsa traces), summaries into gpurun_out/ -> copy to profiles/.
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

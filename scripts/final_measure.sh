@@ -1,10 +1,10 @@
 #!/bin/bash
 # End-of-round measurement on the GPU box (from the repo root): PMC traffic of the Schur kernels, rocprof kernel statistics of the
 # default bench command (look-ahead) and of the serial profile, the default bench line.  Outputs -> gpurun_out/ (copy to profiles/).
-tag=${1:-r05}
+tag=${1:-r06}
 R=$GRAFT_REPO_ROOT
 bash scripts/collect_pmc.sh $tag > gpurun_out/${tag}_collect_pmc.log 2>&1
-cp gpurun_out/${tag}_pmc_schur.json profiles/r05_pmc_schur.json    # bench.py reads this one (same box, same kernels)
+cp gpurun_out/${tag}_pmc_schur.json profiles/r06_pmc_schur.json    # bench.py reads this one (same box, same kernels)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks
 rocprofv3 --kernel-trace --stats -d /tmp/ks -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-point --no-configs4 > /tmp/ks.json 2> /tmp/ks.err
 cd $R
