@@ -183,6 +183,10 @@ int sluamd_plan_table(sluamd_handle_t h, double *buf, int64_t cap_rows, int64_t 
 const char *sluamd_last_error(void);
 /* number of visible HIP devices (0 when none) -- lets callers fail loudly instead of falling back */
 int sluamd_device_count(void);
+/* The value arenas of 1 x 1 x 1 handles come from a process-level pool of physical device chunks (destroyed handles return their chunks to it, later
+ * handles re-map them: no driver-side clearing of re-used memory).  This call returns the chunks no handle uses to the driver (dev < 0: every device);
+ * result = the bytes the pool held.  The library trims by itself when one of its allocations fails.  SLUAMD_NO_DEVPOOL=1: plain hipMalloc. */
+int64_t sluamd_device_pool_trim(int dev);
 /* "domain:bus:device.function" of HIP device `dev` (hipDeviceGetPCIBusId): lets a harness find the device's sysfs node, e.g. to sample its clock beside a
  * measurement (bench.py `device_clock`).  buf of at least 16 bytes. */
 int sluamd_device_pci_bus_id(int dev, char *buf, int len);

@@ -334,3 +334,11 @@ hipError_t hipDeviceSynchronize()
     flush(nullptr, all_empty);
     return hipSuccess;
 }
+
+// the product's pool of physical device chunks (sluamd_devpool.cpp) has nothing to pool on the host: plain allocations
+namespace sluamd {
+int devpool_alloc(void **p, size_t bytes, int) { return hipMalloc(p, bytes) == hipSuccess ? 0 : -4; }
+void devpool_free(void *p) { if (p) hipFree(p); }
+void devpool_trim(int) {}
+size_t devpool_cached_bytes(int) { return 0; }
+}  // namespace sluamd

@@ -44,7 +44,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "sluamd_default_options", "sluamd_dCreateLUHandle", "sluamd_dSetValues", "sluamd_pdgstrf3d",
     "sluamd_dCopyLU2Host", "sluamd_pdgstrs3d", "sluamd_pdgstrs3d_dev", "sluamd_pdgstrs3d_dist", "sluamd_pzgstrs3d_dist", "sluamd_dDestroyLUHandle",
-    "sluamd_get_stats", "sluamd_setup_times", "sluamd_poisson3d", "sluamd_dGetDiagInv", "sluamd_last_error", "sluamd_device_count", "sluamd_device_pci_bus_id", "sluamd_plan_table", "sluamd_dsymbfact", "sluamd_dsymbfact_unsym", "sluamd_order_nd", "sluamd_symb_info",
+    "sluamd_get_stats", "sluamd_setup_times", "sluamd_poisson3d", "sluamd_dGetDiagInv", "sluamd_last_error", "sluamd_device_count", "sluamd_device_pci_bus_id", "sluamd_device_pool_trim", "sluamd_plan_table", "sluamd_dsymbfact", "sluamd_dsymbfact_unsym", "sluamd_order_nd", "sluamd_symb_info",
     "sluamd_symb_view", "sluamd_symb_grid_footprint", "sluamd_ddistribute_host", "sluamd_dCreateLUHandleFromSymb", "sluamd_symb_free",
     "sluamd_zCreateLUHandle", "sluamd_zSetValues", "sluamd_pzgstrf3d", "sluamd_zCopyLU2Host", "sluamd_pzgstrs3d",
     "sluamd_dAttachMatrix", "sluamd_pdgsrfs3d", "sluamd_pdgsrfs3d_dev",

@@ -277,6 +277,13 @@ int sluamd_device_count(void)
     return n;
 }
 
+int64_t sluamd_device_pool_trim(int dev)
+{
+    const int64_t held = (int64_t) devpool_cached_bytes(dev);
+    devpool_trim(dev);
+    return held;
+}
+
 int sluamd_device_pci_bus_id(int dev, char *buf, int len)
 {
     if (!buf || len < 16) { set_error("sluamd_device_pci_bus_id: buffer of at least 16 bytes"); return SLUAMD_EINVAL; }
@@ -615,7 +622,7 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->u2stream) hipStreamSynchronize(H->u2stream);
     if (H->rstream) hipStreamSynchronize(H->rstream);
     for (void *p : H->d_misc) hipFree(p);
-    if (H->d_val) hipFree(H->d_val);
+    if (H->d_val) devpool_free(H->d_val);       // (plain allocations are recognised and freed as such)
     if (H->d_info) hipFree(H->d_info);
     if (H->d_x) hipFree(H->d_x);
     if (H->d_xtmp) hipFree(H->d_xtmp);

@@ -98,7 +98,10 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             const size_t bytes = sizeof(int) * (size_t) S.m_off[2 * S.nlevels];
             size_t fr = 0, tot = 0;
             hipMemGetInfo(&fr, &tot);
-            // the records are an accelerator, not a requirement: leave a tenth of the device free
+            // the records are an accelerator, not a requirement: leave a tenth of the device free.  (Chunks the arena pool holds for later handles count as free:
+            // they go back to the driver when the records need the room.)
+            const size_t cached = devpool_cached_bytes(H->device);
+            if (bytes > 0 && bytes + tot / 10 >= fr && bytes + tot / 10 < fr + cached) { devpool_trim(H->device); hipMemGetInfo(&fr, &tot); }
             if (bytes > 0 && bytes + tot / 10 < fr && hipMalloc((void **) &S.d_tmaps, bytes) == hipSuccess) {
                 H->d_misc.push_back(S.d_tmaps);
                 for (int l = 0; l < S.nlevels; ++l)

@@ -163,6 +163,12 @@ struct DevTables {
 };
 
 // One exchange message of the XY panel exchange: a contiguous range of the value arena sent to / received from one peer
+// value arenas on a process-level pool of physical device chunks (sluamd_devpool.cpp; the CPU test build: oracle/emul/emul_rt.cpp)
+int devpool_alloc(void **p, size_t bytes, int device);
+void devpool_free(void *p);
+void devpool_trim(int device);            // device < 0: every device
+size_t devpool_cached_bytes(int device);
+
 struct XMsg { int peer; int64_t off, len; };   // world rank, arena offset, doubles
 
 struct LevelSched {

@@ -1443,7 +1443,13 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     struct Joiner { std::thread th; ~Joiner() { if (th.joinable()) th.join(); } } arena_job;
     arena_job.th = std::thread([H, arena_bytes, &arena_rc] {
         if (hipSetDevice(H->device) != hipSuccess) { arena_rc = 3; return; }
-        if (hipMalloc((void **) &H->d_val, arena_bytes) != hipSuccess) { H->d_val = nullptr; arena_rc = 1; return; }
+        // single-rank handles: from the pool of physical chunks (a later handle of the process re-maps what an earlier one released); grids: plain hipMalloc
+        const bool pooled = H->grid.size() == 1 && !H->comm;
+        if (pooled ? devpool_alloc((void **) &H->d_val, arena_bytes, H->device) != 0 : hipMalloc((void **) &H->d_val, arena_bytes) != hipSuccess) {
+            (void) hipGetLastError();
+            devpool_trim(H->device);          // what the pool holds may be what is missing
+            if (hipMalloc((void **) &H->d_val, arena_bytes) != hipSuccess) { H->d_val = nullptr; arena_rc = 1; return; }
+        }
         if (hipMemset(H->d_val, 0, arena_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) arena_rc = 2;
     });
 
@@ -1688,12 +1694,22 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     H->h_sn_dinv = t.sn_dinv;
     {
         double *dv;
-        if (hipMalloc((void **) &dv, esz * (size_t) std::max<int64_t>(t.dinv_total, 1)) != hipSuccess) { set_error("hipMalloc(dinv) failed"); return SLUAMD_ENOMEM; }
+        auto malloc_retry = [&](void **q, size_t bytes) {      // (once more after the arena pool gave its unused chunks back to the driver)
+            if (hipMalloc(q, bytes) == hipSuccess) return true;
+            (void) hipGetLastError();
+            devpool_trim(H->device);
+            return hipMalloc(q, bytes) == hipSuccess;
+        };
+        if (!malloc_retry((void **) &dv, esz * (size_t) std::max<int64_t>(t.dinv_total, 1))) { set_error("hipMalloc(dinv) failed"); return SLUAMD_ENOMEM; }
         K.push_back(dv); T.dinv = dv;
     }
     if (!H->z) {   // Linv / Uinv of the owned diagonal blocks (solve); complex handles use their own first-correct solves
         double *iv;
-        if (hipMalloc((void **) &iv, sizeof(double) * (size_t) std::max<int64_t>(t.inv_total, 1)) != hipSuccess) { set_error("hipMalloc(inv) failed"); return SLUAMD_ENOMEM; }
+        if (hipMalloc((void **) &iv, sizeof(double) * (size_t) std::max<int64_t>(t.inv_total, 1)) != hipSuccess) {
+            (void) hipGetLastError();
+            devpool_trim(H->device);
+            if (hipMalloc((void **) &iv, sizeof(double) * (size_t) std::max<int64_t>(t.inv_total, 1)) != hipSuccess) { set_error("hipMalloc(inv) failed"); return SLUAMD_ENOMEM; }
+        }
         K.push_back(iv); T.inv = iv;
     }
     if (!H->z && g.Pr * g.Pc == 1 && H->env.solve_join) { H->h_lrow_near.assign(std::max<size_t>(t.lrow.size(), 1), 0); H->h_ucol_near.assign(std::max<size_t>(t.ucol_gc.size(), 1), 0); }

@@ -249,3 +249,29 @@ def test_blocks_of_right_hand_sides_against_single_solves(nrhs):
     x = y[symb.perm_c, :]
     assert np.abs(x - xt).max() <= 1e-9 * np.abs(xt).max()
     h.destroy(); symb.free()
+
+
+def test_value_arenas_of_later_handles_come_from_the_device_pool():
+    """Round 6 (sluamd_devpool.cpp): the arena of a destroyed 1 x 1 x 1 handle stays with the process as physical chunks; the next handle re-maps them (no
+    driver-side clearing of re-used device memory), results unchanged; sluamd_device_pool_trim returns what no handle uses and reports its size."""
+    import numpy as np
+    from superlu_dist_amd import driver, matgen, _lib
+    L = _lib.load()
+    L.sluamd_device_pool_trim.restype = __import__("ctypes").c_int64
+    N = 56                     # 1.3 GB of factors: above the pool's 1 GiB chunk
+    n, rp, ci, v = matgen.poisson3d(N)
+    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
+    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 1)
+    L.sluamd_device_pool_trim(-1)
+    xs = []
+    for rep in range(3):
+        symb = driver.Symbolic(n, rp, ci, perm, relax=64, maxsup=256)
+        h = driver.LUHandle.from_symbolic(symb, v)
+        assert h.pdgstrf3d(0.0) == 0
+        xp = np.zeros_like(b, order="F"); xp[symb.perm_c, :] = b
+        xs.append(h.pdgstrs3d(xp)[symb.perm_c, :])
+        h.destroy(); symb.free()
+        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, xs[-1])) <= 1e-12 * np.linalg.norm(b)
+    held = L.sluamd_device_pool_trim(-1)
+    assert held >= (1 << 30) and held % (1 << 30) == 0, held
+    assert L.sluamd_device_pool_trim(-1) == 0
