@@ -779,6 +779,7 @@ int sluamd_set_profile(sluamd_handle_t h, int on)
 {
     if (!h) return SLUAMD_EINVAL;
     h->H.opt.verbose = on ? 2 : 0;
+    if (!on) h->H.profile = h->H.env.profile;      // at once, not at the next factorisation: the solves after a profiled factorisation ran their serial (unjoined) form until then
     return 0;
 }
 

@@ -2877,6 +2877,7 @@ template <int NT, int RBv, int NBT, int CBT, bool UNR, int MINW> struct SweepCfg
     }
 int sweep_attrs()
 {
+
     return SweepCfg<SWEEP_V0>::attrs() | SweepCfg<SWEEP_V1>::attrs() | SweepCfg<SWEEP_V5>::attrs() | SweepCfg<SWEEP_N0>::attrs();
 }
 
