@@ -126,7 +126,7 @@ def test_library_poisson_generator_equals_the_numpy_construction():
         assert got == nnz and (rp2 == rp).all() and (ci2 == ci).all() and (v2 == v).all(), (nx, ny, nz)
 
 
-@pytest.mark.parametrize("case", ["poisson_nd", "stencil_unsym", "natural"])
+@pytest.mark.parametrize("case", ["poisson_nd", "stencil_unsym", "natural", "poisson_nd_cut_below_relax", "random_unsym_cut_below_relax"])
 def test_parallel_supernodal_structure_equals_the_serial_pass(case, monkeypatch):
     """sluamd_dsymbfact builds the row structures of disjoint etree subtrees on worker threads and finishes the supernodes that reach a subtree's root (and
     everything above the cut) serially: the structure (supernode partition, L index, U index, value offsets, final perm_c) must be the serial pass's,
@@ -136,10 +136,15 @@ def test_parallel_supernodal_structure_equals_the_serial_pass(case, monkeypatch)
         n, rp, ci, v = matgen.poisson3d(18); perm = matgen.nd_perm_grid3d(18, 18, 18, leaf=27); relax, maxsup = 8, 64
     elif case == "stencil_unsym":
         n, rp, ci, v = matgen.stencil3d_unsym(12, drop=0.3, seed=4); perm = matgen.nd_perm_grid3d(12, 12, 12, leaf=27); relax, maxsup = 4, 32
+    elif case == "poisson_nd_cut_below_relax":
+        # a task subtree strictly INSIDE a relaxed subtree (cut < relax) used to emit units the serial pass then covered again with the relaxed unit
+        n, rp, ci, v = matgen.poisson3d(14); perm = matgen.nd_perm_grid3d(14, 14, 14, leaf=27); relax, maxsup = 16, 64
+    elif case == "random_unsym_cut_below_relax":
+        n, rp, ci, v = matgen.random_unsym(3000, 0.002, seed=3); perm = None; relax, maxsup = 32, 64
     else:
         n, rp, ci, v = matgen.poisson3d(12); perm = None; relax, maxsup = 1, 16
     ref = None
-    for cut in ["0", "1", "7", "150", "100000"]:
+    for cut in (["0", "3", "5", "12", "20", "150"] if case.endswith("cut_below_relax") else ["0", "1", "7", "150", "100000"]):
         monkeypatch.setenv("SLUAMD_SYMB_CUT", cut)
         s = driver.Symbolic(n, rp, ci, perm, relax=relax, maxsup=maxsup)
         fs = s.flat_store(values=False)
