@@ -51,3 +51,28 @@ def test_plan_tables_of_a_grid_conserve_flops_and_bytes(emul, grid):
     if Pz > 1:
         assert max(abs(t[:, 15]).max() for t in tabs) > 0
     symb.free()
+
+
+def test_scale_model_on_plan_tables(emul):
+    """superlu_dist_amd/scale_model.py (the harness behind profiles/r06_scale_model.txt and bench.py's `predicted` block): on the plan tables of a real grid the
+    prediction is positive, the exposed-reduction figure is not below the hidden one, slower links never make it faster, and a one-rank table has no exchange term."""
+    from superlu_dist_amd import scale_model
+    n, rp, ci, v, symb = _problem(18)
+    h = driver.LUHandle.from_symbolic(symb, v)
+    t1 = [h.plan_table()]
+    h.destroy()
+    T1h, T1e, rows1 = scale_model.predict(t1)
+    assert T1h > 0 and T1h == T1e and all(r[4] == 0.0 for r in rows1)          # no exchange, no reduction
+    tree = symb.partition(2)
+    comms = grid3d.local_comms(2, 2, 2)
+    tabs = []
+    for r in range(8):
+        g = grid3d.GridHandle.from_symbolic(symb, v, comms[r], tree)
+        tabs.append(g.plan_table()); g.destroy()
+    Th, Te, rows = scale_model.predict(tabs)
+    assert 0 < Th <= Te and len(rows) == 2 and rows[0][6] > 0                   # the Z reduction follows Z level 0
+    slow_h, slow_e, _ = scale_model.predict(tabs, {"link_gbs": 5.0, "lat_us": 200.0})
+    assert slow_h >= Th and slow_e >= Te
+    fast_h, _, _ = scale_model.predict(tabs, {"link_gbs": 1e6, "lat_us": 0.0})
+    assert fast_h <= Th
+    symb.free()
