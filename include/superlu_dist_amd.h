@@ -114,8 +114,8 @@ typedef struct sluamd_stats {
     int32_t reserved_i;
     int64_t schur_launches, schur_tiles;
     double  schur_bytes_alg;   /* algorithmic HBM bytes of all Schur launches             */
-    int64_t chain_units;       /* work units of the dataflow (persistent-kernel) part of one forward sweep */
-    int32_t chain_levels;      /* DAG levels covered by it (0: level-set sweeps only)                 */
+    int64_t chain_units;       /* always 0 (the opt-in persistent dataflow sweeps of rounds 3-5 were removed: slower, NOTEBOOK.md); kept for layout */
+    int32_t chain_levels;      /* always 0, as above                                                  */
     int32_t solve_launches;    /* kernel launches of the last sluamd_pdgstrs3d (one right-hand-side chunk) */
     double  t_exchange_ms;     /* grid handles, profiling on: time of the XY panel-exchange phases ... */
     double  t_reduce_ms;       /* ... and of the Z ancestor reduction inside the last sluamd_pdgstrf3d */

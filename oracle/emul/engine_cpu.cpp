@@ -650,44 +650,6 @@ void zero_nodes(hipStream_t, const DevTables &T, const int *nodes, int nn, doubl
             for (int r = T.xsup[nodes[i]]; r < T.xsup[nodes[i] + 1]; ++r) x[r + (int64_t) q * ldx] = 0.0;
 }
 
-// Dataflow sweep (k_chain): the device runs a unit as soon as the flags it waits for have reached their values -- in ANY order
-// that honours those waits.  Here: immediate mode = list order; adversarial modes = a seeded random choice among the ready units,
-// so a wait missing from the host-built table changes the result on CPU.  A unit list that cannot complete (a signal nobody sends)
-// raises the abort word exactly like the bounded spin of the kernel.
-void chain_sweep(hipStream_t s, bool lower, int, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs, int *flags, int nflags,
-                 int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs, int mx)
-{
-    std::fill(flags, flags + nflags, 0);
-    std::vector<char> done(std::max(nunits, 0), 0);
-    std::mt19937 rng(emul_launch_seed());
-    const bool shuffle = emul_launch_seed() != 0;
-    std::vector<int> ready;
-    for (int left = nunits; left > 0; --left) {
-        ready.clear();
-        for (int u = 0; u < nunits && (shuffle || ready.empty()); ++u) {
-            if (done[u]) continue;
-            const int *rec = units + 8 * (size_t) u;
-            bool ok = true;
-            for (int i = 0; i < rec[4] && ok; ++i) ok = flags[waits[rec[3] + i].x] >= waits[rec[3] + i].y;
-            if (ok) ready.push_back(u);
-        }
-        if (ready.empty()) { *host_abort = 1; return; }
-        const int u = ready[shuffle ? rng() % ready.size() : 0];
-        const int *rec = units + 8 * (size_t) u;
-        const int k = rec[1];
-        const int2 one = make_int2(k, rec[2]);
-        if (rec[0] == 0) {    // whole-node diagonal solve, lower xa -> xb, upper xb -> xa
-            const int nst = (T.xsup[k + 1] - T.xsup[k] + 63) / 64;
-            std::vector<int2> du(nst);
-            for (int st = 0; st < nst; ++st) du[st] = make_int2(k, st);
-            diag_strips(lower, T, du.data(), nst, lower ? xa : xb, lower ? xb : xa, ldx, nrhs);
-        } else if (lower) fwd_update(s, T, nullptr, nullptr, 0, 1, xb, xa, ldx, nrhs, mx, &one);
-        else bwd_update(s, T, nullptr, nullptr, 0, 1, xa, xb, ldx, nrhs, mx, &one);
-        for (int i = 0; i < rec[6]; ++i) flags[sigs[rec[5] + i]]++;
-        done[u] = 1;
-    }
-}
-
 void scatter_values(hipStream_t, double *val, const int64_t *pos, const double *a, int64_t nnz)
 {
     for (int64_t e = 0; e < nnz; ++e) val[pos[e]] = a[e];
@@ -833,13 +795,6 @@ void zero_nodes(hipStream_t s, const DevTables &T, const int *nodes, int nn, dou
 {
     if (nn <= 0) return;
     emul_enqueue(s, [=] { impl::zero_nodes(s, T, nodes, nn, x, ldx, nrhs); });
-}
-
-void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs, int *flags, int nflags,
-                 int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc)
-{
-    if (nunits <= 0) return;
-    emul_enqueue(s, [=] { impl::chain_sweep(s, lower, mode, T, units, nunits, waits, sigs, flags, nflags, host_abort, xa, xb, ldx, nrhs, max_nsupc); });
 }
 
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)

@@ -1,15 +1,12 @@
 #!/bin/bash
 # Development aid (CPU): does tests/test_stream_order.py catch a forgotten dependency?  Deletes one hipStreamWaitEvent of the
-# look-ahead schedule at a time from sluamd_factor.cpp -- or one entry of the dependency table of the dataflow sweeps from
-# sluamd_plan.cpp (build_chain) -- rebuilds the emulation library and expects the test file to FAIL.
+# look-ahead schedule at a time from sluamd_factor.cpp, rebuilds the emulation library and expects the test file to FAIL.
 # The sources are restored on exit.  (All mutations are caught; the unmodified code passes every seed.)
 set -u
 cd "$(dirname "$0")/.."
 src=superlu_dist_amd/csrc/sluamd_factor.cpp
-src2=superlu_dist_amd/csrc/sluamd_plan.cpp
 cp $src /tmp/sluamd_factor_orig.cpp
-cp $src2 /tmp/sluamd_plan_orig.cpp
-trap 'cp /tmp/sluamd_factor_orig.cpp $src; cp /tmp/sluamd_plan_orig.cpp $src2; make -C oracle >/dev/null 2>&1' EXIT
+trap 'cp /tmp/sluamd_factor_orig.cpp $src; make -C oracle >/dev/null 2>&1' EXIT
 muts=(
   'hipStreamWaitEvent(ps, e_u1, 0);'
   'hipStreamWaitEvent(us, e_p, 0); hipStreamWaitEvent(u2s, e_p, 0); hipStreamWaitEvent(s, e_p, 0);'
@@ -26,33 +23,9 @@ muts=(
   'hipEventRecord(e_g, s); hipStreamWaitEvent(H->gstream, e_g, 0);'
   'if (!H->lvl_groups.empty() && H->gstream) wait_on(s, H->gstream);'
 )
-# dependency table of the dataflow sweeps: forward update waits for its supernode's diagonal solve; diagonal solve waits for the
-# updates it receives (forward / backward); backward update waits for the supernodes whose x it reads
-muts2=(
-  'S.cf_waits.push_back(make_int2(f_done(k), 1));'
-  'if (need[cidx[k]]) S.cf_waits.push_back(make_int2(f_cnt(k), need[cidx[k]]));'
-  'if (nchunk) S.cb_waits.push_back(make_int2(f_cnt(k), nchunk));'
-  'for (int g : tg) S.cb_waits.push_back(make_int2(f_done(g), 1)); => for (int g : tg) S.cb_waits.push_back(make_int2(f_done(g), 0));'
-)
 # ONLY_NEW=1: just the e_u1 wait (both branches) and the split-panel waits
-if [ -n "${ONLY_NEW:-}" ]; then muts=("${muts[@]:0:1}" "${muts[@]:6}"); muts2=(); fi
+if [ -n "${ONLY_NEW:-}" ]; then muts=("${muts[@]:0:1}" "${muts[@]:6}"); fi
 bad=0
-for m in "${muts2[@]}"; do
-  cp /tmp/sluamd_plan_orig.cpp $src2
-  python - "$m" <<'PY'
-import sys
-p = 'superlu_dist_amd/csrc/sluamd_plan.cpp'
-s = open(p).read(); m = sys.argv[1]
-m, _, repl = m.partition(' => ')       # "text" deletes the statement, "text => other" rewrites it (a wait that is always satisfied)
-assert s.count(m) == 1, (m, s.count(m))
-open(p, 'w').write(s.replace(m, repl or '/* mutated */;'))
-PY
-  make -C oracle >/dev/null 2>&1
-  out=$(timeout 900 python -m pytest tests/test_stream_order.py -q -k 'dataflow' 2>&1 | grep -E ' (passed|failed)' | tail -1)
-  echo "without '$m': $out"
-  case "$out" in *failed*) ;; *) bad=1; echo "  NOT CAUGHT";; esac
-done
-cp /tmp/sluamd_plan_orig.cpp $src2
 for m in "${muts[@]}"; do
   cp /tmp/sluamd_factor_orig.cpp $src
   python - "$m" <<'PY'

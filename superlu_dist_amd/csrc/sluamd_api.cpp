@@ -425,18 +425,6 @@ int sluamd_pzgstrs3d(sluamd_handle_t h, sluamd_doublecomplex *x, int64_t ldx, in
     return 0;
 }
 
-// the dataflow sweeps (k_chain) raise a pinned host word when a dependency counter never reaches its value (bounded spins):
-// checked after the stream was synchronised
-static int chain_check(Handle *H)
-{
-    if (H->chain_abort && *H->chain_abort) {
-        *H->chain_abort = 0;
-        set_error("triangular solve: a dependency of the dataflow sweep never arrived (SLUAMD_CHAIN=0 selects the level-set form)");
-        return SLUAMD_EHIP;
-    }
-    return 0;
-}
-
 int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nrhs)
 {
     if (!h || !d_x || nrhs < 0 || ldx < h->H.hs.n) { set_error("bad solve arguments"); return SLUAMD_EINVAL; }
@@ -451,7 +439,7 @@ int sluamd_pdgstrs3d_dev(sluamd_handle_t h, double *d_x, int64_t ldx, int32_t nr
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_solve_ms = ms;
-    return chain_check(H);
+    return 0;
 }
 
 // B: host, this rank's m_loc rows (vs doubles per value), leading dimension ldb in values
@@ -480,7 +468,6 @@ static int solve_dist_host(sluamd_handle_t h, double *B, int64_t ldb, int32_t nr
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_solve_ms = ms;
-    if ((rc = chain_check(H))) return rc;
     for (int q = 0; q < nrhs && m_loc; ++q) HIPCHK(hipMemcpy(B + (size_t) q * ldb * vs, H->d_bloc + (size_t) q * ldd * vs, sizeof(double) * (size_t) m_loc * vs, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -587,7 +574,7 @@ int sluamd_pdgsrfs3d_dev(sluamd_handle_t h, const double *d_B, int64_t ldb, doub
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (steps) *steps = count;
-    return chain_check(H);
+    return 0;
 }
 
 int sluamd_pdgsrfs3d(sluamd_handle_t h, const double *B, int64_t ldb, double *X, int64_t ldx, int32_t nrhs, double *berr, int32_t *steps)
@@ -630,7 +617,6 @@ void sluamd_dDestroyLUHandle(sluamd_handle_t h)
     if (H->d_apos) hipFree(H->d_apos);
     if (H->d_aval) hipFree(H->d_aval);
     if (H->h_pinned) hipHostFree(H->h_pinned);
-    if (H->chain_abort) hipHostFree(H->chain_abort);
     if (H->d_bloc) hipFree(H->d_bloc);
     for (void *q : H->dist.bufs) hipFree(q);
     free_rfs(H);

@@ -623,7 +623,6 @@ static int xseg_exchange(Handle *H, double *d_x, int64_t ldx, int nrhs, const st
 // reference's solve gets this overlap from its message-driven fmod / bmod counters (pdgstrs_lsum.c:414-960); here it is static.
 // (Measured and rejected: the far units on side streams -- each event record / wait costs the chain ~6 us; the feeding units
 // run by the diagonal workgroup itself -- serial 64-row strips, 7.05 -> 8.1 ms.)
-static bool use_chain(const Handle *H, const LevelSched &S) { return S.chain_l0 >= 0 && H->env.chain_mode && H->chain_abort; }
 
 static int max_rhs_chunk(const Handle *H);
 // second vector of the sweeps below: the diagonal solves are out of place (strips of one supernode = independent workgroups)
@@ -732,25 +731,16 @@ static int solve_fwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
     const int nl = S.nlevels;
     if (nl == 0) return 0;
     double *w = H->d_w;
-    // levels >= l0: the dataflow form (one persistent launch, LevelSched::cf_*); below it one launch pair per level
-    const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
     const int4 *fr = S.d_fwd_recs, *dr = S.d_diag_recs;     // unit records (null on complex handles)
-    if (l0 > 0) eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[0], S.du_off[1] - S.du_off[0], nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0], dr ? dr + 2 * (size_t) S.du_off[0] : nullptr, nullptr);
-    for (int l = 0; l < l0; ++l) {
+    eng::sweep_step(s, true, T, S.d_diag_units + S.du_off[0], S.du_off[1] - S.du_off[0], nullptr, 0, d_x, w, ldx, nrhs, S.max_nsupc[0], dr ? dr + 2 * (size_t) S.du_off[0] : nullptr, nullptr);
+    for (int l = 0; l < nl; ++l) {
         const int u0 = S.fu_off[2 * l], u1 = S.fu_off[2 * l + 1], u2 = S.fu_off[2 * l + 2];
-        const int nd = (l + 1 < l0) ? S.du_off[l + 2] - S.du_off[l + 1] : 0;     // the diagonal solves of level l0 belong to the chain
+        const int nd = (l + 1 < nl) ? S.du_off[l + 2] - S.du_off[l + 1] : 0;
         const int mx = std::max(S.max_nsupc[l], l + 1 < nl ? S.max_nsupc[l + 1] : 0);
         eng::fwd_update(s, T, nullptr, nullptr, 0, u1 - u0, w, d_x, ldx, nrhs, S.max_nsupc[l], S.d_fwd_units + u0, fr ? fr + 2 * (size_t) u0 : nullptr);
         eng::sweep_step(s, true, T, S.d_diag_units + (nd ? S.du_off[l + 1] : 0), nd, S.d_fwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, mx,
                         dr ? dr + 2 * (size_t) (nd ? S.du_off[l + 1] : 0) : nullptr, fr ? fr + 2 * (size_t) u1 : nullptr);
         H->st.solve_launches += 2;
-    }
-    if (l0 < nl) {
-        int mx = 0;
-        for (int l = l0; l < nl; ++l) mx = std::max(mx, S.max_nsupc[l]);
-        eng::chain_sweep(s, true, H->env.chain_mode, T, S.d_cf_units, (int) (S.cf_units.size() / 8), S.d_cf_waits, S.d_cf_sigs, S.d_chain_flags, S.chain_nflags,
-                         H->chain_abort, d_x, w, ldx, nrhs, mx);
-        H->st.solve_launches += 1;
     }
     return 0;
 }
@@ -764,20 +754,12 @@ static int solve_bwd_links(Handle *H, LevelSched &S, double *d_x, int64_t ldx, i
     if (nl == 0) return 0;
     double *w = H->d_w;
     const int4 *br = S.d_bwd_recs, *dr = S.d_diag_recs;
-    const int l0 = use_chain(H, S) ? S.chain_l0 : nl;
-    if (l0 < nl) {
-        int mx = 0;
-        for (int l = l0; l < nl; ++l) mx = std::max(mx, S.max_nsupc[l]);
-        if (l0 > 0) mx = std::max(mx, S.max_nsupc[l0 - 1]);      // the far chunks of level l0 - 1 ride along (LevelSched: F(l - 1) after D(l))
-        eng::chain_sweep(s, false, H->env.chain_mode, T, S.d_cb_units, (int) (S.cb_units.size() / 8), S.d_cb_waits, S.d_cb_sigs, S.d_chain_flags, S.chain_nflags,
-                         H->chain_abort, d_x, w, ldx, nrhs, mx);
-        H->st.solve_launches += 1;
-    } else {   // far chunks of the top level (columns of ancestors in other forests, solved before this sweep)
+    {   // far chunks of the top level (columns of ancestors in other forests, solved before this sweep)
         const int u1 = S.bu_off[2 * (nl - 1) + 1], u2 = S.bu_off[2 * (nl - 1) + 2];
         eng::sweep_step(s, false, T, nullptr, 0, S.d_bwd_units + u1, u2 - u1, d_x, w, ldx, nrhs, S.max_nsupc[nl - 1], nullptr, br ? br + 2 * (size_t) u1 : nullptr);
         H->st.solve_launches += 1;
     }
-    for (int l = l0 - 1; l >= 0; --l) {
+    for (int l = nl - 1; l >= 0; --l) {
         const int u0 = S.bu_off[2 * l], u1 = S.bu_off[2 * l + 1];
         const int nd = S.du_off[l + 1] - S.du_off[l];
         const int b1 = l > 0 ? S.bu_off[2 * (l - 1) + 1] : 0, b2 = l > 0 ? S.bu_off[2 * (l - 1) + 2] : 0;   // far chunks of level l-1: x of levels >= l+1 only
@@ -806,7 +788,7 @@ static int solve_fwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));
         if (!rc && !H->ssched.empty() && H->ssched[z].join && groups_fit(H, nrhs)) return solve_fwd_join(H, H->ssched[z], d_x, ldx, nrhs);     // merged chain groups: the contracted schedule
-        if (!rc && S.join && !use_chain(H, S)) return solve_fwd_join(H, S, d_x, ldx, nrhs);
+        if (!rc && S.join) return solve_fwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_fwd_links(H, S, d_x, ldx, nrhs);
     }
     for (int l = 0; l < S.nlevels; ++l) {
@@ -835,7 +817,7 @@ static int solve_bwd_z(Handle *H, int z, double *d_x, int64_t ldx, int nrhs)
     if (!xy && !H->z && !H->profile) {
         int rc = ensure_w(H, ldx * (int64_t) max_rhs_chunk(H));      // (already there: the forward sweep ran first)
         if (!rc && !H->ssched.empty() && H->ssched[z].join && groups_fit(H, nrhs)) return solve_bwd_join(H, H->ssched[z], d_x, ldx, nrhs);
-        if (!rc && S.join && !use_chain(H, S)) return solve_bwd_join(H, S, d_x, ldx, nrhs);
+        if (!rc && S.join) return solve_bwd_join(H, S, d_x, ldx, nrhs);
         return rc ? rc : solve_bwd_links(H, S, d_x, ldx, nrhs);
     }
     for (int l = S.nlevels - 1; l >= 0; --l) {

@@ -71,8 +71,6 @@ void read_env(Handle::Env &e)
     if (const char *v = getenv("SLUAMD_DIAG_TAIL")) e.diag_tail = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_MIN_PCT")) e.fuse_min_pct = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_MAX_PREV")) e.fuse_max_prev = std::max(1, std::min(3, atoi(v)));
-    if (const char *v = getenv("SLUAMD_CHAIN")) e.chain_mode = std::max(0, std::min(2, atoi(v)));
-    if (const char *v = getenv("SLUAMD_CHAIN_MAX_NODES")) e.chain_max_nodes = std::max(1, atoi(v));
     if (const char *v = getenv("SLUAMD_RESERVE_CUS")) e.reserve_cus = std::max(0, atoi(v));
 }
 

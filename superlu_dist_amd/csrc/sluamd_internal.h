@@ -194,19 +194,6 @@ struct LevelSched {
     std::vector<int> fu_off, bu_off;          // [2*nlevels+1]: index 2*level + part
     std::vector<int2> diag_units;             // (supernode, 64-row strip) of every owned diagonal block, level by level: the out-of-place diagonal solves of the sweeps
     std::vector<int> du_off;                  // [nlevels+1]
-    // Dataflow ("chain") form of the two sweeps over the TOP of the schedule, levels >= chain_l0 (1 x 1 layers, real): few
-    // supernodes per level, one dependent launch pair per level in the level-set form -- launch latency, not bandwidth.  Here
-    // ONE persistent launch per sweep walks a topologically ordered unit list with device-side dependency counters, the
-    // reference's fmod / bmod counters (pdgstrs_lsum.c:414-960, the GPU solve's spin-wait kernels pdgstrs_lsum_cuda.cu:2197-2596)
-    // built on the host: unit = {type (0 diagonal solve, 1 update), supernode, strip / chunk, wait range, signal range, 0};
-    // wait = (flag, value to reach), signal = flag to increment.  flags: [0] ticket, [1] abort, [2 + 2 c] updates received by
-    // chain node c, [3 + 2 c] its diagonal solve done.
-    int chain_l0 = -1;              // -1: none
-    int chain_nflags = 0;
-    std::vector<int> cf_units, cf_sigs, cb_units, cb_sigs;   // 8 ints per unit
-    std::vector<int2> cf_waits, cb_waits;
-    int *d_cf_units = nullptr, *d_cf_sigs = nullptr, *d_cb_units = nullptr, *d_cb_sigs = nullptr, *d_chain_flags = nullptr;
-    int2 *d_cf_waits = nullptr, *d_cb_waits = nullptr;
     std::vector<int> finv_prefix;   // per level (lvl_poff layout): 64-row identity strips of the Linv / Uinv computation, 2 * ceil(ns / 64) per owned diagonal block
     std::vector<int> max_nsupc;     // per level
     std::vector<double> lvl_flops_schur, lvl_flops_panel;   // per level, THIS rank's share: exact-segment Schur flops of its tiles; diagonal LU + panel solves it owns (sluamd_plan_table)
@@ -330,8 +317,6 @@ struct Handle {
         int z_fuse_max_nodes = 16;   // SLUAMD_ZFUSE_MAX_NODES: complex16 sweeps run the levels of at most this many supernodes as fused links (one launch per level and sweep); 0 = never
         bool info_last = false;      // SLUAMD_INFO_LAST=1: `info` = the zero pivot met LAST on a rank (largest column; what pdgstrf2.c:568-571 leaves in *info), MIN over the ranks (pdgstrf3d.c:388-392); default: the first column
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
-        int chain_mode = 0, chain_max_nodes = 8;   // SLUAMD_CHAIN: dataflow sweeps over the top levels (0 = off, the default: measured slower than the level-set launches,
-                                                   // profiles/r03_ab_dataflow_sweeps.txt; 1 = agent-scope fences; 2 = write-through x, no fences)
     } env;
     // device arenas
     double *d_val = nullptr;
@@ -383,7 +368,6 @@ struct Handle {
     bool inv_ready = false;                                 // T.inv (Linv / Uinv) too
     bool factored = false;                                  // the resident values are FACTORS (run_factor since the last SetValues / ResetValues): sluamd_dGetDiagInv refuses otherwise
     int *d_ztickets = nullptr;                              // complex fused backward links: one ticket counter per supernode (zero between sweeps)
-    int *chain_abort = nullptr;                             // pinned host word written by k_chain when a dependency never arrives (checked after every solve)
     bool profile = false;                                   // per-kernel-family HIP-event timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_schur, ev_panel, ev_xchg, ev_red;
     size_t ev_schur_used = 0, ev_panel_used = 0, ev_xchg_used = 0, ev_red_used = 0;
@@ -470,11 +454,6 @@ void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs
                 double *xa, double *xb, int64_t ldx, int nrhs, int max_nsupc);
 // x[rows of the supernodes `nodes`] = 0 (all right-hand sides)
 void zero_nodes(hipStream_t s, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs);
-// dataflow sweep over a topologically ordered unit list (LevelSched::cf_* / cb_*): ONE persistent launch; `flags` zeroed on s first;
-// the same two vectors as sweep_step
-void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,
-                 int *flags, int nflags, int *host_abort /* pinned host word, set to 1 when a dependency never arrived */, double *xa, double *xb, int64_t ldx, int nrhs,
-                 int max_nsupc);
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz);
 void rfs_residual(hipStream_t s, int n, const int *rp, const int *ci, const double *av, const double *x, const double *b, const int *pc,
                   double *r_perm, unsigned long long *s_out, double safe1, double safe2);

@@ -1732,21 +1732,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
 // x_k <- Linv x_k (unit lower) or Uinv x_k: one workgroup per supernode of the level, ONE dense triangular GEMV with the full
 // inverse (what the reference's DiagInv=YES solve does with Linv / Uinv, pdgstrs_lsum.c:414-520) -- no dependent chain
 // inside the block.  Used on XY layers, where the exchanges separate the diagonal solve from the updates.
-// x accessors of the sweeps.  COH = true (the fence-free form of the dataflow sweeps, k_chain): every access to x is an 8-byte
-// agent-scope access -- loads served by L2 past the CU's L1, stores written through -- so that workgroups on other CUs / XCDs read
-// what was published without cache-maintenance fences (the fp64 atomics of the updates are agent-scope as well)
-template <bool COH> __device__ __forceinline__ double ld_x(const double *p)
-{
-    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool COH> __device__ __forceinline__ void st_x(double *p, double v)
-{
-    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
-template <bool LOWER, int NT, bool COH = false>   // NT = 1024, or 256 for levels whose supernodes are at most 64 wide (one column quarter)
+template <bool LOWER, int NT>   // NT = 1024, or 256 for levels whose supernodes are at most 64 wide (one column quarter)
 __device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, const double *xin, double *xout, int64_t ldx, int nrhs, double *xs /* ns x nrhs */)
 {
     __shared__ double s_part[NT / 256][256];
@@ -1754,7 +1740,7 @@ __device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, const
     const int fst = T.xsup[k], ns = T.xsup[k + 1] - fst;
     const double *Ti = T.inv + T.sn_inv[k] + (LOWER ? 0 : (size_t) ns * ns);
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xs[idx] = ld_x<COH>(xin + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xs[idx] = xin[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
     // thread = (row i, quarter of the columns): <= 4 batches of 16 L2 loads; the inverse stores explicit zeros in the other
     // triangle, column blocks entirely outside the wave's rows are skipped
@@ -1783,7 +1769,7 @@ __device__ __forceinline__ void solve_diag_body(const DevTables &T, int k, const
         if (tid < ns) {
             double a = s_part[0][tid];
             if (NT == 1024) a = (a + s_part[1][tid]) + (s_part[NT == 1024 ? 2 : 0][tid] + s_part[NT == 1024 ? 3 : 0][tid]);
-            st_x<COH>(xout + fst + tid + (int64_t) q * ldx, a);
+            xout[fst + tid + (int64_t) q * ldx] = a;
         }
         __syncthreads();
     }
@@ -1806,7 +1792,7 @@ __global__ __launch_bounds__(NT) void k_solve_diag(DevTables T, const int *__res
 // RK (round 6): right-hand sides per pass over the values.  1 = the loop of rounds 1-5 (every right-hand side re-reads the unit's factor entries: right for nrhs = 1);
 // 4 = a block of four right-hand sides rides along each batch of loads -- the reference's nrhs > 1 path is a GEMM there (pdgstrs_lsum.c:414-960) -- chosen by the
 // launch wrappers when nrhs >= 2: nrhs = 16 reads the factors 4 x instead of 16 x
-template <int NT, bool COH = false, int NBT = 16, int RK = 1>   // NBT: loads per thread and batch (16: one batch covers a 256-column supernode with 1024 threads; 8: the builds for 8 waves per SIMD)
+template <int NT, int NBT = 16, int RK = 1>   // NBT: loads per thread and batch (16: one batch covers a 256-column supernode with 1024 threads; 8: the builds for 8 waves per SIMD)
 __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int strip, const double *xsrc /* solved x_k */, double *xdst /* lsum accumulators */,
                                                 int64_t ldx, int nrhs, double *xk /* ns x nrhs */, const int4 *rec = nullptr)
 {
@@ -1841,7 +1827,7 @@ __device__ __forceinline__ void fwd_update_body(const DevTables &T, int k, int s
     double lv0[NBT];
 #pragma unroll
     for (int u = 0; u < NBT; ++u) lv0[u] = (rvalid && ka + u < kb) ? __builtin_nontemporal_load(L + (size_t) (ka + u) * lda) : 0.0;
-    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = ld_x<COH>(xsrc + fst + (idx % ns) + (int64_t) (idx / ns) * ldx);
+    for (int idx = tid; idx < ns * nrhs; idx += NT) xk[idx] = xsrc[fst + (idx % ns) + (int64_t) (idx / ns) * ldx];
     __syncthreads();
     if (RK > 1) {
         for (int q0 = 0; q0 < nrhs; q0 += RK) {
@@ -1924,17 +1910,17 @@ __global__ __launch_bounds__(NT, MINW) void k_fwd_update(DevTables T, const int 
                                                    const int4 *__restrict__ recs)
 {
     extern __shared__ double xk[];  // ns x nrhs
-    if (recs) { fwd_update_body<NT, false, NBT, RK>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
+    if (recs) { fwd_update_body<NT, NBT, RK>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
     int k, strip;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; strip = u.y; }   // host-built (supernode, strip) list of one launch
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
-    fwd_update_body<NT, false, NBT, RK>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
+    fwd_update_body<NT, NBT, RK>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
 }
 
 // x_k -= U(k, chunk of 64 non-empty columns) x_cols  (dlsum_bmod_inv, pdgstrs_lsum.c:1362): workgroup = (supernode, chunk);
 // lanes run along the rows of supernode k (coalesced over the skyline segments), wave w takes the chunk's columns 4 w .. 4 w + 3
 // (one batch of 16 loads per lane); the 16 partial sums are combined in LDS and subtracted from x_k with fp64 atomics.
-template <int NT, bool COH = false, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true, int RK = 1>
+template <int NT, int RBv = (NT == 1024 ? 4 : 1), int CBT = 4, bool UNR = true, int RK = 1>
 // NT = 1024 (16 waves x 4 columns), or 256 for levels whose supernodes are at most 64 wide (4 waves x 16 columns, one row block);
 // RBv = 4 with NT = 512 / 256: supernodes of up to 256 columns in smaller workgroups (more of them resident per CU: levels of MANY units, where overlapping the phases
 // of a workgroup's life -- record, maps, values, reduction, atomics -- across workgroups counts for more than the length of one life);
@@ -1988,7 +1974,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
         for (int r0 = 0; r0 < nrhs; r0 += RK) {
             if (tid < ncol)
 #pragma unroll
-                for (int j = 0; j < RK; ++j) s_xc[j][tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) min(r0 + j, nrhs - 1) * ldx);
+                for (int j = 0; j < RK; ++j) s_xc[j][tid] = xcols[s_gc[tid] + (int64_t) min(r0 + j, nrhs - 1) * ldx];
             __syncthreads();
             double a[RK][RB];
 #pragma unroll
@@ -2033,7 +2019,7 @@ __device__ __forceinline__ void bwd_update_body(const DevTables &T, int k, int c
         return;
     }
     for (int r = 0; r < nrhs; ++r) {
-        if (tid < ncol) s_xc[0][tid] = ld_x<COH>(xcols + s_gc[tid] + (int64_t) r * ldx);      // solved x of this chunk's columns: one gather
+        if (tid < ncol) s_xc[0][tid] = xcols[s_gc[tid] + (int64_t) r * ldx];      // solved x of this chunk's columns: one gather
         __syncthreads();
         {
             double a[RB];
@@ -2074,11 +2060,11 @@ __global__ __launch_bounds__(NT, MINW) void k_bwd_update(DevTables T, const int 
                                                    int nn, const double *xcols, double *xrows, int64_t ldx, int nrhs, const int2 *__restrict__ units,
                                                    const int4 *__restrict__ recs)
 {
-    if (recs) { bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
+    if (recs) { bwd_update_body<NT, RBv, CBT, UNR, RK>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
     int k, chunk;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; chunk = u.y; }
     else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
-    bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, k, chunk, xcols, xrows, ldx, nrhs);
+    bwd_update_body<NT, RBv, CBT, UNR, RK>(T, k, chunk, xcols, xrows, ldx, nrhs);
 }
 
 // One 64-row strip of a diagonal solve, OUT OF PLACE: xout_k[strip rows] = (Linv or Uinv)[strip rows, :] xin_k.  The diagonal solve of a
@@ -2214,13 +2200,13 @@ __global__ __launch_bounds__(NT, MINW) void k_sweep(DevTables T, const int2 *__r
         return;
     }
     if (urecs) {
-        if (LOWER) fwd_update_body<NT, false, NBT, RK>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - ndu));
-        else bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - ndu));
+        if (LOWER) fwd_update_body<NT, NBT, RK>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - ndu));
+        else bwd_update_body<NT, RBv, CBT, UNR, RK>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - ndu));
         return;
     }
     const int2 u = units[bid - ndu];
-    if (LOWER) fwd_update_body<NT, false, NBT, RK>(T, u.x, u.y, xb, xa, ldx, nrhs, dyn);
-    else bwd_update_body<NT, false, RBv, CBT, UNR, RK>(T, u.x, u.y, xa, xb, ldx, nrhs);
+    if (LOWER) fwd_update_body<NT, NBT, RK>(T, u.x, u.y, xb, xa, ldx, nrhs, dyn);
+    else bwd_update_body<NT, RBv, CBT, UNR, RK>(T, u.x, u.y, xa, xb, ldx, nrhs);
 }
 
 // ---- joined links (LevelSched::join) -----------------------------------------------------------------------------------------------------------------
@@ -2385,8 +2371,8 @@ __global__ __launch_bounds__(NT, MINW) void k_sweep_join(DevTables T, const int4
         else join_bwd_body<NT, NBT>(T, jrecs + 4 * (size_t) bid, jaux, xa, xb, ldx, nrhs);
         return;
     }
-    if (LOWER) fwd_update_body<NT, false, NBT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - nj));
-    else bwd_update_body<NT, false, RBv, CBT, UNR>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - nj));
+    if (LOWER) fwd_update_body<NT, NBT>(T, 0, 0, xb, xa, ldx, nrhs, dyn, urecs + 2 * (size_t) (bid - nj));
+    else bwd_update_body<NT, RBv, CBT, UNR>(T, 0, 0, xa, xb, ldx, nrhs, urecs + 2 * (size_t) (bid - nj));
 }
 
 __global__ __launch_bounds__(256) void k_zero_nodes(const int *__restrict__ xsup, const int *__restrict__ nodes, int nn, double *__restrict__ x, int64_t ldx, int nrhs)
@@ -2396,75 +2382,6 @@ __global__ __launch_bounds__(256) void k_zero_nodes(const int *__restrict__ xsup
     const int k = nodes[ni], f = xsup[k], l = xsup[k + 1];
     for (int q = 0; q < nrhs; ++q)
         for (int rr = f + lane; rr < l; rr += 64) x[rr + (int64_t) q * ldx] = 0.0;
-}
-
-// Dataflow sweeps over the top of the elimination DAG (LevelSched::chain_l0): ONE persistent launch walks a topologically
-// ordered unit list -- diagonal solves and 64-row / 64-column update units of the levels that hold only a few supernodes each --
-// instead of two dependent launches per level.  The reference's GPU solve does the same with spin-waits on its fmod / bmod
-// counters (dlsum_fmod_inv_gpu_mrhs / dlsum_bmod_inv_gpu_mrhs, pdgstrs_lsum_cuda.cu:2197-2596, :3038); here the dependency
-// structure is a host-built table of (flag, value) waits and flag increments per unit.
-//   * a workgroup takes the next unit by ticket (flags[0]): units are STARTED in list order and only wait for earlier units, so
-//     the unit with the smallest unfinished ticket can always run -- progress does not depend on how many workgroups are resident;
-//   * hand-off between workgroups (cdna_hip_programming.md section 6, Guideline 16): producer = every wave drains its memory
-//     operations, barrier, ONE lane releases at agent scope, then increments the flags with relaxed agent-scope atomics;
-//     consumer = the first wave polls its flags relaxed (one lane per flag, s_sleep between polls), ONE agent-scope acquire,
-//     barrier, plain loads.  MODE 2: every access to x is an agent-scope 8-byte access instead (updates are fp64 atomics, the
-//     diagonal solve writes x_k through) -- no cache-maintenance fence on either side;
-//   * spins are bounded: a dependency that never arrives raises flags[1] and every workgroup leaves (the host reports it).
-constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 22;     // x ~0.3 us per poll: about a second
-template <bool LOWER, int MODE>
-__global__ __launch_bounds__(1024) void k_chain(DevTables T, const int *__restrict__ units, int nunits, const int2 *__restrict__ waits,
-                                                const int *__restrict__ sigs, int *flags, int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs)
-{
-    extern __shared__ double dyn[];  // max_nsupc x nrhs
-    __shared__ int s_u[2];
-    constexpr bool COH = MODE == 2;
-    const int tid = threadIdx.x;
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) {
-            s_u[0] = __hip_atomic_fetch_add(&flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_u[1] = __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        const int u = s_u[0];
-        if (u >= nunits || s_u[1]) return;
-        const int *rec = units + 8 * (size_t) u;
-        const int type = rec[0], k = rec[1], idx = rec[2], w_off = rec[3], w_n = rec[4], s_off = rec[5], s_n = rec[6];
-        // ---- consume: wait for the units this one depends on ----
-        if (tid < 64) {
-            bool fail = false;
-            if (tid < w_n) {
-                const int2 w = waits[w_off + tid];
-                unsigned spins = 0;
-                while (__hip_atomic_load(&flags[w.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < w.y) {
-                    if (++spins > CHAIN_SPIN_LIMIT || __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = true; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
-            if (__any(fail)) {
-                if (tid == 0) {
-                    __hip_atomic_store(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_u[1] = 1;
-                    __hip_atomic_store(host_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // pinned host word: the API reports the failure
-                }
-            }
-            else if (MODE == 1 && tid == 0 && w_n > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (s_u[1]) return;
-        // ---- the unit ----
-        // the same two vectors as k_sweep: forward xa -> xb at the diagonal solves, backward xb -> xa
-        if (type == 0) { if (LOWER) solve_diag_body<true, 1024, COH>(T, k, xa, xb, ldx, nrhs, dyn); else solve_diag_body<false, 1024, COH>(T, k, xb, xa, ldx, nrhs, dyn); }
-        else if (LOWER) fwd_update_body<1024, COH>(T, k, idx, xb, xa, ldx, nrhs, dyn);
-        else bwd_update_body<1024, COH>(T, k, idx, xa, xb, ldx, nrhs);
-        // ---- publish ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores / atomics have left the CU
-        __syncthreads();
-        if (tid == 0) {
-            if (MODE == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            for (int i = 0; i < s_n; ++i) __hip_atomic_fetch_add(&flags[sigs[s_off + i]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 
 // A's entries -> value arena (device-side pddistribute): val[pos[e]] = a[e]
@@ -2571,10 +2488,6 @@ int setup()
     HIPCHK(hipFuncSetAttribute((const void *) kz_diag_lu, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *) k_solve_diag<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_chain<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_chain<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_chain<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *) k_chain<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) g_num_cus = pr.multiProcessorCount; }
     // the 256-thread variants stage max_nsupc (<= 64) x nrhs values: above 64 KiB when a matrix of narrow supernodes is solved for many right-hand sides
     if (sweep_attrs()) return 1;
@@ -2912,22 +2825,6 @@ void sweep_join(hipStream_t s, bool lower, const DevTables &T, const int4 *jrecs
 void zero_nodes(hipStream_t s, const DevTables &T, const int *nodes, int nn, double *x, int64_t ldx, int nrhs)
 {
     if (nn > 0) hipLaunchKernelGGL(k_zero_nodes, dim3((nn + 3) / 4), dim3(256), 0, s, T.xsup, nodes, nn, x, ldx, nrhs);
-}
-
-void chain_sweep(hipStream_t s, bool lower, int mode, const DevTables &T, const int *units, int nunits, const int2 *waits, const int *sigs,
-                 int *flags, int nflags, int *host_abort, double *xa, double *xb, int64_t ldx, int nrhs, int mx)
-{
-    if (nunits <= 0) return;
-    hipMemsetAsync(flags, 0, sizeof(int) * (size_t) nflags, s);      // tickets, abort flag, dependency counters: zeroed before every launch
-    const size_t lds = (size_t) mx * nrhs * sizeof(double);
-    const int grid = std::min(nunits, g_num_cus);                   // one 1024-thread workgroup per CU; fewer resident ones are fine (tickets)
-    if (mode == 2) {
-        if (lower) hipLaunchKernelGGL((k_chain<true, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
-        else hipLaunchKernelGGL((k_chain<false, 2>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
-    } else {
-        if (lower) hipLaunchKernelGGL((k_chain<true, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
-        else hipLaunchKernelGGL((k_chain<false, 1>), dim3(grid), dim3(1024), lds, s, T, units, nunits, waits, sigs, flags, host_abort, xa, xb, ldx, nrhs);
-    }
 }
 
 void scatter_values(hipStream_t s, double *val, const int64_t *pos, const double *a, int64_t nnz)

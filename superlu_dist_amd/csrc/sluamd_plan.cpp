@@ -655,104 +655,6 @@ static void build_panel_split(const Handle &H, const HostTables &t, LevelSched &
     }
 }
 
-// Dataflow unit lists of the sweeps over the top of the schedule (LevelSched::chain_l0 ...): the levels from the first one
-// after which no level has more than `chain_max_nodes` supernodes.  Forward order: D(l0) U(l0) | D(l+1) F(l) U(l+1) | ... | F(last)
-// (D = diagonal solves, U / F = the urgent / far update units of S.fwd_units); backward: F(last) | U(l) D(l) F(l-1) | ... down
-// to l0.  Every unit only waits for units earlier in its list, so workgroups that take units in list order (device-side ticket)
-// always make progress, whatever the number of resident workgroups.
-static void build_chain(const Handle &H, const HostTables &t, const std::vector<int> &lvl, LevelSched &S)
-{
-    S.chain_l0 = -1; S.chain_nflags = 0;
-    S.cf_units.clear(); S.cf_waits.clear(); S.cf_sigs.clear(); S.cb_units.clear(); S.cb_waits.clear(); S.cb_sigs.clear();
-    if (H.grid.Pr * H.grid.Pc != 1 || H.z || !H.env.chain_mode || S.nlevels < 8) return;
-    int l0 = S.nlevels;
-    while (l0 > 0 && S.lvl_off[l0] - S.lvl_off[l0 - 1] <= H.env.chain_max_nodes) --l0;
-    if (S.nlevels - l0 < 6) return;            // too short to pay for a launch of its own
-    const int base = S.lvl_off[l0], nchain = S.lvl_off[S.nlevels] - base;
-    std::vector<int> cidx(lvl.size(), -1);
-    for (int i = base; i < S.lvl_off[S.nlevels]; ++i) cidx[S.nodes[i]] = i - base;
-    auto f_cnt = [&](int k) { return 2 + 2 * cidx[k]; };
-    auto f_done = [&](int k) { return 3 + 2 * cidx[k]; };
-    std::vector<int> tg;
-    auto fwd_targets = [&](int k, int strip) {      // chain supernodes whose rows the strip updates
-        tg.clear();
-        const int ldiag = t.sn_ldiag[k], r0 = ldiag + 64 * strip, r1 = std::min(r0 + 64, t.sn_nsupr[k]);
-        for (int b = 0; b < t.sn_nlb[k]; ++b) {
-            const int bi = t.sn_lb_off[k] + b, g = t.lb_gid[bi];
-            if (g == k || t.lb_rowoff[bi] >= r1 || t.lb_rowoff[bi] + t.lb_nbrow[bi] <= r0) continue;
-            if (cidx[g] >= 0 && std::find(tg.begin(), tg.end(), g) == tg.end()) tg.push_back(g);
-        }
-    };
-    auto bwd_sources = [&](int k, int chunk) {      // chain supernodes whose x the chunk reads
-        tg.clear();
-        const int c0 = 64 * chunk, c1 = std::min(c0 + 64, t.sn_ncolu[k]);
-        for (int b = 0; b < t.sn_nub[k]; ++b) {
-            const int bi = t.sn_ub_off[k] + b, g = t.ub_gid[bi];
-            if (!t.ub_ncols[bi] || t.ub_stcol[bi] >= c1 || t.ub_stcol[bi] + t.ub_ncols[bi] <= c0) continue;
-            if (cidx[g] >= 0 && std::find(tg.begin(), tg.end(), g) == tg.end()) tg.push_back(g);
-        }
-    };
-    bool ok = true;
-    // ---- forward ----
-    std::vector<int> need(nchain, 0);
-    for (int l = l0; l < S.nlevels; ++l)
-        for (int u = S.fu_off[2 * l]; u < S.fu_off[2 * l + 2]; ++u) { fwd_targets(S.fwd_units[u].x, S.fwd_units[u].y); for (int g : tg) need[cidx[g]]++; }
-    auto f_diag = [&](int l) {
-        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
-            const int k = S.nodes[i];
-            if (!(t.sn_flags[k] & SNF_OWN_DIAG)) continue;
-            const int w0 = (int) S.cf_waits.size(), s0 = (int) S.cf_sigs.size();
-            if (need[cidx[k]]) S.cf_waits.push_back(make_int2(f_cnt(k), need[cidx[k]]));
-            S.cf_sigs.push_back(f_done(k));
-            const int rec[8] = {0, k, 0, w0, (int) S.cf_waits.size() - w0, s0, 1, 0};
-            S.cf_units.insert(S.cf_units.end(), rec, rec + 8);
-        }
-    };
-    auto f_upd = [&](int l, int part) {
-        for (int u = S.fu_off[2 * l + part]; u < S.fu_off[2 * l + part + 1]; ++u) {
-            const int k = S.fwd_units[u].x, strip = S.fwd_units[u].y;
-            fwd_targets(k, strip);
-            const int w0 = (int) S.cf_waits.size(), s0 = (int) S.cf_sigs.size();
-            S.cf_waits.push_back(make_int2(f_done(k), 1));
-            for (int g : tg) S.cf_sigs.push_back(f_cnt(g));
-            const int rec[8] = {1, k, strip, w0, 1, s0, (int) tg.size(), 0};
-            S.cf_units.insert(S.cf_units.end(), rec, rec + 8);
-        }
-    };
-    f_diag(l0); f_upd(l0, 0);
-    for (int l = l0; l + 1 < S.nlevels; ++l) { f_diag(l + 1); f_upd(l, 1); f_upd(l + 1, 0); }
-    f_upd(S.nlevels - 1, 1);
-    // ---- backward ----
-    auto b_upd = [&](int l, int part) {
-        for (int u = S.bu_off[2 * l + part]; u < S.bu_off[2 * l + part + 1]; ++u) {
-            const int k = S.bwd_units[u].x, chunk = S.bwd_units[u].y;
-            bwd_sources(k, chunk);
-            if (tg.size() > 64) ok = false;
-            const int w0 = (int) S.cb_waits.size(), s0 = (int) S.cb_sigs.size();
-            for (int g : tg) S.cb_waits.push_back(make_int2(f_done(g), 1));
-            if (cidx[k] >= 0) S.cb_sigs.push_back(f_cnt(k));       // (the far chunks of level l0 - 1 ride along: their supernode is solved by the launches that follow)
-            const int rec[8] = {1, k, chunk, w0, (int) tg.size(), s0, (int) S.cb_sigs.size() - s0, 0};
-            S.cb_units.insert(S.cb_units.end(), rec, rec + 8);
-        }
-    };
-    auto b_diag = [&](int l) {
-        for (int i = S.lvl_off[l]; i < S.lvl_off[l + 1]; ++i) {
-            const int k = S.nodes[i];
-            if (!(t.sn_flags[k] & SNF_OWN_DIAG)) continue;
-            const int nchunk = (t.sn_flags[k] & SNF_U_OWN) ? (t.sn_ncolu[k] + 63) / 64 : 0;
-            const int w0 = (int) S.cb_waits.size(), s0 = (int) S.cb_sigs.size();
-            if (nchunk) S.cb_waits.push_back(make_int2(f_cnt(k), nchunk));
-            S.cb_sigs.push_back(f_done(k));
-            const int rec[8] = {0, k, 0, w0, (int) S.cb_waits.size() - w0, s0, 1, 0};
-            S.cb_units.insert(S.cb_units.end(), rec, rec + 8);
-        }
-    };
-    b_upd(S.nlevels - 1, 1);
-    for (int l = S.nlevels - 1; l >= l0; --l) { b_upd(l, 0); b_diag(l); if (l > 0) b_upd(l - 1, 1); }
-    if (!ok) { S.cf_units.clear(); S.cb_units.clear(); return; }
-    S.chain_l0 = l0; S.chain_nflags = 2 + 2 * nchain;
-}
-
 // Level schedule of one forest (lvl / nlevels from dag_levels): node order, per-level work-unit prefix arrays, urgent tile
 // lists, K-fused pairs.
 static void build_schedule(Handle &H, const HostTables &t, const std::vector<int> &list, const std::vector<int> &lvl, int nlevels, LevelSched &S)
@@ -853,7 +755,6 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
         S.du_off[l + 1] = (int) S.diag_units.size();
     }
     H.setup.lap("sched.prefixes_sweep_units");
-    build_chain(H, t, lvl, S);
     // K-fused chain groups of up to four supernodes (a, a+1, a+2, a+3) in consecutive levels: every member but the last
     // runs only its urgent tiles; every member's executed tiles accumulate all earlier members' deferred updates.
     // XY layers (round 4): a deferred supernode's received panels outlive one more exchange -- three scratch copies by level modulo 3
@@ -1217,7 +1118,6 @@ static void build_solve_sched(Handle &H, const HostTables &t, const std::vector<
     }
     S.lvl_has_group.assign(nslev, 0);
     for (int k : list) if (H.grp_of[k] >= 0) S.lvl_has_group[slev[k]] = 1;
-    S.chain_l0 = -1;
     S.lvl_defer.assign(nslev, 0);
     S.u_off.assign(8 * nslev + 1, 0);
     S.ps_off.assign(4 * (size_t) nslev + 1, 0);
@@ -1311,13 +1211,6 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
             for (auto *v : {&S.jf_recs, &S.jf_aux, &S.jb_recs, &S.jb_aux, &S.jfu_recs, &S.jbu_recs}) std::vector<int4>().swap(*v);
             H.setup.lap("upload.joined_sweep_tables");
         }
-    }
-    if (S.chain_l0 >= 0) {
-        if (upload(H.d_misc, S.cf_units, &S.d_cf_units) || upload(H.d_misc, S.cf_waits, &S.d_cf_waits) || upload(H.d_misc, S.cf_sigs, &S.d_cf_sigs)) return SLUAMD_EHIP;
-        if (upload(H.d_misc, S.cb_units, &S.d_cb_units) || upload(H.d_misc, S.cb_waits, &S.d_cb_waits) || upload(H.d_misc, S.cb_sigs, &S.d_cb_sigs)) return SLUAMD_EHIP;
-        std::vector<int> zero(S.chain_nflags, 0);
-        if (upload(H.d_misc, zero, &S.d_chain_flags)) return SLUAMD_EHIP;
-        if (!H.chain_abort) { HIPCHK(hipHostMalloc((void **) &H.chain_abort, sizeof(int), hipHostMallocDefault)); *H.chain_abort = 0; }
     }
     return 0;
 }
@@ -1664,7 +1557,6 @@ int plan_and_upload(Handle *H, SlotInput &in, HostTables &t)
     H->st.num_levels = nlevtot;
     H->setup.lap("sched.rest");
     H->st.chain_levels = 0; H->st.chain_units = 0;
-    for (auto &S : H->sched) if (S.chain_l0 >= 0) { H->st.chain_levels += S.nlevels - S.chain_l0; H->st.chain_units += (int64_t) S.cf_units.size() / 8; }
 
     // ---- 7. device allocations + uploads (the value arena is still being allocated and zero-filled by its helper thread: joined at the end, nothing here touches it) ----
     if (H->env.reserve_cus > 0) {

@@ -174,30 +174,6 @@ def test_factor_twice_after_device_reset_reproduces_the_solution():
     h.destroy()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_dataflow_sweeps_on_the_device(monkeypatch, mode):
-    """SLUAMD_CHAIN=1 / 2: the persistent-kernel form of the sweeps over the top of the elimination DAG (k_chain: ticketed unit list,
-    device-side dependency counters; mode 1 = agent-scope release / acquire fences, mode 2 = write-through accesses to x) against the
-    level-set launches on the same factors -- workgroups of all eight XCDs hand x over inside one launch."""
-    import numpy as np
-    from superlu_dist_amd import driver, matgen
-    N = 24
-    n, rp, ci, v = matgen.poisson3d(N)
-    rng = np.random.default_rng(3)
-    v = v * (1.0 + 0.2 * rng.random(v.size))
-    perm = matgen.nd_perm_grid3d(N, N, N, leaf=64)
-    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 3)
-    monkeypatch.setenv("SLUAMD_CHAIN", "0")
-    x_ref, info, st0 = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=64, maxsup=128)
-    assert info == 0 and st0["chain_levels"] == 0
-    monkeypatch.setenv("SLUAMD_CHAIN", str(mode))
-    for rep in range(3):          # fresh handles: different workgroup placements / arrival orders
-        x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=64, maxsup=128)
-        assert info == 0 and st["chain_levels"] >= 6
-        assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
-        assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
-
-
 @pytest.mark.parametrize("join_max", [1 << 30, 32, 4, 1])
 def test_joined_links_of_the_sweeps_on_the_device(monkeypatch, join_max):
     """Round 4: one launch per level in the triangular sweeps of a 1 x 1 layer (k_sweep_join: the 64 x 64 blocks of the next level's diagonal inverses

@@ -158,34 +158,6 @@ def test_joined_links_per_forest_on_z_layers(sched, monkeypatch, grid):
     _sched(sched, 0)
 
 
-@pytest.mark.parametrize("max_nodes", [8, 3, 100000])
-@pytest.mark.parametrize("mode,seed", [(0, 1), (1, 1), (1, 5), (2, 2), (3, 3)])
-def test_dataflow_sweeps_honour_only_their_dependency_table(sched, monkeypatch, max_nodes, mode, seed):
-    """The persistent-kernel form of the triangular sweeps over the top of the DAG (k_chain; LevelSched::cf_* / cb_*): the emulated
-    launch runs the units in a seeded random order that honours ONLY the host-built (flag, value) waits, like workgroups racing on
-    the device.  max_nodes = 100000: the whole schedule is one dataflow launch per sweep (chain_l0 = 0); 3: the chain starts high in
-    the tree, the far units of the level below it ride along in the backward launch."""
-    monkeypatch.setenv("SLUAMD_CHAIN_MAX_NODES", str(max_nodes))
-    N = 12
-    n, rp, ci, v = matgen.poisson3d(N)
-    rng = np.random.default_rng(7)
-    v = v * (1.0 + 0.2 * rng.random(v.size))
-    perm = matgen.nd_perm_grid3d(N, N, N, leaf=27)
-    xt, b = matgen.xtrue_rhs(n, rp, ci, v, 3)
-    monkeypatch.setenv("SLUAMD_CHAIN", "0")
-    x_ref, info, st0 = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=16, maxsup=48)      # level-set sweeps
-    assert info == 0 and st0["chain_levels"] == 0
-    monkeypatch.setenv("SLUAMD_CHAIN", "1")
-    _sched(sched, mode, seed)
-    x, info, st = driver.pdgssvx3d(n, rp, ci, v, b, perm, relax=16, maxsup=48)
-    _sched(sched, 0)
-    assert info == 0 and st["chain_levels"] >= 6 and st["chain_units"] > 20
-    if max_nodes == 100000:
-        assert st["chain_levels"] == st["num_levels"]
-    assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
-    assert np.linalg.norm(b - matgen.csr_matvec(n, rp, ci, v, x)) <= 1e-12 * np.linalg.norm(b)
-
-
 @pytest.mark.parametrize("mode,seed", [(1, 1), (1, 2), (2, 1), (3, 1)])
 def test_wide_supernodes_big_tiles_and_fused_pairs(sched, mode, seed):
     """256-wide supernodes: the 128 x 128 tile lists, K-fused chain pairs, Crout diagonal kernel + full inverses on the chain."""
