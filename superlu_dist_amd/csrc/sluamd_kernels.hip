@@ -31,6 +31,30 @@ __device__ __forceinline__ int find_node(const int *__restrict__ prefix, int nn,
     return lo;
 }
 
+// The same search by a whole wave -- id wave-uniform, all 64 lanes active (kernel entry): 64 probes per round trip instead of one.  The kernels of a
+// latency-bound level start with this search; a binary search over a level of 16 supernodes is four dependent loads, over a leaf level of 9 000 fourteen.
+#ifndef SLUAMD_FIND_WAVE
+#define SLUAMD_FIND_WAVE 1
+#endif
+__device__ __forceinline__ int find_node_wave(const int *__restrict__ prefix, int nn, int id)
+{
+#if SLUAMD_FIND_WAVE
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = nn;                             // prefix[lo] <= id < prefix[hi]
+    while (hi - lo > 1) {
+        const int stride = (hi - lo + 62) >> 6;      // candidates lo + 1 .. hi - 1 in at most 64 steps of `stride`
+        const int p = lo + (lane + 1) * stride;
+        const bool le = p < hi && prefix[p] <= id;   // monotone: the set lanes are a prefix of the wave
+        const int cnt = __popcll(__ballot(le));
+        lo += cnt * stride;
+        hi = min(hi, lo + stride);
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+#else
+    return find_node(prefix, nn, id);
+#endif
+}
+
 __device__ __forceinline__ void atomic_sub_f64(double *p, double v)
 {
     unsafeAtomicAdd(p, -v);  // global_atomic_add_f64 (hardware fp64 atomic on gfx950)
@@ -886,11 +910,11 @@ __global__ __launch_bounds__(RSv * 4) void k_panel_trsm(DevTables T, const int *
         return;
     }
     if ((int) blockIdx.x < nl) {
-        const int ni = find_node(lprefix, nn, blockIdx.x);
+        const int ni = find_node_wave(lprefix, nn, blockIdx.x);
         panel_trsm_body<0, RSv>(T, nodes[ni], blockIdx.x - lprefix[ni], sm);
     } else {
         const int id = blockIdx.x - nl;
-        const int ni = find_node(uprefix, nn, id);
+        const int ni = find_node_wave(uprefix, nn, id);
         panel_trsm_body<1, RSv>(T, nodes[ni], id - uprefix[ni], sm);
     }
 }
@@ -1004,11 +1028,11 @@ __global__ __launch_bounds__(256) void k_panel_gemm(DevTables T, const int *__re
         return;
     }
     if ((int) blockIdx.x < nl) {
-        const int ni = find_node(lprefix, nn, blockIdx.x);
+        const int ni = find_node_wave(lprefix, nn, blockIdx.x);
         panel_gemm_wg<0, NQ>(T, nodes[ni], blockIdx.x - lprefix[ni], Ts);
     } else {
         const int id = blockIdx.x - nl;
-        const int ni = find_node(uprefix, nn, id);
+        const int ni = find_node_wave(uprefix, nn, id);
         panel_gemm_wg<1, NQ>(T, nodes[ni], id - uprefix[ni], Ts);
     }
 }
@@ -1021,7 +1045,7 @@ __global__ __launch_bounds__(FIS * 4) void k_full_inv(DevTables T, const int *__
 {
     __builtin_amdgcn_s_setprio(3);   // panel chain: its waves go first when they share a SIMD with Schur tiles
     extern __shared__ double sm[];
-    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int ni = find_node_wave(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int ns = T.xsup[k + 1] - T.xsup[k];
     const int per = (ns + FIS - 1) / FIS;
@@ -1913,7 +1937,7 @@ __global__ __launch_bounds__(NT, MINW) void k_fwd_update(DevTables T, const int 
     if (recs) { fwd_update_body<NT, NBT, RK>(T, 0, 0, xsrc, xdst, ldx, nrhs, xk, recs + 2 * (size_t) blockIdx.x); return; }   // unit records of the same list
     int k, strip;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; strip = u.y; }   // host-built (supernode, strip) list of one launch
-    else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
+    else { const int ni = find_node_wave(prefix, nn, blockIdx.x); k = nodes[ni]; strip = blockIdx.x - prefix[ni]; }
     fwd_update_body<NT, NBT, RK>(T, k, strip, xsrc, xdst, ldx, nrhs, xk);
 }
 
@@ -2063,7 +2087,7 @@ __global__ __launch_bounds__(NT, MINW) void k_bwd_update(DevTables T, const int 
     if (recs) { bwd_update_body<NT, RBv, CBT, UNR, RK>(T, 0, 0, xcols, xrows, ldx, nrhs, recs + 2 * (size_t) blockIdx.x); return; }
     int k, chunk;
     if (units) { const int2 u = units[blockIdx.x]; k = u.x; chunk = u.y; }
-    else { const int ni = find_node(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
+    else { const int ni = find_node_wave(prefix, nn, blockIdx.x); k = nodes[ni]; chunk = blockIdx.x - prefix[ni]; }
     bwd_update_body<NT, RBv, CBT, UNR, RK>(T, k, chunk, xcols, xrows, ldx, nrhs);
 }
 
@@ -2423,7 +2447,7 @@ template <int VS>    // VS doubles per value: 1 (double), 2 (complex16)
 __global__ __launch_bounds__(256) void k_pack_diag(DevTables T, const int *__restrict__ nodes, const int *__restrict__ prefix,
                                                    const int64_t *__restrict__ off, int nn, double *__restrict__ stage)
 {
-    const int ni = find_node(prefix, nn, blockIdx.x);
+    const int ni = find_node_wave(prefix, nn, blockIdx.x);
     const int k = nodes[ni];
     const int ns = T.xsup[k + 1] - T.xsup[k];
     const int e0 = (blockIdx.x - prefix[ni]) * DGC, e1 = min(e0 + DGC, ns * ns);
