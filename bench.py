@@ -288,7 +288,9 @@ def cpu_baseline(N, leaf, relax, maxsup, want_reference=True, grid_n=0, mkl_n=60
                        + "GFLOP/s uses our symbolic flop count of OUR supernode partition (reference_ops_FACT = the reference's own tally on the same matrix). "
                          "Measured on the bounded sample only: the reference's rate on the benched 100^3 problem is NOT measured (hours at these rates); "
                          "supernodes are wider there, so its GFLOP/s would be somewhat higher")
-    if grid_n:
+    if grid_n and not have_ref:
+        out["grid_2x2x2"] = {"skipped": "no build of the reference on this box (oracle/_ref, oracle/_ref_mkl): the 2x2x2 CPU leg runs the reference's own pddrive3d flow"}
+    elif grid_n:
         try:
             out["grid_2x2x2"] = (cpu_baseline_grid(mkl_grid_n, leaf, relax, maxsup, mkl_bin, host_cores, mkl=mkl_desc) if mkl_bin and mkl
                                  else cpu_baseline_grid(grid_n, leaf, relax, maxsup, ref_bin, host_cores))
