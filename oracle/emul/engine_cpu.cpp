@@ -747,7 +747,7 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 }
 
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int prio,
-           const int *, int mmode, int /* ksplit: shares of K per tile on the device; the restatement computes a tile once */)
+           const int *, int mmode, int /* ksplit: shares of K per tile on the device; the restatement computes a tile once */, const int *, int /* XCD ranges: a device mapping */)
 {
     if (mmode == 1) return;     // build pass of the per-tile records: the restatement reads the tables every time
     emul_enqueue(s, [=] { impl::schur(s, cfg, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio); });
@@ -947,7 +947,7 @@ void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int 
     emul_enqueue(s, [=] { impl::zpanel_trsm(T, nodes, nn); });
 }
 void zschur(hipStream_t s, int, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info, const int4 *ulist, int,
-            const int *, int mmode)
+            const int *, int mmode, const int *, int)
 {
     if (ntiles <= 0 || mmode == 1) return;
     emul_enqueue(s, [=] { impl::schur_t<impl::zc>(T, nodes, prefix, nn, id_base, ntiles, info, ulist); });

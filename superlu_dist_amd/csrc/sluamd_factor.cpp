@@ -117,12 +117,12 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
         }
     }
     auto schur = [&](hipStream_t st, bool big, int ntile, const int *nodes, const int *prefix, int nn, int id_base,
-                     const int4 *ulist, int prio = 0, const int *tmaps = nullptr, int ksplit = 1) {
+                     const int4 *ulist, int prio = 0, const int *tmaps = nullptr, int ksplit = 1, const int *xoff = nullptr, int xmax = 0) {
         if (H->profile && H->env.profile_dump) H->schur_rec.push_back({cur_level, cur_pass, big ? 1 : 0, ntile, S.max_nsupc[cur_level]});
         if (H->profile) { if (H->ev_schur_big.size() <= H->ev_schur_used) H->ev_schur_big.resize(H->ev_schur_used + 1); H->ev_schur_big[H->ev_schur_used] = big ? 1 : 0; }
         ev_begin(H, H->ev_schur, H->ev_schur_used, st);
-        if (H->z) eng::zschur(st, big ? 0 : 1, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0);     // complex16: k_schur on the real embedding
-        else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0, ksplit);
+        if (H->z) eng::zschur(st, big ? 0 : 1, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0, xoff, xmax);     // complex16: k_schur on the real embedding
+        else eng::schur(st, big ? (H->env.schur_4waves ? 1 : 0) : 2, T, nodes, prefix, nn, id_base, ntile, H->d_info, ulist, prio, tmaps, tmaps ? 2 : 0, ksplit, xoff, xmax);
         ev_end(H, H->ev_schur, H->ev_schur_used, st);
         H->st.num_launches++; H->st.schur_launches++; H->st.schur_tiles += ntile;
     };
@@ -243,7 +243,10 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             const int *tm = S.maps_state == 1 ? S.d_tmaps + S.m_off[2 * l + g] + (int64_t) (u0 - S.u_off[(2 * l + g) * 4]) * eng::schur_rec_ints(g == 0 ? 0 : 2, H->z) : nullptr;
             // the diagonal-block tiles of the next level (part 0, on the panel stream) when they are few: split K over several workgroups per tile
             const int ks = (lookahead && p0 == 0 && p1 == 0 && g == 0 && nu <= 64 && !H->z && !H->env.schur_4waves) ? H->env.ksplit : 1;
-            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, (lookahead && p1 < 3) ? 1 : 0, tm, ks);
+            // a launch of the bulk alone: the XCDs' ranges of equal modelled cost (balance_bulk)
+            const bool bal = p0 == 3 && p1 == 3 && S.d_x_off && !S.x_off.empty() && S.x_off[10 * (size_t) (2 * l + g) + 9] > 0;
+            if (nu) schur(st, g == 0, nu, nullptr, nullptr, 0, 0, S.d_ulist + u0, (lookahead && p1 < 3) ? 1 : 0, tm, ks, bal ? S.d_x_off + 10 * (size_t) (2 * l + g) : nullptr,
+                          bal ? S.x_off[10 * (size_t) (2 * l + g) + 9] : 0);
         }
     };
     // deterministic mode: one supernode per launch over its full tile grid -- tiles of one k hit distinct destinations, the
@@ -279,8 +282,13 @@ static int run_factor_sched(Handle *H, LevelSched &S, double thresh)
             // serial partition (also the measurement harness of the Schur kernel, as in rounds 1-2): one launch per level and
             // tile-size group; only K-fused levels need their level-(l+1) urgent tiles launched apart
             if (H->opt.deterministic) { cur_pass = 3; grid_launch(s, l); }
-            else if (T.defer && S.lvl_defer[l]) { cur_pass = 0; list_launch(s, l, 0, 0); cur_pass = 1; list_launch(s, l, 1, 1); cur_pass = 3; list_launch(s, l, 2, 3); }
-            else { cur_pass = 3; list_launch(s, l, 0, 3); }
+            // (the bulk as its own launch: its XCD ranges are balanced, LevelSched::x_off)
+            else {
+                const bool bal = !S.x_off.empty() && (S.x_off[10 * (size_t) (2 * l) + 9] > 0 || S.x_off[10 * (size_t) (2 * l + 1) + 9] > 0);
+                if (T.defer && S.lvl_defer[l]) { cur_pass = 0; list_launch(s, l, 0, 0); cur_pass = 1; list_launch(s, l, 1, 1); cur_pass = 3; if (bal) { list_launch(s, l, 2, 2); list_launch(s, l, 3, 3); } else list_launch(s, l, 2, 3); }
+                else if (bal) { cur_pass = 3; list_launch(s, l, 0, 2); list_launch(s, l, 3, 3); }
+                else { cur_pass = 3; list_launch(s, l, 0, 3); }
+            }
             if (more) {
                 panelA(l + 1); panelB(l + 1);
                 if (tail_level(l + 1)) deferred_inv(s, l + 1);
@@ -497,6 +505,7 @@ int run_factor(Handle *H, double thresh, int *info)
     HIPCHK(hipStreamSynchronize(H->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, H->ev0, H->ev1));
     H->st.t_factor_ms = ms;
+    if (getenv("SLUAMD_EXP_COUNT")) fprintf(stderr, "[sluamd] K chunks of the Schur tiles (instrumented kernel build only): 128 x 128 clean %d other %d; 64 x 64 clean %d other %d\n", res[4], res[5], res[6], res[7]);
     H->dinv_ready = true; H->inv_ready = !H->env.trsm_panels && !H->z; H->factored = true;
     if (H->profile && H->env.profile_dump && H->schur_rec.size() == H->ev_schur_used)
         for (size_t i = 0; i < H->ev_schur_used; ++i) {

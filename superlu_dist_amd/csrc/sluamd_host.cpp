@@ -72,6 +72,8 @@ void read_env(Handle::Env &e)
     if (const char *v = getenv("SLUAMD_FUSE_MIN_PCT")) e.fuse_min_pct = atoi(v);
     if (const char *v = getenv("SLUAMD_FUSE_MAX_PREV")) e.fuse_max_prev = std::max(1, std::min(3, atoi(v)));
     if (const char *v = getenv("SLUAMD_RESERVE_CUS")) e.reserve_cus = std::max(0, atoi(v));
+    if (const char *v = getenv("SLUAMD_BALANCE_MIN_TILES")) e.balance_min_tiles = std::max(0, atoi(v));
+    if (const char *v = getenv("SLUAMD_BALANCE_OVH")) e.balance_ovh = atof(v);
 }
 
 int trsm_rs(const Handle &H, int nsp) { return (nsp > 128 && H.env.trsm_rs32) ? 32 : 64; }

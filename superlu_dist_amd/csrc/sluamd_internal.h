@@ -213,6 +213,11 @@ struct LevelSched {
     std::vector<int> u_off;         // [8*nlevels+1] offsets into ulist: index (2*level + group) * 4 + part
     std::vector<int64_t> m_off;     // [2*nlevels+1] first int of the tile records of (level, group) in d_tmaps (record of tile u of the group: + (u - u_off[group start]) * rec)
     int *d_tmaps = nullptr;         // per-tile records of k_schur, built on the first factorisation (owned by Handle::d_misc)
+    // Balanced bulk launches (round 6; balance_bulk): k_schur gives XCD x the tiles [x_off[x], x_off[x + 1]) of the launch -- eight contiguous ranges of EQUAL MODELLED COST
+    // (K chunks of all sources x share of the waves that run MFMAs) instead of equal counts; the level's supernodes are listed longest tiles first.
+    // x_off: 10 ints per (level, group) at 10 * (2 * level + group): nine range boundaries relative to the launch's first tile + the longest range; [9] == 0: not balanced
+    std::vector<int> x_off;
+    int *d_x_off = nullptr;
     int maps_state = 0;             // 0: not built yet, 1: built, -1: unavailable (memory / switched off)
     // ---- XY block-cyclic exchange plan (empty on a 1 x 1 layer): per level, in ascending supernode order ----
     std::vector<int> dg_prefix;               // per node (lvl_poff layout): 1024-double chunks of the own diagonal blocks to pack
@@ -317,6 +322,8 @@ struct Handle {
         int z_fuse_max_nodes = 16;   // SLUAMD_ZFUSE_MAX_NODES: complex16 sweeps run the levels of at most this many supernodes as fused links (one launch per level and sweep); 0 = never
         bool info_last = false;      // SLUAMD_INFO_LAST=1: `info` = the zero pivot met LAST on a rank (largest column; what pdgstrf2.c:568-571 leaves in *info), MIN over the ranks (pdgstrf3d.c:388-392); default: the first column
         bool no_tile_maps = false;   // SLUAMD_NO_TILE_MAPS: the Schur tiles chase their tables instead of reading the per-tile records
+        int balance_min_tiles = 1024; // SLUAMD_BALANCE_MIN_TILES: bulk launches of at least this many tiles give the XCDs ranges of equal modelled cost (LevelSched::x_off); 0 = never
+        double balance_ovh = 4.0;    // SLUAMD_BALANCE_OVH: fixed cost of a tile (record, prologue, scatter) in K-chunk periods of the cost model
     } env;
     // device arenas
     double *d_val = nullptr;
@@ -424,7 +431,8 @@ void panel_gemm(hipStream_t s, const DevTables &T, const int *nodes, const int *
                 const int2 *units = nullptr);
 // cfg: 0 = 128x128 tiles / 8 waves, 1 = 128x128 / 4 waves, 2 = 64x64 / 4 waves
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0, int ksplit = 1 /* > 1: that many workgroups per tile, each a share of K (128 x 128 tiles) */);
+           const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0, int ksplit = 1 /* > 1: that many workgroups per tile, each a share of K (128 x 128 tiles) */,
+           const int *xoff = nullptr, int xmax = 0 /* balanced bulk launch: device pointer to the launch's nine XCD range boundaries (LevelSched::x_off) and the longest range */);
 // per-tile records of the list schedules (k_schur): mmode 1 = build pass (writes the records of the launch's tiles at tmaps, no update),
 // mmode 2 = the tiles read their records; ints per record for a tile configuration
 inline int schur_rec_ints(int cfg, bool z) { return (cfg <= 1) ? 64 + 128 + 3 * 128 : 64 + 64 + 3 * 64; (void) z; }
@@ -475,7 +483,7 @@ int mfma_selftest(const double *A, const double *B, double *D);   // host pointe
 void zdiag_lu(hipStream_t s, const DevTables &T, const int *nodes, int nn, int max_nsupc, int replace_tiny, double thresh, int *info);
 void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *lprefix, const int *uprefix, int nn, int nl, int nu, int max_nsupc);
 void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-            const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0);   // cfg 0: tiles of 64 panel rows x 128 columns, else 32 x 64
+            const int4 *ulist = nullptr, int prio = 0, const int *tmaps = nullptr, int mmode = 0, const int *xoff = nullptr, int xmax = 0);   // cfg 0: tiles of 64 panel rows x 128 columns, else 32 x 64
 void zsolve_diag(hipStream_t s, bool lower, const DevTables &T, const int *nodes, int nn, void *x, int64_t ldx, int nrhs, int max_nsupc);
 void zfwd_update(hipStream_t s, const DevTables &T, const int *nodes, const int *prefix, int nn, int nwork, void *x, int64_t ldx, int nrhs,
                  int max_nsupc);

@@ -1197,6 +1197,11 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 #ifndef SLUAMD_EXP_NOLOAD
 #define SLUAMD_EXP_NOLOAD 0
 #endif
+//   SLUAMD_EXP_VALU   N > 0: N extra dependent-free integer VALU instructions per K chunk and wave beside the loader (is ordinary VALU work hidden behind the other
+//                     waves' fp64 MFMAs, or does it add to them?); SLUAMD_EXP_VALU_MID: the same instructions spread between the MFMA groups of the chunk
+#ifndef SLUAMD_EXP_VALU
+#define SLUAMD_EXP_VALU 0
+#endif
 #ifndef SLUAMD_SCHUR_FETCH2
 #define SLUAMD_SCHUR_FETCH2 1     // 0: the loader of rounds 1-5 (kept for the same-box A/B)
 #endif
@@ -1204,6 +1209,23 @@ __device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, 
 #ifndef SLUAMD_SCHUR_FETCH3
 #define SLUAMD_SCHUR_FETCH3 1     // the loader in 16-byte loads (two tile rows of one panel column / two k of one U column per lane): half the load instructions,
 #endif                            // map reads and predicates of SLUAMD_SCHUR_FETCH2; 0: that loader
+// raw buffer loads: address = 48-bit base of a wave-uniform resource descriptor (4 SGPRs) + 32-bit per-lane byte offset (VGPR) + 32-bit wave-uniform byte offset
+// (SGPR): no 64-bit vector arithmetic in front of the load
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ i32x4 llvm_amdgcn_raw_buffer_load_i32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+__device__ __forceinline__ i32x4 buffer_rsrc(const void *p)     // p wave-uniform; unbounded raw buffer (stride 0)
+{
+    const uint64_t v = (uint64_t) p;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int) (uint32_t) v);
+    r.y = __builtin_amdgcn_readfirstlane((int) ((uint32_t) (v >> 32) & 0xFFFFu));
+    r.z = (int) 0xFFFFFFFFu;
+    r.w = 0x00020000;
+    return r;
+}
+#ifndef SLUAMD_SCHUR_CLEAN
+#define SLUAMD_SCHUR_CLEAN 1      // the predicate-free loader for clean sources (see `clean` in k_schur); 0: fetch3 / stash3 everywhere (same-box A/B)
+#endif
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef const d2 __attribute__((address_space(1), aligned(8))) *gd2_t;      // (the pairs are 8-byte aligned only: panel leading dimensions and segment offsets are arbitrary)
 typedef const char __attribute__((address_space(1))) *gbytes_t;     // (global address space kept through the integer round trip: global_load, not flat_load)
@@ -1233,7 +1255,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
                                                                     const int *__restrict__ prefix, int nn, int id_base,
                                                                     int ntiles, int *__restrict__ info,
                                                                     const int4 *__restrict__ ulist, int prio,
-                                                                    const int *__restrict__ tmaps)
+                                                                    const int *__restrict__ tmaps, const int *__restrict__ xoff)
 {
     constexpr int LDL = TMv + 16;   // == 16 mod 32 doubles: conflict-free ds_read_b64 fragment reads
     constexpr int LDU = TNv + 17;   // odd: the k-major U stash (16 lanes x stride LDU) spreads over all banks too
@@ -1266,8 +1288,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     const int tid = threadIdx.x;
     // XCD-aware mapping: workgroup b runs on XCD b%8; give every XCD a contiguous range of tiles so that the
     // row tile (L rows) shared by consecutive tiles stays in ONE XCD's L2
+    // (xoff, balanced bulk launches: the eight ranges have equal modelled COST instead of equal counts -- boundaries from the planner, balance_bulk)
     int bid;
-    {
+    if (xoff) {
+        const int x = blockIdx.x & 7;
+        const int b0 = xoff[x], b1 = xoff[x + 1];
+        bid = b0 + (int) (blockIdx.x >> 3);
+        if (bid >= b1) return;
+        bid += id_base;
+    } else {
         const int chunk = (ntiles + 7) >> 3;
         bid = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
         if ((blockIdx.x >> 3) >= chunk || bid >= ntiles) return;
@@ -1527,9 +1556,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     bool lon[F3 ? LQ3 : 1];                       // per L load: its panel column lies inside the source
     uint32_t lvo3 = (uint32_t) (2 * li2 + lk3 * lda) << 3;
     // (two rows that both exist in a predecessor's panel are neighbours there: the planner only fuses pairs whose row map is monotone, build_pair_maps)
+    bool rows_ok3 = true;                         // this thread's pair of tile rows is one 16-byte run of the source panel (or lies outside the tile): see `clean`
     auto l3_source = [&](int ra0, int ra1, int ldas) {
         l_has0 = ra0 >= 0; l_has1 = ra1 >= 0;
         lvo3 = (uint32_t) ((l_has0 ? ra0 : max(ra1, 0)) + lk3 * ldas) << 3;
+        const bool p0 = 2 * li2 < nr, p1 = 2 * li2 + 1 < nr;
+        rows_ok3 = !p0 || (l_has0 && (!p1 || ra1 == ra0 + 1));
     };
     // Every load is UNCONDITIONAL (a lane with nothing to fetch reads the first 16 bytes of the source instead): no exec-mask branches, no zero initialisation of
     // the destination registers -- which the compiler guards with s_waitcnt vmcnt(0), i.e. with the arrival of the loads issued just before
@@ -1567,6 +1599,67 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             const double y0 = un0[q] ? wu[q].x : 0.0, y1 = un1[q] ? (un0[q] ? wu[q].y : wu[q].x) : 0.0;
             Us[buf][(2 * uk2) * LDU + uj3 + UJS3 * q] = y0;
             Us[buf][(2 * uk2 + 1) * LDU + uj3 + UJS3 * q] = y1;
+        }
+    };
+
+    // ---- the CLEAN form of the loader (round 6, profiles/r06_ab_valu_additive.txt) ----
+    // On this device the fp64 MFMA runs at the vector ALU's rate and SHARES it: every ordinary VALU instruction of a wave adds its cycles to the MFMA time of its
+    // SIMD instead of hiding behind the other waves' MFMAs (32 / 96 extra v_add_u32 per chunk and wave: +7.4 / +20.5 ms on the 247 ms of all Schur launches = 0.22 ms
+    // per instruction).  The loader above is ~80 VALU instructions per chunk (predicates, selects, 64-bit address arithmetic).  A source is CLEAN for a tile when no
+    // column of the tile has leading zeros inside the source's K range and every pair of tile rows is one 16-byte run of its panel (always true for the tile's own
+    // supernode; for a K-fused predecessor: all rows present -- chains inside one separator): its FULL chunks then need no predicate at all -- per-thread byte
+    // offsets fixed per source, the chunk's advance in the wave-uniform (SGPR) base, plain stores into the stage.  Rows >= nr / columns >= nc of a ragged tile hold
+    // whatever their (valid) addresses hold: they only reach accumulators that are never scattered.  Partial chunks and unclean sources take fetch3 / stash3.
+    bool clean = false;
+    uint32_t uvoc[F3 ? UQ3 : 1];                 // per U load: byte offset of (column, first k of this thread's pair) from the source's U base at k = kbeg0
+    int kbeg0 = 0;
+    bool cur_fast = false;                       // the chunk in the registers was fetched by fetch_clean
+    i32x4 rsL = {0, 0, 0, 0}, rsU = {0, 0, 0, 0};     // resource descriptors of the current source's panel / U row block (SGPRs; set by source_clean)
+    auto source_clean = [&](int kb, bool rows_ok) {
+        int ok = rows_ok ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) {
+            const int c = uj3 + UJS3 * q;
+            const int ld = ldS[c], cp = cpS[c];
+            if (c < nc && ld > kb) ok = 0;
+            uvoc[q] = (c < nc) ? (uint32_t) (cp - ld + kb + 2 * uk2) << 3 : (uint32_t) (2 * uk2) << 3;
+        }
+        kbeg0 = kb;
+        clean = __syncthreads_and(ok) != 0;
+        // (32-bit offsets: a panel / a U row block is far below 4 GB -- 300^3: 9e4 rows x 256 columns x 8 bytes)
+        if (clean) { rsL = buffer_rsrc(Lsrc); rsU = buffer_rsrc(Uvs); }
+    };
+    auto fetch_clean = [&](int k0) {
+#ifdef SLUAMD_EXP_NOWAIT      // (instrumented build: the loads are issued, their data is never waited for at the stash -- it is "used" here, a whole chunk later; the stage gets constants)
+#pragma unroll
+        for (int q = 0; q < LQ3; ++q) asm volatile("" :: "v"(wl[q]));
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) asm volatile("" :: "v"(wu[q]));
+#endif
+#pragma unroll
+        for (int q = 0; q < LQ3; ++q)
+            wl[q] = __builtin_bit_cast(d2, llvm_amdgcn_raw_buffer_load_i32x4(rsL, (int) lvo3, (int) ((uint32_t) (k0 + LKS3 * q) * (uint32_t) lda_s << 3), 0));
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) wu[q] = __builtin_bit_cast(d2, llvm_amdgcn_raw_buffer_load_i32x4(rsU, (int) uvoc[q], (int) ((uint32_t) (k0 - kbeg0) << 3), 0));
+    };
+    auto stash_clean = [&](int buf) {
+#ifdef SLUAMD_EXP_NOWAIT
+        const d2 cst = {1.0 + 1e-9 * tid, 1.0 - 1e-9 * tid};
+#pragma unroll
+        for (int q = 0; q < LQ3; ++q) *(d2 *) &Ls[buf][(lk3 + LKS3 * q) * LDL + 2 * li2] = cst;
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) {
+            Us[buf][(2 * uk2) * LDU + uj3 + UJS3 * q] = cst.x;
+            Us[buf][(2 * uk2 + 1) * LDU + uj3 + UJS3 * q] = cst.y;
+        }
+        return;
+#endif
+#pragma unroll
+        for (int q = 0; q < LQ3; ++q) *(d2 *) &Ls[buf][(lk3 + LKS3 * q) * LDL + 2 * li2] = wl[q];
+#pragma unroll
+        for (int q = 0; q < UQ3; ++q) {
+            Us[buf][(2 * uk2) * LDU + uj3 + UJS3 * q] = wu[q].x;
+            Us[buf][(2 * uk2 + 1) * LDU + uj3 + UJS3 * q] = wu[q].y;
         }
     };
 
@@ -1637,10 +1730,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
 #pragma unroll
         for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + UJS * q] = pu[q];
     };
-    auto fetch = [&](int k0, bool restart = false) { if (F3 && !SLUAMD_EXP_NOLOAD) fetch3(k0); else fetch_into(pl, pu, k0, restart); };
-    auto stash = [&](int buf) { if (F3 && !SLUAMD_EXP_NOLOAD) stash3(buf); else stash_from(pl, pu, buf); };
+    int kend_cur = 0;                            // end of the current source's K range (this workgroup's share of it)
+#ifdef SLUAMD_EXP_COUNT
+    int cnt_fast = 0, cnt_slow = 0;
+#endif
+    auto fetch = [&](int k0, bool restart = false) {
+        if (F3 && !SLUAMD_EXP_NOLOAD) {
+            cur_fast = SLUAMD_SCHUR_CLEAN && clean && k0 + KC <= kend_cur;       // workgroup-uniform
+#ifdef SLUAMD_EXP_COUNT
+            if (cur_fast) ++cnt_fast; else ++cnt_slow;
+#endif
+            if (cur_fast) fetch_clean(k0); else fetch3(k0);
+        } else fetch_into(pl, pu, k0, restart);
+    };
+    auto stash = [&](int buf) {
+        if (F3 && !SLUAMD_EXP_NOLOAD) { if (cur_fast) stash_clean(buf); else stash3(buf); }
+        else stash_from(pl, pu, buf);
+    };
 
     int buf = 0;
+#if SLUAMD_EXP_VALU
+    int dummy0 = tid, dummy1 = tid + 1, dummy2 = tid + 2, dummy3 = tid + 3;
+#endif
     for (int src = 0; src <= nprev; ++src) {       // farthest predecessor first, k itself last
         int kbeg;
         if (MM == 2 && src < nprev) {
@@ -1655,12 +1766,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
                 s_lead2[t] = (t < nc) ? cinfo[2 * t + 1] : nss;
             }
             __syncthreads();
-            ns_s = nss; lda_s = ph[1];
+            ns_s = __builtin_amdgcn_readfirstlane(nss); lda_s = __builtin_amdgcn_readfirstlane(ph[1]);
             Lsrc = T.val + (((int64_t) ph[4] << 32) | (uint32_t) ph[3]); lvo = (uint32_t) (max(ra, 0) + lk * lda_s) << 3;
             if (F3) l3_source(2 * li2 < nr ? T.pair_rowmap[ro + 2 * li2] : -1, 2 * li2 + 1 < nr ? T.pair_rowmap[ro + 2 * li2 + 1] : -1, lda_s);
             Lrow = T.val + (((int64_t) ph[4] << 32) | (uint32_t) ph[3]) + max(ra, 0);
             Uvs = T.val + (((int64_t) ph[6] << 32) | (uint32_t) ph[5]);
-            kbeg = ph[2]; lrow_ok = ra >= 0;
+            kbeg = __builtin_amdgcn_readfirstlane(ph[2]); lrow_ok = ra >= 0;
             cpS = s_cptr2; ldS = s_lead2;
         } else if (src < nprev) {
             const int pj = 3 * k + (nprev - 1 - src);
@@ -1673,18 +1784,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
                 s_lead2[t] = (t < nc) ? cinfo[2 * t + 1] : nss;
             }
             __syncthreads();
-            ns_s = nss; lda_s = T.sn_nsupr[ks]; Lrow = T.val + T.sn_lval[ks] + max(ra, 0); Uvs = T.val + T.sn_uval[ks];
+            ns_s = __builtin_amdgcn_readfirstlane(nss); lda_s = __builtin_amdgcn_readfirstlane(T.sn_nsupr[ks]); Lrow = T.val + T.sn_lval[ks] + max(ra, 0); Uvs = T.val + T.sn_uval[ks];
             Lsrc = T.val + T.sn_lval[ks]; lvo = (uint32_t) (max(ra, 0) + lk * lda_s) << 3;
             if (F3) { const int64_t ro = (int64_t) T.pair_roff[pj] + Rw; l3_source(2 * li2 < nr ? T.pair_rowmap[ro + 2 * li2] : -1, 2 * li2 + 1 < nr ? T.pair_rowmap[ro + 2 * li2 + 1] : -1, lda_s); }
-            kbeg = (nss - T.sn_ldu[ks]) & ~3; lrow_ok = ra >= 0;
+            kbeg = __builtin_amdgcn_readfirstlane((nss - T.sn_ldu[ks]) & ~3); lrow_ok = ra >= 0;
             cpS = s_cptr2; ldS = s_lead2;
         } else {
-            ns_s = ZS * ns; lda_s = lda; Lrow = Lp + lrow0; Uvs = Uv; lrow_ok = li < nr;
+            ns_s = __builtin_amdgcn_readfirstlane(ZS * ns); lda_s = __builtin_amdgcn_readfirstlane(lda); Lrow = Lp + lrow0; Uvs = Uv; lrow_ok = li < nr;
             Lsrc = Lp; lvo = (uint32_t) (lrow0 + lk * lda) << 3;
             if (F3) l3_source(2 * li2 < nr ? 2 * li2 : -1, 2 * li2 + 1 < nr ? 2 * li2 + 1 : -1, lda);
-            kbeg = kbeg_own;
+            kbeg = __builtin_amdgcn_readfirstlane(kbeg_own);
             cpS = s_cptr; ldS = s_lead;
         }
+        if (F3 && SLUAMD_SCHUR_CLEAN) source_clean(kbeg, rows_ok3);
         int kend = ns_s;
         if (SK) {   // this workgroup's share of the source's chunks
             const int nch = (ns_s - kbeg + KC - 1) / KC;
@@ -1693,6 +1805,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             if (kbeg >= kend) continue;
         }
         // chunk at which the destination lines are touched: the one before the last chunk of the last source
+        kend_cur = kend;
         const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((kend - 1 - kbeg) / KC - 1) * KC) : -1;
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
         fetch(kbeg, true);
@@ -1701,6 +1814,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         for (int k0 = kbeg; k0 < kend; k0 += KC) {
             const bool more = k0 + KC < kend;
             if (more) fetch(k0 + KC);
+#if SLUAMD_EXP_VALU
+#pragma unroll
+            for (int e = 0; e < SLUAMD_EXP_VALU / 4; ++e)
+                asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, %2, %3\n\tv_add_u32 %3, %3, %0" : "+v"(dummy0), "+v"(dummy1), "+v"(dummy2), "+v"(dummy3));
+#endif
             if (k0 == ktouch) {
                 // one chunk before the last: touch one element of every destination line (16 rows x 1 column of the tile) so
                 // that the fp64 atomics of the epilogue find their lines in L2 instead of each holding an L2 miss slot
@@ -1719,6 +1837,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     }
 
     // ---- scatter (epilogue) ----------------------------------------------------------------------
+#ifdef SLUAMD_EXP_COUNT
+    if (tid == 0 && TMv == 128) { atomicAdd(&info[4], cnt_fast); atomicAdd(&info[5], cnt_slow); }
+    if (tid == 0 && TMv == 64) { atomicAdd(&info[6], cnt_fast); atomicAdd(&info[7], cnt_slow); }
+#endif
+#if SLUAMD_EXP_VALU
+    if (__builtin_expect((dummy0 ^ dummy1 ^ dummy2 ^ dummy3) == 0x7fffffff && tid == 777, 0)) atomicAdd(&info[3], 1);
+#endif
     if (!has_dst) return;
     if (__builtin_expect(touch0 == 1.2345e-300 && touch1 == 1.2345e-300, 0)) atomicAdd(&info[3], 1);   // keeps the touch loads alive
 #if SLUAMD_EXP_EPI == 0
@@ -2556,18 +2681,19 @@ void panel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int *
 
 #define SCHUR_LAUNCH(TM, TN, NWV, ZV, THREADS) \
     do { \
-        if (mmode == 2) hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 2>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps); \
-        else if (mmode == 1) hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 1>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps); \
-        else hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 0>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps); \
+        if (mmode == 2) hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 2>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps, xoff); \
+        else if (mmode == 1) hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 1>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps, xoff); \
+        else hipLaunchKernelGGL((k_schur<TM, TN, NWV, ZV, 0>), dim3(grid), dim3(THREADS), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps, xoff); \
     } while (0)
 void schur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-           const int4 *ulist, int prio, const int *tmaps, int mmode, int ksplit)
+           const int4 *ulist, int prio, const int *tmaps, int mmode, int ksplit, const int *xoff, int xmax)
 {
     if (ntiles <= 0) return;
-    const int grid = ((ntiles + 7) / 8) * 8;
+    if (!xoff || xmax <= 0 || ksplit > 1) xoff = nullptr;
+    const int grid = xoff ? 8 * xmax : ((ntiles + 7) / 8) * 8;
     if (ksplit > 1 && cfg == 0 && mmode != 1) {   // split-K form of the 128 x 128 configuration (chain tiles)
-        if (mmode == 2) hipLaunchKernelGGL((k_schur<128, 128, 8, false, 2, true>), dim3(grid, ksplit), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps);
-        else hipLaunchKernelGGL((k_schur<128, 128, 8, false, 0, true>), dim3(grid, ksplit), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps);
+        if (mmode == 2) hipLaunchKernelGGL((k_schur<128, 128, 8, false, 2, true>), dim3(grid, ksplit), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps, nullptr);
+        else hipLaunchKernelGGL((k_schur<128, 128, 8, false, 0, true>), dim3(grid, ksplit), dim3(512), 0, s, T, nodes, prefix, nn, id_base, ntiles, info, ulist, prio, tmaps, nullptr);
         return;
     }
     if (cfg == 0) SCHUR_LAUNCH(128, 128, 8, false, 512);
@@ -2940,11 +3066,12 @@ void zpanel_trsm(hipStream_t s, const DevTables &T, const int *nodes, const int 
     else hipLaunchKernelGGL(kz_panel_trsm, dim3(nl + nu), dim3(64), 0, s, T, nodes, lprefix, uprefix, nn, nl);
 }
 void zschur(hipStream_t s, int cfg, const DevTables &T, const int *nodes, const int *prefix, int nn, int id_base, int ntiles, int *info,
-            const int4 *ulist, int prio, const int *tmaps, int mmode)
+            const int4 *ulist, int prio, const int *tmaps, int mmode, const int *xoff, int xmax)
 {
     // the real kernel on the real embedding: tiles of 64 panel rows x 128 columns (cfg 0) / 32 x 64
     if (ntiles <= 0) return;
-    const int grid = ((ntiles + 7) / 8) * 8;
+    if (!xoff || xmax <= 0) xoff = nullptr;
+    const int grid = xoff ? 8 * xmax : ((ntiles + 7) / 8) * 8;
     if (cfg == 0) SCHUR_LAUNCH(128, 128, 8, true, 512);
     else SCHUR_LAUNCH(64, 64, 4, true, 256);
 }

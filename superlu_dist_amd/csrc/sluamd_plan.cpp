@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <queue>
+#include <functional>
 #include <cmath>
 #include "sluamd_comm.h"
 #include "sluamd_plan.h"
@@ -595,6 +597,107 @@ static void build_tile_lists(const HostTables &t, const std::vector<int> &lvl, c
                     dbg_exact[g] > 0 ? dbg_full[g] / dbg_exact[g] : 0.0);
 }
 
+// Modelled cost of one Schur tile in K-chunk periods: the chunks of all its sources (the K-fused predecessors run in the same tile) x the share of its waves that run
+// MFMAs (a wave whose part of a ragged tile is empty skips them: k_schur `wave_on`; the loader and the barriers stay) + a fixed part (record, prologue, scatter).
+static inline double tile_cost(const Handle &H, const HostTables &t, const int4 &u, int g, double ovh)
+{
+    const auto &hs = H.hs;
+    auto chunks_of = [&](int s) { const int nss = hs.xsup[s + 1] - hs.xsup[s]; const int kb = (nss - t.sn_ldu[s]) & ~3; return (nss - kb + KC - 1) / KC; };
+    const int k = u.x, nr = t.rtile[u.y].z * (H.z ? 2 : 1), nc = t.ctile[u.z].z;
+    int ch = chunks_of(k);
+    if (!H.h_fuse_prev.empty())
+        for (int j = 0; j < 3 && H.h_fuse_prev[3 * (size_t) k + j] >= 0; ++j) ch += chunks_of(H.h_fuse_prev[3 * (size_t) k + j]);
+    const double frac = g == 0 ? ((nr + 31) / 32) * ((nc + 63) / 64) / 8.0 : ((nr + 31) / 32) * ((nc + 31) / 32) / 4.0;
+    return ovh + ch * (0.35 + 0.65 * std::min(frac, 1.0));
+}
+
+// Balanced bulk launches (LevelSched::x_off).  k_schur gives every XCD one contiguous range of a launch's tile list (the 8 x 8 bands of a range share their L row
+// tiles and U column tiles in that XCD's L2) and the hardware hands an XCD's workgroups to its free slots in list order.  With ranges of equal COUNT the launch
+// ends with its slowest XCD: where a level mixes K-fused groups (tiles of 2-3 sources) with plain supernodes, or wide with ragged tiles, the busiest eighth
+// is 4-15 % above the mean (SLUAMD_PLAN_BALANCE: 100^3, levels 11 / 14 / 19 / 29 / 39).  Here: the supernodes of a bulk list are ordered longest tiles first
+// (their order inside a level is free: the scatter is atomic) and the list is cut into eight ranges of equal modelled cost; a range's tail then holds its shortest tiles.
+static void balance_bulk(const Handle &H, const HostTables &t, LevelSched &S)
+{
+    S.x_off.assign(20 * (size_t) S.nlevels, 0);
+    if (H.env.balance_min_tiles <= 0 || H.opt.deterministic) return;
+    struct Seg { int a, n; double c; };
+    std::vector<Seg> segs;
+    std::vector<int4> tmp;
+    std::vector<double> pre;
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int g = 0; g < 2; ++g) {
+            const int u0 = S.u_off[(2 * l + g) * 4 + 3], n = S.u_off[(2 * l + g) * 4 + 4] - u0;
+            if (n < H.env.balance_min_tiles) continue;
+            // the supernodes' runs, longest tiles first (stable: equal ones keep the schedule order)
+            segs.clear();
+            for (int i = 0; i < n;) {
+                int j = i;
+                while (j < n && S.ulist[u0 + j].x == S.ulist[u0 + i].x) ++j;
+                int4 full = S.ulist[u0 + i];
+                segs.push_back({i, j - i, tile_cost(H, t, full, g, 0.0)});     // (the first tile of a run: the K of the run; its ragged tiles are priced below)
+                i = j;
+            }
+            std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.c > y.c; });
+            tmp.clear(); tmp.reserve(n);
+            for (const Seg &sg : segs) tmp.insert(tmp.end(), S.ulist.begin() + u0 + sg.a, S.ulist.begin() + u0 + sg.a + sg.n);
+            std::copy(tmp.begin(), tmp.end(), S.ulist.begin() + u0);
+            pre.assign(n + 1, 0.0);
+            for (int i = 0; i < n; ++i) pre[i + 1] = pre[i] + tile_cost(H, t, S.ulist[u0 + i], g, H.env.balance_ovh);
+            int *xo = S.x_off.data() + 10 * (size_t) (2 * l + g);
+            xo[0] = 0; xo[8] = n;
+            for (int x = 1; x < 8; ++x) {
+                const double want = pre[n] * x / 8.0;
+                int pos = (int) (std::lower_bound(pre.begin(), pre.end(), want) - pre.begin());
+                if (pos > 0 && want - pre[pos - 1] < pre[pos] - want) --pos;         // the nearer boundary
+                xo[x] = std::max(xo[x - 1], std::min(n, pos));
+            }
+            int mx = 0;
+            for (int x = 0; x < 8; ++x) mx = std::max(mx, xo[x + 1] - xo[x]);
+            xo[9] = mx;
+        }
+}
+
+// SLUAMD_PLAN_BALANCE (diagnostic, plan time, CPU build too): how evenly the bulk tile lists fill the device -- per bulk launch the modelled makespan (greedy
+// in-order list scheduling of every XCD's range on its slots) against the same work spread perfectly.
+static void report_balance(const Handle &H, const HostTables &t, const LevelSched &S)
+{
+    const double ovh = H.env.balance_ovh;
+    double tot_ideal[2] = {0, 0}, tot_xcd[2] = {0, 0}, tot_sim[2] = {0, 0};
+    int nlaunch[2] = {0, 0}, nbal[2] = {0, 0};
+    std::vector<double> cost;
+    for (int l = 0; l < S.nlevels; ++l)
+        for (int g = 0; g < 2; ++g) {
+            const int u0 = S.u_off[(2 * l + g) * 4 + 3], u1 = S.u_off[(2 * l + g) * 4 + 4];
+            const int n = u1 - u0;
+            if (n <= 0) continue;
+            const int slots = g == 0 ? 64 : 160;
+            cost.resize(n);
+            for (int i = 0; i < n; ++i) cost[i] = tile_cost(H, t, S.ulist[u0 + i], g, ovh);
+            const int *xo = S.x_off.empty() ? nullptr : S.x_off.data() + 10 * (size_t) (2 * l + g);
+            const bool bal = xo && xo[9] > 0;
+            const int chunk = (n + 7) >> 3;
+            double sum = 0, mx_x = 0, mk = 0;
+            for (int x = 0; x < 8; ++x) {
+                const int a = bal ? xo[x] : std::min(n, x * chunk), b = bal ? xo[x + 1] : std::min(n, (x + 1) * chunk);
+                double sx = 0;
+                std::priority_queue<double, std::vector<double>, std::greater<double>> q;
+                for (int s2 = 0; s2 < slots; ++s2) q.push(0.0);
+                double end = 0;
+                for (int i = a; i < b; ++i) { sx += cost[i]; const double st = q.top(); q.pop(); q.push(st + cost[i]); end = std::max(end, st + cost[i]); }
+                sum += sx; mx_x = std::max(mx_x, sx / slots); mk = std::max(mk, end);
+            }
+            const double ideal = sum / (8.0 * slots);
+            tot_ideal[g] += ideal; tot_xcd[g] += mx_x; tot_sim[g] += mk; nlaunch[g] += 1; nbal[g] += bal;
+            if (getenv("SLUAMD_PLAN_BALANCE_V"))
+                fprintf(stderr, "[balance] level %3d %s%s: %6d tiles, ideal %8.1f, busiest XCD %8.1f (%.3f), in-order makespan %8.1f (%.3f)\n", l, g ? "64" : "128", bal ? " balanced" : "", n, ideal,
+                        mx_x, mx_x / ideal, mk, mk / ideal);
+        }
+    for (int g = 0; g < 2; ++g)
+        if (nlaunch[g])
+            fprintf(stderr, "[balance] %s x %s bulk launches: %d (%d balanced), sum of ideal spans %.0f chunk periods, busiest-XCD spans %.0f (%.3f x), in-order makespans %.0f (%.3f x)\n",
+                    g ? "64" : "128", g ? "64" : "128", nlaunch[g], nbal[g], tot_ideal[g], tot_xcd[g], tot_xcd[g] / tot_ideal[g], tot_sim[g], tot_sim[g] / tot_ideal[g]);
+}
+
 // Split panel solves (LevelSched::ps_units): per level the strips of L(:, k) / chunks of U(k, :) its part-0 tiles read.  Derived from the tile lists
 // themselves -- merged row / column tiles run across block boundaries, so "the rows of the blocks whose supernode is in the next level" would miss rows.
 // Levels that are split: 1 x 1 layers, real arithmetic, 64-high units, not the first level (its panels are solved before the loop) nor the last (no
@@ -817,6 +920,8 @@ static void build_schedule(Handle &H, const HostTables &t, const std::vector<int
     H.setup.lap("sched.fused_pair_maps");
     build_tile_lists(t, lvl, H.h_defer, S, H.z);
     H.setup.lap("sched.tile_lists");
+    balance_bulk(H, t, S);
+    if (getenv("SLUAMD_PLAN_BALANCE")) report_balance(H, t, S);
     build_panel_split(H, t, S);
     // by-configuration accounting: a supernode's Schur flops run in ITS tile configuration, except a deferred (K-fused) one's, whose update is applied by
     // the tiles of the first non-deferred successor of its chain (the few urgent tiles it runs itself are counted there too)
@@ -1140,6 +1245,7 @@ static int upload_schedule(Handle &H, LevelSched &S, const HostTables &t)
     if (upload(H.d_misc, S.zltr_prefix, &S.d_zltr_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.sn_level, &S.d_sn_level)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.ulist, &S.d_ulist)) return SLUAMD_EHIP;
+    if (upload(H.d_misc, S.x_off, &S.d_x_off)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.dg_prefix, &S.d_dg_prefix)) return SLUAMD_EHIP;
     if (upload(H.d_misc, S.zfwd_prefix, &S.d_zfwd_prefix)) return SLUAMD_EHIP;
     if (H.z && (upload(H.d_misc, S.zffu_prefix, &S.d_zffu_prefix) || upload(H.d_misc, S.zbfu_prefix, &S.d_zbfu_prefix))) return SLUAMD_EHIP;
