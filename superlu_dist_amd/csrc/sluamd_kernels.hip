@@ -1169,17 +1169,21 @@ __global__ __launch_bounds__(256) void k_rfs_update(int n, const int *__restrict
 // (everything else).  Software pipeline: the next K chunk is fetched from HBM/L2 into registers while the
 // MFMAs of the current chunk run out of the other LDS buffer (one barrier per chunk).
 // the MFMAs of one K chunk for a wave that owns RA x CA 16 x 16 blocks
-template <int RA, int CA, int LDL, int LDU>
-__device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, int rm0, int cn0, int lane, d4 (&acc)[CA][RA])
+typedef const volatile double __attribute__((address_space(3))) *lds_vdouble_t;
+// USW: the U stage in the swizzled column-major form (see k_schur): `pa` is the lane's index for k4 = 0, column block 0
+template <int RA, int CA, int LDL, int LDU, bool USW>
+__device__ __forceinline__ void schur_chunk(const double *Lb, const double *Ub, int rm0, int cn0, int lane, d4 (&acc)[CA][RA], int pa)
 {
 #pragma unroll
     for (int k4 = 0; k4 < KC; k4 += 4) {
         const int kr = k4 + (lane >> 4);
         double a[CA], b[RA];
 #pragma unroll
-        for (int c = 0; c < CA; ++c) a[c] = Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
+        for (int c = 0; c < CA; ++c) a[c] = USW ? ((lds_vdouble_t) Ub)[(pa ^ k4) + 256 * c] : Ub[kr * LDU + cn0 + 16 * c + (lane & 15)];
+        // (volatile: single ds_read_b64 -- two lane groups of 32 over 64 banks, 2 LDS cycles -- instead of the merged ds_read2[st64]_b64, whose 16-lane groups over 32
+        //  banks take 8 cycles and see the swizzled columns 2-way conflicted)
 #pragma unroll
-        for (int r = 0; r < RA; ++r) b[r] = Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
+        for (int r = 0; r < RA; ++r) b[r] = USW ? ((lds_vdouble_t) Lb)[kr * LDL + rm0 + 16 * r + (lane & 15)] : Lb[kr * LDL + rm0 + 16 * r + (lane & 15)];
 #pragma unroll
         for (int c = 0; c < CA; ++c)
 #pragma unroll
@@ -1223,6 +1227,29 @@ __device__ __forceinline__ i32x4 buffer_rsrc(const void *p)     // p wave-unifor
     r.w = 0x00020000;
     return r;
 }
+// ... and straight into LDS (LDS-DMA): the wave's 64 x 16 bytes land at the wave-uniform LDS address (M0) + lane * 16, no VGPR on the way.  As an asm statement:
+// behind the intrinsic (llvm.amdgcn.raw.buffer.load.lds) hipcc waits vmcnt(0) in front of the NEXT LDS read -- the prefetch of the next chunk would be
+// drained before the MFMAs of the current one start.  The statement's loads are outside the compiler's vmcnt bookkeeping: lds_dma_wait() before the barrier that
+// publishes the stage (the counter is in order: untracked loads can only make the compiler's own waits longer, never too short).
+__device__ __forceinline__ void lds_dma_16(i32x4 rsrc, uint32_t lds_byte, int voffset, int soffset)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voffset), "s"(rsrc), "s"(soffset), "s"(lds_byte) : "memory");
+}
+#ifdef SLUAMD_EXP_NODMAWAIT      // (instrumented build: nobody waits for the LDS-DMA loads -- wrong factors, timing only)
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("" ::: "memory"); }
+#else
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+__device__ __forceinline__ uint32_t lds_byte_addr(const void *p) { return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const void *) p; }
+#ifndef SLUAMD_SCHUR_TOUCH
+#define SLUAMD_SCHUR_TOUCH 0      // 1: one chunk before the last, a tile touches its destination lines (rounds 2-5; at the 128-VGPR cap of the round-6 kernel the two touched
+                                  // values are spilled, i.e. waited for at once: 265.6 ms); 2: the touch as loads into an LDS sink (262.2 ms); 0: none (259.6 ms, profiles/r06_ab_dma_loader.txt)
+#endif
+#ifndef SLUAMD_SCHUR_DMA
+#define SLUAMD_SCHUR_DMA 1        // clean sources of the 128-row tile configurations load their chunks straight into the LDS stage; 0: through registers (same-box A/B)
+#endif
 #ifndef SLUAMD_SCHUR_CLEAN
 #define SLUAMD_SCHUR_CLEAN 1      // the predicate-free loader for clean sources (see `clean` in k_schur); 0: fetch3 / stash3 everywhere (same-box A/B)
 #endif
@@ -1271,7 +1298,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     // life is dependent index loads -- trade the second stage for occupancy: 24 KB instead of 44 KB per workgroup
     constexpr int NBUF = (TMv == 64 && SCHUR64_WGS > 4) ? 1 : 2;
     __shared__ double Ls[NBUF][KC * LDL];
-    __shared__ double Us[NBUF][KC * LDU];
+    // U stage.  USW (the 16-byte loader, real arithmetic): column-major in 16-byte slots -- column c, k pair kp at doubles c * 16 + 2 * (kp ^ ((c >> 1) & 7)) -- so that a
+    // thread's loaded pair (two k of one column) is ONE 16-byte store, a wave's 64 pairs (8 columns x 8 pairs) are 1 KiB in lane order (what a load straight into
+    // LDS writes), and the MFMA fragment reads (16 lanes = 16 columns of one k) fall on 16 different slots of a 256-byte window (the XOR); otherwise k-major, padded
+    constexpr bool USW = SLUAMD_SCHUR_FETCH3 && !Z;
+    __shared__ __attribute__((aligned(16))) double Us[NBUF][USW ? KC * TNv : KC * LDU];
+    auto uidx = [](int k, int c) { return USW ? c * 16 + ((((k >> 1) ^ ((c >> 1) & 7)) << 1) | (k & 1)) : k * LDU + c; };
     __shared__ int s_ind[256 + 8];
     __shared__ int s_rowmap[TMv];
     __shared__ int s_colmap[TNv];
@@ -1281,6 +1313,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     __shared__ int s_lead2[TNv];
     __shared__ int s_jj[TNv];     // column id inside supernode jb
     __shared__ int s_dinfo[1];
+    __shared__ int s_sink[(SLUAMD_SCHUR_TOUCH == 2 && TMv == 128) ? NW * 64 : 1];     // destination of the touch loads of the LDS-DMA configurations
     constexpr int HDR = 64;                          // header ints of a tile record: [0,16) the tile itself, [16] number of K-fused predecessors, [17 + 11 j, 28 + 11 j) predecessor j (nearest first)
     __shared__ int s_hdr[HDR];
     constexpr int REC = HDR + TMv + 3 * TNv;         // ints per tile record (MM 1 / 2)
@@ -1520,6 +1553,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     // different SIMDs (wave w runs on SIMD w % 4).
     const int rm0 = ((wave + bid) % WR) * (TMv / WR), cn0 = (wave / WR) * (TNv / WC);
     const bool wave_on = rm0 < nr && cn0 < nc;
+    // the lane's index into the swizzled U stage for the k group 0 and its first column block (schur_chunk: ^ k4, + 256 per block of 16 columns)
+    const int pa = uidx(lane >> 4, cn0 + (lane & 15));
     d4 acc[NBC][NBR];
 #pragma unroll
     for (int a = 0; a < NBC; ++a)
@@ -1596,9 +1631,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         }
 #pragma unroll
         for (int q = 0; q < UQ3; ++q) {
-            const double y0 = un0[q] ? wu[q].x : 0.0, y1 = un1[q] ? (un0[q] ? wu[q].y : wu[q].x) : 0.0;
-            Us[buf][(2 * uk2) * LDU + uj3 + UJS3 * q] = y0;
-            Us[buf][(2 * uk2 + 1) * LDU + uj3 + UJS3 * q] = y1;
+            d2 y;
+            y.x = un0[q] ? wu[q].x : 0.0; y.y = un1[q] ? (un0[q] ? wu[q].y : wu[q].x) : 0.0;
+            *(d2 *) &Us[buf][uidx(2 * uk2, uj3 + UJS3 * q)] = y;
         }
     };
 
@@ -1622,20 +1657,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
             const int c = uj3 + UJS3 * q;
             const int ld = ldS[c], cp = cpS[c];
             if (c < nc && ld > kb) ok = 0;
-            uvoc[q] = (c < nc) ? (uint32_t) (cp - ld + kb + 2 * uk2) << 3 : (uint32_t) (2 * uk2) << 3;
+            // (the thread fetches the k pair uk2 ^ swizzle(c) and owns slot uk2 of column c in the stage: its 16 bytes sit at lane * 16 of the wave's 1 KiB)
+            uvoc[q] = (c < nc) ? (uint32_t) (cp - ld + kb + 2 * (uk2 ^ ((c >> 1) & 7))) << 3 : (uint32_t) (2 * uk2) << 3;
         }
         kbeg0 = kb;
         clean = __syncthreads_and(ok) != 0;
         // (32-bit offsets: a panel / a U row block is far below 4 GB -- 300^3: 9e4 rows x 256 columns x 8 bytes)
         if (clean) { rsL = buffer_rsrc(Lsrc); rsU = buffer_rsrc(Uvs); }
     };
-    auto fetch_clean = [&](int k0) {
+    constexpr bool DMA = F3 && TMv == 128 && NBUF == 2 && SLUAMD_SCHUR_DMA && SLUAMD_SCHUR_CLEAN;
+    static_assert(!DMA || (LRP == 64 && UJS3 * UQ3 == TNv), "LDS-DMA loader: one panel column / eight tile columns per wave and load");
+    auto fetch_clean = [&](int k0, int tb) {
 #ifdef SLUAMD_EXP_NOWAIT      // (instrumented build: the loads are issued, their data is never waited for at the stash -- it is "used" here, a whole chunk later; the stage gets constants)
 #pragma unroll
         for (int q = 0; q < LQ3; ++q) asm volatile("" :: "v"(wl[q]));
 #pragma unroll
         for (int q = 0; q < UQ3; ++q) asm volatile("" :: "v"(wu[q]));
 #endif
+        if (DMA) {
+            // the stage `tb` is free: every wave is past the MFMAs that read it (the barrier that closed the previous chunk / the previous source)
+#pragma unroll
+            for (int q = 0; q < LQ3; ++q)
+                lds_dma_16(rsL, __builtin_amdgcn_readfirstlane(lds_byte_addr(&Ls[tb][(wave + LKS3 * q) * LDL])), (int) lvo3, (int) ((uint32_t) (k0 + LKS3 * q) * (uint32_t) lda_s << 3));
+#pragma unroll
+            for (int q = 0; q < UQ3; ++q)
+                lds_dma_16(rsU, __builtin_amdgcn_readfirstlane(lds_byte_addr(&Us[tb][(8 * wave + UJS3 * q) * 16])), (int) uvoc[q], (int) ((uint32_t) (k0 - kbeg0) << 3));
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < LQ3; ++q)
             wl[q] = __builtin_bit_cast(d2, llvm_amdgcn_raw_buffer_load_i32x4(rsL, (int) lvo3, (int) ((uint32_t) (k0 + LKS3 * q) * (uint32_t) lda_s << 3), 0));
@@ -1643,14 +1691,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         for (int q = 0; q < UQ3; ++q) wu[q] = __builtin_bit_cast(d2, llvm_amdgcn_raw_buffer_load_i32x4(rsU, (int) uvoc[q], (int) ((uint32_t) (k0 - kbeg0) << 3), 0));
     };
     auto stash_clean = [&](int buf) {
+        if (DMA) { lds_dma_wait(); return; }          // (the loads wrote the stage themselves)
+#ifdef SLUAMD_EXP_NOSTASH     // (instrumented build, with SLUAMD_EXP_NOWAIT: no stores into the stage either -- what the five LDS writes per chunk cost)
+        return;
+#endif
 #ifdef SLUAMD_EXP_NOWAIT
         const d2 cst = {1.0 + 1e-9 * tid, 1.0 - 1e-9 * tid};
 #pragma unroll
         for (int q = 0; q < LQ3; ++q) *(d2 *) &Ls[buf][(lk3 + LKS3 * q) * LDL + 2 * li2] = cst;
 #pragma unroll
         for (int q = 0; q < UQ3; ++q) {
-            Us[buf][(2 * uk2) * LDU + uj3 + UJS3 * q] = cst.x;
-            Us[buf][(2 * uk2 + 1) * LDU + uj3 + UJS3 * q] = cst.y;
+            *(d2 *) &Us[buf][(uj3 + UJS3 * q) * 16 + 2 * uk2] = cst;
         }
         return;
 #endif
@@ -1658,8 +1709,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         for (int q = 0; q < LQ3; ++q) *(d2 *) &Ls[buf][(lk3 + LKS3 * q) * LDL + 2 * li2] = wl[q];
 #pragma unroll
         for (int q = 0; q < UQ3; ++q) {
-            Us[buf][(2 * uk2) * LDU + uj3 + UJS3 * q] = wu[q].x;
-            Us[buf][(2 * uk2 + 1) * LDU + uj3 + UJS3 * q] = wu[q].y;
+            *(d2 *) &Us[buf][(uj3 + UJS3 * q) * 16 + 2 * uk2] = wu[q];        // slot uk2 of its column = the k pair uk2 ^ swizzle it fetched
         }
     };
 
@@ -1728,19 +1778,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
 #pragma unroll
         for (int q = 0; q < LQ; ++q) Ls[buf][(lk + LKS * q) * LDL + li] = pl[q];
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) Us[buf][uk * LDU + uj + UJS * q] = pu[q];
+        for (int q = 0; q < UQ; ++q) Us[buf][uidx(uk, uj + UJS * q)] = pu[q];
     };
     int kend_cur = 0;                            // end of the current source's K range (this workgroup's share of it)
 #ifdef SLUAMD_EXP_COUNT
     int cnt_fast = 0, cnt_slow = 0;
 #endif
-    auto fetch = [&](int k0, bool restart = false) {
+    auto fetch = [&](int k0, int tb, bool restart = false) {       // tb: the stage this chunk goes to (the LDS-DMA loads write it at once, every other form at `stash`)
         if (F3 && !SLUAMD_EXP_NOLOAD) {
             cur_fast = SLUAMD_SCHUR_CLEAN && clean && k0 + KC <= kend_cur;       // workgroup-uniform
 #ifdef SLUAMD_EXP_COUNT
             if (cur_fast) ++cnt_fast; else ++cnt_slow;
 #endif
-            if (cur_fast) fetch_clean(k0); else fetch3(k0);
+            if (cur_fast) fetch_clean(k0, tb); else fetch3(k0);
         } else fetch_into(pl, pu, k0, restart);
     };
     auto stash = [&](int buf) {
@@ -1808,28 +1858,42 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         kend_cur = kend;
         const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((kend - 1 - kbeg) / KC - 1) * KC) : -1;
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
-        fetch(kbeg, true);
+        fetch(kbeg, buf, true);
         stash(buf);
         __syncthreads();
         for (int k0 = kbeg; k0 < kend; k0 += KC) {
             const bool more = k0 + KC < kend;
-            if (more) fetch(k0 + KC);
+            if (more) fetch(k0 + KC, NBUF == 2 ? buf ^ 1 : 0);
 #if SLUAMD_EXP_VALU
 #pragma unroll
             for (int e = 0; e < SLUAMD_EXP_VALU / 4; ++e)
                 asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, %2, %3\n\tv_add_u32 %3, %3, %0" : "+v"(dummy0), "+v"(dummy1), "+v"(dummy2), "+v"(dummy3));
 #endif
-            if (k0 == ktouch) {
+            if (SLUAMD_SCHUR_TOUCH && k0 == ktouch) {
                 // one chunk before the last: touch one element of every destination line (16 rows x 1 column of the tile) so
                 // that the fp64 atomics of the epilogue find their lines in L2 instead of each holding an L2 miss slot
                 constexpr int RG = TMv / 16;
                 const int id0 = tid, id1 = tid + NT;
                 const int c0 = id0 / RG, g0 = id0 % RG, c1 = id1 / RG, g1 = id1 % RG;
+#if SLUAMD_SCHUR_TOUCH == 2
+                if (DMA) {
+                    // the touch as two 4-byte loads per lane into a scratch kilobyte of LDS nobody reads: no destination registers (at the 128-VGPR cap the two
+                    // touched values were spilled, i.e. waited for at once), drained with the chunk's own loads / before the scatter
+                    const double *t0 = (id0 < TNv * RG && c0 < nc && g0 * 16 < nr) ? dst + s_colmap[c0] + s_rowmap[g0 * 16] : dst;
+                    const double *t1 = (id1 < TNv * RG && c1 < nc && g1 * 16 < nr) ? dst + s_colmap[c1] + s_rowmap[g1 * 16] : dst;
+                    const uint32_t sink = __builtin_amdgcn_readfirstlane(lds_byte_addr(&s_sink[wave * 64]));
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(t0), "v"(t1), "s"(sink) : "memory");
+                } else
+#endif
+                {
                 if (id0 < TNv * RG && c0 < nc && g0 * 16 < nr) touch0 = dst[s_colmap[c0] + s_rowmap[g0 * 16]];
                 if (id1 < TNv * RG && c1 < nc && g1 * 16 < nr) touch1 = dst[s_colmap[c1] + s_rowmap[g1 * 16]];
+                }
             }
             const double *Lb = Ls[buf], *Ub = Us[buf];
-            if (wave_on) schur_chunk<NBR, NBC, LDL, LDU>(Lb, Ub, rm0, cn0, lane, acc);
+            if (wave_on) schur_chunk<NBR, NBC, LDL, LDU, USW>(Lb, Ub, rm0, cn0, lane, acc, pa);
             if (NBUF == 2) { if (more) stash(buf ^ 1); buf ^= 1; }
             else if (more) { __syncthreads(); stash(0); }   // single stage: every wave is done reading before it is overwritten
             __syncthreads();
@@ -1837,6 +1901,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
     }
 
     // ---- scatter (epilogue) ----------------------------------------------------------------------
+    if (DMA && SLUAMD_SCHUR_TOUCH == 2) lds_dma_wait();
 #ifdef SLUAMD_EXP_COUNT
     if (tid == 0 && TMv == 128) { atomicAdd(&info[4], cnt_fast); atomicAdd(&info[5], cnt_slow); }
     if (tid == 0 && TMv == 64) { atomicAdd(&info[6], cnt_fast); atomicAdd(&info[7], cnt_slow); }
