@@ -1656,11 +1656,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         for (int q = 0; q < UQ3; ++q) {
             const int c = uj3 + UJS3 * q;
             const int ld = ldS[c], cp = cpS[c];
-            if (c < nc && ld > kb) ok = 0;
+            if (c < nc && (ld > kb || cp > 0x0F000000)) ok = 0;       // (32-bit byte offsets: value offsets inside the source's U row block below 2 GB)
             // (the thread fetches the k pair uk2 ^ swizzle(c) and owns slot uk2 of column c in the stage: its 16 bytes sit at lane * 16 of the wave's 1 KiB)
             uvoc[q] = (c < nc) ? (uint32_t) (cp - ld + kb + 2 * (uk2 ^ ((c >> 1) & 7))) << 3 : (uint32_t) (2 * uk2) << 3;
         }
         kbeg0 = kb;
+        if ((uint64_t) (uint32_t) ns_s * (uint64_t) (uint32_t) lda_s > 0x0F000000ull) ok = 0;     // ... and the source panel
         clean = __syncthreads_and(ok) != 0;
         // (32-bit offsets: a panel / a U row block is far below 4 GB -- 300^3: 9e4 rows x 256 columns x 8 bytes)
         if (clean) { rsL = buffer_rsrc(Lsrc); rsU = buffer_rsrc(Uvs); }
