@@ -1247,6 +1247,9 @@ __device__ __forceinline__ uint32_t lds_byte_addr(const void *p) { return (uint3
 #define SLUAMD_SCHUR_TOUCH 0      // 1: one chunk before the last, a tile touches its destination lines (rounds 2-5; at the 128-VGPR cap of the round-6 kernel the two touched
                                   // values are spilled, i.e. waited for at once: 265.6 ms); 2: the touch as loads into an LDS sink (262.2 ms); 0: none (259.6 ms, profiles/r06_ab_dma_loader.txt)
 #endif
+#ifndef SLUAMD_SCHUR_TIGHT
+#define SLUAMD_SCHUR_TIGHT 1      // the full chunks of a clean source of the LDS-DMA configurations run in a loop of their own (0: inside the general pipeline; same-box A/B)
+#endif
 #ifndef SLUAMD_SCHUR_DMA
 #define SLUAMD_SCHUR_DMA 1        // clean sources of the 128-row tile configurations load their chunks straight into the LDS stage; 0: through registers (same-box A/B)
 #endif
@@ -1858,6 +1861,31 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : (TMv == 128 ? 2 : (Z ? 6 : 
         // chunk at which the destination lines are touched: the one before the last chunk of the last source
         kend_cur = kend;
         const int ktouch = (src == nprev && has_dst) ? max(kbeg, kbeg + ((kend - 1 - kbeg) / KC - 1) * KC) : -1;
+#if SLUAMD_SCHUR_TIGHT
+        if (DMA && clean && !SLUAMD_EXP_NOLOAD && SLUAMD_SCHUR_TOUCH == 0) {
+            // the full chunks of a clean source in a loop of their own: four LDS-DMA loads, the MFMAs, one wait, one barrier -- none of the general loader's state
+            // (predicates, registers of the staged loads, which-path flags) is live or merged at its joins
+            const int nfull = (kend - kbeg) / KC;
+            if (nfull > 0) {
+                fetch_clean(kbeg, buf);
+                lds_dma_wait();
+                __syncthreads();
+                for (int c = 0; c < nfull; ++c) {
+                    const bool more = c + 1 < nfull;
+                    if (more) fetch_clean(kbeg + KC, buf ^ 1);
+                    if (wave_on) schur_chunk<NBR, NBC, LDL, LDU, USW>(Ls[buf], Us[buf], rm0, cn0, lane, acc, pa);
+                    if (more) lds_dma_wait();
+                    buf ^= 1;
+                    kbeg += KC;
+                    __syncthreads();
+                }
+#ifdef SLUAMD_EXP_COUNT
+                cnt_fast += nfull;
+#endif
+                if (kbeg >= kend) continue;
+            }
+        }
+#endif
         // (re)start of the software pipeline: every wave is past the last chunk's MFMAs (closing barrier of the loop)
         fetch(kbeg, buf, true);
         stash(buf);
