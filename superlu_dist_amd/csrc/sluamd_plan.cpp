@@ -692,6 +692,22 @@ static void report_balance(const Handle &H, const HostTables &t, const LevelSche
                 fprintf(stderr, "[balance] level %3d %s%s: %6d tiles, ideal %8.1f, busiest XCD %8.1f (%.3f), in-order makespan %8.1f (%.3f)\n", l, g ? "64" : "128", bal ? " balanced" : "", n, ideal,
                         mx_x, mx_x / ideal, mk, mk / ideal);
         }
+    {   // tiles and K chunks by the number of sources a tile runs (its own supernode + K-fused predecessors): every source restarts the tile's load pipeline
+        double nt[2][4] = {{0}}, nch[2][4] = {{0}};
+        auto chunks_of = [&](int s2) { const int nss = H.hs.xsup[s2 + 1] - H.hs.xsup[s2]; const int kb = (nss - t.sn_ldu[s2]) & ~3; return (nss - kb + KC - 1) / KC; };
+        for (int l = 0; l < S.nlevels; ++l)
+            for (int g = 0; g < 2; ++g)
+                for (int u = S.u_off[(2 * l + g) * 4]; u < S.u_off[(2 * l + g) * 4 + 4]; ++u) {
+                    const int k = S.ulist[u].x;
+                    int ns2 = 0, ch = chunks_of(k);
+                    if (!H.h_fuse_prev.empty())
+                        for (int j = 0; j < 3 && H.h_fuse_prev[3 * (size_t) k + j] >= 0; ++j) { ++ns2; ch += chunks_of(H.h_fuse_prev[3 * (size_t) k + j]); }
+                    nt[g][ns2] += 1; nch[g][ns2] += ch;
+                }
+        for (int g = 0; g < 2; ++g)
+            fprintf(stderr, "[balance] %s tiles by sources 1/2/3/4: %.0f %.0f %.0f %.0f; their K chunks: %.0f %.0f %.0f %.0f\n", g ? "64 x 64" : "128 x 128", nt[g][0], nt[g][1], nt[g][2], nt[g][3],
+                    nch[g][0], nch[g][1], nch[g][2], nch[g][3]);
+    }
     for (int g = 0; g < 2; ++g)
         if (nlaunch[g])
             fprintf(stderr, "[balance] %s x %s bulk launches: %d (%d balanced), sum of ideal spans %.0f chunk periods, busiest-XCD spans %.0f (%.3f x), in-order makespans %.0f (%.3f x)\n",

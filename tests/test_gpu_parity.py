@@ -51,6 +51,21 @@ def test_factor_matches_reference(golden, case):
     h.destroy()
 
 
+@pytest.mark.parametrize("case", ["poisson10_nd", "unsym300", "g20_1x1x1", "z_grid24_nd"])
+def test_balanced_xcd_ranges_on_every_bulk_launch(golden, case, monkeypatch):
+    """The bulk tile lists cut into eight XCD ranges of equal modelled cost (LevelSched::x_off, supernodes listed longest tiles first) are used from 1 024 tiles per
+    launch by default -- no fixture has that many.  SLUAMD_BALANCE_MIN_TILES=1: every bulk launch, including those of fewer than eight tiles (empty ranges): the
+    factors of the reference."""
+    monkeypatch.setenv("SLUAMD_BALANCE_MIN_TILES", "1")
+    g = golden(case)
+    st, h, info = _factor(g)
+    assert info == int(g["r0__info"][0])
+    scale = max(np.abs(g["r0__Lnzval_pre"]).max(), np.abs(g["r0__Unzval_pre"]).max())
+    assert np.abs(st.Lnzval - g["r0__Lnzval_post"]).max() <= 1e-12 * scale
+    assert np.abs(st.Unzval - g["r0__Unzval_post"]).max() <= 1e-12 * scale
+    h.destroy()
+
+
 @pytest.mark.parametrize("case", CASES_1RANK)
 def test_solve_matches_reference(golden, case):
     g = golden(case)
